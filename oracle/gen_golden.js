@@ -1,0 +1,57 @@
+'use strict';
+/*
+ * gen_golden.js -- TEST INFRASTRUCTURE ONLY.
+ * Generates tests/golden/*.json by running the unmodified reference
+ * (/root/reference, present only in the build container) under the seeded
+ * Philox stream.  Run:  node oracle/gen_golden.js [case-name ...]
+ * The fixtures are committed; this script is committed so they can be regenerated.
+ */
+const fs = require('fs');
+const path = require('path');
+const h = require('./ref_harness.js');
+const OUT = path.join(__dirname, '..', 'tests', 'golden');
+const SEED = 20260925, DSEED = 20260925;
+
+const CASES = [
+  // BASELINE.json configs[0]: README.md:20 data, burn 1000 + 5000 draws
+  { name: 'cfg1_heights', model: 'normal', data: { x: [183, 192, 182, 183, 177, 185, 188, 188, 182, 185] }, store_data: true,
+    seed: SEED, chains: [0, 1, 2, 3], schedule: [{ op: 'burn', n: 1000 }, { op: 'sample', n: 5000, keep: 200 }] },
+  { name: 'normal_n1000', model: 'normal', N: 1000, data_seed: DSEED, store_data: true,
+    seed: SEED, chains: [0, 1, 5, 77777], schedule: [{ op: 'burn', n: 300 }, { op: 'sample', n: 300, keep: 100 }] },
+  // configs[1] at full size, first and last chain id of the 65 536
+  { name: 'cfg2_full', model: 'normal', N: 10000, data_seed: DSEED,
+    seed: SEED, chains: [0, 65535], schedule: [{ op: 'burn', n: 500 }, { op: 'sample', n: 500, keep: 20 }] },
+  // option merging (mcmc.js:869-878), stop/start adaptation, thinning
+  { name: 'normal_opts', model: 'normal', N: 200, data_seed: DSEED + 1, store_data: true,
+    options: { batch_size: 10, target_accept_rate: 0.3, max_adaptation: 0.5, prop_log_scale: -1, params: { mu: { max_adaptation: 0.1 } } },
+    seed: SEED + 1, chains: [0, 9],
+    schedule: [{ op: 'burn', n: 105 }, { op: 'stop' }, { op: 'sample', n: 50 }, { op: 'start' }, { op: 'sample', n: 100, thin: 7 }] },
+  { name: 'beta_bern_n2000', model: 'beta_bern', N: 2000, data_seed: DSEED, store_data: true,
+    seed: SEED, chains: [0, 1, 2], schedule: [{ op: 'burn', n: 400 }, { op: 'sample', n: 400, keep: 100 }] },
+  { name: 'cfg3_full', model: 'beta_bern', N: 100000, data_seed: DSEED,
+    seed: SEED, chains: [0, 262143], schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 20 }] },
+  { name: 'hier_small', model: 'hier_normal', N: 640, G: 8, data_seed: DSEED, store_data: true,
+    seed: SEED, chains: [0, 1], schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 50 }] },
+  { name: 'cfg4_full', model: 'hier_normal', N: 10000, G: 32, data_seed: DSEED,
+    seed: SEED, chains: [0, 16383], schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 10 }] },
+  { name: 'glm_small', model: 'pois_glm', N: 500, data_seed: DSEED, store_data: true,
+    seed: SEED, chains: [0, 1], schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }] },
+  { name: 'cfg5_full', model: 'pois_glm', N: 50000, data_seed: DSEED,
+    seed: SEED, chains: [0], schedule: [{ op: 'burn', n: 30 }, { op: 'sample', n: 30, keep: 10 }] },
+];
+
+function checksum(data) { // order-sensitive sum so the Python twin of synth.js can be checked at full N
+  const out = {};
+  for (const k of Object.keys(data)) if (Array.isArray(data[k])) { let s = 0; for (let i = 0; i < data[k].length; i++) s += data[k][i] * (1 + (i % 7)); out[k] = s; }
+  return out;
+}
+
+const want = process.argv.slice(2);
+for (const c of CASES) {
+  if (want.length && want.indexOf(c.name) < 0) continue;
+  const t0 = Date.now();
+  const res = h.runCase(c);
+  res.data_checksum = checksum(h.makeData(c));
+  fs.writeFileSync(path.join(OUT, c.name + '.json'), h.stringify(res));
+  console.log(c.name, ((Date.now() - t0) / 1000).toFixed(1) + 's');
+}

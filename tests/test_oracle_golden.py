@@ -1,0 +1,85 @@
+"""Pins the CPU oracle (oracle/amwg_oracle.c) against the UNMODIFIED reference.
+
+tests/golden/*.json were produced by oracle/gen_golden.js: the reference sampler
+(mcmc.js + distributions.js) run under Node with Math.random replaced by the seeded
+Philox twin.  With lanes=1 (the reference's sequential summation order) the oracle must
+reproduce every recorded number bit for bit.  With lanes>1 (the HIP kernel's summation
+order) every accept decision must still be identical (north_star: "same seed => bit-identical
+integer accept counts") and draws agree to ~1e-12 relative.
+"""
+import numpy as np
+import pytest
+
+import golden_io
+import model_spec
+import oracle_lib
+
+CASES = ["cfg1_heights", "normal_n1000", "cfg2_full", "normal_opts", "beta_bern_n2000", "cfg3_full", "hier_small",
+         "cfg4_full", "glm_small", "cfg5_full"]
+
+
+def run_schedule(chain, schedule):
+    segs = []
+    thin = 1
+    for seg in schedule:
+        if seg["op"] == "burn":
+            chain.burn(seg["n"])
+        elif seg["op"] == "stop":
+            chain.set_adapting(False)
+        elif seg["op"] == "start":
+            chain.set_adapting(True)
+        elif seg["op"] == "sample":
+            thin = seg.get("thin", thin)
+            segs.append(chain.sample(seg["n"], thin))
+    return segs
+
+
+def check_chain(gold, rec, lanes):
+    spec = model_spec.spec_from_golden(gold, rec)
+    ch = oracle_lib.OracleChain(spec, gold["case"]["seed"], rec["chain"], lanes=lanes)
+    segs = run_schedule(ch, gold["case"]["schedule"])
+    info = ch.info()
+    exact = lanes == 1
+    # integer state: identical in every summation order
+    assert info["accepts"].tolist() == rec["accepts"]
+    assert info["inbounds"].tolist() == rec["inbounds"]
+    assert info["batch_count"].tolist() == rec["batch_count"]
+    assert info["acceptance_count"].tolist() == rec["acceptance_count"]
+    assert info["iterations_since_adaption"].tolist() == rec["iterations_since_adaption"]
+    assert ch.uniforms() == rec["uniforms"]
+    assert ch.named_order().tolist() == rec["named_order"]
+    # adaptation is driven by the integer counts only => exact in every order
+    assert info["prop_log_scale"].tolist() == rec["prop_log_scale"]
+    for got, want in zip(segs, rec["samples"]):
+        assert got.shape[0] == want["kept"]
+        w = np.array(want["draws"], dtype=np.float64).reshape(-1, got.shape[1])
+        g = got[: w.shape[0]]
+        if exact:
+            assert g.tobytes() == w.tobytes()
+            # running sum over ALL kept draws, same sequential order as the harness
+            s = np.zeros(got.shape[1])
+            for t in range(got.shape[0]):
+                s = s + got[t]
+            assert s.tolist() == want["sum"]
+        else:
+            np.testing.assert_allclose(g, w, rtol=1e-11, atol=0)
+    if exact:
+        assert ch.state().tolist() == rec["final_state"]
+        assert ch.log_post() == rec["log_post"]
+    else:
+        np.testing.assert_allclose(ch.state(), rec["final_state"], rtol=1e-11)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_bit_exact_vs_reference(name):
+    gold = golden_io.load(name)
+    for rec in gold["chains"]:
+        check_chain(gold, rec, lanes=1)
+
+
+@pytest.mark.parametrize("name", ["cfg1_heights", "normal_n1000", "normal_opts", "beta_bern_n2000", "hier_small", "glm_small"])
+@pytest.mark.parametrize("lanes", [4, 64])
+def test_oracle_kernel_order_same_decisions(name, lanes):
+    gold = golden_io.load(name)
+    for rec in gold["chains"][:2]:
+        check_chain(gold, rec, lanes=lanes)
