@@ -1,0 +1,219 @@
+"""ctypes binding of libamwg.so (include/amwg.h) for bench.py and the Python tests.
+
+The product's host language is JavaScript (bayes.js_amd/mcmc.js over the N-API shim); this
+binding exists because the driver's bench/test harness is Python.  It carries no logic
+beyond marshalling: every computation happens in the HIP library, and loading fails loudly
+if the library is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libamwg.so")
+MODEL_ID = {"normal": 1, "beta_bern": 2, "hier_normal": 3, "pois_glm": 4}
+
+
+class ParamDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("len", C.c_int32), ("top", C.c_int32), ("multidim", C.c_int32),
+                ("lower", C.c_double), ("upper", C.c_double)]
+
+
+class CompOpt(C.Structure):
+    _fields_ = [("prop_log_scale", C.c_double), ("max_adaptation", C.c_double), ("initial_adaptation", C.c_double),
+                ("target_accept_rate", C.c_double), ("batch_size", C.c_int32), ("is_adapting", C.c_int32)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("model", C.c_int32), ("n_obs", C.c_int32), ("x", C.POINTER(C.c_double)), ("y", C.POINTER(C.c_double)),
+                ("g", C.POINTER(C.c_int32)), ("G", C.c_int32), ("K", C.c_int32)]
+
+
+class Options(C.Structure):
+    _fields_ = [("chains", C.c_int64), ("seed", C.c_uint64), ("chain_offset", C.c_uint64), ("device", C.c_int32),
+                ("lanes_per_chain", C.c_int32), ("block_threads", C.c_int32), ("steps_per_launch", C.c_int32),
+                ("exact_division", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+EXPORTS = ["amwg_create", "amwg_burn", "amwg_sample", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
+           "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components",
+           "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp",
+           "amwg_log", "amwg_uniform", "amwg_device_eval"]
+
+_lib = None
+
+
+def lib():
+    """Loads libamwg.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libamwg.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+        pd, pi32, pi64, pu64 = C.POINTER(dbl), C.POINTER(i32), C.POINTER(i64), C.POINTER(u64)
+        L.amwg_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(ParamDesc), i32, pd, C.POINTER(CompOpt),
+                                  C.POINTER(Options), C.POINTER(vp)]
+        L.amwg_burn.argtypes = [vp, i64]
+        L.amwg_sample.argtypes = [vp, i64, i64, pd, C.c_size_t]
+        L.amwg_sample_device.argtypes = [vp, i64, i64, vp, C.c_size_t]
+        L.amwg_set_adapting.argtypes = [vp, i32]
+        L.amwg_get_state.argtypes = [vp, pd, C.c_size_t]
+        L.amwg_info.argtypes = [vp, pd, pi32, pi32, pi32, pi64, pi64]
+        L.amwg_chain_diag.argtypes = [vp, pu64, pd, pi32]
+        L.amwg_last_sample_moments.argtypes = [vp, pd, pd]
+        L.amwg_sync.argtypes = [vp]
+        L.amwg_num_components.argtypes = [vp]
+        L.amwg_num_chains.argtypes = [vp]
+        L.amwg_num_chains.restype = i64
+        L.amwg_launch_info.argtypes = [vp, pi32, pi32, pi32, pi32, pi32, pd]
+        L.amwg_destroy.argtypes = [vp]
+        L.amwg_last_error.restype = C.c_char_p
+        L.amwg_version.restype = C.c_char_p
+        L.amwg_exp.restype = dbl
+        L.amwg_exp.argtypes = [dbl]
+        L.amwg_log.restype = dbl
+        L.amwg_log.argtypes = [dbl]
+        L.amwg_uniform.restype = dbl
+        L.amwg_uniform.argtypes = [u64, u64, u64]
+        L.amwg_device_eval.argtypes = [i32, i32, i64, pd, pd, pd, pd]
+        _lib = L
+    return _lib
+
+
+class AmwgError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise AmwgError("amwg error %d: %s" % (rc, lib().amwg_last_error().decode()))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Sampler:
+    """Many-chain sampler handle.  `spec` = dict(model, n_obs, data{x[,y,g,G,K]}, params[], P, init[], comp_opts[])."""
+
+    def __init__(self, spec, chains, seed, chain_offset=0, device=0, lanes_per_chain=0, block_threads=0,
+                 steps_per_launch=0, exact_division=0):
+        L = lib()
+        d = spec["data"]
+        md = ModelDesc()
+        md.model = MODEL_ID[spec["model"]]
+        md.n_obs = spec["n_obs"]
+        keep = []
+        x = np.ascontiguousarray(d["x"], dtype=np.float64)
+        keep.append(x)
+        md.x = _dp(x)
+        if "y" in d:
+            y = np.ascontiguousarray(d["y"], dtype=np.float64)
+            keep.append(y)
+            md.y = _dp(y)
+        if "g" in d:
+            g = np.ascontiguousarray(d["g"], dtype=np.int32)
+            keep.append(g)
+            md.g = g.ctypes.data_as(C.POINTER(C.c_int32))
+        md.G = int(spec.get("G", 0))
+        md.K = int(spec.get("K", 0))
+        n = len(spec["params"])
+        pa = (ParamDesc * n)()
+        for i, p in enumerate(spec["params"]):
+            pa[i].type = 1 if p["type"] == "int" else 0
+            pa[i].len, pa[i].top, pa[i].multidim = p["len"], p["top"], p["multidim"]
+            pa[i].lower, pa[i].upper = p["lower"], p["upper"]
+        P = spec["P"]
+        oa = (CompOpt * P)()
+        for i, o in enumerate(spec["comp_opts"]):
+            oa[i].prop_log_scale = o["prop_log_scale"]
+            oa[i].max_adaptation = o["max_adaptation"]
+            oa[i].initial_adaptation = o["initial_adaptation"]
+            oa[i].target_accept_rate = o["target_accept_rate"]
+            oa[i].batch_size = int(o["batch_size"])
+            oa[i].is_adapting = int(bool(o["is_adapting"]))
+        init = np.ascontiguousarray(spec["init"], dtype=np.float64)
+        op = Options()
+        op.chains, op.seed, op.chain_offset, op.device = chains, seed, chain_offset, device
+        op.lanes_per_chain, op.block_threads, op.steps_per_launch = lanes_per_chain, block_threads, steps_per_launch
+        op.exact_division = exact_division
+        h = C.c_void_p()
+        _check(L.amwg_create(C.byref(md), pa, n, _dp(init), oa, C.byref(op), C.byref(h)))
+        self.h = h
+        self.P = P
+        self.C = chains
+        self.n_params = n
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().amwg_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def burn(self, n):
+        _check(lib().amwg_burn(self.h, n))
+
+    def sample(self, n, thin=1):
+        """-> array [kept][P][chains]"""
+        kept = -(-n // thin)
+        out = np.empty((kept, self.P, self.C), dtype=np.float64)
+        _check(lib().amwg_sample(self.h, n, thin, _dp(out), out.nbytes))
+        return out
+
+    def sample_device(self, n, thin, dev_ptr, nbytes):
+        _check(lib().amwg_sample_device(self.h, n, thin, C.c_void_p(dev_ptr), nbytes))
+
+    def sync(self):
+        _check(lib().amwg_sync(self.h))
+
+    def set_adapting(self, flag):
+        _check(lib().amwg_set_adapting(self.h, int(bool(flag))))
+
+    def state(self):
+        out = np.empty((self.P, self.C), dtype=np.float64)
+        _check(lib().amwg_get_state(self.h, _dp(out), out.nbytes))
+        return out
+
+    def info(self):
+        P, Cn = self.P, self.C
+        pls = np.empty((P, Cn))
+        ac, it, bc = (np.empty((P, Cn), dtype=np.int32) for _ in range(3))
+        acc, inb = (np.empty((P, Cn), dtype=np.int64) for _ in range(2))
+        i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+        _check(lib().amwg_info(self.h, _dp(pls), i32(ac), i32(it), i32(bc), i64(acc), i64(inb)))
+        return {"prop_log_scale": pls, "acceptance_count": ac, "iterations_since_adaption": it, "batch_count": bc,
+                "accepts": acc, "inbounds": inb}
+
+    def diag(self):
+        un = np.empty(self.C, dtype=np.uint64)
+        lp = np.empty(self.C)
+        order = np.empty((self.C, self.n_params), dtype=np.int32)
+        _check(lib().amwg_chain_diag(self.h, un.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(lp),
+                                     order.ctypes.data_as(C.POINTER(C.c_int32))))
+        return {"uniforms": un, "log_post": lp, "named_order": order}
+
+    def moments(self):
+        m, s = np.empty(self.P), np.empty(self.P)
+        _check(lib().amwg_last_sample_moments(self.h, _dp(m), _dp(s)))
+        return m, s
+
+    def launch_info(self):
+        v = [C.c_int32() for _ in range(5)]
+        ms = C.c_double()
+        _check(lib().amwg_launch_info(self.h, *[C.byref(x) for x in v], C.byref(ms)))
+        return {"lanes_per_chain": v[0].value, "block_threads": v[1].value, "grid_blocks": v[2].value,
+                "lds_bytes": v[3].value, "n_launches": v[4].value, "kernel_ms": ms.value}
+
+
+def device_eval(op, a, b=None, c=None, device=0):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.empty_like(a)
+    bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
+    cc = np.ascontiguousarray(c, dtype=np.float64) if c is not None else None
+    _check(lib().amwg_device_eval(device, op, a.size, _dp(a), _dp(bb) if bb is not None else None,
+                                  _dp(cc) if cc is not None else None, _dp(out)))
+    return out

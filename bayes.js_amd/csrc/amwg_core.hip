@@ -1,0 +1,597 @@
+// amwg_core.hip -- host side of libamwg.so: the C ABI of include/amwg.h over the fused
+// gfx950 step kernel (amwg_kernel.h).  No torch, no oracle, no CPU fallback: every entry
+// point that computes runs on the HIP device or fails with AMWG_EHIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/amwg.h"
+#include "amwg_kernel.h"
+
+using namespace amwg;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(AMWG_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+typedef void (*step_kernel_t)(const StepArgs);
+
+template <class Model>
+step_kernel_t kernel_for_lanes(int G) {
+  switch (G) {
+    case 1: return amwg_step_kernel<Model, 1>;
+    case 2: return amwg_step_kernel<Model, 2>;
+    case 4: return amwg_step_kernel<Model, 4>;
+    case 8: return amwg_step_kernel<Model, 8>;
+    case 16: return amwg_step_kernel<Model, 16>;
+    case 32: return amwg_step_kernel<Model, 32>;
+    case 64: return amwg_step_kernel<Model, 64>;
+  }
+  return nullptr;
+}
+
+step_kernel_t pick_kernel(int model, int G) {
+  switch (model) {
+    case AMWG_MODEL_NORMAL: return kernel_for_lanes<NormalModel>(G);
+    case AMWG_MODEL_BETA_BERN: return kernel_for_lanes<BetaBernModel>(G);
+    case AMWG_MODEL_HIER_NORMAL: return kernel_for_lanes<HierNormalModel>(G);
+    case AMWG_MODEL_POIS_GLM: return kernel_for_lanes<PoisGlmModel>(G);
+  }
+  return nullptr;
+}
+
+size_t model_lds_bytes(int model, int n_obs, int G) {
+  switch (model) {
+    case AMWG_MODEL_NORMAL: return NormalModel::lds_bytes(n_obs, G);
+    case AMWG_MODEL_BETA_BERN: return BetaBernModel::lds_bytes(n_obs, G);
+    case AMWG_MODEL_HIER_NORMAL: return HierNormalModel::lds_bytes(n_obs, G);
+    case AMWG_MODEL_POIS_GLM: return PoisGlmModel::lds_bytes(n_obs, G);
+  }
+  return 0;
+}
+
+bool value_mid_range(double v) { return v == 0.0 || mid_range(std::fabs(v)); }
+
+}  // namespace
+
+struct amwg_sampler {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int model = 0, P = 0, n_params = 0;
+  int64_t C = 0;
+  amwg_options opt{};
+  ParamLayout pl{};
+  ModelConsts mc{};
+  DataRef d{};
+  ChainArrays ch{};
+  std::vector<void *> dev_allocs;
+  CompConst *d_cc = nullptr;
+  uint8_t *d_adapt = nullptr;
+  std::vector<uint8_t> h_adapt;
+  // geometry
+  int lanes = 0, block = 0, grid = 0, lds = 0;
+  step_kernel_t kernel = nullptr;
+  bool lp_ready = false;
+  // last call
+  int n_launches = 0;
+  double kernel_ms = 0.0;
+  double *d_draws = nullptr;       // library-owned draw buffer of the last amwg_sample
+  size_t d_draws_cap = 0;
+  const double *last_draws = nullptr;  // device pointer (library- or caller-owned) of the last sample call
+  int64_t last_rows = 0;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(amwg_sampler *s, T **p, size_t n) {
+  void *q = nullptr;
+  HIP_TRY(hipMalloc(&q, n * sizeof(T) ? n * sizeof(T) : 1));
+  s->dev_allocs.push_back(q);
+  *p = static_cast<T *>(q);
+  return AMWG_OK;
+}
+
+// Geometry.  Preference order: (1) at least one workgroup per CU, using the LARGEST workgroup
+// (more waves share one LDS copy of the data and hide each other's latency) and, for that size,
+// the FEWEST lanes per chain (less replicated scalar work); (2) if even one wavefront per chain
+// cannot give every CU a workgroup, one wavefront per chain in single-wave workgroups.
+int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
+  const amwg_options &o = s->opt;
+  const size_t data_bytes = model_lds_bytes(s->model, s->d.n_obs, s->d.G);
+  auto fits = [&](int bt, int G) {
+    return bt % G == 0 && lds_layout(data_bytes, s->P, bt / G, s->pl.max_top).total <= max_lds;
+  };
+  const int bts[5] = {1024, 512, 256, 128, 64};
+  int bestG = 0, bestB = 0;
+  for (int bi = 0; bi < 5 && !bestG; ++bi) {
+    const int bt = bts[bi];
+    if (o.block_threads && bt != o.block_threads) continue;
+    for (int G = 1; G <= 64; G <<= 1) {
+      if (o.lanes_per_chain && G != o.lanes_per_chain) continue;
+      if (!fits(bt, G)) continue;
+      const int CPB = bt / G;
+      if ((s->C + CPB - 1) / CPB >= n_cus) { bestG = G; bestB = bt; break; }
+    }
+  }
+  if (!bestG) {  // too few chains to fill the chip: widest chain, smallest workgroup that fits
+    for (int bi = 4; bi >= 0 && !bestG; --bi) {
+      const int bt = bts[bi];
+      if (o.block_threads && bt != o.block_threads) continue;
+      for (int G = 64; G >= 1; G >>= 1) {
+        if (o.lanes_per_chain && G != o.lanes_per_chain) continue;
+        if (fits(bt, G)) { bestG = G; bestB = bt; break; }
+      }
+    }
+  }
+  if (!bestG) return fail(AMWG_EINVAL, "no launch geometry fits: the model needs more than %zu bytes of LDS", max_lds);
+  s->lanes = bestG;
+  s->block = bestB;
+  const int CPB = bestB / bestG;
+  s->grid = (int)((s->C + CPB - 1) / CPB);
+  s->lds = (int)lds_layout(data_bytes, s->P, CPB, s->pl.max_top).total;
+  s->kernel = pick_kernel(s->model, s->lanes);
+  if (!s->kernel) return fail(AMWG_EINVAL, "no kernel for model %d with %d lanes per chain", s->model, s->lanes);
+  return AMWG_OK;
+}
+
+int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
+  const int64_t chunk = s->opt.steps_per_launch > 0 ? s->opt.steps_per_launch : (1 << 20);
+  StepArgs a{};
+  a.C = s->C;
+  a.seed = s->opt.seed;
+  a.chain_offset = s->opt.chain_offset;
+  a.thin = (int32_t)thin;
+  a.draws = d_draws;
+  a.cc = s->d_cc;
+  a.is_adapting = s->d_adapt;
+  a.pl = s->pl;
+  a.mc = s->mc;
+  a.d = s->d;
+  a.ch = s->ch;
+  s->n_launches = 0;
+  HIP_TRY(hipEventRecord(s->ev0, s->stream));
+  int64_t done = 0, row = 0;
+  do {
+    const int64_t m = (n - done < chunk) ? n - done : chunk;
+    a.n_steps = (int32_t)m;
+    a.init_lp = s->lp_ready ? 0 : 1;
+    // steps until the first recorded step of this launch: smallest t >= 0 with (done + t) % thin == 0
+    a.step0 = (thin - (done % thin)) % thin;
+    a.row0 = row;
+    hipLaunchKernelGGL(s->kernel, dim3(s->grid), dim3(s->block), (size_t)s->lds, s->stream, a);
+    HIP_TRY(hipGetLastError());
+    s->lp_ready = true;
+    s->n_launches++;
+    if (d_draws) row += (m > a.step0) ? (m - a.step0 + thin - 1) / thin : 0;
+    done += m;
+  } while (done < n);
+  HIP_TRY(hipEventRecord(s->ev1, s->stream));
+  return AMWG_OK;
+}
+
+int finish_timing(amwg_sampler *s) {
+  HIP_TRY(hipEventSynchronize(s->ev1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+  s->kernel_ms = ms;
+  return AMWG_OK;
+}
+
+__global__ void moments_kernel(const double *draws, int64_t rows, int P, int64_t C, double *mean, double *sd) {
+  __shared__ double red[1024];
+  const int p = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int64_t n = rows * C;
+  double sum = 0;
+  for (int64_t i = tid; i < n; i += nt) sum += draws[((i / C) * P + p) * C + (i % C)];
+  red[tid] = sum;
+  __syncthreads();
+  for (int o = nt / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  const double m = red[0] / (double)n;
+  __syncthreads();
+  double ss = 0;
+  for (int64_t i = tid; i < n; i += nt) { const double dlt = draws[((i / C) * P + p) * C + (i % C)] - m; ss += dlt * dlt; }
+  red[tid] = ss;
+  __syncthreads();
+  for (int o = nt / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  if (tid == 0) { mean[p] = m; sd[p] = n > 1 ? sqrt(red[0] / (double)(n - 1)) : 0.0; }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *amwg_last_error(void) { return g_err.c_str(); }
+const char *amwg_version(void) { return "amwg-mi355x 0.1 (gfx950)"; }
+
+double amwg_exp(double x) { return exp_v8(x); }
+double amwg_log(double x) { return log_v8(x); }
+double amwg_uniform(uint64_t seed, uint64_t chain, uint64_t index) {
+  ChainStream s;
+  s.init(seed, chain, index);
+  return s.next();
+}
+
+int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t n_params, const double *init,
+                const amwg_comp_opt *comp_opts, const amwg_options *options, amwg_sampler **out) {
+  if (!m || !params || !init || !comp_opts || !options || !out) return fail(AMWG_EINVAL, "amwg_create: null argument");
+  if (n_params < 1 || n_params > kMaxNamed) return fail(AMWG_EINVAL, "amwg_create: %d named parameters (supported: 1..%d)", n_params, kMaxNamed);
+  if (options->chains < 1) return fail(AMWG_EINVAL, "amwg_create: chains must be >= 1");
+  if (m->n_obs < 0) return fail(AMWG_EINVAL, "amwg_create: n_obs < 0");
+  const int G_opt = options->lanes_per_chain;
+  if (G_opt && (G_opt < 1 || G_opt > 64 || (G_opt & (G_opt - 1)))) return fail(AMWG_EINVAL, "lanes_per_chain must be a power of two in 1..64");
+  if (options->block_threads && (options->block_threads % 64 || options->block_threads > 1024 || options->block_threads < 64))
+    return fail(AMWG_EINVAL, "block_threads must be a multiple of 64 in 64..1024");
+
+  amwg_sampler *s = new amwg_sampler();
+  s->opt = *options;
+  s->model = m->model;
+  s->C = options->chains;
+  s->n_params = n_params;
+  s->device = options->device;
+  auto bail = [&](int rc) { amwg_destroy(s); return rc; };
+
+  // ---- parameter layout (completed params, mcmc.js:357-403)
+  ParamLayout &pl = s->pl;
+  pl.n_params = n_params;
+  pl.max_top = 1;
+  int P = 0;
+  for (int p = 0; p < n_params; ++p) {
+    const amwg_param_desc &q = params[p];
+    if (q.type != AMWG_REAL && q.type != AMWG_INT) return bail(fail(AMWG_EINVAL, "AmwgStepper can't handle parameter %d with type %d", p, q.type));
+    if (q.len < 1 || q.top < 1 || q.len % q.top) return bail(fail(AMWG_EINVAL, "parameter %d: bad dim (len %d, top %d)", p, q.len, q.top));
+    if (q.top > kMaxTop) return bail(fail(AMWG_EINVAL, "parameter %d: leading dimension %d > %d", p, q.top, kMaxTop));
+    if (!q.multidim && q.len != 1) return bail(fail(AMWG_EINVAL, "parameter %d: dim [1] but len %d", p, q.len));
+    pl.base[p] = P; pl.len[p] = q.len; pl.top[p] = q.top; pl.multidim[p] = q.multidim ? 1 : 0;
+    if (q.multidim && q.top > pl.max_top) pl.max_top = q.top;
+    P += q.len;
+  }
+  pl.P = P;
+  s->P = P;
+
+  // ---- model / data checks
+  const int N = m->n_obs;
+  switch (m->model) {
+    case AMWG_MODEL_NORMAL:
+      if (P != 2 || n_params != 2) return bail(fail(AMWG_EINVAL, "normal model expects params {mu, sigma}"));
+      if (!m->x && N) return bail(fail(AMWG_EINVAL, "normal model: x is null"));
+      break;
+    case AMWG_MODEL_BETA_BERN:
+      if (P != 1) return bail(fail(AMWG_EINVAL, "beta_bern model expects params {theta}"));
+      if (!m->x && N) return bail(fail(AMWG_EINVAL, "beta_bern model: x is null"));
+      break;
+    case AMWG_MODEL_HIER_NORMAL:
+      if (n_params != 3 || m->G < 1 || m->G > 256 || params[0].len != m->G || P != m->G + 2)
+        return bail(fail(AMWG_EINVAL, "hier_normal model expects params {theta[G], mu, sigma}, 1 <= G <= 256"));
+      if ((!m->x || !m->g) && N) return bail(fail(AMWG_EINVAL, "hier_normal model: y or g is null"));
+      break;
+    case AMWG_MODEL_POIS_GLM:
+      if (n_params != 2 || params[0].len != 8 || P != 9 || m->K != 7)
+        return bail(fail(AMWG_EINVAL, "pois_glm model expects params {beta[8], cp} and K = 7"));
+      if ((!m->x || !m->y) && N) return bail(fail(AMWG_EINVAL, "pois_glm model: X or y is null"));
+      break;
+    default: return bail(fail(AMWG_EINVAL, "unknown model id %d", m->model));
+  }
+
+  // ---- device
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1) return bail(fail(AMWG_EHIP, "no HIP device available (%s)", hipGetErrorString(e)));
+  if (s->device < 0 || s->device >= ndev) return bail(fail(AMWG_EINVAL, "device %d out of range (%d visible)", s->device, ndev));
+#define TRYB(x) do { int rc_ = (x); if (rc_ != AMWG_OK) return bail(rc_); } while (0)
+#define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(AMWG_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
+  HIPB(hipSetDevice(s->device));
+  hipDeviceProp_t prop;
+  HIPB(hipGetDeviceProperties(&prop, s->device));
+  HIPB(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIPB(hipEventCreate(&s->ev0));
+  HIPB(hipEventCreate(&s->ev1));
+
+  // ---- model constants, with the kernel's own log (same roundings as the reference expression trees)
+  ModelConsts &mc = s->mc;
+  mc.neg_half_log_2pi = -0.5 * log_v8(2 * kPi);
+  mc.c_sd100 = mc.neg_half_log_2pi - log_v8(100.0);
+  mc.c_sd10 = mc.neg_half_log_2pi - log_v8(10.0);
+  mc.lunif_0_100 = log_v8(1 / (100.0 - 0.0));
+  mc.cp_upper = (double)(N - 1);
+  mc.lunif_cp = log_v8(1 / (mc.cp_upper - 0.0));
+  mc.lbeta_2_2 = lbeta_js(2, 2);
+  mc.exact_division = options->exact_division ? 1 : 0;
+
+  // ---- data upload
+  DataRef &d = s->d;
+  d.n_obs = N; d.G = m->G; d.K = m->K;
+  bool mid = true;
+  if (m->model == AMWG_MODEL_NORMAL || m->model == AMWG_MODEL_HIER_NORMAL) {
+    for (int i = 0; i < N; ++i) mid = mid && value_mid_range(m->x[i]);
+    double *dx = nullptr;
+    TRYB(dev_alloc(s, &dx, (size_t)N));
+    if (N) HIPB(hipMemcpy(dx, m->x, (size_t)N * 8, hipMemcpyHostToDevice));
+    d.x = dx;
+    if (m->model == AMWG_MODEL_HIER_NORMAL) {
+      std::vector<uint8_t> gb((size_t)N);
+      for (int i = 0; i < N; ++i) {
+        if (m->g[i] < 0 || m->g[i] >= m->G) return bail(fail(AMWG_EINVAL, "hier_normal: g[%d] = %d outside 0..%d", i, m->g[i], m->G - 1));
+        gb[i] = (uint8_t)m->g[i];
+      }
+      uint8_t *dg = nullptr;
+      TRYB(dev_alloc(s, &dg, (size_t)N));
+      if (N) HIPB(hipMemcpy(dg, gb.data(), (size_t)N, hipMemcpyHostToDevice));
+      d.xb = dg;
+    }
+  } else if (m->model == AMWG_MODEL_BETA_BERN) {
+    std::vector<uint8_t> xb((size_t)N);
+    for (int i = 0; i < N; ++i) xb[i] = m->x[i] == 0 ? 0 : (m->x[i] == 1 ? 1 : 2);
+    uint8_t *dxb = nullptr;
+    TRYB(dev_alloc(s, &dxb, (size_t)N));
+    if (N) HIPB(hipMemcpy(dxb, xb.data(), (size_t)N, hipMemcpyHostToDevice));
+    d.xb = dxb;
+  } else {  // POIS_GLM
+    std::vector<double> lf((size_t)N);
+    for (int i = 0; i < N; ++i) lf[i] = m->y[i] < 0 ? (double)INFINITY : lfactorial_js(m->y[i]);
+    double *dX = nullptr, *dy = nullptr, *dlf = nullptr;
+    TRYB(dev_alloc(s, &dX, (size_t)N * 7));
+    TRYB(dev_alloc(s, &dy, (size_t)N));
+    TRYB(dev_alloc(s, &dlf, (size_t)N));
+    if (N) {
+      HIPB(hipMemcpy(dX, m->x, (size_t)N * 7 * 8, hipMemcpyHostToDevice));
+      HIPB(hipMemcpy(dy, m->y, (size_t)N * 8, hipMemcpyHostToDevice));
+      HIPB(hipMemcpy(dlf, lf.data(), (size_t)N * 8, hipMemcpyHostToDevice));
+    }
+    d.x = dX; d.y = dy; d.lfact = dlf;
+  }
+  mc.data_mid_range = mid ? 1 : 0;
+
+  // ---- per-component constants and per-chain state
+  std::vector<CompConst> hcc((size_t)P);
+  s->h_adapt.resize((size_t)P);
+  for (int p = 0, ci = 0; p < n_params; ++p)
+    for (int e2 = 0; e2 < params[p].len; ++e2, ++ci) {
+      const amwg_comp_opt &o = comp_opts[ci];
+      if (o.batch_size < 1) return bail(fail(AMWG_EINVAL, "component %d: batch_size %d < 1", ci, o.batch_size));
+      hcc[ci] = CompConst{params[p].lower, params[p].upper, o.max_adaptation, o.initial_adaptation, o.target_accept_rate,
+                          o.batch_size, params[p].type};
+      s->h_adapt[ci] = o.is_adapting ? 1 : 0;
+    }
+  TRYB(dev_alloc(s, &s->d_cc, (size_t)P));
+  HIPB(hipMemcpy(s->d_cc, hcc.data(), (size_t)P * sizeof(CompConst), hipMemcpyHostToDevice));
+  TRYB(dev_alloc(s, &s->d_adapt, (size_t)P));
+  HIPB(hipMemcpy(s->d_adapt, s->h_adapt.data(), (size_t)P, hipMemcpyHostToDevice));
+
+  const size_t PC = (size_t)P * (size_t)s->C, C = (size_t)s->C;
+  ChainArrays &ch = s->ch;
+  TRYB(dev_alloc(s, &ch.state, PC));
+  TRYB(dev_alloc(s, &ch.prop_log_scale, PC));
+  TRYB(dev_alloc(s, &ch.acceptance_count, PC));
+  TRYB(dev_alloc(s, &ch.iterations_since_adaption, PC));
+  TRYB(dev_alloc(s, &ch.batch_count, PC));
+  TRYB(dev_alloc(s, &ch.accepts, PC));
+  TRYB(dev_alloc(s, &ch.inbounds, PC));
+  TRYB(dev_alloc(s, &ch.perm, C));
+  TRYB(dev_alloc(s, &ch.rng_n, C));
+  TRYB(dev_alloc(s, &ch.lp_curr, C));
+  {
+    std::vector<double> tmp(PC);
+    for (int p = 0; p < P; ++p) for (size_t c = 0; c < C; ++c) tmp[(size_t)p * C + c] = init[p];
+    HIPB(hipMemcpy(ch.state, tmp.data(), PC * 8, hipMemcpyHostToDevice));
+    for (int p = 0; p < P; ++p) for (size_t c = 0; c < C; ++c) tmp[(size_t)p * C + c] = comp_opts[p].prop_log_scale;
+    HIPB(hipMemcpy(ch.prop_log_scale, tmp.data(), PC * 8, hipMemcpyHostToDevice));
+    uint32_t ident = 0;
+    for (int i = 0; i < kMaxNamed; ++i) ident |= (uint32_t)i << (4 * i);
+    std::vector<uint32_t> pv(C, ident);
+    HIPB(hipMemcpy(ch.perm, pv.data(), C * 4, hipMemcpyHostToDevice));
+  }
+  HIPB(hipMemset(ch.acceptance_count, 0, PC * 4));
+  HIPB(hipMemset(ch.iterations_since_adaption, 0, PC * 4));
+  HIPB(hipMemset(ch.batch_count, 0, PC * 4));
+  HIPB(hipMemset(ch.accepts, 0, PC * 4));
+  HIPB(hipMemset(ch.inbounds, 0, PC * 4));
+  HIPB(hipMemset(ch.rng_n, 0, C * 8));
+  HIPB(hipMemset(ch.lp_curr, 0, C * 8));
+
+  // ---- geometry + the constructor's warm-up log_post (mcmc.js:961-963) as a 0-step launch
+  const size_t max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
+  TRYB(choose_geometry(s, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, max_lds));
+  HIPB(hipFuncSetAttribute(reinterpret_cast<const void *>(s->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds));
+  TRYB(launch_steps(s, 0, 1, nullptr));
+  HIPB(hipStreamSynchronize(s->stream));
+  *out = s;
+  return AMWG_OK;
+#undef TRYB
+#undef HIPB
+}
+
+int amwg_destroy(amwg_sampler *s) {
+  if (!s) return AMWG_OK;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (void *p : s->dev_allocs) (void)hipFree(p);
+  if (s->d_draws) (void)hipFree(s->d_draws);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+  return AMWG_OK;
+}
+
+int amwg_burn(amwg_sampler *s, int64_t n) {
+  if (!s || n < 0) return fail(AMWG_EINVAL, "amwg_burn: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  int rc = launch_steps(s, n, 1, nullptr);
+  if (rc != AMWG_OK) return rc;
+  return finish_timing(s);
+}
+
+int amwg_sample_device(amwg_sampler *s, int64_t n, int64_t thin, double *out_dev, size_t out_bytes) {
+  if (!s || n < 0 || thin < 1 || (!out_dev && n > 0)) return fail(AMWG_EINVAL, "amwg_sample_device: bad argument");
+  const int64_t rows = (n + thin - 1) / thin;
+  const size_t need = (size_t)rows * (size_t)s->P * (size_t)s->C * 8;
+  if (out_bytes < need) return fail(AMWG_ESIZE, "amwg_sample: output needs %zu bytes, got %zu", need, out_bytes);
+  HIP_TRY(hipSetDevice(s->device));
+  int rc = launch_steps(s, n, thin, out_dev);
+  if (rc != AMWG_OK) return rc;
+  s->last_draws = out_dev;
+  s->last_rows = rows;
+  return AMWG_OK;
+}
+
+int amwg_sample(amwg_sampler *s, int64_t n, int64_t thin, double *out, size_t out_bytes) {
+  if (!s || n < 0 || thin < 1 || (!out && n > 0)) return fail(AMWG_EINVAL, "amwg_sample: bad argument");
+  const int64_t rows = (n + thin - 1) / thin;
+  const size_t need = (size_t)rows * (size_t)s->P * (size_t)s->C * 8;
+  if (out_bytes < need) return fail(AMWG_ESIZE, "amwg_sample: output needs %zu bytes, got %zu", need, out_bytes);
+  HIP_TRY(hipSetDevice(s->device));
+  if (need > s->d_draws_cap) {
+    if (s->d_draws) { (void)hipFree(s->d_draws); s->d_draws = nullptr; s->d_draws_cap = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_draws), need ? need : 8));
+    s->d_draws_cap = need;
+  }
+  int rc = amwg_sample_device(s, n, thin, s->d_draws, need);
+  if (rc != AMWG_OK) return rc;
+  rc = finish_timing(s);
+  if (rc != AMWG_OK) return rc;
+  if (need) HIP_TRY(hipMemcpyAsync(out, s->d_draws, need, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return AMWG_OK;
+}
+
+int amwg_sync(amwg_sampler *s) {
+  if (!s) return fail(AMWG_EINVAL, "amwg_sync: null sampler");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return finish_timing(s);
+}
+
+int amwg_set_adapting(amwg_sampler *s, int32_t flag) {
+  if (!s) return fail(AMWG_EINVAL, "amwg_set_adapting: null sampler");
+  HIP_TRY(hipSetDevice(s->device));
+  for (auto &b : s->h_adapt) b = flag ? 1 : 0;
+  HIP_TRY(hipMemcpyAsync(s->d_adapt, s->h_adapt.data(), s->h_adapt.size(), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return AMWG_OK;
+}
+
+int amwg_get_state(amwg_sampler *s, double *out, size_t out_bytes) {
+  if (!s || !out) return fail(AMWG_EINVAL, "amwg_get_state: null argument");
+  const size_t need = (size_t)s->P * (size_t)s->C * 8;
+  if (out_bytes < need) return fail(AMWG_ESIZE, "amwg_get_state: output needs %zu bytes, got %zu", need, out_bytes);
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(out, s->ch.state, need, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return AMWG_OK;
+}
+
+int amwg_info(amwg_sampler *s, double *pls, int32_t *ac, int32_t *it, int32_t *bc, int64_t *acc, int64_t *inb) {
+  if (!s) return fail(AMWG_EINVAL, "amwg_info: null sampler");
+  const size_t PC = (size_t)s->P * (size_t)s->C;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (pls) HIP_TRY(hipMemcpy(pls, s->ch.prop_log_scale, PC * 8, hipMemcpyDeviceToHost));
+  if (ac) HIP_TRY(hipMemcpy(ac, s->ch.acceptance_count, PC * 4, hipMemcpyDeviceToHost));
+  if (it) HIP_TRY(hipMemcpy(it, s->ch.iterations_since_adaption, PC * 4, hipMemcpyDeviceToHost));
+  if (bc) HIP_TRY(hipMemcpy(bc, s->ch.batch_count, PC * 4, hipMemcpyDeviceToHost));
+  std::vector<int32_t> tmp;
+  if (acc) {
+    tmp.resize(PC);
+    HIP_TRY(hipMemcpy(tmp.data(), s->ch.accepts, PC * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < PC; ++i) acc[i] = tmp[i];
+  }
+  if (inb) {
+    tmp.resize(PC);
+    HIP_TRY(hipMemcpy(tmp.data(), s->ch.inbounds, PC * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < PC; ++i) inb[i] = tmp[i];
+  }
+  return AMWG_OK;
+}
+
+int amwg_chain_diag(amwg_sampler *s, uint64_t *uniforms, double *log_post_out, int32_t *named_order) {
+  if (!s) return fail(AMWG_EINVAL, "amwg_chain_diag: null sampler");
+  const size_t C = (size_t)s->C;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (uniforms) HIP_TRY(hipMemcpy(uniforms, s->ch.rng_n, C * 8, hipMemcpyDeviceToHost));
+  if (log_post_out) HIP_TRY(hipMemcpy(log_post_out, s->ch.lp_curr, C * 8, hipMemcpyDeviceToHost));
+  if (named_order) {
+    std::vector<uint32_t> pv(C);
+    HIP_TRY(hipMemcpy(pv.data(), s->ch.perm, C * 4, hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < C; ++c)
+      for (int k = 0; k < s->n_params; ++k) named_order[c * s->n_params + k] = (int32_t)((pv[c] >> (4 * k)) & 0xF);
+  }
+  return AMWG_OK;
+}
+
+int amwg_last_sample_moments(amwg_sampler *s, double *mean, double *sd) {
+  if (!s || !mean || !sd) return fail(AMWG_EINVAL, "amwg_last_sample_moments: null argument");
+  if (!s->last_draws || s->last_rows < 1) return fail(AMWG_EINVAL, "amwg_last_sample_moments: no sample() call yet");
+  HIP_TRY(hipSetDevice(s->device));
+  double *dm = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dm), (size_t)s->P * 16));
+  hipLaunchKernelGGL(moments_kernel, dim3(s->P), dim3(1024), 0, s->stream, s->last_draws, s->last_rows, s->P, s->C, dm, dm + s->P);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(mean, dm, (size_t)s->P * 8, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(sd, dm + s->P, (size_t)s->P * 8, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  (void)hipFree(dm);
+  if (e != hipSuccess) return fail(AMWG_EHIP, "moments kernel failed: %s", hipGetErrorString(e));
+  return AMWG_OK;
+}
+
+int amwg_num_components(const amwg_sampler *s) { return s ? s->P : 0; }
+int64_t amwg_num_chains(const amwg_sampler *s) { return s ? s->C : 0; }
+
+int amwg_launch_info(const amwg_sampler *s, int32_t *lanes, int32_t *block, int32_t *grid, int32_t *lds, int32_t *n_launches, double *kernel_ms) {
+  if (!s) return fail(AMWG_EINVAL, "amwg_launch_info: null sampler");
+  if (lanes) *lanes = s->lanes;
+  if (block) *block = s->block;
+  if (grid) *grid = s->grid;
+  if (lds) *lds = s->lds;
+  if (n_launches) *n_launches = s->n_launches;
+  if (kernel_ms) *kernel_ms = s->kernel_ms;
+  return AMWG_OK;
+}
+
+int amwg_device_eval(int32_t device, int32_t op, int64_t n, const double *a, const double *b, const double *c, double *out) {
+  if (!a || !out || n < 0) return fail(AMWG_EINVAL, "amwg_device_eval: bad argument");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1) return fail(AMWG_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
+  HIP_TRY(hipSetDevice(device));
+  double *da = nullptr, *db = nullptr, *dc = nullptr, *dout = nullptr;
+  const size_t bytes = (size_t)n * 8;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&da), bytes ? bytes : 8));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dout), bytes ? bytes : 8));
+  HIP_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+  if (b) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&db), bytes ? bytes : 8)); HIP_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice)); }
+  if (c) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dc), bytes ? bytes : 8)); HIP_TRY(hipMemcpy(dc, c, bytes, hipMemcpyHostToDevice)); }
+  if (n) hipLaunchKernelGGL(amwg_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, n, da, db, dc, dout);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+  (void)hipFree(da); (void)hipFree(dout);
+  if (db) (void)hipFree(db);
+  if (dc) (void)hipFree(dc);
+  return AMWG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,262 @@
+// amwg_kernel.h -- the fused many-chain AMWG step kernel for gfx950.
+//
+// One launch advances every chain by n_steps Sampler.step()s (mcmc.js:985-997).  Fused per
+// chain: the persistent shuffle of the named sub-steppers (mcmc.js:886-892), the per-step
+// shuffle of a multidimensional parameter's components (mcmc.js:685-688, 244-263), and for
+// every scalar component the whole OnedimMetropolisStepper.step (mcmc.js:517-553): Philox ->
+// rnorm proposal (mcmc.js:43-54, 577-579, 596-598) -> bounds -> log_post of the proposal (the
+// user's closure + ld.*) -> exp(delta) > u -> Roberts-Rosenthal batch adaptation of the
+// log proposal SD, plus the optional draw write-back of Sampler.sample (mcmc.js:1020-1027).
+//
+// Mapping (CDNA4, wave64): a chain is owned by G consecutive lanes of one wavefront,
+// G in {1,2,4,...,64}.  All G lanes run the chain's scalar logic redundantly (same stream,
+// same decisions -- no broadcast needed); the observation loop of log_post is split G ways
+// (lane j takes observations j, j+G, ...) and the G partial sums are combined with an xor
+// butterfly (offsets 1,2,4,..).  G = 64 is "one wavefront per chain"; G = 1 is "one lane
+// per chain", whose summation order is exactly the reference's sequential `lp += term`.
+// The host picks G so the launch fills the 1024 SIMDs of the chip (amwg_core.hip).
+//
+// The chain-shared data vector is staged ONCE per launch into LDS with coalesced loads
+// (80 KB at cfg2 -- one workgroup of up to 16 waves per CU shares it) and is then read
+// conflict-free: the G lanes of a chain read G consecutive elements, the 64/G chains of a
+// wave read the same addresses (LDS broadcast).  Per-chain scalar state lives in LDS
+// ([component][chain-in-block]) because the component a lane updates is data dependent.
+// Data too large for LDS (cfg5's 3.6 MB design matrix) is read through L2/MALL.
+//
+// Reference work avoided without changing any result: the reference evaluates log_post
+// twice per update (mcmc.js:524-526); the current state's value is cached per chain, which
+// is exact because log_post is a pure function of the state.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "amwg_models.h"
+#include "amwg_philox.h"
+#include "amwg_types.h"
+
+namespace amwg {
+
+struct LdsLayout {
+  uint32_t data, state, cc, adapt, pl, idx, total;
+};
+__host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CPB, int max_top) {
+  LdsLayout L;
+  uint32_t o = 0;
+  L.data = o;  o += (uint32_t)((data_bytes + 15) & ~(size_t)15);
+  L.state = o; o += (uint32_t)P * CPB * 8;
+  L.cc = o;    o += (uint32_t)P * sizeof(CompConst);
+  L.adapt = o; o += ((uint32_t)P + 7) & ~7u;
+  L.pl = o;    o += (uint32_t)((sizeof(ParamLayout) + 7) & ~(size_t)7);
+  L.idx = o;   o += (max_top > 1) ? (((uint32_t)max_top * CPB + 15) & ~15u) : 0;
+  L.total = (o + 15) & ~15u;
+  return L;
+}
+
+template <class Model, bool FAST, int G>
+__device__ __forceinline__ double pass_over_data(const typename Model::Pass &ps, int n_obs, int sub, double acc) {
+  constexpr int U = 8;
+  const int n_full = n_obs / G, rem = n_obs % G;
+  int k = 0;
+  for (; k + U <= n_full; k += U) {
+    double t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) t[u] = Model::template term<FAST>(ps, (k + u) * G + sub);
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += t[u];
+  }
+  for (; k < n_full; ++k) acc += Model::template term<FAST>(ps, k * G + sub);
+  if (sub < rem) acc += Model::template term<FAST>(ps, n_full * G + sub);
+  return acc;
+}
+
+template <class T> struct has_fast { static constexpr bool value = false; };
+template <> struct has_fast<NormalModel> { static constexpr bool value = true; };
+template <> struct has_fast<HierNormalModel> { static constexpr bool value = true; };
+
+// log_post(state) in the documented order: lane 0 of the chain starts from the prior sum
+// (accumulated sequentially as the closure does), every lane adds its observations in
+// increasing index order, then the xor butterfly.  For G = 1 this is the reference's order.
+template <class Model, int G>
+__device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a, const unsigned char *smem, int sub) {
+  const typename Model::Pass ps = Model::begin(S, a.mc, a.d, smem);
+  const double prior = Model::prior(S, a.mc, a.d);
+  double acc = (sub == 0) ? prior : 0.0;
+  if constexpr (has_fast<Model>::value) {
+    if (ps.fast) acc = pass_over_data<Model, true, G>(ps, a.d.n_obs, sub, acc);
+    else acc = pass_over_data<Model, false, G>(ps, a.d.n_obs, sub, acc);
+  } else {
+    acc = pass_over_data<Model, false, G>(ps, a.d.n_obs, sub, acc);
+  }
+#pragma unroll
+  for (int off = 1; off < G; off <<= 1) acc = acc + __shfl_xor(acc, off, 64);
+  return acc;
+}
+
+__device__ __forceinline__ double rnorm_js(ChainStream &rng, double mean, double sd) {  // mcmc.js:43-54
+  double u, v, q;
+  do {
+    u = rng.next();
+    v = 1.7156 * (rng.next() - 0.5);
+    const double x = u - 0.449871;
+    const double y = __builtin_fabs(v) + 0.386595;
+    q = x * x + y * (0.19600 * y - 0.25472 * x);
+  } while (q > 0.27597 && (q > 0.27846 || v * v > -4 * log_v8(u) * u * u));
+  return (v / u) * sd + mean;
+}
+
+__device__ __forceinline__ uint32_t perm_get(uint32_t perm, int i) { return (perm >> (4 * i)) & 0xFu; }
+__device__ __forceinline__ uint32_t perm_swap(uint32_t perm, int i, int j) {
+  const uint32_t d = ((perm >> (4 * i)) ^ (perm >> (4 * j))) & 0xFu;
+  return perm ^ (d << (4 * i)) ^ (d << (4 * j));
+}
+
+template <class Model, int G>
+__global__ void __launch_bounds__(1024) amwg_step_kernel(const StepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int CPB = nt / G;
+  const int c_in = tid / G, sub = tid % G;
+  const int P = a.pl.P;
+  const LdsLayout L = lds_layout(Model::lds_bytes(a.d.n_obs, a.d.G), P, CPB, a.pl.max_top);
+
+  const unsigned char *data_lds = smem + L.data;
+  double *Sblk = reinterpret_cast<double *>(smem + L.state);
+  CompConst *cc = reinterpret_cast<CompConst *>(smem + L.cc);
+  uint8_t *adapt = smem + L.adapt;
+  ParamLayout *pl = reinterpret_cast<ParamLayout *>(smem + L.pl);
+  uint8_t *idx = smem + L.idx + c_in;  // this chain's shuffle indices at idx[t * CPB]
+
+  // ---- stage chain-shared data and per-component constants (coalesced, once per launch)
+  Model::stage(smem + L.data, a.d, tid, nt);
+  for (int p = tid; p < P; p += nt) { cc[p] = a.cc[p]; adapt[p] = a.is_adapting[p]; }
+  if (tid == 0) *pl = a.pl;
+
+  const int64_t chain_raw = (int64_t)blockIdx.x * CPB + c_in;
+  const bool live = chain_raw < a.C;
+  const int64_t cl = live ? chain_raw : a.C - 1;  // dead lanes shadow the last chain and never store
+  const bool writer = live && sub == 0;
+  const int64_t C = a.C;
+
+  double *Sme = Sblk + c_in;
+  for (int p = 0; p < P; ++p) Sme[p * CPB] = a.ch.state[p * C + cl];
+  const StateView S{Sme, CPB};
+  uint32_t perm = a.ch.perm[cl];
+  ChainStream rng;
+  rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl]);
+  double lp_curr = a.ch.lp_curr[cl];
+  __syncthreads();
+  if (a.init_lp) lp_curr = log_post<Model, G>(S, a, data_lds, sub);  // ctor warm-up call, mcmc.js:961-963
+
+  const int n_named = pl->n_params;
+  int64_t row = a.row0;
+  int32_t next_rec = (int32_t)a.step0;  // host passes steps-until-first-recorded-step here
+
+  for (int step = 0; step < a.n_steps; ++step) {
+    // ---- Sampler.sample: record the state BEFORE the step (mcmc.js:1020-1027)
+    if (a.draws != nullptr && step == next_rec) {
+      if (writer)
+        for (int p = 0; p < P; ++p) a.draws[(row * P + p) * C + cl] = S(p);
+      ++row;
+      next_rec += a.thin;
+    }
+    // ---- AmwgStepper.step: in-place Durstenfeld shuffle of the named sub-steppers (mcmc.js:887, 228-236)
+    for (int i = n_named - 1; i > 0; --i) {
+      const int j = (int)__builtin_floor(rng.next() * (double)(i + 1));
+      perm = perm_swap(perm, i, j);
+    }
+    // ---- every scalar component exactly once; `slot` is uniform across the block
+    int np = 0, e = 0;
+    for (int slot = 0; slot < P; ++slot) {
+      const int p = (int)perm_get(perm, np);
+      const int len = pl->len[p];
+      int comp = pl->base[p];
+      if (pl->multidim[p]) {
+        const int top = pl->top[p];
+        if (e == 0) {  // fresh shuffle of the top dimension (mcmc.js:248-252)
+          for (int t = 0; t < top; ++t) idx[t * CPB] = (uint8_t)t;
+          for (int i = top - 1; i > 0; --i) {
+            const int j = (int)__builtin_floor(rng.next() * (double)(i + 1));
+            const uint8_t ti = idx[i * CPB];
+            idx[i * CPB] = idx[j * CPB];
+            idx[j * CPB] = ti;
+          }
+        }
+        const int inner = len / top;
+        comp += (int)idx[(e / inner) * CPB] * inner + (e % inner);
+      }
+      if (++e == len) { e = 0; ++np; }
+
+      // ---- OnedimMetropolisStepper.step (mcmc.js:517-553)
+      const CompConst k = cc[comp];
+      const int64_t gi = (int64_t)comp * C + cl;
+      double pls = a.ch.prop_log_scale[gi];
+      const double cur = S(comp);
+      double prop = rnorm_js(rng, cur, exp_v8(pls));
+      if (k.type == 1) prop = js_round(prop);
+      const bool inb = !(prop < k.lower || prop > k.upper);
+      bool accepted = false;
+      if (inb) {
+        Sme[comp * CPB] = prop;
+        const double prop_lp = log_post<Model, G>(S, a, data_lds, sub);
+        const double accept_prob = exp_v8(prop_lp - lp_curr);
+        if (accept_prob > rng.next()) {
+          accepted = true;
+          lp_curr = prop_lp;
+        } else {
+          Sme[comp * CPB] = cur;
+        }
+      }
+      const bool adapting = adapt[comp] != 0;
+      int32_t ac = 0, it = 0;
+      if (adapting) {
+        ac = a.ch.acceptance_count[gi] + (accepted ? 1 : 0);
+        it = a.ch.iterations_since_adaption[gi] + 1;
+        if (it >= k.batch_size) {
+          const int32_t bc = a.ch.batch_count[gi] + 1;
+          const double adj = __builtin_fmin(k.max_adaptation, k.initial_adaptation / __builtin_sqrt((double)bc));
+          if ((double)ac / (double)k.batch_size > k.target_accept_rate) pls += adj; else pls -= adj;
+          ac = 0;
+          it = 0;
+          if (writer) { a.ch.batch_count[gi] = bc; a.ch.prop_log_scale[gi] = pls; }
+        }
+      }
+      if (writer) {
+        if (adapting) { a.ch.acceptance_count[gi] = ac; a.ch.iterations_since_adaption[gi] = it; }
+        if (inb) a.ch.inbounds[gi] += 1;
+        if (accepted) a.ch.accepts[gi] += 1;
+      }
+    }
+  }
+
+  if (writer) {
+    for (int p = 0; p < P; ++p) a.ch.state[p * C + cl] = S(p);
+    a.ch.perm[cl] = perm;
+    a.ch.rng_n[cl] = rng.n;
+    a.ch.lp_curr[cl] = lp_curr;
+  }
+}
+
+// ---- device evaluation of the arithmetic building blocks (tests only; amwg_device_eval)
+__global__ void amwg_eval_kernel(int op, int64_t n, const double *a, const double *b, const double *c, double *out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = a[i], y = b ? b[i] : 0.0, z = c ? c[i] : 0.0;
+  double r = 0;
+  switch (op) {
+    case 0: r = exp_v8(x); break;
+    case 1: r = log_v8(x); break;
+    case 2: r = __builtin_sqrt(x); break;
+    case 3: r = lgamma_js(x); break;
+    case 4: r = div_by_invariant(x, y, 1.0 / y); break;
+    case 5: r = x / y; break;
+    case 6: r = ld_norm(x, y, z); break;
+    case 7: r = js_round(x); break;
+    case 8: { ChainStream s; s.init((uint64_t)x, (uint64_t)y, (uint64_t)z); r = s.next(); } break;
+    case 9: r = ld_pois(x, y); break;
+    case 10: r = ld_beta(x, y, z); break;
+    case 11: r = ld_bern(x, y); break;
+    case 12: r = ld_unif(x, y, z); break;
+  }
+  out[i] = r;
+}
+
+}  // namespace amwg

@@ -1,0 +1,130 @@
+// amwg_math.h -- fp64 exp/log for the AMWG kernel, bit-identical to the JavaScript
+// engine the reference runs on.
+//
+// The reference computes every transcendental with V8's Math.exp / Math.log
+// (mcmc.js:51, 527, 578; distributions.js:94-95), which are the Sun fdlibm algorithms
+// (V8 src/base/ieee754.cc).  To make "same seed => same accept decisions, same draws"
+// a testable statement rather than a statistical one, the kernel evaluates the same
+// published algorithms operation for operation (compile with -ffp-contract=off; the only
+// fused operations are the explicit fma() calls of amwg_div.h).  tests/test_core_math.py
+// pins the host build against 120 000 outputs of Node's Math.exp/Math.log and the device
+// build against the host build.
+//
+// GPU shaping: both functions are straight-line on the common path; range/special handling
+// is folded into selects or rare branches so 64 chains with different arguments stay converged.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define AMWG_HD __host__ __device__ __forceinline__
+#else
+#define AMWG_HD inline
+#endif
+
+namespace amwg {
+
+AMWG_HD uint64_t f64_bits(double x) { return __builtin_bit_cast(uint64_t, x); }
+AMWG_HD double bits_f64(uint64_t u) { return __builtin_bit_cast(double, u); }
+AMWG_HD int32_t hi_word(double x) { return (int32_t)(f64_bits(x) >> 32); }
+AMWG_HD uint32_t lo_word(double x) { return (uint32_t)f64_bits(x); }
+AMWG_HD double set_hi_word(double x, int32_t hi) {
+  return bits_f64(((uint64_t)(uint32_t)hi << 32) | (uint64_t)lo_word(x));
+}
+
+// exp(x) = 2^k * exp(r), r = x - k ln2 in two pieces, exp(r) = 1 + r + r*c/(2-c),
+// c = r - r^2 * P(r^2).
+AMWG_HD double exp_v8(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double inv_ln2 = 1.44269504088896338700e+00, two_m1000 = 9.33263618503218878990e-302;
+  const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+               P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  const uint32_t hx_signed = (uint32_t)hi_word(x);
+  const bool neg = (hx_signed >> 31) != 0;
+  const uint32_t hx = hx_signed & 0x7fffffffu;
+
+  if (hx >= 0x40862E42u) {  // |x| >= 709.78, inf or NaN: rare
+    if (hx >= 0x7ff00000u) {
+      if (((hx & 0xfffffu) | lo_word(x)) != 0) return x + x;
+      return neg ? 0.0 : x;
+    }
+    if (x > 7.09782712893383973096e+02) return 1.0e+300 * 1.0e+300;
+    if (x < -7.45133219101941108420e+02) return two_m1000 * two_m1000;
+  }
+  double hi = 0.0, lo = 0.0;
+  int32_t k = 0;
+  if (hx > 0x3fd62e42u) {  // |x| > 0.5 ln2
+    if (hx < 0x3FF0A2B2u) {  // |x| < 1.5 ln2
+      if (x == 1.0) return 2.718281828459045;  // V8 returns Math.E here
+      hi = neg ? x + ln2_hi : x - ln2_hi;      // x - (-ln2_hi) == x + ln2_hi exactly
+      lo = neg ? -ln2_lo : ln2_lo;
+      k = neg ? -1 : 1;
+    } else {
+      k = (int32_t)(inv_ln2 * x + (neg ? -0.5 : 0.5));
+      const double t = (double)k;
+      hi = x - t * ln2_hi;
+      lo = t * ln2_lo;
+    }
+    x = hi - lo;
+  } else if (hx < 0x3e300000u) {  // |x| < 2^-28
+    return 1.0 + x;               // fdlibm's `huge + x > one` guard is always true here
+  }
+  const double t = x * x;
+  const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+  const double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+  if (k >= -1021) {
+    if (k == 1024) return y * 2.0 * 8.98846567431157953865e+307;
+    return set_hi_word(y, hi_word(y) + (k << 20));
+  }
+  return set_hi_word(y, hi_word(y) + ((k + 1000) << 20)) * two_m1000;
+}
+
+// log(x): x = 2^k (1+f), sqrt(2)/2 < 1+f < sqrt(2); s = f/(2+f); log(1+f) = f - s (f - R(s^2)).
+AMWG_HD double log_v8(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double two54 = 1.80143985094819840000e+16;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  int32_t hx = hi_word(x), k = 0;
+  if (hx < 0x00100000) {  // zero, negative, subnormal: rare
+    if (((hx & 0x7fffffff) | (int32_t)lo_word(x)) == 0) return -two54 / 0.0;
+    if (hx < 0) return (x - x) / 0.0;
+    k -= 54;
+    x *= two54;
+    hx = hi_word(x);
+  }
+  if (hx >= 0x7ff00000) return x + x;
+  k += (hx >> 20) - 1023;
+  hx &= 0x000fffff;
+  const int32_t i = (hx + 0x95f64) & 0x100000;
+  x = set_hi_word(x, hx | (i ^ 0x3ff00000));
+  k += (i >> 20);
+  const double f = x - 1.0;
+  const double dk = (double)k;
+  if ((0x000fffff & (2 + hx)) < 3) {  // |f| < 2^-20: rare
+    if (f == 0.0) return (k == 0) ? 0.0 : dk * ln2_hi + dk * ln2_lo;
+    const double R = f * f * (0.5 - 0.33333333333333333 * f);
+    return (k == 0) ? f - R : dk * ln2_hi - ((R - dk * ln2_lo) - f);
+  }
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  const double R = t2 + t1;
+  if (((hx - 0x6147a) | (0x6b851 - hx)) > 0) {
+    const double hfsq = 0.5 * f * f;
+    return (k == 0) ? f - (hfsq - s * (hfsq + R)) : dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  }
+  return (k == 0) ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+// Math.round: nearest integer, ties toward +infinity (mcmc.js:597).
+AMWG_HD double js_round(double x) {
+  if (!(__builtin_fabs(x) < 4503599627370496.0)) return x;
+  const double f = __builtin_floor(x);
+  return (x - f >= 0.5) ? f + 1.0 : f;
+}
+
+}  // namespace amwg

@@ -1,0 +1,180 @@
+// amwg_models.h -- the built-in log_post functors (the user's JS closure, mcmc.js:958-960,
+// for the BASELINE.json model families).  Each model gives
+//   prior(S, mc)            sequential sum of the prior terms, in the closure's order
+//   begin(S, mc, d) -> Pass loop-invariant values of one pass over the data
+//   term<FAST>(pass, i)     the i-th observation's log density
+// and the generic log_post() in amwg_kernel.h adds them in the documented order.
+// S(p) reads scalar component p of this chain's state.
+#pragma once
+#include "amwg_div.h"
+#include "amwg_ld.h"
+#include "amwg_types.h"
+
+namespace amwg {
+
+// LDS-resident view of this chain's state: component p at S.base[p * stride].
+struct StateView {
+  const double *base;
+  int stride;
+  __device__ __forceinline__ double operator()(int p) const { return base[p * stride]; }
+};
+
+// ld.norm(v, 0|m, sd) with constant sd (a prior): c_sd - (v-m)^2 / (2*sd*sd)
+__device__ __forceinline__ double norm_const_sd(double v, double m, double c_sd, double den) {
+  const double t = v - m;
+  return c_sd - (t * t) / den;
+}
+
+// ---------------------------------------------------------------------------------------------
+// x_i ~ norm(mu, sigma); mu ~ norm(0,100); sigma ~ unif(0,100)            README.md:22-36
+struct NormalModel {
+  static constexpr bool kDataInLds = true;
+  struct Pass { double mu, c, den, y; bool fast; const double *x; };
+  __host__ __device__ static size_t lds_bytes(int n_obs, int) { return (size_t)n_obs * 8; }
+  __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt) {
+    double *dst = reinterpret_cast<double *>(smem);
+    for (int i = tid; i < d.n_obs; i += nt) dst[i] = d.x[i];
+  }
+  __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &) {
+    double lp = 0;
+    lp += norm_const_sd(S(0), 0, mc.c_sd100, 2 * 100.0 * 100.0);
+    const double sigma = S(1);
+    lp += (sigma < 0 || sigma > 100) ? -kInf : mc.lunif_0_100;
+    return lp;
+  }
+  __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &mc, const DataRef &,
+                                               const unsigned char *smem) {
+    Pass ps;
+    ps.mu = S(0);
+    const double sd = S(1);
+    ps.c = norm_c(mc.neg_half_log_2pi, sd);
+    ps.den = norm_den(sd);
+    ps.y = 1.0 / ps.den;
+    ps.fast = !mc.exact_division && mc.data_mid_range && mid_range(ps.den) &&
+              (ps.mu == 0 || mid_range(__builtin_fabs(ps.mu)));
+    ps.x = reinterpret_cast<const double *>(smem);
+    return ps;
+  }
+  template <bool FAST>
+  __device__ __forceinline__ static double term(const Pass &ps, int i) {
+    const double t = ps.x[i] - ps.mu;
+    const double tt = t * t;
+    return ps.c - (FAST ? div_by_invariant(tt, ps.den, ps.y) : tt / ps.den);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// x_i ~ bern(theta); theta ~ beta(2,2)                                    README.md:149-164
+// ld.bern(x,p) = log(x*p + (1-x)*(1-p)) is exactly log(p) for x=1 and log(1-p) for x=0
+// (1*p + 0*(1-p) = p + 0 = p), so the two logs are hoisted and selected per observation.
+struct BetaBernModel {
+  static constexpr bool kDataInLds = true;
+  struct Pass { double l1, l0; const uint8_t *x; };
+  __host__ __device__ static size_t lds_bytes(int n_obs, int) { return ((size_t)n_obs + 15) & ~(size_t)15; }
+  __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt) {
+    for (int i = tid; i < d.n_obs; i += nt) smem[i] = d.xb[i];
+  }
+  __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &) {
+    const double th = S(0);
+    double lp = 0;
+    lp += (th > 1 || th < 0) ? -kInf : ((2 - 1) * log_v8(th) + (2 - 1) * log_v8(1 - th) - mc.lbeta_2_2);
+    return lp;
+  }
+  __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &, const DataRef &,
+                                               const unsigned char *smem) {
+    Pass ps;
+    const double th = S(0);
+    ps.l1 = log_v8(th);       // x = 1: log(1*th + 0*(1-th))
+    ps.l0 = log_v8(1 - th);   // x = 0: log(0*th + 1*(1-th))
+    ps.x = smem;
+    return ps;
+  }
+  template <bool FAST>
+  __device__ __forceinline__ static double term(const Pass &ps, int i) {
+    const unsigned b = ps.x[i];
+    return b == 1 ? ps.l1 : (b == 0 ? ps.l0 : -kInf);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// y_i ~ norm(theta[g_i], sigma); theta_g ~ norm(mu,10); mu ~ norm(0,100); sigma ~ unif(0,100)
+// components: theta[0..G-1], mu, sigma                                    SURVEY.md §8(d) cfg4
+struct HierNormalModel {
+  static constexpr bool kDataInLds = true;
+  struct Pass { double c, den, y; bool fast; const double *x; const uint8_t *g; StateView S; };
+  __host__ __device__ static size_t lds_bytes(int n_obs, int) { return (size_t)n_obs * 8 + (((size_t)n_obs + 15) & ~(size_t)15); }
+  __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt) {
+    double *dst = reinterpret_cast<double *>(smem);
+    uint8_t *gd = smem + (size_t)d.n_obs * 8;
+    for (int i = tid; i < d.n_obs; i += nt) { dst[i] = d.x[i]; gd[i] = d.xb[i]; }
+  }
+  __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &d) {
+    const double mu = S(d.G), sigma = S(d.G + 1);
+    double lp = 0;
+    lp += norm_const_sd(mu, 0, mc.c_sd100, 2 * 100.0 * 100.0);
+    lp += (sigma < 0 || sigma > 100) ? -kInf : mc.lunif_0_100;
+    for (int k = 0; k < d.G; ++k) lp += norm_const_sd(S(k), mu, mc.c_sd10, 2 * 10.0 * 10.0);
+    return lp;
+  }
+  __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &mc, const DataRef &d,
+                                               const unsigned char *smem) {
+    Pass ps;
+    const double sd = S(d.G + 1);
+    ps.c = norm_c(mc.neg_half_log_2pi, sd);
+    ps.den = norm_den(sd);
+    ps.y = 1.0 / ps.den;
+    bool ok = !mc.exact_division && mc.data_mid_range && mid_range(ps.den);
+    for (int k = 0; k < d.G; ++k) { const double th = S(k); ok = ok && (th == 0 || mid_range(__builtin_fabs(th))); }
+    ps.fast = ok;
+    ps.x = reinterpret_cast<const double *>(smem);
+    ps.g = smem + (size_t)d.n_obs * 8;
+    ps.S = S;
+    return ps;
+  }
+  template <bool FAST>
+  __device__ __forceinline__ static double term(const Pass &ps, int i) {
+    const double t = ps.x[i] - ps.S(ps.g[i]);
+    const double tt = t * t;
+    return ps.c - (FAST ? div_by_invariant(tt, ps.den, ps.y) : tt / ps.den);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// y_i ~ pois(exp(sum_k X[i][k]*beta[k] + [i >= cp]*beta[7])); beta_k ~ norm(0,10); cp ~ unif(0,N-1)
+// components: beta[0..7], cp (int)                                        SURVEY.md §8(d) cfg5
+// The design matrix (3.6 MB at N=5e4) is read straight from L2/MALL: every wave walks the
+// same rows, and the per-observation exp+log dominate by two orders of magnitude.
+struct PoisGlmModel {
+  static constexpr bool kDataInLds = false;
+  struct Pass { double b[8]; double cp; const double *X, *y, *lfact; int K; };
+  __host__ __device__ static size_t lds_bytes(int, int) { return 0; }
+  __device__ static void stage(unsigned char *, const DataRef &, int, int) {}
+  __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &) {
+    double lp = 0;
+    for (int k = 0; k < 8; ++k) lp += norm_const_sd(S(k), 0, mc.c_sd10, 2 * 10.0 * 10.0);
+    const double cp = S(8);
+    lp += (cp < 0 || cp > mc.cp_upper) ? -kInf : mc.lunif_cp;
+    return lp;
+  }
+  __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &, const DataRef &d,
+                                               const unsigned char *) {
+    Pass ps;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ps.b[k] = S(k);
+    ps.cp = S(8);
+    ps.X = d.x; ps.y = d.y; ps.lfact = d.lfact; ps.K = d.K;
+    return ps;
+  }
+  template <bool FAST>
+  __device__ __forceinline__ static double term(const Pass &ps, int i) {
+    const double *row = ps.X + (size_t)i * 7;
+    double eta = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) eta += row[k] * ps.b[k];
+    if ((double)i >= ps.cp) eta += ps.b[7];
+    const double lam = exp_v8(eta);
+    return log_v8(lam) * ps.y[i] - lam - ps.lfact[i];
+  }
+};
+
+}  // namespace amwg

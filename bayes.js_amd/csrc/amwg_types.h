@@ -1,0 +1,73 @@
+// amwg_types.h -- plain structs shared by the host core and the kernels.
+#pragma once
+#include <stdint.h>
+
+namespace amwg {
+
+constexpr int kMaxNamed = 8;     // named parameters per model (packed 4-bit permutation)
+constexpr int kMaxTop = 256;     // largest shuffled dimension (index bytes)
+
+// Per scalar component, identical for all chains (mcmc.js:497-505).
+struct CompConst {
+  double lower, upper, max_adaptation, initial_adaptation, target_accept_rate;
+  int32_t batch_size;
+  int32_t type;  // AMWG_REAL / AMWG_INT
+};
+
+// Completed parameter layout (mcmc.js:357-403), flattened.
+struct ParamLayout {
+  int32_t n_params, P, max_top, pad;
+  int32_t base[kMaxNamed], len[kMaxNamed], top[kMaxNamed], multidim[kMaxNamed];
+};
+
+// Loop-invariant constants of the built-in models, computed ON THE HOST with the same
+// log_v8 the kernel uses (so the roundings are those of the reference's expression trees).
+struct ModelConsts {
+  double neg_half_log_2pi;          // -0.5*log(2*pi)
+  double c_sd100, c_sd10;           // (-0.5*log(2*pi)) - log(100 | 10)
+  double lunif_0_100;               // log(1/(100-0))
+  double lunif_cp;                  // log(1/((N-1)-0))
+  double cp_upper;                  // N-1
+  double lbeta_2_2;                 // lbeta(2,2)
+  int32_t data_mid_range;           // every data value is 0 or within 2^-200..2^200 in magnitude
+  int32_t exact_division;           // 1 = always use IEEE '/'
+};
+
+// Device pointers to the (read-only, chain-shared) data.
+struct DataRef {
+  int32_t n_obs, G, K, pad;
+  const double *x;      // NORMAL x[N] | HIER y[N] | GLM X[N][K]
+  const double *y;      // GLM counts
+  const double *lfact;  // GLM lfactorial(y_i) (+inf encodes y_i < 0, i.e. term = -inf)
+  const uint8_t *xb;    // BETA_BERN x as bytes (2 = neither 0 nor 1) | HIER group index
+};
+
+// Per-chain state, structure-of-arrays with the chain index fastest: element (p, c) at p*C + c.
+struct ChainArrays {
+  double *state;            // [P][C] current value of every scalar component
+  double *prop_log_scale;   // [P][C]
+  int32_t *acceptance_count, *iterations_since_adaption, *batch_count;  // [P][C]  (mcmc.js:509-511)
+  int32_t *accepts, *inbounds;   // [P][C] run totals (not in the reference; for parity checks)
+  uint32_t *perm;           // [C] order of the named sub-steppers, 4 bits each (mcmc.js:887 shuffles in place)
+  uint64_t *rng_n;          // [C] uniforms consumed
+  double *lp_curr;          // [C] log_post(state)
+};
+
+struct StepArgs {
+  int64_t C;                // chains on this device
+  uint64_t seed, chain_offset;
+  int32_t n_steps, thin;
+  int64_t step0;            // index of the first step of this launch inside the sample() call (for i % thin)
+  double *draws;            // nullptr for burn(); else [row][P][C]
+  int64_t row0;             // first draw row this launch writes
+  const CompConst *cc;      // [P]
+  const uint8_t *is_adapting;  // [P]
+  int32_t init_lp;          // 1 = first launch: compute lp_curr = log_post(init) (the ctor's warm-up call, mcmc.js:961-963)
+  int32_t pad;
+  ParamLayout pl;
+  ModelConsts mc;
+  DataRef d;
+  ChainArrays ch;
+};
+
+}  // namespace amwg

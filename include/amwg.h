@@ -1,0 +1,159 @@
+/*
+ * amwg.h -- C ABI of libamwg.so: many-chain Adaptive-Metropolis-within-Gibbs on MI355X.
+ *
+ * This is the drop-in boundary for ONE path of rasmusab/bayes.js:
+ *
+ *     new mcmc.AmwgSampler(params, log_post, data, options)      mcmc.js:1090-1099 (Sampler ctor :940-966)
+ *     sampler.burn(n)                                            mcmc.js:1035-1039
+ *     sampler.sample(n)                                          mcmc.js:1005-1030
+ *     sampler.thin(k) / .monitor(names)                          mcmc.js:1053-1055 / :1045-1047  (host side; see thin arg)
+ *     sampler.start_adaptation() / .stop_adaptation()            mcmc.js:1060-1073
+ *     sampler.info()                                             mcmc.js:977-980 -> :906-912 -> :563-571
+ *     sampler.state                                              mcmc.js:964
+ *
+ * Each entry point below names the reference method it replaces.  The reference has no
+ * FFI of its own (it is two plain-JS files); the binding a maintainer adds is the N-API
+ * shim bayes.js_amd/csrc/amwg_napi.c, described in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a
+ * negative AMWG_E* code, with text available from amwg_last_error() (thread-local).  The
+ * caller owns every host buffer it passes; the library owns all device memory it allocates.
+ * Calls on one sampler must be serialised by the caller (the reference is single-threaded).
+ * Many independent chains run per sampler; chain c (global id chain_offset + c) uses the
+ * Philox4x32-10 stream keyed by (seed, global id), so results do not depend on how chains
+ * are sharded over GPUs.
+ */
+#ifndef AMWG_H
+#define AMWG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMWG_OK 0
+#define AMWG_EINVAL (-1)   /* bad argument / unsupported model description */
+#define AMWG_EHIP (-2)     /* HIP runtime error (no device, launch failure, out of memory) */
+#define AMWG_ESIZE (-3)    /* caller buffer too small */
+
+/* Built-in model registry: the user's `log_post(state, data)` closure (mcmc.js:958-960),
+ * restricted to the BASELINE.json model families.  Each is the README pattern
+ * (README.md:149-164): priors, then a loop over the data adding one ld.* term per observation. */
+enum {
+  AMWG_MODEL_NORMAL = 1,      /* mu ~ norm(0,100); sigma ~ unif(0,100); x_i ~ norm(mu, sigma)            (README.md:22-36) */
+  AMWG_MODEL_BETA_BERN = 2,   /* theta ~ beta(2,2); x_i ~ bern(theta)                                    (README.md:149-164) */
+  AMWG_MODEL_HIER_NORMAL = 3, /* mu ~ norm(0,100); sigma ~ unif(0,100); theta_g ~ norm(mu,10); y_i ~ norm(theta[g_i], sigma) */
+  AMWG_MODEL_POIS_GLM = 4     /* beta_k ~ norm(0,10); cp ~ unif(0,N-1); y_i ~ pois(exp(X_i.beta[0:K] + [i>=cp] beta[7])) */
+};
+
+enum { AMWG_REAL = 0, AMWG_INT = 1 };
+
+/* One named parameter AFTER complete_params() (mcmc.js:357-403), flattened row-major.
+ * The order of the array is Object.keys(params) order (mcmc.js:839). */
+typedef struct {
+  int32_t type;      /* AMWG_REAL | AMWG_INT  ("binary" is not on this path: SURVEY.md §8f) */
+  int32_t len;       /* prod(dim) */
+  int32_t top;       /* dim[0]: the only dimension whose visiting order is shuffled (mcmc.js:244-258) */
+  int32_t multidim;  /* 0 iff dim equals [1]  (stepper dispatch rule, mcmc.js:846-857) */
+  double lower, upper;
+} amwg_param_desc;
+
+/* Stepper options of one scalar component, already merged the way AmwgStepper merges them
+ * (mcmc.js:869-878) and defaulted (mcmc.js:500-505). */
+typedef struct {
+  double prop_log_scale;      /* default 0    */
+  double max_adaptation;      /* default 0.33 */
+  double initial_adaptation;  /* default 1.0  */
+  double target_accept_rate;  /* default 0.44 */
+  int32_t batch_size;         /* default 50   */
+  int32_t is_adapting;        /* default 1    */
+} amwg_comp_opt;
+
+/* The `data` argument (mcmc.js:942): host arrays, copied to the device by amwg_create. */
+typedef struct {
+  int32_t model;     /* AMWG_MODEL_* */
+  int32_t n_obs;
+  const double *x;   /* NORMAL: x[N]; BETA_BERN: x[N]; HIER_NORMAL: y[N]; POIS_GLM: X[N][K] row-major */
+  const double *y;   /* POIS_GLM: counts y[N]; otherwise NULL */
+  const int32_t *g;  /* HIER_NORMAL: group index of observation i, 0 <= g_i < G; otherwise NULL */
+  int32_t G;         /* HIER_NORMAL: number of groups (= len of the first param) */
+  int32_t K;         /* POIS_GLM: number of real columns (7) */
+} amwg_model_desc;
+
+typedef struct {
+  int64_t chains;          /* independent chains on this sampler (>= 1) */
+  uint64_t seed;           /* Philox key */
+  uint64_t chain_offset;   /* global id of local chain 0 (multi-GPU sharding) */
+  int32_t device;          /* HIP device ordinal */
+  int32_t lanes_per_chain; /* 0 = auto; else a power of two 1..64: lanes that split one chain's observation loop */
+  int32_t block_threads;   /* 0 = auto; else multiple of 64, <= 1024 */
+  int32_t steps_per_launch;/* 0 = auto (one launch per burn/sample call up to 2^20 steps) */
+  int32_t exact_division;  /* 0 = default (hoisted-reciprocal division, bit-identical to IEEE, verified); 1 = plain IEEE '/' */
+  int32_t reserved[3];
+} amwg_options;
+
+typedef struct amwg_sampler amwg_sampler;
+
+/* Replaces `new mcmc.AmwgSampler(params, log_post, data, options)` (mcmc.js:1090, 940-966).
+ * init: P = sum(len) initial values (completed params' init, mcmc.js:954-957), the same for every chain. */
+int amwg_create(const amwg_model_desc *model, const amwg_param_desc *params, int32_t n_params, const double *init,
+                const amwg_comp_opt *comp_opts, const amwg_options *options, amwg_sampler **out);
+
+/* Replaces sampler.burn(n) (mcmc.js:1035-1039). */
+int amwg_burn(amwg_sampler *s, int64_t n);
+
+/* Replaces sampler.sample(n) with thinning interval `thin` (mcmc.js:1005-1030, 1053-1055):
+ * draw k is the state BEFORE step k*thin.  out_draws (host) receives ceil(n/thin) * P * chains
+ * doubles laid out [draw][component][chain]; out_bytes is its capacity. */
+int amwg_sample(amwg_sampler *s, int64_t n, int64_t thin, double *out_draws, size_t out_bytes);
+
+/* Same, but the destination is DEVICE memory owned by the caller (e.g. a buffer that is then
+ * gathered across GPUs with RCCL); no host copy is made.  Asynchronous on the sampler's stream
+ * until amwg_sync(). */
+int amwg_sample_device(amwg_sampler *s, int64_t n, int64_t thin, double *out_draws_dev, size_t out_bytes);
+
+/* Replaces sampler.start_adaptation() / .stop_adaptation() (mcmc.js:1060-1073). */
+int amwg_set_adapting(amwg_sampler *s, int32_t flag);
+
+/* Replaces reading sampler.state (mcmc.js:964): out[component][chain], P*chains doubles. */
+int amwg_get_state(amwg_sampler *s, double *out, size_t out_bytes);
+
+/* Replaces sampler.info() (mcmc.js:977-980 -> 906-912 -> 563-571).  Every array is
+ * [component][chain]; any pointer may be NULL.  `accepts`/`inbounds` are run totals the
+ * reference does not keep (accept decisions and in-bounds proposals), used by parity tests. */
+int amwg_info(amwg_sampler *s, double *prop_log_scale, int32_t *acceptance_count, int32_t *iterations_since_adaption,
+              int32_t *batch_count, int64_t *accepts, int64_t *inbounds);
+
+/* Per chain: uniforms consumed so far, cached log_post(state), and the current order of the
+ * named sub-steppers (mcmc.js:887), order[chain * n_params + k]. */
+int amwg_chain_diag(amwg_sampler *s, uint64_t *uniforms, double *log_post, int32_t *named_order);
+
+/* Posterior summaries computed on the device over the draws of the LAST amwg_sample* call:
+ * mean[P], sd[P] (n-1 denominator) over all chains x kept draws. */
+int amwg_last_sample_moments(amwg_sampler *s, double *mean, double *sd);
+
+int amwg_sync(amwg_sampler *s);
+int amwg_num_components(const amwg_sampler *s);
+int64_t amwg_num_chains(const amwg_sampler *s);
+/* Launch geometry actually used and HIP-event time of the step kernels of the last burn/sample call. */
+int amwg_launch_info(const amwg_sampler *s, int32_t *lanes_per_chain, int32_t *block_threads, int32_t *grid_blocks,
+                     int32_t *lds_bytes, int32_t *n_launches, double *kernel_ms);
+int amwg_destroy(amwg_sampler *s);
+const char *amwg_last_error(void);
+const char *amwg_version(void);
+
+/* Arithmetic building blocks, exported so they can be pinned individually (tests only).
+ * Host evaluations of the exact same source the kernel compiles (csrc/amwg_math.h, amwg_ld.h). */
+double amwg_exp(double x);   /* bit-identical to V8 Math.exp */
+double amwg_log(double x);   /* bit-identical to V8 Math.log */
+double amwg_uniform(uint64_t seed, uint64_t chain, uint64_t index);
+/* Device evaluation: op in {0:exp,1:log,2:sqrt,3:lgamma,4:a/b via hoisted reciprocal,5:ld_norm(a,b,c),...};
+ * a,b,c host arrays of n doubles (b,c may be NULL), out host array of n doubles. */
+int amwg_device_eval(int32_t device, int32_t op, int64_t n, const double *a, const double *b, const double *c, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,36 @@
+"""Shared helpers for the -m gpu parity tests (HIP path vs oracle / golden)."""
+import numpy as np
+
+import amwg_ctypes
+import oracle_lib
+
+
+def run_schedule(s, schedule):
+    """Runs a golden-style schedule on a Sampler or OracleChain; returns list of draw arrays."""
+    segs, thin = [], 1
+    for seg in schedule:
+        if seg["op"] == "burn":
+            s.burn(seg["n"])
+        elif seg["op"] == "stop":
+            s.set_adapting(False)
+        elif seg["op"] == "start":
+            s.set_adapting(True)
+        elif seg["op"] == "sample":
+            thin = seg.get("thin", thin)
+            segs.append(s.sample(seg["n"], thin))
+    return segs
+
+
+def assert_chain_equals_oracle(gpu, local, orc, gpu_segs, orc_segs):
+    """Bit-exact comparison of local chain `local` of a GPU sampler with an oracle chain run in the same order."""
+    for g, o in zip(gpu_segs, orc_segs):
+        assert g[:, :, local].tobytes() == np.ascontiguousarray(o).tobytes()
+    gi, oi = gpu.info(), orc.info()
+    for k in ("accepts", "inbounds", "batch_count", "acceptance_count", "iterations_since_adaption"):
+        assert gi[k][:, local].tolist() == oi[k].tolist(), k
+    assert gi["prop_log_scale"][:, local].tobytes() == oi["prop_log_scale"].tobytes()
+    assert gpu.state()[:, local].tobytes() == orc.state().tobytes()
+    d = gpu.diag()
+    assert int(d["uniforms"][local]) == orc.uniforms()
+    assert d["named_order"][local].tolist() == orc.named_order().tolist()
+    assert np.float64(d["log_post"][local]).tobytes() == np.float64(orc.log_post()).tobytes()

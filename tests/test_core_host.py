@@ -1,0 +1,66 @@
+"""CPU-side checks of libamwg.so: it loads, exports the whole C ABI, its host build of the
+kernel arithmetic is bit-identical to V8, and it refuses to run without a GPU (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import amwg_ctypes
+import golden_io
+import model_spec
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = amwg_ctypes.lib()
+    hdr = open(os.path.join(ROOT, "include", "amwg.h")).read()
+    declared = set(re.findall(r"\b(amwg_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(amwg_ctypes.EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert b"gfx950" in L.amwg_version()
+
+
+def test_host_math_bit_exact_vs_v8():
+    L = amwg_ctypes.lib()
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_math_pairs.bin"), dtype="<f8").reshape(-1, 3)
+    bad = 0
+    for x, e, l in a:
+        bad += np.float64(L.amwg_exp(x)).tobytes() != np.float64(e).tobytes()
+        bad += np.float64(L.amwg_log(abs(x))).tobytes() != np.float64(l).tobytes()
+    assert bad == 0
+
+
+def test_host_uniform_stream_matches_twin():
+    L = amwg_ctypes.lib()
+    u = synth.uniforms(20260925, 3, 64)
+    for i in range(64):
+        assert L.amwg_uniform(20260925, 3, i) == u[i]
+    u = synth.uniforms(7, (1 << 32) + 5, 4)      # 64-bit chain ids
+    assert L.amwg_uniform(7, (1 << 32) + 5, 3) == u[3]
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
+def test_no_cpu_fallback_without_gpu():
+    data = synth.normal(100, 1)
+    spec = model_spec.build_spec("normal", data)
+    with pytest.raises(amwg_ctypes.AmwgError) as ei:
+        amwg_ctypes.Sampler(spec, chains=4, seed=1)
+    assert "HIP" in str(ei.value) or "device" in str(ei.value)
+
+
+def test_bad_arguments_are_rejected_before_touching_the_device():
+    data = synth.normal(10, 1)
+    spec = model_spec.build_spec("normal", data)
+    with pytest.raises(amwg_ctypes.AmwgError):
+        amwg_ctypes.Sampler(spec, chains=0, seed=1)
+    with pytest.raises(amwg_ctypes.AmwgError):
+        amwg_ctypes.Sampler(spec, chains=4, seed=1, lanes_per_chain=3)
+    bad = model_spec.build_spec("normal", data)
+    bad["model"] = "beta_bern"       # two params handed to a one-param model
+    with pytest.raises(amwg_ctypes.AmwgError):
+        amwg_ctypes.Sampler(bad, chains=4, seed=1)

@@ -1,0 +1,71 @@
+"""-m gpu: the kernel's arithmetic building blocks, evaluated ON THE DEVICE, against V8 / IEEE."""
+import os
+
+import numpy as np
+import pytest
+
+import amwg_ctypes as A
+import golden_io
+import oracle_lib
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_exp_log_bit_exact_vs_v8():
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_math_pairs.bin"), dtype="<f8").reshape(-1, 3)
+    e = A.device_eval(0, a[:, 0])
+    l = A.device_eval(1, np.abs(a[:, 0]))
+    assert e.tobytes() == np.ascontiguousarray(a[:, 1]).tobytes()
+    assert l.tobytes() == np.ascontiguousarray(a[:, 2]).tobytes()
+
+
+def test_device_sqrt_correctly_rounded():
+    k = np.arange(1, 200001, dtype=np.float64)       # batch_count values, mcmc.js:542
+    assert A.device_eval(2, k).tobytes() == np.sqrt(k).tobytes()
+    r = np.random.default_rng(1).uniform(0, 1e6, 200000)
+    assert A.device_eval(2, r).tobytes() == np.sqrt(r).tobytes()
+
+
+def test_division_by_invariant_equals_ieee():
+    rng = np.random.default_rng(2)
+    n = 2_000_000
+    a = np.concatenate([rng.uniform(0, 1e4, n), np.exp(rng.uniform(-300, 300, n)), [0.0, 1.0, 3.0, 2.0 ** -450, 2.0 ** 400]])
+    b = np.concatenate([rng.uniform(1e-3, 1e3, n), np.exp(rng.uniform(-130, 130, n)), [7.0, 3.0, 3.0, 2.0 ** 190, 2.0 ** -190]])
+    # adversarial divisors: significand all ones / just above a power of two
+    b[:1000] = np.nextafter(2.0 ** rng.integers(-5, 5, 1000).astype(np.float64), 0)
+    b[1000:2000] = np.nextafter(2.0 ** rng.integers(-5, 5, 1000).astype(np.float64), 1e300)
+    fast = A.device_eval(4, a, b)
+    ieee = A.device_eval(5, a, b)
+    assert ieee.tobytes() == (a / b).tobytes()        # device '/' is IEEE
+    assert fast.tobytes() == ieee.tobytes()
+
+
+def test_device_ld_and_helpers_match_oracle():
+    L = oracle_lib.lib()
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0.1, 200, 5000)
+    lg = A.device_eval(3, x)
+    assert lg.tobytes() == np.array([L.orc_lgamma(v) for v in x]).tobytes()
+    m, sd = rng.normal(0, 5, 5000), rng.uniform(0.1, 9, 5000)
+    got = A.device_eval(6, x, m, sd)
+    assert got.tobytes() == np.array([L.orc_ld_norm(*v) for v in zip(x, m, sd)]).tobytes()
+    cnt = np.floor(rng.uniform(0, 60, 5000))
+    lam = rng.uniform(0.01, 50, 5000)
+    assert A.device_eval(9, cnt, lam).tobytes() == np.array([L.orc_ld_pois(*v) for v in zip(cnt, lam)]).tobytes()
+    th = rng.uniform(0, 1, 5000)
+    assert A.device_eval(10, th, np.full(5000, 2.0), np.full(5000, 2.0)).tobytes() == \
+        np.array([L.orc_ld_beta(v, 2, 2) for v in th]).tobytes()
+    xb = np.floor(rng.uniform(0, 2, 5000))
+    assert A.device_eval(11, xb, th).tobytes() == np.array([L.orc_ld_bern(*v) for v in zip(xb, th)]).tobytes()
+    assert A.device_eval(12, x, np.zeros(5000), np.full(5000, 100.0)).tobytes() == \
+        np.array([L.orc_ld_unif(v, 0, 100) for v in x]).tobytes()
+    r = np.concatenate([rng.uniform(-50, 50, 5000), [0.5, -0.5, 1.5, -1.5, 2.5, 0.49999999999999994]])
+    assert A.device_eval(7, r).tobytes() == np.array([L.orc_js_round(v) for v in r]).tobytes()
+
+
+def test_device_philox_stream():
+    n = 4096
+    idx = np.arange(n, dtype=np.float64)
+    got = A.device_eval(8, np.full(n, 20260925.0), np.full(n, 12345.0), idx)
+    assert got.tobytes() == synth.uniforms(20260925, 12345, n).tobytes()

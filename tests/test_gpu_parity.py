@@ -1,0 +1,121 @@
+"""-m gpu: the HIP path, through the C ABI, against the reference goldens and the oracle.
+
+Bars (north_star): integer/decision state bit-identical; with one lane per chain (the
+reference's summation order) every double bit-identical to the REFERENCE; with G lanes per
+chain every double bit-identical to the oracle run in the same G-lane order, and every accept
+decision still identical to the reference's.
+"""
+import numpy as np
+import pytest
+
+import amwg_ctypes as A
+import golden_io
+import model_spec
+import oracle_lib
+from gpu_util import assert_chain_equals_oracle, run_schedule
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN_CASES = ["cfg1_heights", "normal_n1000", "cfg2_full", "normal_opts", "beta_bern_n2000", "cfg3_full", "hier_small",
+                "cfg4_full", "glm_small", "cfg5_full"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_one_lane_per_chain_is_bit_identical_to_reference(name):
+    gold = golden_io.load(name)
+    case = gold["case"]
+    for rec in gold["chains"]:
+        spec = model_spec.spec_from_golden(gold, rec)
+        s = A.Sampler(spec, chains=3, seed=case["seed"], chain_offset=rec["chain"], lanes_per_chain=1)
+        segs = run_schedule(s, case["schedule"])
+        for got, want in zip(segs, rec["samples"]):
+            assert got.shape[0] == want["kept"]
+            w = np.array(want["draws"], dtype=np.float64).reshape(-1, got.shape[1])
+            assert np.ascontiguousarray(got[: w.shape[0], :, 0]).tobytes() == w.tobytes()
+            tot = np.zeros(got.shape[1])
+            for t in range(got.shape[0]):
+                tot = tot + got[t, :, 0]
+            assert tot.tolist() == want["sum"]
+        info, d = s.info(), s.diag()
+        assert s.state()[:, 0].tolist() == rec["final_state"]
+        assert info["accepts"][:, 0].tolist() == rec["accepts"]
+        assert info["inbounds"][:, 0].tolist() == rec["inbounds"]
+        assert info["prop_log_scale"][:, 0].tolist() == rec["prop_log_scale"]
+        assert info["batch_count"][:, 0].tolist() == rec["batch_count"]
+        assert info["acceptance_count"][:, 0].tolist() == rec["acceptance_count"]
+        assert info["iterations_since_adaption"][:, 0].tolist() == rec["iterations_since_adaption"]
+        assert int(d["uniforms"][0]) == rec["uniforms"]
+        assert d["named_order"][0].tolist() == rec["named_order"]
+        assert float(d["log_post"][0]) == rec["log_post"]
+        s.close()
+
+
+@pytest.mark.parametrize("name", ["cfg1_heights", "normal_n1000", "normal_opts", "beta_bern_n2000", "hier_small", "glm_small"])
+@pytest.mark.parametrize("lanes", [2, 4, 8, 16, 32, 64])
+def test_g_lanes_per_chain_matches_oracle_and_reference_decisions(name, lanes):
+    gold = golden_io.load(name)
+    case = gold["case"]
+    rec = gold["chains"][0]
+    spec = model_spec.spec_from_golden(gold, rec)
+    s = A.Sampler(spec, chains=5, seed=case["seed"], chain_offset=rec["chain"], lanes_per_chain=lanes)
+    o = oracle_lib.OracleChain(spec, case["seed"], rec["chain"], lanes=lanes)
+    gs, os_ = run_schedule(s, case["schedule"]), run_schedule(o, case["schedule"])
+    assert_chain_equals_oracle(s, 0, o, gs, os_)
+    assert s.info()["accepts"][:, 0].tolist() == rec["accepts"]      # the reference's decisions
+    assert int(s.diag()["uniforms"][0]) == rec["uniforms"]
+    s.close()
+
+
+@pytest.mark.parametrize("model,n_obs,G", [("normal", 777, 0), ("beta_bern", 1500, 0), ("hier_normal", 900, 6), ("pois_glm", 300, 0)])
+def test_many_chains_auto_geometry_vs_oracle(model, n_obs, G):
+    """Seeded inputs, auto geometry, ragged N: a sample of chains (first, last, middle) bit-equal to the oracle."""
+    data = model_spec.make_data(model, n_obs, 99, G=G or 32, exp=oracle_lib.lib().orc_exp)
+    spec = model_spec.build_spec(model, data)
+    chains, seed, off = 1000, 4242, 10_000_000_000      # > 2^32 global ids exercise the 64-bit counter words
+    s = A.Sampler(spec, chains=chains, seed=seed, chain_offset=off)
+    lanes = s.launch_info()["lanes_per_chain"]
+    sched = [{"op": "burn", "n": 120}, {"op": "sample", "n": 60, "thin": 3}]
+    gs = run_schedule(s, sched)
+    for local in (0, 499, 999):
+        o = oracle_lib.OracleChain(spec, seed, off + local, lanes=lanes)
+        assert_chain_equals_oracle(s, local, o, gs, run_schedule(o, sched))
+    s.close()
+
+
+def test_sharding_chunking_and_division_mode_do_not_change_results():
+    data = model_spec.make_data("normal", 500, 5)
+    spec = model_spec.build_spec("normal", data)
+    kw = dict(seed=11, lanes_per_chain=4, block_threads=256)
+    whole = A.Sampler(spec, chains=128, **kw)
+    whole.burn(77)
+    ref = whole.sample(40, 2)
+    halves = [A.Sampler(spec, chains=64, chain_offset=o, **kw) for o in (0, 64)]
+    parts = []
+    for h in halves:
+        h.burn(77)
+        parts.append(h.sample(40, 2))
+    assert np.concatenate(parts, axis=2).tobytes() == ref.tobytes()          # 1 shard == 2 shards
+    chunked = A.Sampler(spec, chains=128, steps_per_launch=7, **kw)
+    chunked.burn(77)
+    assert chunked.sample(40, 2).tobytes() == ref.tobytes()                  # launch chunking
+    assert chunked.launch_info()["n_launches"] == 6
+    ieee = A.Sampler(spec, chains=128, exact_division=1, **kw)
+    ieee.burn(77)
+    assert ieee.sample(40, 2).tobytes() == ref.tobytes()                     # hoisted reciprocal == IEEE '/'
+    again = A.Sampler(spec, chains=128, **kw)
+    again.burn(77)
+    assert again.sample(40, 2).tobytes() == ref.tobytes()                    # run-to-run reproducible
+    m, sd = whole.moments()
+    flat = ref.transpose(1, 0, 2).reshape(2, -1)
+    np.testing.assert_allclose(m, flat.mean(axis=1), rtol=1e-12)
+    np.testing.assert_allclose(sd, flat.std(axis=1, ddof=1), rtol=1e-10)
+
+
+def test_edge_cases_empty_data_single_chain_thin_larger_than_n():
+    spec = model_spec.build_spec("normal", {"x": np.zeros(0)})
+    s = A.Sampler(spec, chains=1, seed=3)
+    o = oracle_lib.OracleChain(spec, 3, 0, lanes=s.launch_info()["lanes_per_chain"])
+    sched = [{"op": "burn", "n": 10}, {"op": "sample", "n": 5, "thin": 9}, {"op": "sample", "n": 0}]
+    gs, os_ = run_schedule(s, sched), run_schedule(o, sched)
+    assert gs[0].shape == (1, 2, 1) and gs[1].shape == (0, 2, 1)
+    assert_chain_equals_oracle(s, 0, o, gs, os_)
