@@ -27,7 +27,10 @@ class CompOpt(C.Structure):
 
 class ModelDesc(C.Structure):
     _fields_ = [("model", C.c_int32), ("n_obs", C.c_int32), ("x", C.POINTER(C.c_double)), ("y", C.POINTER(C.c_double)),
-                ("g", C.POINTER(C.c_int32)), ("G", C.c_int32), ("K", C.c_int32)]
+                ("g", C.POINTER(C.c_int32)), ("G", C.c_int32), ("K", C.c_int32), ("hyper", C.c_double * 8)]
+
+
+DEFAULT_HYPER = {"normal": [0, 100, 0, 100], "beta_bern": [2, 2], "hier_normal": [0, 100, 0, 100, 10], "pois_glm": [0, 10]}
 
 
 class Options(C.Structure):
@@ -36,7 +39,7 @@ class Options(C.Structure):
                 ("exact_division", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
-EXPORTS = ["amwg_create", "amwg_burn", "amwg_sample", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
+EXPORTS = ["amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
            "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components",
            "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp",
            "amwg_log", "amwg_uniform", "amwg_device_eval"]
@@ -56,6 +59,9 @@ def lib():
         L.amwg_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(ParamDesc), i32, pd, C.POINTER(CompOpt),
                                   C.POINTER(Options), C.POINTER(vp)]
         L.amwg_burn.argtypes = [vp, i64]
+        L.amwg_burn_async.argtypes = [vp, i64]
+        L.amwg_sample_async.argtypes = [vp, i64, i64]
+        L.amwg_fetch_draws.argtypes = [vp, pd, C.c_size_t]
         L.amwg_sample.argtypes = [vp, i64, i64, pd, C.c_size_t]
         L.amwg_sample_device.argtypes = [vp, i64, i64, vp, C.c_size_t]
         L.amwg_set_adapting.argtypes = [vp, i32]
@@ -119,6 +125,8 @@ class Sampler:
             md.g = g.ctypes.data_as(C.POINTER(C.c_int32))
         md.G = int(spec.get("G", 0))
         md.K = int(spec.get("K", 0))
+        for i, v in enumerate(spec.get("hyper") or DEFAULT_HYPER[spec["model"]]):
+            md.hyper[i] = float(v)
         n = len(spec["params"])
         pa = (ParamDesc * n)()
         for i, p in enumerate(spec["params"]):
@@ -161,6 +169,18 @@ class Sampler:
         kept = -(-n // thin)
         out = np.empty((kept, self.P, self.C), dtype=np.float64)
         _check(lib().amwg_sample(self.h, n, thin, _dp(out), out.nbytes))
+        return out
+
+    def burn_async(self, n):
+        _check(lib().amwg_burn_async(self.h, n))
+
+    def sample_async(self, n, thin=1):
+        _check(lib().amwg_sample_async(self.h, n, thin))
+        self._pending = -(-n // thin)
+
+    def fetch_draws(self):
+        out = np.empty((self._pending, self.P, self.C), dtype=np.float64)
+        _check(lib().amwg_fetch_draws(self.h, _dp(out), out.nbytes))
         return out
 
     def sample_device(self, n, thin, dev_ptr, nbytes):

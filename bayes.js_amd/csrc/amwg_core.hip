@@ -312,12 +312,26 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   // ---- model constants, with the kernel's own log (same roundings as the reference expression trees)
   ModelConsts &mc = s->mc;
   mc.neg_half_log_2pi = -0.5 * log_v8(2 * kPi);
-  mc.c_sd100 = mc.neg_half_log_2pi - log_v8(100.0);
-  mc.c_sd10 = mc.neg_half_log_2pi - log_v8(10.0);
-  mc.lunif_0_100 = log_v8(1 / (100.0 - 0.0));
+  const double *h = m->hyper;
+  if (m->model == AMWG_MODEL_NORMAL || m->model == AMWG_MODEL_HIER_NORMAL || m->model == AMWG_MODEL_POIS_GLM) {
+    mc.m0 = h[0];
+    mc.c0 = mc.neg_half_log_2pi - log_v8(h[1]);     // ld.norm's  -0.5*log(2*pi) - log(sd)
+    mc.den0 = 2 * h[1] * h[1];                      //            (2*sd)*sd
+  }
+  if (m->model == AMWG_MODEL_NORMAL || m->model == AMWG_MODEL_HIER_NORMAL) {
+    mc.ua = h[2]; mc.ub = h[3];
+    mc.lunif = log_v8(1 / (h[3] - h[2]));           // ld.unif's log(1/(max-min))
+  }
+  if (m->model == AMWG_MODEL_HIER_NORMAL) {
+    mc.c1 = mc.neg_half_log_2pi - log_v8(h[4]);
+    mc.den1 = 2 * h[4] * h[4];
+  }
+  if (m->model == AMWG_MODEL_BETA_BERN) {
+    mc.ba = h[0]; mc.bb = h[1];
+    mc.lbeta_ab = lbeta_js(h[0], h[1]);
+  }
   mc.cp_upper = (double)(N - 1);
   mc.lunif_cp = log_v8(1 / (mc.cp_upper - 0.0));
-  mc.lbeta_2_2 = lbeta_js(2, 2);
   mc.exact_division = options->exact_division ? 1 : 0;
 
   // ---- data upload
@@ -436,10 +450,14 @@ int amwg_destroy(amwg_sampler *s) {
   return AMWG_OK;
 }
 
-int amwg_burn(amwg_sampler *s, int64_t n) {
+int amwg_burn_async(amwg_sampler *s, int64_t n) {
   if (!s || n < 0) return fail(AMWG_EINVAL, "amwg_burn: bad argument");
   HIP_TRY(hipSetDevice(s->device));
-  int rc = launch_steps(s, n, 1, nullptr);
+  return launch_steps(s, n, 1, nullptr);
+}
+
+int amwg_burn(amwg_sampler *s, int64_t n) {
+  int rc = amwg_burn_async(s, n);
   if (rc != AMWG_OK) return rc;
   return finish_timing(s);
 }
@@ -457,24 +475,45 @@ int amwg_sample_device(amwg_sampler *s, int64_t n, int64_t thin, double *out_dev
   return AMWG_OK;
 }
 
-int amwg_sample(amwg_sampler *s, int64_t n, int64_t thin, double *out, size_t out_bytes) {
-  if (!s || n < 0 || thin < 1 || (!out && n > 0)) return fail(AMWG_EINVAL, "amwg_sample: bad argument");
+int amwg_sample_async(amwg_sampler *s, int64_t n, int64_t thin) {
+  if (!s || n < 0 || thin < 1) return fail(AMWG_EINVAL, "amwg_sample: bad argument");
   const int64_t rows = (n + thin - 1) / thin;
   const size_t need = (size_t)rows * (size_t)s->P * (size_t)s->C * 8;
-  if (out_bytes < need) return fail(AMWG_ESIZE, "amwg_sample: output needs %zu bytes, got %zu", need, out_bytes);
   HIP_TRY(hipSetDevice(s->device));
   if (need > s->d_draws_cap) {
     if (s->d_draws) { (void)hipFree(s->d_draws); s->d_draws = nullptr; s->d_draws_cap = 0; }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_draws), need ? need : 8));
     s->d_draws_cap = need;
   }
-  int rc = amwg_sample_device(s, n, thin, s->d_draws, need);
-  if (rc != AMWG_OK) return rc;
-  rc = finish_timing(s);
+  if (!s->d_draws) {  // n == 0 before any allocation
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_draws), 8));
+    s->d_draws_cap = 8;
+  }
+  return amwg_sample_device(s, n, thin, s->d_draws, need);
+}
+
+int amwg_fetch_draws(amwg_sampler *s, double *out, size_t out_bytes) {
+  if (!s) return fail(AMWG_EINVAL, "amwg_fetch_draws: null sampler");
+  if (s->last_draws != s->d_draws) return fail(AMWG_EINVAL, "amwg_fetch_draws: no amwg_sample_async pending");
+  const size_t need = (size_t)s->last_rows * (size_t)s->P * (size_t)s->C * 8;
+  if (need && !out) return fail(AMWG_EINVAL, "amwg_fetch_draws: null output");
+  if (out_bytes < need) return fail(AMWG_ESIZE, "amwg_sample: output needs %zu bytes, got %zu", need, out_bytes);
+  HIP_TRY(hipSetDevice(s->device));
+  int rc = finish_timing(s);
   if (rc != AMWG_OK) return rc;
   if (need) HIP_TRY(hipMemcpyAsync(out, s->d_draws, need, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return AMWG_OK;
+}
+
+int amwg_sample(amwg_sampler *s, int64_t n, int64_t thin, double *out, size_t out_bytes) {
+  if (!s || n < 0 || thin < 1 || (!out && n > 0)) return fail(AMWG_EINVAL, "amwg_sample: bad argument");
+  const int64_t rows = (n + thin - 1) / thin;
+  const size_t need = (size_t)rows * (size_t)s->P * (size_t)s->C * 8;
+  if (out_bytes < need) return fail(AMWG_ESIZE, "amwg_sample: output needs %zu bytes, got %zu", need, out_bytes);
+  int rc = amwg_sample_async(s, n, thin);
+  if (rc != AMWG_OK) return rc;
+  return amwg_fetch_draws(s, out, out_bytes);
 }
 
 int amwg_sync(amwg_sampler *s) {

@@ -26,7 +26,7 @@ __device__ __forceinline__ double norm_const_sd(double v, double m, double c_sd,
 }
 
 // ---------------------------------------------------------------------------------------------
-// x_i ~ norm(mu, sigma); mu ~ norm(0,100); sigma ~ unif(0,100)            README.md:22-36
+// x_i ~ norm(mu, sigma); mu ~ norm(m0,s0); sigma ~ unif(a,b)              README.md:22-36
 struct NormalModel {
   static constexpr bool kDataInLds = true;
   struct Pass { double mu, c, den, y; bool fast; const double *x; };
@@ -37,9 +37,9 @@ struct NormalModel {
   }
   __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &) {
     double lp = 0;
-    lp += norm_const_sd(S(0), 0, mc.c_sd100, 2 * 100.0 * 100.0);
+    lp += norm_const_sd(S(0), mc.m0, mc.c0, mc.den0);
     const double sigma = S(1);
-    lp += (sigma < 0 || sigma > 100) ? -kInf : mc.lunif_0_100;
+    lp += (sigma < mc.ua || sigma > mc.ub) ? -kInf : mc.lunif;
     return lp;
   }
   __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &mc, const DataRef &,
@@ -64,7 +64,7 @@ struct NormalModel {
 };
 
 // ---------------------------------------------------------------------------------------------
-// x_i ~ bern(theta); theta ~ beta(2,2)                                    README.md:149-164
+// x_i ~ bern(theta); theta ~ beta(a,b)                                    README.md:149-164
 // ld.bern(x,p) = log(x*p + (1-x)*(1-p)) is exactly log(p) for x=1 and log(1-p) for x=0
 // (1*p + 0*(1-p) = p + 0 = p), so the two logs are hoisted and selected per observation.
 struct BetaBernModel {
@@ -77,7 +77,9 @@ struct BetaBernModel {
   __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &) {
     const double th = S(0);
     double lp = 0;
-    lp += (th > 1 || th < 0) ? -kInf : ((2 - 1) * log_v8(th) + (2 - 1) * log_v8(1 - th) - mc.lbeta_2_2);
+    if (th > 1 || th < 0) lp += -kInf;
+    else if (mc.ba == 1 && mc.bb == 1) lp += 0.0;
+    else lp += (mc.ba - 1) * log_v8(th) + (mc.bb - 1) * log_v8(1 - th) - mc.lbeta_ab;
     return lp;
   }
   __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &, const DataRef &,
@@ -111,9 +113,9 @@ struct HierNormalModel {
   __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &d) {
     const double mu = S(d.G), sigma = S(d.G + 1);
     double lp = 0;
-    lp += norm_const_sd(mu, 0, mc.c_sd100, 2 * 100.0 * 100.0);
-    lp += (sigma < 0 || sigma > 100) ? -kInf : mc.lunif_0_100;
-    for (int k = 0; k < d.G; ++k) lp += norm_const_sd(S(k), mu, mc.c_sd10, 2 * 10.0 * 10.0);
+    lp += norm_const_sd(mu, mc.m0, mc.c0, mc.den0);
+    lp += (sigma < mc.ua || sigma > mc.ub) ? -kInf : mc.lunif;
+    for (int k = 0; k < d.G; ++k) lp += norm_const_sd(S(k), mu, mc.c1, mc.den1);
     return lp;
   }
   __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &mc, const DataRef &d,
@@ -151,7 +153,7 @@ struct PoisGlmModel {
   __device__ static void stage(unsigned char *, const DataRef &, int, int) {}
   __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &) {
     double lp = 0;
-    for (int k = 0; k < 8; ++k) lp += norm_const_sd(S(k), 0, mc.c_sd10, 2 * 10.0 * 10.0);
+    for (int k = 0; k < 8; ++k) lp += norm_const_sd(S(k), mc.m0, mc.c0, mc.den0);
     const double cp = S(8);
     lp += (cp < 0 || cp > mc.cp_upper) ? -kInf : mc.lunif_cp;
     return lp;

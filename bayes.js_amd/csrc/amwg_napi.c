@@ -1,0 +1,455 @@
+/*
+ * amwg_napi.c -- Node N-API shim over the C ABI of include/amwg.h.
+ *
+ * This is the binding a bayes.js maintainer adds: the reference is pure JS
+ * with no FFI, so the JS front-end (bayes.js_amd/mcmc.js) keeps the AmwgSampler API
+ * (mcmc.js:1090-1099) and forwards to these functions.  Marshalling only: typed arrays in,
+ * typed arrays out, errors from amwg_last_error() rethrown as JS Errors.  All calls are
+ * synchronous on the single JS thread, like the reference.
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/amwg.h"
+
+#define NAPI_OK(call)                                                   \
+  do {                                                                  \
+    if ((call) != napi_ok) {                                            \
+      napi_throw_error(env, NULL, "amwg_napi: N-API call failed: " #call); \
+      return NULL;                                                      \
+    }                                                                   \
+  } while (0)
+
+static napi_value throw_amwg(napi_env env, int rc) {
+  char buf[600];
+  snprintf(buf, sizeof buf, "amwg error %d: %s", rc, amwg_last_error());
+  napi_throw_error(env, rc == AMWG_EHIP ? "AMWG_EHIP" : (rc == AMWG_ESIZE ? "AMWG_ESIZE" : "AMWG_EINVAL"), buf);
+  return NULL;
+}
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv) {
+  size_t argc = want;
+  if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+    napi_throw_type_error(env, NULL, "amwg_napi: wrong number of arguments");
+    return 0;
+  }
+  return 1;
+}
+
+static int prop(napi_env env, napi_value obj, const char *name, napi_value *out) {
+  bool has = false;
+  if (napi_has_named_property(env, obj, name, &has) != napi_ok || !has) return 0;
+  if (napi_get_named_property(env, obj, name, out) != napi_ok) return 0;
+  napi_valuetype t;
+  if (napi_typeof(env, *out, &t) != napi_ok || t == napi_undefined || t == napi_null) return 0;
+  return 1;
+}
+
+static double prop_double(napi_env env, napi_value obj, const char *name, double dflt) {
+  napi_value v;
+  double d = dflt;
+  if (prop(env, obj, name, &v)) napi_get_value_double(env, v, &d);
+  return d;
+}
+
+static int64_t prop_i64(napi_env env, napi_value obj, const char *name, int64_t dflt) {
+  napi_value v;
+  if (!prop(env, obj, name, &v)) return dflt;
+  double d = (double)dflt;
+  napi_valuetype t;
+  napi_typeof(env, v, &t);
+  if (t == napi_boolean) { bool b = false; napi_get_value_bool(env, v, &b); return b ? 1 : 0; }
+  napi_get_value_double(env, v, &d);
+  return (int64_t)d;
+}
+
+/* unsigned 64-bit from a JS number (exact below 2^53) or a BigInt */
+static uint64_t prop_u64(napi_env env, napi_value obj, const char *name, uint64_t dflt) {
+  napi_value v;
+  if (!prop(env, obj, name, &v)) return dflt;
+  napi_valuetype t;
+  napi_typeof(env, v, &t);
+  if (t == napi_bigint) {
+    uint64_t u = dflt;
+    bool lossless = true;
+    napi_get_value_bigint_uint64(env, v, &u, &lossless);
+    return u;
+  }
+  double d = 0;
+  napi_get_value_double(env, v, &d);
+  return d <= 0 ? 0 : (uint64_t)d;
+}
+
+static void *typed_data(napi_env env, napi_value v, napi_typedarray_type want, size_t *len) {
+  bool is = false;
+  if (napi_is_typedarray(env, v, &is) != napi_ok || !is) return NULL;
+  napi_typedarray_type t;
+  void *data = NULL;
+  napi_value ab;
+  size_t off;
+  if (napi_get_typedarray_info(env, v, &t, len, &data, &ab, &off) != napi_ok || t != want) return NULL;
+  return data;
+}
+
+static napi_value new_f64(napi_env env, size_t n, double **data) {
+  napi_value ab, ta;
+  void *p = NULL;
+  if (napi_create_arraybuffer(env, n * 8, &p, &ab) != napi_ok) return NULL;
+  if (napi_create_typedarray(env, napi_float64_array, n, ab, 0, &ta) != napi_ok) return NULL;
+  *data = (double *)p;
+  return ta;
+}
+
+static napi_value new_i32(napi_env env, size_t n, int32_t **data) {
+  napi_value ab, ta;
+  void *p = NULL;
+  if (napi_create_arraybuffer(env, n * 4, &p, &ab) != napi_ok) return NULL;
+  if (napi_create_typedarray(env, napi_int32_array, n, ab, 0, &ta) != napi_ok) return NULL;
+  *data = (int32_t *)p;
+  return ta;
+}
+
+static void finalize_sampler(napi_env env, void *data, void *hint) {
+  (void)env; (void)hint;
+  amwg_sampler **box = (amwg_sampler **)data;
+  if (box) { if (*box) amwg_destroy(*box); free(box); }
+}
+
+static amwg_sampler *unwrap(napi_env env, napi_value v) {
+  amwg_sampler **box = NULL;
+  if (napi_get_value_external(env, v, (void **)&box) != napi_ok || !box || !*box) {
+    napi_throw_error(env, NULL, "amwg_napi: sampler handle is closed or invalid");
+    return NULL;
+  }
+  return *box;
+}
+
+/* create(model, params[], init Float64Array, compOpts[], options) -> external handle */
+static napi_value Create(napi_env env, napi_callback_info info) {
+  napi_value a[5];
+  if (!get_args(env, info, 5, a)) return NULL;
+  amwg_model_desc md;
+  memset(&md, 0, sizeof md);
+  md.model = (int32_t)prop_i64(env, a[0], "model", 0);
+  md.n_obs = (int32_t)prop_i64(env, a[0], "n_obs", 0);
+  md.G = (int32_t)prop_i64(env, a[0], "G", 0);
+  md.K = (int32_t)prop_i64(env, a[0], "K", 0);
+  napi_value v;
+  size_t n = 0;
+  if (prop(env, a[0], "x", &v)) md.x = (const double *)typed_data(env, v, napi_float64_array, &n);
+  if (prop(env, a[0], "y", &v)) md.y = (const double *)typed_data(env, v, napi_float64_array, &n);
+  if (prop(env, a[0], "g", &v)) md.g = (const int32_t *)typed_data(env, v, napi_int32_array, &n);
+  if (prop(env, a[0], "hyper", &v)) {
+    const double *h = (const double *)typed_data(env, v, napi_float64_array, &n);
+    for (size_t i = 0; h && i < n && i < 8; i++) md.hyper[i] = h[i];
+  }
+  uint32_t n_params = 0, n_comp = 0;
+  NAPI_OK(napi_get_array_length(env, a[1], &n_params));
+  NAPI_OK(napi_get_array_length(env, a[3], &n_comp));
+  size_t n_init = 0;
+  const double *init = (const double *)typed_data(env, a[2], napi_float64_array, &n_init);
+  if (!init || n_init != n_comp || n_params < 1) {
+    napi_throw_type_error(env, NULL, "amwg_napi.create: init must be a Float64Array with one value per component");
+    return NULL;
+  }
+  amwg_param_desc *pd = (amwg_param_desc *)calloc(n_params, sizeof *pd);
+  amwg_comp_opt *co = (amwg_comp_opt *)calloc(n_comp, sizeof *co);
+  for (uint32_t i = 0; i < n_params; i++) {
+    napi_value e;
+    napi_get_element(env, a[1], i, &e);
+    pd[i].type = (int32_t)prop_i64(env, e, "type", 0);
+    pd[i].len = (int32_t)prop_i64(env, e, "len", 1);
+    pd[i].top = (int32_t)prop_i64(env, e, "top", 1);
+    pd[i].multidim = (int32_t)prop_i64(env, e, "multidim", 0);
+    pd[i].lower = prop_double(env, e, "lower", -1.0 / 0.0);
+    pd[i].upper = prop_double(env, e, "upper", 1.0 / 0.0);
+  }
+  for (uint32_t i = 0; i < n_comp; i++) {
+    napi_value e;
+    napi_get_element(env, a[3], i, &e);
+    co[i].prop_log_scale = prop_double(env, e, "prop_log_scale", 0.0);
+    co[i].max_adaptation = prop_double(env, e, "max_adaptation", 0.33);
+    co[i].initial_adaptation = prop_double(env, e, "initial_adaptation", 1.0);
+    co[i].target_accept_rate = prop_double(env, e, "target_accept_rate", 0.44);
+    co[i].batch_size = (int32_t)prop_i64(env, e, "batch_size", 50);
+    co[i].is_adapting = (int32_t)prop_i64(env, e, "is_adapting", 1);
+  }
+  amwg_options op;
+  memset(&op, 0, sizeof op);
+  op.chains = prop_i64(env, a[4], "chains", 1);
+  op.seed = prop_u64(env, a[4], "seed", 0);
+  op.chain_offset = prop_u64(env, a[4], "chain_offset", 0);
+  op.device = (int32_t)prop_i64(env, a[4], "device", 0);
+  op.lanes_per_chain = (int32_t)prop_i64(env, a[4], "lanes_per_chain", 0);
+  op.block_threads = (int32_t)prop_i64(env, a[4], "block_threads", 0);
+  op.steps_per_launch = (int32_t)prop_i64(env, a[4], "steps_per_launch", 0);
+  op.exact_division = (int32_t)prop_i64(env, a[4], "exact_division", 0);
+  amwg_sampler *s = NULL;
+  int rc = amwg_create(&md, pd, (int32_t)n_params, init, co, &op, &s);
+  free(pd);
+  free(co);
+  if (rc != AMWG_OK) return throw_amwg(env, rc);
+  amwg_sampler **box = (amwg_sampler **)malloc(sizeof *box);
+  *box = s;
+  napi_value ext;
+  if (napi_create_external(env, box, finalize_sampler, NULL, &ext) != napi_ok) {
+    amwg_destroy(s);
+    free(box);
+    napi_throw_error(env, NULL, "amwg_napi: napi_create_external failed");
+    return NULL;
+  }
+  return ext;
+}
+
+static napi_value Destroy(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  amwg_sampler **box = NULL;
+  if (napi_get_value_external(env, a[0], (void **)&box) == napi_ok && box && *box) {
+    amwg_destroy(*box);
+    *box = NULL;
+  }
+  return NULL;
+}
+
+static int64_t arg_i64(napi_env env, napi_value v) {
+  double d = 0;
+  napi_get_value_double(env, v, &d);
+  return (int64_t)d;
+}
+
+static napi_value Burn(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  int rc = amwg_burn(s, arg_i64(env, a[1]));
+  return rc == AMWG_OK ? NULL : throw_amwg(env, rc);
+}
+
+static napi_value BurnAsync(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  int rc = amwg_burn_async(s, arg_i64(env, a[1]));
+  return rc == AMWG_OK ? NULL : throw_amwg(env, rc);
+}
+
+static napi_value Sync(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  int rc = amwg_sync(s);
+  return rc == AMWG_OK ? NULL : throw_amwg(env, rc);
+}
+
+static napi_value SampleAsync(napi_env env, napi_callback_info info) {
+  napi_value a[3];
+  if (!get_args(env, info, 3, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  int rc = amwg_sample_async(s, arg_i64(env, a[1]), arg_i64(env, a[2]));
+  return rc == AMWG_OK ? NULL : throw_amwg(env, rc);
+}
+
+/* fetchDraws(handle, rows) -> Float64Array [rows][P][chains] */
+static napi_value FetchDraws(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  const int64_t rows = arg_i64(env, a[1]);
+  const size_t n = (size_t)rows * (size_t)amwg_num_components(s) * (size_t)amwg_num_chains(s);
+  double *data = NULL;
+  napi_value out = new_f64(env, n, &data);
+  if (!out) { napi_throw_error(env, NULL, "amwg_napi: cannot allocate the draws array"); return NULL; }
+  int rc = amwg_fetch_draws(s, data, n * 8);
+  return rc == AMWG_OK ? out : throw_amwg(env, rc);
+}
+
+/* sample(handle, n, thin) -> Float64Array [ceil(n/thin)][P][chains] */
+static napi_value Sample(napi_env env, napi_callback_info info) {
+  napi_value a[3];
+  if (!get_args(env, info, 3, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  const int64_t nsteps = arg_i64(env, a[1]), thin = arg_i64(env, a[2]);
+  if (nsteps < 0 || thin < 1) { napi_throw_range_error(env, NULL, "amwg_napi.sample: n >= 0 and thin >= 1 required"); return NULL; }
+  const int64_t rows = (nsteps + thin - 1) / thin;
+  const size_t n = (size_t)rows * (size_t)amwg_num_components(s) * (size_t)amwg_num_chains(s);
+  double *data = NULL;
+  napi_value out = new_f64(env, n, &data);
+  if (!out) { napi_throw_error(env, NULL, "amwg_napi: cannot allocate the draws array"); return NULL; }
+  int rc = amwg_sample(s, nsteps, thin, data, n * 8);
+  return rc == AMWG_OK ? out : throw_amwg(env, rc);
+}
+
+static napi_value SetAdapting(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  bool flag = false;
+  napi_coerce_to_bool(env, a[1], &a[1]);
+  napi_get_value_bool(env, a[1], &flag);
+  int rc = amwg_set_adapting(s, flag ? 1 : 0);
+  return rc == AMWG_OK ? NULL : throw_amwg(env, rc);
+}
+
+static napi_value GetState(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  const size_t n = (size_t)amwg_num_components(s) * (size_t)amwg_num_chains(s);
+  double *data = NULL;
+  napi_value out = new_f64(env, n, &data);
+  if (!out) return NULL;
+  int rc = amwg_get_state(s, data, n * 8);
+  return rc == AMWG_OK ? out : throw_amwg(env, rc);
+}
+
+static napi_value Info(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  const size_t n = (size_t)amwg_num_components(s) * (size_t)amwg_num_chains(s);
+  double *pls, *accd, *inbd;
+  int32_t *ac, *it, *bc;
+  napi_value vpls = new_f64(env, n, &pls), vac = new_i32(env, n, &ac), vit = new_i32(env, n, &it), vbc = new_i32(env, n, &bc);
+  napi_value vacc = new_f64(env, n, &accd), vinb = new_f64(env, n, &inbd);
+  if (!vpls || !vac || !vit || !vbc || !vacc || !vinb) return NULL;
+  int64_t *acc = (int64_t *)malloc(n * 8 + 8), *inb = (int64_t *)malloc(n * 8 + 8);
+  int rc = amwg_info(s, pls, ac, it, bc, acc, inb);
+  if (rc == AMWG_OK) for (size_t i = 0; i < n; i++) { accd[i] = (double)acc[i]; inbd[i] = (double)inb[i]; }
+  free(acc);
+  free(inb);
+  if (rc != AMWG_OK) return throw_amwg(env, rc);
+  napi_value o;
+  NAPI_OK(napi_create_object(env, &o));
+  napi_set_named_property(env, o, "prop_log_scale", vpls);
+  napi_set_named_property(env, o, "acceptance_count", vac);
+  napi_set_named_property(env, o, "iterations_since_adaption", vit);
+  napi_set_named_property(env, o, "batch_count", vbc);
+  napi_set_named_property(env, o, "accepts", vacc);
+  napi_set_named_property(env, o, "inbounds", vinb);
+  return o;
+}
+
+static napi_value Diag(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  const size_t C = (size_t)amwg_num_chains(s);
+  const size_t np = (size_t)arg_i64(env, a[1]);
+  double *un, *lp;
+  int32_t *ord;
+  napi_value vun = new_f64(env, C, &un), vlp = new_f64(env, C, &lp), vord = new_i32(env, C * np, &ord);
+  if (!vun || !vlp || !vord) return NULL;
+  uint64_t *u = (uint64_t *)malloc(C * 8 + 8);
+  int rc = amwg_chain_diag(s, u, lp, ord);
+  if (rc == AMWG_OK) for (size_t i = 0; i < C; i++) un[i] = (double)u[i];
+  free(u);
+  if (rc != AMWG_OK) return throw_amwg(env, rc);
+  napi_value o;
+  NAPI_OK(napi_create_object(env, &o));
+  napi_set_named_property(env, o, "uniforms", vun);
+  napi_set_named_property(env, o, "log_post", vlp);
+  napi_set_named_property(env, o, "named_order", vord);
+  return o;
+}
+
+static napi_value Moments(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  const size_t P = (size_t)amwg_num_components(s);
+  double *m, *sd;
+  napi_value vm = new_f64(env, P, &m), vsd = new_f64(env, P, &sd);
+  if (!vm || !vsd) return NULL;
+  int rc = amwg_last_sample_moments(s, m, sd);
+  if (rc != AMWG_OK) return throw_amwg(env, rc);
+  napi_value o;
+  NAPI_OK(napi_create_object(env, &o));
+  napi_set_named_property(env, o, "mean", vm);
+  napi_set_named_property(env, o, "sd", vsd);
+  return o;
+}
+
+static napi_value LaunchInfo(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  int32_t v[5];
+  double ms = 0;
+  int rc = amwg_launch_info(s, &v[0], &v[1], &v[2], &v[3], &v[4], &ms);
+  if (rc != AMWG_OK) return throw_amwg(env, rc);
+  static const char *names[5] = {"lanes_per_chain", "block_threads", "grid_blocks", "lds_bytes", "n_launches"};
+  napi_value o, t;
+  NAPI_OK(napi_create_object(env, &o));
+  for (int i = 0; i < 5; i++) { napi_create_int32(env, v[i], &t); napi_set_named_property(env, o, names[i], t); }
+  napi_create_double(env, ms, &t);
+  napi_set_named_property(env, o, "kernel_ms", t);
+  return o;
+}
+
+static napi_value Version(napi_env env, napi_callback_info info) {
+  (void)info;
+  napi_value v;
+  NAPI_OK(napi_create_string_utf8(env, amwg_version(), NAPI_AUTO_LENGTH, &v));
+  return v;
+}
+
+static napi_value MathExp(napi_env env, napi_callback_info info) {
+  napi_value a[1], r;
+  if (!get_args(env, info, 1, a)) return NULL;
+  double x = 0;
+  napi_get_value_double(env, a[0], &x);
+  NAPI_OK(napi_create_double(env, amwg_exp(x), &r));
+  return r;
+}
+
+static napi_value MathLog(napi_env env, napi_callback_info info) {
+  napi_value a[1], r;
+  if (!get_args(env, info, 1, a)) return NULL;
+  double x = 0;
+  napi_get_value_double(env, a[0], &x);
+  NAPI_OK(napi_create_double(env, amwg_log(x), &r));
+  return r;
+}
+
+static napi_value Uniform(napi_env env, napi_callback_info info) {
+  napi_value a[3], r;
+  if (!get_args(env, info, 3, a)) return NULL;
+  double s = 0, c = 0, i = 0;
+  napi_get_value_double(env, a[0], &s);
+  napi_get_value_double(env, a[1], &c);
+  napi_get_value_double(env, a[2], &i);
+  NAPI_OK(napi_create_double(env, amwg_uniform((uint64_t)s, (uint64_t)c, (uint64_t)i), &r));
+  return r;
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+  static const struct { const char *name; napi_callback fn; } fns[] = {
+      {"create", Create}, {"destroy", Destroy}, {"burn", Burn}, {"burnAsync", BurnAsync}, {"sync", Sync},
+      {"sample", Sample}, {"sampleAsync", SampleAsync}, {"fetchDraws", FetchDraws}, {"setAdapting", SetAdapting},
+      {"getState", GetState}, {"info", Info}, {"diag", Diag}, {"moments", Moments}, {"launchInfo", LaunchInfo},
+      {"version", Version}, {"mathExp", MathExp}, {"mathLog", MathLog}, {"uniform", Uniform}};
+  for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
+    napi_value f;
+    if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
+    if (napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) return NULL;
+  }
+  return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

@@ -24,11 +24,16 @@ struct ParamLayout {
 // log_v8 the kernel uses (so the roundings are those of the reference's expression trees).
 struct ModelConsts {
   double neg_half_log_2pi;          // -0.5*log(2*pi)
-  double c_sd100, c_sd10;           // (-0.5*log(2*pi)) - log(100 | 10)
-  double lunif_0_100;               // log(1/(100-0))
-  double lunif_cp;                  // log(1/((N-1)-0))
-  double cp_upper;                  // N-1
-  double lbeta_2_2;                 // lbeta(2,2)
+  // prior of the location parameter:  ld.norm(v, m0, s0) = c0 - (v-m0)^2 / den0
+  double m0, c0, den0;
+  // prior of the scale parameter:     ld.unif(v, ua, ub)
+  double ua, ub, lunif;
+  // second-level normal prior with constant sd tau (HIER: theta_g ~ norm(mu, tau)): c1 - (v-mu)^2 / den1
+  double c1, den1;
+  // ld.beta(theta, ba, bb)
+  double ba, bb, lbeta_ab;
+  // ld.unif(cp, 0, N-1)
+  double cp_upper, lunif_cp;
   int32_t data_mid_range;           // every data value is 0 or within 2^-200..2^200 in magnitude
   int32_t exact_division;           // 1 = always use IEEE '/'
 };

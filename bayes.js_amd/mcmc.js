@@ -1,0 +1,322 @@
+'use strict';
+/*
+ * mcmc.js -- JavaScript front-end of the MI355X many-chain AMWG sampler.
+ *
+ * Keeps the user-facing surface of the reference's sampler (SURVEY.md §8b):
+ *     new mcmc.AmwgSampler(params, log_post, data, options)     mcmc.js:1090-1099, 940-966
+ *     .burn(n) .sample(n) .step() .thin(k) .monitor(names)      mcmc.js:1035, 1005, 985, 1053, 1045
+ *     .start_adaptation() .stop_adaptation() .info() .state     mcmc.js:1060-1073, 977, 964
+ *     mcmc.complete_params, mcmc.param_init_fixed               mcmc.js:357-403, 313-341
+ * and runs the stepping on the GPU through the N-API shim (csrc/amwg_napi.c) over the C ABI
+ * (include/amwg.h).  There is no JavaScript stepping path here: if the addon or a GPU is
+ * missing, construction throws.
+ *
+ * What is new relative to the reference (all optional):
+ *     options.chains   number of independent chains (default 1)
+ *     options.seed     Philox key, number or BigInt (default: drawn from Math.random, like an unseeded run)
+ *     options.devices  HIP device ordinals to shard the chains over (default [0])
+ *     options.lanes_per_chain / block_threads / steps_per_launch / exact_division  -> amwg_options
+ * With chains === 1 every return value has the reference's shape.  With chains > 1 each
+ * monitored parameter is a Float64Array laid out [draw][element][chain] with a non-enumerable
+ * `.layout = {kept, len, chains, dim}`.
+ */
+const path = require('path');
+const models = require('./models.js');
+const ld = require('./ld.js');
+
+let nativeCache = null;
+function native() {
+  if (!nativeCache) {
+    try {
+      nativeCache = require(path.join(__dirname, 'csrc', 'amwg_napi.node'));
+    } catch (e) {
+      throw 'AmwgSampler (MI355X): the native addon csrc/amwg_napi.node could not be loaded (' + e.message +
+            '); build it with `make -C bayes.js_amd/csrc`. There is no JavaScript fallback.';
+    }
+  }
+  return nativeCache;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Parameter completion.  Semantics of mcmc.js:313-341 and :357-403, pinned by the reference's
+// only deterministic test (tests/test_mcmc_js.R:39-46 with tests/test_data.js:9-74).
+function param_init_fixed(type, lower, upper) {
+  if (lower > upper) throw 'Can not initialize parameter where lower bound > upper bound';
+  const noLo = lower === -Infinity, noHi = upper === Infinity;
+  if (type === 'real') {
+    if (noLo && noHi) return 0.5;
+    if (noLo) return upper - 0.5;
+    if (noHi) return lower + 0.5;
+    if (lower <= upper) return (lower + upper) / 2;
+  } else if (type === 'int') {
+    if (noLo && noHi) return 1;
+    if (noLo) return upper - 1;
+    if (noHi) return lower + 1;
+    if (lower <= upper) return Math.round((lower + upper) / 2);
+  } else if (type === 'binary') {
+    return 1;
+  }
+  throw 'Could not initialize parameter of type ' + type + '[' + lower + ', ' + upper + ']';
+}
+
+function cloneSpec(v) {                     // params are deep-copied, functions kept by reference (mcmc.js:358)
+  if (Array.isArray(v)) return v.map(cloneSpec);
+  if (v && typeof v === 'object') { const o = {}; for (const k of Object.keys(v)) o[k] = cloneSpec(v[k]); return o; }
+  return v;
+}
+function filled(dim, init) {                // nested array of shape dim; a function is called once per element
+  if (dim.length === 0) throw "create_array can't create a dimensionless array";
+  const out = new Array(dim[0]);
+  for (let i = 0; i < dim[0]; i++) out[i] = dim.length === 1 ? (typeof init === 'function' ? init() : init) : filled(dim.slice(1), init);
+  return out;
+}
+function shapeOf(a) { return Array.isArray(a[0]) ? [a.length].concat(shapeOf(a[0])) : [a.length]; }
+function sameShape(a, b) { return a.length === b.length && a.every((v, i) => v == b[i]); }
+const isScalarDim = (dim) => sameShape(dim, [1]);
+
+function complete_params(params_to_complete, param_init) {
+  const params = cloneSpec(params_to_complete);
+  for (const name of Object.keys(params)) {
+    const p = params[name];
+    if (!p.hasOwnProperty('type')) p.type = 'real';
+    if (!p.hasOwnProperty('dim')) p.dim = [1];
+    if (typeof p.dim === 'number') p.dim = [p.dim];
+    if (p.type == 'binary') { p.upper = 1; p.lower = 0; }
+    if (!p.hasOwnProperty('upper')) p.upper = Infinity;
+    if (!p.hasOwnProperty('lower')) p.lower = -Infinity;
+    if (p.hasOwnProperty('init')) {
+      if (isScalarDim(p.dim) && typeof p.init === 'function') p.init = p.init();
+      else if (!isScalarDim(p.dim) && !Array.isArray(p.init)) p.init = filled(p.dim, p.init);
+    } else if (isScalarDim(p.dim)) {
+      p.init = param_init(p.type, p.lower, p.upper);
+    } else {
+      p.init = filled(p.dim, () => param_init(p.type, p.lower, p.upper));
+    }
+  }
+  return params;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stepper options.  AmwgStepper merges per-parameter and global options with `||`
+// (mcmc.js:869-878: falsy overrides such as 0 or false are ignored -- kept, it is observable),
+// then each stepper applies defaults with get_option (mcmc.js:280-285, 500-505); multi-
+// dimensional parameters accept a scalar or an array of exactly the parameter's shape
+// (mcmc.js:293-303, 644-649).
+const OPTION_DEFAULTS = { prop_log_scale: 0, batch_size: 50, max_adaptation: 0.33, initial_adaptation: 1.0,
+  target_accept_rate: 0.44, is_adapting: true };
+const OPTION_KEYS = Object.keys(OPTION_DEFAULTS);
+
+function flatten(v, out) { if (Array.isArray(v)) v.forEach((e) => flatten(e, out)); else out.push(v); return out; }
+
+function componentOptions(name, param, options) {
+  options = options || {};
+  const own = (options.params && options.params[name]) || {};
+  const len = param.dim.reduce((a, b) => a * b, 1);
+  const perKey = {};
+  for (const key of OPTION_KEYS) {
+    const merged = own[key] || options[key];
+    let v = (merged !== undefined && merged !== null) ? merged : OPTION_DEFAULTS[key];
+    if (isScalarDim(param.dim)) {
+      perKey[key] = [v];
+    } else {
+      if (!Array.isArray(v)) v = filled(param.dim, v);
+      if (!sameShape(shapeOf(v), param.dim))
+        throw 'The option ' + key + ' is of dimension [' + shapeOf(v) + '] but should be [' + param.dim + '].';
+      perKey[key] = flatten(v, []);
+    }
+  }
+  const out = [];
+  for (let e = 0; e < len; e++) {
+    const o = {};
+    for (const key of OPTION_KEYS) o[key] = perKey[key][e];
+    out.push(o);
+  }
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+function toF64(a) { return a instanceof Float64Array ? a : Float64Array.from(a); }
+
+function buildModelDesc(recog, data) {
+  const parts = recog.extract(data);
+  const family = recog.family;
+  const hyper = new Float64Array(8);
+  recog.hyper.forEach((v, i) => { hyper[i] = v; });
+  const desc = { model: models.FAMILY_ID[family], hyper, G: 0, K: 0 };
+  if (family === 'pois_glm') {
+    desc.y = toF64(parts.y); desc.n_obs = desc.y.length; desc.K = 7; desc.x = toF64(parts.x);
+    if (desc.x.length !== desc.n_obs * 7) throw 'pois_glm: data.X must hold N x 7 values';
+  } else {
+    if (parts.x === undefined || parts.x === null) throw 'AmwgSampler (MI355X): the data argument does not contain the observations the model loops over';
+    desc.x = toF64(parts.x); desc.n_obs = desc.x.length;
+    if (family === 'hier_normal') { desc.g = Int32Array.from(parts.g); desc.G = parts.G; }
+  }
+  return desc;
+}
+
+function nest(flat, offset, dim) {          // row-major flat values -> nested array of shape dim
+  if (dim.length === 1) return Array.prototype.slice.call(flat, offset, offset + dim[0]);
+  const inner = dim.slice(1).reduce((a, b) => a * b, 1), out = [];
+  for (let i = 0; i < dim[0]; i++) out.push(nest(flat, offset + i * inner, dim.slice(1)));
+  return out;
+}
+
+function AmwgSampler(params, log_post, data, options) {
+  options = options || {};
+  const opt = (k, d) => (options.hasOwnProperty(k) && options[k] !== undefined && options[k] !== null) ? options[k] : d;
+  this.param_names = Object.keys(params);
+  this.param_init_fun = opt('param_init_fun', param_init_fixed);
+  this.thin(opt('thin', 1));
+  this.monitor(opt('monitor', null));
+  this.options = options;
+  this.data = data;
+  this.params = complete_params(params, this.param_init_fun);
+
+  const recog = models.recognise(log_post);
+  if (!recog)
+    throw 'AmwgSampler (MI355X): log_post is not a model this GPU sampler can run. Write it in the README pattern ' +
+          '(priors, then one for-loop over the data adding one ld.* term per observation; Normal and beta-Bernoulli ' +
+          'are recognised from source) or build it with mcmc.models.normal/beta_bern/hier_normal/pois_glm.';
+  this.model = recog.family;
+  if (recog.paramNames && recog.paramNames.join() !== this.param_names.join())
+    throw 'AmwgSampler (MI355X): the ' + recog.family + ' model expects params declared as {' + recog.paramNames.join(', ') +
+          '} (in that order), got {' + this.param_names.join(', ') + '}';
+
+  // flatten params / init / options in Object.keys order (the stepper order of mcmc.js:839)
+  const descs = [], init = [], compOpts = [];
+  this._layout = [];
+  let base = 0;
+  for (const name of this.param_names) {
+    const p = this.params[name];
+    if (p.type !== 'real' && p.type !== 'int')
+      throw "AmwgStepper can't handle parameter " + name + ' with type ' + p.type;   // message of mcmc.js:867 ("binary": SURVEY.md §8f)
+    const len = p.dim.reduce((a, b) => a * b, 1);
+    descs.push({ type: p.type === 'int' ? 1 : 0, len, top: p.dim[0], multidim: isScalarDim(p.dim) ? 0 : 1, lower: p.lower, upper: p.upper });
+    const flatInit = flatten(p.init, []);
+    if (flatInit.length !== len) throw 'parameter ' + name + ': init does not match dim [' + p.dim + ']';
+    flatInit.forEach((v) => init.push(v));
+    componentOptions(name, p, options).forEach((o) => compOpts.push(o));
+    this._layout.push({ name, base, len, dim: p.dim, scalar: isScalarDim(p.dim) });
+    base += len;
+  }
+  this.P = base;
+  this.chains = opt('chains', 1);
+  if (!(this.chains >= 1) || Math.floor(this.chains) !== this.chains) throw 'options.chains must be a positive integer';
+  this.seed = opt('seed', Math.floor(Math.random() * 9007199254740992));
+  const devices = opt('devices', [opt('device', 0)]);
+  const desc = buildModelDesc(recog, data);
+
+  // contiguous shards of global chain ids, one native sampler per device (SURVEY.md §8e)
+  const N = native();
+  this._shards = [];
+  const D = Math.min(devices.length, this.chains), per = Math.floor(this.chains / D), rem = this.chains % D;
+  let offset = 0;
+  for (let r = 0; r < D; r++) {
+    const count = per + (r < rem ? 1 : 0);
+    const handle = N.create(desc, descs, Float64Array.from(init), compOpts, {
+      chains: count, seed: this.seed, chain_offset: opt('chain_offset', 0) + offset, device: devices[r],
+      lanes_per_chain: opt('lanes_per_chain', 0), block_threads: opt('block_threads', 0),
+      steps_per_launch: opt('steps_per_launch', 0), exact_division: opt('exact_division', 0) });
+    this._shards.push({ handle, offset, count, device: devices[r] });
+    offset += count;
+  }
+  this.log_post = () => log_post(this.state, data);   // host evaluation at the current state of chain 0
+}
+
+AmwgSampler.prototype._each = function (f) { return this._shards.map(f); };
+
+AmwgSampler.prototype._merge = function (blocks, rows) {   // per-shard [rows][c_shard] -> [rows][chains]
+  if (blocks.length === 1) return blocks[0];
+  const out = new Float64Array(rows * this.chains);
+  this._shards.forEach((sh, k) => {
+    for (let r = 0; r < rows; r++) out.set(blocks[k].subarray(r * sh.count, (r + 1) * sh.count), r * this.chains + sh.offset);
+  });
+  return out;
+};
+
+AmwgSampler.prototype.burn = function (n_iterations) {
+  const N = native();
+  this._each((sh) => N.burnAsync(sh.handle, n_iterations));
+  this._each((sh) => N.sync(sh.handle));
+};
+
+AmwgSampler.prototype.step = function () { this.burn(1); return this.state; };
+
+AmwgSampler.prototype.sample = function (n_iterations) {
+  const N = native(), thin = this.thinning_interval;
+  const kept = Math.ceil(n_iterations / thin);
+  this._each((sh) => N.sampleAsync(sh.handle, n_iterations, thin));
+  const flat = this._merge(this._each((sh) => N.fetchDraws(sh.handle, kept)), kept * this.P);   // [kept][P][chains]
+  const monitored = this.monitored_params === null ? this.param_names : this.monitored_params;
+  const C = this.chains, P = this.P, out = {};
+  for (const name of monitored) {
+    const L = this._layout.find((l) => l.name === name);
+    if (!L) { out[name] = []; continue; }
+    if (C === 1) {                          // reference shape (mcmc.js:1015-1029): one entry per kept draw
+      const draws = new Array(kept);
+      for (let t = 0; t < kept; t++) draws[t] = L.scalar ? flat[t * P + L.base] : nest(flat, t * P + L.base, L.dim);
+      out[name] = draws;
+    } else {
+      const arr = new Float64Array(kept * L.len * C);
+      for (let t = 0; t < kept; t++) arr.set(flat.subarray((t * P + L.base) * C, (t * P + L.base + L.len) * C), t * L.len * C);
+      Object.defineProperty(arr, 'layout', { value: { kept, len: L.len, chains: C, dim: L.dim }, enumerable: false });
+      out[name] = arr;
+    }
+  }
+  return out;
+};
+
+Object.defineProperty(AmwgSampler.prototype, 'state', {
+  get: function () {
+    const N = native(), C = this.chains;
+    const flat = this._merge(this._each((sh) => N.getState(sh.handle)), this.P);   // [P][chains]
+    const st = {};
+    for (const L of this._layout) {
+      if (C === 1) st[L.name] = L.scalar ? flat[L.base] : nest(flat, L.base, L.dim);
+      else st[L.name] = flat.subarray(L.base * C, (L.base + L.len) * C);
+    }
+    return st;
+  },
+});
+
+AmwgSampler.prototype.monitor = function (params_to_monitor) { this.monitored_params = params_to_monitor; };
+AmwgSampler.prototype.thin = function (thinning_interval) { this.thinning_interval = thinning_interval; };
+AmwgSampler.prototype.start_adaptation = function () { const N = native(); this._each((sh) => N.setAdapting(sh.handle, true)); this._adapting = true; };
+AmwgSampler.prototype.stop_adaptation = function () { const N = native(); this._each((sh) => N.setAdapting(sh.handle, false)); this._adapting = false; };
+
+/** Per-parameter stepper state (the content of mcmc.js:563-571), plus run totals.  chains === 1:
+ *  plain numbers / nested arrays as in the reference; otherwise typed arrays [element][chain]. */
+AmwgSampler.prototype.info = function () {
+  const N = native(), C = this.chains;
+  const per = this._each((sh) => N.info(sh.handle));
+  const keys = ['prop_log_scale', 'acceptance_count', 'iterations_since_adaption', 'batch_count', 'accepts', 'inbounds'];
+  const merged = {};
+  for (const k of keys) {
+    if (per.length === 1) { merged[k] = per[0][k]; continue; }
+    const out = new (per[0][k].constructor)(this.P * C);
+    this._shards.forEach((sh, s) => { for (let p = 0; p < this.P; p++) out.set(per[s][k].subarray(p * sh.count, (p + 1) * sh.count), p * C + sh.offset); });
+    merged[k] = out;
+  }
+  const steppers = {};
+  for (const L of this._layout) {
+    const one = (e) => { const o = {}; for (const k of keys) o[k] = merged[k][(L.base + e) * C]; return o; };
+    if (C === 1) steppers[L.name] = L.scalar ? one(0) : nest(Array.from({ length: L.len }, (_, e) => one(e)), 0, L.dim);
+    else { const o = {}; for (const k of keys) o[k] = merged[k].subarray(L.base * C, (L.base + L.len) * C); steppers[L.name] = o; }
+  }
+  return { state: this.state, thin: this.thinning_interval, monitor: this.monitored_params, steppers,
+           launch: this._each((sh) => Object.assign({ device: sh.device, chains: sh.count }, N.launchInfo(sh.handle))) };
+};
+
+/** Posterior mean / sd per scalar component over all chains x kept draws of the last sample() (device-side reduction, single shard). */
+AmwgSampler.prototype.moments = function () {
+  const N = native();
+  if (this._shards.length !== 1) throw 'moments(): only available on a single-device sampler';
+  const m = N.moments(this._shards[0].handle), out = {};
+  for (const L of this._layout) out[L.name] = { mean: Array.from(m.mean.subarray(L.base, L.base + L.len)), sd: Array.from(m.sd.subarray(L.base, L.base + L.len)) };
+  return out;
+};
+
+AmwgSampler.prototype.diagnostics = function () { const N = native(); return this._each((sh) => N.diag(sh.handle, this.param_names.length)); };
+AmwgSampler.prototype.close = function () { const N = native(); this._each((sh) => N.destroy(sh.handle)); this._shards = []; };
+
+module.exports = { AmwgSampler, complete_params, param_init_fixed, componentOptions, models, ld, native };

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- the AMWG hot path on N MI355X, measured the way BASELINE.json asks.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[1] -- Normal(mu, sigma) model, 1e4 synthetic
+observations (SURVEY.md §8d recipe), 65 536 chains PER GPU (weak scaling; chain ids are global, so
+rank r runs chains [r*65536, (r+1)*65536) of one logical job).  A "step" is one Sampler.step()
+(mcmc.js:985-997) of every chain = P = 2 parameter updates per chain.  W untimed steps, then EXACTLY
+K steps timed between barrier + synchronize pairs; K steps are one sample() call = one kernel launch
+that also records every `--thin`-th draw into HBM, followed for N > 1 by the RCCL gather of the
+recorded draws to rank 0 (the "gather at sample collection" of north_star).  Inputs are resident in
+HBM before the timed region; the D2H copy of draws is outside it (see DESIGN.md for the PCIe-inclusive rate).
+
+value = (chains on all GPUs) * K * P / max-over-ranks seconds  [param-updates/s]
+roofline.achieved = algorithmic bytes of one launch / HIP-event duration of that launch, where one
+    param-update streams the data vector once: 80 024 B -- an EFFECTIVE bandwidth:
+    the vector is LDS-resident and re-read from LDS, so it may exceed the HBM peak by design.
+cpu_baseline = the C oracle (reference's algorithm, one pass per update, 1 thread) on the same data.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes.js_amd"), os.path.join(ROOT, "tests")]
+
+import numpy as np  # noqa: E402
+
+N_OBS = 10_000
+CHAINS_PER_GPU = 65_536
+SEED = 20260925
+DATA_SEED = 20260925
+B_ALG_PER_UPDATE = N_OBS * 8 + 8 * 2 + 8     # 80 024 B: data once + state read + draw write
+HBM_PEAK_GBPS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK = 78.6e12 / 2                 # lane-FMA/s: 256 CU * 4 SIMD * 16 lanes/clk * 2.4 GHz
+
+
+def normal_spec():
+    import synth
+    data = synth.normal(N_OBS, DATA_SEED)
+    opt = {"prop_log_scale": 0.0, "batch_size": 50, "max_adaptation": 0.33, "initial_adaptation": 1.0,
+           "target_accept_rate": 0.44, "is_adapting": True}                     # mcmc.js:500-505
+    inf = float("inf")
+    params = [  # complete_params() of {mu:{type:"real"}, sigma:{type:"real", lower:0}} (README.md:22-24)
+        {"type": "real", "len": 1, "top": 1, "multidim": 0, "lower": -inf, "upper": inf, "init": [0.5]},
+        {"type": "real", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": inf, "init": [0.5]}]
+    return {"model": "normal", "n_obs": N_OBS, "data": data, "params": params, "P": 2, "init": [0.5, 0.5],
+            "comp_opts": [dict(opt), dict(opt)], "G": 0, "K": 0}
+
+
+def cpu_baseline(spec, budget_s=12.0):
+    """The oracle (a C port of the reference algorithm), single thread, same data, 1 chain."""
+    import oracle_lib
+    ch = oracle_lib.OracleChain(spec, SEED, 0, lanes=1)
+    ch.burn(1000)                       # adapted, steady state
+    t0 = time.perf_counter()
+    ch.burn(500)
+    rate = 500 / (time.perf_counter() - t0)
+    n = max(500, int(rate * budget_s))
+    t0 = time.perf_counter()
+    ch.burn(n)
+    dt = time.perf_counter() - t0
+    return {"value": n * spec["P"] / dt, "unit": "param-updates/s", "cores": 1, "kind": "port",
+            "sample": "oracle/amwg_oracle.c, same model+data (N=%d), 1 chain, %d steps after 1000 burn-in (%.1f s); "
+                      "the unmodified JS reference measured 3.3e4-3.45e4 on the build container (BASELINE.md §2)" % (N_OBS, n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=1000)
+    ap.add_argument("--thin", type=int, default=10, help="record every thin-th draw inside the timed region")
+    ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
+    ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import amwg_ctypes as A
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from shard import chain_shard, gather_draws
+    spec = normal_spec()
+    chains = args.chains_per_gpu
+    offset, _ = chain_shard(rank, world, chains * world)
+    s = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=local_rank,
+                  lanes_per_chain=args.lanes, block_threads=args.block)
+    P, K, W, thin = spec["P"], args.steps, args.warmup, max(1, args.thin)
+    rows = -(-K // thin)
+    draws = torch.empty((rows, P, chains), dtype=torch.float64, device="cuda")
+    gathered = [torch.empty_like(draws) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if W > 0:
+        s.burn(W)
+    barrier()
+    t0 = time.perf_counter()
+    s.sample_device(K, thin, draws.data_ptr(), draws.numel() * 8)
+    s.sync()
+    if dist is not None:
+        gather_draws(dist, draws, gathered, rank)
+    barrier()
+    dt = time.perf_counter() - t0
+    li = s.launch_info()
+    if dist is not None:
+        t = torch.tensor([dt, li["kernel_ms"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, kernel_ms = float(t[0]), float(t[1])
+    else:
+        kernel_ms = li["kernel_ms"]
+
+    if rank == 0:
+        total_chains = chains * world
+        value = total_chains * K * P / dt
+        launches = max(1, li["n_launches"])
+        launch_s = kernel_ms * 1e-3 / launches
+        updates_per_launch = chains * (K / launches) * P
+        achieved = updates_per_launch * B_ALG_PER_UPDATE / launch_s / 1e9
+        mean, sd = s.moments()
+        x = spec["data"]["x"]
+        out = {
+            "metric": "posterior draws/sec (= param-updates/sec)", "value": value, "unit": "param-updates/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt * 1e3 / K, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: Normal(mu,sigma) AMWG, 1e4 synthetic obs, 65536 chains per GPU",
+                       "n_obs": N_OBS, "chains_per_gpu": chains, "chains_total": total_chains, "components": P,
+                       "draws_recorded_per_chain": rows, "thin": thin, "lanes_per_chain": li["lanes_per_chain"],
+                       "block_threads": li["block_threads"], "grid_blocks": li["grid_blocks"], "lds_bytes": li["lds_bytes"],
+                       "gather": "rccl gather of recorded draws to rank 0" if world > 1 else "none (1 GPU)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "amwg_step_kernel<NormalModel,%d>" % li["lanes_per_chain"],
+                         "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_update": B_ALG_PER_UPDATE,
+                         "note": "effective bandwidth: the 80 KB data vector is staged once per launch into LDS and "
+                                 "re-read from LDS, so HBM traffic is ~0 and frac may exceed 1; the binding limit is fp64 VALU "
+                                 "(see fp64_valu)",
+                         "fp64_valu": {"lane_ops_per_obs": 9, "achieved_lane_ops_per_s": updates_per_launch * N_OBS * 9 / launch_s,
+                                       "peak_lane_ops_per_s": FP64_VALU_PEAK,
+                                       "frac": updates_per_launch * N_OBS * 9 / launch_s / FP64_VALU_PEAK}},
+            "kernel_only_value": chains * K * P / (kernel_ms * 1e-3),
+            "posterior": {"mean": mean.tolist(), "sd": sd.tolist(), "data_mean": float(np.mean(x)), "data_sd": float(np.std(x, ddof=1)),
+                          "note": "moments over all recorded draws of rank 0 (after %d warm-up steps)" % W},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec)
+            out["chains_equiv"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    s.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,12 @@ typedef struct {
   const int32_t *g;  /* HIER_NORMAL: group index of observation i, 0 <= g_i < G; otherwise NULL */
   int32_t G;         /* HIER_NORMAL: number of groups (= len of the first param) */
   int32_t K;         /* POIS_GLM: number of real columns (7) */
+  /* Prior hyper-parameters (the numeric literals of the user's closure):
+   *   NORMAL      {m0, s0, a, b}        mu ~ norm(m0,s0); sigma ~ unif(a,b)              default {0,100,0,100}
+   *   BETA_BERN   {a, b}                theta ~ beta(a,b)                                default {2,2}
+   *   HIER_NORMAL {m0, s0, a, b, tau}   mu ~ norm(m0,s0); sigma ~ unif(a,b); theta_g ~ norm(mu,tau)   default {0,100,0,100,10}
+   *   POIS_GLM    {m, s}                beta_k ~ norm(m,s); cp ~ unif(0,N-1)             default {0,10} */
+  double hyper[8];
 } amwg_model_desc;
 
 typedef struct {
@@ -101,13 +107,21 @@ typedef struct amwg_sampler amwg_sampler;
 int amwg_create(const amwg_model_desc *model, const amwg_param_desc *params, int32_t n_params, const double *init,
                 const amwg_comp_opt *comp_opts, const amwg_options *options, amwg_sampler **out);
 
-/* Replaces sampler.burn(n) (mcmc.js:1035-1039). */
+/* Replaces sampler.burn(n) (mcmc.js:1035-1039).  amwg_burn blocks until the steps are done;
+ * amwg_burn_async only enqueues them on the sampler's stream (pair with amwg_sync), which is how
+ * one host thread keeps several GPUs busy. */
 int amwg_burn(amwg_sampler *s, int64_t n);
+int amwg_burn_async(amwg_sampler *s, int64_t n);
 
 /* Replaces sampler.sample(n) with thinning interval `thin` (mcmc.js:1005-1030, 1053-1055):
  * draw k is the state BEFORE step k*thin.  out_draws (host) receives ceil(n/thin) * P * chains
  * doubles laid out [draw][component][chain]; out_bytes is its capacity. */
 int amwg_sample(amwg_sampler *s, int64_t n, int64_t thin, double *out_draws, size_t out_bytes);
+
+/* Two-phase form of amwg_sample for multi-GPU hosts: enqueue the steps into a library-owned
+ * device buffer, then (after doing the same on the other devices) copy the draws out. */
+int amwg_sample_async(amwg_sampler *s, int64_t n, int64_t thin);
+int amwg_fetch_draws(amwg_sampler *s, double *out_draws, size_t out_bytes);
 
 /* Same, but the destination is DEVICE memory owned by the caller (e.g. a buffer that is then
  * gathered across GPUs with RCCL); no host copy is made.  Asynchronous on the sampler's stream

@@ -36,6 +36,7 @@ typedef struct {
   const double *y;   /* pois_glm: counts y[N] */
   const int32_t *g;  /* hier_normal: group of obs i */
   int32_t G, K;
+  double hyper[8];   /* prior hyper-parameters, same meaning as amwg_model_desc.hyper */
 } orc_data;
 
 typedef struct orc_chain orc_chain;
@@ -56,6 +57,7 @@ void orc_get_info(const orc_chain *c, double *prop_log_scale, int32_t *acceptanc
                   int32_t *batch_count, int64_t *accepts, int64_t *inbounds /* each P, may be NULL */);
 uint64_t orc_uniforms_used(const orc_chain *c);
 double orc_log_post(orc_chain *c);
+double orc_log_post_unhoisted(orc_chain *c); /* same value, every ld.* call spelled out per observation */
 void orc_named_order(const orc_chain *c, int32_t *order /*n_params*/);
 
 /* exposed pieces, pinned individually by tests */

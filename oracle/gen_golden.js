@@ -26,6 +26,17 @@ const CASES = [
     options: { batch_size: 10, target_accept_rate: 0.3, max_adaptation: 0.5, prop_log_scale: -1, params: { mu: { max_adaptation: 0.1 } } },
     seed: SEED + 1, chains: [0, 9],
     schedule: [{ op: 'burn', n: 105 }, { op: 'stop' }, { op: 'sample', n: 50 }, { op: 'start' }, { op: 'sample', n: 100, thin: 7 }] },
+  // non-default prior hyper-parameters (amwg_model_desc.hyper)
+  { name: 'normal_hyper', model: 'normal', N: 150, data_seed: DSEED + 2, store_data: true, hyper: [2.5, 7, 0.5, 30],
+    seed: SEED + 2, chains: [0, 4], schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 100 }] },
+  { name: 'beta_bern_hyper', model: 'beta_bern', N: 300, data_seed: DSEED + 3, store_data: true, hyper: [1, 1],
+    seed: SEED + 3, chains: [0], schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 100 }] },
+  { name: 'beta_bern_hyper2', model: 'beta_bern', N: 300, data_seed: DSEED + 3, store_data: true, hyper: [0.5, 3.5],
+    seed: SEED + 3, chains: [1], schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 100 }] },
+  { name: 'hier_hyper', model: 'hier_normal', N: 300, G: 5, data_seed: DSEED + 4, store_data: true, hyper: [4, 20, 0, 50, 3],
+    seed: SEED + 4, chains: [0], schedule: [{ op: 'burn', n: 100 }, { op: 'sample', n: 60 }] },
+  { name: 'glm_hyper', model: 'pois_glm', N: 200, data_seed: DSEED + 5, store_data: true, hyper: [0.1, 2],
+    seed: SEED + 5, chains: [0], schedule: [{ op: 'burn', n: 80 }, { op: 'sample', n: 40 }] },
   { name: 'beta_bern_n2000', model: 'beta_bern', N: 2000, data_seed: DSEED, store_data: true,
     seed: SEED, chains: [0, 1, 2], schedule: [{ op: 'burn', n: 400 }, { op: 'sample', n: 400, keep: 100 }] },
   { name: 'cfg3_full', model: 'beta_bern', N: 100000, data_seed: DSEED,

@@ -20,7 +20,8 @@ const mcmc = require(path.join(REF_DIR, 'mcmc.js'));
 const ld = require(path.join(REF_DIR, 'distributions.js'));
 const { stream } = require('./philox.js');
 const synth = require('./synth.js');
-const models = require('./ref_models.js')(ld);
+const makeModels = require('./ref_models.js');
+const models = makeModels(ld);
 
 function makeData(c) {
   switch (c.model) {
@@ -45,7 +46,7 @@ function runChain(c, data, chain) {
   const saved = Math.random;
   Math.random = rand;
   try {
-    const m = models[c.model];
+    const m = (c.hyper ? makeModels(ld, { [c.model]: c.hyper }) : models)[c.model];
     const params = m.params(data);
     const sampler = new mcmc.AmwgSampler(params, m.log_post, data, c.options);
     const names = Object.keys(params);

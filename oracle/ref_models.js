@@ -6,15 +6,19 @@
  * reference's own `ld` object.  ref_harness.js feeds these to the UNMODIFIED
  * reference sampler; the registry ids are the ones include/amwg.h exposes.
  */
-module.exports = function (ld) {
+const DEFAULT_HYPER = { normal: [0, 100, 0, 100], beta_bern: [2, 2], hier_normal: [0, 100, 0, 100, 10], pois_glm: [0, 10] };
+
+module.exports = function (ld, hyperOverride) {
+  const H = (m) => (hyperOverride && hyperOverride[m]) || DEFAULT_HYPER[m];
   return {
     // cfg1/cfg2 -- README.md:22-36
     normal: {
       params: () => ({ mu: { type: 'real' }, sigma: { type: 'real', lower: 0 } }),
       log_post: function (s, d) {
         let lp = 0;
-        lp += ld.norm(s.mu, 0, 100);
-        lp += ld.unif(s.sigma, 0, 100);
+        const h = H('normal');
+        lp += ld.norm(s.mu, h[0], h[1]);
+        lp += ld.unif(s.sigma, h[2], h[3]);
         for (let i = 0; i < d.x.length; i++) lp += ld.norm(d.x[i], s.mu, s.sigma);
         return lp;
       },
@@ -24,7 +28,8 @@ module.exports = function (ld) {
       params: () => ({ theta: { type: 'real', lower: 0, upper: 1 } }),
       log_post: function (s, d) {
         let lp = 0;
-        lp += ld.beta(s.theta, 2, 2);
+        const h = H('beta_bern');
+        lp += ld.beta(s.theta, h[0], h[1]);
         const n = d.x.length;
         for (let i = 0; i < n; i++) lp += ld.bern(d.x[i], s.theta);
         return lp;
@@ -35,9 +40,10 @@ module.exports = function (ld) {
       params: (d) => ({ theta: { type: 'real', dim: [d.G] }, mu: { type: 'real' }, sigma: { type: 'real', lower: 0, init: 1 } }),
       log_post: function (s, d) {
         let lp = 0;
-        lp += ld.norm(s.mu, 0, 100);
-        lp += ld.unif(s.sigma, 0, 100);
-        for (let k = 0; k < d.G; k++) lp += ld.norm(s.theta[k], s.mu, 10);
+        const h = H('hier_normal');
+        lp += ld.norm(s.mu, h[0], h[1]);
+        lp += ld.unif(s.sigma, h[2], h[3]);
+        for (let k = 0; k < d.G; k++) lp += ld.norm(s.theta[k], s.mu, h[4]);
         for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], s.sigma);
         return lp;
       },
@@ -48,7 +54,8 @@ module.exports = function (ld) {
       log_post: function (s, d) {
         let lp = 0;
         const N = d.y.length, K = d.K;
-        for (let k = 0; k < 8; k++) lp += ld.norm(s.beta[k], 0, 10);
+        const h = H('pois_glm');
+        for (let k = 0; k < 8; k++) lp += ld.norm(s.beta[k], h[0], h[1]);
         lp += ld.unif(s.cp, 0, N - 1);
         for (let i = 0; i < N; i++) {
           let eta = 0;

@@ -1,0 +1,129 @@
+'use strict';
+// Host-logic tests of the JS front-end (no GPU): parameter completion KATs, option merging,
+// model recognition, error behaviour.  Expected values are the reference's: the completion
+// KATs restate tests/test_data.js:9-74 (checked by tests/test_mcmc_js.R:39-46); option
+// merging is compared with what the reference's steppers held in tests/golden/normal_opts.json;
+// when /root/reference is present everything is ALSO compared with the live reference.
+const assert = require('assert');
+const fs = require('fs');
+const path = require('path');
+const { mcmc, ld, models } = require('../../bayes.js_amd');
+
+const REF = process.env.AMWG_REF_DIR || '/root/reference';
+const haveRef = fs.existsSync(path.join(REF, 'mcmc.js'));
+const ref = haveRef ? require(path.join(REF, 'mcmc.js')) : null;
+const refld = haveRef ? require(path.join(REF, 'distributions.js')) : null;
+
+// ---- complete_params KATs
+const params1 = { mu: { type: 'real' }, sigma: { type: 'real', lower: 0, init: 1 } };
+const params1_completed = { mu: { type: 'real', dim: [1], upper: Infinity, lower: -Infinity, init: 0.5 },
+  sigma: { type: 'real', dim: [1], upper: Infinity, lower: 0, init: 1 } };
+const params2 = { theta: { init: function () { return 1.5; } }, state: { type: 'binary', init: 1 },
+  mat: { type: 'int', dim: [3, 3], init: function () { return 2; } } };
+const params2_completed = { theta: { type: 'real', dim: [1], upper: Infinity, lower: -Infinity, init: 1.5 },
+  state: { type: 'binary', init: 1, dim: [1], upper: 1, lower: 0 },
+  mat: { type: 'int', dim: [3, 3], upper: Infinity, lower: -Infinity, init: [[2, 2, 2], [2, 2, 2], [2, 2, 2]] } };
+assert.deepStrictEqual(mcmc.complete_params(params1, mcmc.param_init_fixed), params1_completed);
+assert.deepStrictEqual(mcmc.complete_params(params2, mcmc.param_init_fixed), params2_completed);
+assert.strictEqual(params1.mu.dim, undefined, 'input must not be modified');
+const more = { a: { lower: 2 }, b: { upper: -1 }, c: { lower: 0, upper: 5 }, d: { type: 'int' }, e: { type: 'int', lower: 3 },
+  f: { type: 'int', upper: 9 }, g: { type: 'int', lower: 0, upper: 9 }, h: { dim: 4, lower: 1 }, i: { dim: [2, 2], init: 7 } };
+const moreDone = mcmc.complete_params(more, mcmc.param_init_fixed);
+assert.deepStrictEqual([moreDone.a.init, moreDone.b.init, moreDone.c.init, moreDone.d.init, moreDone.e.init, moreDone.f.init, moreDone.g.init],
+  [2.5, -1.5, 2.5, 1, 4, 8, 5]);
+assert.deepStrictEqual(moreDone.h.init, [1.5, 1.5, 1.5, 1.5]);
+assert.deepStrictEqual(moreDone.h.dim, [4]);
+assert.deepStrictEqual(moreDone.i.init, [[7, 7], [7, 7]]);
+assert.throws(() => mcmc.param_init_fixed('real', 3, 1), (e) => e === 'Can not initialize parameter where lower bound > upper bound');
+if (haveRef) {
+  for (const p of [params1, params2, more]) assert.deepStrictEqual(mcmc.complete_params(p, mcmc.param_init_fixed), ref.complete_params(p, ref.param_init_fixed));
+}
+
+// ---- option merging (mcmc.js:869-878 `||` semantics + defaults of :500-505)
+const gold = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'golden', 'normal_opts.json'), 'utf8'));
+const done = mcmc.complete_params({ mu: { type: 'real' }, sigma: { type: 'real', lower: 0 } }, mcmc.param_init_fixed);
+const merged = [].concat(mcmc.componentOptions('mu', done.mu, gold.case.options), mcmc.componentOptions('sigma', done.sigma, gold.case.options));
+assert.deepStrictEqual(merged, gold.chains[0].comp_opts);
+// falsy per-parameter overrides are ignored (0 || global, false || global); a falsy GLOBAL value survives
+const quirk = mcmc.componentOptions('mu', done.mu, { prop_log_scale: 2, is_adapting: true, params: { mu: { prop_log_scale: 0, is_adapting: false } } });
+assert.strictEqual(quirk[0].prop_log_scale, 2);
+assert.strictEqual(quirk[0].is_adapting, true);
+assert.strictEqual(mcmc.componentOptions('mu', done.mu, { is_adapting: false })[0].is_adapting, false);
+// multidimensional: scalar broadcast, array of the right shape, wrong shape throws the reference's message
+const md = mcmc.complete_params({ b: { dim: [2, 2] } }, mcmc.param_init_fixed).b;
+assert.deepStrictEqual(mcmc.componentOptions('b', md, { batch_size: 10 }).map((o) => o.batch_size), [10, 10, 10, 10]);
+assert.deepStrictEqual(mcmc.componentOptions('b', md, { params: { b: { target_accept_rate: [[0.1, 0.2], [0.3, 0.4]] } } }).map((o) => o.target_accept_rate), [0.1, 0.2, 0.3, 0.4]);
+assert.throws(() => mcmc.componentOptions('b', md, { params: { b: { batch_size: [1, 2, 3] } } }),
+  (e) => e === 'The option batch_size is of dimension [3] but should be [2,2].');
+if (haveRef) {   // same merge as the live reference's steppers
+  const opts = { batch_size: 10, max_adaptation: 0.5, params: { x: { max_adaptation: 0.1, prop_log_scale: [[1, 2], [3, 4]] } } };
+  const st = { x: [[0, 0], [0, 0]], y: 1 };
+  const prm = ref.complete_params({ x: { dim: [2, 2] }, y: {} }, ref.param_init_fixed);
+  const stp = new ref.AmwgStepper(prm, st, () => 0, JSON.parse(JSON.stringify(opts)));
+  const flat = []; stp.substeppers[0].substeppers.forEach((r) => r.forEach((s) => flat.push(s))); flat.push(stp.substeppers[1]);
+  const want = flat.map((s) => ({ prop_log_scale: s.prop_log_scale, batch_size: s.batch_size, max_adaptation: s.max_adaptation,
+    initial_adaptation: s.initial_adaptation, target_accept_rate: s.target_accept_rate, is_adapting: s.is_adapting }));
+  const mine = mcmc.complete_params({ x: { dim: [2, 2] }, y: {} }, mcmc.param_init_fixed);
+  assert.deepStrictEqual([].concat(mcmc.componentOptions('x', mine.x, opts), mcmc.componentOptions('y', mine.y, opts)), want);
+}
+
+// ---- host ld.* equals the reference's outputs (SURVEY.md Appendix B7)
+assert.strictEqual(ld.norm(183, 184.4, 4.9), -2.5489900648518664);
+assert.strictEqual(ld.unif(5, 0, 100), -4.605170185988091);
+assert.strictEqual(ld.pois(3, 10), -4.884004190245918);
+assert.strictEqual(ld.beta(0.3, 2, 2), 0.23111172096338728);
+assert.strictEqual(ld.bern(1, 0.3), -1.2039728043259361);
+if (haveRef) for (const x of [0.1, 0.5, 3, 7.25]) {
+  assert.strictEqual(ld.norm(x, 1, 2), refld.norm(x, 1, 2)); assert.strictEqual(ld.pois(Math.floor(x), 2.5), refld.pois(Math.floor(x), 2.5));
+  assert.strictEqual(ld.beta(x / 8, 2, 3), refld.beta(x / 8, 2, 3)); assert.strictEqual(ld.lgamma(x), refld.lgamma(x));
+}
+
+// ---- model recognition: the README closures verbatim (README.md:26-36, 150-163)
+global.ld = ld;
+const readme_normal = function(state, data) {
+  var log_post = 0;
+  // Priors
+  log_post += ld.norm(state.mu, 0, 100);
+  log_post += ld.unif(state.sigma, 0, 100);
+  // Likelihood
+  for(var i = 0; i < data.length; i++) {
+    log_post += ld.norm(data[i], state.mu, state.sigma);
+  }
+  return log_post;
+};
+const readme_bern = function(state, data) {
+  var log_post = 0;
+  log_post += ld.beta(state.theta, 2, 2);
+  var n = data.x.length;
+  for(var i = 0; i < n; i++) {
+    log_post += ld.bern(data.x[i], state.theta)
+  }
+  return log_post;
+}
+let r = models.recognise(readme_normal);
+assert.deepStrictEqual([r.family, r.hyper, r.paramNames], ['normal', [0, 100, 0, 100], ['mu', 'sigma']]);
+assert.deepStrictEqual(r.extract([1, 2, 3]), { x: [1, 2, 3] });
+r = models.recognise(readme_bern);
+assert.deepStrictEqual([r.family, r.hyper, r.paramNames], ['beta_bern', [2, 2], ['theta']]);
+r = models.recognise((s, d) => { let lp = 0; lp += ld.norm(s.m, -2.5, 7); lp += ld.unif(s.s, 0.5, 30); for (let i = 0; i < d.obs.length; i++) lp += ld.norm(d.obs[i], s.m, s.s); return lp; });
+assert.deepStrictEqual([r.family, r.hyper, r.paramNames], ['normal', [-2.5, 7, 0.5, 30], ['m', 's']]);
+for (const bad of [function (s, d) { return Math.sin(s.x); },
+  function (s, d) { var lp = 0; for (var i = 0; i < d.length; i++) { lp += ld.norm(d[i], s.mu, s.sigma); } lp += ld.norm(s.mu, 0, 100); lp += ld.unif(s.sigma, 0, 100); return lp; },  // priors after the loop: different summation order
+  function (s, d) { var lp = 0; lp += ld.norm(s.mu, 0, 100); lp += ld.unif(s.sigma, 0, 100); for (var i = 0; i < d.length; i++) { lp += ld.norm(d[i], s.mu, 2 * s.sigma); } return lp; }])
+  assert.strictEqual(models.recognise(bad), null);
+// descriptor closures evaluate like the README closure on the host
+const data10 = [183, 192, 182, 183, 177, 185, 188, 188, 182, 185];
+assert.strictEqual(models.normal()({ mu: 180, sigma: 5 }, data10), readme_normal({ mu: 180, sigma: 5 }, data10));
+
+// ---- errors (thrown as strings, like the reference) before any device is touched
+const params = { mu: { type: 'real' }, sigma: { type: 'real', lower: 0 } };
+assert.throws(() => new mcmc.AmwgSampler(params, (s, d) => 0, data10), (e) => typeof e === 'string' && /not a model this GPU sampler can run/.test(e));
+assert.throws(() => new mcmc.AmwgSampler({ sigma: { lower: 0 }, mu: {} }, readme_normal, data10), (e) => typeof e === 'string' && /expects params declared as/.test(e));
+assert.throws(() => new mcmc.AmwgSampler({ mu: { type: 'binary' }, sigma: {} }, readme_normal, data10), (e) => e === "AmwgStepper can't handle parameter mu with type binary");
+// the addon loads and, without a GPU, construction fails loudly (no JS fallback)
+const nat = mcmc.native();
+assert.ok(/gfx950/.test(nat.version()));
+assert.strictEqual(nat.mathExp(1), Math.exp(1));
+assert.strictEqual(nat.mathLog(0.3), Math.log(0.3));
+if (!fs.existsSync('/dev/kfd')) assert.throws(() => new mcmc.AmwgSampler(params, readme_normal, data10, { seed: 1 }), (e) => /no HIP device/.test(e.message));
+console.log('frontend ok' + (haveRef ? ' (also checked against the live reference)' : ''));

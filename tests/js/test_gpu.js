@@ -1,0 +1,132 @@
+'use strict';
+// GPU tests of the JS front-end through the N-API addon: the README programs run unchanged
+// and reproduce the seeded reference runs stored in tests/golden/ bit for bit.
+const assert = require('assert');
+const fs = require('fs');
+const path = require('path');
+const { mcmc, ld, models } = require('../../bayes.js_amd');
+global.ld = ld;
+
+function golden(name) {
+  const untag = (k, v) => (v === '__inf' ? Infinity : v === '__-inf' ? -Infinity : v === '__nan' ? NaN : v);
+  return JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'golden', name + '.json'), 'utf8'), untag);
+}
+const flat = (v) => { const o = []; (function r(x) { Array.isArray(x) ? x.forEach(r) : o.push(x); })(v); return o; };
+
+function checkAgainstGolden(name, makeSampler, names) {
+  const g = golden(name);
+  for (const rec of g.chains) {
+    const s = makeSampler(g, rec);
+    const segs = [];
+    for (const seg of g.case.schedule) {
+      if (seg.op === 'burn') assert.strictEqual(s.burn(seg.n), undefined);
+      else if (seg.op === 'stop') s.stop_adaptation();
+      else if (seg.op === 'start') s.start_adaptation();
+      else { if (seg.thin) s.thin(seg.thin); segs.push(s.sample(seg.n)); }
+    }
+    segs.forEach((smp, k) => {
+      const want = rec.samples[k];
+      assert.deepStrictEqual(Object.keys(smp), names);
+      assert.strictEqual(smp[names[0]].length, want.kept);
+      want.draws.forEach((row, t) => { let got = []; for (const nm of names) got = got.concat(flat(smp[nm][t])); assert.deepStrictEqual(got, row); });
+      const sum = new Array(want.sum.length).fill(0);
+      for (let t = 0; t < want.kept; t++) { let j = 0; for (const nm of names) for (const v of flat(smp[nm][t])) sum[j++] += v; }
+      assert.deepStrictEqual(sum, want.sum);
+    });
+    let st = []; for (const nm of names) st = st.concat(flat(s.state[nm]));
+    assert.deepStrictEqual(st, rec.final_state);
+    const inf = s.info();
+    let pls = []; for (const nm of names) pls = pls.concat(flat(inf.steppers[nm]).map((o) => o.prop_log_scale));
+    assert.deepStrictEqual(pls, rec.prop_log_scale);
+    let acc = []; for (const nm of names) acc = acc.concat(flat(inf.steppers[nm]).map((o) => o.accepts));
+    assert.deepStrictEqual(acc, rec.accepts);
+    assert.strictEqual(s.diagnostics()[0].uniforms[0], rec.uniforms);
+    assert.strictEqual(s.log_post(), rec.log_post);          // host closure at the final state == reference's value
+    s.close();
+  }
+}
+
+// ---- 1. README.md:18-43, verbatim -------------------------------------------------------------
+{
+  // The heights of the last ten American presidents in cm, from Kennedy to Obama
+  var data = [183, 192, 182, 183, 177, 185, 188, 188, 182, 185];
+  var params = {
+    mu: {type: "real"},
+    sigma: {type: "real", lower: 0} };
+  var log_post = function(state, data) {
+    var log_post = 0;
+    // Priors
+    log_post += ld.norm(state.mu, 0, 100);
+    log_post += ld.unif(state.sigma, 0, 100);
+    // Likelihood
+    for(var i = 0; i < data.length; i++) {
+      log_post += ld.norm(data[i], state.mu, state.sigma);
+    }
+    return log_post;
+  };
+  checkAgainstGolden('cfg1_heights', (g, rec) => new mcmc.AmwgSampler(params, log_post, data,
+    { seed: g.case.seed, chain_offset: rec.chain, lanes_per_chain: 1 }), ['mu', 'sigma']);
+  // options plumbing end to end: global + per-parameter stepper options, stop/start, thin
+  checkAgainstGolden('normal_opts', (g, rec) => new mcmc.AmwgSampler(params, log_post, g.data.x,
+    Object.assign({ seed: g.case.seed, chain_offset: rec.chain, lanes_per_chain: 1 }, g.case.options)), ['mu', 'sigma']);
+  // unseeded construction works and two unseeded samplers differ, like the reference
+  var a = new mcmc.AmwgSampler(params, log_post, data), b = new mcmc.AmwgSampler(params, log_post, data);
+  a.burn(50); b.burn(50);
+  assert.notDeepStrictEqual(a.state, b.state);
+  a.close(); b.close();
+}
+
+// ---- 2. README.md:149-164 beta-Bernoulli, verbatim ----------------------------------------------
+{
+  var log_post = function(state, data) {
+    // Start by defining a variable to hold the log posterior initialized to 0
+    var log_post = 0;
+    log_post += ld.beta(state.theta, 2, 2);
+    var n = data.x.length;
+    for(var i = 0; i < n; i++) {
+      log_post += ld.bern(data.x[i], state.theta)
+    }
+    return log_post;
+  }
+  checkAgainstGolden('beta_bern_n2000', (g, rec) => new mcmc.AmwgSampler({ theta: { type: 'real', lower: 0, upper: 1 } }, log_post,
+    { x: g.data.x }, { seed: g.case.seed, chain_offset: rec.chain, lanes_per_chain: 1 }), ['theta']);
+}
+
+// ---- 3. descriptor models: multidimensional draws come back as nested arrays ----------------------
+checkAgainstGolden('hier_small', (g, rec) => new mcmc.AmwgSampler(
+  { theta: { type: 'real', dim: [g.data.G] }, mu: { type: 'real' }, sigma: { type: 'real', lower: 0, init: 1 } },
+  models.hier_normal(), { y: g.data.y, g: g.data.g, G: g.data.G }, { seed: g.case.seed, chain_offset: rec.chain, lanes_per_chain: 1 }),
+  ['theta', 'mu', 'sigma']);
+checkAgainstGolden('glm_small', (g, rec) => new mcmc.AmwgSampler(
+  { beta: { type: 'real', dim: [8], init: 0 }, cp: { type: 'int', lower: 0, upper: g.data.y.length - 1 } },
+  models.pois_glm(), { X: g.data.X, y: g.data.y }, { seed: g.case.seed, chain_offset: rec.chain, lanes_per_chain: 1 }), ['beta', 'cp']);
+
+// ---- 4. many chains, thinning, monitor, sharding over "devices" -------------------------------------
+{
+  const g = golden('normal_n1000');
+  const params = { mu: {}, sigma: { lower: 0 } };
+  const mk = (extra) => new mcmc.AmwgSampler(params, models.normal(), g.data.x, Object.assign({ seed: 77, chains: 96, lanes_per_chain: 4 }, extra));
+  const one = mk({}), two = mk({ devices: [0, 0, 0] });           // three shards on one GPU == one shard
+  one.burn(60); two.burn(60);
+  one.thin(4); two.thin(4);
+  const s1 = one.sample(30), s2 = two.sample(30);
+  assert.ok(s1.mu instanceof Float64Array);
+  assert.deepStrictEqual(s1.mu.layout, { kept: 8, len: 1, chains: 96, dim: [1] });
+  assert.deepStrictEqual(Array.from(s1.mu), Array.from(s2.mu));
+  assert.deepStrictEqual(Array.from(s1.sigma), Array.from(s2.sigma));
+  assert.deepStrictEqual(Array.from(one.state.mu), Array.from(two.state.mu));
+  assert.deepStrictEqual(Array.from(one.info().steppers.sigma.prop_log_scale), Array.from(two.info().steppers.sigma.prop_log_scale));
+  // chain 7 of the many-chain run == a single-chain sampler with chain_offset 7 (reference-shaped output)
+  const solo = new mcmc.AmwgSampler(params, models.normal(), g.data.x, { seed: 77, chain_offset: 7, lanes_per_chain: 4, thin: 4 });
+  solo.burn(60);
+  const ss = solo.sample(30);
+  assert.ok(Array.isArray(ss.mu) && ss.mu.length === 8);
+  for (let t = 0; t < 8; t++) { assert.strictEqual(ss.mu[t], s1.mu[t * 96 + 7]); assert.strictEqual(ss.sigma[t], s1.sigma[t * 96 + 7]); }
+  one.monitor(['sigma']);
+  assert.deepStrictEqual(Object.keys(one.sample(3)), ['sigma']);
+  const m = one.moments();
+  assert.ok(Math.abs(m.sigma.mean[0] - 2) < 0.5 && m.sigma.sd[0] > 0);
+  assert.ok(typeof one.step().mu[0] === 'number');
+  one.close(); two.close(); solo.close();
+}
+console.log('gpu frontend ok');

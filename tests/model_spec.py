@@ -51,7 +51,7 @@ def default_params(model, n_obs, G=32):
     raise ValueError(model)
 
 
-def build_spec(model, data, params=None, comp_opts=None, G=None):
+def build_spec(model, data, params=None, comp_opts=None, G=None, hyper=None):
     n_obs = len(data["y"]) if model == "pois_glm" else len(data["x"])
     G = G if G is not None else data.get("G", 0)
     if params is None:
@@ -61,7 +61,7 @@ def build_spec(model, data, params=None, comp_opts=None, G=None):
     if comp_opts is None:
         comp_opts = [dict(DEFAULT_OPT) for _ in range(P)]
     return {"model": model, "n_obs": n_obs, "data": data, "params": params, "P": P, "init": init,
-            "comp_opts": comp_opts, "G": int(G or 0), "K": int(data.get("K", 0))}
+            "comp_opts": comp_opts, "G": int(G or 0), "K": int(data.get("K", 0)), "hyper": hyper}
 
 
 def spec_from_golden(gold, chain_rec=None):
@@ -84,4 +84,4 @@ def spec_from_golden(gold, chain_rec=None):
         dim = p["dim"]
         params.append({"type": p["type"], "len": int(np.prod(dim)), "top": int(dim[0]), "multidim": int(list(dim) != [1]),
                        "lower": float(p["lower"]), "upper": float(p["upper"]), "init": [float(v) for v in p["init"]]})
-    return build_spec(c["model"], data, params=params, comp_opts=rec["comp_opts"], G=data.get("G"))
+    return build_spec(c["model"], data, params=params, comp_opts=rec["comp_opts"], G=data.get("G"), hyper=c.get("hyper"))

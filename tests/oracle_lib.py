@@ -20,7 +20,10 @@ class OrcCompOpt(C.Structure):
 
 class OrcData(C.Structure):
     _fields_ = [("model", C.c_int32), ("n_obs", C.c_int32), ("x", C.POINTER(C.c_double)), ("y", C.POINTER(C.c_double)),
-                ("g", C.POINTER(C.c_int32)), ("G", C.c_int32), ("K", C.c_int32)]
+                ("g", C.POINTER(C.c_int32)), ("G", C.c_int32), ("K", C.c_int32), ("hyper", C.c_double * 8)]
+
+
+DEFAULT_HYPER = {"normal": [0, 100, 0, 100], "beta_bern": [2, 2], "hier_normal": [0, 100, 0, 100, 10], "pois_glm": [0, 10]}
 
 
 _lib = None
@@ -45,6 +48,8 @@ def lib():
         L.orc_uniforms_used.argtypes = [C.c_void_p]
         L.orc_log_post.restype = C.c_double
         L.orc_log_post.argtypes = [C.c_void_p]
+        L.orc_log_post_unhoisted.restype = C.c_double
+        L.orc_log_post_unhoisted.argtypes = [C.c_void_p]
         L.orc_named_order.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.orc_uniform.restype = C.c_double
         L.orc_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
@@ -87,6 +92,8 @@ class OracleChain:
             od.g = g.ctypes.data_as(C.POINTER(C.c_int32))
         od.G = spec.get("G", 0)
         od.K = spec.get("K", 0)
+        for i, v in enumerate(spec.get("hyper") or DEFAULT_HYPER[spec["model"]]):
+            od.hyper[i] = float(v)
         n = len(spec["params"])
         pa = (OrcParam * n)()
         for i, p in enumerate(spec["params"]):
@@ -149,6 +156,9 @@ class OracleChain:
 
     def log_post(self):
         return float(lib().orc_log_post(self.h))
+
+    def log_post_unhoisted(self):
+        return float(lib().orc_log_post_unhoisted(self.h))
 
     def named_order(self):
         o = np.empty(self.n_params, dtype=np.int32)

@@ -17,7 +17,7 @@ from gpu_util import assert_chain_equals_oracle, run_schedule
 pytestmark = pytest.mark.gpu
 
 GOLDEN_CASES = ["cfg1_heights", "normal_n1000", "cfg2_full", "normal_opts", "beta_bern_n2000", "cfg3_full", "hier_small",
-                "cfg4_full", "glm_small", "cfg5_full"]
+                "cfg4_full", "glm_small", "cfg5_full", "normal_hyper", "beta_bern_hyper", "beta_bern_hyper2", "hier_hyper", "glm_hyper"]
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)

@@ -15,7 +15,7 @@ import model_spec
 import oracle_lib
 
 CASES = ["cfg1_heights", "normal_n1000", "cfg2_full", "normal_opts", "beta_bern_n2000", "cfg3_full", "hier_small",
-         "cfg4_full", "glm_small", "cfg5_full"]
+         "cfg4_full", "glm_small", "cfg5_full", "normal_hyper", "beta_bern_hyper", "beta_bern_hyper2", "hier_hyper", "glm_hyper"]
 
 
 def run_schedule(chain, schedule):
@@ -66,6 +66,7 @@ def check_chain(gold, rec, lanes):
     if exact:
         assert ch.state().tolist() == rec["final_state"]
         assert ch.log_post() == rec["log_post"]
+        assert ch.log_post_unhoisted() == rec["log_post"]
     else:
         np.testing.assert_allclose(ch.state(), rec["final_state"], rtol=1e-11)
 
