@@ -425,11 +425,11 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   HIPB(hipMemset(ch.rng_n, 0, C * 8));
   HIPB(hipMemset(ch.lp_curr, 0, C * 8));
 
-  // ---- geometry + the constructor's warm-up log_post (mcmc.js:961-963) as a 0-step launch
+  // ---- geometry.  The constructor's warm-up log_post (mcmc.js:961-963) is folded into the first
+  // launch (StepArgs.init_lp); amwg_chain_diag forces it with a 0-step launch if asked earlier.
   const size_t max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
   TRYB(choose_geometry(s, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, max_lds));
   HIPB(hipFuncSetAttribute(reinterpret_cast<const void *>(s->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds));
-  TRYB(launch_steps(s, 0, 1, nullptr));
   HIPB(hipStreamSynchronize(s->stream));
   *out = s;
   return AMWG_OK;
@@ -569,6 +569,7 @@ int amwg_chain_diag(amwg_sampler *s, uint64_t *uniforms, double *log_post_out, i
   if (!s) return fail(AMWG_EINVAL, "amwg_chain_diag: null sampler");
   const size_t C = (size_t)s->C;
   HIP_TRY(hipSetDevice(s->device));
+  if (!s->lp_ready) { int rc = launch_steps(s, 0, 1, nullptr); if (rc != AMWG_OK) return rc; }
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (uniforms) HIP_TRY(hipMemcpy(uniforms, s->ch.rng_n, C * 8, hipMemcpyDeviceToHost));
   if (log_post_out) HIP_TRY(hipMemcpy(log_post_out, s->ch.lp_curr, C * 8, hipMemcpyDeviceToHost));

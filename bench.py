@@ -8,9 +8,9 @@ Workload (config.workload): BASELINE.json configs[1] -- Normal(mu, sigma) model,
 observations (SURVEY.md §8d recipe), 65 536 chains PER GPU (weak scaling; chain ids are global, so
 rank r runs chains [r*65536, (r+1)*65536) of one logical job).  A "step" is one Sampler.step()
 (mcmc.js:985-997) of every chain = P = 2 parameter updates per chain.  W untimed steps, then EXACTLY
-K steps timed between barrier + synchronize pairs; K steps are one sample() call = one kernel launch
-that also records every `--thin`-th draw into HBM, followed for N > 1 by the RCCL gather of the
-recorded draws to rank 0 (the "gather at sample collection" of north_star).  Inputs are resident in
+K steps timed between barrier + synchronize pairs; the K steps are one sample() call (chunked into
+kernel launches of --steps-per-launch steps) that also records every `--thin`-th draw into HBM,
+followed for N > 1 by the RCCL gather of the recorded draws to rank 0 (the "gather at sample collection" of north_star).  Inputs are resident in
 HBM before the timed region; the D2H copy of draws is outside it (see DESIGN.md for the PCIe-inclusive rate).
 
 value = (chains on all GPUs) * K * P / max-over-ranks seconds  [param-updates/s]
@@ -52,6 +52,20 @@ def normal_spec():
             "comp_opts": [dict(opt), dict(opt)], "G": 0, "K": 0}
 
 
+def measured_traffic(chains, steps_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_summary.json, written by
+    tools/profile.sh + tools/summarize_profile.py for this same command); None if no matching profile."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+        try:
+            p = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if p.get("chains") == chains and p.get("steps_per_launch") == steps_per_launch and p.get("hbm_traffic_bytes_per_launch"):
+            return p["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
+
+
 def cpu_baseline(spec, budget_s=12.0):
     """The oracle (a C port of the reference algorithm), single thread, same data, 1 chain."""
     import oracle_lib
@@ -78,6 +92,9 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--steps-per-launch", type=int, default=100,
+                    help="steps fused into one kernel launch; warm-up and timed steps use the same launch size so the "
+                         "per-launch time bench.py reports is comparable with rocprofv3's per-kernel average")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -105,7 +122,7 @@ def main():
     chains = args.chains_per_gpu
     offset, _ = chain_shard(rank, world, chains * world)
     s = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=local_rank,
-                  lanes_per_chain=args.lanes, block_threads=args.block)
+                  lanes_per_chain=args.lanes, block_threads=args.block, steps_per_launch=args.steps_per_launch)
     P, K, W, thin = spec["P"], args.steps, args.warmup, max(1, args.thin)
     rows = -(-K // thin)
     draws = torch.empty((rows, P, chains), dtype=torch.float64, device="cuda")
@@ -144,6 +161,7 @@ def main():
         achieved = updates_per_launch * B_ALG_PER_UPDATE / launch_s / 1e9
         mean, sd = s.moments()
         x = spec["data"]["x"]
+        traffic, traffic_src = measured_traffic(chains, args.steps_per_launch)
         out = {
             "metric": "posterior draws/sec (= param-updates/sec)", "value": value, "unit": "param-updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt * 1e3 / K, "higher_is_better": True,
@@ -152,9 +170,12 @@ def main():
                        "n_obs": N_OBS, "chains_per_gpu": chains, "chains_total": total_chains, "components": P,
                        "draws_recorded_per_chain": rows, "thin": thin, "lanes_per_chain": li["lanes_per_chain"],
                        "block_threads": li["block_threads"], "grid_blocks": li["grid_blocks"], "lds_bytes": li["lds_bytes"],
+                       "steps_per_launch": args.steps_per_launch, "launches_timed": launches,
                        "gather": "rccl gather of recorded draws to rank 0" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 --pmc passes",
+                         "algorithmic_bytes_per_launch": updates_per_launch * B_ALG_PER_UPDATE,
                          "kernel": "amwg_step_kernel<NormalModel,%d>" % li["lanes_per_chain"],
                          "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_update": B_ALG_PER_UPDATE,
                          "note": "effective bandwidth: the 80 KB data vector is staged once per launch into LDS and "
