@@ -61,12 +61,12 @@ step_kernel_t pick_kernel(int model, int G) {
   return nullptr;
 }
 
-size_t model_lds_bytes(int model, int n_obs, int G) {
+size_t model_lds_bytes(int model, int n_obs, int groups, int lanes) {
   switch (model) {
-    case AMWG_MODEL_NORMAL: return NormalModel::lds_bytes(n_obs, G);
-    case AMWG_MODEL_BETA_BERN: return BetaBernModel::lds_bytes(n_obs, G);
-    case AMWG_MODEL_HIER_NORMAL: return HierNormalModel::lds_bytes(n_obs, G);
-    case AMWG_MODEL_POIS_GLM: return PoisGlmModel::lds_bytes(n_obs, G);
+    case AMWG_MODEL_NORMAL: return NormalModel::lds_bytes(n_obs, groups, lanes);
+    case AMWG_MODEL_BETA_BERN: return BetaBernModel::lds_bytes(n_obs, groups, lanes);
+    case AMWG_MODEL_HIER_NORMAL: return HierNormalModel::lds_bytes(n_obs, groups, lanes);
+    case AMWG_MODEL_POIS_GLM: return PoisGlmModel::lds_bytes(n_obs, groups, lanes);
   }
   return 0;
 }
@@ -120,10 +120,10 @@ int dev_alloc(amwg_sampler *s, T **p, size_t n) {
 // cannot give every CU a workgroup, one wavefront per chain in single-wave workgroups.
 int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const amwg_options &o = s->opt;
-  const size_t data_bytes = model_lds_bytes(s->model, s->d.n_obs, s->d.G);
-  auto fits = [&](int bt, int G) {
-    return bt % G == 0 && lds_layout(data_bytes, s->P, bt / G, s->pl.max_top).total <= max_lds;
+  auto layout = [&](int bt, int G) {
+    return lds_layout(model_lds_bytes(s->model, s->d.n_obs, s->d.G, G), s->P, bt / G, s->pl.max_top);
   };
+  auto fits = [&](int bt, int G) { return bt % G == 0 && layout(bt, G).total <= max_lds; };
   const int bts[5] = {1024, 512, 256, 128, 64};
   int bestG = 0, bestB = 0;
   for (int bi = 0; bi < 5 && !bestG; ++bi) {
@@ -151,7 +151,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   s->block = bestB;
   const int CPB = bestB / bestG;
   s->grid = (int)((s->C + CPB - 1) / CPB);
-  s->lds = (int)lds_layout(data_bytes, s->P, CPB, s->pl.max_top).total;
+  s->lds = (int)layout(bestB, bestG).total;
   s->kernel = pick_kernel(s->model, s->lanes);
   if (!s->kernel) return fail(AMWG_EINVAL, "no kernel for model %d with %d lanes per chain", s->model, s->lanes);
   return AMWG_OK;
@@ -357,11 +357,23 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
     }
   } else if (m->model == AMWG_MODEL_BETA_BERN) {
     std::vector<uint8_t> xb((size_t)N);
-    for (int i = 0; i < N; ++i) xb[i] = m->x[i] == 0 ? 0 : (m->x[i] == 1 ? 1 : 2);
+    std::vector<uint32_t> xw((size_t)N / 32 + 2, 0u);
+    bool invalid = false;
+    for (int i = 0; i < N; ++i) {
+      const bool one = m->x[i] == 1;
+      invalid = invalid || !(one || m->x[i] == 0);
+      xb[i] = one ? 1 : 0;
+      if (one) xw[(size_t)i >> 5] |= 1u << (i & 31);
+    }
+    mc.has_invalid = invalid ? 1 : 0;
     uint8_t *dxb = nullptr;
+    uint32_t *dxw = nullptr;
     TRYB(dev_alloc(s, &dxb, (size_t)N));
+    TRYB(dev_alloc(s, &dxw, xw.size()));
     if (N) HIPB(hipMemcpy(dxb, xb.data(), (size_t)N, hipMemcpyHostToDevice));
+    HIPB(hipMemcpy(dxw, xw.data(), xw.size() * 4, hipMemcpyHostToDevice));
     d.xb = dxb;
+    d.xw = dxw;
   } else {  // POIS_GLM
     std::vector<double> lf((size_t)N);
     for (int i = 0; i < N; ++i) lf[i] = m->y[i] < 0 ? (double)INFINITY : lfactorial_js(m->y[i]);
@@ -370,7 +382,9 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
     TRYB(dev_alloc(s, &dy, (size_t)N));
     TRYB(dev_alloc(s, &dlf, (size_t)N));
     if (N) {
-      HIPB(hipMemcpy(dX, m->x, (size_t)N * 7 * 8, hipMemcpyHostToDevice));
+      std::vector<double> Xt((size_t)N * 7);   // row-major [N][7] -> column-major [7][N]
+      for (int i = 0; i < N; ++i) for (int k = 0; k < 7; ++k) Xt[(size_t)k * N + i] = m->x[(size_t)i * 7 + k];
+      HIPB(hipMemcpy(dX, Xt.data(), (size_t)N * 7 * 8, hipMemcpyHostToDevice));
       HIPB(hipMemcpy(dy, m->y, (size_t)N * 8, hipMemcpyHostToDevice));
       HIPB(hipMemcpy(dlf, lf.data(), (size_t)N * 8, hipMemcpyHostToDevice));
     }

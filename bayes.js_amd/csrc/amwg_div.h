@@ -2,27 +2,38 @@
 //
 // ld.norm divides every observation's squared residual by the same 2*sd*sd
 // (distributions.js:120).  IEEE division on CDNA4 is an 11-instruction sequence with a
-// quarter-rate v_rcp_f64; with the divisor fixed for a whole pass the reciprocal
-// y = RN(1/b) is computed once (true IEEE division) and each quotient is
-//     q0 = RN(a*y);  r0 = RN(a - b*q0);  q1 = RN(q0 + r0*y);  r1 = a - b*q1 (exact);  q = RN(q1 + r1*y)
-// After the first correction q1 is a faithful quotient, and Markstein's theorem (IBM J. R&D
-// 34(1), 1990; Muller et al., Handbook of Floating-Point Arithmetic §4.7) then gives
-// q = RN(a/b) exactly, provided y is the correctly rounded reciprocal and nothing
-// over/underflows.  Callers guarantee the range precondition (see div_range_ok) and fall
-// back to '/' otherwise, so results are bit-identical to IEEE division -- which is what the
-// reference computes.  tests/test_gpu_math.py compares 4e6 random and adversarial (a,b)
-// pairs against '/' on the device.
+// quarter-rate v_rcp_f64; with the divisor b fixed for a whole pass, 1/b is prepared once as
+// a double-double  y_hi = RN(1/b) (true IEEE division),  y_lo ~= 1/b - y_hi  (from the exact
+// residual 1 - b*y_hi), and each quotient takes four operations:
+//     t  = RN(a * y_lo)
+//     q1 = RN(a * y_hi + t)          |q1 - a/b| <= (1/2 + 2^-50) ulp: a faithful quotient
+//     r  = a - b * q1                exact in one fma (q1 faithful)
+//     q  = RN(q1 + r * y_hi)         = RN(a / b)
+// The last step is Markstein's correction (IBM J. R&D 34(1), 1990; Muller et al., Handbook of
+// Floating-Point Arithmetic, 2nd ed., section 4.7): with q1 faithful and y_hi the correctly
+// rounded reciprocal, q is the correctly rounded quotient, provided nothing over/underflows.
+// Callers guarantee that range precondition (mid_range) and otherwise use '/', so results are
+// bit-identical to IEEE division -- which is what the reference computes.
+// tests/test_gpu_math.py compares 4e6 random and adversarial (a,b) pairs with '/' on the device.
 #pragma once
 #include "amwg_math.h"
 
 namespace amwg {
 
-AMWG_HD double div_by_invariant(double a, double b, double y) {
-  double q = a * y;
-  double r = __builtin_fma(-b, q, a);
-  q = __builtin_fma(r, y, q);
-  r = __builtin_fma(-b, q, a);
-  return __builtin_fma(r, y, q);
+struct Reciprocal { double hi, lo; };
+
+AMWG_HD Reciprocal make_reciprocal(double b) {
+  Reciprocal y;
+  y.hi = 1.0 / b;                                 // correctly rounded
+  y.lo = __builtin_fma(-b, y.hi, 1.0) * y.hi;     // (1 - b*y_hi) is exact; times ~1/b
+  return y;
+}
+
+AMWG_HD double div_by_invariant(double a, double b, Reciprocal y) {
+  const double t = a * y.lo;
+  const double q1 = __builtin_fma(a, y.hi, t);
+  const double r = __builtin_fma(-b, q1, a);
+  return __builtin_fma(r, y.hi, q1);
 }
 
 // true iff 2^-200 <= v <= 2^200 (positive, normal, comfortably inside the exponent range)

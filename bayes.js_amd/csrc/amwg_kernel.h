@@ -20,7 +20,7 @@
 // (80 KB at cfg2 -- one workgroup of up to 16 waves per CU shares it) and is then read
 // conflict-free: the G lanes of a chain read G consecutive elements, the 64/G chains of a
 // wave read the same addresses (LDS broadcast).  Per-chain scalar state lives in LDS
-// ([component][chain-in-block]) because the component a lane updates is data dependent.
+// ([chain-in-block][component], odd stride) because the component a lane updates is data dependent.
 // Data too large for LDS (cfg5's 3.6 MB design matrix) is read through L2/MALL.
 //
 // Reference work avoided without changing any result: the reference evaluates log_post
@@ -36,13 +36,14 @@
 namespace amwg {
 
 struct LdsLayout {
-  uint32_t data, state, cc, adapt, pl, idx, total;
+  uint32_t data, state, cc, adapt, pl, idx, total, stride;
 };
 __host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CPB, int max_top) {
   LdsLayout L;
   uint32_t o = 0;
+  L.stride = (uint32_t)P | 1u;  // doubles per chain, odd (see StateView)
   L.data = o;  o += (uint32_t)((data_bytes + 15) & ~(size_t)15);
-  L.state = o; o += (uint32_t)P * CPB * 8;
+  L.state = o; o += L.stride * CPB * 8;
   L.cc = o;    o += (uint32_t)P * sizeof(CompConst);
   L.adapt = o; o += ((uint32_t)P + 7) & ~7u;
   L.pl = o;    o += (uint32_t)((sizeof(ParamLayout) + 7) & ~(size_t)7);
@@ -71,6 +72,8 @@ __device__ __forceinline__ double pass_over_data(const typename Model::Pass &ps,
 template <class T> struct has_fast { static constexpr bool value = false; };
 template <> struct has_fast<NormalModel> { static constexpr bool value = true; };
 template <> struct has_fast<HierNormalModel> { static constexpr bool value = true; };
+template <class T> struct has_one_lane_pass { static constexpr bool value = false; };
+template <> struct has_one_lane_pass<BetaBernModel> { static constexpr bool value = true; };
 
 // log_post(state) in the documented order: lane 0 of the chain starts from the prior sum
 // (accumulated sequentially as the closure does), every lane adds its observations in
@@ -83,8 +86,13 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
   if constexpr (has_fast<Model>::value) {
     if (ps.fast) acc = pass_over_data<Model, true, G>(ps, a.d.n_obs, sub, acc);
     else acc = pass_over_data<Model, false, G>(ps, a.d.n_obs, sub, acc);
+  } else if constexpr (has_one_lane_pass<Model>::value && G == 1) {
+    acc = Model::pass_one_lane(ps, a.d.n_obs, acc);
   } else {
     acc = pass_over_data<Model, false, G>(ps, a.d.n_obs, sub, acc);
+  }
+  if constexpr (has_one_lane_pass<Model>::value) {
+    if (ps.has_invalid) acc = acc + (-kInf);   // some x_i outside {0,1}: that term is -inf wherever it sits in the sum
   }
 #pragma unroll
   for (int off = 1; off < G; off <<= 1) acc = acc + __shfl_xor(acc, off, 64);
@@ -116,7 +124,7 @@ __global__ void __launch_bounds__(1024) amwg_step_kernel(const StepArgs a) {
   const int CPB = nt / G;
   const int c_in = tid / G, sub = tid % G;
   const int P = a.pl.P;
-  const LdsLayout L = lds_layout(Model::lds_bytes(a.d.n_obs, a.d.G), P, CPB, a.pl.max_top);
+  const LdsLayout L = lds_layout(Model::lds_bytes(a.d.n_obs, a.d.G, G), P, CPB, a.pl.max_top);
 
   const unsigned char *data_lds = smem + L.data;
   double *Sblk = reinterpret_cast<double *>(smem + L.state);
@@ -126,7 +134,7 @@ __global__ void __launch_bounds__(1024) amwg_step_kernel(const StepArgs a) {
   uint8_t *idx = smem + L.idx + c_in;  // this chain's shuffle indices at idx[t * CPB]
 
   // ---- stage chain-shared data and per-component constants (coalesced, once per launch)
-  Model::stage(smem + L.data, a.d, tid, nt);
+  Model::stage(smem + L.data, a.d, tid, nt, G);
   for (int p = tid; p < P; p += nt) { cc[p] = a.cc[p]; adapt[p] = a.is_adapting[p]; }
   if (tid == 0) *pl = a.pl;
 
@@ -136,9 +144,9 @@ __global__ void __launch_bounds__(1024) amwg_step_kernel(const StepArgs a) {
   const bool writer = live && sub == 0;
   const int64_t C = a.C;
 
-  double *Sme = Sblk + c_in;
-  for (int p = 0; p < P; ++p) Sme[p * CPB] = a.ch.state[p * C + cl];
-  const StateView S{Sme, CPB};
+  double *Sme = Sblk + (size_t)c_in * L.stride;
+  for (int p = 0; p < P; ++p) Sme[p] = a.ch.state[p * C + cl];
+  const StateView S{Sme};
   uint32_t perm = a.ch.perm[cl];
   ChainStream rng;
   rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl]);
@@ -195,14 +203,14 @@ __global__ void __launch_bounds__(1024) amwg_step_kernel(const StepArgs a) {
       const bool inb = !(prop < k.lower || prop > k.upper);
       bool accepted = false;
       if (inb) {
-        Sme[comp * CPB] = prop;
+        Sme[comp] = prop;
         const double prop_lp = log_post<Model, G>(S, a, data_lds, sub);
         const double accept_prob = exp_v8(prop_lp - lp_curr);
         if (accept_prob > rng.next()) {
           accepted = true;
           lp_curr = prop_lp;
         } else {
-          Sme[comp * CPB] = cur;
+          Sme[comp] = cur;
         }
       }
       const bool adapting = adapt[comp] != 0;
@@ -246,7 +254,7 @@ __global__ void amwg_eval_kernel(int op, int64_t n, const double *a, const doubl
     case 1: r = log_v8(x); break;
     case 2: r = __builtin_sqrt(x); break;
     case 3: r = lgamma_js(x); break;
-    case 4: r = div_by_invariant(x, y, 1.0 / y); break;
+    case 4: r = div_by_invariant(x, y, make_reciprocal(y)); break;
     case 5: r = x / y; break;
     case 6: r = ld_norm(x, y, z); break;
     case 7: r = js_round(x); break;

@@ -36,15 +36,18 @@ struct ModelConsts {
   double cp_upper, lunif_cp;
   int32_t data_mid_range;           // every data value is 0 or within 2^-200..2^200 in magnitude
   int32_t exact_division;           // 1 = always use IEEE '/'
+  int32_t has_invalid;              // BETA_BERN: some x_i is neither 0 nor 1 => that term is -inf (distributions.js:229)
+  int32_t pad;
 };
 
 // Device pointers to the (read-only, chain-shared) data.
 struct DataRef {
   int32_t n_obs, G, K, pad;
-  const double *x;      // NORMAL x[N] | HIER y[N] | GLM X[N][K]
+  const double *x;      // NORMAL x[N] | HIER y[N] | GLM X column-major [K][N] (coalesced across observations)
   const double *y;      // GLM counts
   const double *lfact;  // GLM lfactorial(y_i) (+inf encodes y_i < 0, i.e. term = -inf)
-  const uint8_t *xb;    // BETA_BERN x as bytes (2 = neither 0 nor 1) | HIER group index
+  const uint8_t *xb;    // BETA_BERN x as bytes (invalid values stored as 0, see has_invalid) | HIER group index
+  const uint32_t *xw;   // BETA_BERN x as bits: observation i = bit (i & 31) of word (i >> 5)
 };
 
 // Per-chain state, structure-of-arrays with the chain index fastest: element (p, c) at p*C + c.
