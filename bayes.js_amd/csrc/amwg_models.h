@@ -106,37 +106,99 @@ struct BetaBernModel {
   // register (log theta or log(1-theta)) the single v_add_f64 of that observation adds --
   // 1 vector instruction per observation instead of compare + 2 selects + add.  The adds are
   // inline asm so the compiler cannot turn the uniform branch back into per-lane selects.
-  // acc += bit b of the wave-uniform word w ? l1 : l0, as ONE vector instruction: the scalar unit
-  // tests the bit and branches around the other add.  One asm statement per observation so both
-  // arms write the same register (no phi copies) and the compiler cannot if-convert the branch.
-#define AMWG_BERN_ADD(B)                                                                              \
-  asm volatile("s_bitcmp1_b32 %3, " #B "\n\ts_cbranch_scc1 1f\n\tv_add_f64 %0, %0, %2\n\ts_branch 2f\n"  \
+  // Sequential sum for ONE lane per chain (the reference's order).  Every lane of the wave adds
+  // the same observation at the same time, so the observation bit is wave-uniform: it travels
+  // through the scalar unit and only decides WHICH per-lane register (log theta or
+  // log(1-theta)) the observation's single v_add_f64 adds -- 1 vector instruction per
+  // observation instead of compare + 2 selects + add.  On CDNA a SIMD issues at most one scalar
+  // instruction per 4-cycle turn, the same cadence as one fp64 add, so a per-observation
+  // test-and-branch (>= 3 scalar/branch issues) runs at 12 cycles per observation (measured).
+  // Instead 8 observations are dispatched at once: the next data byte indexes a table of 256
+  // straight-line blocks (8 adds + branch back, 68 bytes each) via s_setpc_b64 -- ~0.9 scalar
+  // issues per observation, leaving the fp64 adds as the bound.  Hand-written because the
+  // compiler would turn the uniform choice back into per-lane selects.
+#define AMWG_A0 "v_add_f64 %[acc], %[acc], %[l0]\n"
+#define AMWG_A1 "v_add_f64 %[acc], %[acc], %[l1]\n"
+#define AMWG_N0 AMWG_A0 AMWG_A0 AMWG_A0 AMWG_A0
+#define AMWG_N1 AMWG_A1 AMWG_A0 AMWG_A0 AMWG_A0
+#define AMWG_N2 AMWG_A0 AMWG_A1 AMWG_A0 AMWG_A0
+#define AMWG_N3 AMWG_A1 AMWG_A1 AMWG_A0 AMWG_A0
+#define AMWG_N4 AMWG_A0 AMWG_A0 AMWG_A1 AMWG_A0
+#define AMWG_N5 AMWG_A1 AMWG_A0 AMWG_A1 AMWG_A0
+#define AMWG_N6 AMWG_A0 AMWG_A1 AMWG_A1 AMWG_A0
+#define AMWG_N7 AMWG_A1 AMWG_A1 AMWG_A1 AMWG_A0
+#define AMWG_N8 AMWG_A0 AMWG_A0 AMWG_A0 AMWG_A1
+#define AMWG_N9 AMWG_A1 AMWG_A0 AMWG_A0 AMWG_A1
+#define AMWG_N10 AMWG_A0 AMWG_A1 AMWG_A0 AMWG_A1
+#define AMWG_N11 AMWG_A1 AMWG_A1 AMWG_A0 AMWG_A1
+#define AMWG_N12 AMWG_A0 AMWG_A0 AMWG_A1 AMWG_A1
+#define AMWG_N13 AMWG_A1 AMWG_A0 AMWG_A1 AMWG_A1
+#define AMWG_N14 AMWG_A0 AMWG_A1 AMWG_A1 AMWG_A1
+#define AMWG_N15 AMWG_A1 AMWG_A1 AMWG_A1 AMWG_A1
+#define AMWG_B(HI, LO) AMWG_N##LO AMWG_N##HI "s_branch 25b\n"     /* byte HI*16+LO: low nibble = first 4 observations */
+#define AMWG_ROW(HI)                                                                                   \
+  AMWG_B(HI, 0) AMWG_B(HI, 1) AMWG_B(HI, 2) AMWG_B(HI, 3) AMWG_B(HI, 4) AMWG_B(HI, 5) AMWG_B(HI, 6) AMWG_B(HI, 7) \
+  AMWG_B(HI, 8) AMWG_B(HI, 9) AMWG_B(HI, 10) AMWG_B(HI, 11) AMWG_B(HI, 12) AMWG_B(HI, 13) AMWG_B(HI, 14) AMWG_B(HI, 15)
+#define AMWG_BERN_ADD_BIT0                                                                             \
+  asm volatile("s_bitcmp1_b32 %3, 0\n\ts_cbranch_scc1 1f\n\tv_add_f64 %0, %0, %2\n\ts_branch 2f\n"        \
                "1:\n\tv_add_f64 %0, %0, %1\n2:"                                                        \
                : "+v"(acc) : "v"(l1), "v"(l0), "s"(w) : "scc")
-  __device__ __forceinline__ static double pass_one_lane(const Pass &ps, int n_obs, double acc) {
+  __device__ __attribute__((noinline)) static double pass_one_lane(const Pass &ps, int n_obs, double acc) {
     const double l1 = ps.l1, l0 = ps.l0;
-    const int nw = n_obs >> 5;
-    uint32_t w_next = nw > 0 ? ps.bits[0] : 0u;
-    for (int k = 0; k < nw; ++k) {
-      const uint32_t w = __builtin_amdgcn_readfirstlane(w_next);
-      if (k + 1 < nw || (n_obs & 31)) w_next = ps.bits[k + 1];
-      AMWG_BERN_ADD(0);  AMWG_BERN_ADD(1);  AMWG_BERN_ADD(2);  AMWG_BERN_ADD(3);
-      AMWG_BERN_ADD(4);  AMWG_BERN_ADD(5);  AMWG_BERN_ADD(6);  AMWG_BERN_ADD(7);
-      AMWG_BERN_ADD(8);  AMWG_BERN_ADD(9);  AMWG_BERN_ADD(10); AMWG_BERN_ADD(11);
-      AMWG_BERN_ADD(12); AMWG_BERN_ADD(13); AMWG_BERN_ADD(14); AMWG_BERN_ADD(15);
-      AMWG_BERN_ADD(16); AMWG_BERN_ADD(17); AMWG_BERN_ADD(18); AMWG_BERN_ADD(19);
-      AMWG_BERN_ADD(20); AMWG_BERN_ADD(21); AMWG_BERN_ADD(22); AMWG_BERN_ADD(23);
-      AMWG_BERN_ADD(24); AMWG_BERN_ADD(25); AMWG_BERN_ADD(26); AMWG_BERN_ADD(27);
-      AMWG_BERN_ADD(28); AMWG_BERN_ADD(29); AMWG_BERN_ADD(30); AMWG_BERN_ADD(31);
+    // wave-uniform by construction; make that explicit so they live in SGPRs
+    const uint64_t pbits = (uint64_t)reinterpret_cast<uintptr_t>(ps.bits);
+    const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t)pbits), phi = __builtin_amdgcn_readfirstlane((uint32_t)(pbits >> 32));
+    const uint32_t *bits = reinterpret_cast<const uint32_t *>((uintptr_t)(((uint64_t)phi << 32) | plo));
+    n_obs = __builtin_amdgcn_readfirstlane(n_obs);
+    const int nw = n_obs >> 5;      // full 32-observation words go through the byte-dispatch loop
+    if (nw > 0) {
+      asm volatile(
+          "s_mov_b64 s[40:41], %[ptr]\n"
+          "s_mov_b32 s42, %[nw]\n"
+          "s_getpc_b64 s[44:45]\n"
+          "10:\n"
+          "s_add_u32 s44, s44, 30f-10b\n"      // s[44:45] = address of the block table
+          "s_addc_u32 s45, s45, 0\n"
+          "20:\n"                              // ---- next word: s[46:47] = {word, sentinel 1}
+          "s_load_dword s46, s[40:41], 0x0\n"
+          "s_mov_b32 s47, 1\n"
+          "s_add_u32 s40, s40, 4\n"
+          "s_addc_u32 s41, s41, 0\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "22:\n"                              // ---- next byte of the word
+          "s_and_b32 s48, s46, 0xff\n"
+          "s_mul_i32 s48, s48, 68\n"           // 8 * 8-byte VOP3 adds + 4-byte s_branch
+          "s_add_u32 s48, s44, s48\n"
+          "s_addc_u32 s49, s45, 0\n"
+          "s_setpc_b64 s[48:49]\n"
+          "25:\n"                              // ---- blocks return here
+          "s_lshr_b64 s[46:47], s[46:47], 8\n"
+          "s_cmp_lg_u64 s[46:47], 1\n"         // only the sentinel left => word done
+          "s_cbranch_scc1 22b\n"
+          "s_sub_u32 s42, s42, 1\n"
+          "s_cmp_lg_u32 s42, 0\n"
+          "s_cbranch_scc1 20b\n"
+          "s_branch 40f\n"
+          "30:\n"
+          AMWG_ROW(0) AMWG_ROW(1) AMWG_ROW(2) AMWG_ROW(3) AMWG_ROW(4) AMWG_ROW(5) AMWG_ROW(6) AMWG_ROW(7)
+          AMWG_ROW(8) AMWG_ROW(9) AMWG_ROW(10) AMWG_ROW(11) AMWG_ROW(12) AMWG_ROW(13) AMWG_ROW(14) AMWG_ROW(15)
+          "40:\n"
+          : [acc] "+v"(acc)
+          : [l1] "v"(l1), [l0] "v"(l0), [ptr] "s"(bits), [nw] "s"(nw)
+          : "s40", "s41", "s42", "s44", "s45", "s46", "s47", "s48", "s49", "scc", "memory");
     }
-    uint32_t w = __builtin_amdgcn_readfirstlane(w_next);
-    for (int b = 0; b < (n_obs & 31); ++b) {
-      AMWG_BERN_ADD(0);
-      w >>= 1;
+    if (n_obs & 31) {               // ragged tail, one test-and-branch per observation
+      uint32_t w = __builtin_amdgcn_readfirstlane(bits[nw]);
+      for (int b = 0; b < (n_obs & 31); ++b) {
+        AMWG_BERN_ADD_BIT0;
+        w >>= 1;
+      }
     }
     return acc;
   }
-#undef AMWG_BERN_ADD
+#undef AMWG_BERN_ADD_BIT0
+#undef AMWG_ROW
+#undef AMWG_B
 };
 
 // ---------------------------------------------------------------------------------------------
