@@ -71,6 +71,16 @@ size_t model_lds_bytes(int model, int n_obs, int groups, int lanes) {
   return 0;
 }
 
+int model_max_threads(int model) {
+  switch (model) {
+    case AMWG_MODEL_NORMAL: return NormalModel::kMaxThreads;
+    case AMWG_MODEL_BETA_BERN: return BetaBernModel::kMaxThreads;
+    case AMWG_MODEL_HIER_NORMAL: return HierNormalModel::kMaxThreads;
+    case AMWG_MODEL_POIS_GLM: return PoisGlmModel::kMaxThreads;
+  }
+  return 64;
+}
+
 bool value_mid_range(double v) { return v == 0.0 || mid_range(std::fabs(v)); }
 
 }  // namespace
@@ -114,37 +124,42 @@ int dev_alloc(amwg_sampler *s, T **p, size_t n) {
   return AMWG_OK;
 }
 
-// Geometry.  Preference order: (1) at least one workgroup per CU, using the LARGEST workgroup
-// (more waves share one LDS copy of the data and hide each other's latency) and, for that size,
-// the FEWEST lanes per chain (less replicated scalar work); (2) if even one wavefront per chain
-// cannot give every CU a workgroup, one wavefront per chain in single-wave workgroups.
+// Geometry.  For every lanes-per-chain G (ascending: fewer lanes = less replicated scalar work)
+// take the largest workgroup that still gives every CU a workgroup (more waves share one LDS copy
+// of the data), estimate the resident waves per SIMD, and stop at the first G that reaches 4 --
+// enough to hide LDS/fp64 latencies in the dependent chains.  If no G gets there (few chains), keep
+// the best occupancy seen; ties go to the smaller G.
 int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const amwg_options &o = s->opt;
   auto layout = [&](int bt, int G) {
     return lds_layout(model_lds_bytes(s->model, s->d.n_obs, s->d.G, G), s->P, bt / G, s->pl.max_top);
   };
-  auto fits = [&](int bt, int G) { return bt % G == 0 && layout(bt, G).total <= max_lds; };
+  const int max_bt = model_max_threads(s->model);
+  auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds; };
   const int bts[5] = {1024, 512, 256, 128, 64};
   int bestG = 0, bestB = 0;
-  for (int bi = 0; bi < 5 && !bestG; ++bi) {
-    const int bt = bts[bi];
-    if (o.block_threads && bt != o.block_threads) continue;
-    for (int G = 1; G <= 64; G <<= 1) {
-      if (o.lanes_per_chain && G != o.lanes_per_chain) continue;
-      if (!fits(bt, G)) continue;
-      const int CPB = bt / G;
-      if ((s->C + CPB - 1) / CPB >= n_cus) { bestG = G; bestB = bt; break; }
-    }
-  }
-  if (!bestG) {  // too few chains to fill the chip: widest chain, smallest workgroup that fits
-    for (int bi = 4; bi >= 0 && !bestG; --bi) {
+  double bestOcc = -1.0;
+  for (int G = 1; G <= 64; G <<= 1) {
+    if (o.lanes_per_chain && G != o.lanes_per_chain) continue;
+    int pick = 0;
+    for (int bi = 0; bi < 5; ++bi) {   // largest workgroup with >= one workgroup per CU, else the smallest that fits
       const int bt = bts[bi];
       if (o.block_threads && bt != o.block_threads) continue;
-      for (int G = 64; G >= 1; G >>= 1) {
-        if (o.lanes_per_chain && G != o.lanes_per_chain) continue;
-        if (fits(bt, G)) { bestG = G; bestB = bt; break; }
-      }
+      if (!fits(bt, G)) continue;
+      pick = bt;
+      if ((s->C + bt / G - 1) / (bt / G) >= n_cus) break;
     }
+    if (!pick) continue;
+    const int CPB = pick / G;
+    const int64_t blocks = (s->C + CPB - 1) / CPB;
+    const uint32_t lds = layout(pick, G).total;
+    int64_t per_cu = 2048 / pick;                                  // 32 waves per CU
+    if (lds > 0 && (int64_t)(max_lds / lds) < per_cu) per_cu = (int64_t)(max_lds / lds);
+    if (per_cu < 1) per_cu = 1;
+    const int64_t resident = blocks < per_cu * n_cus ? blocks : per_cu * n_cus;
+    const double occ = (double)resident * (pick / 64) / (4.0 * n_cus);  // waves per SIMD
+    if (occ > bestOcc + 1e-9) { bestOcc = occ; bestG = G; bestB = pick; }
+    if (occ >= 4.0) break;
   }
   if (!bestG) return fail(AMWG_EINVAL, "no launch geometry fits: the model needs more than %zu bytes of LDS", max_lds);
   s->lanes = bestG;
@@ -244,6 +259,8 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   if (G_opt && (G_opt < 1 || G_opt > 64 || (G_opt & (G_opt - 1)))) return fail(AMWG_EINVAL, "lanes_per_chain must be a power of two in 1..64");
   if (options->block_threads && (options->block_threads % 64 || options->block_threads > 1024 || options->block_threads < 64))
     return fail(AMWG_EINVAL, "block_threads must be a multiple of 64 in 64..1024");
+  if (options->block_threads > model_max_threads(m->model))
+    return fail(AMWG_EINVAL, "block_threads %d exceeds this model's workgroup limit %d", options->block_threads, model_max_threads(m->model));
 
   amwg_sampler *s = new amwg_sampler();
   s->opt = *options;

@@ -36,7 +36,7 @@
 namespace amwg {
 
 struct LdsLayout {
-  uint32_t data, state, cc, adapt, pl, idx, total, stride;
+  uint32_t data, state, pls, cnt, cc, adapt, pl, idx, total, stride;
 };
 __host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CPB, int max_top) {
   LdsLayout L;
@@ -44,6 +44,8 @@ __host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CP
   L.stride = (uint32_t)P | 1u;  // doubles per chain, odd (see StateView)
   L.data = o;  o += (uint32_t)((data_bytes + 15) & ~(size_t)15);
   L.state = o; o += L.stride * CPB * 8;
+  L.pls = o;   o += L.stride * CPB * 8;   // prop_log_scale, same [chain][stride] layout as the state
+  L.cnt = o;   o += L.stride * CPB * 8;   // {acceptance_count, iterations_since_adaption} int32 pairs
   L.cc = o;    o += (uint32_t)P * sizeof(CompConst);
   L.adapt = o; o += ((uint32_t)P + 7) & ~7u;
   L.pl = o;    o += (uint32_t)((sizeof(ParamLayout) + 7) & ~(size_t)7);
@@ -54,7 +56,7 @@ __host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CP
 
 template <class Model, bool FAST, int G>
 __device__ __forceinline__ double pass_over_data(const typename Model::Pass &ps, int n_obs, int sub, double acc) {
-  constexpr int U = 8;
+  constexpr int U = Model::kUnroll;
   const int n_full = n_obs / G, rem = n_obs % G;
   int k = 0;
   for (; k + U <= n_full; k += U) {
@@ -118,7 +120,7 @@ __device__ __forceinline__ uint32_t perm_swap(uint32_t perm, int i, int j) {
 }
 
 template <class Model, int G>
-__global__ void __launch_bounds__(1024) amwg_step_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(Model::kMaxThreads) amwg_step_kernel(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int CPB = nt / G;
@@ -132,6 +134,8 @@ __global__ void __launch_bounds__(1024) amwg_step_kernel(const StepArgs a) {
   uint8_t *adapt = smem + L.adapt;
   ParamLayout *pl = reinterpret_cast<ParamLayout *>(smem + L.pl);
   uint8_t *idx = smem + L.idx + c_in;  // this chain's shuffle indices at idx[t * CPB]
+  double *PLSme = reinterpret_cast<double *>(smem + L.pls) + (size_t)(tid / G) * L.stride;
+  int2 *CNTme = reinterpret_cast<int2 *>(smem + L.cnt) + (size_t)(tid / G) * L.stride;
 
   // ---- stage chain-shared data and per-component constants (coalesced, once per launch)
   Model::stage(smem + L.data, a.d, tid, nt, G);
@@ -145,7 +149,12 @@ __global__ void __launch_bounds__(1024) amwg_step_kernel(const StepArgs a) {
   const int64_t C = a.C;
 
   double *Sme = Sblk + (size_t)c_in * L.stride;
-  for (int p = 0; p < P; ++p) Sme[p] = a.ch.state[p * C + cl];
+  // per-chain stepper state lives in LDS for the whole launch: an update never waits on HBM/L2
+  for (int p = 0; p < P; ++p) {
+    Sme[p] = a.ch.state[p * C + cl];
+    PLSme[p] = a.ch.prop_log_scale[p * C + cl];
+    CNTme[p] = make_int2(a.ch.acceptance_count[p * C + cl], a.ch.iterations_since_adaption[p * C + cl]);
+  }
   const StateView S{Sme};
   uint32_t perm = a.ch.perm[cl];
   ChainStream rng;
@@ -196,7 +205,7 @@ __global__ void __launch_bounds__(1024) amwg_step_kernel(const StepArgs a) {
       // ---- OnedimMetropolisStepper.step (mcmc.js:517-553)
       const CompConst k = cc[comp];
       const int64_t gi = (int64_t)comp * C + cl;
-      double pls = a.ch.prop_log_scale[gi];
+      double pls = PLSme[comp];
       const double cur = S(comp);
       double prop = rnorm_js(rng, cur, exp_v8(pls));
       if (k.type == 1) prop = js_round(prop);
@@ -213,30 +222,34 @@ __global__ void __launch_bounds__(1024) amwg_step_kernel(const StepArgs a) {
           Sme[comp] = cur;
         }
       }
-      const bool adapting = adapt[comp] != 0;
-      int32_t ac = 0, it = 0;
-      if (adapting) {
-        ac = a.ch.acceptance_count[gi] + (accepted ? 1 : 0);
-        it = a.ch.iterations_since_adaption[gi] + 1;
-        if (it >= k.batch_size) {
+      if (adapt[comp] != 0) {
+        int2 cnt = CNTme[comp];
+        cnt.x += accepted ? 1 : 0;      // acceptance_count (mcmc.js:530)
+        cnt.y += 1;                     // iterations_since_adaption (mcmc.js:537)
+        if (cnt.y >= k.batch_size) {    // batch boundary: the only time batch_count is touched (it stays in HBM)
           const int32_t bc = a.ch.batch_count[gi] + 1;
           const double adj = __builtin_fmin(k.max_adaptation, k.initial_adaptation / __builtin_sqrt((double)bc));
-          if ((double)ac / (double)k.batch_size > k.target_accept_rate) pls += adj; else pls -= adj;
-          ac = 0;
-          it = 0;
-          if (writer) { a.ch.batch_count[gi] = bc; a.ch.prop_log_scale[gi] = pls; }
+          if ((double)cnt.x / (double)k.batch_size > k.target_accept_rate) pls += adj; else pls -= adj;
+          cnt = make_int2(0, 0);
+          PLSme[comp] = pls;
+          if (writer) a.ch.batch_count[gi] = bc;
         }
+        CNTme[comp] = cnt;
       }
-      if (writer) {
-        if (adapting) { a.ch.acceptance_count[gi] = ac; a.ch.iterations_since_adaption[gi] = it; }
-        if (inb) a.ch.inbounds[gi] += 1;
-        if (accepted) a.ch.accepts[gi] += 1;
+      if (writer) {   // run totals (not in the reference): fire-and-forget atomics, nothing waits on them
+        if (inb) __hip_atomic_fetch_add(&a.ch.inbounds[gi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (accepted) __hip_atomic_fetch_add(&a.ch.accepts[gi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
 
   if (writer) {
-    for (int p = 0; p < P; ++p) a.ch.state[p * C + cl] = S(p);
+    for (int p = 0; p < P; ++p) {
+      a.ch.state[p * C + cl] = S(p);
+      a.ch.prop_log_scale[p * C + cl] = PLSme[p];
+      a.ch.acceptance_count[p * C + cl] = CNTme[p].x;
+      a.ch.iterations_since_adaption[p * C + cl] = CNTme[p].y;
+    }
     a.ch.perm[cl] = perm;
     a.ch.rng_n[cl] = rng.n;
     a.ch.lp_curr[cl] = lp_curr;

@@ -33,7 +33,8 @@ AMWG_HD double set_hi_word(double x, int32_t hi) {
 
 // exp(x) = 2^k * exp(r), r = x - k ln2 in two pieces, exp(r) = 1 + r + r*c/(2-c),
 // c = r - r^2 * P(r^2).
-AMWG_HD double exp_v8(double x) {
+// Full fdlibm control flow (every special case); the kernel reaches it only on the rare path.
+AMWG_HD double exp_v8_full(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const double inv_ln2 = 1.44269504088896338700e+00, two_m1000 = 9.33263618503218878990e-302;
   const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
@@ -80,7 +81,8 @@ AMWG_HD double exp_v8(double x) {
 }
 
 // log(x): x = 2^k (1+f), sqrt(2)/2 < 1+f < sqrt(2); s = f/(2+f); log(1+f) = f - s (f - R(s^2)).
-AMWG_HD double log_v8(double x) {
+// Full fdlibm control flow; rare path of log_v8 below.
+AMWG_HD double log_v8_full(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const double two54 = 1.80143985094819840000e+16;
   const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
@@ -118,6 +120,63 @@ AMWG_HD double log_v8(double x) {
     return (k == 0) ? f - (hfsq - s * (hfsq + R)) : dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
   }
   return (k == 0) ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+// ---- straight-line front ends -------------------------------------------------------------------
+// Same values as the *_full versions (tests pin both against V8), shaped for a 64-lane SIMD: the
+// three argument-reduction cases of exp and the two polynomial tails of log become selects, the
+// k == 0 special forms are folded into the general ones (they are the general formula with
+// lo = 0, hi = x resp. dk = 0: x/(c-2) == -(x/(2-c)), 0 - a == -a, a + 0 == a, all exact), and
+// everything else (|x| >= 708, |x| < 2^-28, exp(1); log of <= 0, subnormal, inf/NaN, |f| < 2^-20)
+// leaves through ONE rarely-taken branch.
+AMWG_HD double exp_v8(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double inv_ln2 = 1.44269504088896338700e+00;
+  const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+               P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  const uint32_t hx = (uint32_t)hi_word(x) & 0x7fffffffu;
+  // rare: |x| >= ~708 (overflow/underflow/denormal scaling/inf/NaN), |x| < 2^-28, or exactly 1.0
+  if (__builtin_expect(hx >= 0x40862000u || hx < 0x3e300000u || x == 1.0, 0)) return exp_v8_full(x);
+  const bool neg = x < 0;
+  const bool big = hx >= 0x3FF0A2B2u;        // |x| >= 1.5 ln2: k from the multiply
+  const bool mid = hx > 0x3fd62e42u;         // |x| >  0.5 ln2: k != 0
+  const int32_t kb = (int32_t)(inv_ln2 * x + (neg ? -0.5 : 0.5));
+  const int32_t k = mid ? (big ? kb : (neg ? -1 : 1)) : 0;
+  const double t = (double)k;
+  // k = +-1: x -+ ln2_hi and +-ln2_lo are exactly t*ln2_hi / t*ln2_lo subtracted/used below
+  const double hi = mid ? x - t * ln2_hi : x;
+  const double lo = mid ? t * ln2_lo : 0.0;
+  const double r = mid ? hi - lo : x;
+  const double rr = r * r;
+  const double c = r - rr * (P1 + rr * (P2 + rr * (P3 + rr * (P4 + rr * P5))));
+  const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  return set_hi_word(y, hi_word(y) + (k << 20));
+}
+
+AMWG_HD double log_v8(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  const int32_t hx0 = hi_word(x);
+  const int32_t hx = hx0 & 0x000fffff;
+  // rare: x <= 0 or subnormal, inf/NaN, or |f| < 2^-20 (x within 2^-20 of a power of two)
+  if (__builtin_expect(hx0 < 0x00100000 || hx0 >= 0x7ff00000 || (0x000fffff & (2 + hx)) < 3, 0)) return log_v8_full(x);
+  const int32_t i = (hx + 0x95f64) & 0x100000;
+  const double m = set_hi_word(x, hx | (i ^ 0x3ff00000));
+  const int32_t k = (hx0 >> 20) - 1023 + (i >> 20);
+  const double f = m - 1.0;
+  const double dk = (double)k;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double a = dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  const double b = dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+  return (((hx - 0x6147a) | (0x6b851 - hx)) > 0) ? a : b;
 }
 
 // Math.round: nearest integer, ties toward +infinity (mcmc.js:597).

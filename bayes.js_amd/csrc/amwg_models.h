@@ -31,6 +31,8 @@ __device__ __forceinline__ double norm_const_sd(double v, double m, double c_sd,
 // x_i ~ norm(mu, sigma); mu ~ norm(m0,s0); sigma ~ unif(a,b)              README.md:22-36
 struct NormalModel {
   static constexpr bool kDataInLds = true;
+  static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
+  static constexpr int kUnroll = 8;   // independent terms in flight per lane (ILP across the division chains)
   struct Pass { double mu, c, den; Reciprocal y; bool fast; const double *x; };
   __host__ __device__ static size_t lds_bytes(int n_obs, int, int) { return (size_t)n_obs * 8; }
   __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int) {
@@ -71,6 +73,8 @@ struct NormalModel {
 // (1*p + 0*(1-p) = p + 0 = p), so the two logs are hoisted and selected per observation.
 struct BetaBernModel {
   static constexpr bool kDataInLds = true;
+  static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
+  static constexpr int kUnroll = 8;
   struct Pass { double l1, l0; const uint8_t *x; const uint32_t *bits; bool has_invalid; };
   // one lane per chain reads the observations as bits through the scalar cache: no LDS copy
   __host__ __device__ static size_t lds_bytes(int n_obs, int, int lanes) { return lanes == 1 ? 0 : (((size_t)n_obs + 15) & ~(size_t)15); }
@@ -206,6 +210,8 @@ struct BetaBernModel {
 // components: theta[0..G-1], mu, sigma                                    SURVEY.md §8(d) cfg4
 struct HierNormalModel {
   static constexpr bool kDataInLds = true;
+  static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
+  static constexpr int kUnroll = 8;
   struct Pass { double c, den; Reciprocal y; bool fast; const double *x; const uint8_t *g; StateView S; };
   __host__ __device__ static size_t lds_bytes(int n_obs, int, int) { return (size_t)n_obs * 8 + (((size_t)n_obs + 15) & ~(size_t)15); }
   __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int) {
@@ -252,6 +258,8 @@ struct HierNormalModel {
 // exp+log dominate the arithmetic by two orders of magnitude.
 struct PoisGlmModel {
   static constexpr bool kDataInLds = false;
+  static constexpr int kMaxThreads = 256;    // exp+log per observation want > 128 VGPRs; no LDS tile to share anyway
+  static constexpr int kUnroll = 2;   // exp+log per term: more would spill
   struct Pass { double b[8]; double cp; const double *X, *y, *lfact; int N; };
   __host__ __device__ static size_t lds_bytes(int, int, int) { return 0; }
   __device__ static void stage(unsigned char *, const DataRef &, int, int, int) {}

@@ -110,23 +110,31 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # Development switches (not used by the driver): AMWG_BENCH_BACKEND=gloo + AMWG_BENCH_ONE_DEVICE=1 run the
+    # N-rank code path on a box with a single GPU (ranks share cuda:0, gather goes through host memory).
+    backend = os.environ.get("AMWG_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("AMWG_BENCH_ONE_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":      # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     from shard import chain_shard, gather_draws
     spec = normal_spec()
     chains = args.chains_per_gpu
     offset, _ = chain_shard(rank, world, chains * world)
-    s = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=local_rank,
+    s = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=dev_index,
                   lanes_per_chain=args.lanes, block_threads=args.block, steps_per_launch=args.steps_per_launch)
     P, K, W, thin = spec["P"], args.steps, args.warmup, max(1, args.thin)
     rows = -(-K // thin)
     draws = torch.empty((rows, P, chains), dtype=torch.float64, device="cuda")
-    gathered = [torch.empty_like(draws) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty(draws.shape, dtype=draws.dtype, device=coll_dev) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -141,12 +149,12 @@ def main():
     s.sample_device(K, thin, draws.data_ptr(), draws.numel() * 8)
     s.sync()
     if dist is not None:
-        gather_draws(dist, draws, gathered, rank)
+        gather_draws(dist, draws if coll_dev == "cuda" else draws.cpu(), gathered, rank)
     barrier()
     dt = time.perf_counter() - t0
     li = s.launch_info()
     if dist is not None:
-        t = torch.tensor([dt, li["kernel_ms"]], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, li["kernel_ms"]], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kernel_ms = float(t[0]), float(t[1])
     else:
@@ -171,7 +179,7 @@ def main():
                        "draws_recorded_per_chain": rows, "thin": thin, "lanes_per_chain": li["lanes_per_chain"],
                        "block_threads": li["block_threads"], "grid_blocks": li["grid_blocks"], "lds_bytes": li["lds_bytes"],
                        "steps_per_launch": args.steps_per_launch, "launches_timed": launches,
-                       "gather": "rccl gather of recorded draws to rank 0" if world > 1 else "none (1 GPU)"},
+                       "gather": ("%s gather of recorded draws to rank 0" % ("rccl" if backend == "nccl" else backend)) if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 --pmc passes",
