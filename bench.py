@@ -189,9 +189,9 @@ def main():
                          "note": "effective bandwidth: the 80 KB data vector is staged once per launch into LDS and "
                                  "re-read from LDS, so HBM traffic is ~0 and frac may exceed 1; the binding limit is fp64 VALU "
                                  "(see fp64_valu)",
-                         "fp64_valu": {"lane_ops_per_obs": 9, "achieved_lane_ops_per_s": updates_per_launch * N_OBS * 9 / launch_s,
+                         "fp64_valu": {"lane_ops_per_obs": 8, "achieved_lane_ops_per_s": updates_per_launch * N_OBS * 8 / launch_s,
                                        "peak_lane_ops_per_s": FP64_VALU_PEAK,
-                                       "frac": updates_per_launch * N_OBS * 9 / launch_s / FP64_VALU_PEAK}},
+                                       "frac": updates_per_launch * N_OBS * 8 / launch_s / FP64_VALU_PEAK}},
             "kernel_only_value": chains * K * P / (kernel_ms * 1e-3),
             "posterior": {"mean": mean.tolist(), "sd": sd.tolist(), "data_mean": float(np.mean(x)), "data_sd": float(np.std(x, ddof=1)),
                           "note": "moments over all recorded draws of rank 0 (after %d warm-up steps)" % W},
