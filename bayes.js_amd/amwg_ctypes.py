@@ -39,7 +39,13 @@ class Options(C.Structure):
                 ("exact_division", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
-EXPORTS = ["amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
+class UserModel(C.Structure):
+    _fields_ = [("source", C.c_char_p), ("n_arrays", C.c_int32), ("arrays", C.POINTER(C.POINTER(C.c_double))),
+                ("array_len", C.POINTER(C.c_int64)), ("n_derived", C.c_int32), ("lds_bytes", C.c_int32),
+                ("parallel", C.c_int32), ("max_threads", C.c_int32)]
+
+
+EXPORTS = ["amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
            "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components",
            "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp",
            "amwg_log", "amwg_uniform", "amwg_device_eval"]
@@ -84,6 +90,15 @@ def lib():
         L.amwg_uniform.restype = dbl
         L.amwg_uniform.argtypes = [u64, u64, u64]
         L.amwg_device_eval.argtypes = [i32, i32, i64, pd, pd, pd, pd]
+        L.amwg_compile_user.argtypes = [C.c_char_p, i32, i32, C.c_char_p, C.POINTER(C.c_size_t)]
+        L.amwg_create_user.argtypes = [C.POINTER(UserModel), C.POINTER(ParamDesc), i32, pd, C.POINTER(CompOpt),
+                                       C.POINTER(Options), C.POINTER(vp)]
+        L.amwg_num_recorded.argtypes = [vp]
+        L.amwg_pow.restype = dbl
+        L.amwg_pow.argtypes = [dbl, dbl]
+        L.amwg_ld_host.restype = dbl
+        L.amwg_ld_host.argtypes = [i32, dbl, dbl, dbl, dbl]
+        L.amwg_ld_device.argtypes = [i32, i64, pd, pd]
         _lib = L
     return _lib
 
@@ -102,35 +117,54 @@ def _dp(a):
 
 
 class Sampler:
-    """Many-chain sampler handle.  `spec` = dict(model, n_obs, data{x[,y,g,G,K]}, params[], P, init[], comp_opts[])."""
+    """Many-chain sampler handle.  `spec` = dict(model, n_obs, data{x[,y,g,G,K]}, params[], P, init[], comp_opts[]) for a
+    built-in family, or dict(user={source, arrays[], n_derived, lds_bytes, parallel, max_threads}, params[], P, init[],
+    comp_opts[]) for a closure translated by bayes.js_amd/translate.js (amwg_create_user)."""
 
     def __init__(self, spec, chains, seed, chain_offset=0, device=0, lanes_per_chain=0, block_threads=0,
                  steps_per_launch=0, exact_division=0):
         L = lib()
-        d = spec["data"]
-        md = ModelDesc()
-        md.model = MODEL_ID[spec["model"]]
-        md.n_obs = spec["n_obs"]
         keep = []
-        x = np.ascontiguousarray(d["x"], dtype=np.float64)
-        keep.append(x)
-        md.x = _dp(x)
-        if "y" in d:
-            y = np.ascontiguousarray(d["y"], dtype=np.float64)
-            keep.append(y)
-            md.y = _dp(y)
-        if "g" in d:
-            g = np.ascontiguousarray(d["g"], dtype=np.int32)
-            keep.append(g)
-            md.g = g.ctypes.data_as(C.POINTER(C.c_int32))
-        md.G = int(spec.get("G", 0))
-        md.K = int(spec.get("K", 0))
-        for i, v in enumerate(spec.get("hyper") or DEFAULT_HYPER[spec["model"]]):
-            md.hyper[i] = float(v)
+        user = spec.get("user")
+        if user is None:
+            d = spec["data"]
+            md = ModelDesc()
+            md.model = MODEL_ID[spec["model"]]
+            md.n_obs = spec["n_obs"]
+            x = np.ascontiguousarray(d["x"], dtype=np.float64)
+            keep.append(x)
+            md.x = _dp(x)
+            if "y" in d:
+                y = np.ascontiguousarray(d["y"], dtype=np.float64)
+                keep.append(y)
+                md.y = _dp(y)
+            if "g" in d:
+                g = np.ascontiguousarray(d["g"], dtype=np.int32)
+                keep.append(g)
+                md.g = g.ctypes.data_as(C.POINTER(C.c_int32))
+            md.G = int(spec.get("G", 0))
+            md.K = int(spec.get("K", 0))
+            for i, v in enumerate(spec.get("hyper") or DEFAULT_HYPER[spec["model"]]):
+                md.hyper[i] = float(v)
+        else:
+            um = UserModel()
+            src = user["source"].encode() if isinstance(user["source"], str) else user["source"]
+            keep.append(src)
+            um.source = src
+            arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in user["arrays"]]
+            keep.append(arrs)
+            um.n_arrays = len(arrs)
+            ptrs = (C.POINTER(C.c_double) * max(1, len(arrs)))(*[_dp(a) for a in arrs])
+            lens = (C.c_int64 * max(1, len(arrs)))(*[a.size for a in arrs])
+            keep += [ptrs, lens]
+            um.arrays, um.array_len = ptrs, lens
+            um.n_derived, um.lds_bytes = int(user.get("n_derived", 0)), int(user.get("lds_bytes", 0))
+            um.parallel, um.max_threads = int(user.get("parallel", 0)), int(user.get("max_threads", 0))
         n = len(spec["params"])
         pa = (ParamDesc * n)()
+        TYPE = {"real": 0, "int": 1, "binary": 2}
         for i, p in enumerate(spec["params"]):
-            pa[i].type = 1 if p["type"] == "int" else 0
+            pa[i].type = TYPE[p["type"]]
             pa[i].len, pa[i].top, pa[i].multidim = p["len"], p["top"], p["multidim"]
             pa[i].lower, pa[i].upper = p["lower"], p["upper"]
         P = spec["P"]
@@ -148,9 +182,13 @@ class Sampler:
         op.lanes_per_chain, op.block_threads, op.steps_per_launch = lanes_per_chain, block_threads, steps_per_launch
         op.exact_division = exact_division
         h = C.c_void_p()
-        _check(L.amwg_create(C.byref(md), pa, n, _dp(init), oa, C.byref(op), C.byref(h)))
+        if user is None:
+            _check(L.amwg_create(C.byref(md), pa, n, _dp(init), oa, C.byref(op), C.byref(h)))
+        else:
+            _check(L.amwg_create_user(C.byref(um), pa, n, _dp(init), oa, C.byref(op), C.byref(h)))
         self.h = h
         self.P = P
+        self.PR = L.amwg_num_recorded(h)   # values per draw row: P + derived quantities
         self.C = chains
         self.n_params = n
 
@@ -165,9 +203,9 @@ class Sampler:
         _check(lib().amwg_burn(self.h, n))
 
     def sample(self, n, thin=1):
-        """-> array [kept][P][chains]"""
+        """-> array [kept][P + derived][chains]"""
         kept = -(-n // thin)
-        out = np.empty((kept, self.P, self.C), dtype=np.float64)
+        out = np.empty((kept, self.PR, self.C), dtype=np.float64)
         _check(lib().amwg_sample(self.h, n, thin, _dp(out), out.nbytes))
         return out
 
@@ -179,7 +217,7 @@ class Sampler:
         self._pending = -(-n // thin)
 
     def fetch_draws(self):
-        out = np.empty((self._pending, self.P, self.C), dtype=np.float64)
+        out = np.empty((self._pending, self.PR, self.C), dtype=np.float64)
         _check(lib().amwg_fetch_draws(self.h, _dp(out), out.nbytes))
         return out
 
@@ -217,7 +255,7 @@ class Sampler:
         return {"uniforms": un, "log_post": lp, "named_order": order}
 
     def moments(self):
-        m, s = np.empty(self.P), np.empty(self.P)
+        m, s = np.empty(self.PR), np.empty(self.PR)
         _check(lib().amwg_last_sample_moments(self.h, _dp(m), _dp(s)))
         return m, s
 

@@ -2,18 +2,31 @@
 // gfx950 step kernel (amwg_kernel.h).  No torch, no oracle, no CPU fallback: every entry
 // point that computes runs on the HIP device or fails with AMWG_EHIP.
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/amwg.h"
+#include "amwg_eval.h"
 #include "amwg_kernel.h"
+#include "amwg_models.h"
 
 using namespace amwg;
+
+// The kernel headers as text (amwg_rtc_headers.c, .incbin): hiprtc compiles a translated closure
+// together with the very same step kernel source the built-in models are compiled from.
+extern "C" {
+extern const char amwg_hdr_stdint[], amwg_hdr_types[], amwg_hdr_math[], amwg_hdr_div[], amwg_hdr_ld[], amwg_hdr_philox[],
+    amwg_hdr_kernel[], amwg_hdr_user[];
+}
 
 namespace {
 
@@ -104,6 +117,12 @@ struct amwg_sampler {
   int lanes = 0, block = 0, grid = 0, lds = 0;
   step_kernel_t kernel = nullptr;
   bool lp_ready = false;
+  // translated closure (amwg_create_user): hiprtc module function instead of a built-in kernel
+  bool user = false;
+  int D = 0;                       // derived quantities recorded after the P components
+  int user_lds = 0, user_parallel = 0, user_max_threads = 1024;
+  hipFunction_t user_fn = nullptr;
+  hipModule_t user_module = nullptr;
   // last call
   int n_launches = 0;
   double kernel_ms = 0.0;
@@ -132,15 +151,17 @@ int dev_alloc(amwg_sampler *s, T **p, size_t n) {
 int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const amwg_options &o = s->opt;
   auto layout = [&](int bt, int G) {
-    return lds_layout(model_lds_bytes(s->model, s->d.n_obs, s->d.G, G), s->P, bt / G, s->pl.max_top);
+    const size_t data_bytes = s->user ? (size_t)s->user_lds : model_lds_bytes(s->model, s->d.n_obs, s->d.G, G);
+    return lds_layout(data_bytes, s->P, bt / G, s->pl.max_top);
   };
-  const int max_bt = model_max_threads(s->model);
+  const int max_bt = s->user ? s->user_max_threads : model_max_threads(s->model);
   auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds; };
   const int bts[5] = {1024, 512, 256, 128, 64};
   int bestG = 0, bestB = 0;
   double bestOcc = -1.0;
   for (int G = 1; G <= 64; G <<= 1) {
     if (o.lanes_per_chain && G != o.lanes_per_chain) continue;
+    if (s->user && !s->user_parallel && G > 1) break;   // nothing to split: one lane per chain
     int pick = 0;
     for (int bi = 0; bi < 5; ++bi) {   // largest workgroup with >= one workgroup per CU, else the smallest that fits
       const int bt = bts[bi];
@@ -167,6 +188,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const int CPB = bestB / bestG;
   s->grid = (int)((s->C + CPB - 1) / CPB);
   s->lds = (int)layout(bestB, bestG).total;
+  if (s->user) return AMWG_OK;    // the kernel is compiled for this geometry afterwards
   s->kernel = pick_kernel(s->model, s->lanes);
   if (!s->kernel) return fail(AMWG_EINVAL, "no kernel for model %d with %d lanes per chain", s->model, s->lanes);
   return AMWG_OK;
@@ -196,8 +218,14 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
     // steps until the first recorded step of this launch: smallest t >= 0 with (done + t) % thin == 0
     a.step0 = (thin - (done % thin)) % thin;
     a.row0 = row;
-    hipLaunchKernelGGL(s->kernel, dim3(s->grid), dim3(s->block), (size_t)s->lds, s->stream, a);
-    HIP_TRY(hipGetLastError());
+    if (s->user) {
+      size_t arg_bytes = sizeof a;
+      void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_bytes, HIP_LAUNCH_PARAM_END};
+      HIP_TRY(hipModuleLaunchKernel(s->user_fn, (unsigned)s->grid, 1, 1, (unsigned)s->block, 1, 1, (unsigned)s->lds, s->stream, nullptr, extra));
+    } else {
+      hipLaunchKernelGGL(s->kernel, dim3(s->grid), dim3(s->block), (size_t)s->lds, s->stream, a);
+      HIP_TRY(hipGetLastError());
+    }
     s->lp_ready = true;
     s->n_launches++;
     if (d_draws) row += (m > a.step0) ? (m - a.step0 + thin - 1) / thin : 0;
@@ -243,25 +271,184 @@ const char *amwg_version(void) { return "amwg-mi355x 0.1 (gfx950)"; }
 
 double amwg_exp(double x) { return exp_v8(x); }
 double amwg_log(double x) { return log_v8(x); }
+double amwg_pow(double x, double y) { return pow_v8(x, y); }
+double amwg_ld_host(int32_t id, double x, double a, double b, double c) { return ld_by_id(id, x, a, b, c); }
 double amwg_uniform(uint64_t seed, uint64_t chain, uint64_t index) {
   ChainStream s;
   s.init(seed, chain, index);
   return s.next();
 }
 
-int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t n_params, const double *init,
-                const amwg_comp_opt *comp_opts, const amwg_options *options, amwg_sampler **out) {
-  if (!m || !params || !init || !comp_opts || !options || !out) return fail(AMWG_EINVAL, "amwg_create: null argument");
-  if (n_params < 1 || n_params > kMaxNamed) return fail(AMWG_EINVAL, "amwg_create: %d named parameters (supported: 1..%d)", n_params, kMaxNamed);
+}  // extern "C"
+
+// ---- pieces of construction shared by the built-in and the translated models
+#define TRYB(x) do { int rc_ = (x); if (rc_ != AMWG_OK) return rc_; } while (0)
+#define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(AMWG_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+static int check_options(const amwg_options *options, int max_threads) {
   if (options->chains < 1) return fail(AMWG_EINVAL, "amwg_create: chains must be >= 1");
-  if (m->n_obs < 0) return fail(AMWG_EINVAL, "amwg_create: n_obs < 0");
   const int G_opt = options->lanes_per_chain;
   if (G_opt && (G_opt < 1 || G_opt > 64 || (G_opt & (G_opt - 1)))) return fail(AMWG_EINVAL, "lanes_per_chain must be a power of two in 1..64");
   if (options->block_threads && (options->block_threads % 64 || options->block_threads > 1024 || options->block_threads < 64))
     return fail(AMWG_EINVAL, "block_threads must be a multiple of 64 in 64..1024");
-  if (options->block_threads > model_max_threads(m->model))
-    return fail(AMWG_EINVAL, "block_threads %d exceeds this model's workgroup limit %d", options->block_threads, model_max_threads(m->model));
+  if (options->block_threads > max_threads)
+    return fail(AMWG_EINVAL, "block_threads %d exceeds this model's workgroup limit %d", options->block_threads, max_threads);
+  return AMWG_OK;
+}
 
+// completed params (mcmc.js:357-403) -> flat layout
+static int build_layout(amwg_sampler *s, const amwg_param_desc *params, int n_params) {
+  ParamLayout &pl = s->pl;
+  pl.n_params = n_params;
+  pl.max_top = 1;
+  int P = 0;
+  for (int p = 0; p < n_params; ++p) {
+    const amwg_param_desc &q = params[p];
+    if (q.type != AMWG_REAL && q.type != AMWG_INT && q.type != AMWG_BINARY)
+      return fail(AMWG_EINVAL, "AmwgStepper can't handle parameter %d with type %d", p, q.type);   // mcmc.js:867
+    if (q.len < 1 || q.top < 1 || q.len % q.top) return fail(AMWG_EINVAL, "parameter %d: bad dim (len %d, top %d)", p, q.len, q.top);
+    if (q.top > kMaxTop) return fail(AMWG_EINVAL, "parameter %d: leading dimension %d > %d", p, q.top, kMaxTop);
+    if (!q.multidim && q.len != 1) return fail(AMWG_EINVAL, "parameter %d: dim [1] but len %d", p, q.len);
+    pl.base[p] = P; pl.len[p] = q.len; pl.top[p] = q.top; pl.multidim[p] = q.multidim ? 1 : 0;
+    if (q.multidim && q.top > pl.max_top) pl.max_top = q.top;
+    P += q.len;
+  }
+  pl.P = P;
+  s->P = P;
+  return AMWG_OK;
+}
+
+static int open_device(amwg_sampler *s, hipDeviceProp_t *prop) {
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1) return fail(AMWG_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
+  if (s->device < 0 || s->device >= ndev) return fail(AMWG_EINVAL, "device %d out of range (%d visible)", s->device, ndev);
+  HIPB(hipSetDevice(s->device));
+  HIPB(hipGetDeviceProperties(prop, s->device));
+  HIPB(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIPB(hipEventCreate(&s->ev0));
+  HIPB(hipEventCreate(&s->ev1));
+  return AMWG_OK;
+}
+
+// per-component constants and per-chain state (every chain starts at the same init, mcmc.js:954-957)
+static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int n_params, const double *init,
+                             const amwg_comp_opt *comp_opts) {
+  const int P = s->P;
+  std::vector<CompConst> hcc((size_t)P);
+  s->h_adapt.resize((size_t)P);
+  for (int p = 0, ci = 0; p < n_params; ++p)
+    for (int e2 = 0; e2 < params[p].len; ++e2, ++ci) {
+      const amwg_comp_opt &o = comp_opts[ci];
+      if (o.batch_size < 1) return fail(AMWG_EINVAL, "component %d: batch_size %d < 1", ci, o.batch_size);
+      hcc[ci] = CompConst{params[p].lower, params[p].upper, o.max_adaptation, o.initial_adaptation, o.target_accept_rate,
+                          o.batch_size, params[p].type};
+      s->h_adapt[ci] = o.is_adapting ? 1 : 0;
+    }
+  TRYB(dev_alloc(s, &s->d_cc, (size_t)P));
+  HIPB(hipMemcpy(s->d_cc, hcc.data(), (size_t)P * sizeof(CompConst), hipMemcpyHostToDevice));
+  TRYB(dev_alloc(s, &s->d_adapt, (size_t)P));
+  HIPB(hipMemcpy(s->d_adapt, s->h_adapt.data(), (size_t)P, hipMemcpyHostToDevice));
+
+  const size_t PC = (size_t)P * (size_t)s->C, C = (size_t)s->C;
+  ChainArrays &ch = s->ch;
+  TRYB(dev_alloc(s, &ch.state, PC));
+  TRYB(dev_alloc(s, &ch.prop_log_scale, PC));
+  TRYB(dev_alloc(s, &ch.acceptance_count, PC));
+  TRYB(dev_alloc(s, &ch.iterations_since_adaption, PC));
+  TRYB(dev_alloc(s, &ch.batch_count, PC));
+  TRYB(dev_alloc(s, &ch.accepts, PC));
+  TRYB(dev_alloc(s, &ch.inbounds, PC));
+  TRYB(dev_alloc(s, &ch.perm, C));
+  TRYB(dev_alloc(s, &ch.rng_n, C));
+  TRYB(dev_alloc(s, &ch.lp_curr, C));
+  {
+    std::vector<double> tmp(PC);
+    for (int p = 0; p < P; ++p) for (size_t c = 0; c < C; ++c) tmp[(size_t)p * C + c] = init[p];
+    HIPB(hipMemcpy(ch.state, tmp.data(), PC * 8, hipMemcpyHostToDevice));
+    for (int p = 0; p < P; ++p) for (size_t c = 0; c < C; ++c) tmp[(size_t)p * C + c] = comp_opts[p].prop_log_scale;
+    HIPB(hipMemcpy(ch.prop_log_scale, tmp.data(), PC * 8, hipMemcpyHostToDevice));
+    uint32_t ident = 0;
+    for (int i = 0; i < kMaxNamed; ++i) ident |= (uint32_t)i << (4 * i);
+    std::vector<uint32_t> pv(C, ident);
+    HIPB(hipMemcpy(ch.perm, pv.data(), C * 4, hipMemcpyHostToDevice));
+  }
+  HIPB(hipMemset(ch.acceptance_count, 0, PC * 4));
+  HIPB(hipMemset(ch.iterations_since_adaption, 0, PC * 4));
+  HIPB(hipMemset(ch.batch_count, 0, PC * 4));
+  HIPB(hipMemset(ch.accepts, 0, PC * 4));
+  HIPB(hipMemset(ch.inbounds, 0, PC * 4));
+  HIPB(hipMemset(ch.rng_n, 0, C * 8));
+  HIPB(hipMemset(ch.lp_curr, 0, C * 8));
+  return AMWG_OK;
+}
+
+// ---- hiprtc: a translated closure + the step kernel -> code object for one (lanes, workgroup) geometry
+static std::string user_program(const char *source, int lanes, int block) {
+  std::string p = "#include \"amwg_kernel.h\"\n#include \"amwg_user.h\"\n";
+  p += source;
+  char tail[512];
+  snprintf(tail, sizeof tail,
+           "\nextern \"C\" __global__ void __launch_bounds__(%d) amwg_user_step(const amwg::StepArgs a) {\n"
+           "  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n"
+           "  amwg::step_body<amwg::UserModel, %d>(a, smem);\n}\n",
+           block, lanes);
+  p += tail;
+  return p;
+}
+
+static int compile_user(const char *source, int lanes, int block, const char *arch, std::vector<char> *code) {
+  static const char *names[] = {"amwg_stdint.h", "amwg_types.h", "amwg_math.h", "amwg_div.h", "amwg_ld.h", "amwg_philox.h",
+                                "amwg_kernel.h", "amwg_user.h"};
+  const char *texts[] = {amwg_hdr_stdint, amwg_hdr_types, amwg_hdr_math, amwg_hdr_div, amwg_hdr_ld, amwg_hdr_philox,
+                         amwg_hdr_kernel, amwg_hdr_user};
+  const std::string prog_src = user_program(source, lanes, block);
+  hiprtcProgram prog = nullptr;
+  hiprtcResult r = hiprtcCreateProgram(&prog, prog_src.c_str(), "amwg_user_model.hip", 8, texts, names);
+  if (r != HIPRTC_SUCCESS) return fail(AMWG_EHIP, "hiprtcCreateProgram failed: %s", hiprtcGetErrorString(r));
+  const std::string arch_opt = std::string("--offload-arch=") + arch;
+  // same floating-point contract as the Makefile: one rounding per operation, no fused contraction
+  const char *opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value"};
+  r = hiprtcCompileProgram(prog, 6, opts);
+  if (r != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n ? n : 1, '\0');
+    if (n) hiprtcGetProgramLog(prog, &log[0]);
+    hiprtcDestroyProgram(&prog);
+    g_err = "the translated log_post did not compile (hiprtc): " + log;
+    return AMWG_EINVAL;
+  }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  code->resize(cs);
+  hiprtcGetCode(prog, code->data());
+  hiprtcDestroyProgram(&prog);
+  if (const char *dump = getenv("AMWG_DUMP_CODE_OBJECT")) {   // development aid: inspect the ISA with llvm-objdump
+    if (FILE *f = fopen(dump, "wb")) { fwrite(code->data(), 1, code->size(), f); fclose(f); }
+  }
+  return AMWG_OK;
+}
+
+extern "C" {
+
+int amwg_compile_user(const char *source, int32_t lanes_per_chain, int32_t block_threads, const char *arch, size_t *code_bytes) {
+  if (!source || !arch) return fail(AMWG_EINVAL, "amwg_compile_user: null argument");
+  std::vector<char> code;
+  int rc = compile_user(source, lanes_per_chain, block_threads, arch, &code);
+  if (rc == AMWG_OK && code_bytes) *code_bytes = code.size();
+  return rc;
+}
+
+int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t n_params, const double *init,
+                const amwg_comp_opt *comp_opts, const amwg_options *options, amwg_sampler **out) {
+  if (!m || !params || !init || !comp_opts || !options || !out) return fail(AMWG_EINVAL, "amwg_create: null argument");
+  if (n_params < 1 || n_params > kMaxNamed) return fail(AMWG_EINVAL, "amwg_create: %d named parameters (supported: 1..%d)", n_params, kMaxNamed);
+  if (m->n_obs < 0) return fail(AMWG_EINVAL, "amwg_create: n_obs < 0");
+  {
+    int rc = check_options(options, model_max_threads(m->model));
+    if (rc != AMWG_OK) return rc;
+  }
   amwg_sampler *s = new amwg_sampler();
   s->opt = *options;
   s->model = m->model;
@@ -269,24 +456,12 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   s->n_params = n_params;
   s->device = options->device;
   auto bail = [&](int rc) { amwg_destroy(s); return rc; };
-
-  // ---- parameter layout (completed params, mcmc.js:357-403)
-  ParamLayout &pl = s->pl;
-  pl.n_params = n_params;
-  pl.max_top = 1;
-  int P = 0;
-  for (int p = 0; p < n_params; ++p) {
-    const amwg_param_desc &q = params[p];
-    if (q.type != AMWG_REAL && q.type != AMWG_INT) return bail(fail(AMWG_EINVAL, "AmwgStepper can't handle parameter %d with type %d", p, q.type));
-    if (q.len < 1 || q.top < 1 || q.len % q.top) return bail(fail(AMWG_EINVAL, "parameter %d: bad dim (len %d, top %d)", p, q.len, q.top));
-    if (q.top > kMaxTop) return bail(fail(AMWG_EINVAL, "parameter %d: leading dimension %d > %d", p, q.top, kMaxTop));
-    if (!q.multidim && q.len != 1) return bail(fail(AMWG_EINVAL, "parameter %d: dim [1] but len %d", p, q.len));
-    pl.base[p] = P; pl.len[p] = q.len; pl.top[p] = q.top; pl.multidim[p] = q.multidim ? 1 : 0;
-    if (q.multidim && q.top > pl.max_top) pl.max_top = q.top;
-    P += q.len;
-  }
-  pl.P = P;
-  s->P = P;
+#undef TRYB
+#undef HIPB
+#define TRYB(x) do { int rc_ = (x); if (rc_ != AMWG_OK) return bail(rc_); } while (0)
+#define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(AMWG_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
+  TRYB(build_layout(s, params, n_params));
+  const int P = s->P;
 
   // ---- model / data checks
   const int N = m->n_obs;
@@ -312,20 +487,8 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
     default: return bail(fail(AMWG_EINVAL, "unknown model id %d", m->model));
   }
 
-  // ---- device
-  int ndev = 0;
-  hipError_t e = hipGetDeviceCount(&ndev);
-  if (e != hipSuccess || ndev < 1) return bail(fail(AMWG_EHIP, "no HIP device available (%s)", hipGetErrorString(e)));
-  if (s->device < 0 || s->device >= ndev) return bail(fail(AMWG_EINVAL, "device %d out of range (%d visible)", s->device, ndev));
-#define TRYB(x) do { int rc_ = (x); if (rc_ != AMWG_OK) return bail(rc_); } while (0)
-#define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(AMWG_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
-  HIPB(hipSetDevice(s->device));
   hipDeviceProp_t prop;
-  HIPB(hipGetDeviceProperties(&prop, s->device));
-  HIPB(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  HIPB(hipEventCreate(&s->ev0));
-  HIPB(hipEventCreate(&s->ev1));
-
+  TRYB(open_device(s, &prop));
   // ---- model constants, with the kernel's own log (same roundings as the reference expression trees)
   ModelConsts &mc = s->mc;
   mc.neg_half_log_2pi = -0.5 * log_v8(2 * kPi);
@@ -409,58 +572,81 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   }
   mc.data_mid_range = mid ? 1 : 0;
 
-  // ---- per-component constants and per-chain state
-  std::vector<CompConst> hcc((size_t)P);
-  s->h_adapt.resize((size_t)P);
-  for (int p = 0, ci = 0; p < n_params; ++p)
-    for (int e2 = 0; e2 < params[p].len; ++e2, ++ci) {
-      const amwg_comp_opt &o = comp_opts[ci];
-      if (o.batch_size < 1) return bail(fail(AMWG_EINVAL, "component %d: batch_size %d < 1", ci, o.batch_size));
-      hcc[ci] = CompConst{params[p].lower, params[p].upper, o.max_adaptation, o.initial_adaptation, o.target_accept_rate,
-                          o.batch_size, params[p].type};
-      s->h_adapt[ci] = o.is_adapting ? 1 : 0;
-    }
-  TRYB(dev_alloc(s, &s->d_cc, (size_t)P));
-  HIPB(hipMemcpy(s->d_cc, hcc.data(), (size_t)P * sizeof(CompConst), hipMemcpyHostToDevice));
-  TRYB(dev_alloc(s, &s->d_adapt, (size_t)P));
-  HIPB(hipMemcpy(s->d_adapt, s->h_adapt.data(), (size_t)P, hipMemcpyHostToDevice));
-
-  const size_t PC = (size_t)P * (size_t)s->C, C = (size_t)s->C;
-  ChainArrays &ch = s->ch;
-  TRYB(dev_alloc(s, &ch.state, PC));
-  TRYB(dev_alloc(s, &ch.prop_log_scale, PC));
-  TRYB(dev_alloc(s, &ch.acceptance_count, PC));
-  TRYB(dev_alloc(s, &ch.iterations_since_adaption, PC));
-  TRYB(dev_alloc(s, &ch.batch_count, PC));
-  TRYB(dev_alloc(s, &ch.accepts, PC));
-  TRYB(dev_alloc(s, &ch.inbounds, PC));
-  TRYB(dev_alloc(s, &ch.perm, C));
-  TRYB(dev_alloc(s, &ch.rng_n, C));
-  TRYB(dev_alloc(s, &ch.lp_curr, C));
-  {
-    std::vector<double> tmp(PC);
-    for (int p = 0; p < P; ++p) for (size_t c = 0; c < C; ++c) tmp[(size_t)p * C + c] = init[p];
-    HIPB(hipMemcpy(ch.state, tmp.data(), PC * 8, hipMemcpyHostToDevice));
-    for (int p = 0; p < P; ++p) for (size_t c = 0; c < C; ++c) tmp[(size_t)p * C + c] = comp_opts[p].prop_log_scale;
-    HIPB(hipMemcpy(ch.prop_log_scale, tmp.data(), PC * 8, hipMemcpyHostToDevice));
-    uint32_t ident = 0;
-    for (int i = 0; i < kMaxNamed; ++i) ident |= (uint32_t)i << (4 * i);
-    std::vector<uint32_t> pv(C, ident);
-    HIPB(hipMemcpy(ch.perm, pv.data(), C * 4, hipMemcpyHostToDevice));
-  }
-  HIPB(hipMemset(ch.acceptance_count, 0, PC * 4));
-  HIPB(hipMemset(ch.iterations_since_adaption, 0, PC * 4));
-  HIPB(hipMemset(ch.batch_count, 0, PC * 4));
-  HIPB(hipMemset(ch.accepts, 0, PC * 4));
-  HIPB(hipMemset(ch.inbounds, 0, PC * 4));
-  HIPB(hipMemset(ch.rng_n, 0, C * 8));
-  HIPB(hipMemset(ch.lp_curr, 0, C * 8));
+  TRYB(alloc_chain_state(s, params, n_params, init, comp_opts));
 
   // ---- geometry.  The constructor's warm-up log_post (mcmc.js:961-963) is folded into the first
   // launch (StepArgs.init_lp); amwg_chain_diag forces it with a 0-step launch if asked earlier.
   const size_t max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
   TRYB(choose_geometry(s, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, max_lds));
   HIPB(hipFuncSetAttribute(reinterpret_cast<const void *>(s->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds));
+  HIPB(hipStreamSynchronize(s->stream));
+  *out = s;
+  return AMWG_OK;
+}
+
+int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, int32_t n_params, const double *init,
+                     const amwg_comp_opt *comp_opts, const amwg_options *options, amwg_sampler **out) {
+  if (!m || !m->source || !params || !init || !comp_opts || !options || !out) return fail(AMWG_EINVAL, "amwg_create_user: null argument");
+  if (n_params < 1 || n_params > kMaxNamed) return fail(AMWG_EINVAL, "amwg_create_user: %d named parameters (supported: 1..%d)", n_params, kMaxNamed);
+  if (m->n_arrays < 0 || m->n_arrays > kMaxUserArrays) return fail(AMWG_EINVAL, "amwg_create_user: %d data arrays (supported: 0..%d)", m->n_arrays, kMaxUserArrays);
+  if (m->n_arrays && (!m->arrays || !m->array_len)) return fail(AMWG_EINVAL, "amwg_create_user: arrays is null");
+  if (m->n_derived < 0 || m->lds_bytes < 0) return fail(AMWG_EINVAL, "amwg_create_user: negative size");
+  const int max_threads = m->max_threads > 0 ? (m->max_threads / 64) * 64 : 1024;
+  if (max_threads < 64 || max_threads > 1024) return fail(AMWG_EINVAL, "amwg_create_user: max_threads must be in 64..1024");
+  {
+    int rc = check_options(options, max_threads);
+    if (rc != AMWG_OK) return rc;
+  }
+  amwg_sampler *s = new amwg_sampler();
+  s->opt = *options;
+  s->model = 0;
+  s->user = true;
+  s->D = m->n_derived;
+  s->user_lds = (m->lds_bytes + 15) & ~15;
+  s->user_parallel = m->parallel ? 1 : 0;
+  s->user_max_threads = max_threads;
+  s->C = options->chains;
+  s->n_params = n_params;
+  s->device = options->device;
+  auto bail = [&](int rc) { amwg_destroy(s); return rc; };
+  TRYB(build_layout(s, params, n_params));
+  hipDeviceProp_t prop;
+  TRYB(open_device(s, &prop));
+
+  // ---- data: every array the closure reads, as f64, row-major
+  DataRef &d = s->d;
+  d.n_obs = 0;
+  for (int j = 0; j < m->n_arrays; ++j) {
+    const int64_t n = m->array_len[j];
+    if (n < 0 || (n && !m->arrays[j])) return bail(fail(AMWG_EINVAL, "amwg_create_user: array %d is null or has a negative length", j));
+    double *p = nullptr;
+    TRYB(dev_alloc(s, &p, (size_t)n));
+    if (n) HIPB(hipMemcpy(p, m->arrays[j], (size_t)n * 8, hipMemcpyHostToDevice));
+    d.arr[j] = p;
+  }
+  TRYB(alloc_chain_state(s, params, n_params, init, comp_opts));
+
+  const size_t max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
+  TRYB(choose_geometry(s, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, max_lds));
+
+  // ---- compile for this geometry (cached per process by source text + geometry + arch) and load on this device
+  {
+    static std::mutex mu;
+    static std::map<std::string, std::vector<char>> cache;
+    const std::string key = std::string(prop.gcnArchName) + "|" + std::to_string(s->lanes) + "|" + std::to_string(s->block) + "|" + m->source;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+      std::vector<char> code;
+      TRYB(compile_user(m->source, s->lanes, s->block, prop.gcnArchName, &code));
+      it = cache.emplace(key, std::move(code)).first;
+    }
+    HIPB(hipModuleLoadData(&s->user_module, it->second.data()));
+    HIPB(hipModuleGetFunction(&s->user_fn, s->user_module, "amwg_user_step"));
+  }
+  // workgroups of this kernel use up to the whole 160 KB LDS of a CU; not every runtime needs (or accepts) the opt-in for module functions
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(s->user_fn), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds);
+  (void)hipGetLastError();
   HIPB(hipStreamSynchronize(s->stream));
   *out = s;
   return AMWG_OK;
@@ -474,6 +660,7 @@ int amwg_destroy(amwg_sampler *s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (void *p : s->dev_allocs) (void)hipFree(p);
   if (s->d_draws) (void)hipFree(s->d_draws);
+  if (s->user_module) (void)hipModuleUnload(s->user_module);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -496,7 +683,7 @@ int amwg_burn(amwg_sampler *s, int64_t n) {
 int amwg_sample_device(amwg_sampler *s, int64_t n, int64_t thin, double *out_dev, size_t out_bytes) {
   if (!s || n < 0 || thin < 1 || (!out_dev && n > 0)) return fail(AMWG_EINVAL, "amwg_sample_device: bad argument");
   const int64_t rows = (n + thin - 1) / thin;
-  const size_t need = (size_t)rows * (size_t)s->P * (size_t)s->C * 8;
+  const size_t need = (size_t)rows * (size_t)(s->P + s->D) * (size_t)s->C * 8;
   if (out_bytes < need) return fail(AMWG_ESIZE, "amwg_sample: output needs %zu bytes, got %zu", need, out_bytes);
   HIP_TRY(hipSetDevice(s->device));
   int rc = launch_steps(s, n, thin, out_dev);
@@ -509,7 +696,7 @@ int amwg_sample_device(amwg_sampler *s, int64_t n, int64_t thin, double *out_dev
 int amwg_sample_async(amwg_sampler *s, int64_t n, int64_t thin) {
   if (!s || n < 0 || thin < 1) return fail(AMWG_EINVAL, "amwg_sample: bad argument");
   const int64_t rows = (n + thin - 1) / thin;
-  const size_t need = (size_t)rows * (size_t)s->P * (size_t)s->C * 8;
+  const size_t need = (size_t)rows * (size_t)(s->P + s->D) * (size_t)s->C * 8;
   HIP_TRY(hipSetDevice(s->device));
   if (need > s->d_draws_cap) {
     if (s->d_draws) { (void)hipFree(s->d_draws); s->d_draws = nullptr; s->d_draws_cap = 0; }
@@ -526,7 +713,7 @@ int amwg_sample_async(amwg_sampler *s, int64_t n, int64_t thin) {
 int amwg_fetch_draws(amwg_sampler *s, double *out, size_t out_bytes) {
   if (!s) return fail(AMWG_EINVAL, "amwg_fetch_draws: null sampler");
   if (s->last_draws != s->d_draws) return fail(AMWG_EINVAL, "amwg_fetch_draws: no amwg_sample_async pending");
-  const size_t need = (size_t)s->last_rows * (size_t)s->P * (size_t)s->C * 8;
+  const size_t need = (size_t)s->last_rows * (size_t)(s->P + s->D) * (size_t)s->C * 8;
   if (need && !out) return fail(AMWG_EINVAL, "amwg_fetch_draws: null output");
   if (out_bytes < need) return fail(AMWG_ESIZE, "amwg_sample: output needs %zu bytes, got %zu", need, out_bytes);
   HIP_TRY(hipSetDevice(s->device));
@@ -540,7 +727,7 @@ int amwg_fetch_draws(amwg_sampler *s, double *out, size_t out_bytes) {
 int amwg_sample(amwg_sampler *s, int64_t n, int64_t thin, double *out, size_t out_bytes) {
   if (!s || n < 0 || thin < 1 || (!out && n > 0)) return fail(AMWG_EINVAL, "amwg_sample: bad argument");
   const int64_t rows = (n + thin - 1) / thin;
-  const size_t need = (size_t)rows * (size_t)s->P * (size_t)s->C * 8;
+  const size_t need = (size_t)rows * (size_t)(s->P + s->D) * (size_t)s->C * 8;
   if (out_bytes < need) return fail(AMWG_ESIZE, "amwg_sample: output needs %zu bytes, got %zu", need, out_bytes);
   int rc = amwg_sample_async(s, n, thin);
   if (rc != AMWG_OK) return rc;
@@ -618,11 +805,12 @@ int amwg_last_sample_moments(amwg_sampler *s, double *mean, double *sd) {
   if (!s->last_draws || s->last_rows < 1) return fail(AMWG_EINVAL, "amwg_last_sample_moments: no sample() call yet");
   HIP_TRY(hipSetDevice(s->device));
   double *dm = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dm), (size_t)s->P * 16));
-  hipLaunchKernelGGL(moments_kernel, dim3(s->P), dim3(1024), 0, s->stream, s->last_draws, s->last_rows, s->P, s->C, dm, dm + s->P);
+  const int PR = s->P + s->D;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dm), (size_t)PR * 16));
+  hipLaunchKernelGGL(moments_kernel, dim3(PR), dim3(1024), 0, s->stream, s->last_draws, s->last_rows, PR, s->C, dm, dm + PR);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(mean, dm, (size_t)s->P * 8, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(sd, dm + s->P, (size_t)s->P * 8, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(mean, dm, (size_t)PR * 8, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(sd, dm + PR, (size_t)PR * 8, hipMemcpyDeviceToHost, s->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
   (void)hipFree(dm);
   if (e != hipSuccess) return fail(AMWG_EHIP, "moments kernel failed: %s", hipGetErrorString(e));
@@ -630,6 +818,7 @@ int amwg_last_sample_moments(amwg_sampler *s, double *mean, double *sd) {
 }
 
 int amwg_num_components(const amwg_sampler *s) { return s ? s->P : 0; }
+int amwg_num_recorded(const amwg_sampler *s) { return s ? s->P + s->D : 0; }
 int64_t amwg_num_chains(const amwg_sampler *s) { return s ? s->C : 0; }
 
 int amwg_launch_info(const amwg_sampler *s, int32_t *lanes, int32_t *block, int32_t *grid, int32_t *lds, int32_t *n_launches, double *kernel_ms) {
@@ -640,6 +829,23 @@ int amwg_launch_info(const amwg_sampler *s, int32_t *lanes, int32_t *block, int3
   if (lds) *lds = s->lds;
   if (n_launches) *n_launches = s->n_launches;
   if (kernel_ms) *kernel_ms = s->kernel_ms;
+  return AMWG_OK;
+}
+
+int amwg_ld_device(int32_t device, int64_t n, const double *records, double *out) {
+  if (!records || !out || n < 0) return fail(AMWG_EINVAL, "amwg_ld_device: bad argument");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1) return fail(AMWG_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
+  HIP_TRY(hipSetDevice(device));
+  double *dr = nullptr, *dout = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dr), n ? (size_t)n * 40 : 8));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dout), n ? (size_t)n * 8 : 8));
+  HIP_TRY(hipMemcpy(dr, records, (size_t)n * 40, hipMemcpyHostToDevice));
+  if (n) hipLaunchKernelGGL(amwg_ld_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, dr, dout);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(dr); (void)hipFree(dout);
   return AMWG_OK;
 }
 

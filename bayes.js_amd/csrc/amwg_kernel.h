@@ -27,9 +27,12 @@
 // twice per update (mcmc.js:524-526); the current state's value is cached per chain, which
 // is exact because log_post is a pure function of the state.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
+#endif
 
-#include "amwg_models.h"
+#include "amwg_div.h"
+#include "amwg_ld.h"
 #include "amwg_philox.h"
 #include "amwg_types.h"
 
@@ -71,30 +74,31 @@ __device__ __forceinline__ double pass_over_data(const typename Model::Pass &ps,
   return acc;
 }
 
-template <class T> struct has_fast { static constexpr bool value = false; };
-template <> struct has_fast<NormalModel> { static constexpr bool value = true; };
-template <> struct has_fast<HierNormalModel> { static constexpr bool value = true; };
-template <class T> struct has_one_lane_pass { static constexpr bool value = false; };
-template <> struct has_one_lane_pass<BetaBernModel> { static constexpr bool value = true; };
-
 // log_post(state) in the documented order: lane 0 of the chain starts from the prior sum
 // (accumulated sequentially as the closure does), every lane adds its observations in
 // increasing index order, then the xor butterfly.  For G = 1 this is the reference's order.
 template <class Model, int G>
 __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a, const unsigned char *smem, int sub) {
-  const typename Model::Pass ps = Model::begin(S, a.mc, a.d, smem);
-  const double prior = Model::prior(S, a.mc, a.d);
-  double acc = (sub == 0) ? prior : 0.0;
-  if constexpr (has_fast<Model>::value) {
-    if (ps.fast) acc = pass_over_data<Model, true, G>(ps, a.d.n_obs, sub, acc);
-    else acc = pass_over_data<Model, false, G>(ps, a.d.n_obs, sub, acc);
-  } else if constexpr (has_one_lane_pass<Model>::value && G == 1) {
-    acc = Model::pass_one_lane(ps, a.d.n_obs, acc);
+  double acc;
+  if constexpr (Model::kUser) {
+    // translated closure: the generated body returns this lane's partial sum (lane 0 carries every
+    // term outside the lane-split loops), see bayes.js_amd/translate.js
+    acc = Model::template eval<G, false>(S, a.d, smem, sub, nullptr);
   } else {
-    acc = pass_over_data<Model, false, G>(ps, a.d.n_obs, sub, acc);
-  }
-  if constexpr (has_one_lane_pass<Model>::value) {
-    if (ps.has_invalid) acc = acc + (-kInf);   // some x_i outside {0,1}: that term is -inf wherever it sits in the sum
+    const typename Model::Pass ps = Model::begin(S, a.mc, a.d, smem);
+    const double prior = Model::prior(S, a.mc, a.d);
+    acc = (sub == 0) ? prior : 0.0;
+    if constexpr (Model::kHasFast) {
+      if (ps.fast) acc = pass_over_data<Model, true, G>(ps, a.d.n_obs, sub, acc);
+      else acc = pass_over_data<Model, false, G>(ps, a.d.n_obs, sub, acc);
+    } else if constexpr (Model::kOneLanePass && G == 1) {
+      acc = Model::pass_one_lane(ps, a.d.n_obs, acc);
+    } else {
+      acc = pass_over_data<Model, false, G>(ps, a.d.n_obs, sub, acc);
+    }
+    if constexpr (Model::kOneLanePass) {
+      if (ps.has_invalid) acc = acc + (-kInf);   // some x_i outside {0,1}: that term is -inf wherever it sits in the sum
+    }
   }
 #pragma unroll
   for (int off = 1; off < G; off <<= 1) acc = acc + __shfl_xor(acc, off, 64);
@@ -119,9 +123,15 @@ __device__ __forceinline__ uint32_t perm_swap(uint32_t perm, int i, int j) {
   return perm ^ (d << (4 * i)) ^ (d << (4 * j));
 }
 
+// Math.max of two numbers (mcmc.js:758): NaN if either is NaN, +0 > -0.
+__device__ __forceinline__ double js_max2(double a, double b) {
+  if (a != a || b != b) return __builtin_nan("");
+  if (a == b) return (a == 0 && __builtin_signbit(a)) ? b : a;
+  return a > b ? a : b;
+}
+
 template <class Model, int G>
-__global__ void __launch_bounds__(Model::kMaxThreads) amwg_step_kernel(const StepArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int CPB = nt / G;
   const int c_in = tid / G, sub = tid % G;
@@ -164,6 +174,8 @@ __global__ void __launch_bounds__(Model::kMaxThreads) amwg_step_kernel(const Ste
   if (a.init_lp) lp_curr = log_post<Model, G>(S, a, data_lds, sub);  // ctor warm-up call, mcmc.js:961-963
 
   const int n_named = pl->n_params;
+  constexpr int D = Model::kDerived;
+  const int PR = P + D;   // recorded values per draw: the parameters, then the closure's derived quantities
   int64_t row = a.row0;
   int32_t next_rec = (int32_t)a.step0;  // host passes steps-until-first-recorded-step here
 
@@ -171,7 +183,16 @@ __global__ void __launch_bounds__(Model::kMaxThreads) amwg_step_kernel(const Ste
     // ---- Sampler.sample: record the state BEFORE the step (mcmc.js:1020-1027)
     if (a.draws != nullptr && step == next_rec) {
       if (writer)
-        for (int p = 0; p < P; ++p) a.draws[(row * P + p) * C + cl] = S(p);
+        for (int p = 0; p < P; ++p) a.draws[(row * PR + p) * C + cl] = S(p);
+      if constexpr (D > 0) {
+        // derived quantities (`state.var = ...` inside log_post, mcmc.js:961-963, 990-995): the
+        // reference re-evaluates log_post at the end of every step, so what sample() records is the
+        // closure's assignment at the recorded state.
+        double dv[D];
+        (void)Model::template eval<G, true>(S, a.d, data_lds, sub, dv);
+        if (writer)
+          for (int q = 0; q < D; ++q) a.draws[(row * PR + P + q) * C + cl] = dv[q];
+      }
       ++row;
       next_rec += a.thin;
     }
@@ -202,13 +223,33 @@ __global__ void __launch_bounds__(Model::kMaxThreads) amwg_step_kernel(const Ste
       }
       if (++e == len) { e = 0; ++np; }
 
-      // ---- OnedimMetropolisStepper.step (mcmc.js:517-553)
       const CompConst k = cc[comp];
       const int64_t gi = (int64_t)comp * C + cl;
+      if (k.type == kTypeBinary) {
+        // ---- BinaryStepper.step (mcmc.js:753-767): both states evaluated, 0 chosen with
+        // probability exp(z - log(exp(z) + exp(o))) after subtracting the larger log density
+        const double old = S(comp);
+        Sme[comp] = 0.0;
+        const double zero_ld = log_post<Model, G>(S, a, data_lds, sub);
+        Sme[comp] = 1.0;
+        const double one_ld = log_post<Model, G>(S, a, data_lds, sub);
+        const double mx = js_max2(zero_ld, one_ld);
+        const double z = zero_ld - mx, o = one_ld - mx;
+        const double zero_prob = exp_v8(z - log_v8(exp_v8(z) + exp_v8(o)));
+        double now = 1.0;
+        lp_curr = one_ld;
+        if (rng.next() < zero_prob) { Sme[comp] = 0.0; now = 0.0; lp_curr = zero_ld; }
+        if (writer) {   // run totals: evaluations and flips
+          a.ch.inbounds[gi] += 1;
+          if (now != old) a.ch.accepts[gi] += 1;
+        }
+        continue;
+      }
+      // ---- OnedimMetropolisStepper.step (mcmc.js:517-553)
       double pls = PLSme[comp];
       const double cur = S(comp);
       double prop = rnorm_js(rng, cur, exp_v8(pls));
-      if (k.type == 1) prop = js_round(prop);
+      if (k.type == kTypeInt) prop = js_round(prop);
       const bool inb = !(prop < k.lower || prop > k.upper);
       bool accepted = false;
       if (inb) {
@@ -256,28 +297,10 @@ __global__ void __launch_bounds__(Model::kMaxThreads) amwg_step_kernel(const Ste
   }
 }
 
-// ---- device evaluation of the arithmetic building blocks (tests only; amwg_device_eval)
-__global__ void amwg_eval_kernel(int op, int64_t n, const double *a, const double *b, const double *c, double *out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double x = a[i], y = b ? b[i] : 0.0, z = c ? c[i] : 0.0;
-  double r = 0;
-  switch (op) {
-    case 0: r = exp_v8(x); break;
-    case 1: r = log_v8(x); break;
-    case 2: r = __builtin_sqrt(x); break;
-    case 3: r = lgamma_js(x); break;
-    case 4: r = div_by_invariant(x, y, make_reciprocal(y)); break;
-    case 5: r = x / y; break;
-    case 6: r = ld_norm(x, y, z); break;
-    case 7: r = js_round(x); break;
-    case 8: { ChainStream s; s.init((uint64_t)x, (uint64_t)y, (uint64_t)z); r = s.next(); } break;
-    case 9: r = ld_pois(x, y); break;
-    case 10: r = ld_beta(x, y, z); break;
-    case 11: r = ld_bern(x, y); break;
-    case 12: r = ld_unif(x, y, z); break;
-  }
-  out[i] = r;
+template <class Model, int G>
+__global__ void __launch_bounds__(Model::kMaxThreads) amwg_step_kernel(const StepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  step_body<Model, G>(a, smem);
 }
 
 }  // namespace amwg

@@ -3,6 +3,8 @@
 //   lgamma / lfactorial / lbeta   distributions.js:63-77, 79-82, 89-92
 //   ld.beta   :104-113     ld.norm  :119-121     ld.unif  :221-223
 //   ld.bern   :228-230     ld.pois  :282-284
+//   cauchy, laplace/dexp, gamma, invgamma, lnorm, pareto, t, weibull, logis, exp, binom, nbinom,
+//   hyper, lchoose            distributions.js:84-86, 115-280 (cited per function below)
 // Math.pow(t, 2) is evaluated as t*t: V8 returns exactly that for exponent 2 (pinned by the
 // golden trajectories, which would diverge otherwise).
 #pragma once
@@ -37,6 +39,69 @@ AMWG_HD double ld_beta(double x, double a, double b) {
 }
 AMWG_HD double ld_bern(double x, double p) { return !(x == 0 || x == 1) ? -kInf : log_v8(x * p + (1 - x) * (1 - p)); }
 AMWG_HD double ld_pois(double x, double lambda) { return x < 0 ? -kInf : log_v8(lambda) * x - lambda - lfactorial_js(x); }
+
+// ---- the remaining scalar densities of distributions.js, same expression trees.
+// pow(t, 2) is t*t (V8's pow special case), general exponents go through pow_v8.
+AMWG_HD double lchoose_js(double n, double k) { return lfactorial_js(n) - lfactorial_js(k) - lfactorial_js(n - k); }   // :84-86
+AMWG_HD double ld_cauchy(double x, double location, double scale) {   // :115-117
+  const double t = x - location;
+  return log_v8(scale) - log_v8(t * t + scale * scale) - log_v8(kPi);
+}
+AMWG_HD double ld_laplace(double x, double location, double scale) {  // :136-138 (ld.dexp is the same function)
+  return (-__builtin_fabs(x - location) / scale) - log_v8(2 * scale);
+}
+AMWG_HD double ld_gamma(double x, double shape, double rate) {   // :142-152
+  const double scale = 1 / rate;
+  if (x < 0) return -kInf;
+  if (x == 0 && shape == 1) return -log_v8(scale);
+  return (shape - 1) * log_v8(x) - x / scale - lgamma_js(shape) - shape * log_v8(scale);
+}
+AMWG_HD double ld_invgamma(double x, double shape, double scale) {   // :154-159
+  if (x <= 0) return -kInf;
+  return -(shape + 1) * log_v8(x) - scale / x - lgamma_js(shape) + shape * log_v8(scale);
+}
+AMWG_HD double ld_lnorm(double x, double meanlog, double sdlog) {   // :161-167
+  if (x <= 0) return -kInf;
+  const double t = log_v8(x) - meanlog;
+  return -log_v8(x) - 0.5 * log_v8(2 * kPi) - log_v8(sdlog) - (t * t) / (2 * sdlog * sdlog);
+}
+AMWG_HD double ld_pareto(double x, double scale, double shape) {   // :169-174
+  if (x < scale) return -kInf;
+  return log_v8(shape) + shape * log_v8(scale) - (shape + 1) * log_v8(x);
+}
+AMWG_HD double ld_t(double x, double location, double scale, double df) {   // :176-180
+  df = df > 1e100 ? 1e100 : df;
+  const double q = (x - location) / scale;
+  return lgamma_js((df + 1) / 2) - lgamma_js(df / 2) - log_v8(__builtin_sqrt(kPi * df) * scale) +
+         log_v8(pow_v8(1 + (1 / df) * (q * q), -(df + 1) / 2));
+}
+AMWG_HD double ld_weibull(double x, double shape, double scale) {   // :185-191
+  if (x < 0) return -kInf;
+  if (x == 0 && shape < 1) return kInf;
+  const double tmp1 = pow_v8(x / scale, shape - 1);
+  const double tmp2 = tmp1 * (x / scale);
+  return -tmp2 + log_v8(shape * tmp1 / scale);
+}
+AMWG_HD double ld_logis(double x, double location, double scale) {   // :196-201
+  x = __builtin_fabs((x - location) / scale);
+  const double e = exp_v8(-x);
+  const double f = 1.0 + e;
+  return -(x + log_v8(scale * f * f));
+}
+AMWG_HD double ld_exp(double x, double rate) { return x < 0 ? -kInf : log_v8(rate) - rate * x; }   // :217-219
+AMWG_HD double ld_binom(double x, double size, double prob) {   // :240-248
+  if (x > size || x < 0) return -kInf;
+  if (prob == 0 || prob == 1) return (size * prob) == x ? 0.0 : -kInf;
+  return lchoose_js(size, x) + x * log_v8(prob) + (size - x) * log_v8(1 - prob);
+}
+AMWG_HD double ld_nbinom(double x, double size, double prob) {   // :267-272
+  if (x < 0) return -kInf;
+  return lchoose_js(x + size - 1, size - 1) + x * log_v8(1 - prob) + size * log_v8(prob);
+}
+AMWG_HD double ld_hyper(double x, double m, double n, double k) {   // :274-280
+  if (x < 0 || x > k) return -kInf;
+  return lchoose_js(m, x) + lchoose_js(n, k - x) - lchoose_js(m + n, k);
+}
 
 // ld.norm split into its loop-invariant part and its per-observation part: for a whole pass
 // over the data (mean, sd) are fixed, so   ld.norm(x) = c - (x-mean)^2 / den   with

@@ -12,15 +12,6 @@
 
 namespace amwg {
 
-// LDS-resident view of this chain's state: component p at S.base[p].  Chains are laid out
-// [chain][stride] with an ODD stride (in doubles): lanes that own different chains and read the
-// same component hit 32 distinct 8-byte bank slots, and the G lanes of one chain that gather
-// different components (theta[g_i]) read consecutive addresses -- conflict-free both ways.
-struct StateView {
-  const double *base;
-  __device__ __forceinline__ double operator()(int p) const { return base[p]; }
-};
-
 // ld.norm(v, 0|m, sd) with constant sd (a prior): c_sd - (v-m)^2 / (2*sd*sd)
 __device__ __forceinline__ double norm_const_sd(double v, double m, double c_sd, double den) {
   const double t = v - m;
@@ -30,7 +21,8 @@ __device__ __forceinline__ double norm_const_sd(double v, double m, double c_sd,
 // ---------------------------------------------------------------------------------------------
 // x_i ~ norm(mu, sigma); mu ~ norm(m0,s0); sigma ~ unif(a,b)              README.md:22-36
 struct NormalModel {
-  static constexpr bool kDataInLds = true;
+  static constexpr bool kUser = false, kHasFast = true, kOneLanePass = false;
+  static constexpr int kDerived = 0;
   static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
   static constexpr int kUnroll = 8;   // independent terms in flight per lane (ILP across the division chains)
   struct Pass { double mu, c, den; Reciprocal y; bool fast; const double *x; };
@@ -72,7 +64,8 @@ struct NormalModel {
 // ld.bern(x,p) = log(x*p + (1-x)*(1-p)) is exactly log(p) for x=1 and log(1-p) for x=0
 // (1*p + 0*(1-p) = p + 0 = p), so the two logs are hoisted and selected per observation.
 struct BetaBernModel {
-  static constexpr bool kDataInLds = true;
+  static constexpr bool kUser = false, kHasFast = false, kOneLanePass = true;
+  static constexpr int kDerived = 0;
   static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
   static constexpr int kUnroll = 8;
   struct Pass { double l1, l0; const uint8_t *x; const uint32_t *bits; bool has_invalid; };
@@ -209,7 +202,8 @@ struct BetaBernModel {
 // y_i ~ norm(theta[g_i], sigma); theta_g ~ norm(mu,10); mu ~ norm(0,100); sigma ~ unif(0,100)
 // components: theta[0..G-1], mu, sigma                                    SURVEY.md §8(d) cfg4
 struct HierNormalModel {
-  static constexpr bool kDataInLds = true;
+  static constexpr bool kUser = false, kHasFast = true, kOneLanePass = false;
+  static constexpr int kDerived = 0;
   static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
   static constexpr int kUnroll = 8;
   struct Pass { double c, den; Reciprocal y; bool fast; const double *x; const uint8_t *g; StateView S; };
@@ -257,7 +251,8 @@ struct HierNormalModel {
 // G lanes of a chain read consecutive observations of one column (coalesced); the per-observation
 // exp+log dominate the arithmetic by two orders of magnitude.
 struct PoisGlmModel {
-  static constexpr bool kDataInLds = false;
+  static constexpr bool kUser = false, kHasFast = false, kOneLanePass = false;
+  static constexpr int kDerived = 0;
   static constexpr int kMaxThreads = 256;    // exp+log per observation want > 128 VGPRs; no LDS tile to share anyway
   static constexpr int kUnroll = 2;   // exp+log per term: more would spill
   struct Pass { double b[8]; double cp; const double *X, *y, *lfact; int N; };

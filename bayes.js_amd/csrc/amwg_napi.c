@@ -127,33 +127,21 @@ static amwg_sampler *unwrap(napi_env env, napi_value v) {
   return *box;
 }
 
-/* create(model, params[], init Float64Array, compOpts[], options) -> external handle */
-static napi_value Create(napi_env env, napi_callback_info info) {
-  napi_value a[5];
-  if (!get_args(env, info, 5, a)) return NULL;
-  amwg_model_desc md;
-  memset(&md, 0, sizeof md);
-  md.model = (int32_t)prop_i64(env, a[0], "model", 0);
-  md.n_obs = (int32_t)prop_i64(env, a[0], "n_obs", 0);
-  md.G = (int32_t)prop_i64(env, a[0], "G", 0);
-  md.K = (int32_t)prop_i64(env, a[0], "K", 0);
-  napi_value v;
-  size_t n = 0;
-  if (prop(env, a[0], "x", &v)) md.x = (const double *)typed_data(env, v, napi_float64_array, &n);
-  if (prop(env, a[0], "y", &v)) md.y = (const double *)typed_data(env, v, napi_float64_array, &n);
-  if (prop(env, a[0], "g", &v)) md.g = (const int32_t *)typed_data(env, v, napi_int32_array, &n);
-  if (prop(env, a[0], "hyper", &v)) {
-    const double *h = (const double *)typed_data(env, v, napi_float64_array, &n);
-    for (size_t i = 0; h && i < n && i < 8; i++) md.hyper[i] = h[i];
-  }
+static int64_t arg_i64(napi_env env, napi_value v);
+
+/* params[], init, compOpts[], options -> C descriptors (caller frees *pd and *co) */
+static int parse_common(napi_env env, napi_value *a /* [1]=params [2]=init [3]=compOpts [4]=options */, amwg_param_desc **pd_out,
+                        amwg_comp_opt **co_out, uint32_t *n_params_out, const double **init_out, amwg_options *op) {
   uint32_t n_params = 0, n_comp = 0;
-  NAPI_OK(napi_get_array_length(env, a[1], &n_params));
-  NAPI_OK(napi_get_array_length(env, a[3], &n_comp));
+  if (napi_get_array_length(env, a[1], &n_params) != napi_ok || napi_get_array_length(env, a[3], &n_comp) != napi_ok) {
+    napi_throw_type_error(env, NULL, "amwg_napi.create: params and compOpts must be arrays");
+    return 0;
+  }
   size_t n_init = 0;
   const double *init = (const double *)typed_data(env, a[2], napi_float64_array, &n_init);
   if (!init || n_init != n_comp || n_params < 1) {
     napi_throw_type_error(env, NULL, "amwg_napi.create: init must be a Float64Array with one value per component");
-    return NULL;
+    return 0;
   }
   amwg_param_desc *pd = (amwg_param_desc *)calloc(n_params, sizeof *pd);
   amwg_comp_opt *co = (amwg_comp_opt *)calloc(n_comp, sizeof *co);
@@ -177,21 +165,20 @@ static napi_value Create(napi_env env, napi_callback_info info) {
     co[i].batch_size = (int32_t)prop_i64(env, e, "batch_size", 50);
     co[i].is_adapting = (int32_t)prop_i64(env, e, "is_adapting", 1);
   }
-  amwg_options op;
-  memset(&op, 0, sizeof op);
-  op.chains = prop_i64(env, a[4], "chains", 1);
-  op.seed = prop_u64(env, a[4], "seed", 0);
-  op.chain_offset = prop_u64(env, a[4], "chain_offset", 0);
-  op.device = (int32_t)prop_i64(env, a[4], "device", 0);
-  op.lanes_per_chain = (int32_t)prop_i64(env, a[4], "lanes_per_chain", 0);
-  op.block_threads = (int32_t)prop_i64(env, a[4], "block_threads", 0);
-  op.steps_per_launch = (int32_t)prop_i64(env, a[4], "steps_per_launch", 0);
-  op.exact_division = (int32_t)prop_i64(env, a[4], "exact_division", 0);
-  amwg_sampler *s = NULL;
-  int rc = amwg_create(&md, pd, (int32_t)n_params, init, co, &op, &s);
-  free(pd);
-  free(co);
-  if (rc != AMWG_OK) return throw_amwg(env, rc);
+  memset(op, 0, sizeof *op);
+  op->chains = prop_i64(env, a[4], "chains", 1);
+  op->seed = prop_u64(env, a[4], "seed", 0);
+  op->chain_offset = prop_u64(env, a[4], "chain_offset", 0);
+  op->device = (int32_t)prop_i64(env, a[4], "device", 0);
+  op->lanes_per_chain = (int32_t)prop_i64(env, a[4], "lanes_per_chain", 0);
+  op->block_threads = (int32_t)prop_i64(env, a[4], "block_threads", 0);
+  op->steps_per_launch = (int32_t)prop_i64(env, a[4], "steps_per_launch", 0);
+  op->exact_division = (int32_t)prop_i64(env, a[4], "exact_division", 0);
+  *pd_out = pd; *co_out = co; *n_params_out = n_params; *init_out = init;
+  return 1;
+}
+
+static napi_value wrap_sampler(napi_env env, amwg_sampler *s) {
   amwg_sampler **box = (amwg_sampler **)malloc(sizeof *box);
   *box = s;
   napi_value ext;
@@ -202,6 +189,98 @@ static napi_value Create(napi_env env, napi_callback_info info) {
     return NULL;
   }
   return ext;
+}
+
+/* create(model, params[], init Float64Array, compOpts[], options) -> external handle */
+static napi_value Create(napi_env env, napi_callback_info info) {
+  napi_value a[5];
+  if (!get_args(env, info, 5, a)) return NULL;
+  amwg_model_desc md;
+  memset(&md, 0, sizeof md);
+  md.model = (int32_t)prop_i64(env, a[0], "model", 0);
+  md.n_obs = (int32_t)prop_i64(env, a[0], "n_obs", 0);
+  md.G = (int32_t)prop_i64(env, a[0], "G", 0);
+  md.K = (int32_t)prop_i64(env, a[0], "K", 0);
+  napi_value v;
+  size_t n = 0;
+  if (prop(env, a[0], "x", &v)) md.x = (const double *)typed_data(env, v, napi_float64_array, &n);
+  if (prop(env, a[0], "y", &v)) md.y = (const double *)typed_data(env, v, napi_float64_array, &n);
+  if (prop(env, a[0], "g", &v)) md.g = (const int32_t *)typed_data(env, v, napi_int32_array, &n);
+  if (prop(env, a[0], "hyper", &v)) {
+    const double *h = (const double *)typed_data(env, v, napi_float64_array, &n);
+    for (size_t i = 0; h && i < n && i < 8; i++) md.hyper[i] = h[i];
+  }
+  amwg_param_desc *pd; amwg_comp_opt *co; uint32_t n_params; const double *init; amwg_options op;
+  if (!parse_common(env, a, &pd, &co, &n_params, &init, &op)) return NULL;
+  amwg_sampler *s = NULL;
+  int rc = amwg_create(&md, pd, (int32_t)n_params, init, co, &op, &s);
+  free(pd);
+  free(co);
+  if (rc != AMWG_OK) return throw_amwg(env, rc);
+  return wrap_sampler(env, s);
+}
+
+/* createUser({source, arrays: [Float64Array...], n_derived, lds_bytes, parallel, max_threads}, params[], init, compOpts[], options)
+ * -- a closure translated by bayes.js_amd/translate.js (amwg_create_user) */
+static napi_value CreateUser(napi_env env, napi_callback_info info) {
+  napi_value a[5];
+  if (!get_args(env, info, 5, a)) return NULL;
+  napi_value v;
+  if (!prop(env, a[0], "source", &v)) { napi_throw_type_error(env, NULL, "amwg_napi.createUser: source missing"); return NULL; }
+  size_t slen = 0;
+  if (napi_get_value_string_utf8(env, v, NULL, 0, &slen) != napi_ok) { napi_throw_type_error(env, NULL, "amwg_napi.createUser: source must be a string"); return NULL; }
+  char *src = (char *)malloc(slen + 1);
+  napi_get_value_string_utf8(env, v, src, slen + 1, &slen);
+  const double *arrs[AMWG_MAX_USER_ARRAYS];
+  int64_t lens[AMWG_MAX_USER_ARRAYS];
+  uint32_t n_arr = 0;
+  if (prop(env, a[0], "arrays", &v)) napi_get_array_length(env, v, &n_arr);
+  if (n_arr > AMWG_MAX_USER_ARRAYS) { free(src); napi_throw_range_error(env, NULL, "amwg_napi.createUser: too many data arrays"); return NULL; }
+  for (uint32_t i = 0; i < n_arr; i++) {
+    napi_value e;
+    size_t n = 0;
+    napi_get_element(env, v, i, &e);
+    arrs[i] = (const double *)typed_data(env, e, napi_float64_array, &n);
+    lens[i] = (int64_t)n;
+    if (!arrs[i] && n) { free(src); napi_throw_type_error(env, NULL, "amwg_napi.createUser: arrays must be Float64Arrays"); return NULL; }
+  }
+  amwg_user_model um;
+  memset(&um, 0, sizeof um);
+  um.source = src;
+  um.n_arrays = (int32_t)n_arr;
+  um.arrays = arrs;
+  um.array_len = lens;
+  um.n_derived = (int32_t)prop_i64(env, a[0], "n_derived", 0);
+  um.lds_bytes = (int32_t)prop_i64(env, a[0], "lds_bytes", 0);
+  um.parallel = (int32_t)prop_i64(env, a[0], "parallel", 0);
+  um.max_threads = (int32_t)prop_i64(env, a[0], "max_threads", 0);
+  amwg_param_desc *pd; amwg_comp_opt *co; uint32_t n_params; const double *init; amwg_options op;
+  if (!parse_common(env, a, &pd, &co, &n_params, &init, &op)) { free(src); return NULL; }
+  amwg_sampler *s = NULL;
+  int rc = amwg_create_user(&um, pd, (int32_t)n_params, init, co, &op, &s);
+  free(pd);
+  free(co);
+  free(src);
+  if (rc != AMWG_OK) return throw_amwg(env, rc);
+  return wrap_sampler(env, s);
+}
+
+/* compileUser(source, lanes, block, arch) -> code object size; throws with the hiprtc log (no device needed) */
+static napi_value CompileUser(napi_env env, napi_callback_info info) {
+  napi_value a[4], r;
+  if (!get_args(env, info, 4, a)) return NULL;
+  size_t slen = 0, alen = 0;
+  napi_get_value_string_utf8(env, a[0], NULL, 0, &slen);
+  char *src = (char *)malloc(slen + 1);
+  napi_get_value_string_utf8(env, a[0], src, slen + 1, &slen);
+  char arch[64];
+  napi_get_value_string_utf8(env, a[3], arch, sizeof arch, &alen);
+  size_t bytes = 0;
+  int rc = amwg_compile_user(src, (int32_t)arg_i64(env, a[1]), (int32_t)arg_i64(env, a[2]), arch, &bytes);
+  free(src);
+  if (rc != AMWG_OK) return throw_amwg(env, rc);
+  NAPI_OK(napi_create_double(env, (double)bytes, &r));
+  return r;
 }
 
 static napi_value Destroy(napi_env env, napi_callback_info info) {
@@ -264,7 +343,7 @@ static napi_value FetchDraws(napi_env env, napi_callback_info info) {
   amwg_sampler *s = unwrap(env, a[0]);
   if (!s) return NULL;
   const int64_t rows = arg_i64(env, a[1]);
-  const size_t n = (size_t)rows * (size_t)amwg_num_components(s) * (size_t)amwg_num_chains(s);
+  const size_t n = (size_t)rows * (size_t)amwg_num_recorded(s) * (size_t)amwg_num_chains(s);
   double *data = NULL;
   napi_value out = new_f64(env, n, &data);
   if (!out) { napi_throw_error(env, NULL, "amwg_napi: cannot allocate the draws array"); return NULL; }
@@ -281,7 +360,7 @@ static napi_value Sample(napi_env env, napi_callback_info info) {
   const int64_t nsteps = arg_i64(env, a[1]), thin = arg_i64(env, a[2]);
   if (nsteps < 0 || thin < 1) { napi_throw_range_error(env, NULL, "amwg_napi.sample: n >= 0 and thin >= 1 required"); return NULL; }
   const int64_t rows = (nsteps + thin - 1) / thin;
-  const size_t n = (size_t)rows * (size_t)amwg_num_components(s) * (size_t)amwg_num_chains(s);
+  const size_t n = (size_t)rows * (size_t)amwg_num_recorded(s) * (size_t)amwg_num_chains(s);
   double *data = NULL;
   napi_value out = new_f64(env, n, &data);
   if (!out) { napi_throw_error(env, NULL, "amwg_napi: cannot allocate the draws array"); return NULL; }
@@ -371,7 +450,7 @@ static napi_value Moments(napi_env env, napi_callback_info info) {
   if (!get_args(env, info, 1, a)) return NULL;
   amwg_sampler *s = unwrap(env, a[0]);
   if (!s) return NULL;
-  const size_t P = (size_t)amwg_num_components(s);
+  const size_t P = (size_t)amwg_num_recorded(s);
   double *m, *sd;
   napi_value vm = new_f64(env, P, &m), vsd = new_f64(env, P, &sd);
   if (!vm || !vsd) return NULL;
@@ -440,7 +519,7 @@ static napi_value Uniform(napi_env env, napi_callback_info info) {
 
 static napi_value Init(napi_env env, napi_value exports) {
   static const struct { const char *name; napi_callback fn; } fns[] = {
-      {"create", Create}, {"destroy", Destroy}, {"burn", Burn}, {"burnAsync", BurnAsync}, {"sync", Sync},
+      {"create", Create}, {"createUser", CreateUser}, {"compileUser", CompileUser}, {"destroy", Destroy}, {"burn", Burn}, {"burnAsync", BurnAsync}, {"sync", Sync},
       {"sample", Sample}, {"sampleAsync", SampleAsync}, {"fetchDraws", FetchDraws}, {"setAdapting", SetAdapting},
       {"getState", GetState}, {"info", Info}, {"diag", Diag}, {"moments", Moments}, {"launchInfo", LaunchInfo},
       {"version", Version}, {"mathExp", MathExp}, {"mathLog", MathLog}, {"uniform", Uniform}};

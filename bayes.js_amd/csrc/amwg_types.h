@@ -1,17 +1,33 @@
 // amwg_types.h -- plain structs shared by the host core and the kernels.
 #pragma once
-#include <stdint.h>
+#include "amwg_stdint.h"
 
 namespace amwg {
 
 constexpr int kMaxNamed = 8;     // named parameters per model (packed 4-bit permutation)
 constexpr int kMaxTop = 256;     // largest shuffled dimension (index bytes)
+constexpr int kMaxUserArrays = 16;   // data arrays of a translated (user) log_post
+constexpr int kTypeReal = 0, kTypeInt = 1, kTypeBinary = 2;   // AMWG_REAL / AMWG_INT / AMWG_BINARY
+
+// LDS-resident view of this chain's state: component p at S.base[p].  Chains are laid out
+// [chain][stride] with an ODD stride (in doubles): lanes that own different chains and read the
+// same component hit 32 distinct 8-byte bank slots, and the G lanes of one chain that gather
+// different components (theta[g_i]) read consecutive addresses -- conflict-free both ways.
+struct StateView {
+  const double *base;
+#if defined(__HIPCC__)
+  __host__ __device__ __forceinline__
+#else
+  inline
+#endif
+  double operator()(int p) const { return base[p]; }
+};
 
 // Per scalar component, identical for all chains (mcmc.js:497-505).
 struct CompConst {
   double lower, upper, max_adaptation, initial_adaptation, target_accept_rate;
   int32_t batch_size;
-  int32_t type;  // AMWG_REAL / AMWG_INT
+  int32_t type;  // AMWG_REAL / AMWG_INT / AMWG_BINARY
 };
 
 // Completed parameter layout (mcmc.js:357-403), flattened.
@@ -48,6 +64,7 @@ struct DataRef {
   const double *lfact;  // GLM lfactorial(y_i) (+inf encodes y_i < 0, i.e. term = -inf)
   const uint8_t *xb;    // BETA_BERN x as bytes (invalid values stored as 0, see has_invalid) | HIER group index
   const uint32_t *xw;   // BETA_BERN x as bits: observation i = bit (i & 31) of word (i >> 5)
+  const double *arr[kMaxUserArrays];   // translated models: the data arrays the closure reads (row-major, f64)
 };
 
 // Per-chain state, structure-of-arrays with the chain index fastest: element (p, c) at p*C + c.

@@ -1,0 +1,58 @@
+// amwg_user.h -- support code for translated closures (bayes.js_amd/translate.js emits calls to
+// these).  Everything follows the reference's expression trees; see amwg_ld.h for the densities.
+#pragma once
+#include "amwg_div.h"
+#include "amwg_ld.h"
+#include "amwg_types.h"
+
+namespace amwg {
+
+// Loop-invariant part of ld.norm(x, mean, sd) for a loop in which sd does not change
+// (distributions.js:119-121): c = -0.5*log(2*pi) - log(sd), den = 2*sd*sd -- the same roundings,
+// in the same order, as the full expression -- plus the double-double reciprocal of amwg_div.h.
+struct NormInv { double c, den; Reciprocal y; bool fast; };
+AMWG_HD NormInv norm_inv(double sd) {
+  NormInv k;
+  k.c = norm_c(-0.5 * log_v8(2 * kPi), sd);
+  k.den = norm_den(sd);
+  k.y = make_reciprocal(k.den);
+  k.fast = mid_range(k.den);
+  return k;
+}
+// |a| in 2^-600..2^600 (or exactly zero is NOT included: 0 takes the IEEE path, it is rare)
+AMWG_HD bool wide_range(double a) {
+  const uint32_t h = (uint32_t)hi_word(a) & 0x7fffffffu;
+  return (h - 0x1A700000u) <= (0x65700000u - 0x1A700000u);
+}
+AMWG_HD double ld_norm_inv(double x, double mean, const NormInv &k) {
+  const double t = x - mean;
+  const double tt = t * t;
+  // the quotient is the correctly rounded tt/den either way (amwg_div.h); '/' when a range precondition fails
+  const double q = (k.fast && wide_range(tt)) ? div_by_invariant(tt, k.den, k.y) : tt / k.den;
+  return k.c - q;
+}
+
+// ld.bern(x, p) for a loop in which p does not change (distributions.js:228-230): the two values
+// log(1*p + 0*(1-p)) and log(0*p + 1*(1-p)) the expression can take, selected per observation.
+struct BernInv { double l1, l0; };
+AMWG_HD BernInv bern_inv(double p) { return BernInv{ld_bern(1.0, p), ld_bern(0.0, p)}; }
+AMWG_HD double ld_bern_inv(double x, const BernInv &k) { return x == 1 ? k.l1 : (x == 0 ? k.l0 : -kInf); }
+
+// JavaScript operators that differ from C++
+AMWG_HD double js_mod(double a, double b) {   // % on numbers: sign of the dividend (fmod); exact
+  return __builtin_fmod(a, b);
+}
+AMWG_HD double js_max(double a, double b) {   // Math.max: NaN if either is NaN, +0 > -0
+  if (a != a || b != b) return __builtin_nan("");
+  if (a == b) return (a == 0 && __builtin_signbit(a)) ? b : a;
+  return a > b ? a : b;
+}
+AMWG_HD double js_min(double a, double b) {
+  if (a != a || b != b) return __builtin_nan("");
+  if (a == b) return (a == 0 && __builtin_signbit(a)) ? a : b;
+  return a < b ? a : b;
+}
+AMWG_HD double js_sign(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
+AMWG_HD double js_trunc(double x) { return __builtin_trunc(x); }
+
+}  // namespace amwg

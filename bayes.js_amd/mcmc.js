@@ -11,6 +11,14 @@
  * (include/amwg.h).  There is no JavaScript stepping path here: if the addon or a GPU is
  * missing, construction throws.
  *
+ * log_post.  The four BASELINE.json model families have hand-tuned kernels (models.js recognises
+ * the README programs from their source, or take mcmc.models.*()).  Every other closure is
+ * translated to HIP by translate.js and compiled at construction with hiprtc: real, int and binary
+ * parameters, any dim, every scalar ld.* density, derived quantities (`state.key = ...`).
+ * options.translate = true forces the translated path for a recognised closure as well;
+ * options.constants / options.helpers make free variables / helper functions of the closure
+ * visible to the translator.
+ *
  * What is new relative to the reference (all optional):
  *     options.chains   number of independent chains (default 1)
  *     options.seed     Philox key, number or BigInt (default: drawn from Math.random, like an unseeded run)
@@ -23,6 +31,7 @@
 const path = require('path');
 const models = require('./models.js');
 const ld = require('./ld.js');
+const translator = require('./translate.js');
 
 let nativeCache = null;
 function native() {
@@ -73,6 +82,7 @@ function filled(dim, init) {                // nested array of shape dim; a func
 function shapeOf(a) { return Array.isArray(a[0]) ? [a.length].concat(shapeOf(a[0])) : [a.length]; }
 function sameShape(a, b) { return a.length === b.length && a.every((v, i) => v == b[i]); }
 const isScalarDim = (dim) => sameShape(dim, [1]);
+const TYPE_ID = { real: 0, int: 1, binary: 2 };   // AMWG_REAL / AMWG_INT / AMWG_BINARY
 
 function complete_params(params_to_complete, param_init) {
   const params = cloneSpec(params_to_complete);
@@ -172,13 +182,9 @@ function AmwgSampler(params, log_post, data, options) {
   this.data = data;
   this.params = complete_params(params, this.param_init_fun);
 
-  const recog = models.recognise(log_post);
-  if (!recog)
-    throw 'AmwgSampler (MI355X): log_post is not a model this GPU sampler can run. Write it in the README pattern ' +
-          '(priors, then one for-loop over the data adding one ld.* term per observation; Normal and beta-Bernoulli ' +
-          'are recognised from source) or build it with mcmc.models.normal/beta_bern/hier_normal/pois_glm.';
-  this.model = recog.family;
-  if (recog.paramNames && recog.paramNames.join() !== this.param_names.join())
+  const recog = opt('translate', false) ? null : models.recognise(log_post);
+  this.model = recog ? recog.family : 'translated';
+  if (recog && recog.paramNames && recog.paramNames.join() !== this.param_names.join())
     throw 'AmwgSampler (MI355X): the ' + recog.family + ' model expects params declared as {' + recog.paramNames.join(', ') +
           '} (in that order), got {' + this.param_names.join(', ') + '}';
 
@@ -188,10 +194,11 @@ function AmwgSampler(params, log_post, data, options) {
   let base = 0;
   for (const name of this.param_names) {
     const p = this.params[name];
-    if (p.type !== 'real' && p.type !== 'int')
-      throw "AmwgStepper can't handle parameter " + name + ' with type ' + p.type;   // message of mcmc.js:867 ("binary": SURVEY.md §8f)
+    if (p.type !== 'real' && p.type !== 'int' && p.type !== 'binary')
+      throw "AmwgStepper can't handle parameter " + name + ' with type ' + p.type;   // message of mcmc.js:867
+    if (p.type === 'binary' && recog) throw 'AmwgSampler (MI355X): the built-in ' + recog.family + ' model has no binary parameters';
     const len = p.dim.reduce((a, b) => a * b, 1);
-    descs.push({ type: p.type === 'int' ? 1 : 0, len, top: p.dim[0], multidim: isScalarDim(p.dim) ? 0 : 1, lower: p.lower, upper: p.upper });
+    descs.push({ type: TYPE_ID[p.type], len, top: p.dim[0], multidim: isScalarDim(p.dim) ? 0 : 1, lower: p.lower, upper: p.upper });
     const flatInit = flatten(p.init, []);
     if (flatInit.length !== len) throw 'parameter ' + name + ': init does not match dim [' + p.dim + ']';
     flatInit.forEach((v) => init.push(v));
@@ -204,7 +211,19 @@ function AmwgSampler(params, log_post, data, options) {
   if (!(this.chains >= 1) || Math.floor(this.chains) !== this.chains) throw 'options.chains must be a positive integer';
   this.seed = opt('seed', Math.floor(Math.random() * 9007199254740992));
   const devices = opt('devices', [opt('device', 0)]);
-  const desc = buildModelDesc(recog, data);
+  // the model: a built-in family, or the closure translated to HIP (compiled by the addon with hiprtc)
+  let desc = null, user = null;
+  this.derived = [];
+  if (recog) desc = buildModelDesc(recog, data);
+  else {
+    const tr = translator.translate(log_post, this.params, data, { constants: options.constants, helpers: options.helpers,
+      lds_budget: options.lds_budget, max_threads: options.max_threads, unroll: options.unroll });
+    this.derived = tr.derived;
+    this.translation = tr;
+    user = { source: tr.source, arrays: tr.arrays, n_derived: tr.derived.length, lds_bytes: tr.lds_bytes, parallel: tr.parallel,
+             max_threads: tr.max_threads };
+  }
+  this.PR = this.P + this.derived.length;   // values per recorded draw
 
   // contiguous shards of global chain ids, one native sampler per device (SURVEY.md §8e)
   const N = native();
@@ -213,13 +232,14 @@ function AmwgSampler(params, log_post, data, options) {
   let offset = 0;
   for (let r = 0; r < D; r++) {
     const count = per + (r < rem ? 1 : 0);
-    const handle = N.create(desc, descs, Float64Array.from(init), compOpts, {
+    const handle = (user ? N.createUser : N.create)(user || desc, descs, Float64Array.from(init), compOpts, {
       chains: count, seed: this.seed, chain_offset: opt('chain_offset', 0) + offset, device: devices[r],
       lanes_per_chain: opt('lanes_per_chain', 0), block_threads: opt('block_threads', 0),
       steps_per_launch: opt('steps_per_launch', 0), exact_division: opt('exact_division', 0) });
     this._shards.push({ handle, offset, count, device: devices[r] });
     offset += count;
   }
+  this._host_log_post = (st) => log_post(st, data);
   this.log_post = () => log_post(this.state, data);   // host evaluation at the current state of chain 0
 }
 
@@ -246,11 +266,13 @@ AmwgSampler.prototype.sample = function (n_iterations) {
   const N = native(), thin = this.thinning_interval;
   const kept = Math.ceil(n_iterations / thin);
   this._each((sh) => N.sampleAsync(sh.handle, n_iterations, thin));
-  const flat = this._merge(this._each((sh) => N.fetchDraws(sh.handle, kept)), kept * this.P);   // [kept][P][chains]
-  const monitored = this.monitored_params === null ? this.param_names : this.monitored_params;
-  const C = this.chains, P = this.P, out = {};
+  const flat = this._merge(this._each((sh) => N.fetchDraws(sh.handle, kept)), kept * this.PR);   // [kept][P + derived][chains]
+  // mcmc.js:1009-1013: by default every key of the state is recorded, parameters first, then derived quantities
+  const monitored = this.monitored_params === null ? this.param_names.concat(this.derived) : this.monitored_params;
+  const C = this.chains, P = this.PR, out = {};
+  const derivedLayout = this.derived.map((name, q) => ({ name, base: this.P + q, len: 1, dim: [1], scalar: true }));
   for (const name of monitored) {
-    const L = this._layout.find((l) => l.name === name);
+    const L = this._layout.find((l) => l.name === name) || derivedLayout.find((l) => l.name === name);
     if (!L) { out[name] = []; continue; }
     if (C === 1) {                          // reference shape (mcmc.js:1015-1029): one entry per kept draw
       const draws = new Array(kept);
@@ -275,6 +297,7 @@ Object.defineProperty(AmwgSampler.prototype, 'state', {
       if (C === 1) st[L.name] = L.scalar ? flat[L.base] : nest(flat, L.base, L.dim);
       else st[L.name] = flat.subarray(L.base * C, (L.base + L.len) * C);
     }
+    if (C === 1 && this.derived.length) this._host_log_post(st);   // the closure itself fills in its derived keys (mcmc.js:961-963)
     return st;
   },
 });
@@ -313,10 +336,11 @@ AmwgSampler.prototype.moments = function () {
   if (this._shards.length !== 1) throw 'moments(): only available on a single-device sampler';
   const m = N.moments(this._shards[0].handle), out = {};
   for (const L of this._layout) out[L.name] = { mean: Array.from(m.mean.subarray(L.base, L.base + L.len)), sd: Array.from(m.sd.subarray(L.base, L.base + L.len)) };
+  this.derived.forEach((name, q) => { out[name] = { mean: [m.mean[this.P + q]], sd: [m.sd[this.P + q]] }; });
   return out;
 };
 
 AmwgSampler.prototype.diagnostics = function () { const N = native(); return this._each((sh) => N.diag(sh.handle, this.param_names.length)); };
 AmwgSampler.prototype.close = function () { const N = native(); this._each((sh) => N.destroy(sh.handle)); this._shards = []; };
 
-module.exports = { AmwgSampler, complete_params, param_init_fixed, componentOptions, models, ld, native };
+module.exports = { AmwgSampler, complete_params, param_init_fixed, componentOptions, models, ld, native, translate: translator.translate };

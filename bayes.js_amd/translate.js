@@ -1,0 +1,1039 @@
+'use strict';
+/*
+ * translate.js -- turns a user's `log_post(state, data)` closure (mcmc.js:958-960; README.md:18-43,
+ * 149-164; tests/test_data.js:80-211) into the HIP source of `struct amwg::UserModel`, which
+ * libamwg.so compiles with hiprtc together with the fused step kernel (csrc/amwg_kernel.h).
+ *
+ * The closure is read from its own source text (Function.prototype.toString) and must stay
+ * inside a numeric subset of JavaScript:
+ *     var/let/const, assignments (= += -= *= /=, ++ --), for / while / if / else / return, blocks
+ *     numbers, + - * / %, comparisons, && || !, ?:, Math.{log,exp,sqrt,abs,pow,floor,ceil,round,
+ *     min,max,trunc,sign,PI,E,...}, every ld.* of distributions.js with scalar arguments,
+ *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, local
+ *     aliases of those (var p = par.p[0]), derived quantities (state.key = expr, mcmc.js:961-963),
+ *     helper functions and constants passed in options.helpers / options.constants.
+ * Anything else throws a string that says what is not supported (no CPU fallback).
+ *
+ * Fidelity.  Every JavaScript number operation becomes the same IEEE fp64 operation in the same
+ * order (the kernel is compiled with -ffp-contract=off); Math.exp/log are the bit-identical V8
+ * twins of csrc/amwg_math.h; constant sub-expressions are folded HERE, by V8 itself.  With one lane
+ * per chain the generated body is the closure's own evaluation order, so a seeded run reproduces
+ * the reference bit for bit.  With G lanes per chain the top-level loops that only accumulate into
+ * the returned variable are split G ways (lane j takes iterations j, j+G, ...; lane 0 also adds
+ * every term outside those loops) and the kernel adds the lane partial sums with an xor butterfly.
+ *
+ * Two result-preserving optimisations, both applied only where a value provably does not change
+ * inside a loop: ld.norm with a loop-invariant sd uses the hoisted form of csrc/amwg_user.h
+ * (same roundings, correctly rounded quotient), ld.bern with a loop-invariant p selects between
+ * its two possible values.
+ */
+
+// ------------------------------------------------------------------------------------------
+// exact C++ literals
+function hexFloat(v) {
+  if (Number.isNaN(v)) return '__builtin_nan("")';
+  if (v === Infinity) return 'kInf';
+  if (v === -Infinity) return '(-kInf)';
+  if (Number.isInteger(v) && Math.abs(v) < 9007199254740992 && !(v === 0 && 1 / v < 0)) return v.toFixed(1);
+  const buf = new DataView(new ArrayBuffer(8));
+  buf.setFloat64(0, v);
+  const hi = buf.getUint32(0), lo = buf.getUint32(4);
+  const sign = hi >>> 31 ? '-' : '';
+  const exp = (hi >>> 20) & 0x7ff;
+  const mant = ((hi & 0xfffff).toString(16).padStart(5, '0') + lo.toString(16).padStart(8, '0'));
+  if (exp === 0) {
+    if ((hi & 0xfffff) === 0 && lo === 0) return sign + '0.0';
+    return sign + '0x0.' + mant + 'p-1022';
+  }
+  return sign + '0x1.' + mant + 'p' + (exp - 1023 >= 0 ? '+' : '') + (exp - 1023);
+}
+
+// ------------------------------------------------------------------------------------------
+// tokenizer
+const PUNCT = ['===', '!==', '>>>', '==', '!=', '<=', '>=', '&&', '||', '++', '--', '+=', '-=', '*=', '/=', '%=', '=>',
+  '{', '}', '(', ')', '[', ']', ';', ',', '.', '?', ':', '<', '>', '+', '-', '*', '/', '%', '!', '='];
+
+function tokenize(src) {
+  const out = [];
+  let i = 0, nl = false;
+  const n = src.length;
+  while (i < n) {
+    const c = src[i];
+    if (c === '\n') { nl = true; i++; continue; }
+    if (c === ' ' || c === '\t' || c === '\r') { i++; continue; }
+    if (c === '/' && src[i + 1] === '/') { while (i < n && src[i] !== '\n') i++; continue; }
+    if (c === '/' && src[i + 1] === '*') {
+      const e = src.indexOf('*/', i + 2);
+      if (e < 0) throw 'unterminated comment';
+      if (src.slice(i, e).indexOf('\n') >= 0) nl = true;
+      i = e + 2; continue;
+    }
+    if (/\d/.test(c) || (c === '.' && /\d/.test(src[i + 1] || ''))) {
+      const m = /^(?:0[xX][0-9a-fA-F]+|(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?)/.exec(src.slice(i, i + 64));
+      out.push({ t: 'num', v: Number(m[0]), nl }); nl = false; i += m[0].length; continue;
+    }
+    if (/[A-Za-z_$]/.test(c)) {
+      let j = i + 1;
+      while (j < n && /[\w$]/.test(src[j])) j++;
+      out.push({ t: 'id', v: src.slice(i, j), nl }); nl = false; i = j; continue;
+    }
+    if (c === '"' || c === "'") {
+      let j = i + 1, s = '';
+      while (j < n && src[j] !== c) { if (src[j] === '\\') { j++; } s += src[j]; j++; }
+      if (j >= n) throw 'unterminated string literal';
+      out.push({ t: 'str', v: s, nl }); nl = false; i = j + 1; continue;
+    }
+    let hit = null;
+    for (const p of PUNCT) if (src.startsWith(p, i)) { hit = p; break; }
+    if (!hit) throw 'log_post uses a character this translator does not understand: ' + JSON.stringify(c);
+    out.push({ t: 'p', v: hit, nl }); nl = false; i += hit.length;
+  }
+  out.push({ t: 'eof', v: '<end>', nl: true });
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------
+// parser (recursive descent, JavaScript precedence)
+const KEYWORDS = new Set(['var', 'let', 'const', 'for', 'while', 'if', 'else', 'return', 'function', 'true', 'false',
+  'break', 'continue', 'do', 'switch', 'new', 'typeof', 'in', 'of', 'this', 'null', 'undefined', 'throw', 'try']);
+
+function Parser(tokens) { this.tk = tokens; this.i = 0; }
+Parser.prototype = {
+  peek(v) { const t = this.tk[this.i]; return t.t !== 'num' && t.t !== 'str' && t.v === v; },
+  peekAt(k, v) { const t = this.tk[this.i + k]; return t && t.t !== 'num' && t.t !== 'str' && t.v === v; },
+  eat(v) { if (this.peek(v)) { this.i++; return true; } return false; },
+  expect(v) { if (!this.eat(v)) throw "expected '" + v + "' but found '" + this.tk[this.i].v + "' in log_post"; },
+  ident() { const t = this.tk[this.i]; if (t.t !== 'id' || KEYWORDS.has(t.v)) throw "expected a name but found '" + t.v + "'"; this.i++; return t.v; },
+  endStmt() {   // ';' or automatic semicolon insertion (before '}', at a line break, at the end)
+    if (this.eat(';')) return;
+    const t = this.tk[this.i];
+    if (t.t === 'eof' || this.peek('}') || t.nl) return;
+    throw "expected ';' but found '" + t.v + "' in log_post";
+  },
+  parseFunction() {
+    let params = [];
+    if (this.eat('function')) { if (!this.peek('(')) this.ident(); }
+    if (this.eat('(')) {
+      if (!this.peek(')')) do { params.push(this.ident()); } while (this.eat(','));
+      this.expect(')');
+    } else {
+      params.push(this.ident());    // x => ...
+    }
+    const arrow = this.eat('=>');
+    let body;
+    if (this.peek('{')) body = this.block();
+    else if (arrow) body = { k: 'Block', body: [{ k: 'Return', arg: this.assignment() }] };
+    else throw 'log_post must be a function expression or an arrow function';
+    if (this.tk[this.i].t !== 'eof') throw "unexpected '" + this.tk[this.i].v + "' after the end of the function";
+    return { params, body };
+  },
+  block() { this.expect('{'); const body = []; while (!this.peek('}')) body.push(this.statement()); this.expect('}'); return { k: 'Block', body }; },
+  varDecl() {
+    const kind = this.tk[this.i++].v, decls = [];
+    do { const name = this.ident(); let init = null; if (this.eat('=')) init = this.assignment(); decls.push({ name, init }); } while (this.eat(','));
+    return { k: 'VarDecl', kind, decls };
+  },
+  statement() {
+    if (this.peek('{')) return this.block();
+    if (this.eat(';')) return { k: 'Empty' };
+    if (this.peek('var') || this.peek('let') || this.peek('const')) { const d = this.varDecl(); this.endStmt(); return d; }
+    if (this.eat('for')) {
+      this.expect('(');
+      let init = null, test = null, update = null;
+      if (!this.peek(';')) init = (this.peek('var') || this.peek('let') || this.peek('const')) ? this.varDecl() : { k: 'ExprStmt', expr: this.expression() };
+      if (this.peek('in') || this.peek('of')) throw 'for-in / for-of loops are not supported; use for (var i = 0; i < n; i++)';
+      this.expect(';');
+      if (!this.peek(';')) test = this.expression();
+      this.expect(';');
+      if (!this.peek(')')) update = this.expression();
+      this.expect(')');
+      return { k: 'For', init, test, update, body: this.statement() };
+    }
+    if (this.eat('while')) { this.expect('('); const test = this.expression(); this.expect(')'); return { k: 'For', init: null, test, update: null, body: this.statement() }; }
+    if (this.eat('if')) {
+      this.expect('('); const test = this.expression(); this.expect(')');
+      const cons = this.statement();
+      let alt = null;
+      if (this.eat('else')) alt = this.statement();
+      return { k: 'If', test, cons, alt };
+    }
+    if (this.eat('return')) {
+      let arg = null;
+      const t = this.tk[this.i];
+      if (!this.peek(';') && !this.peek('}') && !t.nl && t.t !== 'eof') arg = this.expression();
+      this.endStmt();
+      return { k: 'Return', arg };
+    }
+    for (const kw of ['break', 'continue', 'do', 'switch', 'throw', 'try', 'function'])
+      if (this.peek(kw)) throw "'" + kw + "' statements are not supported inside log_post";
+    const expr = this.expression();
+    this.endStmt();
+    return { k: 'ExprStmt', expr };
+  },
+  expression() { let e = this.assignment(); while (this.eat(',')) e = { k: 'Seq', l: e, r: this.assignment() }; return e; },
+  assignment() {
+    const left = this.conditional();
+    for (const op of ['=', '+=', '-=', '*=', '/=', '%=']) if (this.peek(op)) { this.i++; return { k: 'Assign', op, target: left, value: this.assignment() }; }
+    return left;
+  },
+  conditional() {
+    const test = this.binary(0);
+    if (this.eat('?')) { const a = this.assignment(); this.expect(':'); const b = this.assignment(); return { k: 'Cond', test, a, b }; }
+    return test;
+  },
+  binary(level) {
+    const LEVELS = [['||'], ['&&'], ['===', '!==', '==', '!='], ['<=', '>=', '<', '>'], ['+', '-'], ['*', '/', '%']];
+    if (level === LEVELS.length) return this.unary();
+    let left = this.binary(level + 1);
+    for (;;) {
+      let hit = null;
+      for (const op of LEVELS[level]) if (this.peek(op)) { hit = op; break; }
+      if (!hit) return left;
+      this.i++;
+      const right = this.binary(level + 1);
+      left = { k: level < 2 ? 'Logical' : 'Binary', op: hit, l: left, r: right };
+    }
+  },
+  unary() {
+    for (const op of ['-', '+', '!']) if (this.peek(op)) { this.i++; return { k: 'Unary', op, arg: this.unary() }; }
+    for (const op of ['++', '--']) if (this.peek(op)) { this.i++; return { k: 'Update', op, prefix: true, target: this.unary() }; }
+    if (this.peek('typeof') || this.peek('new')) throw "'" + this.tk[this.i].v + "' is not supported inside log_post";
+    return this.postfix();
+  },
+  postfix() {
+    let e = this.primary();
+    for (;;) {
+      if (this.eat('.')) { const t = this.tk[this.i]; if (t.t !== 'id') throw "expected a property name after '.'"; this.i++; e = { k: 'Member', obj: e, prop: t.v }; }
+      else if (this.eat('[')) {
+        const idx = this.expression(); this.expect(']');
+        e = idx.k === 'Str' ? { k: 'Member', obj: e, prop: idx.v } : { k: 'Index', obj: e, idx };
+      } else if (this.eat('(')) {
+        const args = [];
+        if (!this.peek(')')) do { args.push(this.assignment()); } while (this.eat(','));
+        this.expect(')');
+        e = { k: 'Call', callee: e, args };
+      } else if ((this.peek('++') || this.peek('--')) && !this.tk[this.i].nl) { e = { k: 'Update', op: this.tk[this.i++].v, prefix: false, target: e }; }
+      else return e;
+    }
+  },
+  primary() {
+    const t = this.tk[this.i];
+    if (t.t === 'num') { this.i++; return { k: 'Num', v: t.v }; }
+    if (t.t === 'str') { this.i++; return { k: 'Str', v: t.v }; }
+    if (this.eat('(')) { const e = this.expression(); this.expect(')'); return e; }
+    if (this.eat('[')) {
+      const elems = [];
+      if (!this.peek(']')) do { elems.push(this.assignment()); } while (this.eat(','));
+      this.expect(']');
+      return { k: 'ArrayLit', elems };
+    }
+    if (t.t === 'id') {
+      if (t.v === 'true' || t.v === 'false') { this.i++; return { k: 'Bool', v: t.v === 'true' }; }
+      if (t.v === 'function') throw 'nested functions are not supported inside log_post; pass helpers in options.helpers';
+      if (KEYWORDS.has(t.v)) throw "'" + t.v + "' is not supported inside log_post";
+      this.i++;
+      return { k: 'Id', name: t.v };
+    }
+    throw "unexpected '" + t.v + "' in log_post";
+  },
+};
+
+function parseFunctionSource(src) { return new Parser(tokenize(src)).parseFunction(); }
+
+// ------------------------------------------------------------------------------------------
+// AST helpers
+function walk(node, f) {
+  if (!node || typeof node !== 'object') return;
+  if (Array.isArray(node)) { node.forEach((x) => walk(x, f)); return; }
+  if (node.k) f(node);
+  for (const key of Object.keys(node)) if (key !== 'k') walk(node[key], f);
+}
+function assignedNames(node) {   // every local name written anywhere inside node
+  const s = new Set();
+  walk(node, (x) => {
+    if (x.k === 'VarDecl') x.decls.forEach((d) => s.add(d.name));
+    if ((x.k === 'Assign' || x.k === 'Update') && x.target.k === 'Id') s.add(x.target.name);
+  });
+  return s;
+}
+// Definite-assignment walk: true iff no variable of `tracked` is read before it was assigned on
+// every path through `stmts` (so it carries nothing from one loop iteration to the next).
+function definitelyAssigned(stmts, tracked, defined, acc) {
+  const reads = (node) => { for (const nm of idsOf(node)) if (tracked.has(nm) && !defined.has(nm)) return false; return true; };
+  for (const st of stmts) {
+    switch (st.k) {
+      case 'Empty': break;
+      case 'Block': if (!definitelyAssigned(st.body, tracked, defined, acc)) return false; break;
+      case 'VarDecl':
+        for (const d of st.decls) { if (d.init) { if (!reads(d.init)) return false; defined.add(d.name); } }
+        break;
+      case 'ExprStmt': {
+        const e = st.expr;
+        if (e.k === 'Assign' && e.target.k === 'Id') {
+          if (!reads(e.value)) return false;
+          if (e.target.name === acc) break;
+          if (e.op === '=') defined.add(e.target.name);
+          else if (tracked.has(e.target.name) && !defined.has(e.target.name)) return false;
+        } else if (e.k === 'Update' && e.target.k === 'Id') {
+          if (tracked.has(e.target.name) && !defined.has(e.target.name)) return false;
+        } else if (!reads(e)) return false;
+        break;
+      }
+      case 'If': {
+        if (!reads(st.test)) return false;
+        const a = new Set(defined), b = new Set(defined);
+        if (!definitelyAssigned([st.cons], tracked, a, acc)) return false;
+        if (st.alt && !definitelyAssigned([st.alt], tracked, b, acc)) return false;
+        if (st.alt) for (const nm of a) if (b.has(nm)) defined.add(nm);
+        break;
+      }
+      case 'For': {
+        if (st.init && !definitelyAssigned([st.init], tracked, defined, acc)) return false;
+        if (st.test && !reads(st.test)) return false;
+        const inner = new Set(defined);
+        if (!definitelyAssigned([st.body], tracked, inner, acc)) return false;
+        if (st.update && !definitelyAssigned([{ k: 'ExprStmt', expr: st.update }], tracked, inner, acc)) return false;
+        break;
+      }
+      case 'Return': if (st.arg && !reads(st.arg)) return false; break;
+      default: return false;
+    }
+  }
+  return true;
+}
+function idsOf(node) { const s = new Set(); walk(node, (x) => { if (x.k === 'Id') s.add(x.name); }); return s; }
+function containsKind(node, kind) { let hit = false; walk(node, (x) => { if (x.k === kind) hit = true; }); return hit; }
+
+// the densities of distributions.js with scalar arguments: name -> [device function, arity]
+const LD_FUNS = {
+  norm: ['ld_norm', 3], unif: ['ld_unif', 3], beta: ['ld_beta', 3], bern: ['ld_bern', 2], pois: ['ld_pois', 2],
+  cauchy: ['ld_cauchy', 3], laplace: ['ld_laplace', 3], dexp: ['ld_laplace', 3], gamma: ['ld_gamma', 3],
+  invgamma: ['ld_invgamma', 3], lnorm: ['ld_lnorm', 3], pareto: ['ld_pareto', 3], t: ['ld_t', 4], weibull: ['ld_weibull', 3],
+  logis: ['ld_logis', 3], exp: ['ld_exp', 2], binom: ['ld_binom', 3], nbinom: ['ld_nbinom', 3], hyper: ['ld_hyper', 4],
+  lgamma: ['lgamma_js', 1], lfactorial: ['lfactorial_js', 1], lchoose: ['lchoose_js', 2], lbeta: ['lbeta_js', 2],
+};
+const MATH_CONST = { PI: Math.PI, E: Math.E, LN2: Math.LN2, LN10: Math.LN10, LOG2E: Math.LOG2E, LOG10E: Math.LOG10E, SQRT2: Math.SQRT2, SQRT1_2: Math.SQRT1_2 };
+// Math.f -> [device function, arity, host function used for constant folding]
+const MATH_FUNS = {
+  log: ['log_v8', 1, Math.log], exp: ['exp_v8', 1, Math.exp], sqrt: ['__builtin_sqrt', 1, Math.sqrt], abs: ['__builtin_fabs', 1, Math.abs],
+  floor: ['__builtin_floor', 1, Math.floor], ceil: ['__builtin_ceil', 1, Math.ceil], round: ['js_round', 1, Math.round],
+  trunc: ['js_trunc', 1, Math.trunc], sign: ['js_sign', 1, Math.sign],
+};
+const HEAVY = new Set(['log_v8', 'exp_v8', 'pow_v8', 'ld_norm', 'ld_beta', 'ld_pois', 'ld_bern', 'ld_gamma', 'ld_invgamma', 'ld_lnorm', 'ld_t',
+  'ld_weibull', 'ld_logis', 'ld_binom', 'ld_nbinom', 'ld_hyper', 'ld_cauchy', 'ld_pareto', 'ld_exp', 'ld_laplace', 'ld_unif', 'lgamma_js', 'lfactorial_js', 'lchoose_js', 'lbeta_js']);
+
+// ------------------------------------------------------------------------------------------
+function Translator(fn, params, data, opts, isHelper) {
+  this.opts = opts || {};
+  this.isHelper = !!isHelper;
+  this.fnSource = typeof fn === 'string' ? fn : Function.prototype.toString.call(fn);
+  this.ast = parseFunctionSource(this.fnSource);
+  if (!isHelper && (this.ast.params.length < 1 || this.ast.params.length > 2)) throw 'log_post must take (state) or (state, data)';
+  this.stateName = isHelper ? null : this.ast.params[0];
+  this.dataName = isHelper ? null : (this.ast.params[1] || null);
+  this.data = data;
+  // parameter layout in Object.keys order (mcmc.js:839), flattened row-major
+  this.layout = {};
+  let base = 0;
+  for (const name of Object.keys(params)) {
+    const dim = params[name].dim.slice();
+    const len = dim.reduce((a, b) => a * b, 1);
+    this.layout[name] = { base, dim, len, scalar: dim.length === 1 && dim[0] === 1 };
+    base += len;
+  }
+  this.P = base;
+  this.arrays = [];          // {key, flat: Float64Array, dims}
+  this.arrayIds = new Map();
+  this.derived = [];         // names, in order of first assignment
+  this.localTypes = {};      // name -> 'int' | 'double'
+  this.aliases = {};         // name -> symbolic value
+  this.helpers = {};         // name -> {cname, nargs}
+  this.helperSources = [];
+  this.tmp = 0;
+  this.heavy = false;
+}
+
+Translator.prototype.fail = function (msg) { throw 'AmwgSampler (MI355X): cannot translate log_post: ' + msg; };
+
+// ---- data arrays -----------------------------------------------------------------------------
+function shapeOfData(v) {
+  if (ArrayBuffer.isView(v)) return [v.length];
+  if (!Array.isArray(v)) return null;
+  if (v.length === 0) return [0];
+  if (Array.isArray(v[0]) || ArrayBuffer.isView(v[0])) {
+    const inner = shapeOfData(v[0]);
+    if (!inner) return null;
+    for (const e of v) { const s = shapeOfData(e); if (!s || s.join() !== inner.join()) return null; }
+    return [v.length].concat(inner);
+  }
+  for (const e of v) if (typeof e !== 'number' && typeof e !== 'boolean') return null;
+  return [v.length];
+}
+function flattenData(v, out) { if (Array.isArray(v) || ArrayBuffer.isView(v)) { for (let i = 0; i < v.length; i++) flattenData(v[i], out); } else out.push(Number(v)); return out; }
+
+Translator.prototype.registerArray = function (key, value) {
+  if (this.arrayIds.has(key)) return this.arrayIds.get(key);
+  const dims = shapeOfData(value);
+  if (!dims) this.fail('data' + key + ' is not a rectangular array of numbers');
+  const flat = Float64Array.from(flattenData(value, []));
+  if (this.arrays.length >= 16) this.fail('more than 16 data arrays');
+  const id = this.arrays.length;
+  this.arrays.push({ key, flat, dims });
+  this.arrayIds.set(key, id);
+  return id;
+};
+
+// ---- symbolic values -----------------------------------------------------------------------------
+const num = (code, int, cst) => ({ t: 'num', code, int: !!int, cst });
+const cnum = (v) => {
+  const isInt = Number.isInteger(v) && Math.abs(v) < 2147483648 && !(v === 0 && 1 / v < 0);
+  return { t: 'num', code: isInt ? String(v) : hexFloat(v), int: isInt, cst: v };
+};
+Translator.prototype.asD = function (v) {
+  if (v.t === 'num') {
+    if (v.cst !== undefined) return hexFloat(v.cst);
+    return v.int ? '(double)(' + v.code + ')' : v.code;
+  }
+  if (v.t === 'bool') return '((' + v.code + ') ? 1.0 : 0.0)';
+  this.fail('a ' + this.describe(v) + ' is used where a number is needed');
+};
+Translator.prototype.asI = function (v) {
+  if (v.t === 'num') return v.int ? v.code : '(int)(' + v.code + ')';
+  this.fail('a ' + this.describe(v) + ' is used as an array index');
+};
+Translator.prototype.asB = function (v) {
+  if (v.t === 'bool') return v.code;
+  if (v.t === 'num') { const d = this.asD(v); return '((' + d + ') != 0.0 && (' + d + ') == (' + d + '))'; }
+  this.fail('a ' + this.describe(v) + ' is used as a condition');
+};
+Translator.prototype.describe = function (v) {
+  return { stateObj: 'state object', stateArr: 'parameter array', dataObj: 'data object', dataArr: 'data array', ns: 'namespace', fn: 'function', bool: 'boolean', num: 'number' }[v.t] || v.t;
+};
+
+// ---- expressions -----------------------------------------------------------------------------------
+Translator.prototype.lookup = function (name) {
+  if (name === this.stateName) return { t: 'stateObj' };
+  if (this.dataName && name === this.dataName) return this.dataValue('', this.data);
+  if (Object.prototype.hasOwnProperty.call(this.aliases, name)) return this.aliases[name];
+  if (Object.prototype.hasOwnProperty.call(this.localTypes, name)) return num('v_' + name, this.localTypes[name] === 'int');
+  if (name === 'ld') return { t: 'ns', name: 'ld' };
+  if (name === 'Math') return { t: 'ns', name: 'Math' };
+  if (name === 'Infinity') return cnum(Infinity);
+  if (name === 'NaN') return cnum(NaN);
+  const consts = this.opts.constants || {};
+  if (Object.prototype.hasOwnProperty.call(consts, name)) return this.dataValue('#' + name, consts[name]);
+  const helpers = this.opts.helpers || {};
+  if (Object.prototype.hasOwnProperty.call(helpers, name)) return { t: 'fn', ns: 'helper', name };
+  this.fail("'" + name + "' is not defined inside log_post (free variables of the closure are invisible to the translator: " +
+            'pass numbers/arrays in options.constants and functions in options.helpers)');
+};
+
+Translator.prototype.dataValue = function (path, v) {
+  if (typeof v === 'number') return cnum(v);
+  if (typeof v === 'boolean') return cnum(v ? 1 : 0);
+  if (Array.isArray(v) || ArrayBuffer.isView(v)) {
+    const id = this.registerArray(path, v);
+    return { t: 'dataArr', id, off: '0', dims: this.arrays[id].dims.slice() };
+  }
+  if (v && typeof v === 'object') return { t: 'dataObj', path, value: v };
+  this.fail('data' + path + ' is ' + (v === undefined ? 'undefined' : typeof v) + ', not a number, array or object');
+};
+
+Translator.prototype.member = function (objV, prop) {
+  if (objV.t === 'stateObj') {
+    if (Object.prototype.hasOwnProperty.call(this.layout, prop)) {
+      const L = this.layout[prop];
+      if (L.scalar) return num('S(' + L.base + ')', false);
+      return { t: 'stateArr', base: String(L.base), dims: L.dim.slice() };
+    }
+    if (this.derived.indexOf(prop) >= 0) return num('dq_' + prop, false);
+    this.fail("state." + prop + ' is read but it is neither a parameter nor a derived quantity assigned earlier');
+  }
+  if (objV.t === 'dataObj') {
+    if (!Object.prototype.hasOwnProperty.call(objV.value, prop)) this.fail('data' + objV.path + '.' + prop + ' does not exist');
+    return this.dataValue(objV.path + '.' + prop, objV.value[prop]);
+  }
+  if (objV.t === 'dataArr' || objV.t === 'stateArr') {
+    if (prop === 'length') return cnum(objV.dims[0]);
+    this.fail("property '" + prop + "' of an array is not supported");
+  }
+  if (objV.t === 'ns') {
+    if (objV.name === 'Math' && Object.prototype.hasOwnProperty.call(MATH_CONST, prop)) return cnum(MATH_CONST[prop]);
+    return { t: 'fn', ns: objV.name, name: prop };
+  }
+  this.fail("cannot read property '" + prop + "' of a " + this.describe(objV));
+};
+
+Translator.prototype.index = function (objV, idxV) {
+  if (objV.t !== 'dataArr' && objV.t !== 'stateArr') this.fail('indexing a ' + this.describe(objV));
+  const dims = objV.dims, inner = dims.slice(1).reduce((a, b) => a * b, 1);
+  let off;
+  if (idxV.cst !== undefined && Number.isInteger(idxV.cst)) {
+    if (idxV.cst < 0 || idxV.cst >= dims[0]) this.fail('constant index ' + idxV.cst + ' is outside an array of length ' + dims[0]);
+    off = idxV.cst * inner;
+  } else {
+    const i = this.asI(idxV);
+    off = inner === 1 ? i : '(' + i + ') * ' + inner;
+  }
+  const base = objV.t === 'dataArr' ? objV.off : objV.base;
+  let sum;
+  if (typeof off === 'number' && /^\d+$/.test(base)) sum = String(Number(base) + off);
+  else if (base === '0') sum = String(off);
+  else sum = base + ' + ' + off;
+  if (dims.length > 1) return objV.t === 'dataArr' ? { t: 'dataArr', id: objV.id, off: sum, dims: dims.slice(1) } : { t: 'stateArr', base: sum, dims: dims.slice(1) };
+  if (objV.t === 'dataArr') {
+    // a constant element of a data array is a constant
+    if (/^\d+$/.test(sum)) return cnum(this.arrays[objV.id].flat[Number(sum)]);
+    return num('A' + objV.id + '[' + sum + ']', false);
+  }
+  return num('S(' + sum + ')', false);
+};
+
+const ARITH = { '+': (a, b) => a + b, '-': (a, b) => a - b, '*': (a, b) => a * b, '/': (a, b) => a / b, '%': (a, b) => a % b };
+const CMP = { '<': (a, b) => a < b, '<=': (a, b) => a <= b, '>': (a, b) => a > b, '>=': (a, b) => a >= b, '===': (a, b) => a === b, '==': (a, b) => a === b, '!==': (a, b) => a !== b, '!=': (a, b) => a !== b };
+
+Translator.prototype.expr = function (e) {
+  switch (e.k) {
+    case 'Num': return cnum(e.v);
+    case 'Bool': return { t: 'bool', code: e.v ? 'true' : 'false', cst: e.v };
+    case 'Id': return this.lookup(e.name);
+    case 'Member': return this.member(this.expr(e.obj), e.prop);
+    case 'Index': return this.index(this.expr(e.obj), this.expr(e.idx));
+    case 'ArrayLit': {
+      const vals = e.elems.map((x) => { const v = this.expr(x); if (v.cst === undefined || v.t !== 'num') this.fail('array literals may only hold constants'); return v.cst; });
+      const key = '#lit' + JSON.stringify(vals);
+      const id = this.registerArray(key, vals);
+      return { t: 'dataArr', id, off: '0', dims: [vals.length] };
+    }
+    case 'Unary': {
+      const a = this.expr(e.arg);
+      if (e.op === '!') { if (a.cst !== undefined) return { t: 'bool', code: a.cst ? 'false' : 'true', cst: !a.cst }; return { t: 'bool', code: '!(' + this.asB(a) + ')' }; }
+      if (a.t !== 'num') this.fail("unary '" + e.op + "' on a " + this.describe(a));
+      if (e.op === '+') return a;
+      if (a.cst !== undefined) return cnum(-a.cst);
+      return a.int ? num('(-(' + a.code + '))', true) : num('(-(' + a.code + '))', false);
+    }
+    case 'Binary': {
+      const l = this.expr(e.l), r = this.expr(e.r);
+      if (CMP[e.op]) {
+        if (l.t === 'bool' && r.t === 'bool') return { t: 'bool', code: '((' + l.code + ') ' + (e.op[0] === '!' ? '!=' : '==') + ' (' + r.code + '))' };
+        if (l.t !== 'num' || r.t !== 'num') this.fail("comparison '" + e.op + "' between a " + this.describe(l) + ' and a ' + this.describe(r));
+        if (l.cst !== undefined && r.cst !== undefined) { const v = CMP[e.op](l.cst, r.cst); return { t: 'bool', code: v ? 'true' : 'false', cst: v }; }
+        const op = e.op === '===' ? '==' : (e.op === '!==' ? '!=' : e.op);
+        if (l.int && r.int) return { t: 'bool', code: '(' + l.code + ' ' + op + ' ' + r.code + ')' };
+        return { t: 'bool', code: '(' + this.asD(l) + ' ' + op + ' ' + this.asD(r) + ')' };
+      }
+      if (l.t !== 'num' || r.t !== 'num') {
+        if (e.op === '+' ) this.fail("'+' between a " + this.describe(l) + ' and a ' + this.describe(r) + ' (string concatenation is not supported)');
+        this.fail("'" + e.op + "' between a " + this.describe(l) + ' and a ' + this.describe(r));
+      }
+      if (l.cst !== undefined && r.cst !== undefined) return cnum(ARITH[e.op](l.cst, r.cst));   // folded by V8 itself
+      if (e.op === '/') return num('(' + this.asD(l) + ' / ' + this.asD(r) + ')', false);
+      if (e.op === '%') {
+        if (l.int && r.int && r.cst !== undefined && r.cst !== 0) return num('(' + l.code + ' % ' + r.code + ')', true);
+        return num('js_mod(' + this.asD(l) + ', ' + this.asD(r) + ')', false);
+      }
+      if (l.int && r.int) return num('(' + l.code + ' ' + e.op + ' ' + r.code + ')', true);
+      return num('(' + this.asD(l) + ' ' + e.op + ' ' + this.asD(r) + ')', false);
+    }
+    case 'Logical': {
+      const l = this.expr(e.l), r = this.expr(e.r);
+      if ((l.t !== 'bool' && l.t !== 'num') || (r.t !== 'bool' && r.t !== 'num')) this.fail("'" + e.op + "' on a " + this.describe(l.t !== 'bool' ? l : r));
+      if (l.t === 'num' || r.t === 'num') {
+        if (!this.inCondition) this.fail("'" + e.op + "' is only supported between conditions (value-selecting a || b is not)");
+      }
+      return { t: 'bool', code: '(' + this.asB(l) + ' ' + e.op + ' ' + this.asB(r) + ')' };
+    }
+    case 'Cond': {
+      const t = this.cond(e.test), a = this.expr(e.a), b = this.expr(e.b);
+      if (t.cst !== undefined) return t.cst ? a : b;
+      if (a.t === 'bool' && b.t === 'bool') return { t: 'bool', code: '(' + t.code + ' ? ' + a.code + ' : ' + b.code + ')' };
+      if (a.t !== 'num' || b.t !== 'num') this.fail('both branches of ?: must be numbers');
+      if (a.int && b.int) return num('(' + t.code + ' ? ' + a.code + ' : ' + b.code + ')', true);
+      return num('(' + t.code + ' ? ' + this.asD(a) + ' : ' + this.asD(b) + ')', false);
+    }
+    case 'Call': return this.call(e);
+    case 'Assign': case 'Update': this.fail('assignments are only supported as statements');  // eslint-disable-line no-fallthrough
+    case 'Str': this.fail('strings are not supported (only as property names: data["x"])');   // eslint-disable-line no-fallthrough
+    case 'Seq': this.fail("the ',' operator is not supported");   // eslint-disable-line no-fallthrough
+  }
+  this.fail('unsupported expression (' + e.k + ')');
+};
+
+Translator.prototype.cond = function (e) {
+  const saved = this.inCondition;
+  this.inCondition = true;
+  const v = this.expr(e);
+  this.inCondition = saved;
+  if (v.t === 'bool') return v;
+  return { t: 'bool', code: this.asB(v), cst: v.cst !== undefined ? !!v.cst : undefined };
+};
+
+Translator.prototype.call = function (e) {
+  const f = this.expr(e.callee);
+  if (f.t !== 'fn') this.fail('calling a ' + this.describe(f));
+  const args = e.args.map((a) => this.expr(a));
+  const nums = () => args.map((a) => { if (a.t !== 'num' && a.t !== 'bool') this.fail(f.ns + '.' + f.name + ' got a ' + this.describe(a) + ' argument (only scalar arguments are supported)'); return a; });
+  const allConst = () => args.every((a) => a.cst !== undefined && a.t === 'num');
+  if (f.ns === 'Math') {
+    nums();
+    if (f.name === 'pow') {
+      if (args.length !== 2) this.fail('Math.pow takes two arguments');
+      if (allConst()) return cnum(Math.pow(args[0].cst, args[1].cst));
+      const x = this.asD(args[0]);
+      // V8's pow returns exactly x*x for an exponent of 2 (fdlibm e_pow.c special case), sqrt(x) for 0.5 and x >= 0
+      if (args[1].cst === 2) { const t = this.temp(x); return num('(' + t + ' * ' + t + ')', false, undefined); }
+      if (args[1].cst === 1) return num(x, false);
+      if (this.loops.length) this.heavyLoop = true;
+      return num('pow_v8(' + x + ', ' + this.asD(args[1]) + ')', false);
+    }
+    if (f.name === 'min' || f.name === 'max') {
+      if (args.length < 1) this.fail('Math.' + f.name + ' needs arguments');
+      if (allConst()) return cnum(Math[f.name].apply(null, args.map((a) => a.cst)));
+      let code = this.asD(args[0]);
+      for (let k = 1; k < args.length; k++) code = 'js_' + f.name + '(' + code + ', ' + this.asD(args[k]) + ')';
+      return num(code, false);
+    }
+    const M = MATH_FUNS[f.name];
+    if (!M) this.fail('Math.' + f.name + ' is not supported');
+    if (args.length !== M[1]) this.fail('Math.' + f.name + ' takes ' + M[1] + ' argument(s)');
+    if (allConst()) return cnum(M[2](args[0].cst));
+    if (HEAVY.has(M[0]) && this.loops.length) this.heavyLoop = true;
+    if ((f.name === 'floor' || f.name === 'ceil' || f.name === 'round' || f.name === 'trunc' || f.name === 'abs') && args[0].int)
+      return f.name === 'abs' ? num('(' + args[0].code + ' < 0 ? -(' + args[0].code + ') : ' + args[0].code + ')', true) : args[0];
+    return num(M[0] + '(' + this.asD(args[0]) + ')', false);
+  }
+  if (f.ns === 'ld') {
+    const L = LD_FUNS[f.name];
+    if (!L) this.fail('ld.' + f.name + ' is not supported on the GPU path (array-valued densities: dirichlet, cat, bivarnorm are not translated)');
+    if (args.length !== L[1]) this.fail('ld.' + f.name + ' takes ' + L[1] + ' arguments, got ' + args.length);
+    nums();
+    const a = args.map((x) => this.asD(x));
+    if (f.name === 'norm') { const k = this.hoist(e.args[2], 'NormInv', 'norm_inv', a[2]); if (k) return num('ld_norm_inv(' + a[0] + ', ' + a[1] + ', ' + k + ')', false); }
+    if (f.name === 'bern') { const k = this.hoist(e.args[1], 'BernInv', 'bern_inv', a[1]); if (k) return num('ld_bern_inv(' + a[0] + ', ' + k + ')', false); }
+    if (this.loops.length) this.heavyLoop = true;
+    return num(L[0] + '(' + a.join(', ') + ')', false);
+  }
+  if (f.ns === 'helper') {
+    const h = this.helper(f.name);
+    if (args.length !== h.nargs) this.fail('helper ' + f.name + ' takes ' + h.nargs + ' argument(s)');
+    nums();
+    if (this.loops.length) this.heavyLoop = true;
+    return num(h.cname + '(' + args.map((x) => this.asD(x)).join(', ') + ')', false);
+  }
+  this.fail('unsupported call');
+};
+
+// a named temporary for a value that is used twice (keeps the evaluation single, as in JS)
+Translator.prototype.temp = function (code) {
+  if (/^[\w.]+$/.test(code) || /^S\(\d+\)$/.test(code)) return code;
+  const name = 't' + (this.tmp++);
+  this.pending.push('const double ' + name + ' = ' + code + ';');
+  return name;
+};
+
+// Hoists `ctor(code)` to just before the outermost enclosing loop in which argAst cannot change.
+Translator.prototype.hoist = function (argAst, type, ctor, code) {
+  if (this.noHoist || this.loops.length === 0) return null;
+  const free = idsOf(argAst);
+  let j = this.loops.length;
+  while (j > 0) {
+    const L = this.loops[j - 1];
+    let variant = false;
+    for (const nm of free) if (L.assigned.has(nm)) { variant = true; break; }
+    if (variant) break;
+    j--;
+  }
+  if (j === this.loops.length) return null;   // changes inside the innermost loop
+  if (this.pending.length) return null;       // the argument needs temporaries computed inside the loop
+  const name = 'k' + (this.tmp++);
+  this.loops[j].preamble.push('const ' + type + ' ' + name + ' = ' + ctor + '(' + code + ');');
+  return name;
+};
+
+// ---- helper functions (options.helpers) --------------------------------------------------------
+Translator.prototype.helper = function (name) {
+  if (this.helpers[name]) return this.helpers[name];
+  const fn = this.opts.helpers[name];
+  if (typeof fn !== 'function') this.fail('options.helpers.' + name + ' is not a function');
+  const sub = new Translator(fn, {}, null, { constants: this.opts.constants, helpers: this.opts.helpers }, true);
+  sub.helpers = this.helpers;
+  sub.arrays = this.arrays; sub.arrayIds = this.arrayIds;
+  sub.helperSources = this.helperSources;
+  const h = { cname: 'h_' + name, nargs: sub.ast.params.length };
+  this.helpers[name] = h;
+  const body = sub.functionBody(sub.ast.params, false);
+  this.helperSources.push('AMWG_HD double ' + h.cname + '(' + sub.ast.params.map((p) => 'double v_' + p).join(', ') + ') {\n' + body.join('\n') + '\n}');
+  return h;
+};
+
+// ---- statements ----------------------------------------------------------------------------------
+Translator.prototype.setLocal = function (name, v) {     // records the inferred C++ type of a local
+  if (v.t === 'bool') v = num(this.asD(v), false);
+  if (v.t !== 'num') return false;
+  if (!Object.prototype.hasOwnProperty.call(this.localTypes, name)) this.localTypes[name] = v.int ? 'int' : 'double';
+  else if (this.localTypes[name] === 'int' && !v.int) { this.localTypes[name] = 'double'; this.retype = true; }
+  if (this.forcedDouble.has(name) && this.localTypes[name] === 'int') this.localTypes[name] = 'double';
+  return true;
+};
+
+Translator.prototype.flush = function (out, indent) { for (const p of this.pending) out.push(indent + p); this.pending = []; };
+
+Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) {
+  if (target.k === 'Id') {
+    const name = target.name;
+    if (name === this.stateName || name === this.dataName) this.fail('assigning to ' + name);
+    const v = this.expr(valueAst);
+    if (v.t !== 'num' && v.t !== 'bool') {
+      if (op !== '=') this.fail("'" + op + "' with a " + this.describe(v));
+      if (this.loops.length) this.fail('aliasing an array or object (' + name + ') inside a loop');
+      if (Object.prototype.hasOwnProperty.call(this.localTypes, name)) this.fail(name + ' holds a number elsewhere and an array/object here');
+      this.aliases[name] = v;
+      return;
+    }
+    if (Object.prototype.hasOwnProperty.call(this.aliases, name)) this.fail(name + ' holds an array/object elsewhere and a number here');
+    if (this.acc && name === this.acc) {
+      if (op === '+=') {
+        this.flush(out, indent);
+        out.push(indent + ((ctx.split || !this.split) ? '' : 'if (sub == 0) ') + 'v_' + name + ' += ' + this.asD(v) + ';');
+        return;
+      }
+      // the initialisation `var lp = <const>`
+      this.setLocal(name, num('', false));
+      this.flush(out, indent);
+      out.push(indent + 'v_' + name + ' = ' + (this.split ? '(sub == 0) ? ' + this.asD(v) + ' : 0.0' : this.asD(v)) + ';');
+      return;
+    }
+    if (op === '=') {
+      this.setLocal(name, v);
+      this.flush(out, indent);
+      const isInt = this.localTypes[name] === 'int';
+      out.push(indent + 'v_' + name + ' = ' + (isInt ? this.asI(v) : this.asD(v)) + ';');
+      return;
+    }
+    if (!Object.prototype.hasOwnProperty.call(this.localTypes, name)) this.fail(name + ' is used before it is assigned');
+    const cur = num('v_' + name, this.localTypes[name] === 'int');
+    const bop = op[0];
+    let res;
+    if (bop === '/') res = num('(' + this.asD(cur) + ' / ' + this.asD(v) + ')', false);
+    else if (bop === '%') res = num('js_mod(' + this.asD(cur) + ', ' + this.asD(v) + ')', false);
+    else if (cur.int && v.int) res = num('(' + cur.code + ' ' + bop + ' ' + v.code + ')', true);
+    else res = num('(' + this.asD(cur) + ' ' + bop + ' ' + this.asD(v) + ')', false);
+    this.setLocal(name, res);
+    this.flush(out, indent);
+    out.push(indent + 'v_' + name + ' = ' + (this.localTypes[name] === 'int' ? this.asI(res) : this.asD(res)) + ';');
+    return;
+  }
+  if (target.k === 'Member' && target.obj.k === 'Id' && target.obj.name === this.stateName) {
+    const key = target.prop;
+    if (Object.prototype.hasOwnProperty.call(this.layout, key)) this.fail('log_post assigns to the parameter state.' + key + ' (only derived quantities may be assigned)');
+    if (this.loops.length) this.fail('the derived quantity state.' + key + ' is assigned inside a loop');
+    const v = this.expr(valueAst);
+    if (v.t !== 'num' && v.t !== 'bool') this.fail('the derived quantity state.' + key + ' must be a number (array-valued derived quantities are not supported)');
+    if (this.derived.indexOf(key) < 0) { if (op !== '=') this.fail('state.' + key + ' is updated before it is assigned'); this.derived.push(key); }
+    this.flush(out, indent);
+    const rhs = op === '=' ? this.asD(v) : '(dq_' + key + ' ' + op[0] + ' ' + this.asD(v) + ')';
+    out.push(indent + 'dq_' + key + ' = ' + rhs + ';');
+    return;
+  }
+  this.fail('assignment to this kind of target is not supported (only local variables and derived quantities state.key)');
+};
+
+Translator.prototype.canonicalLoop = function (s) {    // for (i = A; i < B; i++) with B fixed during the loop
+  if (!s.init || !s.test || !s.update) return null;
+  let name, startAst;
+  if (s.init.k === 'VarDecl' && s.init.decls.length === 1 && s.init.decls[0].init) { name = s.init.decls[0].name; startAst = s.init.decls[0].init; }
+  else if (s.init.k === 'ExprStmt' && s.init.expr.k === 'Assign' && s.init.expr.op === '=' && s.init.expr.target.k === 'Id') { name = s.init.expr.target.name; startAst = s.init.expr.value; }
+  else return null;
+  const t = s.test;
+  if (t.k !== 'Binary' || (t.op !== '<' && t.op !== '<=') || t.l.k !== 'Id' || t.l.name !== name) return null;
+  const u = s.update;
+  const inc = (u.k === 'Update' && u.op === '++' && u.target.k === 'Id' && u.target.name === name) ||
+              (u.k === 'Assign' && u.op === '+=' && u.target.k === 'Id' && u.target.name === name && u.value.k === 'Num' && u.value.v === 1);
+  if (!inc) return null;
+  const bodyAssigned = assignedNames(s.body);
+  if (bodyAssigned.has(name)) return null;
+  for (const nm of idsOf(t.r)) if (bodyAssigned.has(nm) || nm === name) return null;
+  return { name, startAst, boundAst: t.r, le: t.op === '<=' };
+};
+
+// can the iterations of this top-level loop be dealt to the lanes of a chain?
+Translator.prototype.splittable = function (s, canon) {
+  if (!this.split || !canon) return false;
+  if (containsKind(s.body, 'Return')) return false;
+  let ok = true;
+  const written = assignedNames(s.body);
+  written.delete(this.acc);
+  // every other variable written in the body must be private to one iteration: definitely assigned
+  // before it is read in every iteration, and not referenced outside loops
+  if (!definitelyAssigned(s.body.k === 'Block' ? s.body.body : [s.body], written, new Set(), this.acc)) ok = false;
+  for (const nm of written) if (this.topLevelRefs.has(nm)) ok = false;
+  if (this.topLevelRefs.has(canon.name)) ok = false;
+  walk(s.body, (x) => {
+    if (x.k === 'Assign' && x.target.k === 'Id' && x.target.name === this.acc && x.op !== '+=') ok = false;
+    if (x.k === 'Assign' && x.target.k !== 'Id') ok = false;   // derived quantities inside a loop
+  });
+  return ok;
+};
+
+Translator.prototype.stmt = function (s, out, indent, ctx) {
+  switch (s.k) {
+    case 'Empty': return;
+    case 'Block': for (const x of s.body) this.stmt(x, out, indent, ctx); return;
+    case 'VarDecl':
+      for (const d of s.decls) {
+        if (d.init) this.assign({ k: 'Id', name: d.name }, '=', d.init, out, indent, ctx);
+        else if (!Object.prototype.hasOwnProperty.call(this.localTypes, d.name) && !Object.prototype.hasOwnProperty.call(this.aliases, d.name)) this.declaredOnly.add(d.name);
+      }
+      return;
+    case 'ExprStmt': {
+      const e = s.expr;
+      if (e.k === 'Assign') return this.assign(e.target, e.op, e.value, out, indent, ctx);
+      if (e.k === 'Update') return this.assign(e.target, e.op === '++' ? '+=' : '-=', { k: 'Num', v: 1 }, out, indent, ctx);
+      if (e.k === 'Seq') { this.stmt({ k: 'ExprStmt', expr: e.l }, out, indent, ctx); this.stmt({ k: 'ExprStmt', expr: e.r }, out, indent, ctx); return; }
+      this.fail('an expression statement that is not an assignment has no effect');
+    }  // eslint-disable-line no-fallthrough
+    case 'If': {
+      const t = this.cond(s.test);
+      this.flush(out, indent);
+      if (t.cst !== undefined) { if (t.cst) this.stmt(s.cons, out, indent, ctx); else if (s.alt) this.stmt(s.alt, out, indent, ctx); return; }
+      out.push(indent + 'if (' + t.code + ') {');
+      this.stmt(s.cons, out, indent + '  ', ctx);
+      if (s.alt) { out.push(indent + '} else {'); this.stmt(s.alt, out, indent + '  ', ctx); }
+      out.push(indent + '}');
+      return;
+    }
+    case 'Return': {
+      if (!s.arg) this.fail('log_post returns nothing');
+      if (this.acc && s.arg.k === 'Id' && s.arg.name === this.acc) {   // `return lp` (the last statement)
+        out.push(indent + this.deriveStore());
+        out.push(indent + 'return v_' + this.acc + ';');
+        return;
+      }
+      if (ctx.split) this.fail('return inside a lane-split loop');   // excluded by splittable()
+      const v = this.expr(s.arg);
+      this.flush(out, indent);
+      out.push(indent + this.deriveStore());
+      out.push(indent + 'return ' + (this.split ? '(sub == 0) ? ' + this.asD(v) + ' : 0.0' : this.asD(v)) + ';');
+      return;
+    }
+    case 'For': return this.forLoop(s, out, indent, ctx);
+  }
+  this.fail('unsupported statement (' + s.k + ')');
+};
+
+Translator.prototype.deriveStore = function () {
+  if (this.isHelper) return '';
+  if (!this.derivedFinal || this.derivedFinal.length === 0) return 'if constexpr (DERIVE) { (void)dv; }';
+  return 'if constexpr (DERIVE) { ' + this.derivedFinal.map((nm, q) => 'dv[' + q + '] = dq_' + nm + ';').join(' ') + ' }';
+};
+
+Translator.prototype.forLoop = function (s, out, indent, ctx) {
+  const canon = this.canonicalLoop(s);
+  const split = !ctx.inLoop && this.splittable(s, canon);
+  if (split) this.nSplit++;
+  const assigned = assignedNames(s);
+  const L = { assigned, preamble: [] };
+  const inner = [];
+  const ind2 = indent + '    ';
+  if (canon) {
+    const startV = this.expr(canon.startAst), boundV = this.expr(canon.boundAst);
+    this.flush(out, indent);
+    this.setLocal(canon.name, startV);
+    const isInt = this.localTypes[canon.name] === 'int';
+    this.loops.push(L);
+    const body = s.body.k === 'Block' ? s.body.body : [s.body];
+    const bctx = { inLoop: true, split: split || ctx.split };
+    // single `acc += term` body of a lane-split loop: U independent terms in flight, added in order
+    const single = split && isInt && boundV.int && body.length === 1 && body[0].k === 'ExprStmt' && body[0].expr.k === 'Assign' &&
+                   body[0].expr.op === '+=' && body[0].expr.target.k === 'Id' && body[0].expr.target.name === this.acc;
+    if (single) {
+      const term = this.expr(body[0].expr.value);
+      const pend = this.pending; this.pending = [];
+      this.loops.pop();
+      out.push(indent + '{');
+      for (const p of L.preamble) out.push(indent + '  ' + p);
+      const U = this.opts.unroll || 8;
+      out.push(indent + '  const int i0_ = ' + this.asI(startV) + ' + sub, n_ = (' + boundV.code + (canon.le ? ' + 1' : '') + ' - i0_ + G - 1) / G;');
+      out.push(indent + '  int it_ = 0;');
+      out.push(indent + '  for (; it_ + ' + U + ' <= n_; it_ += ' + U + ') {');
+      out.push(indent + '    double tb_[' + U + '];');
+      out.push(indent + '#pragma unroll');
+      out.push(indent + '    for (int u_ = 0; u_ < ' + U + '; ++u_) { const int v_' + canon.name + ' = i0_ + (it_ + u_) * G; ' + pend.join(' ') + ' tb_[u_] = ' + this.asD(term) + '; }');
+      out.push(indent + '#pragma unroll');
+      out.push(indent + '    for (int u_ = 0; u_ < ' + U + '; ++u_) v_' + this.acc + ' += tb_[u_];');
+      out.push(indent + '  }');
+      out.push(indent + '  for (; it_ < n_; ++it_) { const int v_' + canon.name + ' = i0_ + it_ * G; ' + pend.join(' ') + ' v_' + this.acc + ' += ' + this.asD(term) + '; }');
+      out.push(indent + '}');
+      return;
+    }
+    for (const x of body) this.stmt(x, inner, ind2, bctx);
+    this.loops.pop();
+    out.push(indent + '{');
+    for (const p of L.preamble) out.push(indent + '  ' + p);
+    const v = 'v_' + canon.name;
+    const cmp = canon.le ? ' <= ' : ' < ';
+    const bound = isInt && boundV.int ? boundV.code : this.asD(boundV);
+    const lhs = isInt && !boundV.int ? '(double)' + v : v;
+    const start = isInt ? this.asI(startV) : this.asD(startV);
+    if (split) out.push(indent + '  for (' + v + ' = ' + start + ' + sub; ' + lhs + cmp + bound + '; ' + v + ' += G) {');
+    else out.push(indent + '  for (' + v + ' = ' + start + '; ' + lhs + cmp + bound + '; ' + v + ' += 1) {');
+    for (const ln of inner) out.push(ln);
+    out.push(indent + '  }');
+    out.push(indent + '}');
+    return;
+  }
+  // general loop: init; while (test) { body; update; }
+  if (s.init) this.stmt(s.init, out, indent, ctx);
+  this.loops.push(L);
+  const bctx = { inLoop: true, split: ctx.split };
+  this.noHoist = true;   // temporaries of the condition would have to be recomputed; keep it simple
+  const t = s.test ? this.cond(s.test) : { code: 'true' };
+  if (this.pending.length) this.fail('this loop condition is too complex (it needs temporaries)');
+  this.noHoist = false;
+  this.stmt(s.body, inner, ind2, bctx);
+  if (s.update) this.stmt({ k: 'ExprStmt', expr: s.update }, inner, ind2, bctx);
+  this.loops.pop();
+  out.push(indent + '{');
+  for (const p of L.preamble) out.push(indent + '  ' + p);
+  out.push(indent + '  while (' + t.code + ') {');
+  for (const ln of inner) out.push(ln);
+  out.push(indent + '  }');
+  out.push(indent + '}');
+};
+
+// Generates the body (declarations + statements) with a fix-point over the inferred local types.
+Translator.prototype.functionBody = function (numericParams, allowSplit) {
+  const body = this.ast.body;
+  // ---- accumulator discipline (is the result a sum that lanes can share?)
+  this.acc = null;
+  this.split = false;
+  const stmts = body.body;
+  const last = stmts[stmts.length - 1];
+  if (allowSplit && last && last.k === 'Return' && last.arg && last.arg.k === 'Id') {
+    const name = last.arg.name;
+    let ok = true, reads = 0;
+    walk(body, (x) => {
+      if (x.k === 'Assign' && x.target.k === 'Id' && x.target.name === name) { if (x.op !== '+=' && x.op !== '=') ok = false; if (idsOf(x.value).has(name)) ok = false; }
+      else if (x.k === 'Update' && x.target.k === 'Id' && x.target.name === name) ok = false;
+      if (x.k === 'Id' && x.name === name) reads++;
+    });
+    // occurrences: one per declaration-free assignment target, plus the final return
+    let writes = 0, decls = 0, constInit = true;
+    walk(body, (x) => {
+      if (x.k === 'Assign' && x.target.k === 'Id' && x.target.name === name) { writes++; if (x.op === '=' && idsOf(x.value).size) constInit = false; }
+      if (x.k === 'VarDecl') x.decls.forEach((d) => { if (d.name === name) { decls++; if (d.init && idsOf(d.init).size) constInit = false; } });
+    });
+    let returns = 0;
+    walk(body, (x) => { if (x.k === 'Return' && x.arg && idsOf(x.arg).has(name)) returns++; });
+    if (ok && constInit && decls <= 1 && reads === writes + returns && returns === 1) { this.acc = name; this.split = true; }
+  }
+  // names referenced at the top level of the function (outside every loop): lane-split loops may not leak into them
+  this.topLevelRefs = new Set();
+  const scanTop = (list) => {
+    for (const st of list) {
+      if (st.k === 'For') { if (st.init && st.init.k === 'ExprStmt') idsOf(st.init).forEach((n) => 0); continue; }
+      if (st.k === 'Block') { scanTop(st.body); continue; }
+      if (st.k === 'If') { idsOf(st.test).forEach((n) => this.topLevelRefs.add(n)); scanTop([st.cons]); if (st.alt) scanTop([st.alt]); continue; }
+      if (st.k === 'VarDecl') { st.decls.forEach((d) => { if (d.init) idsOf(d.init).forEach((n) => this.topLevelRefs.add(n)); }); continue; }
+      idsOf(st).forEach((n) => this.topLevelRefs.add(n));
+    }
+  };
+  scanTop(stmts);
+  if (this.acc) this.topLevelRefs.delete(this.acc);
+
+  this.forcedDouble = new Set();
+  let lines;
+  for (let round = 0; round < 8; round++) {
+    const keepTypes = this.localTypes;
+    this.localTypes = {};
+    for (const p of numericParams) this.localTypes[p] = 'double';
+    for (const nm of Object.keys(keepTypes)) if (keepTypes[nm] === 'double') this.forcedDouble.add(nm);
+    this.aliases = {};
+    this.declaredOnly = new Set();
+    this.derivedFinal = this.derived.slice();
+    this.derived = [];
+    this.loops = [];
+    this.pending = [];
+    this.retype = false;
+    this.tmp = 0;
+    this.nSplit = 0;
+    this.heavyLoop = false;
+    lines = [];
+    for (const st of stmts) this.stmt(st, lines, '    ', { inLoop: false, split: false });
+    if (!last || last.k !== 'Return') this.fail('log_post must end with a return statement');
+    const stable = !this.retype && this.derivedFinal.join() === this.derived.join();
+    if (stable) break;
+    if (round === 7) this.fail('could not infer variable types');
+  }
+  const decl = [];
+  for (const nm of Object.keys(this.localTypes)) {
+    if (numericParams.indexOf(nm) >= 0) continue;
+    decl.push('    ' + (this.localTypes[nm] === 'int' ? 'int' : 'double') + ' v_' + nm + ' = 0;');
+  }
+  for (const nm of this.derived) decl.push('    double dq_' + nm + ' = 0;');
+  return decl.concat(lines);
+};
+
+Translator.prototype.run = function () {
+  const body = this.functionBody([], true);
+  // did any loop actually get split?
+  const parallel = this.split && this.nSplit > 0;
+  // ---- LDS staging plan: whole arrays, in order of first use, while they fit the budget
+  const budget = this.opts.lds_budget === undefined ? 98304 : this.opts.lds_budget;
+  let off = 0;
+  const plan = this.arrays.map((a) => {
+    const bytes = a.flat.length * 8;
+    if (bytes > 0 && off + bytes <= budget) { const o = off; off += (bytes + 15) & ~15; return { lds: true, off: o }; }
+    return { lds: false, off: 0 };
+  });
+  const D = this.derived.length;
+  const maxThreads = this.opts.max_threads || (this.heavyLoop ? 256 : 1024);
+  const src = [];
+  src.push('// generated by bayes.js_amd/translate.js from the user\'s log_post closure');
+  src.push('namespace amwg {');
+  for (const h of this.helperSources) src.push(h);
+  src.push('struct UserModel {');
+  src.push('  static constexpr bool kUser = true, kHasFast = false, kOneLanePass = false;');
+  src.push('  static constexpr int kDerived = ' + D + ';');
+  src.push('  static constexpr int kMaxThreads = ' + maxThreads + ';');
+  src.push('#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)');
+  src.push('  __host__ __device__ static size_t lds_bytes(int, int, int) { return ' + off + '; }');
+  src.push('  __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int) {');
+  this.arrays.forEach((a, j) => {
+    if (plan[j].lds) src.push('    { double *dst = reinterpret_cast<double *>(smem + ' + plan[j].off + '); const double *src = d.arr[' + j + ']; for (int i = tid; i < ' + a.flat.length + '; i += nt) dst[i] = src[i]; }');
+  });
+  src.push('  }');
+  src.push('#endif');
+  src.push('  template <int G, bool DERIVE>');
+  src.push('  AMWG_HD static double eval(const StateView &S, const DataRef &d, const unsigned char *smem, int sub, double *dv) {');
+  src.push('#if defined(__HIP_DEVICE_COMPILE__)');
+  this.arrays.forEach((a, j) => {
+    src.push('    const double *A' + j + ' = ' + (plan[j].lds ? 'reinterpret_cast<const double *>(smem + ' + plan[j].off + ')' : 'd.arr[' + j + ']') + ';');
+  });
+  src.push('#else');
+  this.arrays.forEach((a, j) => { src.push('    const double *A' + j + ' = d.arr[' + j + '];'); });
+  src.push('#endif');
+  src.push('    (void)smem; (void)sub; (void)d;');
+  for (const ln of body) src.push(ln);
+  src.push('  }');
+  src.push('};');
+  src.push('}  // namespace amwg');
+  return {
+    source: src.join('\n') + '\n',
+    arrays: this.arrays.map((a) => a.flat),
+    array_keys: this.arrays.map((a) => a.key),
+    derived: this.derived.slice(),
+    lds_bytes: off,
+    parallel: parallel ? 1 : 0,
+    max_threads: maxThreads,
+    P: this.P,
+  };
+};
+
+/** translate(log_post, completedParams, data[, options]) -> {source, arrays, derived, lds_bytes, parallel, max_threads} */
+function translate(fn, params, data, options) {
+  return new Translator(fn, params, data, options).run();
+}
+
+module.exports = { translate, parseFunctionSource, hexFloat, tokenize };

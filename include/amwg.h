@@ -48,12 +48,12 @@ enum {
   AMWG_MODEL_POIS_GLM = 4     /* beta_k ~ norm(0,10); cp ~ unif(0,N-1); y_i ~ pois(exp(X_i.beta[0:K] + [i>=cp] beta[7])) */
 };
 
-enum { AMWG_REAL = 0, AMWG_INT = 1 };
+enum { AMWG_REAL = 0, AMWG_INT = 1, AMWG_BINARY = 2 };
 
 /* One named parameter AFTER complete_params() (mcmc.js:357-403), flattened row-major.
  * The order of the array is Object.keys(params) order (mcmc.js:839). */
 typedef struct {
-  int32_t type;      /* AMWG_REAL | AMWG_INT  ("binary" is not on this path: SURVEY.md §8f) */
+  int32_t type;      /* AMWG_REAL | AMWG_INT (Metropolis steppers, mcmc.js:517-553) | AMWG_BINARY (BinaryStepper, mcmc.js:753-767) */
   int32_t len;       /* prod(dim) */
   int32_t top;       /* dim[0]: the only dimension whose visiting order is shuffled (mcmc.js:244-258) */
   int32_t multidim;  /* 0 iff dim equals [1]  (stepper dispatch rule, mcmc.js:846-857) */
@@ -107,6 +107,31 @@ typedef struct amwg_sampler amwg_sampler;
 int amwg_create(const amwg_model_desc *model, const amwg_param_desc *params, int32_t n_params, const double *init,
                 const amwg_comp_opt *comp_opts, const amwg_options *options, amwg_sampler **out);
 
+/* A user-written `log_post(state, data)` closure (mcmc.js:958-960) translated to HIP by
+ * bayes.js_amd/translate.js.  `source` defines `struct amwg::UserModel` (interface: csrc/amwg_kernel.h,
+ * "translated closure"); amwg_create_user compiles it with hiprtc for the device's gfx target,
+ * together with the same step kernel the built-in models use.  Arrays are the numeric arrays of
+ * the closure's `data` argument that the body reads, flattened row-major. */
+#define AMWG_MAX_USER_ARRAYS 16
+typedef struct {
+  const char *source;            /* HIP C++ text (NUL-terminated) */
+  int32_t n_arrays;              /* <= AMWG_MAX_USER_ARRAYS */
+  const double *const *arrays;   /* host pointers; copied to the device by amwg_create_user */
+  const int64_t *array_len;      /* elements per array */
+  int32_t n_derived;             /* derived quantities (`state.key = expr`, mcmc.js:961-963, 990-995) recorded after the P components */
+  int32_t lds_bytes;             /* bytes of data the generated stage() keeps in LDS */
+  int32_t parallel;              /* 1 = the body has lane-split loops, lanes_per_chain > 1 is allowed */
+  int32_t max_threads;           /* workgroup-size cap the translator suggests (0 = 1024) */
+} amwg_user_model;
+
+/* Replaces `new mcmc.AmwgSampler(params, log_post, data, options)` for an arbitrary (translated) closure. */
+int amwg_create_user(const amwg_user_model *model, const amwg_param_desc *params, int32_t n_params, const double *init,
+                     const amwg_comp_opt *comp_opts, const amwg_options *options, amwg_sampler **out);
+
+/* hiprtc compilation of a translated closure without a device (build-time / CPU-test check).
+ * arch e.g. "gfx950".  On failure returns AMWG_EINVAL and amwg_last_error() carries the compiler log. */
+int amwg_compile_user(const char *source, int32_t lanes_per_chain, int32_t block_threads, const char *arch, size_t *code_bytes);
+
 /* Replaces sampler.burn(n) (mcmc.js:1035-1039).  amwg_burn blocks until the steps are done;
  * amwg_burn_async only enqueues them on the sampler's stream (pair with amwg_sync), which is how
  * one host thread keeps several GPUs busy. */
@@ -115,7 +140,8 @@ int amwg_burn_async(amwg_sampler *s, int64_t n);
 
 /* Replaces sampler.sample(n) with thinning interval `thin` (mcmc.js:1005-1030, 1053-1055):
  * draw k is the state BEFORE step k*thin.  out_draws (host) receives ceil(n/thin) * P * chains
- * doubles laid out [draw][component][chain]; out_bytes is its capacity. */
+ * doubles laid out [draw][component][chain]; out_bytes is its capacity.  (P here and below means
+ * amwg_num_recorded(): the parameters followed by a translated closure's derived quantities.) */
 int amwg_sample(amwg_sampler *s, int64_t n, int64_t thin, double *out_draws, size_t out_bytes);
 
 /* Two-phase form of amwg_sample for multi-GPU hosts: enqueue the steps into a library-owned
@@ -149,7 +175,8 @@ int amwg_chain_diag(amwg_sampler *s, uint64_t *uniforms, double *log_post, int32
 int amwg_last_sample_moments(amwg_sampler *s, double *mean, double *sd);
 
 int amwg_sync(amwg_sampler *s);
-int amwg_num_components(const amwg_sampler *s);
+int amwg_num_components(const amwg_sampler *s);   /* P: scalar parameter components */
+int amwg_num_recorded(const amwg_sampler *s);     /* values per draw row: P + derived quantities */
 int64_t amwg_num_chains(const amwg_sampler *s);
 /* Launch geometry actually used and HIP-event time of the step kernels of the last burn/sample call. */
 int amwg_launch_info(const amwg_sampler *s, int32_t *lanes_per_chain, int32_t *block_threads, int32_t *grid_blocks,
@@ -166,6 +193,13 @@ double amwg_uniform(uint64_t seed, uint64_t chain, uint64_t index);
 /* Device evaluation: op in {0:exp,1:log,2:sqrt,3:lgamma,4:a/b via hoisted reciprocal,5:ld_norm(a,b,c),...};
  * a,b,c host arrays of n doubles (b,c may be NULL), out host array of n doubles. */
 int amwg_device_eval(int32_t device, int32_t op, int64_t n, const double *a, const double *b, const double *c, double *out);
+double amwg_pow(double x, double y);   /* bit-identical to V8 Math.pow */
+/* Every scalar ld.* density and helper of distributions.js by id (0 norm 1 unif 2 beta 3 bern 4 pois 5 cauchy
+ * 6 laplace 7 gamma 8 invgamma 9 lnorm 10 pareto 11 t 12 weibull 13 logis 14 exp 15 binom 16 nbinom 17 hyper
+ * 18 lgamma 19 lfactorial 20 lchoose 21 lbeta): host evaluation of the kernel's own source, and the same on
+ * the device for n records of {id, x, a, b, c}. */
+double amwg_ld_host(int32_t id, double x, double a, double b, double c);
+int amwg_ld_device(int32_t device, int64_t n, const double *records, double *out);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,9 @@ double orc_ld_beta(double x, double a, double b);
 double orc_ld_bern(double x, double p);
 double orc_ld_pois(double x, double lambda);
 double orc_lgamma(double x);
+double orc_pow(double x, double y);   /* V8 Math.pow */
+/* every scalar density / helper of distributions.js by id (oracle/gen_ld_golden.js lists the ids) */
+double orc_ld(int id, double x, double a, double b, double c);
 
 #ifdef __cplusplus
 }

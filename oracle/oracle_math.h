@@ -22,6 +22,7 @@
 #ifndef AMWG_ORACLE_MATH_H
 #define AMWG_ORACLE_MATH_H
 
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -149,6 +150,194 @@ static double om_log(double x) {
   }
   if (k == 0) return f - s * (f - R);
   return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+
+/* pow(x, y): fdlibm e_pow.c as carried by V8 (src/base/ieee754.cc, ieee754::pow), which is what
+ * Math.pow evaluates on the reference's engine (distributions.js:98 `pow = Math.pow`; used with
+ * general exponents by ld.t :185-189 and ld.weibull :194-200).  log2(x) in two pieces
+ * (t1 + t2), y*log2(x) in two pieces, then 2^(p_h + p_l).  ECMAScript deviates from C in one
+ * place: (+-1) ** (+-Infinity) is NaN (fdlibm's `y - y`), and V8's port differs from fdlibm in one
+ * grouping (marked below).  Pinned against Node's own Math.pow by
+ * tests/test_oracle_math.py (tests/golden/v8_pow_pairs.bin, oracle/gen_math_pairs.js). */
+static double om_scalbn(double x, int n) { /* fdlibm s_scalbn.c */
+  static const double two54 = 1.80143985094819840000e+16, twom54 = 5.55111512312578270212e-17, huge = 1.0e+300, tiny = 1.0e-300;
+  int32_t hx = om_hi(x), k;
+  uint32_t lx = om_lo(x);
+  k = (hx & 0x7ff00000) >> 20;
+  if (k == 0) {
+    if ((lx | (uint32_t)(hx & 0x7fffffff)) == 0) return x;
+    x *= two54;
+    hx = om_hi(x);
+    k = ((hx & 0x7ff00000) >> 20) - 54;
+    if (n < -50000) return tiny * x;
+  }
+  if (k == 0x7ff) return x + x;
+  k = k + n;
+  if (k > 0x7fe) return huge * (x < 0 ? -huge : huge);
+  if (k > 0) return om_with_hi(x, (hx & (int32_t)0x800fffff) | (k << 20));
+  if (k <= -54) {
+    if (n > 50000) return huge * (x < 0 ? -huge : huge);
+    return tiny * (x < 0 ? -tiny : tiny);
+  }
+  k += 54;
+  x = om_with_hi(x, (hx & (int32_t)0x800fffff) | (k << 20));
+  return x * twom54;
+}
+
+static double om_sqrt(double x) { return sqrt(x); }   /* IEEE, correctly rounded */
+static double om_pow(double x, double y) {
+  static const double bp[2] = {1.0, 1.5}, dp_h[2] = {0.0, 5.84962487220764160156e-01}, dp_l[2] = {0.0, 1.35003920212974897128e-08};
+  static const double zero = 0.0, one = 1.0, two = 2.0, two53 = 9007199254740992.0, huge = 1.0e300, tiny = 1.0e-300,
+    L1 = 5.99999999999994648725e-01, L2 = 4.28571428578550184252e-01, L3 = 3.33333329818377432918e-01,
+    L4 = 2.72728123808534006489e-01, L5 = 2.30660745775561754067e-01, L6 = 2.06975017800338417784e-01,
+    P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+    P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08,
+    lg2 = 6.93147180559945286227e-01, lg2_h = 6.93147182464599609375e-01, lg2_l = -1.90465429995776804525e-09,
+    ovt = 8.0085662595372944372e-0017, cp = 9.61796693925975554329e-01, cp_h = 9.61796700954437255859e-01,
+    cp_l = -7.02846165095275826516e-09, ivln2 = 1.44269504088896338700e+00, ivln2_h = 1.44269502162933349609e+00,
+    ivln2_l = 1.92596299112661746887e-08;
+  double z, ax, z_h, z_l, p_h, p_l, y1, t1, t2, r, s, t, u, v, w;
+  int32_t i, j, k, yisint, n, hx, hy, ix, iy;
+  uint32_t lx, ly;
+  hx = om_hi(x); lx = om_lo(x);
+  hy = om_hi(y); ly = om_lo(y);
+  ix = hx & 0x7fffffff; iy = hy & 0x7fffffff;
+  if ((iy | ly) == 0) return one;
+  if (ix > 0x7ff00000 || ((ix == 0x7ff00000) && (lx != 0)) || iy > 0x7ff00000 || ((iy == 0x7ff00000) && (ly != 0))) return x + y;
+  yisint = 0;
+  if (hx < 0) {
+    if (iy >= 0x43400000) yisint = 2;
+    else if (iy >= 0x3ff00000) {
+      k = (iy >> 20) - 0x3ff;
+      if (k > 20) {
+        j = (int32_t)(ly >> (52 - k));
+        if ((uint32_t)(j << (52 - k)) == ly) yisint = 2 - (j & 1);
+      } else if (ly == 0) {
+        j = iy >> (20 - k);
+        if ((j << (20 - k)) == iy) yisint = 2 - (j & 1);
+      }
+    }
+  }
+  if (ly == 0) {
+    if (iy == 0x7ff00000) {
+      if (((ix - 0x3ff00000) | lx) == 0) return y - y;          /* (+-1)**+-inf is NaN (also the ECMAScript rule) */
+      else if (ix >= 0x3ff00000) return (hy >= 0) ? y : zero;
+      else return (hy < 0) ? -y : zero;
+    }
+    if (iy == 0x3ff00000) { if (hy < 0) return one / x; else return x; }
+    if (hy == 0x40000000) return x * x;
+    if (hy == 0x3fe00000) { if (hx >= 0) return om_sqrt(x); }
+  }
+  ax = x < 0 ? -x : x;
+  if (om_hi(ax) < 0) ax = -ax; /* -0 */
+  if (lx == 0) {
+    if (ix == 0x7ff00000 || ix == 0 || ix == 0x3ff00000) {
+      z = ax;
+      if (hy < 0) z = one / z;
+      if (hx < 0) {
+        if (((ix - 0x3ff00000) | yisint) == 0) z = (z - z) / (z - z);
+        else if (yisint == 1) z = -z;
+      }
+      return z;
+    }
+  }
+  n = (hx < 0) ? 0 : 1;   /* fdlibm: (hx >> 31) + 1 */
+  if ((n | yisint) == 0) return (x - x) / (x - x);
+  s = one;
+  if ((n | (yisint - 1)) == 0) s = -one;
+  if (iy > 0x41e00000) {
+    if (iy > 0x43f00000) {
+      if (ix <= 0x3fefffff) return (hy < 0) ? huge * huge : tiny * tiny;
+      if (ix >= 0x3ff00000) return (hy > 0) ? huge * huge : tiny * tiny;
+    }
+    if (ix < 0x3fefffff) return (hy < 0) ? s * huge * huge : s * tiny * tiny;
+    if (ix > 0x3ff00000) return (hy > 0) ? s * huge * huge : s * tiny * tiny;
+    t = ax - one;
+    w = (t * t) * (0.5 - t * (0.3333333333333333333333 - t * 0.25));
+    u = ivln2_h * t;
+    v = t * ivln2_l - w * ivln2;
+    t1 = u + v;
+    t1 = om_from_bits(om_bits(t1) & 0xffffffff00000000ull);
+    t2 = v - (t1 - u);
+  } else {
+    double ss, s2, s_h, s_l, t_h, t_l;
+    n = 0;
+    if (ix < 0x00100000) { ax *= two53; n -= 53; ix = om_hi(ax); }
+    n += ((ix) >> 20) - 0x3ff;
+    j = ix & 0x000fffff;
+    ix = j | 0x3ff00000;
+    if (j <= 0x3988E) k = 0;
+    else if (j < 0xBB67A) k = 1;
+    else { k = 0; n += 1; ix -= 0x00100000; }
+    ax = om_with_hi(ax, ix);
+    u = ax - bp[k];
+    v = one / (ax + bp[k]);
+    ss = u * v;
+    s_h = om_from_bits(om_bits(ss) & 0xffffffff00000000ull);
+    t_h = om_from_bits((uint64_t)(uint32_t)(((ix >> 1) | 0x20000000) + 0x00080000 + (k << 18)) << 32);
+    t_l = ax - (t_h - bp[k]);
+    s_l = v * ((u - s_h * t_h) - s_h * t_l);
+    s2 = ss * ss;
+    r = s2 * s2 * (L1 + s2 * (L2 + s2 * (L3 + s2 * (L4 + s2 * (L5 + s2 * L6)))));
+    r += s_l * (s_h + ss);
+    s2 = s_h * s_h;
+    t_h = 3.0 + s2 + r;
+    t_h = om_from_bits(om_bits(t_h) & 0xffffffff00000000ull);
+    t_l = r - ((t_h - 3.0) - s2);
+    u = s_h * t_h;
+    v = s_l * t_h + t_l * ss;
+    p_h = u + v;
+    p_h = om_from_bits(om_bits(p_h) & 0xffffffff00000000ull);
+    p_l = v - (p_h - u);
+    z_h = cp_h * p_h;
+    z_l = cp_l * p_h + p_l * cp + dp_l[k];
+    t = (double)n;
+    t1 = (((z_h + z_l) + dp_h[k]) + t);
+    t1 = om_from_bits(om_bits(t1) & 0xffffffff00000000ull);
+    t2 = z_l - (((t1 - t) - dp_h[k]) - z_h);
+  }
+  y1 = om_from_bits(om_bits(y) & 0xffffffff00000000ull);
+  p_l = (y - y1) * t1 + y * t2;
+  p_h = y1 * t1;
+  z = p_l + p_h;
+  j = om_hi(z);
+  i = (int32_t)om_lo(z);
+  if (j >= 0x40900000) {
+    if (((j - 0x40900000) | i) != 0) return s * huge * huge;
+    else { if (p_l + ovt > z - p_h) return s * huge * huge; }
+  } else if ((j & 0x7fffffff) >= 0x4090cc00) {
+    if (((j - (int32_t)0xc090cc00) | i) != 0) return s * tiny * tiny;
+    else { if (p_l <= z - p_h) return s * tiny * tiny; }
+  }
+  i = j & 0x7fffffff;
+  k = (i >> 20) - 0x3ff;
+  n = 0;
+  if (i > 0x3fe00000) {
+    n = j + (0x00100000 >> (k + 1));
+    k = ((n & 0x7fffffff) >> 20) - 0x3ff;
+    t = om_from_bits((uint64_t)(uint32_t)(n & ~(0x000fffff >> k)) << 32);
+    n = ((n & 0x000fffff) | 0x00100000) >> (20 - k);
+    if (j < 0) n = -n;
+    p_h -= t;
+  }
+  t = p_l + p_h;
+  t = om_from_bits(om_bits(t) & 0xffffffff00000000ull);
+  u = t * lg2_h;
+  v = (p_l - (t - p_h)) * lg2 + t * lg2_l;
+  z = u + v;
+  w = v - (z - u);
+  t = z * z;
+  t1 = z - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  /* V8's port groups this as z*t1 / ((t1-2) - (w+z*w)) where fdlibm has (z*t1)/(t1-2) - (w+z*w);
+   * Node's Math.pow follows V8 (300 000 pairs, tests/golden/v8_pow_pairs.bin), so does this. */
+  r = (z * t1) / ((t1 - two) - (w + z * w));
+  z = one - (r - z);
+  j = om_hi(z);
+  j += (n << 20);
+  if ((j >> 20) <= 0) z = om_scalbn(z, n);
+  else z = om_with_hi(z, om_hi(z) + (n << 20));
+  return s * z;
 }
 
 #endif

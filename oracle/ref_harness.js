@@ -41,12 +41,12 @@ function flattenSteppers(amwg) {
 }
 function flat(v) { const o = []; const rec = (x) => { if (Array.isArray(x)) x.forEach(rec); else o.push(x); }; rec(v); return o; }
 
-function runChain(c, data, chain) {
+function runChain(c, data, chain, model) {
   const rand = stream(c.seed, chain);
   const saved = Math.random;
   Math.random = rand;
   try {
-    const m = (c.hyper ? makeModels(ld, { [c.model]: c.hyper }) : models)[c.model];
+    const m = model || (c.hyper ? makeModels(ld, { [c.model]: c.hyper }) : models)[c.model];
     const params = m.params(data);
     const sampler = new mcmc.AmwgSampler(params, m.log_post, data, c.options);
     const names = Object.keys(params);
@@ -59,6 +59,17 @@ function runChain(c, data, chain) {
     const params_completed = names.map((nm) => { const p = sampler.params[nm];
       return { name: nm, type: p.type, dim: p.dim, lower: p.lower, upper: p.upper, init: flat(p.init) }; });
     comps.forEach((st, ci) => {
+      if (st.prop_log_scale === undefined) {   // BinaryStepper (mcmc.js:740-767): count evaluations and flips
+        const protoStep = Object.getPrototypeOf(st).step;
+        st.step = function () {
+          const before = this.state[this.param_name];
+          const r = protoStep.call(this);
+          inbounds[ci]++;
+          if (this.state[this.param_name] !== before) accepts[ci]++;
+          return r;
+        };
+        return;
+      }
       const lp0 = st.log_post; let seen = [];
       st.log_post = function () { const v = lp0(); seen.push(v); return v; };
       const protoStep = Object.getPrototypeOf(st).step;
@@ -78,22 +89,25 @@ function runChain(c, data, chain) {
       else if (seg.op === 'sample') {
         if (seg.thin) sampler.thin(seg.thin);
         const s = sampler.sample(seg.n);
+        // every recorded key: the parameters, then the closure's derived quantities (mcmc.js:1009-1013)
+        const keys = Object.keys(s);
         const kept = s[names[0]].length, rows = [];
         const keep = seg.keep === undefined ? kept : Math.min(kept, seg.keep);
-        for (let t = 0; t < keep; t++) { let row = []; for (const nm of names) row = row.concat(flat(s[nm][t])); rows.push(row); }
+        for (let t = 0; t < keep; t++) { let row = []; for (const nm of keys) row = row.concat(flat(s[nm][t])); rows.push(row); }
         // running sums over ALL kept draws so long runs can be checked without storing them
         const P = rows.length ? rows[0].length : 0, sum = new Array(P).fill(0);
-        for (let t = 0; t < kept; t++) { let j = 0; for (const nm of names) for (const v of flat(s[nm][t])) sum[j++] += v; }
-        segs.push({ kept: kept, draws: rows, sum: sum });
+        for (let t = 0; t < kept; t++) { let j = 0; for (const nm of keys) for (const v of flat(s[nm][t])) sum[j++] += v; }
+        segs.push({ kept: kept, draws: rows, sum: sum, keys: keys });
       }
     }
     out.samples = segs;
     out.final_state = []; for (const nm of names) out.final_state = out.final_state.concat(flat(sampler.state[nm]));
     out.accepts = accepts; out.inbounds = inbounds;
-    out.prop_log_scale = comps.map((s) => s.prop_log_scale);
-    out.batch_count = comps.map((s) => s.batch_count);
-    out.acceptance_count = comps.map((s) => s.acceptance_count);
-    out.iterations_since_adaption = comps.map((s) => s.iterations_since_adaption);
+    const orZero = (v) => (v === undefined ? 0 : v);   // BinarySteppers keep no adaptation state
+    out.prop_log_scale = comps.map((s) => orZero(s.prop_log_scale));
+    out.batch_count = comps.map((s) => orZero(s.batch_count));
+    out.acceptance_count = comps.map((s) => orZero(s.acceptance_count));
+    out.iterations_since_adaption = comps.map((s) => orZero(s.iterations_since_adaption));
     out.uniforms = rand.count;
     out.log_post = sampler.log_post();
     // the order of the named sub-steppers after the last in-place shuffle (mcmc.js:887)
@@ -114,7 +128,7 @@ function stringify(o) {
   return JSON.stringify(o, (k, v) => (typeof v === 'number' && !isFinite(v)) ? (isNaN(v) ? '__nan' : (v > 0 ? '__inf' : '__-inf')) : v);
 }
 
-module.exports = { stringify, runCase, makeData, models, mcmc, ld };
+module.exports = { stringify, runCase, runChain, makeData, models, mcmc, ld };
 
 if (require.main === module) {
   const c = JSON.parse(require('fs').readFileSync(process.argv[2], 'utf8'));

@@ -117,9 +117,43 @@ assert.strictEqual(models.normal()({ mu: 180, sigma: 5 }, data10), readme_normal
 
 // ---- errors (thrown as strings, like the reference) before any device is touched
 const params = { mu: { type: 'real' }, sigma: { type: 'real', lower: 0 } };
-assert.throws(() => new mcmc.AmwgSampler(params, (s, d) => 0, data10), (e) => typeof e === 'string' && /not a model this GPU sampler can run/.test(e));
+// a closure outside the translatable subset is refused with a string that says why (no CPU fallback)
+assert.throws(() => new mcmc.AmwgSampler(params, (s, d) => Math.sin(s.mu), data10), (e) => typeof e === 'string' && /cannot translate log_post: Math\.sin is not supported/.test(e));
+assert.throws(() => new mcmc.AmwgSampler(params, function (s, d) { return helper(s.mu); }, data10), (e) => typeof e === 'string' && /'helper' is not defined inside log_post/.test(e));
+assert.throws(() => new mcmc.AmwgSampler(params, function (s, d) { s.mu = 1; return 0; }, data10), (e) => typeof e === 'string' && /assigns to the parameter state\.mu/.test(e));
+assert.throws(() => new mcmc.AmwgSampler(params, function (s, d) { return s.tau; }, data10), (e) => typeof e === 'string' && /state\.tau is read but it is neither a parameter nor a derived quantity/.test(e));
+assert.throws(() => new mcmc.AmwgSampler(params, function (s, d) { for (var k in d) { } return 0; }, data10), (e) => typeof e === 'string' && /for-in/.test(e));
 assert.throws(() => new mcmc.AmwgSampler({ sigma: { lower: 0 }, mu: {} }, readme_normal, data10), (e) => typeof e === 'string' && /expects params declared as/.test(e));
-assert.throws(() => new mcmc.AmwgSampler({ mu: { type: 'binary' }, sigma: {} }, readme_normal, data10), (e) => e === "AmwgStepper can't handle parameter mu with type binary");
+assert.throws(() => new mcmc.AmwgSampler({ mu: { type: 'binary' }, sigma: {} }, readme_normal, data10), (e) => typeof e === 'string' && /has no binary parameters/.test(e));
+assert.throws(() => new mcmc.AmwgSampler({ mu: { type: 'complex', init: 1 }, sigma: {} }, readme_normal, data10), (e) => e === "AmwgStepper can't handle parameter mu with type complex");
+
+// ---- the translator: every closure of tests/js/user_models.js becomes HIP text that hiprtc compiles for gfx950
+// together with the step kernel (no device needed); values are checked in tests/test_translate.py
+{
+  const um = require('./user_models.js');
+  for (const name of um.names) {
+    const m = um.build(name);
+    const tr = mcmc.translate(m.log_post, mcmc.complete_params(m.params, mcmc.param_init_fixed), m.data, { helpers: m.helpers, constants: m.constants });
+    assert.ok(tr.source.indexOf('struct UserModel') > 0, name);
+    assert.ok(mcmc.native().compileUser(tr.source, tr.parallel ? 4 : 1, 256, 'gfx950') > 10000, name);
+  }
+  // README closures translate to lane-split, LDS-staged, hoisted code
+  const tr = mcmc.translate(readme_normal, mcmc.complete_params(params, mcmc.param_init_fixed), data10, {});
+  assert.strictEqual(tr.parallel, 1);
+  assert.strictEqual(tr.lds_bytes, 80);
+  assert.ok(/norm_inv\(S\(1\)\)/.test(tr.source) && /ld_norm_inv\(A0\[v_i\], S\(0\), k0\)/.test(tr.source));
+  // every host-side ld.* equals the reference's value on the committed argument sets (tests/golden/ld_values.bin)
+  const b = fs.readFileSync(path.join(__dirname, '..', 'golden', 'ld_values.bin'));
+  const fnames = ['norm', 'unif', 'beta', 'bern', 'pois', 'cauchy', 'laplace', 'gamma', 'invgamma', 'lnorm', 'pareto', 't', 'weibull', 'logis', 'exp', 'binom', 'nbinom', 'hyper', 'lgamma', 'lfactorial', 'lchoose', 'lbeta'];
+  let n = 0;
+  for (let i = 0; i < b.length; i += 48) {
+    const r = [0, 1, 2, 3, 4, 5].map((j) => b.readDoubleLE(i + j * 8));
+    assert.ok(Object.is(ld[fnames[r[0]]](r[1], r[2], r[3], r[4]), r[5]), fnames[r[0]]);
+    n++;
+  }
+  assert.strictEqual(n, 13200);
+  if (haveRef) assert.deepStrictEqual(Object.keys(refld).filter((k) => !(k in ld)), []);
+}
 // the addon loads and, without a GPU, construction fails loudly (no JS fallback)
 const nat = mcmc.native();
 assert.ok(/gfx950/.test(nat.version()));

@@ -1,0 +1,30 @@
+'use strict';
+// translate_cli.js -- test helper: translates one closure of tests/js/user_models.js with the PRODUCT's
+// translator and writes <out>/<name>.hip (source), <name>.arrays.bin (u32 count, then per array u64 len + f64 data)
+// and <name>.meta.json.   node tests/js/translate_cli.js <outdir> [name ...]
+const fs = require('fs');
+const path = require('path');
+const { mcmc, ld } = require('../../bayes.js_amd');
+const um = require('./user_models.js');
+global.ld = ld;
+const out = process.argv[2];
+const want = process.argv.slice(3);
+for (const name of um.names) {
+  if (want.length && want.indexOf(name) < 0) continue;
+  const m = um.build(name);
+  const params = mcmc.complete_params(m.params, mcmc.param_init_fixed);
+  const tr = mcmc.translate(m.log_post, params, m.data, { helpers: m.helpers, constants: m.constants });
+  fs.writeFileSync(path.join(out, name + '.hip'), tr.source);
+  let bytes = 4;
+  for (const a of tr.arrays) bytes += 8 + a.length * 8;
+  const buf = Buffer.alloc(bytes);
+  let o = 0;
+  buf.writeUInt32LE(tr.arrays.length, o); o += 4;
+  for (const a of tr.arrays) {
+    buf.writeBigUInt64LE(BigInt(a.length), o); o += 8;
+    for (let i = 0; i < a.length; i++) { buf.writeDoubleLE(a[i], o); o += 8; }
+  }
+  fs.writeFileSync(path.join(out, name + '.arrays.bin'), buf);
+  fs.writeFileSync(path.join(out, name + '.meta.json'), JSON.stringify({ name, P: tr.P, derived: tr.derived, lds_bytes: tr.lds_bytes,
+    parallel: tr.parallel, max_threads: tr.max_threads, array_keys: tr.array_keys, array_len: tr.arrays.map((a) => a.length) }));
+}

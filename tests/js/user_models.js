@@ -1,0 +1,270 @@
+// (sloppy mode on purpose: the reference's own fixtures assign implicit globals, tests/test_data.js:98-101)
+/*
+ * user_models.js -- TEST FIXTURES: log_post closures written the way a bayes.js user writes them
+ * (against a global `ld`), used three ways:
+ *   oracle/gen_user_golden.js  runs them through the UNMODIFIED reference sampler (seeded) -> tests/golden/user_*.json
+ *   tests/test_translate.py    translates them (bayes.js_amd/translate.js), compiles the result for the host and for
+ *                              gfx950, and compares log_post values with the reference's, bit for bit
+ *   tests/js/test_gpu_user.js  runs them on the GPU through mcmc.AmwgSampler and compares whole trajectories
+ * The first group restates the reference's own fixtures (tests/test_data.js:76-211, README.md); the
+ * second group exercises the rest of distributions.js and of the translator's grammar.
+ */
+const synth = require('../../oracle/synth.js');
+
+// seeded helper (LCG, same in every consumer)
+function lcg(seed) { let s = seed >>> 0; return () => { s = (Math.imul(s, 1103515245) + 12345) >>> 0; return s / 4294967296; }; }
+
+const CASES = {};
+
+// ---- README.md:18-43 verbatim (data is the array itself)
+CASES.readme_normal = {
+  params: () => ({ mu: { type: 'real' }, sigma: { type: 'real', lower: 0 } }),
+  data: () => [183, 192, 182, 183, 177, 185, 188, 188, 182, 185],
+  log_post: function(state, data) {
+    var log_post = 0;
+    // Priors
+    log_post += ld.norm(state.mu, 0, 100);
+    log_post += ld.unif(state.sigma, 0, 100);
+    // Likelihood
+    for(var i = 0; i < data.length; i++) {
+      log_post += ld.norm(data[i], state.mu, state.sigma);
+    }
+    return log_post;
+  },
+  schedule: [{ op: 'burn', n: 300 }, { op: 'sample', n: 300, keep: 60 }], chains: [0, 3],
+};
+
+// ---- tests/test_data.js:76-91: aliases and a derived quantity
+CASES.norm_post_derived = {
+  params: () => ({ mu: { type: 'real' }, sigma: { type: 'real', lower: 0, init: 1 } }),
+  data: () => [100, 62, 96, 122, 141, 144, 74, 73, 78, 128],
+  log_post: function(par, data) {
+    var mu = par.mu;
+    var sigma = par.sigma;
+    var log_post = 0;
+    log_post += ld.norm(mu, 0, 100);
+    log_post += ld.unif(sigma, 0, 100);
+    for(var i = 0; i < data.length; i++) {
+      log_post += ld.norm(data[i], mu, sigma);
+    }
+    par.var = sigma * sigma;
+    return log_post;
+  },
+  schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 240, thin: 3, keep: 80 }], chains: [0, 11],
+};
+
+// ---- tests/test_data.js:138-171: real + int + binary parameters, if/else inside the data loop
+CASES.complex_model = {
+  params: () => ({ p1: { type: 'real', lower: 0, upper: 1 }, n1: { type: 'int', lower: 1, init: 1 }, m: { type: 'binary' } }),
+  data: (seed) => { const r = lcg(seed); const x = []; for (let i = 0; i < 40; i++) x.push(Math.floor(r() * 30) + 5); return x; },
+  log_post: function(par, x) {
+    var p1 = par.p1;
+    var n1 = par.n1;
+    var m = par.m;
+    var log_post = 0;
+    log_post += ld.bern(m, 0.4);
+    log_post += ld.beta(p1, 2, 2);
+    log_post += ld.nbinom(n1, 2, 0.1);
+    for(var i = 0; i < x.length; i++) {
+      if(m === 0) {
+        log_post += ld.nbinom(x[i], 21, 0.5);
+      } else {
+        log_post += ld.nbinom(x[i], n1, p1);
+
+      }
+    }
+    return log_post;
+  },
+  schedule: [{ op: 'burn', n: 250 }, { op: 'sample', n: 250, keep: 80 }], chains: [0, 1, 2],
+};
+
+// ---- tests/test_data.js:174-211: dim [1,6] parameter, sub-array alias, helper function
+CASES.hier_binomial = {
+  params: () => ({ p: { type: 'real', init: 0.5, lower: 0, upper: 1, dim: [1, 6] }, mu_logit_p: { type: 'real', init: 0 },
+    sigma_logit_p: { type: 'real', lower: 0, init: 1 } }),
+  data: () => ({ x: [5, 6, 9, 14, 13, 20], n: [10, 10, 20, 20, 30, 30] }),
+  helpers: { logit: function(p) {
+    return Math.log(p / (1 -p));
+  } },
+  log_post: function(par, d) {
+    var p = par.p[0];
+    var mu_logit_p = par.mu_logit_p;
+    var sigma_logit_p = par.sigma_logit_p;
+    var log_post = 0;
+    log_post += ld.norm(mu_logit_p, 0, 10);
+    log_post += ld.norm(sigma_logit_p, 0, 10);
+    for(var i = 0; i < d.x.length; i++) {
+      log_post += ld.norm(logit(p[i]), mu_logit_p, sigma_logit_p);
+      log_post += ld.binom(d.x[i], d.n[i], p[i]);
+    }
+    return log_post;
+  },
+  schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 50 }], chains: [0, 5],
+};
+
+// ---- tests/test_data.js:119-126: binary dim [2,2], implicit globals, no accumulator
+CASES.multi_bern = {
+  params: () => ({ x: { type: 'binary', dim: [2, 2] } }),
+  data: () => null,
+  log_post: function(par) {
+    x1 = par.x[0][0];
+    x2 = par.x[0][1];
+    x3 = par.x[1][0];
+    x4 = par.x[1][1];
+    return Math.log(x1 * x2 * 0.85 + (1 - x1*x2) * 0.15) +
+      Math.log(x3*x4 * 0.75 + (1 - x3*x4) * 0.25);
+  },
+  schedule: [{ op: 'burn', n: 100 }, { op: 'sample', n: 300, keep: 100 }], chains: [0, 1],
+};
+
+// ---- tests/test_data.js:108-117: int dim [2,2] with Poisson targets
+CASES.multivar_poisson = {
+  params: () => ({ x: { type: 'int', dim: [2, 2], lower: 0 } }),
+  data: () => null,
+  log_post: function(par) {
+    x1 = par.x[0][0];
+    x2 = par.x[0][1];
+    x3 = par.x[1][0];
+    x4 = par.x[1][1];
+    var log_post = ld.pois(x1, 0.1) +
+                ld.pois(x2, 10) +
+                ld.pois(x3, 1000) +
+                ld.pois(x4, 100000);
+    return log_post;
+  },
+  schedule: [{ op: 'burn', n: 300 }, { op: 'sample', n: 200, keep: 60 }], chains: [0, 1],
+};
+
+// ---- the BASELINE cfg4 / cfg5 closures (oracle/ref_models.js): the translated path must reproduce the
+// goldens the hand-written kernels reproduce (tests/golden/hier_small.json, glm_small.json)
+CASES.hier_normal_closure = {
+  params: (d) => ({ theta: { type: 'real', dim: [d.G] }, mu: { type: 'real' }, sigma: { type: 'real', lower: 0, init: 1 } }),
+  data: () => synth.hier(640, 8, 20260925),
+  same_as_golden: 'hier_small',
+  log_post: function (s, d) {
+    let lp = 0;
+    lp += ld.norm(s.mu, 0, 100);
+    lp += ld.unif(s.sigma, 0, 100);
+    for (let k = 0; k < d.G; k++) lp += ld.norm(s.theta[k], s.mu, 10);
+    for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], s.sigma);
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 50 }], chains: [0, 1],
+};
+CASES.pois_glm_closure = {
+  params: (d) => ({ beta: { type: 'real', dim: [8], init: 0 }, cp: { type: 'int', lower: 0, upper: d.y.length - 1 } }),
+  data: () => synth.glm(500, 20260925),
+  same_as_golden: 'glm_small',
+  log_post: function (s, d) {
+    let lp = 0;
+    const N = d.y.length, K = d.K;
+    for (let k = 0; k < 8; k++) lp += ld.norm(s.beta[k], 0, 10);
+    lp += ld.unif(s.cp, 0, N - 1);
+    for (let i = 0; i < N; i++) {
+      let eta = 0;
+      for (let k = 0; k < K; k++) eta += d.X[i * K + k] * s.beta[k];
+      if (i >= s.cp) eta += s.beta[7];
+      lp += ld.pois(d.y[i], Math.exp(eta));
+    }
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+
+// ---- spike and slab regression (README.md:216 mentions the use): binary inclusion vector, 2-D data (array of rows)
+CASES.spike_slab = {
+  params: () => ({ gamma: { type: 'binary', dim: [4] }, beta: { type: 'real', dim: [4], init: 0.1 }, sigma: { type: 'real', lower: 0, init: 1 } }),
+  data: (seed) => {
+    const r = lcg(seed), X = [], y = [], bt = [1.5, 0, -2, 0];
+    for (let i = 0; i < 60; i++) {
+      const row = [1, r() * 2 - 1, r() * 2 - 1, r() * 2 - 1];
+      let m = 0; for (let k = 0; k < 4; k++) m += row[k] * bt[k];
+      X.push(row); y.push(m + (r() + r() + r() - 1.5) * 0.8);
+    }
+    return { X, y };
+  },
+  log_post: function(state, data) {
+    var lp = 0;
+    var K = 4;
+    lp += ld.exp(state.sigma, 1);
+    for (var k = 0; k < K; k++) {
+      lp += ld.bern(state.gamma[k], 0.5);
+      lp += ld.norm(state.beta[k], 0, 5);
+    }
+    for (var i = 0; i < data.y.length; i++) {
+      var m = 0;
+      for (var j = 0; j < K; j++) {
+        m += state.gamma[j] * state.beta[j] * data.X[i][j];
+      }
+      lp += ld.norm(data.y[i], m, state.sigma);
+    }
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 60 }], chains: [0, 1],
+};
+
+// ---- the other continuous densities, Math.pow with general exponents, ?:, compound assignment, while, early return
+CASES.survival_mix = {
+  params: () => ({ shape: { type: 'real', lower: 0, init: 1.2 }, scale: { type: 'real', lower: 0, init: 2 }, nu: { type: 'real', lower: 1, upper: 60, init: 5 },
+    loc: { type: 'real', init: 0.2 }, w: { type: 'real', lower: 0, upper: 1, init: 0.4 } }),
+  data: (seed) => {
+    const r = lcg(seed), t = [], z = [];
+    for (let i = 0; i < 50; i++) { t.push(2.2 * Math.pow(-Math.log(1 - r() * 0.999), 1 / 1.4)); z.push((r() - 0.5) * 6 + (r() < 0.1 ? 8 : 0)); }
+    return { t, z, n: 50, half: 0.5 };
+  },
+  constants: { TWO: 2, scales: [0.5, 1, 2] },
+  log_post: function(s, d) {
+    var lp = 0;
+    if (s.shape > 50) { return -Infinity; }
+    lp += ld.gamma(s.shape, 2, 1);
+    lp += ld.invgamma(s.scale, 3, 4);
+    lp += ld.lnorm(s.nu, 1.5, 0.8);
+    lp += ld.cauchy(s.loc, 0, scales[2]);
+    lp += ld.beta(s.w, TWO, 3);
+    lp += ld.pareto(s.scale + 1, 1, 2.5) * d.half;
+    lp += ld.logis(s.loc, 0, 3) / 4;
+    lp += ld.laplace(s.loc, 0.1, 2) - ld.dexp(0, 0.1, 2);
+    var i = 0;
+    while (i < d.n) {
+      lp += ld.weibull(d.t[i], s.shape, s.scale);
+      i += 1;
+    }
+    for (var j = 0; j < d.z.length; j++) {
+      var a = ld.t(d.z[j], s.loc, 1.5, s.nu);
+      var b = ld.norm(d.z[j], s.loc, 4);
+      var hi = a > b ? a : b;
+      var mix = s.w * Math.exp(a - hi) + (1 - s.w) * Math.exp(b - hi);
+      lp += hi + Math.log(mix);
+      lp += Math.pow(Math.abs(d.z[j]), 1.5) * -1e-3 + Math.sqrt(Math.min(s.shape, 4)) * 1e-3 - Math.max(0, s.loc, -1) * 1e-4;
+    }
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+
+// ---- discrete densities: hypergeometric / binomial / Poisson with int parameters
+CASES.discrete_mix = {
+  params: () => ({ k: { type: 'int', lower: 0, upper: 30, init: 10 }, lam: { type: 'real', lower: 0, init: 3 }, q: { type: 'real', lower: 0, upper: 1 } }),
+  data: (seed) => { const r = lcg(seed), c = [], tr = []; for (let i = 0; i < 25; i++) { c.push(Math.floor(r() * 8)); tr.push(10 + Math.floor(r() * 10)); } return { c, tr }; },
+  log_post: function(s, d) {
+    var lp = ld.hyper(4, s.k, 40 - s.k, 10);
+    lp += ld.gamma(s.lam, 2, 0.5) + ld.unif(s.q, 0, 1);
+    for (var i = 0; i < d.c.length; i++) {
+      lp += ld.pois(d.c[i], s.lam);
+      lp += ld.binom(d.c[i], d.tr[i], s.q);
+    }
+    lp += ld.lchoose(30, s.k) * 0.01 + ld.lfactorial(s.k) * 1e-3 - ld.lgamma(s.lam + 1) * 1e-3 + ld.lbeta(s.q + 1, 2) * 1e-3;
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 60 }], chains: [0, 1],
+};
+
+function build(name, seed) {
+  const c = CASES[name];
+  if (!c) throw new Error('unknown user model ' + name);
+  const data = c.data(seed === undefined ? 20260925 : seed);
+  return { name, params: c.params(data), log_post: c.log_post, data, helpers: c.helpers, constants: c.constants,
+           schedule: c.schedule, chains: c.chains, same_as_golden: c.same_as_golden };
+}
+
+module.exports = { CASES, build, names: Object.keys(CASES), lcg };

@@ -1,0 +1,85 @@
+"""-m gpu: translated closures through the C ABI (amwg_create_user).
+
+* one lane per chain: whole trajectories vs the reference goldens are checked from the JS side (tests/js/test_gpu_user.js);
+  here the cached log_post of many chains is compared with the HOST build of the same generated text;
+* G lanes per chain: the device's lane-split sum equals the host emulation of the same order bit for bit, at the
+  state every sampled chain ended in, and the chains still sample the right posterior.
+"""
+import shutil
+
+import numpy as np
+import pytest
+
+import amwg_ctypes as A
+import golden_io
+import user_host
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")]
+
+INF = float("inf")
+
+
+def spec_for(name):
+    """Sampler spec from the golden's completed params (what the reference built) + the translated model."""
+    gold = golden_io.load("user_" + name)
+    rec = gold["chains"][0]
+    m = user_host.host_model(name)
+    params, init, opts = [], [], []
+    for p, in zip(rec["params_completed"]):
+        ln = int(np.prod(p["dim"]))
+        params.append({"type": p["type"], "len": ln, "top": p["dim"][0], "multidim": 0 if p["dim"] == [1] else 1,
+                       "lower": p["lower"], "upper": p["upper"]})
+        init += p["init"]
+    for o in rec["comp_opts"]:
+        opts.append({"prop_log_scale": o.get("prop_log_scale", 0.0), "max_adaptation": o.get("max_adaptation", 0.33),
+                     "initial_adaptation": o.get("initial_adaptation", 1.0), "target_accept_rate": o.get("target_accept_rate", 0.44),
+                     "batch_size": o.get("batch_size", 50), "is_adapting": o.get("is_adapting", True)})
+    user = {"source": m.source, "arrays": m.arrays, "n_derived": len(m.meta["derived"]), "lds_bytes": m.meta["lds_bytes"],
+            "parallel": m.meta["parallel"], "max_threads": m.meta["max_threads"]}
+    return {"user": user, "params": params, "P": len(init), "init": init, "comp_opts": opts}, m, gold
+
+
+@pytest.mark.parametrize("name,lanes", [("readme_normal", 1), ("readme_normal", 4), ("norm_post_derived", 8), ("complex_model", 2),
+                                        ("hier_binomial", 2), ("hier_normal_closure", 16), ("pois_glm_closure", 4), ("pois_glm_closure", 64),
+                                        ("spike_slab", 4), ("survival_mix", 2), ("discrete_mix", 1), ("multi_bern", 1), ("multivar_poisson", 1)])
+def test_device_lane_sum_equals_host_emulation(name, lanes):
+    spec, m, gold = spec_for(name)
+    s = A.Sampler(spec, chains=96, seed=gold["case"]["seed"], lanes_per_chain=lanes)
+    assert s.launch_info()["lanes_per_chain"] == lanes
+    s.burn(120)
+    draws = s.sample(30, 3)
+    st, lp = s.state(), s.diag()["log_post"]
+    for c in range(0, 96, 5):
+        want = m.eval(st[:, c], lanes)
+        assert np.float64(lp[c]).tobytes() == np.float64(want).tobytes(), (name, lanes, c, lp[c], want)
+    if m.meta["derived"]:
+        for t in (0, 9):
+            for c in (0, 50, 95):
+                _, dv = m.eval(draws[t, : s.P, c], 1, derived=True)
+                assert draws[t, s.P:, c].tolist() == dv
+    assert np.all(np.isfinite(lp))
+    if lanes == 1:      # decisions of chain 0 are the reference's
+        rec = gold["chains"][0]
+        if rec["chain"] == 0:
+            s2 = A.Sampler(spec, chains=2, seed=gold["case"]["seed"], lanes_per_chain=1)
+            n = sum(seg["n"] for seg in gold["case"]["schedule"])
+            s2.burn(n)
+            assert s2.info()["accepts"][:, 0].tolist() == rec["accepts"]
+            assert s2.state()[:, 0].tolist() == rec["final_state"]
+            s2.close()
+    s.close()
+
+
+def test_translated_normal_samples_the_analytic_posterior():
+    """Normal model with flat-ish priors: posterior mean of mu ~ data mean, E[sigma^2] ~ s^2 (n-1)/(n-3)."""
+    spec, m, gold = spec_for("norm_post_derived")
+    x = np.array(m.arrays[0])
+    s = A.Sampler(spec, chains=4096, seed=99, lanes_per_chain=2)
+    s.burn(1500)
+    d = s.sample(400, 4)
+    mu, var = d[:, 0, :].ravel(), d[:, 2, :].ravel()
+    n = x.size
+    # mu ~ norm(0,100) pulls the mean by ~1 %, unif(0,100) truncates the sd's tail: generous but non-trivial bounds
+    assert abs(mu.mean() - x.mean()) < 0.08 * x.std()
+    assert abs(var.mean() / (x.var(ddof=1) * (n - 1) / (n - 4)) - 1) < 0.12   # E[sigma^2 | x] under p(sigma) uniform
+    s.close()

@@ -30,3 +30,10 @@ def test_js_frontend_host_logic():
 @pytest.mark.gpu
 def test_js_frontend_on_gpu_matches_reference_goldens():
     assert "gpu frontend ok" in run_node("test_gpu.js", 600)
+
+
+@needs_node
+@pytest.mark.gpu
+def test_translated_closures_on_gpu_match_reference_goldens():
+    """Arbitrary user closures (real/int/binary params, every scalar ld.*, derived quantities) through translate.js + hiprtc."""
+    assert "gpu user models ok" in run_node("test_gpu_user.js", 1200)

@@ -1,0 +1,72 @@
+"""TEST INFRASTRUCTURE: translate the closures of tests/js/user_models.js with the product's translator (node), build
+the generated HIP text for the HOST (tests/host/user_eval_host.cpp, g++ -ffp-contract=off) and evaluate it."""
+import ctypes as C
+import json
+import os
+import shutil
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODE = shutil.which("node")
+_dir = None
+_cache = {}
+
+
+def workdir():
+    global _dir
+    if _dir is None:
+        _dir = tempfile.mkdtemp(prefix="amwg_user_")
+        p = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "translate_cli.js"), _dir], cwd=ROOT, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stdout + "\n" + p.stderr
+    return _dir
+
+
+def read_arrays(path):
+    buf = open(path, "rb").read()
+    n, = struct.unpack_from("<I", buf, 0)
+    o, out = 4, []
+    for _ in range(n):
+        ln, = struct.unpack_from("<Q", buf, o)
+        o += 8
+        out.append(np.frombuffer(buf, dtype="<f8", count=ln, offset=o).copy())
+        o += ln * 8
+    return out
+
+
+class HostModel:
+    """The generated amwg::UserModel compiled for the host."""
+
+    def __init__(self, name):
+        d = workdir()
+        self.name = name
+        self.source = open(os.path.join(d, name + ".hip")).read()
+        self.meta = json.load(open(os.path.join(d, name + ".meta.json")))
+        self.arrays = read_arrays(os.path.join(d, name + ".arrays.bin"))
+        so = os.path.join(d, name + ".so")
+        cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+               "-I", os.path.join(ROOT, "bayes.js_amd", "csrc"), '-DAMWG_USER_SOURCE="%s"' % os.path.join(d, name + ".hip"),
+               "-o", so, os.path.join(ROOT, "tests", "host", "user_eval_host.cpp")]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-4000:]
+        self.lib = C.CDLL(so)
+        self.lib.user_eval.restype = C.c_double
+        self.lib.user_eval.argtypes = [C.POINTER(C.c_double), C.POINTER(C.POINTER(C.c_double)), C.c_int, C.c_int, C.POINTER(C.c_double)]
+        self.ptrs = (C.POINTER(C.c_double) * max(1, len(self.arrays)))(*[a.ctypes.data_as(C.POINTER(C.c_double)) for a in self.arrays])
+        self.D = self.lib.user_num_derived()
+
+    def eval(self, state, lanes=1, derived=False):
+        st = np.ascontiguousarray(state, dtype=np.float64)
+        dv = np.zeros(max(1, self.D))
+        v = self.lib.user_eval(st.ctypes.data_as(C.POINTER(C.c_double)), self.ptrs, len(self.arrays), lanes,
+                               dv.ctypes.data_as(C.POINTER(C.c_double)) if derived else None)
+        return (v, dv[: self.D].tolist()) if derived else v
+
+
+def host_model(name):
+    if name not in _cache:
+        _cache[name] = HostModel(name)
+    return _cache[name]
