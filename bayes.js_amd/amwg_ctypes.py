@@ -41,11 +41,11 @@ class Options(C.Structure):
 
 class UserModel(C.Structure):
     _fields_ = [("source", C.c_char_p), ("n_arrays", C.c_int32), ("arrays", C.POINTER(C.POINTER(C.c_double))),
-                ("array_len", C.POINTER(C.c_int64)), ("n_derived", C.c_int32), ("lds_bytes", C.c_int32),
+                ("array_len", C.POINTER(C.c_int64)), ("array_type", C.POINTER(C.c_int32)), ("n_derived", C.c_int32), ("lds_bytes", C.c_int32),
                 ("parallel", C.c_int32), ("max_threads", C.c_int32)]
 
 
-EXPORTS = ["amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
+EXPORTS = ["amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
            "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components",
            "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp",
            "amwg_log", "amwg_uniform", "amwg_device_eval"]
@@ -94,6 +94,8 @@ def lib():
         L.amwg_create_user.argtypes = [C.POINTER(UserModel), C.POINTER(ParamDesc), i32, pd, C.POINTER(CompOpt),
                                        C.POINTER(Options), C.POINTER(vp)]
         L.amwg_num_recorded.argtypes = [vp]
+        L.amwg_set_state.argtypes = [vp, pd, C.c_size_t]
+        L.amwg_last_sample_diagnostics.argtypes = [vp, pd, pd]
         L.amwg_pow.restype = dbl
         L.amwg_pow.argtypes = [dbl, dbl]
         L.amwg_ld_host.restype = dbl
@@ -156,8 +158,9 @@ class Sampler:
             um.n_arrays = len(arrs)
             ptrs = (C.POINTER(C.c_double) * max(1, len(arrs)))(*[_dp(a) for a in arrs])
             lens = (C.c_int64 * max(1, len(arrs)))(*[a.size for a in arrs])
-            keep += [ptrs, lens]
-            um.arrays, um.array_len = ptrs, lens
+            types = (C.c_int32 * max(1, len(arrs)))(*[int(t) for t in user.get("array_types", [0] * len(arrs))])
+            keep += [ptrs, lens, types]
+            um.arrays, um.array_len, um.array_type = ptrs, lens, types
             um.n_derived, um.lds_bytes = int(user.get("n_derived", 0)), int(user.get("lds_bytes", 0))
             um.parallel, um.max_threads = int(user.get("parallel", 0)), int(user.get("max_threads", 0))
         n = len(spec["params"])
@@ -258,6 +261,16 @@ class Sampler:
         m, s = np.empty(self.PR), np.empty(self.PR)
         _check(lib().amwg_last_sample_moments(self.h, _dp(m), _dp(s)))
         return m, s
+
+    def set_state(self, state):
+        st = np.ascontiguousarray(state, dtype=np.float64)
+        assert st.shape == (self.P, self.C)
+        _check(lib().amwg_set_state(self.h, _dp(st), st.nbytes))
+
+    def convergence(self):
+        r, e = np.empty(self.PR), np.empty(self.PR)
+        _check(lib().amwg_last_sample_diagnostics(self.h, _dp(r), _dp(e)))
+        return r, e
 
     def launch_info(self):
         v = [C.c_int32() for _ in range(5)]

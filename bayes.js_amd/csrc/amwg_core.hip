@@ -262,6 +262,27 @@ __global__ void moments_kernel(const double *draws, int64_t rows, int P, int64_t
   if (tid == 0) { mean[p] = m; sd[p] = n > 1 ? sqrt(red[0] / (double)(n - 1)) : 0.0; }
 }
 
+// per chain and recorded value: mean and (n-1) variance of each half of the chain's kept draws
+// out[((h*2 + stat) * PR + p) * C + c], stat 0 = mean, 1 = variance; draws [row][PR][C] (coalesced over chains)
+__global__ void chain_halves_kernel(const double *draws, int64_t rows, int PR, int64_t C, double *out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (c >= C) return;
+  const int64_t half = rows / 2;
+  for (int h = 0; h < 2; ++h) {
+    const int64_t r0 = h * half, r1 = r0 + half;
+    double m = 0, m2 = 0;   // Welford
+    for (int64_t r = r0; r < r1; ++r) {
+      const double x = draws[(r * PR + p) * C + c];
+      const double dlt = x - m;
+      m += dlt / (double)(r - r0 + 1);
+      m2 += dlt * (x - m);
+    }
+    out[((size_t)(h * 2 + 0) * PR + p) * C + c] = m;
+    out[((size_t)(h * 2 + 1) * PR + p) * C + c] = half > 1 ? m2 / (double)(half - 1) : 0.0;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -619,10 +640,37 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
   for (int j = 0; j < m->n_arrays; ++j) {
     const int64_t n = m->array_len[j];
     if (n < 0 || (n && !m->arrays[j])) return bail(fail(AMWG_EINVAL, "amwg_create_user: array %d is null or has a negative length", j));
-    double *p = nullptr;
-    TRYB(dev_alloc(s, &p, (size_t)n));
-    if (n) HIPB(hipMemcpy(p, m->arrays[j], (size_t)n * 8, hipMemcpyHostToDevice));
-    d.arr[j] = p;
+    const int ty = m->array_type ? m->array_type[j] : AMWG_F64;
+    if (ty == AMWG_F64) {
+      double *p = nullptr;
+      TRYB(dev_alloc(s, &p, (size_t)n));
+      if (n) HIPB(hipMemcpy(p, m->arrays[j], (size_t)n * 8, hipMemcpyHostToDevice));
+      d.arr[j] = p;
+    } else if (ty == AMWG_U8) {
+      std::vector<uint8_t> tmp((size_t)n);
+      for (int64_t i = 0; i < n; ++i) {
+        const double v = m->arrays[j][i];
+        if (!(v >= 0 && v <= 255 && v == (double)(uint8_t)v)) return bail(fail(AMWG_EINVAL, "amwg_create_user: array %d element %lld (%g) does not fit u8", j, (long long)i, v));
+        tmp[(size_t)i] = (uint8_t)v;
+      }
+      uint8_t *p = nullptr;
+      TRYB(dev_alloc(s, &p, (size_t)n + 16));
+      if (n) HIPB(hipMemcpy(p, tmp.data(), (size_t)n, hipMemcpyHostToDevice));
+      d.arr[j] = p;
+    } else if (ty == AMWG_I32) {
+      std::vector<int32_t> tmp((size_t)n);
+      for (int64_t i = 0; i < n; ++i) {
+        const double v = m->arrays[j][i];
+        if (!(v >= -2147483648.0 && v <= 2147483647.0 && v == (double)(int32_t)v)) return bail(fail(AMWG_EINVAL, "amwg_create_user: array %d element %lld (%g) does not fit i32", j, (long long)i, v));
+        tmp[(size_t)i] = (int32_t)v;
+      }
+      int32_t *p = nullptr;
+      TRYB(dev_alloc(s, &p, (size_t)n + 4));
+      if (n) HIPB(hipMemcpy(p, tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+      d.arr[j] = p;
+    } else {
+      return bail(fail(AMWG_EINVAL, "amwg_create_user: array %d has unknown storage type %d", j, ty));
+    }
   }
   TRYB(alloc_chain_state(s, params, n_params, init, comp_opts));
 
@@ -757,6 +805,56 @@ int amwg_get_state(amwg_sampler *s, double *out, size_t out_bytes) {
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipMemcpyAsync(out, s->ch.state, need, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return AMWG_OK;
+}
+
+int amwg_set_state(amwg_sampler *s, const double *state, size_t state_bytes) {
+  if (!s || !state) return fail(AMWG_EINVAL, "amwg_set_state: null argument");
+  const size_t need = (size_t)s->P * (size_t)s->C * 8;
+  if (state_bytes != need) return fail(AMWG_ESIZE, "amwg_set_state: expected %zu bytes, got %zu", need, state_bytes);
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(s->ch.state, state, need, hipMemcpyHostToDevice));
+  s->lp_ready = false;   // the next launch recomputes log_post(state) first
+  return AMWG_OK;
+}
+
+int amwg_last_sample_diagnostics(amwg_sampler *s, double *rhat, double *ess) {
+  if (!s || !rhat || !ess) return fail(AMWG_EINVAL, "amwg_last_sample_diagnostics: null argument");
+  if (!s->last_draws || s->last_rows < 4 || s->C < 2) return fail(AMWG_EINVAL, "amwg_last_sample_diagnostics: needs a sample() of >= 4 kept draws on >= 2 chains");
+  HIP_TRY(hipSetDevice(s->device));
+  const int PR = s->P + s->D;
+  const size_t C = (size_t)s->C, n_out = 4 * (size_t)PR * C;
+  double *dout = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dout), n_out * 8));
+  hipLaunchKernelGGL(chain_halves_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)PR), dim3(256), 0, s->stream, s->last_draws, s->last_rows, PR, s->C, dout);
+  std::vector<double> h(n_out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), dout, n_out * 8, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  (void)hipFree(dout);
+  if (e != hipSuccess) return fail(AMWG_EHIP, "diagnostics kernel failed: %s", hipGetErrorString(e));
+  const double n = (double)(s->last_rows / 2), m = 2.0 * (double)C;   // 2C half-chains of n draws
+  for (int p = 0; p < PR; ++p) {
+    // W = mean within-sequence variance; B/n = variance of the sequence means (over the 2C halves)
+    long double sw = 0, sm = 0;
+    for (int hf = 0; hf < 2; ++hf)
+      for (size_t c = 0; c < C; ++c) { sm += h[((size_t)(hf * 2 + 0) * PR + p) * C + c]; sw += h[((size_t)(hf * 2 + 1) * PR + p) * C + c]; }
+    const double W = (double)(sw / m), gm = (double)(sm / m);
+    long double sb = 0, sbc = 0;
+    for (int hf = 0; hf < 2; ++hf)
+      for (size_t c = 0; c < C; ++c) { const double dlt = h[((size_t)(hf * 2 + 0) * PR + p) * C + c] - gm; sb += (long double)dlt * dlt; }
+    const double B_over_n = (double)(sb / (m - 1));
+    const double var_plus = (n - 1) / n * W + B_over_n;
+    rhat[p] = W > 0 ? std::sqrt(var_plus / W) : (double)NAN;
+    // whole-chain means: average of the two half means (equal lengths)
+    long double smc = 0;
+    for (size_t c = 0; c < C; ++c) smc += 0.5 * (h[((size_t)0 * PR + p) * C + c] + h[((size_t)2 * PR + p) * C + c]);
+    const double gmc = (double)(smc / (double)C);
+    for (size_t c = 0; c < C; ++c) { const double dlt = 0.5 * (h[((size_t)0 * PR + p) * C + c] + h[((size_t)2 * PR + p) * C + c]) - gmc; sbc += (long double)dlt * dlt; }
+    const double var_chain_mean = (double)(sbc / ((double)C - 1));
+    ess[p] = var_chain_mean > 0 ? (double)C * var_plus / var_chain_mean : (double)NAN;
+  }
   return AMWG_OK;
 }
 

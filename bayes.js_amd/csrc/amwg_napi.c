@@ -233,6 +233,8 @@ static napi_value CreateUser(napi_env env, napi_callback_info info) {
   napi_get_value_string_utf8(env, v, src, slen + 1, &slen);
   const double *arrs[AMWG_MAX_USER_ARRAYS];
   int64_t lens[AMWG_MAX_USER_ARRAYS];
+  int32_t types[AMWG_MAX_USER_ARRAYS];
+  memset(types, 0, sizeof types);
   uint32_t n_arr = 0;
   if (prop(env, a[0], "arrays", &v)) napi_get_array_length(env, v, &n_arr);
   if (n_arr > AMWG_MAX_USER_ARRAYS) { free(src); napi_throw_range_error(env, NULL, "amwg_napi.createUser: too many data arrays"); return NULL; }
@@ -250,6 +252,13 @@ static napi_value CreateUser(napi_env env, napi_callback_info info) {
   um.n_arrays = (int32_t)n_arr;
   um.arrays = arrs;
   um.array_len = lens;
+  um.array_type = types;
+  {
+    napi_value tv;
+    uint32_t nt = 0;
+    if (prop(env, a[0], "array_types", &tv) && napi_get_array_length(env, tv, &nt) == napi_ok)
+      for (uint32_t i = 0; i < nt && i < n_arr; i++) { napi_value e; napi_get_element(env, tv, i, &e); types[i] = (int32_t)arg_i64(env, e); }
+  }
   um.n_derived = (int32_t)prop_i64(env, a[0], "n_derived", 0);
   um.lds_bytes = (int32_t)prop_i64(env, a[0], "lds_bytes", 0);
   um.parallel = (int32_t)prop_i64(env, a[0], "parallel", 0);
@@ -463,6 +472,38 @@ static napi_value Moments(napi_env env, napi_callback_info info) {
   return o;
 }
 
+/* setState(handle, Float64Array [P][chains]) */
+static napi_value SetState(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  size_t n = 0;
+  const double *st = (const double *)typed_data(env, a[1], napi_float64_array, &n);
+  if (!st) { napi_throw_type_error(env, NULL, "amwg_napi.setState: state must be a Float64Array"); return NULL; }
+  int rc = amwg_set_state(s, st, n * 8);
+  return rc == AMWG_OK ? NULL : throw_amwg(env, rc);
+}
+
+/* convergence(handle) -> {rhat: Float64Array, ess: Float64Array} over the last sample() */
+static napi_value Convergence(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  const size_t P = (size_t)amwg_num_recorded(s);
+  double *r, *e;
+  napi_value vr = new_f64(env, P, &r), ve = new_f64(env, P, &e);
+  if (!vr || !ve) return NULL;
+  int rc = amwg_last_sample_diagnostics(s, r, e);
+  if (rc != AMWG_OK) return throw_amwg(env, rc);
+  napi_value o;
+  NAPI_OK(napi_create_object(env, &o));
+  napi_set_named_property(env, o, "rhat", vr);
+  napi_set_named_property(env, o, "ess", ve);
+  return o;
+}
+
 static napi_value LaunchInfo(napi_env env, napi_callback_info info) {
   napi_value a[1];
   if (!get_args(env, info, 1, a)) return NULL;
@@ -521,7 +562,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   static const struct { const char *name; napi_callback fn; } fns[] = {
       {"create", Create}, {"createUser", CreateUser}, {"compileUser", CompileUser}, {"destroy", Destroy}, {"burn", Burn}, {"burnAsync", BurnAsync}, {"sync", Sync},
       {"sample", Sample}, {"sampleAsync", SampleAsync}, {"fetchDraws", FetchDraws}, {"setAdapting", SetAdapting},
-      {"getState", GetState}, {"info", Info}, {"diag", Diag}, {"moments", Moments}, {"launchInfo", LaunchInfo},
+      {"getState", GetState}, {"setState", SetState}, {"convergence", Convergence}, {"info", Info}, {"diag", Diag}, {"moments", Moments}, {"launchInfo", LaunchInfo},
       {"version", Version}, {"mathExp", MathExp}, {"mathLog", MathLog}, {"uniform", Uniform}};
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

@@ -64,7 +64,8 @@ struct DataRef {
   const double *lfact;  // GLM lfactorial(y_i) (+inf encodes y_i < 0, i.e. term = -inf)
   const uint8_t *xb;    // BETA_BERN x as bytes (invalid values stored as 0, see has_invalid) | HIER group index
   const uint32_t *xw;   // BETA_BERN x as bits: observation i = bit (i & 31) of word (i >> 5)
-  const double *arr[kMaxUserArrays];   // translated models: the data arrays the closure reads (row-major, f64)
+  const void *arr[kMaxUserArrays];     // translated models: the data arrays the closure reads (row-major; f64, or u8 / i32
+                                       // when every value of the array is a small integer -- the translator picks the type)
 };
 
 // Per-chain state, structure-of-arrays with the chain index fastest: element (p, c) at p*C + c.

@@ -32,11 +32,41 @@ AMWG_HD double ld_norm_inv(double x, double mean, const NormInv &k) {
   return k.c - q;
 }
 
+// Straight-line variants for a lane-split loop: the fast form always takes the 4-operation quotient
+// and only RECORDS the exponent range of the numerators it saw (two 32-bit min/max per term, no
+// branch); after the loop the generated code checks the range and the divisor and, if a precondition
+// of amwg_div.h failed anywhere, restores the accumulator and runs the loop again in the slow form
+// (IEEE division).  Both forms return the correctly rounded quotient, so the sum is the same bits.
+AMWG_HD double ld_norm_fast(double x, double mean, const NormInv &k, uint32_t &rlo, uint32_t &rhi) {
+  const double t = x - mean;
+  const double tt = t * t;                 // >= +0: the sign bit is clear, hi_word orders like the magnitude
+  const uint32_t h = (uint32_t)hi_word(tt);
+  rlo = h < rlo ? h : rlo;
+  rhi = h > rhi ? h : rhi;
+  return k.c - div_by_invariant(tt, k.den, k.y);
+}
+AMWG_HD double ld_norm_slow(double x, double mean, const NormInv &k) {
+  const double t = x - mean;
+  return k.c - (t * t) / k.den;
+}
+AMWG_HD bool norm_range_ok(uint32_t rlo, uint32_t rhi) { return rlo >= 0x1A700000u && rhi <= 0x65700000u; }   // 2^-600 .. 2^600, zero excluded
+
 // ld.bern(x, p) for a loop in which p does not change (distributions.js:228-230): the two values
 // log(1*p + 0*(1-p)) and log(0*p + 1*(1-p)) the expression can take, selected per observation.
 struct BernInv { double l1, l0; };
 AMWG_HD BernInv bern_inv(double p) { return BernInv{ld_bern(1.0, p), ld_bern(0.0, p)}; }
 AMWG_HD double ld_bern_inv(double x, const BernInv &k) { return x == 1 ? k.l1 : (x == 0 ? k.l0 : -kInf); }
+// same, for a data array the translator has checked to hold only 0s and 1s
+template <class T> AMWG_HD double ld_bern_inv01(T x, const BernInv &k) { return x != 0 ? k.l1 : k.l0; }
+
+// ld.pois / ld.binom whose data-only part (lfactorial(x) resp. lchoose(size, x), distributions.js:79-86)
+// was evaluated once per observation on the host by the same formula
+AMWG_HD double ld_pois_pre(double x, double lambda, double lfact_x) { return x < 0 ? -kInf : log_v8(lambda) * x - lambda - lfact_x; }
+AMWG_HD double ld_binom_pre(double x, double size, double prob, double lchoose_size_x) {
+  if (x > size || x < 0) return -kInf;
+  if (prob == 0 || prob == 1) return (size * prob) == x ? 0.0 : -kInf;
+  return lchoose_size_x + x * log_v8(prob) + (size - x) * log_v8(1 - prob);
+}
 
 // JavaScript operators that differ from C++
 AMWG_HD double js_mod(double a, double b) {   // % on numbers: sign of the dividend (fmod); exact

@@ -220,7 +220,7 @@ function AmwgSampler(params, log_post, data, options) {
       lds_budget: options.lds_budget, max_threads: options.max_threads, unroll: options.unroll });
     this.derived = tr.derived;
     this.translation = tr;
-    user = { source: tr.source, arrays: tr.arrays, n_derived: tr.derived.length, lds_bytes: tr.lds_bytes, parallel: tr.parallel,
+    user = { source: tr.source, arrays: tr.arrays, array_types: tr.array_types, n_derived: tr.derived.length, lds_bytes: tr.lds_bytes, parallel: tr.parallel,
              max_threads: tr.max_threads };
   }
   this.PR = this.P + this.derived.length;   // values per recorded draw
@@ -338,6 +338,37 @@ AmwgSampler.prototype.moments = function () {
   for (const L of this._layout) out[L.name] = { mean: Array.from(m.mean.subarray(L.base, L.base + L.len)), sd: Array.from(m.sd.subarray(L.base, L.base + L.len)) };
   this.derived.forEach((name, q) => { out[name] = { mean: [m.mean[this.P + q]], sd: [m.sd[this.P + q]] }; });
   return out;
+};
+
+/** Split-R-hat and effective sample size per scalar component (and derived quantity) over the last sample(): device-side
+ *  per-chain reduction, chains >= 2, single shard. */
+AmwgSampler.prototype.convergence = function () {
+  const N = native();
+  if (this._shards.length !== 1) throw 'convergence(): only available on a single-device sampler';
+  const d = N.convergence(this._shards[0].handle), out = {};
+  for (const L of this._layout) out[L.name] = { rhat: Array.from(d.rhat.subarray(L.base, L.base + L.len)), ess: Array.from(d.ess.subarray(L.base, L.base + L.len)) };
+  this.derived.forEach((name, q) => { out[name] = { rhat: [d.rhat[this.P + q]], ess: [d.ess[this.P + q]] }; });
+  return out;
+};
+
+/** Per-chain starting points: f(chainIndex) -> state object shaped like sampler.state of one chain ({name: number | nested array}).
+ *  The reference starts from the completed `init` (mcmc.js:954-957); many chains want over-dispersed starts. */
+AmwgSampler.prototype.init_chains = function (f) {
+  const N = native(), C = this.chains;
+  const all = new Float64Array(this.P * C);
+  for (let c = 0; c < C; c++) {
+    const st = f(c);
+    for (const L of this._layout) {
+      const vals = flatten(st[L.name], []);
+      if (vals.length !== L.len) throw 'init_chains: ' + L.name + ' of chain ' + c + ' does not match dim [' + L.dim + ']';
+      for (let e = 0; e < L.len; e++) all[(L.base + e) * C + c] = vals[e];
+    }
+  }
+  this._shards.forEach((sh) => {
+    const part = new Float64Array(this.P * sh.count);
+    for (let p = 0; p < this.P; p++) part.set(all.subarray(p * C + sh.offset, p * C + sh.offset + sh.count), p * sh.count);
+    N.setState(sh.handle, part);
+  });
 };
 
 AmwgSampler.prototype.diagnostics = function () { const N = native(); return this._each((sh) => N.diag(sh.handle, this.param_names.length)); };

@@ -322,6 +322,18 @@ const MATH_FUNS = {
 const HEAVY = new Set(['log_v8', 'exp_v8', 'pow_v8', 'ld_norm', 'ld_beta', 'ld_pois', 'ld_bern', 'ld_gamma', 'ld_invgamma', 'ld_lnorm', 'ld_t',
   'ld_weibull', 'ld_logis', 'ld_binom', 'ld_nbinom', 'ld_hyper', 'ld_cauchy', 'ld_pareto', 'ld_exp', 'ld_laplace', 'ld_unif', 'lgamma_js', 'lfactorial_js', 'lchoose_js', 'lbeta_js']);
 
+const ld_host = require('./ld.js');
+
+// ld.norm calls with a hoisted sd are emitted as NORMCALL(x, m, k RANGEARGS); the finished loop decides the form:
+//   'inv'   per-term range check (loops that are not lane-split)
+//   'fast'  4-operation quotient + range recording      'slow'  IEEE division
+function renderNorm(lines, mode) {
+  const call = { inv: 'ld_norm_inv', fast: 'ld_norm_fast', slow: 'ld_norm_slow' }[mode];
+  return lines.map((ln) => ln.split('NORMCALL').join(call).split(' RANGEARGS').join(mode === 'fast' ? ', rlo_, rhi_' : '')
+    .replace(/ KFASTCHECK\((\w+)\)/g, mode === 'fast' ? ' if (!$1.fast) rlo_ = 0u;' : ''));
+}
+const hasNormCall = (lines) => lines.some((ln) => ln.indexOf('NORMCALL') >= 0);
+
 // ------------------------------------------------------------------------------------------
 function Translator(fn, params, data, opts, isHelper) {
   this.opts = opts || {};
@@ -378,7 +390,17 @@ Translator.prototype.registerArray = function (key, value) {
   const flat = Float64Array.from(flattenData(value, []));
   if (this.arrays.length >= 16) this.fail('more than 16 data arrays');
   const id = this.arrays.length;
-  this.arrays.push({ key, flat, dims });
+  // device storage: small non-negative integers as u8, other 32-bit integers as i32 (exact), everything else f64
+  let u8 = flat.length > 0, i32 = flat.length > 0, is01 = flat.length > 0;
+  for (let i = 0; i < flat.length; i++) {
+    const v = flat[i];
+    if (!(Number.isInteger(v) && !(v === 0 && 1 / v < 0))) { u8 = i32 = is01 = false; break; }
+    if (v < 0 || v > 255) u8 = false;
+    if (v < -2147483648 || v > 2147483647) i32 = false;
+    if (v !== 0 && v !== 1) is01 = false;
+  }
+  const type = this.opts.f64_arrays ? 0 : (u8 ? 1 : (i32 ? 2 : 0));
+  this.arrays.push({ key, flat, dims, type, is01: is01 && type === 1, ctype: ['double', 'uint8_t', 'int32_t'][type], esize: [8, 1, 4][type] });
   this.arrayIds.set(key, id);
   return id;
 };
@@ -484,7 +506,10 @@ Translator.prototype.index = function (objV, idxV) {
   if (objV.t === 'dataArr') {
     // a constant element of a data array is a constant
     if (/^\d+$/.test(sum)) return cnum(this.arrays[objV.id].flat[Number(sum)]);
-    return num('A' + objV.id + '[' + sum + ']', false);
+    const A = this.arrays[objV.id];
+    const v = A.type === 0 ? num('A' + objV.id + '[' + sum + ']', false) : num('(int)A' + objV.id + '[' + sum + ']', true);
+    v.src = { id: objV.id, off: sum };
+    return v;
   }
   return num('S(' + sum + ')', false);
 };
@@ -609,8 +634,29 @@ Translator.prototype.call = function (e) {
     if (args.length !== L[1]) this.fail('ld.' + f.name + ' takes ' + L[1] + ' arguments, got ' + args.length);
     nums();
     const a = args.map((x) => this.asD(x));
-    if (f.name === 'norm') { const k = this.hoist(e.args[2], 'NormInv', 'norm_inv', a[2]); if (k) return num('ld_norm_inv(' + a[0] + ', ' + a[1] + ', ' + k + ')', false); }
-    if (f.name === 'bern') { const k = this.hoist(e.args[1], 'BernInv', 'bern_inv', a[1]); if (k) return num('ld_bern_inv(' + a[0] + ', ' + k + ')', false); }
+    if (f.name === 'norm') {
+      // NORMCALL / RANGEARGS / KFASTCHECK are resolved when the enclosing loop is finished (renderNorm)
+      const k = this.hoist(e.args[2], 'NormInv', 'norm_inv', a[2], ' KFASTCHECK(@)');
+      if (k) return num('NORMCALL(' + a[0] + ', ' + a[1] + ', ' + k + ' RANGEARGS)', false);
+    }
+    if (f.name === 'bern') {
+      const k = this.hoist(e.args[1], 'BernInv', 'bern_inv', a[1], '');
+      if (k) {
+        if (args[0].src && this.arrays[args[0].src.id].is01) return num('ld_bern_inv01(A' + args[0].src.id + '[' + args[0].src.off + '], ' + k + ')', false);
+        return num('ld_bern_inv(' + a[0] + ', ' + k + ')', false);
+      }
+    }
+    if (f.name === 'pois' && args[0].src && this.loops.length) {      // lfactorial(x_i) depends on the data only: once, on the host
+      const aux = this.auxArray('lfactorial', [args[0].src.id], (x) => ld_host.lfactorial(x));
+      this.heavyLoop = true;
+      return num('ld_pois_pre(' + a[0] + ', ' + a[1] + ', A' + aux + '[' + args[0].src.off + '])', false);
+    }
+    if (f.name === 'binom' && args[0].src && args[1].src && args[0].src.off === args[1].src.off && this.loops.length &&
+        this.arrays[args[0].src.id].flat.length === this.arrays[args[1].src.id].flat.length) {
+      const aux = this.auxArray('lchoose', [args[1].src.id, args[0].src.id], (size, x) => ld_host.lchoose(size, x));
+      this.heavyLoop = true;
+      return num('ld_binom_pre(' + a[0] + ', ' + a[1] + ', ' + a[2] + ', A' + aux + '[' + args[0].src.off + '])', false);
+    }
     if (this.loops.length) this.heavyLoop = true;
     return num(L[0] + '(' + a.join(', ') + ')', false);
   }
@@ -624,6 +670,15 @@ Translator.prototype.call = function (e) {
   this.fail('unsupported call');
 };
 
+// data-only part of a density, evaluated per observation on the host with the reference's own formula (ld.js)
+Translator.prototype.auxArray = function (fname, ids, f) {
+  const key = '#aux:' + fname + ':' + ids.join(',');
+  if (this.arrayIds.has(key)) return this.arrayIds.get(key);
+  const n = this.arrays[ids[0]].flat.length, vals = new Array(n);
+  for (let i = 0; i < n; i++) vals[i] = f.apply(null, ids.map((id) => this.arrays[id].flat[i]));
+  return this.registerArray(key, vals);
+};
+
 // a named temporary for a value that is used twice (keeps the evaluation single, as in JS)
 Translator.prototype.temp = function (code) {
   if (/^[\w.]+$/.test(code) || /^S\(\d+\)$/.test(code)) return code;
@@ -633,7 +688,7 @@ Translator.prototype.temp = function (code) {
 };
 
 // Hoists `ctor(code)` to just before the outermost enclosing loop in which argAst cannot change.
-Translator.prototype.hoist = function (argAst, type, ctor, code) {
+Translator.prototype.hoist = function (argAst, type, ctor, code, suffix) {
   if (this.noHoist || this.loops.length === 0) return null;
   const free = idsOf(argAst);
   let j = this.loops.length;
@@ -647,7 +702,7 @@ Translator.prototype.hoist = function (argAst, type, ctor, code) {
   if (j === this.loops.length) return null;   // changes inside the innermost loop
   if (this.pending.length) return null;       // the argument needs temporaries computed inside the loop
   const name = 'k' + (this.tmp++);
-  this.loops[j].preamble.push('const ' + type + ' ' + name + ' = ' + ctor + '(' + code + ');');
+  this.loops[j].preamble.push('const ' + type + ' ' + name + ' = ' + ctor + '(' + code + ');' + (suffix || '').replace('@', name));
   return name;
 };
 
@@ -692,6 +747,10 @@ Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) 
       return;
     }
     if (Object.prototype.hasOwnProperty.call(this.aliases, name)) this.fail(name + ' holds an array/object elsewhere and a number here');
+    if (op === '=' && v.t === 'num' && v.cst !== undefined && this.assignCount[name] === 1 && name !== this.acc) {
+      this.aliases[name] = v;     // assigned once, to a constant: it IS that constant (const N = d.y.length)
+      return;
+    }
     if (this.acc && name === this.acc) {
       if (op === '+=') {
         this.flush(out, indent);
@@ -851,20 +910,20 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
       const term = this.expr(body[0].expr.value);
       const pend = this.pending; this.pending = [];
       this.loops.pop();
-      out.push(indent + '{');
-      for (const p of L.preamble) out.push(indent + '  ' + p);
       const U = this.opts.unroll || 8;
-      out.push(indent + '  const int i0_ = ' + this.asI(startV) + ' + sub, n_ = (' + boundV.code + (canon.le ? ' + 1' : '') + ' - i0_ + G - 1) / G;');
-      out.push(indent + '  int it_ = 0;');
-      out.push(indent + '  for (; it_ + ' + U + ' <= n_; it_ += ' + U + ') {');
-      out.push(indent + '    double tb_[' + U + '];');
-      out.push(indent + '#pragma unroll');
-      out.push(indent + '    for (int u_ = 0; u_ < ' + U + '; ++u_) { const int v_' + canon.name + ' = i0_ + (it_ + u_) * G; ' + pend.join(' ') + ' tb_[u_] = ' + this.asD(term) + '; }');
-      out.push(indent + '#pragma unroll');
-      out.push(indent + '    for (int u_ = 0; u_ < ' + U + '; ++u_) v_' + this.acc + ' += tb_[u_];');
-      out.push(indent + '  }');
-      out.push(indent + '  for (; it_ < n_; ++it_) { const int v_' + canon.name + ' = i0_ + it_ * G; ' + pend.join(' ') + ' v_' + this.acc + ' += ' + this.asD(term) + '; }');
-      out.push(indent + '}');
+      const acc = 'v_' + this.acc, iv = 'v_' + canon.name;
+      const loop = [];
+      loop.push('  int it_ = 0;');
+      loop.push('  for (; it_ + ' + U + ' <= n_; it_ += ' + U + ') {');
+      loop.push('    double tb_[' + U + '];');
+      loop.push('#pragma unroll');
+      loop.push('    for (int u_ = 0; u_ < ' + U + '; ++u_) { const int ' + iv + ' = i0_ + (it_ + u_) * G; ' + pend.join(' ') + ' tb_[u_] = ' + this.asD(term) + '; }');
+      loop.push('#pragma unroll');
+      loop.push('    for (int u_ = 0; u_ < ' + U + '; ++u_) ' + acc + ' += tb_[u_];');
+      loop.push('  }');
+      loop.push('  for (; it_ < n_; ++it_) { const int ' + iv + ' = i0_ + it_ * G; ' + pend.join(' ') + ' ' + acc + ' += ' + this.asD(term) + '; }');
+      const head = ['  const int i0_ = ' + this.asI(startV) + ' + sub, n_ = (' + boundV.code + (canon.le ? ' + 1' : '') + ' - i0_ + G - 1) / G;'];
+      this.emitSplit(out, indent, L.preamble, head, loop);
       return;
     }
     for (const x of body) this.stmt(x, inner, ind2, bctx);
@@ -876,8 +935,16 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
     const bound = isInt && boundV.int ? boundV.code : this.asD(boundV);
     const lhs = isInt && !boundV.int ? '(double)' + v : v;
     const start = isInt ? this.asI(startV) : this.asD(startV);
-    if (split) out.push(indent + '  for (' + v + ' = ' + start + ' + sub; ' + lhs + cmp + bound + '; ' + v + ' += G) {');
-    else out.push(indent + '  for (' + v + ' = ' + start + '; ' + lhs + cmp + bound + '; ' + v + ' += 1) {');
+    if (split) {
+      const loop = ['  for (' + v + ' = ' + start + ' + sub; ' + lhs + cmp + bound + '; ' + v + ' += G) {'];
+      for (const ln of inner) loop.push(ln.slice(indent.length));
+      loop.push('  }');
+      out.pop();   // the '{' pushed above: emitSplit writes its own block
+      L.preamble.forEach(() => out.pop());
+      this.emitSplit(out, indent, L.preamble, [], loop);
+      return;
+    }
+    out.push(indent + '  for (' + v + ' = ' + start + '; ' + lhs + cmp + bound + '; ' + v + ' += 1) {');
     for (const ln of inner) out.push(ln);
     out.push(indent + '  }');
     out.push(indent + '}');
@@ -898,6 +965,32 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
   for (const p of L.preamble) out.push(indent + '  ' + p);
   out.push(indent + '  while (' + t.code + ') {');
   for (const ln of inner) out.push(ln);
+  out.push(indent + '  }');
+  out.push(indent + '}');
+};
+
+// A lane-split loop.  If it evaluates ld.norm with a hoisted sd, it is emitted twice: the fast form (4-operation
+// quotient, exponent range of the numerators recorded) and, run only if a range precondition failed, the slow form
+// (IEEE division) from the saved accumulator -- the two give the same bits, the second is the proof obligation.
+Translator.prototype.emitSplit = function (out, indent, preamble, head, loop) {
+  const acc = 'v_' + this.acc;
+  const all = preamble.concat(head, loop);
+  out.push(indent + '{');
+  if (!hasNormCall(all)) {
+    for (const ln of renderNorm(preamble.map((p) => '  ' + p).concat(head, loop), 'inv')) out.push(indent + ln);
+    out.push(indent + '}');
+    return;
+  }
+  out.push(indent + '  const double acc_save_ = ' + acc + ';');
+  out.push(indent + '  uint32_t rlo_ = 0xffffffffu, rhi_ = 0u;');
+  for (const ln of renderNorm(preamble.map((p) => '  ' + p), 'fast')) out.push(indent + ln);
+  for (const ln of head) out.push(indent + ln);
+  out.push(indent + '  {');
+  for (const ln of renderNorm(loop, 'fast')) out.push(indent + '  ' + ln);
+  out.push(indent + '  }');
+  out.push(indent + '  if (!norm_range_ok(rlo_, rhi_)) {');
+  out.push(indent + '    ' + acc + ' = acc_save_;');
+  for (const ln of renderNorm(loop, 'slow')) out.push(indent + '  ' + ln);
   out.push(indent + '  }');
   out.push(indent + '}');
 };
@@ -942,6 +1035,11 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
   scanTop(stmts);
   if (this.acc) this.topLevelRefs.delete(this.acc);
 
+  this.assignCount = {};
+  walk(body, (x) => {
+    if (x.k === 'VarDecl') x.decls.forEach((d) => { if (d.init) this.assignCount[d.name] = (this.assignCount[d.name] || 0) + 1; });
+    if ((x.k === 'Assign' || x.k === 'Update') && x.target.k === 'Id') this.assignCount[x.target.name] = (this.assignCount[x.target.name] || 0) + 1;
+  });
   this.forcedDouble = new Set();
   let lines;
   for (let round = 0; round < 8; round++) {
@@ -972,7 +1070,7 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
     decl.push('    ' + (this.localTypes[nm] === 'int' ? 'int' : 'double') + ' v_' + nm + ' = 0;');
   }
   for (const nm of this.derived) decl.push('    double dq_' + nm + ' = 0;');
-  return decl.concat(lines);
+  return decl.concat(renderNorm(lines, 'inv'));
 };
 
 Translator.prototype.run = function () {
@@ -980,10 +1078,12 @@ Translator.prototype.run = function () {
   // did any loop actually get split?
   const parallel = this.split && this.nSplit > 0;
   // ---- LDS staging plan: whole arrays, in order of first use, while they fit the budget
-  const budget = this.opts.lds_budget === undefined ? 98304 : this.opts.lds_budget;
+  // 160 KB per CU, minus the per-chain stepper state of ~128 chains (24 B per component), minus slack
+  const stateBytes = Math.min(24 * (this.P | 1) * 128, 65536);
+  const budget = this.opts.lds_budget === undefined ? 163840 - 8192 - stateBytes : this.opts.lds_budget;
   let off = 0;
   const plan = this.arrays.map((a) => {
-    const bytes = a.flat.length * 8;
+    const bytes = a.flat.length * a.esize;
     if (bytes > 0 && off + bytes <= budget) { const o = off; off += (bytes + 15) & ~15; return { lds: true, off: o }; }
     return { lds: false, off: 0 };
   });
@@ -1001,7 +1101,7 @@ Translator.prototype.run = function () {
   src.push('  __host__ __device__ static size_t lds_bytes(int, int, int) { return ' + off + '; }');
   src.push('  __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int) {');
   this.arrays.forEach((a, j) => {
-    if (plan[j].lds) src.push('    { double *dst = reinterpret_cast<double *>(smem + ' + plan[j].off + '); const double *src = d.arr[' + j + ']; for (int i = tid; i < ' + a.flat.length + '; i += nt) dst[i] = src[i]; }');
+    if (plan[j].lds) src.push('    { ' + a.ctype + ' *dst = reinterpret_cast<' + a.ctype + ' *>(smem + ' + plan[j].off + '); const ' + a.ctype + ' *src = static_cast<const ' + a.ctype + ' *>(d.arr[' + j + ']); for (int i = tid; i < ' + a.flat.length + '; i += nt) dst[i] = src[i]; }');
   });
   src.push('  }');
   src.push('#endif');
@@ -1009,10 +1109,10 @@ Translator.prototype.run = function () {
   src.push('  AMWG_HD static double eval(const StateView &S, const DataRef &d, const unsigned char *smem, int sub, double *dv) {');
   src.push('#if defined(__HIP_DEVICE_COMPILE__)');
   this.arrays.forEach((a, j) => {
-    src.push('    const double *A' + j + ' = ' + (plan[j].lds ? 'reinterpret_cast<const double *>(smem + ' + plan[j].off + ')' : 'd.arr[' + j + ']') + ';');
+    src.push('    const ' + a.ctype + ' *A' + j + ' = ' + (plan[j].lds ? 'reinterpret_cast<const ' + a.ctype + ' *>(smem + ' + plan[j].off + ')' : 'static_cast<const ' + a.ctype + ' *>(d.arr[' + j + '])') + ';');
   });
   src.push('#else');
-  this.arrays.forEach((a, j) => { src.push('    const double *A' + j + ' = d.arr[' + j + '];'); });
+  this.arrays.forEach((a, j) => { src.push('    const ' + a.ctype + ' *A' + j + ' = static_cast<const ' + a.ctype + ' *>(d.arr[' + j + ']);'); });
   src.push('#endif');
   src.push('    (void)smem; (void)sub; (void)d;');
   for (const ln of body) src.push(ln);
@@ -1022,6 +1122,7 @@ Translator.prototype.run = function () {
   return {
     source: src.join('\n') + '\n',
     arrays: this.arrays.map((a) => a.flat),
+    array_types: this.arrays.map((a) => a.type),
     array_keys: this.arrays.map((a) => a.key),
     derived: this.derived.slice(),
     lds_bytes: off,

@@ -113,11 +113,14 @@ int amwg_create(const amwg_model_desc *model, const amwg_param_desc *params, int
  * together with the same step kernel the built-in models use.  Arrays are the numeric arrays of
  * the closure's `data` argument that the body reads, flattened row-major. */
 #define AMWG_MAX_USER_ARRAYS 16
+enum { AMWG_F64 = 0, AMWG_U8 = 1, AMWG_I32 = 2 };
 typedef struct {
   const char *source;            /* HIP C++ text (NUL-terminated) */
   int32_t n_arrays;              /* <= AMWG_MAX_USER_ARRAYS */
   const double *const *arrays;   /* host pointers; copied to the device by amwg_create_user */
   const int64_t *array_len;      /* elements per array */
+  const int32_t *array_type;     /* device storage per array: AMWG_F64 | AMWG_U8 | AMWG_I32 (values must be exactly representable);
+                                    NULL = all AMWG_F64.  Host arrays are always doubles. */
   int32_t n_derived;             /* derived quantities (`state.key = expr`, mcmc.js:961-963, 990-995) recorded after the P components */
   int32_t lds_bytes;             /* bytes of data the generated stage() keeps in LDS */
   int32_t parallel;              /* 1 = the body has lane-split loops, lanes_per_chain > 1 is allowed */
@@ -160,6 +163,11 @@ int amwg_set_adapting(amwg_sampler *s, int32_t flag);
 /* Replaces reading sampler.state (mcmc.js:964): out[component][chain], P*chains doubles. */
 int amwg_get_state(amwg_sampler *s, double *out, size_t out_bytes);
 
+/* Per-chain starting points (the reference starts every chain of a run at the same completed `init`,
+ * mcmc.js:954-957; with many chains over-dispersed starts are what R-hat needs): state[component][chain],
+ * P*chains doubles.  Invalidates the cached log_post, which is recomputed by the next launch. */
+int amwg_set_state(amwg_sampler *s, const double *state, size_t state_bytes);
+
 /* Replaces sampler.info() (mcmc.js:977-980 -> 906-912 -> 563-571).  Every array is
  * [component][chain]; any pointer may be NULL.  `accepts`/`inbounds` are run totals the
  * reference does not keep (accept decisions and in-bounds proposals), used by parity tests. */
@@ -173,6 +181,12 @@ int amwg_chain_diag(amwg_sampler *s, uint64_t *uniforms, double *log_post, int32
 /* Posterior summaries computed on the device over the draws of the LAST amwg_sample* call:
  * mean[P], sd[P] (n-1 denominator) over all chains x kept draws. */
 int amwg_last_sample_moments(amwg_sampler *s, double *mean, double *sd);
+
+/* Convergence diagnostics over the draws of the LAST amwg_sample* call, computed on the device per recorded value
+ * (what the reference's users do in R on the returned arrays, tests/test_mcmc_js.R): split-R-hat (every chain cut in
+ * two halves; Gelman et al., BDA3 section 11.4) and the effective sample size from the variance of the chain means,
+ * ess = chains * var_plus / Var(chain mean).  Needs >= 2 chains and >= 4 kept draws.  rhat[P], ess[P]. */
+int amwg_last_sample_diagnostics(amwg_sampler *s, double *rhat, double *ess);
 
 int amwg_sync(amwg_sampler *s);
 int amwg_num_components(const amwg_sampler *s);   /* P: scalar parameter components */

@@ -10,13 +10,16 @@
 extern "C" {
 #endif
 
-enum { ORC_MODEL_NORMAL = 1, ORC_MODEL_BETA_BERN = 2, ORC_MODEL_HIER_NORMAL = 3, ORC_MODEL_POIS_GLM = 4 };
-enum { ORC_REAL = 0, ORC_INT = 1 };
+enum { ORC_MODEL_NORMAL = 1, ORC_MODEL_BETA_BERN = 2, ORC_MODEL_HIER_NORMAL = 3, ORC_MODEL_POIS_GLM = 4,
+       ORC_MODEL_CALLBACK = 5 /* log_post supplied by the test (a user closure), see orc_set_callback */ };
+enum { ORC_REAL = 0, ORC_INT = 1, ORC_BINARY = 2 };
+/* log_post(state[P]) summed in the order of `lanes` lanes per chain */
+typedef double (*orc_log_post_fn)(const double *state, int lanes, void *ctx);
 
 /* One named parameter of the reference's `params` object after
  * complete_params() (mcmc.js:357-403), flattened row-major. */
 typedef struct {
-  int32_t type;      /* ORC_REAL | ORC_INT */
+  int32_t type;      /* ORC_REAL | ORC_INT (Metropolis, mcmc.js:517-553) | ORC_BINARY (BinaryStepper, mcmc.js:753-767) */
   int32_t len;       /* prod(dim) */
   int32_t top;       /* dim[0]; the only dimension that is shuffled (mcmc.js:244-258) */
   int32_t multidim;  /* 0 iff dim equals [1] (dispatch rule of mcmc.js:846-857) */
@@ -44,6 +47,8 @@ typedef struct orc_chain orc_chain;
 /* lanes = summation order of the observation loop: 1 = the reference's
  * sequential `lp += term` order; L>1 = L strided partial sums + xor butterfly
  * (offsets 1,2,4..), which is the order the HIP kernel uses with L lanes per chain. */
+/* ORC_MODEL_CALLBACK: the function orc_create and every step will call; set it BEFORE orc_create */
+void orc_set_callback(orc_log_post_fn fn, void *ctx);
 orc_chain *orc_create(const orc_data *d, const orc_param *params, int n_params, const double *init /*P*/,
                       const orc_comp_opt *opts /*P*/, uint64_t seed, uint64_t chain, int lanes);
 void orc_destroy(orc_chain *c);

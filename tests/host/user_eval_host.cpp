@@ -23,7 +23,8 @@ double lanes(const double *state, const amwg::DataRef &d, double *dv) {
 
 extern "C" int user_num_derived() { return amwg::UserModel::kDerived; }
 
-extern "C" double user_eval(const double *state, const double *const *arrays, int n_arrays, int G, double *dv) {
+// arrays[j]: device-typed storage (f64 / u8 / i32 as the translator chose, see meta.array_types)
+extern "C" double user_eval(const double *state, const void *const *arrays, int n_arrays, int G, double *dv) {
   amwg::DataRef d{};
   for (int j = 0; j < n_arrays && j < amwg::kMaxUserArrays; ++j) d.arr[j] = arrays[j];
   switch (G) {

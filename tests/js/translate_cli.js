@@ -9,8 +9,7 @@ const um = require('./user_models.js');
 global.ld = ld;
 const out = process.argv[2];
 const want = process.argv.slice(3);
-for (const name of um.names) {
-  if (want.length && want.indexOf(name) < 0) continue;
+for (const name of (want.length ? want : um.names)) {
   const m = um.build(name);
   const params = mcmc.complete_params(m.params, mcmc.param_init_fixed);
   const tr = mcmc.translate(m.log_post, params, m.data, { helpers: m.helpers, constants: m.constants });
@@ -26,5 +25,5 @@ for (const name of um.names) {
   }
   fs.writeFileSync(path.join(out, name + '.arrays.bin'), buf);
   fs.writeFileSync(path.join(out, name + '.meta.json'), JSON.stringify({ name, P: tr.P, derived: tr.derived, lds_bytes: tr.lds_bytes,
-    parallel: tr.parallel, max_threads: tr.max_threads, array_keys: tr.array_keys, array_len: tr.arrays.map((a) => a.length) }));
+    parallel: tr.parallel, max_threads: tr.max_threads, array_keys: tr.array_keys, array_types: tr.array_types, array_len: tr.arrays.map((a) => a.length) }));
 }

@@ -259,8 +259,26 @@ CASES.discrete_mix = {
   schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 60 }], chains: [0, 1],
 };
 
+// ---- the BASELINE.json configs at full size, written as plain closures (performance of the translated path;
+// not part of `names`, so they have no goldens of their own: cfg2..cfg5 goldens are those of the built-in families)
+const BENCH = {
+  bench_normal: { params: CASES.readme_normal.params, data: () => synth.normal(10000, 20260925).x, log_post: CASES.readme_normal.log_post },
+  bench_bern: { params: () => ({ theta: { type: 'real', lower: 0, upper: 1 } }), data: () => synth.bern(100000, 20260925),
+    log_post: function(state, data) {
+      var log_post = 0;
+      log_post += ld.beta(state.theta, 2, 2);
+      var n = data.x.length;
+      for(var i = 0; i < n; i++) {
+        log_post += ld.bern(data.x[i], state.theta)
+      }
+      return log_post;
+    } },
+  bench_hier: { params: CASES.hier_normal_closure.params, data: () => synth.hier(10000, 32, 20260925), log_post: CASES.hier_normal_closure.log_post },
+  bench_glm: { params: CASES.pois_glm_closure.params, data: () => synth.glm(50000, 20260925), log_post: CASES.pois_glm_closure.log_post },
+};
+
 function build(name, seed) {
-  const c = CASES[name];
+  const c = CASES[name] || BENCH[name];
   if (!c) throw new Error('unknown user model ' + name);
   const data = c.data(seed === undefined ? 20260925 : seed);
   return { name, params: c.params(data), log_post: c.log_post, data, helpers: c.helpers, constants: c.constants,

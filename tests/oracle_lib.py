@@ -26,6 +26,8 @@ class OrcData(C.Structure):
 DEFAULT_HYPER = {"normal": [0, 100, 0, 100], "beta_bern": [2, 2], "hier_normal": [0, 100, 0, 100, 10], "pois_glm": [0, 10]}
 
 
+LOG_POST_FN = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+TYPE_ID = {"real": 0, "int": 1, "binary": 2}
 _lib = None
 
 
@@ -60,6 +62,11 @@ def lib():
             getattr(L, f).restype = C.c_double
             getattr(L, f).argtypes = [C.c_double] * n
         L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_set_callback.argtypes = [LOG_POST_FN, C.c_void_p]
+        L.orc_pow.restype = C.c_double
+        L.orc_pow.argtypes = [C.c_double, C.c_double]
+        L.orc_ld.restype = C.c_double
+        L.orc_ld.argtypes = [C.c_int] + [C.c_double] * 4
         _lib = L
     return _lib
 
@@ -69,35 +76,42 @@ def _dp(a):
 
 
 class OracleChain:
-    """One reference-order chain.  `spec` is a dict from model_spec.build_spec()."""
+    """One reference-order chain.  `spec` is a dict from model_spec.build_spec(), or -- for a user closure -- a dict with
+    `log_post_fn(state ndarray[P], lanes) -> float` instead of model/data (the oracle steps, the callback evaluates)."""
 
     def __init__(self, spec, seed, chain, lanes=1):
         L = lib()
         self.spec = spec
-        d = spec["data"]
         self._keep = []
         od = OrcData()
-        od.model = MODEL_ID[spec["model"]]
-        od.n_obs = spec["n_obs"]
-        x = np.ascontiguousarray(d["x"], dtype=np.float64)
-        self._keep.append(x)
-        od.x = _dp(x)
-        if "y" in d:
-            y = np.ascontiguousarray(d["y"], dtype=np.float64)
-            self._keep.append(y)
-            od.y = _dp(y)
-        if "g" in d:
-            g = np.ascontiguousarray(d["g"], dtype=np.int32)
-            self._keep.append(g)
-            od.g = g.ctypes.data_as(C.POINTER(C.c_int32))
-        od.G = spec.get("G", 0)
-        od.K = spec.get("K", 0)
-        for i, v in enumerate(spec.get("hyper") or DEFAULT_HYPER[spec["model"]]):
-            od.hyper[i] = float(v)
+        if "log_post_fn" in spec:
+            fn, P_ = spec["log_post_fn"], spec["P"]
+            self._cb = LOG_POST_FN(lambda st, ln, ctx: float(fn(np.ctypeslib.as_array(st, shape=(P_,)).copy(), ln)))
+            L.orc_set_callback(self._cb, None)
+            od.model = 5   # ORC_MODEL_CALLBACK
+        else:
+            d = spec["data"]
+            od.model = MODEL_ID[spec["model"]]
+            od.n_obs = spec["n_obs"]
+            x = np.ascontiguousarray(d["x"], dtype=np.float64)
+            self._keep.append(x)
+            od.x = _dp(x)
+            if "y" in d:
+                y = np.ascontiguousarray(d["y"], dtype=np.float64)
+                self._keep.append(y)
+                od.y = _dp(y)
+            if "g" in d:
+                g = np.ascontiguousarray(d["g"], dtype=np.int32)
+                self._keep.append(g)
+                od.g = g.ctypes.data_as(C.POINTER(C.c_int32))
+            od.G = spec.get("G", 0)
+            od.K = spec.get("K", 0)
+            for i, v in enumerate(spec.get("hyper") or DEFAULT_HYPER[spec["model"]]):
+                od.hyper[i] = float(v)
         n = len(spec["params"])
         pa = (OrcParam * n)()
         for i, p in enumerate(spec["params"]):
-            pa[i].type = 1 if p["type"] == "int" else 0
+            pa[i].type = TYPE_ID[p["type"]]
             pa[i].len = p["len"]
             pa[i].top = p["top"]
             pa[i].multidim = p["multidim"]

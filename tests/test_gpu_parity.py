@@ -119,3 +119,37 @@ def test_edge_cases_empty_data_single_chain_thin_larger_than_n():
     gs, os_ = run_schedule(s, sched), run_schedule(o, sched)
     assert gs[0].shape == (1, 2, 1) and gs[1].shape == (0, 2, 1)
     assert_chain_equals_oracle(s, 0, o, gs, os_)
+
+
+def test_set_state_and_convergence_diagnostics():
+    """Per-chain starts (amwg_set_state) restart the cached log_post; split-R-hat / ESS equal a numpy restatement."""
+    data = model_spec.make_data("normal", 400, 21)
+    spec = model_spec.build_spec("normal", data)
+    chains, seed = 256, 77
+    s = A.Sampler(spec, chains=chains, seed=seed, lanes_per_chain=2)
+    rng = np.random.default_rng(5)
+    start = np.stack([rng.normal(3, 5, chains), rng.uniform(0.5, 9, chains)])
+    s.burn(3)                                    # the cached log_post of the old state must not survive set_state
+    s.set_state(start)
+    assert s.state().tobytes() == start.tobytes()
+    s.burn(40)
+    for c in (0, 100, 255):
+        # the invariant a stale cache would break: log_post cached on the device == the oracle's log_post at the device's state
+        cur = dict(spec, init=s.state()[:, c].tolist())
+        assert np.float64(s.diag()["log_post"][c]).tobytes() == np.float64(oracle_lib.OracleChain(cur, seed, c, lanes=2).log_post()).tobytes()
+    s.burn(600)
+    d = s.sample(200, 2)                         # [100][2][256]
+    rhat, ess = s.convergence()
+    rows = d.shape[0]
+    half = rows // 2
+    for p in range(2):
+        x = d[:, p, :]
+        seqs = np.concatenate([x[:half], x[half:2 * half]], axis=1)       # [half][2C]
+        W = seqs.var(axis=0, ddof=1).mean()
+        Bn = seqs.mean(axis=0).var(ddof=1)
+        var_plus = (half - 1) / half * W + Bn
+        np.testing.assert_allclose(rhat[p], np.sqrt(var_plus / W), rtol=1e-10)
+        cm = 0.5 * (x[:half].mean(axis=0) + x[half:2 * half].mean(axis=0))
+        np.testing.assert_allclose(ess[p], chains * var_plus / cm.var(ddof=1), rtol=1e-9)
+        assert 0.98 < rhat[p] < 1.05 and ess[p] > chains
+    s.close()

@@ -34,8 +34,7 @@ def spec_for(name):
         opts.append({"prop_log_scale": o.get("prop_log_scale", 0.0), "max_adaptation": o.get("max_adaptation", 0.33),
                      "initial_adaptation": o.get("initial_adaptation", 1.0), "target_accept_rate": o.get("target_accept_rate", 0.44),
                      "batch_size": o.get("batch_size", 50), "is_adapting": o.get("is_adapting", True)})
-    user = {"source": m.source, "arrays": m.arrays, "n_derived": len(m.meta["derived"]), "lds_bytes": m.meta["lds_bytes"],
-            "parallel": m.meta["parallel"], "max_threads": m.meta["max_threads"]}
+    user = user_host.user_spec_part(m.source, m.arrays, m.meta)
     return {"user": user, "params": params, "P": len(init), "init": init, "comp_opts": opts}, m, gold
 
 
@@ -67,6 +66,27 @@ def test_device_lane_sum_equals_host_emulation(name, lanes):
             assert s2.info()["accepts"][:, 0].tolist() == rec["accepts"]
             assert s2.state()[:, 0].tolist() == rec["final_state"]
             s2.close()
+    s.close()
+
+
+@pytest.mark.parametrize("name,lanes", [("complex_model", 4), ("spike_slab", 8), ("hier_binomial", 2), ("norm_post_derived", 16), ("survival_mix", 4)])
+def test_g_lane_trajectories_equal_oracle_stepper_with_same_lane_order(name, lanes):
+    """Whole trajectories with G lanes per chain: the device == the C oracle's stepper calling the host build of the same
+    generated text in the same lane order (test_translate.py pins that pair against the reference at one lane)."""
+    import oracle_lib
+    from gpu_util import assert_chain_equals_oracle, run_schedule
+    from test_translate import oracle_spec
+    spec, m, gold = spec_for(name)
+    ospec, _, _ = oracle_spec(name)
+    seed = 1234
+    s = A.Sampler(spec, chains=40, seed=seed, chain_offset=7, lanes_per_chain=lanes)
+    sched = [{"op": "burn", "n": 110}, {"op": "sample", "n": 45, "thin": 2}]
+    gs = run_schedule(s, sched)
+    P = s.P
+    for local in (0, 39):
+        o = oracle_lib.OracleChain(ospec, seed, 7 + local, lanes=lanes)
+        os_ = run_schedule(o, sched)
+        assert_chain_equals_oracle(s, local, o, [g[:, :P, :] for g in gs], os_)
     s.close()
 
 

@@ -63,7 +63,7 @@ def test_lane_split_flags():
     assert meta["readme_normal"]["parallel"] == 1 and meta["pois_glm_closure"]["parallel"] == 1
     assert meta["multi_bern"]["parallel"] == 0            # `return expr`: nothing to split
     assert meta["norm_post_derived"]["derived"] == ["var"]
-    assert meta["readme_normal"]["lds_bytes"] == 80
+    assert meta["readme_normal"]["lds_bytes"] == 16 and meta["readme_normal"]["array_types"] == [1]   # integer heights: u8 storage
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -75,3 +75,47 @@ def test_hiprtc_compiles_for_gfx950(name):
     rc = L.amwg_compile_user(m.source.encode(), lanes, min(256, m.meta["max_threads"]), b"gfx950", C.byref(n))
     assert rc == 0, L.amwg_last_error().decode()[-3000:]
     assert n.value > 10000
+
+
+def oracle_spec(name):
+    """OracleChain spec for a user closure: the oracle's stepper + the host build of the translated closure as log_post."""
+    gold = golden_io.load("user_" + name)
+    rec = gold["chains"][0]
+    m = user_host.host_model(name)
+    params, init, opts = [], [], []
+    for p in rec["params_completed"]:
+        ln = int(np.prod(p["dim"]))
+        params.append({"type": p["type"], "len": ln, "top": p["dim"][0], "multidim": 0 if p["dim"] == [1] else 1,
+                       "lower": p["lower"], "upper": p["upper"]})
+        init += p["init"]
+    for o in rec["comp_opts"]:
+        opts.append({"prop_log_scale": o.get("prop_log_scale", 0.0), "max_adaptation": o.get("max_adaptation", 0.33),
+                     "initial_adaptation": o.get("initial_adaptation", 1.0), "target_accept_rate": o.get("target_accept_rate", 0.44),
+                     "batch_size": o.get("batch_size", 50), "is_adapting": o.get("is_adapting", True)})
+    return {"log_post_fn": lambda st, lanes: m.eval(st, lanes), "params": params, "P": len(init), "init": init, "comp_opts": opts}, gold, m
+
+
+@pytest.mark.parametrize("name", ["complex_model", "spike_slab", "multi_bern", "hier_binomial", "discrete_mix"])
+def test_oracle_stepper_with_translated_closure_reproduces_reference(name):
+    """Pins the oracle's BinaryStepper (mcmc.js:753-767) and int/real steppers on user models: the C oracle, stepping with the
+    host build of the translated closure as log_post, reproduces the seeded reference run bit for bit."""
+    import oracle_lib
+    spec, gold, m = oracle_spec(name)
+    P = spec["P"]
+    for rec in gold["chains"]:
+        o = oracle_lib.OracleChain(spec, gold["case"]["seed"], rec["chain"], lanes=1)
+        k = 0
+        for seg in gold["case"]["schedule"]:
+            if seg["op"] == "burn":
+                o.burn(seg["n"])
+            else:
+                got = o.sample(seg["n"], seg.get("thin", 1))
+                want = rec["samples"][k]
+                k += 1
+                w = np.array(want["draws"], dtype=np.float64)[:, :P]
+                assert got[: w.shape[0]].tobytes() == np.ascontiguousarray(w).tobytes()
+        assert o.state().tolist() == rec["final_state"]
+        info = o.info()
+        assert info["accepts"].tolist() == rec["accepts"] and info["inbounds"].tolist() == rec["inbounds"]
+        assert info["prop_log_scale"].tolist() == rec["prop_log_scale"]
+        assert o.uniforms() == rec["uniforms"]

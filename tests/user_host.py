@@ -25,6 +25,28 @@ def workdir():
     return _dir
 
 
+def translate_extra(name):
+    """Translates one closure that is not in user_models.names (the full-size bench_* closures)."""
+    d = workdir()
+    if not os.path.exists(os.path.join(d, name + ".hip")):
+        p = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "translate_cli.js"), d, name], cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + "\n" + p.stderr
+    return d
+
+
+def translated(name):
+    """-> (source, arrays, meta) without building the host harness"""
+    d = translate_extra(name)
+    return (open(os.path.join(d, name + ".hip")).read(), read_arrays(os.path.join(d, name + ".arrays.bin")),
+            json.load(open(os.path.join(d, name + ".meta.json"))))
+
+
+def user_spec_part(source, arrays, meta):
+    """The `user` entry of an amwg_ctypes.Sampler spec."""
+    return {"source": source, "arrays": arrays, "array_types": meta["array_types"], "n_derived": len(meta["derived"]),
+            "lds_bytes": meta["lds_bytes"], "parallel": meta["parallel"], "max_threads": meta["max_threads"]}
+
+
 def read_arrays(path):
     buf = open(path, "rb").read()
     n, = struct.unpack_from("<I", buf, 0)
@@ -54,8 +76,10 @@ class HostModel:
         assert p.returncode == 0, p.stderr[-4000:]
         self.lib = C.CDLL(so)
         self.lib.user_eval.restype = C.c_double
-        self.lib.user_eval.argtypes = [C.POINTER(C.c_double), C.POINTER(C.POINTER(C.c_double)), C.c_int, C.c_int, C.POINTER(C.c_double)]
-        self.ptrs = (C.POINTER(C.c_double) * max(1, len(self.arrays)))(*[a.ctypes.data_as(C.POINTER(C.c_double)) for a in self.arrays])
+        self.lib.user_eval.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_double)]
+        # the storage types the translator chose for the device (f64 / u8 / i32): the host build reads the same types
+        self.typed = [a.astype([np.float64, np.uint8, np.int32][t]) for a, t in zip(self.arrays, self.meta["array_types"])]
+        self.ptrs = (C.c_void_p * max(1, len(self.typed)))(*[a.ctypes.data for a in self.typed])
         self.D = self.lib.user_num_derived()
 
     def eval(self, state, lanes=1, derived=False):
