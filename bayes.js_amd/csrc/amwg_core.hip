@@ -162,6 +162,10 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   for (int G = 1; G <= 64; G <<= 1) {
     if (o.lanes_per_chain && G != o.lanes_per_chain) continue;
     if (s->user && !s->user_parallel && G > 1) break;   // nothing to split: one lane per chain
+    // translated closures: with one lane per chain every data index is wave-uniform and the compiler moves the
+    // per-observation integer logic to the scalar unit, which issues 4x slower than the vector lanes (measured 2.5x on
+    // the beta-Bernoulli closure); two lanes per chain keep it on the vector path at no measurable cost elsewhere
+    if (s->user && s->user_parallel && !o.lanes_per_chain && G == 1) continue;
     int pick = 0;
     for (int bi = 0; bi < 5; ++bi) {   // largest workgroup with >= one workgroup per CU, else the smallest that fits
       const int bt = bts[bi];
