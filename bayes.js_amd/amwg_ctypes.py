@@ -45,7 +45,7 @@ class UserModel(C.Structure):
                 ("parallel", C.c_int32), ("max_threads", C.c_int32)]
 
 
-EXPORTS = ["amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
+EXPORTS = ["amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
            "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components",
            "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp",
            "amwg_log", "amwg_uniform", "amwg_device_eval"]
@@ -95,6 +95,7 @@ def lib():
                                        C.POINTER(Options), C.POINTER(vp)]
         L.amwg_num_recorded.argtypes = [vp]
         L.amwg_set_state.argtypes = [vp, pd, C.c_size_t]
+        L.amwg_fp64_peak.argtypes = [i32, pd]
         L.amwg_last_sample_diagnostics.argtypes = [vp, pd, pd]
         L.amwg_pow.restype = dbl
         L.amwg_pow.argtypes = [dbl, dbl]
@@ -278,6 +279,13 @@ class Sampler:
         _check(lib().amwg_launch_info(self.h, *[C.byref(x) for x in v], C.byref(ms)))
         return {"lanes_per_chain": v[0].value, "block_threads": v[1].value, "grid_blocks": v[2].value,
                 "lds_bytes": v[3].value, "n_launches": v[4].value, "kernel_ms": ms.value}
+
+
+def fp64_peak(device=0):
+    """Measured fp64 fma issue rate of the device, lane-operations per second."""
+    v = C.c_double()
+    _check(lib().amwg_fp64_peak(device, C.byref(v)))
+    return v.value
 
 
 def device_eval(op, a, b=None, c=None, device=0):

@@ -287,6 +287,19 @@ __global__ void chain_halves_kernel(const double *draws, int64_t rows, int PR, i
   }
 }
 
+// 8 independent fma chains per lane, no memory traffic: the fp64 issue rate the chip sustains
+__global__ void __launch_bounds__(1024) fp64_peak_kernel(double *out, int iters, double a, double b) {
+  double x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      x0 = __builtin_fma(x0, a, b); x1 = __builtin_fma(x1, a, b); x2 = __builtin_fma(x2, a, b); x3 = __builtin_fma(x3, a, b);
+      x4 = __builtin_fma(x4, a, b); x5 = __builtin_fma(x5, a, b); x6 = __builtin_fma(x6, a, b); x7 = __builtin_fma(x7, a, b);
+    }
+  }
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
+}
+
 }  // namespace
 
 extern "C" {
@@ -931,6 +944,35 @@ int amwg_launch_info(const amwg_sampler *s, int32_t *lanes, int32_t *block, int3
   if (lds) *lds = s->lds;
   if (n_launches) *n_launches = s->n_launches;
   if (kernel_ms) *kernel_ms = s->kernel_ms;
+  return AMWG_OK;
+}
+
+int amwg_fp64_peak(int32_t device, double *lane_ops_per_s) {
+  if (!lane_ops_per_s) return fail(AMWG_EINVAL, "amwg_fp64_peak: null argument");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1) return fail(AMWG_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  const int blocks = (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * 2, threads = 1024, iters = 20000;
+  double *dout = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dout), (size_t)blocks * threads * 8));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {    // first repetition warms the clocks up
+    HIP_TRY(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(fp64_peak_kernel, dim3(blocks), dim3(threads), 0, 0, dout, iters, 0.999999, 1e-7);
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (rep > 0 && ms < best) best = ms;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(dout);
+  *lane_ops_per_s = (double)blocks * threads * (double)iters * 64.0 / (best * 1e-3);
   return AMWG_OK;
 }
 

@@ -168,6 +168,7 @@ def main():
         updates_per_launch = chains * (K / launches) * P
         achieved = updates_per_launch * B_ALG_PER_UPDATE / launch_s / 1e9
         mean, sd = s.moments()
+        measured_peak = A.fp64_peak(dev_index)      # register-only fma kernel: what the chip sustains under fp64 load
         x = spec["data"]["x"]
         traffic, traffic_src = measured_traffic(chains, args.steps_per_launch)
         out = {
@@ -191,7 +192,10 @@ def main():
                                  "(see fp64_valu)",
                          "fp64_valu": {"lane_ops_per_obs": 8, "achieved_lane_ops_per_s": updates_per_launch * N_OBS * 8 / launch_s,
                                        "peak_lane_ops_per_s": FP64_VALU_PEAK,
-                                       "frac": updates_per_launch * N_OBS * 8 / launch_s / FP64_VALU_PEAK}},
+                                       "frac": updates_per_launch * N_OBS * 8 / launch_s / FP64_VALU_PEAK,
+                                       "measured_peak_lane_ops_per_s": measured_peak,
+                                       "frac_of_measured_peak": updates_per_launch * N_OBS * 8 / launch_s / measured_peak,
+                                       "measured_peak_note": "amwg_fp64_peak: independent v_fma_f64 chains, no memory traffic, same run"}},
             "kernel_only_value": chains * K * P / (kernel_ms * 1e-3),
             "posterior": {"mean": mean.tolist(), "sd": sd.tolist(), "data_mean": float(np.mean(x)), "data_sd": float(np.std(x, ddof=1)),
                           "note": "moments over all recorded draws of rank 0 (after %d warm-up steps)" % W},

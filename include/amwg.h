@@ -207,6 +207,10 @@ double amwg_uniform(uint64_t seed, uint64_t chain, uint64_t index);
 /* Device evaluation: op in {0:exp,1:log,2:sqrt,3:lgamma,4:a/b via hoisted reciprocal,5:ld_norm(a,b,c),...};
  * a,b,c host arrays of n doubles (b,c may be NULL), out host array of n doubles. */
 int amwg_device_eval(int32_t device, int32_t op, int64_t n, const double *a, const double *b, const double *c, double *out);
+/* Measured fp64 vector issue ceiling of the device: a register-only kernel of independent v_fma_f64 chains on every SIMD
+ * (what the chip sustains under fp64 load at its own clocks), in lane-operations per second.  bench.py prices the step
+ * kernel against this next to the datasheet number. */
+int amwg_fp64_peak(int32_t device, double *lane_ops_per_s);
 double amwg_pow(double x, double y);   /* bit-identical to V8 Math.pow */
 /* Every scalar ld.* density and helper of distributions.js by id (0 norm 1 unif 2 beta 3 bern 4 pois 5 cauchy
  * 6 laplace 7 gamma 8 invgamma 9 lnorm 10 pareto 11 t 12 weibull 13 logis 14 exp 15 binom 16 nbinom 17 hyper
