@@ -88,6 +88,7 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
     const typename Model::Pass ps = Model::begin(S, a.mc, a.d, smem);
     const double prior = Model::prior(S, a.mc, a.d);
     acc = (sub == 0) ? prior : 0.0;
+    if constexpr (Model::kSplitPrior) acc = Model::template prior_split<G>(S, a.mc, a.d, sub, acc);
     if constexpr (Model::kHasFast) {
       if (ps.fast) acc = pass_over_data<Model, true, G>(ps, a.d.n_obs, sub, acc);
       else acc = pass_over_data<Model, false, G>(ps, a.d.n_obs, sub, acc);

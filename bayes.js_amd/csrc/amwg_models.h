@@ -21,6 +21,7 @@ __device__ __forceinline__ double norm_const_sd(double v, double m, double c_sd,
 // ---------------------------------------------------------------------------------------------
 // x_i ~ norm(mu, sigma); mu ~ norm(m0,s0); sigma ~ unif(a,b)              README.md:22-36
 struct NormalModel {
+  static constexpr bool kSplitPrior = false;
   static constexpr bool kUser = false, kHasFast = true, kOneLanePass = false;
   static constexpr int kDerived = 0;
   static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
@@ -64,6 +65,7 @@ struct NormalModel {
 // ld.bern(x,p) = log(x*p + (1-x)*(1-p)) is exactly log(p) for x=1 and log(1-p) for x=0
 // (1*p + 0*(1-p) = p + 0 = p), so the two logs are hoisted and selected per observation.
 struct BetaBernModel {
+  static constexpr bool kSplitPrior = false;
   static constexpr bool kUser = false, kHasFast = false, kOneLanePass = true;
   static constexpr int kDerived = 0;
   static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
@@ -213,13 +215,21 @@ struct HierNormalModel {
     uint8_t *gd = smem + (size_t)d.n_obs * 8;
     for (int i = tid; i < d.n_obs; i += nt) { dst[i] = d.x[i]; gd[i] = d.xb[i]; }
   }
+  // Lane order of the priors (the same a translated closure gets, translate.js): lane 0 adds the terms outside
+  // loops -- mu, sigma -- and the `for k` loop over the group means is dealt to the lanes like the data loop.
+  static constexpr bool kSplitPrior = true;
   __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &d) {
     const double mu = S(d.G), sigma = S(d.G + 1);
     double lp = 0;
     lp += norm_const_sd(mu, mc.m0, mc.c0, mc.den0);
     lp += (sigma < mc.ua || sigma > mc.ub) ? -kInf : mc.lunif;
-    for (int k = 0; k < d.G; ++k) lp += norm_const_sd(S(k), mu, mc.c1, mc.den1);
     return lp;
+  }
+  template <int G>
+  __device__ __forceinline__ static double prior_split(const StateView &S, const ModelConsts &mc, const DataRef &d, int sub, double acc) {
+    const double mu = S(d.G);
+    for (int k = sub; k < d.G; k += G) acc += norm_const_sd(S(k), mu, mc.c1, mc.den1);
+    return acc;
   }
   __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &mc, const DataRef &d,
                                                const unsigned char *smem) {
@@ -258,12 +268,17 @@ struct PoisGlmModel {
   struct Pass { double b[8]; double cp; const double *X, *y, *lfact; int N; };
   __host__ __device__ static size_t lds_bytes(int, int, int) { return 0; }
   __device__ static void stage(unsigned char *, const DataRef &, int, int, int) {}
-  __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &) {
-    double lp = 0;
-    for (int k = 0; k < 8; ++k) lp += norm_const_sd(S(k), mc.m0, mc.c0, mc.den0);
-    const double cp = S(8);
-    lp += (cp < 0 || cp > mc.cp_upper) ? -kInf : mc.lunif_cp;
-    return lp;
+  // closure order: `for k` over the 8 coefficients (dealt to the lanes), then the change point's prior (lane 0), then the data
+  static constexpr bool kSplitPrior = true;
+  __device__ __forceinline__ static double prior(const StateView &, const ModelConsts &, const DataRef &) { return 0.0; }
+  template <int G>
+  __device__ __forceinline__ static double prior_split(const StateView &S, const ModelConsts &mc, const DataRef &, int sub, double acc) {
+    for (int k = sub; k < 8; k += G) acc += norm_const_sd(S(k), mc.m0, mc.c0, mc.den0);
+    if (sub == 0) {
+      const double cp = S(8);
+      acc += (cp < 0 || cp > mc.cp_upper) ? -kInf : mc.lunif_cp;
+    }
+    return acc;
   }
   __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &, const DataRef &d,
                                                const unsigned char *) {

@@ -50,7 +50,7 @@ function hexFloat(v) {
 
 // ------------------------------------------------------------------------------------------
 // tokenizer
-const PUNCT = ['===', '!==', '>>>', '==', '!=', '<=', '>=', '&&', '||', '++', '--', '+=', '-=', '*=', '/=', '%=', '=>',
+const PUNCT = ['===', '!==', '>>>', '**', '==', '!=', '<=', '>=', '&&', '||', '++', '--', '+=', '-=', '*=', '/=', '%=', '=>',
   '{', '}', '(', ')', '[', ']', ';', ',', '.', '?', ':', '<', '>', '+', '-', '*', '/', '%', '!', '='];
 
 function tokenize(src) {
@@ -198,7 +198,9 @@ Parser.prototype = {
     for (const op of ['-', '+', '!']) if (this.peek(op)) { this.i++; return { k: 'Unary', op, arg: this.unary() }; }
     for (const op of ['++', '--']) if (this.peek(op)) { this.i++; return { k: 'Update', op, prefix: true, target: this.unary() }; }
     if (this.peek('typeof') || this.peek('new')) throw "'" + this.tk[this.i].v + "' is not supported inside log_post";
-    return this.postfix();
+    const base = this.postfix();
+    if (this.eat('**')) return { k: 'Call', callee: { k: 'Member', obj: { k: 'Id', name: 'Math' }, prop: 'pow' }, args: [base, this.unary()] };   // right-associative
+    return base;
   },
   postfix() {
     let e = this.primary();
@@ -429,7 +431,7 @@ Translator.prototype.asB = function (v) {
   this.fail('a ' + this.describe(v) + ' is used as a condition');
 };
 Translator.prototype.describe = function (v) {
-  return { stateObj: 'state object', stateArr: 'parameter array', dataObj: 'data object', dataArr: 'data array', ns: 'namespace', fn: 'function', bool: 'boolean', num: 'number' }[v.t] || v.t;
+  return { localArr: 'local array', stateObj: 'state object', stateArr: 'parameter array', dataObj: 'data object', dataArr: 'data array', ns: 'namespace', fn: 'function', bool: 'boolean', num: 'number' }[v.t] || v.t;
 };
 
 // ---- expressions -----------------------------------------------------------------------------------
@@ -475,6 +477,7 @@ Translator.prototype.member = function (objV, prop) {
     if (!Object.prototype.hasOwnProperty.call(objV.value, prop)) this.fail('data' + objV.path + '.' + prop + ' does not exist');
     return this.dataValue(objV.path + '.' + prop, objV.value[prop]);
   }
+  if (objV.t === 'localArr') { if (prop === 'length') return cnum(objV.elems.length); this.fail("property '" + prop + "' of an array is not supported"); }
   if (objV.t === 'dataArr' || objV.t === 'stateArr') {
     if (prop === 'length') return cnum(objV.dims[0]);
     this.fail("property '" + prop + "' of an array is not supported");
@@ -487,6 +490,15 @@ Translator.prototype.member = function (objV, prop) {
 };
 
 Translator.prototype.index = function (objV, idxV) {
+  if (objV.t === 'localArr') {
+    if (idxV.cst !== undefined && Number.isInteger(idxV.cst)) {
+      if (idxV.cst < 0 || idxV.cst >= objV.elems.length) this.fail('constant index ' + idxV.cst + ' is outside an array of length ' + objV.elems.length);
+      return objV.name ? num(objV.name + '[' + idxV.cst + ']', false) : objV.elems[idxV.cst];
+    }
+    // run-time index into a small local array: out of range reads give NaN, as `undefined` does in arithmetic
+    const nm = this.materialize(objV), ix = this.temp_int(this.asI(idxV));
+    return num('((unsigned)' + ix + ' < ' + objV.elems.length + 'u ? ' + nm + '[' + ix + '] : __builtin_nan(""))', false);
+  }
   if (objV.t !== 'dataArr' && objV.t !== 'stateArr') this.fail('indexing a ' + this.describe(objV));
   const dims = objV.dims, inner = dims.slice(1).reduce((a, b) => a * b, 1);
   let off;
@@ -525,10 +537,15 @@ Translator.prototype.expr = function (e) {
     case 'Member': return this.member(this.expr(e.obj), e.prop);
     case 'Index': return this.index(this.expr(e.obj), this.expr(e.idx));
     case 'ArrayLit': {
-      const vals = e.elems.map((x) => { const v = this.expr(x); if (v.cst === undefined || v.t !== 'num') this.fail('array literals may only hold constants'); return v.cst; });
-      const key = '#lit' + JSON.stringify(vals);
-      const id = this.registerArray(key, vals);
-      return { t: 'dataArr', id, off: '0', dims: [vals.length] };
+      const vs = e.elems.map((x) => this.expr(x));
+      if (vs.every((v) => v.t === 'num' && v.cst !== undefined)) {      // constants: a (chain-shared) data array
+        const vals = vs.map((v) => v.cst);
+        const id = this.registerArray('#lit' + JSON.stringify(vals), vals);
+        return { t: 'dataArr', id, off: '0', dims: [vals.length] };
+      }
+      for (const v of vs) if (v.t !== 'num' && v.t !== 'bool') this.fail('array literals may only hold numbers (nested arrays of expressions are not supported)');
+      if (vs.length > 64) this.fail('array literal with more than 64 elements');
+      return { t: 'localArr', elems: vs.map((v) => num(this.asD(v), false)) };
     }
     case 'Unary': {
       const a = this.expr(e.arg);
@@ -628,9 +645,10 @@ Translator.prototype.call = function (e) {
       return f.name === 'abs' ? num('(' + args[0].code + ' < 0 ? -(' + args[0].code + ') : ' + args[0].code + ')', true) : args[0];
     return num(M[0] + '(' + this.asD(args[0]) + ')', false);
   }
+  if (f.ns === 'ld' && (f.name === 'dirichlet' || f.name === 'cat' || f.name === 'bivarnorm')) return this.arrayDensity(f.name, args);
   if (f.ns === 'ld') {
     const L = LD_FUNS[f.name];
-    if (!L) this.fail('ld.' + f.name + ' is not supported on the GPU path (array-valued densities: dirichlet, cat, bivarnorm are not translated)');
+    if (!L) this.fail('ld.' + f.name + ' does not exist in distributions.js');
     if (args.length !== L[1]) this.fail('ld.' + f.name + ' takes ' + L[1] + ' arguments, got ' + args.length);
     nums();
     const a = args.map((x) => this.asD(x));
@@ -679,6 +697,33 @@ Translator.prototype.auxArray = function (fname, ids, f) {
   return this.registerArray(key, vals);
 };
 
+Translator.prototype.temp_int = function (code) {
+  if (/^[\w]+$/.test(code)) return code;
+  const name = 'ti' + (this.tmp++);
+  this.pending.push('const int ' + name + ' = ' + code + ';');
+  return name;
+};
+
+// an array of expressions as a C array (needed when it is indexed with a run-time value)
+Translator.prototype.materialize = function (arr) {
+  if (arr.name) return arr.name;
+  const name = 'la' + (this.tmp++);
+  this.pending.push('const double ' + name + '[' + arr.elems.length + '] = {' + arr.elems.map((v) => v.code).join(', ') + '};');
+  return name;
+};
+
+// the elements of a one-dimensional array value (any kind) as numbers
+Translator.prototype.elementsOf = function (v, what) {
+  if (v.t === 'localArr') return v.name ? v.elems.map((_, i) => num(v.name + '[' + i + ']', false)) : v.elems;
+  if ((v.t === 'dataArr' || v.t === 'stateArr') && v.dims.length === 1) {
+    if (v.dims[0] > 64) this.fail(what + ': arrays longer than 64 are not supported here');
+    const out = [];
+    for (let i = 0; i < v.dims[0]; i++) out.push(this.index(v, cnum(i)));
+    return out;
+  }
+  this.fail(what + ' needs a one-dimensional array, got a ' + this.describe(v));
+};
+
 // a named temporary for a value that is used twice (keeps the evaluation single, as in JS)
 Translator.prototype.temp = function (code) {
   if (/^[\w.]+$/.test(code) || /^S\(\d+\)$/.test(code)) return code;
@@ -704,6 +749,44 @@ Translator.prototype.hoist = function (argAst, type, ctor, code, suffix) {
   const name = 'k' + (this.tmp++);
   this.loops[j].preamble.push('const ' + type + ' ' + name + ' = ' + ctor + '(' + code + ');' + (suffix || '').replace('@', name));
   return name;
+};
+
+// ld.dirichlet / ld.cat / ld.bivarnorm (distributions.js:125-134, 203-214, 232-238): the loops of the reference are
+// unrolled over the (translation-time) lengths, every operation in the reference's order.
+Translator.prototype.arrayDensity = function (name, args) {
+  if (this.loops.length) this.heavyLoop = true;
+  const T = (code) => this.temp(code);
+  if (name === 'dirichlet') {
+    if (args.length !== 2) this.fail('ld.dirichlet takes (x, alpha)');
+    const x = this.elementsOf(args[0], 'ld.dirichlet'), al = this.elementsOf(args[1], 'ld.dirichlet');
+    if (x.length < al.length) this.fail('ld.dirichlet: x is shorter than alpha');
+    let sa = '0.0', sl = '0.0', sx = '0.0';
+    for (let i = 0; i < al.length; i++) {
+      const a = T(this.asD(al[i]));
+      sa = T('(' + sa + ' + ' + a + ')');
+      sl = T('(' + sl + ' + lgamma_js(' + a + '))');
+      sx = T('(' + sx + ' + ((' + a + ' - 1.0) * log_v8(' + this.asD(x[i]) + ')))');
+    }
+    return num('((lgamma_js(' + sa + ') - ' + sl + ') + ' + sx + ')', false);
+  }
+  if (name === 'cat') {
+    if (args.length !== 2) this.fail('ld.cat takes (x, probs)');
+    if (args[0].t !== 'num') this.fail('ld.cat: x must be a number');
+    const n = args[1].t === 'localArr' ? args[1].elems.length : ((args[1].dims || [])[0]);
+    if (n === undefined || (args[1].dims && args[1].dims.length !== 1)) this.fail('ld.cat: probs must be a one-dimensional array');
+    const x = T(this.asD(args[0]));
+    const pr = this.index(args[1], num('(int)(' + x + ') - 1', true));   // probs[x - 1]; only evaluated inside the range below
+    return num('((' + x + ' < 1.0 || ' + x + ' > ' + n + '.0) ? -kInf : log_v8(' + this.asD(pr) + '))', false);
+  }
+  // bivarnorm(x, mean, sd, corr)
+  if (args.length !== 4) this.fail('ld.bivarnorm takes (x, mean, sd, corr)');
+  const x = this.elementsOf(args[0], 'ld.bivarnorm'), m = this.elementsOf(args[1], 'ld.bivarnorm'), sd = this.elementsOf(args[2], 'ld.bivarnorm');
+  if (x.length < 2 || m.length < 2 || sd.length < 2 || args[3].t !== 'num') this.fail('ld.bivarnorm takes two-element x, mean, sd and a number corr');
+  const c = T(this.asD(args[3])), s0 = T(this.asD(sd[0])), s1 = T(this.asD(sd[1]));
+  const d0 = T('(' + this.asD(x[0]) + ' - ' + this.asD(m[0]) + ')'), d1 = T('(' + this.asD(x[1]) + ' - ' + this.asD(m[1]) + ')');
+  const z = T('((((' + d0 + ' * ' + d0 + ') / (' + s0 + ' * ' + s0 + ')) + ((' + d1 + ' * ' + d1 + ') / (' + s1 + ' * ' + s1 + '))) - ((((2.0 * ' + c + ') * ' + d0 + ') * ' + d1 + ') / (' + s0 + ' * ' + s1 + ')))');
+  const nf = T('(-((((log_v8(2.0) + log_v8(kPi)) + log_v8(' + s0 + ')) + log_v8(' + s1 + ')) + (0.5 * log_v8(1.0 - (' + c + ' * ' + c + ')))))');
+  return num('(' + nf + ' - (' + z + ' / (2.0 * (1.0 - (' + c + ' * ' + c + ')))))', false);
 };
 
 // ---- helper functions (options.helpers) --------------------------------------------------------
@@ -739,6 +822,18 @@ Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) 
     const name = target.name;
     if (name === this.stateName || name === this.dataName) this.fail('assigning to ' + name);
     const v = this.expr(valueAst);
+    if (v.t === 'localArr' && op === '=') {
+      // a variable holding an array of numbers: C array declared at the top, filled here (elements may be reassigned later)
+      if (Object.prototype.hasOwnProperty.call(this.localTypes, name)) this.fail(name + ' holds a number elsewhere and an array here');
+      const prev = this.aliases[name];
+      if (prev && !(prev.t === 'localArr' && prev.elems.length === v.elems.length)) this.fail(name + ' is re-assigned an array of a different length');
+      const cname = 'va_' + name;
+      this.localArrays[cname] = v.elems.length;
+      this.flush(out, indent);
+      v.elems.forEach((el, i) => out.push(indent + cname + '[' + i + '] = ' + el.code + ';'));
+      this.aliases[name] = { t: 'localArr', elems: v.elems, name: cname };
+      return;
+    }
     if (v.t !== 'num' && v.t !== 'bool') {
       if (op !== '=') this.fail("'" + op + "' with a " + this.describe(v));
       if (this.loops.length) this.fail('aliasing an array or object (' + name + ') inside a loop');
@@ -781,6 +876,16 @@ Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) 
     this.setLocal(name, res);
     this.flush(out, indent);
     out.push(indent + 'v_' + name + ' = ' + (this.localTypes[name] === 'int' ? this.asI(res) : this.asD(res)) + ';');
+    return;
+  }
+  if (target.k === 'Index' && target.obj.k === 'Id' && this.aliases[target.obj.name] && this.aliases[target.obj.name].t === 'localArr' && this.aliases[target.obj.name].name) {
+    const arr = this.aliases[target.obj.name];
+    const idx = this.expr(target.idx), v = this.expr(valueAst);
+    if (v.t !== 'num' && v.t !== 'bool') this.fail('array elements must be numbers');
+    if (idx.cst !== undefined && !(Number.isInteger(idx.cst) && idx.cst >= 0 && idx.cst < arr.elems.length)) this.fail('index ' + idx.cst + ' is outside ' + target.obj.name);
+    this.flush(out, indent);
+    const lhs = arr.name + '[' + this.asI(idx) + ']';
+    out.push(indent + lhs + ' = ' + (op === '=' ? this.asD(v) : '(' + lhs + ' ' + op[0] + ' ' + this.asD(v) + ')') + ';');
     return;
   }
   if (target.k === 'Member' && target.obj.k === 'Id' && target.obj.name === this.stateName) {
@@ -1048,6 +1153,7 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
     for (const p of numericParams) this.localTypes[p] = 'double';
     for (const nm of Object.keys(keepTypes)) if (keepTypes[nm] === 'double') this.forcedDouble.add(nm);
     this.aliases = {};
+    this.localArrays = {};
     this.declaredOnly = new Set();
     this.derivedFinal = this.derived.slice();
     this.derived = [];
@@ -1070,11 +1176,26 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
     decl.push('    ' + (this.localTypes[nm] === 'int' ? 'int' : 'double') + ' v_' + nm + ' = 0;');
   }
   for (const nm of this.derived) decl.push('    double dq_' + nm + ' = 0;');
+  for (const nm of Object.keys(this.localArrays)) decl.push('    double ' + nm + '[' + this.localArrays[nm] + '] = {0};');
   return decl.concat(renderNorm(lines, 'inv'));
 };
 
 Translator.prototype.run = function () {
-  const body = this.functionBody([], true);
+  let body = this.functionBody([], true);
+  // drop data arrays the generated code never reads (constants folded away), renumber the rest
+  {
+    const used = new Set();
+    for (const ln of body.concat(this.helperSources)) { const re = /\bA(\d+)\[/g; let m; while ((m = re.exec(ln))) used.add(Number(m[1])); }
+    const remap = new Map();
+    const kept = [];
+    this.arrays.forEach((a, j) => { if (used.has(j)) { remap.set(j, kept.length); kept.push(a); } });
+    if (kept.length !== this.arrays.length) {
+      const ren = (ln) => ln.replace(/\bA(\d+)\[/g, (all, j) => 'A' + remap.get(Number(j)) + '[');
+      body = body.map(ren);
+      this.helperSources = this.helperSources.map(ren);
+      this.arrays = kept;
+    }
+  }
   // did any loop actually get split?
   const parallel = this.split && this.nSplit > 0;
   // ---- LDS staging plan: whole arrays, in order of first use, while they fit the budget

@@ -277,6 +277,29 @@ const BENCH = {
   bench_glm: { params: CASES.pois_glm_closure.params, data: () => synth.glm(50000, 20260925), log_post: CASES.pois_glm_closure.log_post },
 };
 
+// ---- array-valued densities (distributions.js:125-134, 203-214, 232-238), the ** operator, local arrays
+CASES.mixture_arrays = {
+  params: () => ({ w: { type: 'real', dim: [3], lower: 0, upper: 1, init: 0.3 }, z: { type: 'int', lower: 1, upper: 3, init: 2 },
+    m: { type: 'real', dim: [2], init: 0.5 }, rho: { type: 'real', lower: -0.95, upper: 0.95, init: 0.1 } }),
+  data: (seed) => { const r = lcg(seed), pts = []; for (let i = 0; i < 30; i++) { const a = (r() + r() + r() - 1.5) * 2; pts.push([a + 1, 0.6 * a + (r() - 0.5) * 2 - 1]); } return { pts, alpha: [2, 3, 4], sds: [1.5, 2] }; },
+  log_post: function(s, d) {
+    var lp = 0;
+    var tot = s.w[0] + s.w[1] + s.w[2];
+    var probs = [s.w[0] / tot, s.w[1] / tot, s.w[2] / tot];
+    lp += ld.dirichlet(probs, d.alpha);
+    lp += ld.cat(s.z, probs);
+    lp += ld.cat(2, [0.2, 0.5, 0.3]) + ld.dirichlet([0.2, 0.3, 0.5], [1, 2, 3]);
+    var sd = [d.sds[0] * (1 + 0.1 * s.z), d.sds[1]];
+    sd[1] = sd[1] * 2 ** 0.5;
+    for (var i = 0; i < d.pts.length; i++) {
+      lp += ld.bivarnorm(d.pts[i], s.m, sd, s.rho);
+    }
+    lp += ld.bivarnorm([s.m[0], s.m[1]], [0, 0], [10, 10], 0) - probs[s.z - 1] ** 2;
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 60 }], chains: [0, 1],
+};
+
 function build(name, seed) {
   const c = CASES[name] || BENCH[name];
   if (!c) throw new Error('unknown user model ' + name);
