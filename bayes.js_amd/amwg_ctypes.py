@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libamwg.so")
+LIB_PATH = os.environ.get("AMWG_LIB") or os.path.join(HERE, "csrc", "libamwg.so")   # AMWG_LIB: development builds only
 MODEL_ID = {"normal": 1, "beta_bern": 2, "hier_normal": 3, "pois_glm": 4}
 
 
