@@ -52,6 +52,21 @@ def normal_spec():
             "comp_opts": [dict(opt), dict(opt)], "G": 0, "K": 0}
 
 
+# The other BASELINE.json configs (parity-test cases; measurable with --workload for DESIGN.md's table, never the default):
+#   name: (family, n_obs, chains per GPU, algorithmic bytes per update, fp64 lane-ops per observation, label)
+OTHER_WORKLOADS = {
+    "cfg3": ("beta_bern", 100_000, 262_144, 100_000 * 1 + 8 * 1 + 8, 1, "BASELINE.json configs[2]: Beta-Bernoulli, 1e5 binary obs, 262144 chains per GPU"),
+    "cfg4": ("hier_normal", 10_000, 2_048, 10_000 * 9 + 8 * 34 + 8, 8, "BASELINE.json configs[3]: hierarchical Normal (34 components), 1e4 obs, 2048 chains per GPU (16384 over 8)"),
+    "cfg5": ("pois_glm", 50_000, 8_192, 50_000 * (7 * 8 + 8 + 8) + 8 * 9 + 8, None, "BASELINE.json configs[4]: Poisson GLM + int change point, 5e4 obs, 8192 chains per GPU (65536 over 8)"),
+}
+
+
+def other_spec(name, exp):
+    import model_spec
+    fam, n_obs = OTHER_WORKLOADS[name][0], OTHER_WORKLOADS[name][1]
+    return model_spec.build_spec(fam, model_spec.make_data(fam, n_obs, DATA_SEED, G=32, exp=exp))
+
+
 def measured_traffic(chains, steps_per_launch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_summary.json, written by
     tools/profile.sh + tools/summarize_profile.py for this same command); None if no matching profile."""
@@ -70,17 +85,21 @@ def cpu_baseline(spec, budget_s=12.0):
     """The oracle (a C port of the reference algorithm), single thread, same data, 1 chain."""
     import oracle_lib
     ch = oracle_lib.OracleChain(spec, SEED, 0, lanes=1)
-    ch.burn(1000)                       # adapted, steady state
     t0 = time.perf_counter()
-    ch.burn(500)
-    rate = 500 / (time.perf_counter() - t0)
-    n = max(500, int(rate * budget_s))
+    ch.burn(5)
+    rate = 5 / (time.perf_counter() - t0)
+    warm = int(min(1000, max(5, rate * 3.0)))   # adapted, steady state (1000 steps where a step is cheap enough)
+    ch.burn(warm)
+    t0 = time.perf_counter()
+    ch.burn(max(5, min(500, int(rate))))
+    rate = max(5, min(500, int(rate))) / (time.perf_counter() - t0)
+    n = max(5, int(rate * budget_s))
     t0 = time.perf_counter()
     ch.burn(n)
     dt = time.perf_counter() - t0
     return {"value": n * spec["P"] / dt, "unit": "param-updates/s", "cores": 1, "kind": "port",
-            "sample": "oracle/amwg_oracle.c, same model+data (N=%d), 1 chain, %d steps after 1000 burn-in (%.1f s); "
-                      "the unmodified JS reference measured 3.3e4-3.45e4 on the build container (BASELINE.md §2)" % (N_OBS, n, dt)}
+            "sample": "oracle/amwg_oracle.c, same model+data (N=%d), 1 chain, %d steps after >= %d burn-in (%.1f s); "
+                      "the unmodified JS reference measured 3.3e4-3.45e4 on the build container for cfg2 (BASELINE.md §2)" % (spec["n_obs"], n, warm, dt)}
 
 
 def main():
@@ -96,6 +115,8 @@ def main():
                     help="steps fused into one kernel launch; warm-up and timed steps use the same launch size so the "
                          "per-launch time bench.py reports is comparable with rocprofv3's per-kernel average")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="cfg2 (default) is the bench line; the others measure the remaining BASELINE.json configs")
     args = ap.parse_args()
 
     import torch
@@ -126,7 +147,15 @@ def main():
     coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     from shard import chain_shard, gather_draws
-    spec = normal_spec()
+    b_alg, ops_per_obs, n_obs = B_ALG_PER_UPDATE, 8, N_OBS
+    label = "BASELINE.json configs[1]: Normal(mu,sigma) AMWG, 1e4 synthetic obs, 65536 chains per GPU"
+    if args.workload == "cfg2":
+        spec = normal_spec()
+    else:
+        spec = other_spec(args.workload, A.lib().amwg_exp)
+        _, n_obs, default_chains, b_alg, ops_per_obs, label = OTHER_WORKLOADS[args.workload]
+        if args.chains_per_gpu == CHAINS_PER_GPU:
+            args.chains_per_gpu = default_chains
     chains = args.chains_per_gpu
     offset, _ = chain_shard(rank, world, chains * world)
     s = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=dev_index,
@@ -166,17 +195,18 @@ def main():
         launches = max(1, li["n_launches"])
         launch_s = kernel_ms * 1e-3 / launches
         updates_per_launch = chains * (K / launches) * P
-        achieved = updates_per_launch * B_ALG_PER_UPDATE / launch_s / 1e9
+        achieved = updates_per_launch * b_alg / launch_s / 1e9
         mean, sd = s.moments()
         measured_peak = A.fp64_peak(dev_index)      # register-only fma kernel: what the chip sustains under fp64 load
         x = spec["data"]["x"]
-        traffic, traffic_src = measured_traffic(chains, args.steps_per_launch)
+        traffic, traffic_src = measured_traffic(chains, args.steps_per_launch) if args.workload == "cfg2" else (None, None)
+        kname = {"normal": "NormalModel", "beta_bern": "BetaBernModel", "hier_normal": "HierNormalModel", "pois_glm": "PoisGlmModel"}[spec["model"]]
         out = {
             "metric": "posterior draws/sec (= param-updates/sec)", "value": value, "unit": "param-updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt * 1e3 / K, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: Normal(mu,sigma) AMWG, 1e4 synthetic obs, 65536 chains per GPU",
-                       "n_obs": N_OBS, "chains_per_gpu": chains, "chains_total": total_chains, "components": P,
+            "config": {"workload": label,
+                       "n_obs": n_obs, "chains_per_gpu": chains, "chains_total": total_chains, "components": P,
                        "draws_recorded_per_chain": rows, "thin": thin, "lanes_per_chain": li["lanes_per_chain"],
                        "block_threads": li["block_threads"], "grid_blocks": li["grid_blocks"], "lds_bytes": li["lds_bytes"],
                        "steps_per_launch": args.steps_per_launch, "launches_timed": launches,
@@ -184,20 +214,21 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 --pmc passes",
-                         "algorithmic_bytes_per_launch": updates_per_launch * B_ALG_PER_UPDATE,
-                         "kernel": "amwg_step_kernel<NormalModel,%d>" % li["lanes_per_chain"],
-                         "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_update": B_ALG_PER_UPDATE,
+                         "algorithmic_bytes_per_launch": updates_per_launch * b_alg,
+                         "kernel": "amwg_step_kernel<%s,%d>" % (kname, li["lanes_per_chain"]),
+                         "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_update": b_alg,
                          "note": "effective bandwidth: the 80 KB data vector is staged once per launch into LDS and "
                                  "re-read from LDS, so HBM traffic is ~0 and frac may exceed 1; the binding limit is fp64 VALU "
                                  "(see fp64_valu)",
-                         "fp64_valu": {"lane_ops_per_obs": 8, "achieved_lane_ops_per_s": updates_per_launch * N_OBS * 8 / launch_s,
+                         "fp64_valu": None if ops_per_obs is None else {
+                                       "lane_ops_per_obs": ops_per_obs, "achieved_lane_ops_per_s": updates_per_launch * n_obs * ops_per_obs / launch_s,
                                        "peak_lane_ops_per_s": FP64_VALU_PEAK,
-                                       "frac": updates_per_launch * N_OBS * 8 / launch_s / FP64_VALU_PEAK,
+                                       "frac": updates_per_launch * n_obs * ops_per_obs / launch_s / FP64_VALU_PEAK,
                                        "measured_peak_lane_ops_per_s": measured_peak,
-                                       "frac_of_measured_peak": updates_per_launch * N_OBS * 8 / launch_s / measured_peak,
+                                       "frac_of_measured_peak": updates_per_launch * n_obs * ops_per_obs / launch_s / measured_peak,
                                        "measured_peak_note": "amwg_fp64_peak: independent v_fma_f64 chains, no memory traffic, same run"}},
             "kernel_only_value": chains * K * P / (kernel_ms * 1e-3),
-            "posterior": {"mean": mean.tolist(), "sd": sd.tolist(), "data_mean": float(np.mean(x)), "data_sd": float(np.std(x, ddof=1)),
+            "posterior": {"mean": mean.tolist()[:8], "sd": sd.tolist()[:8], "data_mean": float(np.mean(x)), "data_sd": float(np.std(x, ddof=1)),
                           "note": "moments over all recorded draws of rank 0 (after %d warm-up steps)" % W},
         }
         if world == 1 and not args.no_cpu_baseline:
