@@ -76,6 +76,22 @@ if (!only.length) {
   const one = solo.sample(100);
   for (let t = 0; t < 100; t++) { assert.strictEqual(one.mu[t], smp.mu[t * 200 + 123]); assert.strictEqual(one.var[t], smp.var[t * 200 + 123]); }
   many.close(); solo.close();
+  // three shards on one GPU == one shard (chains are keyed by their global id), binary + int + real parameters
+  const cm = um.build('complex_model');
+  const mk = (extra) => new mcmc.AmwgSampler(cm.params, cm.log_post, cm.data, Object.assign({ seed: 9, chains: 50, lanes_per_chain: 2 }, extra));
+  const a = mk({}), b = mk({ devices: [0, 0, 0] });
+  a.burn(80); b.burn(80);
+  const sa = a.sample(20), sb = b.sample(20);
+  for (const nm of ['p1', 'n1', 'm']) assert.deepStrictEqual(Array.from(sa[nm]), Array.from(sb[nm]), nm);
+  assert.deepStrictEqual(Array.from(a.info().steppers.m.accepts), Array.from(b.info().steppers.m.accepts));
+  // convergence diagnostics and per-chain starts through the front-end
+  const conv = a.convergence();
+  assert.ok(conv.p1.rhat[0] > 0.9 && isFinite(conv.n1.rhat[0]) && conv.p1.ess[0] > 10 && conv.m.ess[0] > 0, JSON.stringify(conv));   // 100 steps of a bimodal model: not converged, only sanity
+  a.init_chains((c) => ({ p1: 0.1 + 0.8 * (c / 50), n1: 1 + (c % 5), m: c % 2 }));
+  const st = a.state;
+  assert.strictEqual(st.n1[7], 3); assert.strictEqual(st.m[7], 1); assert.ok(Math.abs(st.p1[25] - 0.5) < 1e-12);
+  a.burn(5);
+  a.close(); b.close();
   const mb = um.build('multi_bern');
   assert.throws(() => new mcmc.AmwgSampler(mb.params, mb.log_post, mb.data, { seed: 1, lanes_per_chain: 4 }), /lanes|geometry/);
 }
