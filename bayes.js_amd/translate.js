@@ -408,7 +408,10 @@ Translator.prototype.registerArray = function (key, value) {
 };
 
 // ---- symbolic values -----------------------------------------------------------------------------
-const num = (code, int, cst) => ({ t: 'num', code, int: !!int, cst });
+// An int-typed value (loop variables, integer constants, integer-typed data elements and + - * of those) keeps two
+// spellings: `code` in 32-bit int arithmetic, used only for array indices, and `dcode`, the same expression in double
+// arithmetic, used wherever the value is a JavaScript number (so nothing can overflow where JS would not).
+const num = (code, int, cst, dcode) => ({ t: 'num', code, int: !!int, cst, dcode: int ? (dcode || '(double)(' + code + ')') : undefined });
 const cnum = (v) => {
   const isInt = Number.isInteger(v) && Math.abs(v) < 2147483648 && !(v === 0 && 1 / v < 0);
   return { t: 'num', code: isInt ? String(v) : hexFloat(v), int: isInt, cst: v };
@@ -416,7 +419,7 @@ const cnum = (v) => {
 Translator.prototype.asD = function (v) {
   if (v.t === 'num') {
     if (v.cst !== undefined) return hexFloat(v.cst);
-    return v.int ? '(double)(' + v.code + ')' : v.code;
+    return v.int ? v.dcode : v.code;
   }
   if (v.t === 'bool') return '((' + v.code + ') ? 1.0 : 0.0)';
   this.fail('a ' + this.describe(v) + ' is used where a number is needed');
@@ -439,7 +442,7 @@ Translator.prototype.lookup = function (name) {
   if (name === this.stateName) return { t: 'stateObj' };
   if (this.dataName && name === this.dataName) return this.dataValue('', this.data);
   if (Object.prototype.hasOwnProperty.call(this.aliases, name)) return this.aliases[name];
-  if (Object.prototype.hasOwnProperty.call(this.localTypes, name)) return num('v_' + name, this.localTypes[name] === 'int');
+  if (Object.prototype.hasOwnProperty.call(this.localTypes, name)) return num('v_' + name, this.localTypes[name] === 'int', undefined, '(double)v_' + name);
   if (name === 'ld') return { t: 'ns', name: 'ld' };
   if (name === 'Math') return { t: 'ns', name: 'Math' };
   if (name === 'Infinity') return cnum(Infinity);
@@ -519,7 +522,7 @@ Translator.prototype.index = function (objV, idxV) {
     // a constant element of a data array is a constant
     if (/^\d+$/.test(sum)) return cnum(this.arrays[objV.id].flat[Number(sum)]);
     const A = this.arrays[objV.id];
-    const v = A.type === 0 ? num('A' + objV.id + '[' + sum + ']', false) : num('(int)A' + objV.id + '[' + sum + ']', true);
+    const v = A.type === 0 ? num('A' + objV.id + '[' + sum + ']', false) : num('(int)A' + objV.id + '[' + sum + ']', true, undefined, '(double)A' + objV.id + '[' + sum + ']');
     v.src = { id: objV.id, off: sum };
     return v;
   }
@@ -553,7 +556,7 @@ Translator.prototype.expr = function (e) {
       if (a.t !== 'num') this.fail("unary '" + e.op + "' on a " + this.describe(a));
       if (e.op === '+') return a;
       if (a.cst !== undefined) return cnum(-a.cst);
-      return a.int ? num('(-(' + a.code + '))', true) : num('(-(' + a.code + '))', false);
+      return a.int ? num('(-(' + a.code + '))', true, undefined, '(-(' + a.dcode + '))') : num('(-(' + a.code + '))', false);
     }
     case 'Binary': {
       const l = this.expr(e.l), r = this.expr(e.r);
@@ -562,7 +565,8 @@ Translator.prototype.expr = function (e) {
         if (l.t !== 'num' || r.t !== 'num') this.fail("comparison '" + e.op + "' between a " + this.describe(l) + ' and a ' + this.describe(r));
         if (l.cst !== undefined && r.cst !== undefined) { const v = CMP[e.op](l.cst, r.cst); return { t: 'bool', code: v ? 'true' : 'false', cst: v }; }
         const op = e.op === '===' ? '==' : (e.op === '!==' ? '!=' : e.op);
-        if (l.int && r.int) return { t: 'bool', code: '(' + l.code + ' ' + op + ' ' + r.code + ')' };
+        // loop counters against integer bounds compare as ints; everything else as JavaScript numbers
+        if (l.int && r.int && (l.cst !== undefined || r.cst !== undefined || (/^v_\w+$/.test(l.code) && /^v_\w+$/.test(r.code)))) return { t: 'bool', code: '(' + l.code + ' ' + op + ' ' + r.code + ')' };
         return { t: 'bool', code: '(' + this.asD(l) + ' ' + op + ' ' + this.asD(r) + ')' };
       }
       if (l.t !== 'num' || r.t !== 'num') {
@@ -572,10 +576,10 @@ Translator.prototype.expr = function (e) {
       if (l.cst !== undefined && r.cst !== undefined) return cnum(ARITH[e.op](l.cst, r.cst));   // folded by V8 itself
       if (e.op === '/') return num('(' + this.asD(l) + ' / ' + this.asD(r) + ')', false);
       if (e.op === '%') {
-        if (l.int && r.int && r.cst !== undefined && r.cst !== 0) return num('(' + l.code + ' % ' + r.code + ')', true);
+        if (l.int && r.int && r.cst !== undefined && r.cst !== 0) return num('(' + l.code + ' % ' + r.code + ')', true, undefined, 'js_mod(' + this.asD(l) + ', ' + this.asD(r) + ')');
         return num('js_mod(' + this.asD(l) + ', ' + this.asD(r) + ')', false);
       }
-      if (l.int && r.int) return num('(' + l.code + ' ' + e.op + ' ' + r.code + ')', true);
+      if (l.int && r.int) return num('(' + l.code + ' ' + e.op + ' ' + r.code + ')', true, undefined, '(' + this.asD(l) + ' ' + e.op + ' ' + this.asD(r) + ')');
       return num('(' + this.asD(l) + ' ' + e.op + ' ' + this.asD(r) + ')', false);
     }
     case 'Logical': {
@@ -591,7 +595,7 @@ Translator.prototype.expr = function (e) {
       if (t.cst !== undefined) return t.cst ? a : b;
       if (a.t === 'bool' && b.t === 'bool') return { t: 'bool', code: '(' + t.code + ' ? ' + a.code + ' : ' + b.code + ')' };
       if (a.t !== 'num' || b.t !== 'num') this.fail('both branches of ?: must be numbers');
-      if (a.int && b.int) return num('(' + t.code + ' ? ' + a.code + ' : ' + b.code + ')', true);
+      if (a.int && b.int) return num('(' + t.code + ' ? ' + a.code + ' : ' + b.code + ')', true, undefined, '(' + t.code + ' ? ' + this.asD(a) + ' : ' + this.asD(b) + ')');
       return num('(' + t.code + ' ? ' + this.asD(a) + ' : ' + this.asD(b) + ')', false);
     }
     case 'Call': return this.call(e);
@@ -642,7 +646,7 @@ Translator.prototype.call = function (e) {
     if (allConst()) return cnum(M[2](args[0].cst));
     if (HEAVY.has(M[0]) && this.loops.length) this.heavyLoop = true;
     if ((f.name === 'floor' || f.name === 'ceil' || f.name === 'round' || f.name === 'trunc' || f.name === 'abs') && args[0].int)
-      return f.name === 'abs' ? num('(' + args[0].code + ' < 0 ? -(' + args[0].code + ') : ' + args[0].code + ')', true) : args[0];
+      return f.name === 'abs' ? num('(' + args[0].code + ' < 0 ? -(' + args[0].code + ') : ' + args[0].code + ')', true, undefined, '__builtin_fabs(' + args[0].dcode + ')') : args[0];
     return num(M[0] + '(' + this.asD(args[0]) + ')', false);
   }
   if (f.ns === 'ld' && (f.name === 'dirichlet' || f.name === 'cat' || f.name === 'bivarnorm')) return this.arrayDensity(f.name, args);
@@ -809,7 +813,8 @@ Translator.prototype.helper = function (name) {
 Translator.prototype.setLocal = function (name, v) {     // records the inferred C++ type of a local
   if (v.t === 'bool') v = num(this.asD(v), false);
   if (v.t !== 'num') return false;
-  if (!Object.prototype.hasOwnProperty.call(this.localTypes, name)) this.localTypes[name] = v.int ? 'int' : 'double';
+  // int only for the counters of canonical for loops (array indices); every other local is a JavaScript number
+  if (!Object.prototype.hasOwnProperty.call(this.localTypes, name)) this.localTypes[name] = (v.int && this.loopCounters.has(name)) ? 'int' : 'double';
   else if (this.localTypes[name] === 'int' && !v.int) { this.localTypes[name] = 'double'; this.retype = true; }
   if (this.forcedDouble.has(name) && this.localTypes[name] === 'int') this.localTypes[name] = 'double';
   return true;
@@ -836,7 +841,7 @@ Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) 
     }
     if (v.t !== 'num' && v.t !== 'bool') {
       if (op !== '=') this.fail("'" + op + "' with a " + this.describe(v));
-      if (this.loops.length) this.fail('aliasing an array or object (' + name + ') inside a loop');
+      if (this.loops.length || this.condDepth) this.fail('aliasing an array or object (' + name + ') inside a loop or an if');
       if (Object.prototype.hasOwnProperty.call(this.localTypes, name)) this.fail(name + ' holds a number elsewhere and an array/object here');
       this.aliases[name] = v;
       return;
@@ -962,8 +967,10 @@ Translator.prototype.stmt = function (s, out, indent, ctx) {
       this.flush(out, indent);
       if (t.cst !== undefined) { if (t.cst) this.stmt(s.cons, out, indent, ctx); else if (s.alt) this.stmt(s.alt, out, indent, ctx); return; }
       out.push(indent + 'if (' + t.code + ') {');
+      this.condDepth = (this.condDepth || 0) + 1;
       this.stmt(s.cons, out, indent + '  ', ctx);
       if (s.alt) { out.push(indent + '} else {'); this.stmt(s.alt, out, indent + '  ', ctx); }
+      this.condDepth--;
       out.push(indent + '}');
       return;
     }
@@ -1145,6 +1152,8 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
     if (x.k === 'VarDecl') x.decls.forEach((d) => { if (d.init) this.assignCount[d.name] = (this.assignCount[d.name] || 0) + 1; });
     if ((x.k === 'Assign' || x.k === 'Update') && x.target.k === 'Id') this.assignCount[x.target.name] = (this.assignCount[x.target.name] || 0) + 1;
   });
+  this.loopCounters = new Set();
+  walk(body, (x) => { if (x.k === 'For') { const c = this.canonicalLoop(x); if (c) this.loopCounters.add(c.name); } });
   this.forcedDouble = new Set();
   let lines;
   for (let round = 0; round < 8; round++) {
@@ -1154,6 +1163,7 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
     for (const nm of Object.keys(keepTypes)) if (keepTypes[nm] === 'double') this.forcedDouble.add(nm);
     this.aliases = {};
     this.localArrays = {};
+    this.condDepth = 0;
     this.declaredOnly = new Set();
     this.derivedFinal = this.derived.slice();
     this.derived = [];

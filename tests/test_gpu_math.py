@@ -69,3 +69,23 @@ def test_device_philox_stream():
     idx = np.arange(n, dtype=np.float64)
     got = A.device_eval(8, np.full(n, 20260925.0), np.full(n, 12345.0), idx)
     assert got.tobytes() == synth.uniforms(20260925, 12345, n).tobytes()
+
+
+def test_device_ld_functions_and_pow_equal_the_reference_goldens():
+    """Every scalar ld.* / helper and Math.pow evaluated ON THE DEVICE against the reference's recorded outputs."""
+    import ctypes as C
+    import os
+    import golden_io
+    L = A.lib()
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "ld_values.bin"), dtype="<f8").reshape(-1, 6)
+    rec = np.ascontiguousarray(a[:, :5])
+    out = np.empty(a.shape[0])
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    assert L.amwg_ld_device(0, a.shape[0], dp(rec), dp(out)) == 0
+    want = a[:, 5]
+    bad = [(r.tolist(), w, g) for r, w, g in zip(rec, want, out) if not ((w != w and g != g) or np.float64(w).tobytes() == np.float64(g).tobytes())]
+    assert not bad, bad[:3]
+    p = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_pow_pairs.bin"), dtype="<f8").reshape(-1, 3)
+    got = A.device_eval(13, p[:, 0], p[:, 1])
+    ok = (got.view(np.uint64) == p[:, 2].view(np.uint64)) | (np.isnan(got) & np.isnan(p[:, 2]))
+    assert ok.all(), p[~ok][:3]

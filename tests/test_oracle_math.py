@@ -73,3 +73,19 @@ def test_js_round_half_up():
     for x, w in [(0.5, 1.0), (-0.5, -0.0), (1.5, 2.0), (-1.5, -1.0), (2.4999, 2.0), (-2.5001, -3.0),
                  (0.49999999999999994, 0.0), (1e300, 1e300), (-7.0, -7.0)]:
         assert L.orc_js_round(x) == w
+
+
+def _same(a, b):
+    return (a != a and b != b) or np.float64(a).tobytes() == np.float64(b).tobytes()
+
+
+def test_every_ld_function_and_pow_pinned_against_the_reference():
+    """oracle/amwg_oracle.c orc_ld (all 22 scalar densities/helpers of distributions.js) against 13 200 outputs of the
+    unmodified reference; oracle_math.h om_pow against 60 000 outputs of Node's Math.pow (oracle/gen_ld_golden.js)."""
+    L = oracle_lib.lib()
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "ld_values.bin"), dtype="<f8").reshape(-1, 6)
+    assert a.shape[0] == 13200
+    for r in a:
+        assert _same(L.orc_ld(int(r[0]), r[1], r[2], r[3], r[4]), r[5]), r.tolist()
+    p = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_pow_pairs.bin"), dtype="<f8").reshape(-1, 3)
+    assert sum(not _same(L.orc_pow(x, y), w) for x, y, w in p) == 0
