@@ -141,7 +141,7 @@ assert.throws(() => new mcmc.AmwgSampler({ mu: { type: 'complex', init: 1 }, sig
   const tr = mcmc.translate(readme_normal, mcmc.complete_params(params, mcmc.param_init_fixed), data10, {});
   assert.strictEqual(tr.parallel, 1);
   assert.strictEqual(tr.lds_bytes, 16);            // ten integer heights: stored as u8
-  assert.ok(/norm_inv\(S\(1\)\)/.test(tr.source) && /ld_norm_fast\(\(double\)\(\(int\)A0\[v_i\]\), S\(0\), k0, rlo_, rhi_\)/.test(tr.source) && /ld_norm_slow/.test(tr.source));
+  assert.ok(/norm_inv\(S\(1\)\)/.test(tr.source) && /ld_norm_fast\(\(double\)A0\[v_i\], S\(0\), k0, rlo_, rhi_\)/.test(tr.source) && /ld_norm_slow/.test(tr.source));
   // every host-side ld.* equals the reference's value on the committed argument sets (tests/golden/ld_values.bin)
   const b = fs.readFileSync(path.join(__dirname, '..', 'golden', 'ld_values.bin'));
   const fnames = ['norm', 'unif', 'beta', 'bern', 'pois', 'cauchy', 'laplace', 'gamma', 'invgamma', 'lnorm', 'pareto', 't', 'weibull', 'logis', 'exp', 'binom', 'nbinom', 'hyper', 'lgamma', 'lfactorial', 'lchoose', 'lbeta'];
