@@ -374,4 +374,20 @@ AmwgSampler.prototype.init_chains = function (f) {
 AmwgSampler.prototype.diagnostics = function () { const N = native(); return this._each((sh) => N.diag(sh.handle, this.param_names.length)); };
 AmwgSampler.prototype.close = function () { const N = native(); this._each((sh) => N.destroy(sh.handle)); this._shards = []; };
 
-module.exports = { AmwgSampler, complete_params, param_init_fixed, componentOptions, models, ld, native, translate: translator.translate };
+// Host-side random helpers the reference module also exports (mcmc.js:31-54, 1104-1106).  They draw from Math.random,
+// like the reference's; the sampler itself never calls them (its streams are Philox, on the device).
+function runif(min, max) { return Math.random() * (max - min) + min; }
+function runif_discrete(min, max) { return Math.floor(Math.random() * (max - min + 1)) + min; }
+function rnorm(mean, sd) {      // Leva's ratio-of-uniforms, the same constants as csrc/amwg_kernel.h rnorm_js
+  let u, v, x, y, q;
+  do {
+    u = Math.random();
+    v = 1.7156 * (Math.random() - 0.5);
+    x = u - 0.449871;
+    y = Math.abs(v) + 0.386595;
+    q = x * x + y * (0.19600 * y - 0.25472 * x);
+  } while (q > 0.27597 && (q > 0.27846 || v * v > -4 * Math.log(u) * u * u));
+  return (v / u) * sd + mean;
+}
+
+module.exports = { runif, runif_discrete, rnorm, AmwgSampler, complete_params, param_init_fixed, componentOptions, models, ld, native, translate: translator.translate };

@@ -1015,25 +1015,36 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
     this.loops.push(L);
     const body = s.body.k === 'Block' ? s.body.body : [s.body];
     const bctx = { inLoop: true, split: split || ctx.split };
-    // single `acc += term` body of a lane-split loop: U independent terms in flight, added in order
-    const single = split && isInt && boundV.int && body.length === 1 && body[0].k === 'ExprStmt' && body[0].expr.k === 'Assign' &&
-                   body[0].expr.op === '+=' && body[0].expr.target.k === 'Id' && body[0].expr.target.name === this.acc;
+    // body of a lane-split loop that ends in `acc += term` (and writes acc nowhere else): U iterations are evaluated
+    // independently (their temporaries are private, proved by splittable()), then the U terms are added in order
+    const lastSt = body[body.length - 1];
+    const endsInAcc = lastSt && lastSt.k === 'ExprStmt' && lastSt.expr.k === 'Assign' && lastSt.expr.op === '+=' &&
+                      lastSt.expr.target.k === 'Id' && lastSt.expr.target.name === this.acc;
+    let accElsewhere = false;
+    for (const st of body.slice(0, -1)) walk(st, (x) => { if ((x.k === 'Assign' || x.k === 'Update') && x.target.k === 'Id' && x.target.name === this.acc) accElsewhere = true; });
+    const single = split && isInt && boundV.int && endsInAcc && !accElsewhere && !containsKind(s.body, 'Return');
     if (single) {
-      const term = this.expr(body[0].expr.value);
+      const pre = [];
+      const heavyBefore = this.heavyLoop;
+      for (const st of body.slice(0, -1)) this.stmt(st, pre, '', bctx);
+      const term = this.expr(lastSt.expr.value);
       const pend = this.pending; this.pending = [];
       this.loops.pop();
-      const U = this.opts.unroll || 8;
+      const simple = body.length === 1;
+      // plain arithmetic bodies keep 8 terms in flight; bodies with exp/log/ld.* calls 4 (register pressure)
+      const U = this.opts.unroll || ((this.heavyLoop && !simple) || (this.heavyLoop && !heavyBefore && pend.length > 4) ? 4 : 8);
       const acc = 'v_' + this.acc, iv = 'v_' + canon.name;
+      const bodyText = pre.map((ln) => ln.trim()).concat(pend).join(' ');
       const loop = [];
       loop.push('  int it_ = 0;');
       loop.push('  for (; it_ + ' + U + ' <= n_; it_ += ' + U + ') {');
       loop.push('    double tb_[' + U + '];');
       loop.push('#pragma unroll');
-      loop.push('    for (int u_ = 0; u_ < ' + U + '; ++u_) { const int ' + iv + ' = i0_ + (it_ + u_) * G; ' + pend.join(' ') + ' tb_[u_] = ' + this.asD(term) + '; }');
+      loop.push('    for (int u_ = 0; u_ < ' + U + '; ++u_) { const int ' + iv + ' = i0_ + (it_ + u_) * G; ' + bodyText + ' tb_[u_] = ' + this.asD(term) + '; }');
       loop.push('#pragma unroll');
       loop.push('    for (int u_ = 0; u_ < ' + U + '; ++u_) ' + acc + ' += tb_[u_];');
       loop.push('  }');
-      loop.push('  for (; it_ < n_; ++it_) { const int ' + iv + ' = i0_ + it_ * G; ' + pend.join(' ') + ' ' + acc + ' += ' + this.asD(term) + '; }');
+      loop.push('  for (; it_ < n_; ++it_) { const int ' + iv + ' = i0_ + it_ * G; ' + bodyText + ' ' + acc + ' += ' + this.asD(term) + '; }');
       const head = ['  const int i0_ = ' + this.asI(startV) + ' + sub, n_ = (' + boundV.code + (canon.le ? ' + 1' : '') + ' - i0_ + G - 1) / G;'];
       this.emitSplit(out, indent, L.preamble, head, loop);
       return;

@@ -160,4 +160,14 @@ assert.ok(/gfx950/.test(nat.version()));
 assert.strictEqual(nat.mathExp(1), Math.exp(1));
 assert.strictEqual(nat.mathLog(0.3), Math.log(0.3));
 if (!fs.existsSync('/dev/kfd')) assert.throws(() => new mcmc.AmwgSampler(params, readme_normal, data10, { seed: 1 }), (e) => /no HIP device/.test(e.message));
+// host-side helpers exported like the reference's (mcmc.js:1104-1106): same values under the same Math.random stream
+if (haveRef) {
+  const { stream } = require('../../oracle/philox.js');
+  const saved = Math.random;
+  try {
+    Math.random = stream(5, 0); const a = [mcmc.runif(2, 5), mcmc.runif_discrete(1, 6), mcmc.rnorm(3, 2), mcmc.rnorm(0, 1)];
+    Math.random = stream(5, 0); const b = [ref.runif(2, 5), ref.runif_discrete(1, 6), ref.rnorm(3, 2), ref.rnorm(0, 1)];
+    assert.deepStrictEqual(a, b);
+  } finally { Math.random = saved; }
+}
 console.log('frontend ok' + (haveRef ? ' (also checked against the live reference)' : ''));
