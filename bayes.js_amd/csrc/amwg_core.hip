@@ -406,10 +406,10 @@ static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int
     HIPB(hipMemcpy(ch.state, tmp.data(), PC * 8, hipMemcpyHostToDevice));
     for (int p = 0; p < P; ++p) for (size_t c = 0; c < C; ++c) tmp[(size_t)p * C + c] = comp_opts[p].prop_log_scale;
     HIPB(hipMemcpy(ch.prop_log_scale, tmp.data(), PC * 8, hipMemcpyHostToDevice));
-    uint32_t ident = 0;
-    for (int i = 0; i < kMaxNamed; ++i) ident |= (uint32_t)i << (4 * i);
-    std::vector<uint32_t> pv(C, ident);
-    HIPB(hipMemcpy(ch.perm, pv.data(), C * 4, hipMemcpyHostToDevice));
+    uint64_t ident = 0;
+    for (int i = 0; i < kMaxNamed; ++i) ident |= (uint64_t)i << (4 * i);
+    std::vector<uint64_t> pv(C, ident);
+    HIPB(hipMemcpy(ch.perm, pv.data(), C * 8, hipMemcpyHostToDevice));
   }
   HIPB(hipMemset(ch.acceptance_count, 0, PC * 4));
   HIPB(hipMemset(ch.iterations_since_adaption, 0, PC * 4));
@@ -907,8 +907,8 @@ int amwg_chain_diag(amwg_sampler *s, uint64_t *uniforms, double *log_post_out, i
   if (uniforms) HIP_TRY(hipMemcpy(uniforms, s->ch.rng_n, C * 8, hipMemcpyDeviceToHost));
   if (log_post_out) HIP_TRY(hipMemcpy(log_post_out, s->ch.lp_curr, C * 8, hipMemcpyDeviceToHost));
   if (named_order) {
-    std::vector<uint32_t> pv(C);
-    HIP_TRY(hipMemcpy(pv.data(), s->ch.perm, C * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> pv(C);
+    HIP_TRY(hipMemcpy(pv.data(), s->ch.perm, C * 8, hipMemcpyDeviceToHost));
     for (size_t c = 0; c < C; ++c)
       for (int k = 0; k < s->n_params; ++k) named_order[c * s->n_params + k] = (int32_t)((pv[c] >> (4 * k)) & 0xF);
   }

@@ -118,9 +118,9 @@ __device__ __forceinline__ double rnorm_js(ChainStream &rng, double mean, double
   return (v / u) * sd + mean;
 }
 
-__device__ __forceinline__ uint32_t perm_get(uint32_t perm, int i) { return (perm >> (4 * i)) & 0xFu; }
-__device__ __forceinline__ uint32_t perm_swap(uint32_t perm, int i, int j) {
-  const uint32_t d = ((perm >> (4 * i)) ^ (perm >> (4 * j))) & 0xFu;
+__device__ __forceinline__ uint32_t perm_get(uint64_t perm, int i) { return (uint32_t)(perm >> (4 * i)) & 0xFu; }
+__device__ __forceinline__ uint64_t perm_swap(uint64_t perm, int i, int j) {
+  const uint64_t d = ((perm >> (4 * i)) ^ (perm >> (4 * j))) & 0xFull;
   return perm ^ (d << (4 * i)) ^ (d << (4 * j));
 }
 
@@ -167,7 +167,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     CNTme[p] = make_int2(a.ch.acceptance_count[p * C + cl], a.ch.iterations_since_adaption[p * C + cl]);
   }
   const StateView S{Sme};
-  uint32_t perm = a.ch.perm[cl];
+  uint64_t perm = a.ch.perm[cl];
   ChainStream rng;
   rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl]);
   double lp_curr = a.ch.lp_curr[cl];

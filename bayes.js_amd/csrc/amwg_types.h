@@ -4,7 +4,7 @@
 
 namespace amwg {
 
-constexpr int kMaxNamed = 8;     // named parameters per model (packed 4-bit permutation)
+constexpr int kMaxNamed = 16;    // named parameters per model (their shuffled order is sixteen 4-bit fields of one u64)
 constexpr int kMaxTop = 256;     // largest shuffled dimension (index bytes)
 constexpr int kMaxUserArrays = 16;   // data arrays of a translated (user) log_post
 constexpr int kTypeReal = 0, kTypeInt = 1, kTypeBinary = 2;   // AMWG_REAL / AMWG_INT / AMWG_BINARY
@@ -74,7 +74,7 @@ struct ChainArrays {
   double *prop_log_scale;   // [P][C]
   int32_t *acceptance_count, *iterations_since_adaption, *batch_count;  // [P][C]  (mcmc.js:509-511)
   int32_t *accepts, *inbounds;   // [P][C] run totals (not in the reference; for parity checks)
-  uint32_t *perm;           // [C] order of the named sub-steppers, 4 bits each (mcmc.js:887 shuffles in place)
+  uint64_t *perm;           // [C] order of the named sub-steppers, 4 bits each (mcmc.js:887 shuffles in place)
   uint64_t *rng_n;          // [C] uniforms consumed
   double *lp_curr;          // [C] log_post(state)
 };

@@ -300,6 +300,25 @@ CASES.mixture_arrays = {
   schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 60 }], chains: [0, 1],
 };
 
+// ---- more than 8 named parameters (the shuffled order of the named steppers is sixteen 4-bit fields per chain)
+CASES.many_named = {
+  params: () => ({ b0: {}, b1: {}, b2: {}, b3: {}, b4: {}, b5: {}, b6: {}, b7: {}, b8: {}, b9: {}, tau: { lower: 0, init: 1 }, k: { type: 'int', lower: 0, upper: 9, init: 3 } }),
+  data: (seed) => { const r = lcg(seed), x = [], y = []; for (let i = 0; i < 24; i++) { const v = r() * 4 - 2; x.push(v); y.push(0.5 + 1.2 * v - 0.3 * v * v + (r() - 0.5)); } return { x, y }; },
+  log_post: function(s, d) {
+    var lp = ld.gamma(s.tau, 2, 2) + ld.unif(s.k, 0, 9);
+    lp += ld.norm(s.b0, 0, 3) + ld.norm(s.b1, 0, 3) + ld.norm(s.b2, 0, 3) + ld.norm(s.b3, 0, 1) + ld.norm(s.b4, 0, 1);
+    lp += ld.norm(s.b5, 0, 1) + ld.norm(s.b6, 0, 1) + ld.norm(s.b7, 0, 1) + ld.norm(s.b8, 0, 1) + ld.norm(s.b9, 0, 1);
+    var b = [s.b0, s.b1, s.b2, s.b3, s.b4, s.b5, s.b6, s.b7, s.b8, s.b9];
+    for (var i = 0; i < d.y.length; i++) {
+      var m = 0, p = 1;
+      for (var j = 0; j <= s.k; j++) { m += b[j] * p; p *= d.x[i] / 2; }
+      lp += ld.norm(d.y[i], m, 1 / Math.sqrt(s.tau));
+    }
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 120 }, { op: 'sample', n: 120, keep: 40 }], chains: [0, 1],
+};
+
 function build(name, seed) {
   const c = CASES[name] || BENCH[name];
   if (!c) throw new Error('unknown user model ' + name);
