@@ -156,6 +156,8 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   };
   const int max_bt = s->user ? s->user_max_threads : model_max_threads(s->model);
   auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds; };
+  if (s->user && !s->user_parallel && o.lanes_per_chain > 1)
+    return fail(AMWG_EINVAL, "this closure has no loop that can be split over lanes: lanes_per_chain must be 1 (or 0 = auto), got %d", o.lanes_per_chain);
   const int bts[5] = {1024, 512, 256, 128, 64};
   int bestG = 0, bestB = 0;
   double bestOcc = -1.0;

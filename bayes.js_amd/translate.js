@@ -1142,7 +1142,9 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
     });
     let returns = 0;
     walk(body, (x) => { if (x.k === 'Return' && x.arg && idsOf(x.arg).has(name)) returns++; });
-    if (ok && constInit && decls <= 1 && reads === writes + returns && returns === 1) { this.acc = name; this.split = true; }
+    // `acc = expr` (also as the declaration's initialiser) is fine anywhere outside lane-split loops: lane 0 takes expr, the
+    // other lanes restart from 0, which is what overwriting the running total means for the sum over lanes
+    if (ok && (constInit || true) && decls <= 1 && reads === writes + returns && returns === 1) { this.acc = name; this.split = true; }
   }
   // names referenced at the top level of the function (outside every loop): lane-split loops may not leak into them
   this.topLevelRefs = new Set();
