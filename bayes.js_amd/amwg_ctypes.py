@@ -45,7 +45,7 @@ class UserModel(C.Structure):
                 ("parallel", C.c_int32), ("max_threads", C.c_int32)]
 
 
-EXPORTS = ["amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
+EXPORTS = ["amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
            "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components",
            "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp",
            "amwg_log", "amwg_uniform", "amwg_device_eval"]
@@ -96,6 +96,7 @@ def lib():
         L.amwg_num_recorded.argtypes = [vp]
         L.amwg_set_state.argtypes = [vp, pd, C.c_size_t]
         L.amwg_fp64_peak.argtypes = [i32, pd]
+        L.amwg_last_sample_quantiles.argtypes = [vp, pd, i32, pd]
         L.amwg_last_sample_diagnostics.argtypes = [vp, pd, pd]
         L.amwg_pow.restype = dbl
         L.amwg_pow.argtypes = [dbl, dbl]
@@ -272,6 +273,13 @@ class Sampler:
         r, e = np.empty(self.PR), np.empty(self.PR)
         _check(lib().amwg_last_sample_diagnostics(self.h, _dp(r), _dp(e)))
         return r, e
+
+    def quantiles(self, probs):
+        """-> array [P + derived][len(probs)] over all chains x kept draws of the last sample()"""
+        pr = np.ascontiguousarray(probs, dtype=np.float64)
+        out = np.empty((self.PR, pr.size))
+        _check(lib().amwg_last_sample_quantiles(self.h, _dp(pr), pr.size, _dp(out)))
+        return out
 
     def launch_info(self):
         v = [C.c_int32() for _ in range(5)]

@@ -18,6 +18,7 @@
 #include "amwg_eval.h"
 #include "amwg_kernel.h"
 #include "amwg_models.h"
+#include "amwg_sampler.h"
 
 using namespace amwg;
 
@@ -48,7 +49,6 @@ int fail(int code, const char *fmt, ...) {
     if (e_ != hipSuccess) return fail(AMWG_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-typedef void (*step_kernel_t)(const StepArgs);
 
 template <class Model>
 step_kernel_t kernel_for_lanes(int G) {
@@ -98,39 +98,6 @@ bool value_mid_range(double v) { return v == 0.0 || mid_range(std::fabs(v)); }
 
 }  // namespace
 
-struct amwg_sampler {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int model = 0, P = 0, n_params = 0;
-  int64_t C = 0;
-  amwg_options opt{};
-  ParamLayout pl{};
-  ModelConsts mc{};
-  DataRef d{};
-  ChainArrays ch{};
-  std::vector<void *> dev_allocs;
-  CompConst *d_cc = nullptr;
-  uint8_t *d_adapt = nullptr;
-  std::vector<uint8_t> h_adapt;
-  // geometry
-  int lanes = 0, block = 0, grid = 0, lds = 0;
-  step_kernel_t kernel = nullptr;
-  bool lp_ready = false;
-  // translated closure (amwg_create_user): hiprtc module function instead of a built-in kernel
-  bool user = false;
-  int D = 0;                       // derived quantities recorded after the P components
-  int user_lds = 0, user_parallel = 0, user_max_threads = 1024;
-  hipFunction_t user_fn = nullptr;
-  hipModule_t user_module = nullptr;
-  // last call
-  int n_launches = 0;
-  double kernel_ms = 0.0;
-  double *d_draws = nullptr;       // library-owned draw buffer of the last amwg_sample
-  size_t d_draws_cap = 0;
-  const double *last_draws = nullptr;  // device pointer (library- or caller-owned) of the last sample call
-  int64_t last_rows = 0;
-};
 
 namespace {
 
@@ -303,6 +270,16 @@ __global__ void __launch_bounds__(1024) fp64_peak_kernel(double *out, int iters,
 }
 
 }  // namespace
+
+int amwg_fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
 
 extern "C" {
 

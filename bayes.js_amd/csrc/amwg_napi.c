@@ -504,6 +504,22 @@ static napi_value Convergence(napi_env env, napi_callback_info info) {
   return o;
 }
 
+/* quantiles(handle, Float64Array probs) -> Float64Array [P][n_probs] over the last sample() */
+static napi_value Quantiles(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  size_t np = 0;
+  const double *probs = (const double *)typed_data(env, a[1], napi_float64_array, &np);
+  if (!probs || np < 1) { napi_throw_type_error(env, NULL, "amwg_napi.quantiles: probs must be a non-empty Float64Array"); return NULL; }
+  double *q = NULL;
+  napi_value out = new_f64(env, (size_t)amwg_num_recorded(s) * np, &q);
+  if (!out) return NULL;
+  int rc = amwg_last_sample_quantiles(s, probs, (int32_t)np, q);
+  return rc == AMWG_OK ? out : throw_amwg(env, rc);
+}
+
 static napi_value LaunchInfo(napi_env env, napi_callback_info info) {
   napi_value a[1];
   if (!get_args(env, info, 1, a)) return NULL;
@@ -562,7 +578,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   static const struct { const char *name; napi_callback fn; } fns[] = {
       {"create", Create}, {"createUser", CreateUser}, {"compileUser", CompileUser}, {"destroy", Destroy}, {"burn", Burn}, {"burnAsync", BurnAsync}, {"sync", Sync},
       {"sample", Sample}, {"sampleAsync", SampleAsync}, {"fetchDraws", FetchDraws}, {"setAdapting", SetAdapting},
-      {"getState", GetState}, {"setState", SetState}, {"convergence", Convergence}, {"info", Info}, {"diag", Diag}, {"moments", Moments}, {"launchInfo", LaunchInfo},
+      {"getState", GetState}, {"setState", SetState}, {"convergence", Convergence}, {"quantiles", Quantiles}, {"info", Info}, {"diag", Diag}, {"moments", Moments}, {"launchInfo", LaunchInfo},
       {"version", Version}, {"mathExp", MathExp}, {"mathLog", MathLog}, {"uniform", Uniform}};
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

@@ -1,0 +1,50 @@
+// amwg_sampler.h -- the sampler handle behind the C ABI (internal to libamwg.so; shared by amwg_core.hip and
+// amwg_summaries.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/amwg.h"
+#include "amwg_types.h"
+
+typedef void (*step_kernel_t)(const amwg::StepArgs);
+
+struct amwg_sampler {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int model = 0, P = 0, n_params = 0;
+  int64_t C = 0;
+  amwg_options opt{};
+  amwg::ParamLayout pl{};
+  amwg::ModelConsts mc{};
+  amwg::DataRef d{};
+  amwg::ChainArrays ch{};
+  std::vector<void *> dev_allocs;
+  amwg::CompConst *d_cc = nullptr;
+  uint8_t *d_adapt = nullptr;
+  std::vector<uint8_t> h_adapt;
+  // geometry
+  int lanes = 0, block = 0, grid = 0, lds = 0;
+  step_kernel_t kernel = nullptr;
+  bool lp_ready = false;
+  // translated closure (amwg_create_user): hiprtc module function instead of a built-in kernel
+  bool user = false;
+  int D = 0;                       // derived quantities recorded after the P components
+  int user_lds = 0, user_parallel = 0, user_max_threads = 1024;
+  hipFunction_t user_fn = nullptr;
+  hipModule_t user_module = nullptr;
+  // last call
+  int n_launches = 0;
+  double kernel_ms = 0.0;
+  double *d_draws = nullptr;       // library-owned draw buffer of the last amwg_sample
+  size_t d_draws_cap = 0;
+  const double *last_draws = nullptr;  // device pointer (library- or caller-owned) of the last sample call
+  int64_t last_rows = 0;
+};
+
+// shared helper: records an error message for amwg_last_error() and returns `code`
+int amwg_fail(int code, const char *fmt, ...);

@@ -351,6 +351,18 @@ AmwgSampler.prototype.convergence = function () {
   return out;
 };
 
+/** Posterior quantiles per scalar component (and derived quantity) over all chains x kept draws of the last sample():
+ *  device radix sort, R's default (type 7) interpolation.  quantiles([0.025, 0.5, 0.975]) -> {name: [[q...] per element]} */
+AmwgSampler.prototype.quantiles = function (probs) {
+  const N = native();
+  if (this._shards.length !== 1) throw 'quantiles(): only available on a single-device sampler';
+  const pr = Float64Array.from(probs), q = N.quantiles(this._shards[0].handle, pr), out = {};
+  const row = (c) => Array.from(q.subarray(c * pr.length, (c + 1) * pr.length));
+  for (const L of this._layout) out[L.name] = Array.from({ length: L.len }, (_, e) => row(L.base + e));
+  this.derived.forEach((name, k) => { out[name] = [row(this.P + k)]; });
+  return out;
+};
+
 /** Per-chain starting points: f(chainIndex) -> state object shaped like sampler.state of one chain ({name: number | nested array}).
  *  The reference starts from the completed `init` (mcmc.js:954-957); many chains want over-dispersed starts. */
 AmwgSampler.prototype.init_chains = function (f) {

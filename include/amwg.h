@@ -188,6 +188,10 @@ int amwg_last_sample_moments(amwg_sampler *s, double *mean, double *sd);
  * ess = chains * var_plus / Var(chain mean).  Needs >= 2 chains and >= 4 kept draws.  rhat[P], ess[P]. */
 int amwg_last_sample_diagnostics(amwg_sampler *s, double *rhat, double *ess);
 
+/* Posterior quantiles over the draws of the LAST amwg_sample* call (all chains x kept draws pooled), per recorded value:
+ * radix sort on the device, R's default interpolation (type 7).  probs[n_probs] in [0,1]; out[P][n_probs]. */
+int amwg_last_sample_quantiles(amwg_sampler *s, const double *probs, int32_t n_probs, double *out);
+
 int amwg_sync(amwg_sampler *s);
 int amwg_num_components(const amwg_sampler *s);   /* P: scalar parameter components */
 int amwg_num_recorded(const amwg_sampler *s);     /* values per draw row: P + derived quantities */

@@ -152,4 +152,8 @@ def test_set_state_and_convergence_diagnostics():
         cm = 0.5 * (x[:half].mean(axis=0) + x[half:2 * half].mean(axis=0))
         np.testing.assert_allclose(ess[p], chains * var_plus / cm.var(ddof=1), rtol=1e-9)
         assert 0.98 < rhat[p] < 1.05 and ess[p] > chains
+    probs = [0.0, 0.025, 0.25, 0.5, 0.975, 1.0]
+    q = s.quantiles(probs)
+    for p in range(2):
+        np.testing.assert_array_equal(q[p], np.quantile(d[:, p, :].ravel(), probs))      # same order statistics, same interpolation
     s.close()

@@ -119,3 +119,12 @@ def test_oracle_stepper_with_translated_closure_reproduces_reference(name):
         assert info["accepts"].tolist() == rec["accepts"] and info["inbounds"].tolist() == rec["inbounds"]
         assert info["prop_log_scale"].tolist() == rec["prop_log_scale"]
         assert o.uniforms() == rec["uniforms"]
+
+
+def test_hiprtc_errors_surface_with_the_compiler_log():
+    L = A.lib()
+    n = C.c_size_t(0)
+    bad = b"namespace amwg { struct UserModel { static constexpr bool kUser = true; this is not C++ }; }"
+    assert L.amwg_compile_user(bad, 1, 256, b"gfx950", C.byref(n)) == -1
+    msg = L.amwg_last_error().decode()
+    assert "did not compile" in msg and "error" in msg
