@@ -110,11 +110,26 @@ int dev_alloc(amwg_sampler *s, T **p, size_t n) {
   return AMWG_OK;
 }
 
-// Geometry.  For every lanes-per-chain G (ascending: fewer lanes = less replicated scalar work)
-// take the largest workgroup that still gives every CU a workgroup (more waves share one LDS copy
-// of the data), estimate the resident waves per SIMD, and stop at the first G that reaches 4 --
-// enough to hide LDS/fp64 latencies in the dependent chains.  If no G gets there (few chains), keep
-// the best occupancy seen; ties go to the smaller G.
+// Geometry.  For every lanes-per-chain G take the largest workgroup that still gives every CU a workgroup (more waves
+// share one LDS copy of the data) and price it with a two-term model of one parameter update:
+//     T(G)    = S + W / G              instructions a wave issues: the replicated stepper (Philox, proposal, exp, accept,
+//                                      adaptation; S ~ 300) plus its 1/G share of the log-likelihood work W
+//     cost(G) = T(G) * rounds * max(w_res, w0)
+// where w_res is the number of waves a SIMD holds at once (limited by LDS and by the number of chains), rounds the
+// number of such batches, and w0 ~ 2.5 the occupancy below which a SIMD is latency- rather than issue-bound.  The cheapest
+// G wins, ties go to the smaller G.  The choice depends only on the model, the data size and the chain count, so a
+// given sampler configuration always gets the same G (the lane count fixes the summation order, hence the draws).
+double model_work(const amwg_sampler *s, int G) {
+  const double N = (double)s->d.n_obs;
+  switch (s->model) {
+    case AMWG_MODEL_NORMAL: return 9.0 * N;
+    case AMWG_MODEL_BETA_BERN: return (G == 1 ? 1.8 : 6.0) * N;      // one lane: scalar jump-table pass, one add per observation
+    case AMWG_MODEL_HIER_NORMAL: return 10.0 * N + 12.0 * s->d.G;
+    case AMWG_MODEL_POIS_GLM: return 90.0 * N;
+  }
+  return s->user_work > 0 ? s->user_work : 1e6;   // translated closure: the translator's estimate
+}
+
 int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const amwg_options &o = s->opt;
   auto layout = [&](int bt, int G) {
@@ -151,9 +166,11 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     if (lds > 0 && (int64_t)(max_lds / lds) < per_cu) per_cu = (int64_t)(max_lds / lds);
     if (per_cu < 1) per_cu = 1;
     const int64_t resident = blocks < per_cu * n_cus ? blocks : per_cu * n_cus;
-    const double occ = (double)resident * (pick / 64) / (4.0 * n_cus);  // waves per SIMD
-    if (occ > bestOcc + 1e-9) { bestOcc = occ; bestG = G; bestB = pick; }
-    if (occ >= 4.0) break;
+    const double w_res = (double)resident * (pick / 64) / (4.0 * n_cus);          // waves a SIMD holds at once
+    const double w_total = (double)blocks * (pick / 64) / (4.0 * n_cus);            // waves a SIMD has to run in all
+    const double T = 300.0 + model_work(s, G) / G;
+    const double cost = T * (w_total / w_res) * (w_res > 2.5 ? w_res : 2.5);
+    if (bestOcc < 0 || cost < bestOcc * (1.0 - 1e-9)) { bestOcc = cost; bestG = G; bestB = pick; }   // bestOcc holds the best cost
   }
   if (!bestG) return fail(AMWG_EINVAL, "no launch geometry fits: the model needs more than %zu bytes of LDS", max_lds);
   s->lanes = bestG;
@@ -622,6 +639,7 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
   s->user_lds = (m->lds_bytes + 15) & ~15;
   s->user_parallel = m->parallel ? 1 : 0;
   s->user_max_threads = max_threads;
+  s->user_work = m->work_per_eval;
   s->C = options->chains;
   s->n_params = n_params;
   s->device = options->device;

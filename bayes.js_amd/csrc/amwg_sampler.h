@@ -35,6 +35,7 @@ struct amwg_sampler {
   bool user = false;
   int D = 0;                       // derived quantities recorded after the P components
   int user_lds = 0, user_parallel = 0, user_max_threads = 1024;
+  double user_work = 0;            // translator's estimate of the instructions of one log_post evaluation
   hipFunction_t user_fn = nullptr;
   hipModule_t user_module = nullptr;
   // last call

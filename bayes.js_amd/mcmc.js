@@ -221,7 +221,7 @@ function AmwgSampler(params, log_post, data, options) {
     this.derived = tr.derived;
     this.translation = tr;
     user = { source: tr.source, arrays: tr.arrays, array_types: tr.array_types, n_derived: tr.derived.length, lds_bytes: tr.lds_bytes, parallel: tr.parallel,
-             max_threads: tr.max_threads };
+             max_threads: tr.max_threads, work_per_eval: tr.work_per_eval };
   }
   this.PR = this.P + this.derived.length;   // values per recorded draw
 

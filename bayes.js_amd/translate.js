@@ -1272,8 +1272,46 @@ Translator.prototype.run = function () {
     lds_bytes: off,
     parallel: parallel ? 1 : 0,
     max_threads: maxThreads,
+    work_per_eval: this.workEstimate(),
     P: this.P,
   };
+};
+
+// Rough instruction count of one evaluation (steers only the lanes-per-chain choice of the host library): operators 1,
+// Math.exp/log 30, pow 80, ld.norm 10 (hoisted form), other ld.* 70, loops multiply by their trip count when it is a
+// translation-time constant (else by 8).
+Translator.prototype.workEstimate = function () {
+  const tripOf = (st) => {
+    const c = this.canonicalLoop(st);
+    if (!c) return 8;
+    try {
+      const saved = this.pending; this.pending = [];
+      const a = this.expr(c.startAst), b = this.expr(c.boundAst);
+      this.pending = saved;
+      if (a.cst !== undefined && b.cst !== undefined) return Math.max(0, b.cst - a.cst + (c.le ? 1 : 0));
+    } catch (e) { /* not a constant */ }
+    return 8;
+  };
+  const weigh = (node) => {
+    if (!node || typeof node !== 'object') return 0;
+    if (Array.isArray(node)) return node.reduce((t, x) => t + weigh(x), 0);
+    let w = 0;
+    switch (node.k) {
+      case 'For': return weigh(node.init) + tripOf(node) * (2 + weigh(node.test) + weigh(node.update) + weigh(node.body));
+      case 'Binary': case 'Unary': case 'Assign': case 'Update': case 'Index': case 'Cond': w = 1; break;
+      case 'Call': {
+        const c = node.callee;
+        if (c.k === 'Member' && c.obj.k === 'Id' && c.obj.name === 'Math') w = c.prop === 'pow' ? 80 : (c.prop === 'exp' || c.prop === 'log' ? 30 : 4);
+        else if (c.k === 'Member' && c.obj.k === 'Id' && c.obj.name === 'ld') w = c.prop === 'norm' ? 10 : (c.prop === 'bern' ? 4 : 70);
+        else w = 40;
+        break;
+      }
+      default: break;
+    }
+    for (const key of Object.keys(node)) if (key !== 'k') w += weigh(node[key]);
+    return w;
+  };
+  return weigh(this.ast.body);
 };
 
 /** translate(log_post, completedParams, data[, options]) -> {source, arrays, derived, lds_bytes, parallel, max_threads} */

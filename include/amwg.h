@@ -125,6 +125,7 @@ typedef struct {
   int32_t lds_bytes;             /* bytes of data the generated stage() keeps in LDS */
   int32_t parallel;              /* 1 = the body has lane-split loops, lanes_per_chain > 1 is allowed */
   int32_t max_threads;           /* workgroup-size cap the translator suggests (0 = 1024) */
+  double work_per_eval;          /* rough instruction count of one log_post evaluation (0 = unknown); only steers lanes_per_chain */
 } amwg_user_model;
 
 /* Replaces `new mcmc.AmwgSampler(params, log_post, data, options)` for an arbitrary (translated) closure. */

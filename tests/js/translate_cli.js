@@ -25,5 +25,5 @@ for (const name of (want.length ? want : um.names)) {
   }
   fs.writeFileSync(path.join(out, name + '.arrays.bin'), buf);
   fs.writeFileSync(path.join(out, name + '.meta.json'), JSON.stringify({ name, P: tr.P, derived: tr.derived, lds_bytes: tr.lds_bytes,
-    parallel: tr.parallel, max_threads: tr.max_threads, array_keys: tr.array_keys, array_types: tr.array_types, array_len: tr.arrays.map((a) => a.length) }));
+    parallel: tr.parallel, max_threads: tr.max_threads, work_per_eval: tr.work_per_eval, array_keys: tr.array_keys, array_types: tr.array_types, array_len: tr.arrays.map((a) => a.length) }));
 }
