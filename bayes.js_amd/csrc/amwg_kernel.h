@@ -47,7 +47,7 @@ __host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CP
   L.stride = (uint32_t)P | 1u;  // doubles per chain, odd (see StateView)
   L.data = o;  o += (uint32_t)((data_bytes + 15) & ~(size_t)15);
   L.state = o; o += L.stride * CPB * 8;
-  L.pls = o;   o += L.stride * CPB * 8;   // prop_log_scale, same [chain][stride] layout as the state
+  L.pls = o;   o += L.stride * CPB * 8;   // proposal sd = exp(prop_log_scale), same [chain][stride] layout as the state
   L.cnt = o;   o += L.stride * CPB * 8;   // {acceptance_count, iterations_since_adaption} int32 pairs
   L.cc = o;    o += (uint32_t)P * sizeof(CompConst);
   L.adapt = o; o += ((uint32_t)P + 7) & ~7u;
@@ -145,7 +145,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   uint8_t *adapt = smem + L.adapt;
   ParamLayout *pl = reinterpret_cast<ParamLayout *>(smem + L.pl);
   uint8_t *idx = smem + L.idx + c_in;  // this chain's shuffle indices at idx[t * CPB]
-  double *PLSme = reinterpret_cast<double *>(smem + L.pls) + (size_t)(tid / G) * L.stride;
+  double *SDme = reinterpret_cast<double *>(smem + L.pls) + (size_t)(tid / G) * L.stride;   // exp(prop_log_scale), mcmc.js:578
   int2 *CNTme = reinterpret_cast<int2 *>(smem + L.cnt) + (size_t)(tid / G) * L.stride;
 
   // ---- stage chain-shared data and per-component constants (coalesced, once per launch)
@@ -163,7 +163,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // per-chain stepper state lives in LDS for the whole launch: an update never waits on HBM/L2
   for (int p = 0; p < P; ++p) {
     Sme[p] = a.ch.state[p * C + cl];
-    PLSme[p] = a.ch.prop_log_scale[p * C + cl];
+    SDme[p] = exp_v8(a.ch.prop_log_scale[p * C + cl]);   // the log scale itself stays in HBM: it only changes at batch boundaries
     CNTme[p] = make_int2(a.ch.acceptance_count[p * C + cl], a.ch.iterations_since_adaption[p * C + cl]);
   }
   const StateView S{Sme};
@@ -240,16 +240,15 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         double now = 1.0;
         lp_curr = one_ld;
         if (rng.next() < zero_prob) { Sme[comp] = 0.0; now = 0.0; lp_curr = zero_ld; }
-        if (writer) {   // run totals: evaluations and flips
-          a.ch.inbounds[gi] += 1;
-          if (now != old) a.ch.accepts[gi] += 1;
+        if (writer) {   // run totals: evaluations and flips (no-return atomics on chain-private words: nothing to wait for)
+          atomicAdd(&a.ch.inbounds[gi], 1);
+          if (now != old) atomicAdd(&a.ch.accepts[gi], 1);
         }
         continue;
       }
       // ---- OnedimMetropolisStepper.step (mcmc.js:517-553)
-      double pls = PLSme[comp];
       const double cur = S(comp);
-      double prop = rnorm_js(rng, cur, exp_v8(pls));
+      double prop = rnorm_js(rng, cur, SDme[comp]);
       if (k.type == kTypeInt) prop = js_round(prop);
       const bool inb = !(prop < k.lower || prop > k.upper);
       bool accepted = false;
@@ -271,16 +270,17 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         if (cnt.y >= k.batch_size) {    // batch boundary: the only time batch_count is touched (it stays in HBM)
           const int32_t bc = a.ch.batch_count[gi] + 1;
           const double adj = __builtin_fmin(k.max_adaptation, k.initial_adaptation / __builtin_sqrt((double)bc));
+          double pls = a.ch.prop_log_scale[gi];
           if ((double)cnt.x / (double)k.batch_size > k.target_accept_rate) pls += adj; else pls -= adj;
           cnt = make_int2(0, 0);
-          PLSme[comp] = pls;
-          if (writer) a.ch.batch_count[gi] = bc;
+          SDme[comp] = exp_v8(pls);
+          if (writer) { a.ch.batch_count[gi] = bc; a.ch.prop_log_scale[gi] = pls; }
         }
         CNTme[comp] = cnt;
       }
       if (writer && inb) {   // run totals (not in the reference; parity tests compare them with the oracle's):
-        a.ch.inbounds[gi] += 1;   // plain read-modify-write of a chain-private word; stays in L2
-        if (accepted) a.ch.accepts[gi] += 1;
+        atomicAdd(&a.ch.inbounds[gi], 1);   // no-return atomics on chain-private words: the wave does not wait for L2
+        if (accepted) atomicAdd(&a.ch.accepts[gi], 1);
       }
     }
   }
@@ -288,7 +288,6 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   if (writer) {
     for (int p = 0; p < P; ++p) {
       a.ch.state[p * C + cl] = S(p);
-      a.ch.prop_log_scale[p * C + cl] = PLSme[p];
       a.ch.acceptance_count[p * C + cl] = CNTme[p].x;
       a.ch.iterations_since_adaption[p * C + cl] = CNTme[p].y;
     }
