@@ -288,6 +288,15 @@ AmwgSampler.prototype.sample = function (n_iterations) {
   return out;
 };
 
+/** Like sample(n), but the draws stay in HBM: nothing is copied to the host; moments(), quantiles() and convergence()
+ *  then summarise them on the device (65 536 chains x 5 000 draws are 5 GB -- more than a JS ArrayBuffer holds). */
+AmwgSampler.prototype.sample_on_device = function (n_iterations) {
+  const N = native();
+  this._each((sh) => N.sampleAsync(sh.handle, n_iterations, this.thinning_interval));
+  this._each((sh) => N.sync(sh.handle));
+  return Math.ceil(n_iterations / this.thinning_interval);
+};
+
 Object.defineProperty(AmwgSampler.prototype, 'state', {
   get: function () {
     const N = native(), C = this.chains;

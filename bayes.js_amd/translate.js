@@ -12,7 +12,8 @@
  *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, local
  *     aliases of those (var p = par.p[0]), derived quantities (state.key = expr, mcmc.js:961-963),
  *     helper functions and constants passed in options.helpers / options.constants.
- * Anything else throws a string that says what is not supported (no CPU fallback).
+ * Anything else throws a string that says what is not supported (no CPU fallback).  Array reads are not bounds-checked
+ * (JavaScript yields undefined -> NaN for an out-of-range index; here only run-time indices into local arrays are checked).
  *
  * Fidelity.  Every JavaScript number operation becomes the same IEEE fp64 operation in the same
  * order (the kernel is compiled with -ffp-contract=off); Math.exp/log are the bit-identical V8

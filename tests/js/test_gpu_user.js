@@ -87,6 +87,8 @@ if (!only.length) {
   // convergence diagnostics and per-chain starts through the front-end
   const conv = a.convergence();
   assert.ok(conv.p1.rhat[0] > 0.9 && isFinite(conv.n1.rhat[0]) && conv.p1.ess[0] > 10 && conv.m.ess[0] > 0, JSON.stringify(conv));   // 100 steps of a bimodal model: not converged, only sanity
+  assert.strictEqual(a.sample_on_device(30), 30);          // draws stay in HBM, summaries come from there
+  assert.ok(a.moments().p1.mean[0] > 0 && a.moments().p1.mean[0] < 1);
   const qs = a.quantiles([0.025, 0.5, 0.975]);
   assert.ok(qs.p1[0][0] <= qs.p1[0][1] && qs.p1[0][1] <= qs.p1[0][2] && qs.m[0][2] <= 1 && qs.n1[0][0] >= 1, JSON.stringify(qs));
   a.init_chains((c) => ({ p1: 0.1 + 0.8 * (c / 50), n1: 1 + (c % 5), m: c % 2 }));
