@@ -3,6 +3,7 @@
 // point that computes runs on the HIP device or fails with AMWG_EHIP.
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -184,7 +185,29 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   return AMWG_OK;
 }
 
+// Optional tracing: roctx ranges around every burn/sample call, visible to `rocprofv3 --marker-trace`.
+// the roctx library is looked up at run time; without it (or with AMWG_ROCTX=0) these are no-ops.
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char *env = getenv("AMWG_ROCTX");
+    if (env && env[0] == '0') return;
+    void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_GLOBAL);   // ROCm 7
+    if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL);               // older ROCm
+    if (h) {
+      push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+  }
+};
+Roctx &roctx() { static Roctx r; return r; }
+
 int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
+  Roctx &rx = roctx();
+  if (rx.push) rx.push(d_draws ? "amwg_sample" : "amwg_burn");
+  struct PopOnExit { Roctx &r; ~PopOnExit() { if (r.pop) r.pop(); } } pop_on_exit{rx};
   const int64_t chunk = s->opt.steps_per_launch > 0 ? s->opt.steps_per_launch : (1 << 20);
   StepArgs a{};
   a.C = s->C;
