@@ -113,8 +113,8 @@ int dev_alloc(amwg_sampler *s, T **p, size_t n) {
 
 // Geometry.  For every lanes-per-chain G take the largest workgroup that still gives every CU a workgroup (more waves
 // share one LDS copy of the data) and price it with a two-term model of one parameter update:
-//     T(G)    = S + W / G              instructions a wave issues: the replicated stepper (Philox, proposal, exp, accept,
-//                                      adaptation; S ~ 300) plus its 1/G share of the log-likelihood work W
+//     T(G)    = S(G) + W / G           instructions a wave issues: the replicated stepper (Philox, proposal, exp, accept,
+//                                      adaptation; S = 500 + 600/G, measured) plus its 1/G share of the log-likelihood work W
 //     cost(G) = T(G) * rounds * max(w_res, w0)
 // where w_res is the number of waves a SIMD holds at once (limited by LDS and by the number of chains), rounds the
 // number of such batches, and w0 ~ 2.5 the occupancy below which a SIMD is latency- rather than issue-bound.  The cheapest
@@ -169,7 +169,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     const int64_t resident = blocks < per_cu * n_cus ? blocks : per_cu * n_cus;
     const double w_res = (double)resident * (pick / 64) / (4.0 * n_cus);          // waves a SIMD holds at once
     const double w_total = (double)blocks * (pick / 64) / (4.0 * n_cus);            // waves a SIMD has to run in all
-    const double T = 300.0 + model_work(s, G) / G;
+    const double T = 500.0 + 600.0 / G + model_work(s, G) / G;   // S(G): 540 VALU/update measured at G = 64 (rocprofv3, N = 0), ~1100 at G = 1 (64 chains' rnorm loops diverge)
     const double cost = T * (w_total / w_res) * (w_res > 2.5 ? w_res : 2.5);
     if (bestOcc < 0 || cost < bestOcc * (1.0 - 1e-9)) { bestOcc = cost; bestG = G; bestB = pick; }   // bestOcc holds the best cost
   }
