@@ -61,6 +61,10 @@ step_kernel_t kernel_for_lanes(int G) {
     case 16: return amwg_step_kernel<Model, 16>;
     case 32: return amwg_step_kernel<Model, 32>;
     case 64: return amwg_step_kernel<Model, 64>;
+    case 128: return amwg_step_kernel<Model, 128>;     // one chain on 2..16 wavefronts of one workgroup (few chains, long data loops)
+    case 256: return amwg_step_kernel<Model, 256>;
+    case 512: return amwg_step_kernel<Model, 512>;
+    case 1024: return amwg_step_kernel<Model, 1024>;
   }
   return nullptr;
 }
@@ -135,7 +139,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const amwg_options &o = s->opt;
   auto layout = [&](int bt, int G) {
     const size_t data_bytes = s->user ? (size_t)s->user_lds : model_lds_bytes(s->model, s->d.n_obs, s->d.G, G);
-    return lds_layout(data_bytes, s->P, bt / G, s->pl.max_top);
+    return G > 64 ? lds_layout(data_bytes, s->P, G / 64, s->pl.max_top, true) : lds_layout(data_bytes, s->P, bt / G, s->pl.max_top);
   };
   const int max_bt = s->user ? s->user_max_threads : model_max_threads(s->model);
   auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds; };
@@ -144,7 +148,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const int bts[5] = {1024, 512, 256, 128, 64};
   int bestG = 0, bestB = 0;
   double bestOcc = -1.0;
-  for (int G = 1; G <= 64; G <<= 1) {
+  for (int G = 1; G <= 1024; G <<= 1) {
     if (o.lanes_per_chain && G != o.lanes_per_chain) continue;
     if (s->user && !s->user_parallel && G > 1) break;   // nothing to split: one lane per chain
     // translated closures: with one lane per chain every data index is wave-uniform and the compiler moves the
@@ -155,6 +159,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     for (int bi = 0; bi < 5; ++bi) {   // largest workgroup with >= one workgroup per CU, else the smallest that fits
       const int bt = bts[bi];
       if (o.block_threads && bt != o.block_threads) continue;
+      if (G > 64 && bt != G) continue;              // a multi-wave chain is exactly one workgroup
       if (!fits(bt, G)) continue;
       pick = bt;
       if ((s->C + bt / G - 1) / (bt / G) >= n_cus) break;
@@ -169,7 +174,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     const int64_t resident = blocks < per_cu * n_cus ? blocks : per_cu * n_cus;
     const double w_res = (double)resident * (pick / 64) / (4.0 * n_cus);          // waves a SIMD holds at once
     const double w_total = (double)blocks * (pick / 64) / (4.0 * n_cus);            // waves a SIMD has to run in all
-    const double T = 500.0 + 600.0 / G + model_work(s, G) / G;   // S(G): 540 VALU/update measured at G = 64 (rocprofv3, N = 0), ~1100 at G = 1 (64 chains' rnorm loops diverge)
+    const double T = 500.0 + 600.0 / G + model_work(s, G) / G + (G > 64 ? 150.0 : 0.0);   // + the workgroup barrier of every evaluation   // S(G): 540 VALU/update measured at G = 64 (rocprofv3, N = 0), ~1100 at G = 1 (64 chains' rnorm loops diverge)
     const double cost = T * (w_total / w_res) * (w_res > 2.5 ? w_res : 2.5);
     if (bestOcc < 0 || cost < bestOcc * (1.0 - 1e-9)) { bestOcc = cost; bestG = G; bestB = pick; }   // bestOcc holds the best cost
   }
@@ -345,7 +350,10 @@ double amwg_uniform(uint64_t seed, uint64_t chain, uint64_t index) {
 static int check_options(const amwg_options *options, int max_threads) {
   if (options->chains < 1) return fail(AMWG_EINVAL, "amwg_create: chains must be >= 1");
   const int G_opt = options->lanes_per_chain;
-  if (G_opt && (G_opt < 1 || G_opt > 64 || (G_opt & (G_opt - 1)))) return fail(AMWG_EINVAL, "lanes_per_chain must be a power of two in 1..64");
+  if (G_opt && (G_opt < 1 || G_opt > 1024 || (G_opt & (G_opt - 1)))) return fail(AMWG_EINVAL, "lanes_per_chain must be a power of two in 1..1024");
+  if (G_opt > 64 && options->block_threads && options->block_threads != G_opt)
+    return fail(AMWG_EINVAL, "a chain on %d lanes is one workgroup of %d threads: block_threads must be 0 or %d", G_opt, G_opt, G_opt);
+  if (G_opt > max_threads) return fail(AMWG_EINVAL, "lanes_per_chain %d exceeds this model's workgroup limit %d", G_opt, max_threads);
   if (options->block_threads && (options->block_threads % 64 || options->block_threads > 1024 || options->block_threads < 64))
     return fail(AMWG_EINVAL, "block_threads must be a multiple of 64 in 64..1024");
   if (options->block_threads > max_threads)

@@ -39,9 +39,11 @@
 namespace amwg {
 
 struct LdsLayout {
-  uint32_t data, state, pls, cnt, cc, adapt, pl, idx, total, stride;
+  uint32_t data, state, pls, cnt, cc, adapt, pl, idx, total, stride, logpls, bc, xw;
 };
-__host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CPB, int max_top) {
+// CPB = per-chain state copies in the workgroup: chains per workgroup (lanes per chain <= 64), or -- when one chain spans
+// several wavefronts -- one private replica per wavefront (`multi`, see step_body).
+__host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CPB, int max_top, bool multi = false) {
   LdsLayout L;
   uint32_t o = 0;
   L.stride = (uint32_t)P | 1u;  // doubles per chain, odd (see StateView)
@@ -53,6 +55,9 @@ __host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CP
   L.adapt = o; o += ((uint32_t)P + 7) & ~7u;
   L.pl = o;    o += (uint32_t)((sizeof(ParamLayout) + 7) & ~(size_t)7);
   L.idx = o;   o += (max_top > 1) ? (((uint32_t)max_top * CPB + 15) & ~15u) : 0;
+  L.logpls = o; o += multi ? L.stride * CPB * 8 : 0;   // prop_log_scale replicas (single-wave chains keep it in HBM)
+  L.bc = o;     o += multi ? ((L.stride * CPB * 4 + 15) & ~15u) : 0;   // batch_count replicas
+  L.xw = o;     o += multi ? 2u * 16u * 8u : 0;        // cross-wave partial sums, double buffered, <= 16 waves
   L.total = (o + 15) & ~15u;
   return L;
 }
@@ -77,8 +82,17 @@ __device__ __forceinline__ double pass_over_data(const typename Model::Pass &ps,
 // log_post(state) in the documented order: lane 0 of the chain starts from the prior sum
 // (accumulated sequentially as the closure does), every lane adds its observations in
 // increasing index order, then the xor butterfly.  For G = 1 this is the reference's order.
+// Exchange area of a chain that spans several wavefronts (lanes per chain G > 64): every wave leaves its partial sum
+// in LDS, ONE barrier, then every wave adds the partials in the same xor-butterfly order (offsets 64, 128, ...), so all
+// G lanes end up with the same bits.  The buffer alternates between two halves: a wave that races ahead into the next
+// evaluation writes the other half, and cannot come back to this one before everybody passed the next barrier.
+struct CrossWave {
+  double *buf;     // [2][16]
+  int parity;
+};
+
 template <class Model, int G>
-__device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a, const unsigned char *smem, int sub) {
+__device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a, const unsigned char *smem, int sub, CrossWave &xw) {
   double acc;
   if constexpr (Model::kUser) {
     // translated closure: the generated body returns this lane's partial sum (lane 0 carries every
@@ -102,7 +116,27 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
     }
   }
 #pragma unroll
-  for (int off = 1; off < G; off <<= 1) acc = acc + __shfl_xor(acc, off, 64);
+  for (int off = 1; off < (G < 64 ? G : 64); off <<= 1) acc = acc + __shfl_xor(acc, off, 64);
+  if constexpr (G > 64) {
+    constexpr int WV = G / 64;
+    double *slot = xw.buf + xw.parity * 16;
+    xw.parity ^= 1;
+    const int wave = sub >> 6;
+    if ((sub & 63) == 0) slot[wave] = acc;
+    __syncthreads();
+    double t[WV];
+#pragma unroll
+    for (int w = 0; w < WV; ++w) t[w] = slot[w];
+#pragma unroll
+    for (int off = 1; off < WV; off <<= 1) {
+      double u[WV];
+#pragma unroll
+      for (int w = 0; w < WV; ++w) u[w] = t[w] + t[w ^ off];
+#pragma unroll
+      for (int w = 0; w < WV; ++w) t[w] = u[w];
+    }
+    acc = t[0];   // every entry holds the same sum
+  }
   return acc;
 }
 
@@ -134,10 +168,14 @@ __device__ __forceinline__ double js_max2(double a, double b) {
 template <class Model, int G>
 __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int CPB = nt / G;
-  const int c_in = tid / G, sub = tid % G;
+  // G <= 64: nt/G chains per workgroup, each on G lanes of one wave.  G > 64 ("multi"): ONE chain per workgroup on G/64
+  // waves; every wave is a full replica of the chain's scalar logic (same Philox stream => same proposals and decisions)
+  // with its own copy of the stepper state in LDS, so waves share nothing but the data tile and the partial sums.
+  constexpr bool kMulti = G > 64;
+  const int CPB = kMulti ? G / 64 : nt / G;                 // state copies in this workgroup
+  const int c_in = kMulti ? tid / 64 : tid / G, sub = tid % G;
   const int P = a.pl.P;
-  const LdsLayout L = lds_layout(Model::lds_bytes(a.d.n_obs, a.d.G, G), P, CPB, a.pl.max_top);
+  const LdsLayout L = lds_layout(Model::lds_bytes(a.d.n_obs, a.d.G, G), P, CPB, a.pl.max_top, kMulti);
 
   const unsigned char *data_lds = smem + L.data;
   double *Sblk = reinterpret_cast<double *>(smem + L.state);
@@ -145,15 +183,18 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   uint8_t *adapt = smem + L.adapt;
   ParamLayout *pl = reinterpret_cast<ParamLayout *>(smem + L.pl);
   uint8_t *idx = smem + L.idx + c_in;  // this chain's shuffle indices at idx[t * CPB]
-  double *SDme = reinterpret_cast<double *>(smem + L.pls) + (size_t)(tid / G) * L.stride;   // exp(prop_log_scale), mcmc.js:578
-  int2 *CNTme = reinterpret_cast<int2 *>(smem + L.cnt) + (size_t)(tid / G) * L.stride;
+  double *SDme = reinterpret_cast<double *>(smem + L.pls) + (size_t)c_in * L.stride;   // exp(prop_log_scale), mcmc.js:578
+  int2 *CNTme = reinterpret_cast<int2 *>(smem + L.cnt) + (size_t)c_in * L.stride;
+  double *LOGPLSme = reinterpret_cast<double *>(smem + L.logpls) + (size_t)c_in * L.stride;   // multi only
+  int32_t *BCme = reinterpret_cast<int32_t *>(smem + L.bc) + (size_t)c_in * L.stride;         // multi only
+  CrossWave xw{reinterpret_cast<double *>(smem + L.xw), 0};
 
   // ---- stage chain-shared data and per-component constants (coalesced, once per launch)
   Model::stage(smem + L.data, a.d, tid, nt, G);
   for (int p = tid; p < P; p += nt) { cc[p] = a.cc[p]; adapt[p] = a.is_adapting[p]; }
   if (tid == 0) *pl = a.pl;
 
-  const int64_t chain_raw = (int64_t)blockIdx.x * CPB + c_in;
+  const int64_t chain_raw = kMulti ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * CPB + c_in;
   const bool live = chain_raw < a.C;
   const int64_t cl = live ? chain_raw : a.C - 1;  // dead lanes shadow the last chain and never store
   const bool writer = live && sub == 0;
@@ -165,6 +206,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     Sme[p] = a.ch.state[p * C + cl];
     SDme[p] = exp_v8(a.ch.prop_log_scale[p * C + cl]);   // the log scale itself stays in HBM: it only changes at batch boundaries
     CNTme[p] = make_int2(a.ch.acceptance_count[p * C + cl], a.ch.iterations_since_adaption[p * C + cl]);
+    if constexpr (kMulti) { LOGPLSme[p] = a.ch.prop_log_scale[p * C + cl]; BCme[p] = a.ch.batch_count[p * C + cl]; }
   }
   const StateView S{Sme};
   uint64_t perm = a.ch.perm[cl];
@@ -172,7 +214,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl]);
   double lp_curr = a.ch.lp_curr[cl];
   __syncthreads();
-  if (a.init_lp) lp_curr = log_post<Model, G>(S, a, data_lds, sub);  // ctor warm-up call, mcmc.js:961-963
+  if (a.init_lp) lp_curr = log_post<Model, G>(S, a, data_lds, sub, xw);  // ctor warm-up call, mcmc.js:961-963
 
   const int n_named = pl->n_params;
   constexpr int D = Model::kDerived;
@@ -231,9 +273,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         // probability exp(z - log(exp(z) + exp(o))) after subtracting the larger log density
         const double old = S(comp);
         Sme[comp] = 0.0;
-        const double zero_ld = log_post<Model, G>(S, a, data_lds, sub);
+        const double zero_ld = log_post<Model, G>(S, a, data_lds, sub, xw);
         Sme[comp] = 1.0;
-        const double one_ld = log_post<Model, G>(S, a, data_lds, sub);
+        const double one_ld = log_post<Model, G>(S, a, data_lds, sub, xw);
         const double mx = js_max2(zero_ld, one_ld);
         const double z = zero_ld - mx, o = one_ld - mx;
         const double zero_prob = exp_v8(z - log_v8(exp_v8(z) + exp_v8(o)));
@@ -254,7 +296,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       bool accepted = false;
       if (inb) {
         Sme[comp] = prop;
-        const double prop_lp = log_post<Model, G>(S, a, data_lds, sub);
+        const double prop_lp = log_post<Model, G>(S, a, data_lds, sub, xw);
         const double accept_prob = exp_v8(prop_lp - lp_curr);
         if (accept_prob > rng.next()) {
           accepted = true;
@@ -268,13 +310,16 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         cnt.x += accepted ? 1 : 0;      // acceptance_count (mcmc.js:530)
         cnt.y += 1;                     // iterations_since_adaption (mcmc.js:537)
         if (cnt.y >= k.batch_size) {    // batch boundary: the only time batch_count is touched (it stays in HBM)
-          const int32_t bc = a.ch.batch_count[gi] + 1;
+          // single-wave chains: batch_count and the log scale live in HBM (all lanes of the chain are in lockstep, so they
+          // read the old value together before the writer lane stores the new one); multi-wave chains keep per-wave replicas
+          const int32_t bc = (kMulti ? BCme[comp] : a.ch.batch_count[gi]) + 1;
           const double adj = __builtin_fmin(k.max_adaptation, k.initial_adaptation / __builtin_sqrt((double)bc));
-          double pls = a.ch.prop_log_scale[gi];
+          double pls = kMulti ? LOGPLSme[comp] : a.ch.prop_log_scale[gi];
           if ((double)cnt.x / (double)k.batch_size > k.target_accept_rate) pls += adj; else pls -= adj;
           cnt = make_int2(0, 0);
           SDme[comp] = exp_v8(pls);
-          if (writer) { a.ch.batch_count[gi] = bc; a.ch.prop_log_scale[gi] = pls; }
+          if constexpr (kMulti) { BCme[comp] = bc; LOGPLSme[comp] = pls; }
+          else if (writer) { a.ch.batch_count[gi] = bc; a.ch.prop_log_scale[gi] = pls; }
         }
         CNTme[comp] = cnt;
       }
@@ -290,6 +335,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       a.ch.state[p * C + cl] = S(p);
       a.ch.acceptance_count[p * C + cl] = CNTme[p].x;
       a.ch.iterations_since_adaption[p * C + cl] = CNTme[p].y;
+      if constexpr (kMulti) { a.ch.prop_log_scale[p * C + cl] = LOGPLSme[p]; a.ch.batch_count[p * C + cl] = BCme[p]; }
     }
     a.ch.perm[cl] = perm;
     a.ch.rng_n[cl] = rng.n;

@@ -93,7 +93,8 @@ typedef struct {
   uint64_t seed;           /* Philox key */
   uint64_t chain_offset;   /* global id of local chain 0 (multi-GPU sharding) */
   int32_t device;          /* HIP device ordinal */
-  int32_t lanes_per_chain; /* 0 = auto; else a power of two 1..64: lanes that split one chain's observation loop */
+  int32_t lanes_per_chain; /* 0 = auto; else a power of two 1..1024: lanes that split one chain's observation loop (above 64 the chain is one
+                              workgroup of several wavefronts, each a replica of the scalar logic; few chains, long data loops) */
   int32_t block_threads;   /* 0 = auto; else multiple of 64, <= 1024 */
   int32_t steps_per_launch;/* 0 = auto (one launch per burn/sample call up to 2^20 steps) */
   int32_t exact_division;  /* 0 = default (hoisted-reciprocal division, bit-identical to IEEE, verified); 1 = plain IEEE '/' */

@@ -35,6 +35,10 @@ extern "C" double user_eval(const double *state, const void *const *arrays, int 
     case 16: return lanes<16>(state, d, dv);
     case 32: return lanes<32>(state, d, dv);
     case 64: return lanes<64>(state, d, dv);
+    case 128: return lanes<128>(state, d, dv);
+    case 256: return lanes<256>(state, d, dv);
+    case 512: return lanes<512>(state, d, dv);
+    case 1024: return lanes<1024>(state, d, dv);
   }
   return __builtin_nan("");
 }

@@ -66,6 +66,30 @@ def test_g_lanes_per_chain_matches_oracle_and_reference_decisions(name, lanes):
     s.close()
 
 
+@pytest.mark.parametrize("name", ["normal_n1000", "beta_bern_n2000", "hier_small", "glm_small"])
+@pytest.mark.parametrize("lanes", [128, 256, 1024])
+def test_chain_spanning_several_wavefronts_matches_oracle_and_reference_decisions(name, lanes):
+    """lanes_per_chain > 64: one chain per workgroup on lanes/64 wavefronts (each a replica of the scalar logic, partial sums
+    exchanged through LDS).  Same bar as the single-wave case: doubles == oracle in the same lane order, decisions == reference."""
+    gold = golden_io.load(name)
+    case = gold["case"]
+    rec = gold["chains"][0]
+    spec = model_spec.spec_from_golden(gold, rec)
+    if spec["model"] == "pois_glm" and lanes > 256:
+        pytest.skip("the GLM kernel is built for workgroups of at most 256 threads")
+    s = A.Sampler(spec, chains=3, seed=case["seed"], chain_offset=rec["chain"], lanes_per_chain=lanes)
+    li = s.launch_info()
+    assert li["lanes_per_chain"] == lanes and li["block_threads"] == lanes and li["grid_blocks"] == 3
+    o = oracle_lib.OracleChain(spec, case["seed"], rec["chain"], lanes=lanes)
+    gs, os_ = run_schedule(s, case["schedule"]), run_schedule(o, case["schedule"])
+    assert_chain_equals_oracle(s, 0, o, gs, os_)
+    assert s.info()["accepts"][:, 0].tolist() == rec["accepts"]      # the reference's decisions
+    assert int(s.diag()["uniforms"][0]) == rec["uniforms"]
+    o2 = oracle_lib.OracleChain(spec, case["seed"], rec["chain"] + 2, lanes=lanes)
+    assert_chain_equals_oracle(s, 2, o2, gs, run_schedule(o2, case["schedule"]))
+    s.close()
+
+
 @pytest.mark.parametrize("model,n_obs,G", [("normal", 777, 0), ("beta_bern", 1500, 0), ("hier_normal", 900, 6), ("pois_glm", 300, 0)])
 def test_many_chains_auto_geometry_vs_oracle(model, n_obs, G):
     """Seeded inputs, auto geometry, ragged N: a sample of chains (first, last, middle) bit-equal to the oracle."""
