@@ -112,6 +112,41 @@ def test_translated_closure_equals_hand_written_family_at_any_lane_count(name, b
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("closure,golden", [("bench_normal", "cfg2_full"), ("bench_bern", "cfg3_full"), ("bench_hier", "cfg4_full"), ("bench_glm", "cfg5_full")])
+def test_translated_closures_reproduce_the_reference_at_full_baseline_sizes(closure, golden):
+    """BASELINE.json configs[1..4] at their full data sizes, written as plain closures and TRANSLATED: one lane per chain
+    reproduces the seeded runs of the unmodified reference (first and last chain id of each config) bit for bit."""
+    gold = golden_io.load(golden)
+    src, arrays, meta = user_host.translated(closure)
+    for rec in gold["chains"]:
+        params, init, opts = [], [], []
+        for p in rec["params_completed"]:
+            ln = int(np.prod(p["dim"]))
+            params.append({"type": p["type"], "len": ln, "top": p["dim"][0], "multidim": 0 if p["dim"] == [1] else 1, "lower": p["lower"], "upper": p["upper"]})
+            init += p["init"]
+        spec = {"user": user_host.user_spec_part(src, arrays, meta), "params": params, "P": len(init), "init": init, "comp_opts": rec["comp_opts"]}
+        s = A.Sampler(spec, chains=2, seed=gold["case"]["seed"], chain_offset=rec["chain"], lanes_per_chain=1)
+        k = 0
+        for seg in gold["case"]["schedule"]:
+            if seg["op"] == "burn":
+                s.burn(seg["n"])
+            else:
+                got = s.sample(seg["n"], seg.get("thin", 1))
+                want = rec["samples"][k]
+                k += 1
+                w = np.array(want["draws"], dtype=np.float64)
+                assert np.ascontiguousarray(got[: w.shape[0], :, 0]).tobytes() == w.tobytes()
+                tot = np.zeros(got.shape[1])
+                for t in range(got.shape[0]):
+                    tot = tot + got[t, :, 0]
+                assert tot.tolist() == want["sum"]
+        assert s.state()[:, 0].tolist() == rec["final_state"]
+        assert s.info()["accepts"][:, 0].tolist() == rec["accepts"]
+        assert int(s.diag()["uniforms"][0]) == rec["uniforms"]
+        assert float(s.diag()["log_post"][0]) == rec["log_post"]
+        s.close()
+
+
 def test_translated_normal_samples_the_analytic_posterior():
     """Normal model with flat-ish priors: posterior mean of mu ~ data mean, E[sigma^2] ~ s^2 (n-1)/(n-3)."""
     spec, m, gold = spec_for("norm_post_derived")
