@@ -128,7 +128,8 @@ double model_work(const amwg_sampler *s, int G) {
   const double N = (double)s->d.n_obs;
   switch (s->model) {
     case AMWG_MODEL_NORMAL: return 9.0 * N;
-    case AMWG_MODEL_BETA_BERN: return (G == 1 ? 1.8 : 6.0) * N;      // one lane: scalar jump-table pass, one add per observation
+    case AMWG_MODEL_BETA_BERN:   // one lane: exact fast-forward over ~log2(N) binades (or the scalar jump-table pass, one add per observation)
+      return G == 1 ? (s->mc.exact_division ? 1.8 * N : 400.0 * (1.0 + std::log2(N + 2.0))) : 6.0 * N;
     case AMWG_MODEL_HIER_NORMAL: return 10.0 * N + 12.0 * s->d.G;
     case AMWG_MODEL_POIS_GLM: return 90.0 * N;
   }
@@ -602,7 +603,7 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
     }
   } else if (m->model == AMWG_MODEL_BETA_BERN) {
     std::vector<uint8_t> xb((size_t)N);
-    std::vector<uint32_t> xw((size_t)N / 32 + 2, 0u);
+    std::vector<uint32_t> xw(BetaBernModel::words(N), 0u), pre(BetaBernModel::words(N), 0u);
     bool invalid = false;
     for (int i = 0; i < N; ++i) {
       const bool one = m->x[i] == 1;
@@ -611,8 +612,12 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
       if (one) xw[(size_t)i >> 5] |= 1u << (i & 31);
     }
     mc.has_invalid = invalid ? 1 : 0;
+    for (size_t k = 1; k < pre.size(); ++k) pre[k] = pre[k - 1] + (uint32_t)__builtin_popcount(xw[k - 1]);   // ones among observations [0, 32k)
     uint8_t *dxb = nullptr;
-    uint32_t *dxw = nullptr;
+    uint32_t *dxw = nullptr, *dpre = nullptr;
+    TRYB(dev_alloc(s, &dpre, pre.size()));
+    HIPB(hipMemcpy(dpre, pre.data(), pre.size() * 4, hipMemcpyHostToDevice));
+    d.arr[0] = dpre;
     TRYB(dev_alloc(s, &dxb, (size_t)N));
     TRYB(dev_alloc(s, &dxw, xw.size()));
     if (N) HIPB(hipMemcpy(dxb, xb.data(), (size_t)N, hipMemcpyHostToDevice));

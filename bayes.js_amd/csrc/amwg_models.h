@@ -61,6 +61,95 @@ struct NormalModel {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Exact fast-forward of a sequential sum whose terms take only two values.
+//
+// The beta-Bernoulli pass is  acc = (...((acc + t_0) + t_1)...) + t_{N-1}  with every t_i one of two NEGATIVE constants
+// (log theta for x_i = 1, log(1-theta) for x_i = 0), each `+` rounding to nearest-even (mcmc.js log_post closure,
+// distributions.js:228-230).  Once acc is negative the magnitudes add; while |acc| stays inside one binade
+// [2^e, 2^(e+1)) its ulp u = 2^(e-52) is fixed, and  RN(|acc| + |c|) = |acc| + d_c * u  with  d_c = |c| rounded to a
+// multiple of u -- the same d_c for every addition of c in that binade, unless |c| sits exactly half-way between two
+// multiples (a tie, resolved by the parity of acc: then this binade is simply summed term by term).  So inside a binade
+// the significand of acc after m more observations is  A + n0(m)*d0 + n1(m)*d1  in exact integer arithmetic, n1 = number
+// of ones among them (prefix popcounts of the data, computed once on the host).  The code finds, by bisection on m, how
+// far the sum can go before the significand would reach 2^53, jumps there, performs the ONE addition that leaves the
+// binade with a real fp64 add (rounding on the coarser grid is the hardware's), and repeats: ~log2(N) binades instead of
+// N additions, the same bits as the sequential loop (tests compare the two on the device, chain by chain).
+struct BitData {
+  const uint32_t *w;     // observation i = bit (i & 31) of w[i >> 5]
+  const uint32_t *pre;   // pre[k] = number of ones among observations [0, 32k)
+  int n;
+};
+__device__ __forceinline__ int ones_before(const BitData &B, int m) {
+  const int k = m >> 5, b = m & 31;
+  uint32_t c = B.pre[k];
+  if (b) c += (uint32_t)__builtin_popcount(B.w[k] & ((1u << b) - 1u));
+  return (int)c;
+}
+__device__ inline double two_valued_sum(double acc, double l1, double l0, const BitData &B) {
+  const int N = B.n;
+  int i = 0;
+  auto step = [&](int idx) { acc = acc + (((B.w[idx >> 5] >> (idx & 31)) & 1u) ? l1 : l0); };
+  const uint64_t kMant = 0x000fffffffffffffull, kHidden = 0x0010000000000000ull;
+  const uint64_t b1 = f64_bits(-l1), b0 = f64_bits(-l0);
+  const int e1 = (int)(b1 >> 52), e0 = (int)(b0 >> 52);     // sign bit clear iff the addend is negative
+  // both addends negative, finite and normal; anything else (theta at a bound, NaN, ...) is summed term by term
+  if (!(l1 < 0 && l0 < 0 && e1 > 0 && e1 < 0x7ff && e0 > 0 && e0 < 0x7ff)) {
+    for (; i < N; ++i) step(i);
+    return acc;
+  }
+  const uint64_t m1 = (b1 & kMant) | kHidden, m0 = (b0 & kMant) | kHidden;
+  const int emax = e1 > e0 ? e1 : e0;
+  while (i < N) {
+    const uint64_t ab = f64_bits(-acc);
+    const int e = (int)(ab >> 52);                 // includes the sign bit of -acc: > 0x7ff when acc > 0
+    if (!(e >= emax + 1 && e < 0x7ff)) { step(i); ++i; continue; }   // acc not yet negative / not yet 2x the larger addend / inf / NaN
+    uint64_t A = (ab & kMant) | kHidden;           // |acc| = A * 2^(e - 1075), 2^52 <= A < 2^53
+    // d_c = |c| / u rounded to nearest; tie => fall back for this binade
+    uint64_t d1, d0;
+    bool tie = false;
+    {
+      const int s = e - e1;                          // >= 1
+      if (s >= 54) d1 = 0; else { const uint64_t r = m1 & ((1ull << s) - 1ull), h = 1ull << (s - 1); tie = tie || r == h; d1 = (m1 >> s) + (r > h ? 1u : 0u); }
+    }
+    {
+      const int s = e - e0;
+      if (s >= 54) d0 = 0; else { const uint64_t r = m0 & ((1ull << s) - 1ull), h = 1ull << (s - 1); tie = tie || r == h; d0 = (m0 >> s) + (r > h ? 1u : 0u); }
+    }
+    if (tie) {   // rare: sum this binade term by term
+      do { step(i); ++i; } while (i < N && (int)(f64_bits(-acc) >> 52) == e);
+      continue;
+    }
+    const uint64_t limit = (1ull << 53) - A;          // the significand may grow by strictly less than this
+    if (d1 == 0 && d0 == 0) break;                    // the addends are below half an ulp of acc: nothing changes any more
+    // T(m) = n0*d0 + n1*d1 over observations [i, m); products are formed only when they cannot exceed 2^53
+    const uint64_t k1max = d1 ? (limit - 1) / d1 : ~0ull, k0max = d0 ? (limit - 1) / d0 : ~0ull;
+    const int c1_i = ones_before(B, i);
+    uint64_t T_lo = 0;
+    auto below = [&](int m, uint64_t &T) {
+      const uint64_t n1 = (uint64_t)(ones_before(B, m) - c1_i), n0 = (uint64_t)(m - i) - n1;
+      if (n1 > k1max || n0 > k0max) return false;
+      T = n0 * d0 + n1 * d1;
+      return T < limit;
+    };
+    int lo = i, hi = N;
+    uint64_t T = 0;
+    if (below(N, T)) { lo = N; T_lo = T; }
+    else {
+      // first guess from the average increment, then bisection
+      while (hi - lo > 1) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (below(mid, T)) { lo = mid; T_lo = T; } else hi = mid;
+      }
+    }
+    A += T_lo;
+    acc = -bits_f64(((uint64_t)e << 52) | (A & kMant));
+    i = lo;
+    if (i < N) { step(i); ++i; }    // the addition that leaves the binade: a real fp64 add
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // x_i ~ bern(theta); theta ~ beta(a,b)                                    README.md:149-164
 // ld.bern(x,p) = log(x*p + (1-x)*(1-p)) is exactly log(p) for x=1 and log(1-p) for x=0
 // (1*p + 0*(1-p) = p + 0 = p), so the two logs are hoisted and selected per observation.
@@ -70,11 +159,20 @@ struct BetaBernModel {
   static constexpr int kDerived = 0;
   static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
   static constexpr int kUnroll = 8;
-  struct Pass { double l1, l0; const uint8_t *x; const uint32_t *bits; bool has_invalid; };
-  // one lane per chain reads the observations as bits through the scalar cache: no LDS copy
-  __host__ __device__ static size_t lds_bytes(int n_obs, int, int lanes) { return lanes == 1 ? 0 : (((size_t)n_obs + 15) & ~(size_t)15); }
+  struct Pass { double l1, l0; const uint8_t *x; const uint32_t *bits; bool has_invalid, fast_forward; BitData B; };
+  // one lane per chain: the observations as bits plus their prefix popcounts in LDS (two_valued_sum above); the
+  // term-by-term pass (exact_division = 1) reads the bits through the scalar cache instead
+  __host__ __device__ static size_t words(int n_obs) { return (size_t)n_obs / 32 + 2; }
+  __host__ __device__ static size_t lds_bytes(int n_obs, int, int lanes) {
+    return lanes == 1 ? ((2 * words(n_obs) * 4 + 15) & ~(size_t)15) : (((size_t)n_obs + 15) & ~(size_t)15);
+  }
   __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int lanes) {
-    if (lanes == 1) return;
+    if (lanes == 1) {
+      uint32_t *w = reinterpret_cast<uint32_t *>(smem), *pre = w + words(d.n_obs);
+      const uint32_t *src_pre = static_cast<const uint32_t *>(d.arr[0]);
+      for (int k = tid; k < (int)words(d.n_obs); k += nt) { w[k] = d.xw[k]; pre[k] = src_pre[k]; }
+      return;
+    }
     for (int i = tid; i < d.n_obs; i += nt) smem[i] = d.xb[i];
   }
   __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &) {
@@ -94,6 +192,10 @@ struct BetaBernModel {
     ps.x = smem;
     ps.bits = d.xw;
     ps.has_invalid = mc.has_invalid != 0;
+    ps.fast_forward = !mc.exact_division;
+    ps.B.w = reinterpret_cast<const uint32_t *>(smem);
+    ps.B.pre = ps.B.w + words(d.n_obs);
+    ps.B.n = d.n_obs;
     return ps;
   }
   template <bool FAST>
@@ -142,7 +244,11 @@ struct BetaBernModel {
   asm volatile("s_bitcmp1_b32 %3, 0\n\ts_cbranch_scc1 1f\n\tv_add_f64 %0, %0, %2\n\ts_branch 2f\n"        \
                "1:\n\tv_add_f64 %0, %0, %1\n2:"                                                        \
                : "+v"(acc) : "v"(l1), "v"(l0), "s"(w) : "scc")
-  __device__ __attribute__((noinline)) static double pass_one_lane(const Pass &ps, int n_obs, double acc) {
+  __device__ __forceinline__ static double pass_one_lane(const Pass &ps, int n_obs, double acc) {
+    if (ps.fast_forward) return two_valued_sum(acc, ps.l1, ps.l0, ps.B);
+    return pass_one_lane_sequential(ps, n_obs, acc);
+  }
+  __device__ __attribute__((noinline)) static double pass_one_lane_sequential(const Pass &ps, int n_obs, double acc) {
     const double l1 = ps.l1, l0 = ps.l0;
     // wave-uniform by construction; make that explicit so they live in SGPRs
     const uint64_t pbits = (uint64_t)reinterpret_cast<uintptr_t>(ps.bits);

@@ -97,7 +97,8 @@ typedef struct {
                               workgroup of several wavefronts, each a replica of the scalar logic; few chains, long data loops) */
   int32_t block_threads;   /* 0 = auto; else multiple of 64, <= 1024 */
   int32_t steps_per_launch;/* 0 = auto (one launch per burn/sample call up to 2^20 steps) */
-  int32_t exact_division;  /* 0 = default (hoisted-reciprocal division, bit-identical to IEEE, verified); 1 = plain IEEE '/' */
+  int32_t exact_division;  /* 0 = default: result-preserving shortcuts (hoisted-reciprocal division, fast-forward of two-valued sums), bit-identical
+                              to the plain schedule and tested against it; 1 = the reference's operation schedule: IEEE '/', term-by-term sums */
   int32_t reserved[3];
 } amwg_options;
 
