@@ -344,6 +344,40 @@ double amwg_uniform(uint64_t seed, uint64_t chain, uint64_t index) {
 
 }  // extern "C"
 
+// The data-only tables of two_valued_sum (amwg_models.h), back to back: the observations as bits (w), the ones before every
+// word (pre), and for each symbol the marks of the occurrences whose immediately preceding run of the OTHER symbol has odd
+// length (om1 / om0) with their per-word prefix counts (po1 / po0).
+static std::vector<uint32_t> two_valued_tables(const uint8_t *xb, int N) {
+  const size_t W = BetaBernModel::words(N);
+  std::vector<uint32_t> tab(6 * W, 0u);
+  for (int i = 0; i < N; ++i) if (xb[i]) tab[(size_t)i >> 5] |= 1u << (i & 31);
+  for (size_t k = 1; k < W; ++k) tab[W + k] = tab[W + k - 1] + (uint32_t)__builtin_popcount(tab[k - 1]);
+  for (int sym = 1; sym >= 0; --sym) {
+    uint32_t *om = tab.data() + (sym ? 2 : 4) * W, *po = om + W;
+    int run = 0;   // length of the current run of the other symbol
+    for (int i = 0; i < N; ++i) {
+      const int v = xb[i] ? 1 : 0;
+      if (v == sym) { if (run & 1) om[(size_t)i >> 5] |= 1u << (i & 31); run = 0; } else ++run;
+    }
+    for (size_t k = 1; k < W; ++k) po[k] = po[k - 1] + (uint32_t)__builtin_popcount(om[k - 1]);
+  }
+  return tab;
+}
+
+// tests only: thread j sums the same bit sequence from acc0[j] with addends l1[j], l0[j], once with two_valued_sum and
+// once term by term
+__global__ void two_valued_check_kernel(const uint32_t *tab, int N, int64_t m, const double *acc0, const double *l1, const double *l0,
+                                        double *out_ff, double *out_seq) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const size_t W = BetaBernModel::words(N);
+  BitData B{tab, tab + W, tab + 2 * W, tab + 3 * W, tab + 4 * W, tab + 5 * W, N};
+  out_ff[j] = two_valued_sum(acc0[j], l1[j], l0[j], B);
+  double acc = acc0[j];
+  for (int i = 0; i < N; ++i) acc = acc + (((tab[i >> 5] >> (i & 31)) & 1u) ? l1[j] : l0[j]);
+  out_seq[j] = acc;
+}
+
 // ---- pieces of construction shared by the built-in and the translated models
 #define TRYB(x) do { int rc_ = (x); if (rc_ != AMWG_OK) return rc_; } while (0)
 #define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(AMWG_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
@@ -612,12 +646,12 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
       if (one) xw[(size_t)i >> 5] |= 1u << (i & 31);
     }
     mc.has_invalid = invalid ? 1 : 0;
-    for (size_t k = 1; k < pre.size(); ++k) pre[k] = pre[k - 1] + (uint32_t)__builtin_popcount(xw[k - 1]);   // ones among observations [0, 32k)
+    const std::vector<uint32_t> tab = two_valued_tables(xb.data(), N);
     uint8_t *dxb = nullptr;
-    uint32_t *dxw = nullptr, *dpre = nullptr;
-    TRYB(dev_alloc(s, &dpre, pre.size()));
-    HIPB(hipMemcpy(dpre, pre.data(), pre.size() * 4, hipMemcpyHostToDevice));
-    d.arr[0] = dpre;
+    uint32_t *dxw = nullptr, *dtab = nullptr;
+    TRYB(dev_alloc(s, &dtab, tab.size()));
+    HIPB(hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    d.arr[0] = dtab;
     TRYB(dev_alloc(s, &dxb, (size_t)N));
     TRYB(dev_alloc(s, &dxw, xw.size()));
     if (N) HIPB(hipMemcpy(dxb, xb.data(), (size_t)N, hipMemcpyHostToDevice));
@@ -1006,6 +1040,34 @@ int amwg_fp64_peak(int32_t device, double *lane_ops_per_s) {
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(dout);
   *lane_ops_per_s = (double)blocks * threads * (double)iters * 64.0 / (best * 1e-3);
+  return AMWG_OK;
+}
+
+int amwg_two_valued_sum_check(int32_t device, const double *x, int32_t n, int64_t m, const double *acc0, const double *l1, const double *l0,
+                              double *out_fast_forward, double *out_term_by_term) {
+  if (!x || !acc0 || !l1 || !l0 || !out_fast_forward || !out_term_by_term || n < 0 || m < 0) return fail(AMWG_EINVAL, "amwg_two_valued_sum_check: bad argument");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1) return fail(AMWG_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
+  HIP_TRY(hipSetDevice(device));
+  std::vector<uint8_t> xb((size_t)n);
+  for (int i = 0; i < n; ++i) xb[i] = x[i] == 1 ? 1 : 0;
+  const std::vector<uint32_t> tab = two_valued_tables(xb.data(), n);
+  uint32_t *dtab = nullptr;
+  double *d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dtab), tab.size() * 4));
+  HIP_TRY(hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  const double *src[3] = {acc0, l1, l0};
+  for (int k = 0; k < 5; ++k) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d[k]), m ? (size_t)m * 8 : 8));
+    if (k < 3 && m) HIP_TRY(hipMemcpy(d[k], src[k], (size_t)m * 8, hipMemcpyHostToDevice));
+  }
+  if (m) hipLaunchKernelGGL(two_valued_check_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, 0, dtab, n, m, d[0], d[1], d[2], d[3], d[4]);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out_fast_forward, d[3], (size_t)m * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_term_by_term, d[4], (size_t)m * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(dtab);
+  for (int k = 0; k < 5; ++k) (void)hipFree(d[k]);
   return AMWG_OK;
 }
 

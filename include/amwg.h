@@ -223,6 +223,11 @@ double amwg_pow(double x, double y);   /* bit-identical to V8 Math.pow */
  * 6 laplace 7 gamma 8 invgamma 9 lnorm 10 pareto 11 t 12 weibull 13 logis 14 exp 15 binom 16 nbinom 17 hyper
  * 18 lgamma 19 lfactorial 20 lchoose 21 lbeta): host evaluation of the kernel's own source, and the same on
  * the device for n records of {id, x, a, b, c}. */
+/* tests only: out_fast_forward[j] = the two-valued sequential sum of csrc/amwg_models.h (exact fast-forward over binades) and
+ * out_term_by_term[j] = the plain loop, both on the device, over the n observations x (0/1) from acc0[j] with addends
+ * l1[j] (x_i = 1) and l0[j] (x_i = 0); j < m. */
+int amwg_two_valued_sum_check(int32_t device, const double *x, int32_t n, int64_t m, const double *acc0, const double *l1, const double *l0,
+                              double *out_fast_forward, double *out_term_by_term);
 double amwg_ld_host(int32_t id, double x, double a, double b, double c);
 int amwg_ld_device(int32_t device, int64_t n, const double *records, double *out);
 

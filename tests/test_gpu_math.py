@@ -89,3 +89,37 @@ def test_device_ld_functions_and_pow_equal_the_reference_goldens():
     got = A.device_eval(13, p[:, 0], p[:, 1])
     ok = (got.view(np.uint64) == p[:, 2].view(np.uint64)) | (np.isnan(got) & np.isnan(p[:, 2]))
     assert ok.all(), p[~ok][:3]
+
+
+def test_two_valued_sum_fast_forward_is_exact_including_ties():
+    """csrc/amwg_models.h two_valued_sum against the plain loop on the device, bit for bit: random addends, and addends whose
+    significands end in z zero bits, which tie (sit exactly half-way between two multiples of ulp(acc)) in the binade where
+    acc is 2^(z+1) times larger -- for large z a long binade, each of the four tie cases (none / one with even or odd other
+    increment / both), starting accumulators of either sign and magnitude."""
+    import ctypes as C
+    L = A.lib()
+    rng = np.random.default_rng(11)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for n, p_one in ((100000, 0.3), (5000, 0.5), (4099, 0.02), (777, 0.97), (64, 0.5), (1, 0.5), (0, 0.5)):
+        x = (rng.uniform(size=n) < p_one).astype(np.float64)
+        m = 4096
+        l1 = -np.exp(rng.uniform(-12, 3, m))
+        l0 = -np.exp(rng.uniform(-12, 3, m))
+        # clear z trailing bits of the significands (z differs per addend): ties in the binade 2^(z+1) above the addend
+        z1, z0 = rng.integers(0, 30, m), rng.integers(0, 30, m)
+        u1, u0 = l1.view(np.uint64).copy(), l0.view(np.uint64).copy()
+        u1 = (u1 >> z1.astype(np.uint64)) << z1.astype(np.uint64)
+        u0 = (u0 >> z0.astype(np.uint64)) << z0.astype(np.uint64)
+        u1 |= (np.uint64(1) << z1.astype(np.uint64)) * (rng.integers(0, 2, m).astype(np.uint64))     # sometimes make bit z the lowest set bit
+        u0 |= (np.uint64(1) << z0.astype(np.uint64)) * (rng.integers(0, 2, m).astype(np.uint64))
+        l1, l0 = u1.view(np.float64).copy(), u0.view(np.float64).copy()
+        l1[:8] = [-np.inf, np.nan, 0.0, -0.0, 1.5, -5e-324, -1e-310, -1.0]          # the term-by-term fallback cases
+        l0[8:12] = [-np.inf, np.nan, 0.0, 2.0]
+        l1[12:16], l0[12:16] = [-1.0, -0.5, -0.75, -3.0], [-0.5, -0.5, -0.25, -3.0]   # power-of-two-ish addends: many ties
+        acc0 = np.where(rng.uniform(size=m) < 0.5, rng.normal(0, 3, m), -np.exp(rng.uniform(-5, 25, m)))
+        acc0[16:20] = [0.0, -0.0, 1e300, -1e300]
+        ff, seq = np.empty(m), np.empty(m)
+        assert L.amwg_two_valued_sum_check(0, dp(np.ascontiguousarray(x)), n, m, dp(acc0), dp(l1), dp(l0), dp(ff), dp(seq)) == 0
+        same = (ff.view(np.uint64) == seq.view(np.uint64)) | (np.isnan(ff) & np.isnan(seq))
+        bad = np.where(~same)[0]
+        assert bad.size == 0, (n, bad[:5], acc0[bad[:5]], l1[bad[:5]].view(np.uint64), l0[bad[:5]].view(np.uint64), ff[bad[:5]], seq[bad[:5]])
