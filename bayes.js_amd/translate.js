@@ -1136,22 +1136,22 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
       if (x.k === 'Id' && x.name === name) reads++;
     });
     // occurrences: one per declaration-free assignment target, plus the final return
-    let writes = 0, decls = 0, constInit = true;
+    let writes = 0, decls = 0;
     walk(body, (x) => {
-      if (x.k === 'Assign' && x.target.k === 'Id' && x.target.name === name) { writes++; if (x.op === '=' && idsOf(x.value).size) constInit = false; }
-      if (x.k === 'VarDecl') x.decls.forEach((d) => { if (d.name === name) { decls++; if (d.init && idsOf(d.init).size) constInit = false; } });
+      if (x.k === 'Assign' && x.target.k === 'Id' && x.target.name === name) writes++;
+      if (x.k === 'VarDecl') x.decls.forEach((d) => { if (d.name === name) decls++; });
     });
     let returns = 0;
     walk(body, (x) => { if (x.k === 'Return' && x.arg && idsOf(x.arg).has(name)) returns++; });
     // `acc = expr` (also as the declaration's initialiser) is fine anywhere outside lane-split loops: lane 0 takes expr, the
     // other lanes restart from 0, which is what overwriting the running total means for the sum over lanes
-    if (ok && (constInit || true) && decls <= 1 && reads === writes + returns && returns === 1) { this.acc = name; this.split = true; }
+    if (ok && decls <= 1 && reads === writes + returns && returns === 1) { this.acc = name; this.split = true; }
   }
   // names referenced at the top level of the function (outside every loop): lane-split loops may not leak into them
   this.topLevelRefs = new Set();
   const scanTop = (list) => {
     for (const st of list) {
-      if (st.k === 'For') { if (st.init && st.init.k === 'ExprStmt') idsOf(st.init).forEach((n) => 0); continue; }
+      if (st.k === 'For') continue;          // everything inside a loop statement counts as "inside the loop"
       if (st.k === 'Block') { scanTop(st.body); continue; }
       if (st.k === 'If') { idsOf(st.test).forEach((n) => this.topLevelRefs.add(n)); scanTop([st.cons]); if (st.alt) scanTop([st.alt]); continue; }
       if (st.k === 'VarDecl') { st.decls.forEach((d) => { if (d.init) idsOf(d.init).forEach((n) => this.topLevelRefs.add(n)); }); continue; }
