@@ -41,8 +41,8 @@ class Options(C.Structure):
 
 class UserModel(C.Structure):
     _fields_ = [("source", C.c_char_p), ("n_arrays", C.c_int32), ("arrays", C.POINTER(C.POINTER(C.c_double))),
-                ("array_len", C.POINTER(C.c_int64)), ("array_type", C.POINTER(C.c_int32)), ("n_derived", C.c_int32), ("lds_bytes", C.c_int32),
-                ("parallel", C.c_int32), ("max_threads", C.c_int32), ("work_per_eval", C.c_double)]
+                ("array_len", C.POINTER(C.c_int64)), ("array_type", C.POINTER(C.c_int32)), ("n_derived", C.c_int32), ("lds_bytes", C.c_int32), ("lds_bytes_one_lane", C.c_int32),
+                ("parallel", C.c_int32), ("max_threads", C.c_int32), ("work_per_eval", C.c_double), ("work_one_lane", C.c_double)]
 
 
 EXPORTS = ["amwg_two_valued_sum_check", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
@@ -165,8 +165,10 @@ class Sampler:
             keep += [ptrs, lens, types]
             um.arrays, um.array_len, um.array_type = ptrs, lens, types
             um.n_derived, um.lds_bytes = int(user.get("n_derived", 0)), int(user.get("lds_bytes", 0))
+            um.lds_bytes_one_lane = int(user.get("lds_bytes_one_lane", 0))
             um.parallel, um.max_threads = int(user.get("parallel", 0)), int(user.get("max_threads", 0))
             um.work_per_eval = float(user.get("work_per_eval", 0.0))
+            um.work_one_lane = float(user.get("work_one_lane", 0.0))
         n = len(spec["params"])
         pa = (ParamDesc * n)()
         TYPE = {"real": 0, "int": 1, "binary": 2}

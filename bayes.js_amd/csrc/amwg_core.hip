@@ -27,7 +27,7 @@ using namespace amwg;
 // together with the very same step kernel source the built-in models are compiled from.
 extern "C" {
 extern const char amwg_hdr_stdint[], amwg_hdr_types[], amwg_hdr_math[], amwg_hdr_div[], amwg_hdr_ld[], amwg_hdr_philox[],
-    amwg_hdr_kernel[], amwg_hdr_user[];
+    amwg_hdr_kernel[], amwg_hdr_user[], amwg_hdr_twoval[];
 }
 
 namespace {
@@ -133,13 +133,14 @@ double model_work(const amwg_sampler *s, int G) {
     case AMWG_MODEL_HIER_NORMAL: return 10.0 * N + 12.0 * s->d.G;
     case AMWG_MODEL_POIS_GLM: return 90.0 * N;
   }
+  if (G == 1 && s->user_work_one_lane > 0) return s->user_work_one_lane;   // translated closure with a two-valued sum: fast-forwarded
   return s->user_work > 0 ? s->user_work : 1e6;   // translated closure: the translator's estimate
 }
 
 int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const amwg_options &o = s->opt;
   auto layout = [&](int bt, int G) {
-    const size_t data_bytes = s->user ? (size_t)s->user_lds : model_lds_bytes(s->model, s->d.n_obs, s->d.G, G);
+    const size_t data_bytes = s->user ? (size_t)(G == 1 ? s->user_lds_one_lane : s->user_lds) : model_lds_bytes(s->model, s->d.n_obs, s->d.G, G);
     return G > 64 ? lds_layout(data_bytes, s->P, G / 64, s->pl.max_top, true) : lds_layout(data_bytes, s->P, bt / G, s->pl.max_top);
   };
   const int max_bt = s->user ? s->user_max_threads : model_max_threads(s->model);
@@ -155,7 +156,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     // translated closures: with one lane per chain every data index is wave-uniform and the compiler moves the
     // per-observation integer logic to the scalar unit, which issues 4x slower than the vector lanes (measured 2.5x on
     // the beta-Bernoulli closure); two lanes per chain keep it on the vector path at no measurable cost elsewhere
-    if (s->user && s->user_parallel && !o.lanes_per_chain && G == 1) continue;
+    if (s->user && s->user_parallel && !o.lanes_per_chain && G == 1 && !(s->user_work_one_lane > 0)) continue;
     int pick = 0;
     for (int bi = 0; bi < 5; ++bi) {   // largest workgroup with >= one workgroup per CU, else the smallest that fits
       const int bt = bts[bi];
@@ -348,7 +349,7 @@ double amwg_uniform(uint64_t seed, uint64_t chain, uint64_t index) {
 // word (pre), and for each symbol the marks of the occurrences whose immediately preceding run of the OTHER symbol has odd
 // length (om1 / om0) with their per-word prefix counts (po1 / po0).
 static std::vector<uint32_t> two_valued_tables(const uint8_t *xb, int N) {
-  const size_t W = BetaBernModel::words(N);
+  const size_t W = two_valued_words(N);
   std::vector<uint32_t> tab(6 * W, 0u);
   for (int i = 0; i < N; ++i) if (xb[i]) tab[(size_t)i >> 5] |= 1u << (i & 31);
   for (size_t k = 1; k < W; ++k) tab[W + k] = tab[W + k - 1] + (uint32_t)__builtin_popcount(tab[k - 1]);
@@ -499,12 +500,12 @@ static std::string user_program(const char *source, int lanes, int block) {
 
 static int compile_user(const char *source, int lanes, int block, const char *arch, std::vector<char> *code) {
   static const char *names[] = {"amwg_stdint.h", "amwg_types.h", "amwg_math.h", "amwg_div.h", "amwg_ld.h", "amwg_philox.h",
-                                "amwg_kernel.h", "amwg_user.h"};
+                                "amwg_kernel.h", "amwg_user.h", "amwg_twoval.h"};
   const char *texts[] = {amwg_hdr_stdint, amwg_hdr_types, amwg_hdr_math, amwg_hdr_div, amwg_hdr_ld, amwg_hdr_philox,
-                         amwg_hdr_kernel, amwg_hdr_user};
+                         amwg_hdr_kernel, amwg_hdr_user, amwg_hdr_twoval};
   const std::string prog_src = user_program(source, lanes, block);
   hiprtcProgram prog = nullptr;
-  hiprtcResult r = hiprtcCreateProgram(&prog, prog_src.c_str(), "amwg_user_model.hip", 8, texts, names);
+  hiprtcResult r = hiprtcCreateProgram(&prog, prog_src.c_str(), "amwg_user_model.hip", 9, texts, names);
   if (r != HIPRTC_SUCCESS) return fail(AMWG_EHIP, "hiprtcCreateProgram failed: %s", hiprtcGetErrorString(r));
   const std::string arch_opt = std::string("--offload-arch=") + arch;
   // same floating-point contract as the Makefile: one rounding per operation, no fused contraction
@@ -707,9 +708,11 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
   s->user = true;
   s->D = m->n_derived;
   s->user_lds = (m->lds_bytes + 15) & ~15;
+  s->user_lds_one_lane = m->lds_bytes_one_lane > 0 ? ((m->lds_bytes_one_lane + 15) & ~15) : s->user_lds;
   s->user_parallel = m->parallel ? 1 : 0;
   s->user_max_threads = max_threads;
   s->user_work = m->work_per_eval;
+  s->user_work_one_lane = m->work_one_lane;
   s->C = options->chains;
   s->n_params = n_params;
   s->device = options->device;

@@ -261,9 +261,11 @@ static napi_value CreateUser(napi_env env, napi_callback_info info) {
   }
   um.n_derived = (int32_t)prop_i64(env, a[0], "n_derived", 0);
   um.lds_bytes = (int32_t)prop_i64(env, a[0], "lds_bytes", 0);
+  um.lds_bytes_one_lane = (int32_t)prop_i64(env, a[0], "lds_bytes_one_lane", 0);
   um.parallel = (int32_t)prop_i64(env, a[0], "parallel", 0);
   um.max_threads = (int32_t)prop_i64(env, a[0], "max_threads", 0);
   um.work_per_eval = prop_double(env, a[0], "work_per_eval", 0.0);
+  um.work_one_lane = prop_double(env, a[0], "work_one_lane", 0.0);
   amwg_param_desc *pd; amwg_comp_opt *co; uint32_t n_params; const double *init; amwg_options op;
   if (!parse_common(env, a, &pd, &co, &n_params, &init, &op)) { free(src); return NULL; }
   amwg_sampler *s = NULL;

@@ -12,3 +12,4 @@ AMWG_TEXT(amwg_hdr_ld, "amwg_ld.h");
 AMWG_TEXT(amwg_hdr_philox, "amwg_philox.h");
 AMWG_TEXT(amwg_hdr_kernel, "amwg_kernel.h");
 AMWG_TEXT(amwg_hdr_user, "amwg_user.h");
+AMWG_TEXT(amwg_hdr_twoval, "amwg_twoval.h");

@@ -34,8 +34,9 @@ struct amwg_sampler {
   // translated closure (amwg_create_user): hiprtc module function instead of a built-in kernel
   bool user = false;
   int D = 0;                       // derived quantities recorded after the P components
-  int user_lds = 0, user_parallel = 0, user_max_threads = 1024;
+  int user_lds = 0, user_lds_one_lane = 0, user_parallel = 0, user_max_threads = 1024;
   double user_work = 0;            // translator's estimate of the instructions of one log_post evaluation
+  double user_work_one_lane = 0;   // the same with one lane per chain when that enables a fast-forwarded sum (0 = n/a)
   hipFunction_t user_fn = nullptr;
   hipModule_t user_module = nullptr;
   // last call

@@ -3,6 +3,7 @@
 #pragma once
 #include "amwg_div.h"
 #include "amwg_ld.h"
+#include "amwg_twoval.h"
 #include "amwg_types.h"
 
 namespace amwg {
@@ -66,6 +67,15 @@ AMWG_HD double ld_binom_pre(double x, double size, double prob, double lchoose_s
   if (x > size || x < 0) return -kInf;
   if (prob == 0 || prob == 1) return (size * prob) == x ? 0.0 : -kInf;
   return lchoose_size_x + x * log_v8(prob) + (size - x) * log_v8(1 - prob);
+}
+
+// `for (i = 0; i < n; i++) lp += ld.bern(x[i], p)` over a 0/1 data array with one lane per chain: the six tables of
+// amwg_twoval.h for that array (built by the translator, stored back to back as 32-bit words) and the exact fast-forward
+AMWG_HD double bern_loop_one_lane(double acc, const BernInv &k, const int32_t *tab, int n) {
+  const size_t W = two_valued_words(n);
+  const uint32_t *t = reinterpret_cast<const uint32_t *>(tab);
+  const BitData B{t, t + W, t + 2 * W, t + 3 * W, t + 4 * W, t + 5 * W, n};
+  return two_valued_sum(acc, k.l1, k.l0, B);
 }
 
 // JavaScript operators that differ from C++

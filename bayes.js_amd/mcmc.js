@@ -220,8 +220,8 @@ function AmwgSampler(params, log_post, data, options) {
       lds_budget: options.lds_budget, max_threads: options.max_threads, unroll: options.unroll });
     this.derived = tr.derived;
     this.translation = tr;
-    user = { source: tr.source, arrays: tr.arrays, array_types: tr.array_types, n_derived: tr.derived.length, lds_bytes: tr.lds_bytes, parallel: tr.parallel,
-             max_threads: tr.max_threads, work_per_eval: tr.work_per_eval };
+    user = { source: tr.source, arrays: tr.arrays, array_types: tr.array_types, n_derived: tr.derived.length, lds_bytes: tr.lds_bytes, lds_bytes_one_lane: tr.lds_bytes_one_lane, parallel: tr.parallel,
+             max_threads: tr.max_threads, work_per_eval: tr.work_per_eval, work_one_lane: tr.work_one_lane };
   }
   this.PR = this.P + this.derived.length;   // values per recorded draw
 

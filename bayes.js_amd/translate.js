@@ -729,6 +729,30 @@ Translator.prototype.elementsOf = function (v, what) {
   this.fail(what + ' needs a one-dimensional array, got a ' + this.describe(v));
 };
 
+// The six data-only tables of csrc/amwg_twoval.h for a 0/1 array, back to back, as signed 32-bit words (i32 storage).
+Translator.prototype.twoValuedTables = function (id) {
+  const key = '#aux:twoval:' + id;
+  if (this.arrayIds.has(key)) return this.arrayIds.get(key);
+  const x = this.arrays[id].flat, N = x.length, W = Math.floor(N / 32) + 2;
+  const tab = new Uint32Array(6 * W);
+  for (let i = 0; i < N; i++) if (x[i] === 1) tab[i >> 5] |= (1 << (i & 31)) >>> 0;
+  const popc = (v) => { v = v - ((v >>> 1) & 0x55555555); v = (v & 0x33333333) + ((v >>> 2) & 0x33333333); return (((v + (v >>> 4)) & 0x0f0f0f0f) * 0x01010101) >>> 24; };
+  for (let k = 1; k < W; k++) tab[W + k] = tab[W + k - 1] + popc(tab[k - 1]);
+  for (const sym of [1, 0]) {
+    const om = (sym ? 2 : 4) * W, po = om + W;
+    let run = 0;
+    for (let i = 0; i < N; i++) {
+      if (x[i] === sym) { if (run & 1) tab[om + (i >> 5)] |= (1 << (i & 31)) >>> 0; run = 0; } else run++;
+    }
+    for (let k = 1; k < W; k++) tab[po + k] = tab[po + k - 1] + popc(tab[om + k - 1]);
+  }
+  const signed = new Array(6 * W);
+  for (let k = 0; k < 6 * W; k++) signed[k] = tab[k] | 0;
+  const out = this.registerArray(key, signed);
+  if (this.arrays[out].type === 1) { this.arrays[out].type = 2; this.arrays[out].ctype = 'int32_t'; this.arrays[out].esize = 4; this.arrays[out].is01 = false; }   // always i32
+  return out;
+};
+
 // a named temporary for a value that is used twice (keeps the evaluation single, as in JS)
 Translator.prototype.temp = function (code) {
   if (/^[\w.]+$/.test(code) || /^S\(\d+\)$/.test(code)) return code;
@@ -1047,6 +1071,23 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
       loop.push('  }');
       loop.push('  for (; it_ < n_; ++it_) { const int ' + iv + ' = i0_ + it_ * G; ' + bodyText + ' ' + acc + ' += ' + this.asD(term) + '; }');
       const head = ['  const int i0_ = ' + this.asI(startV) + ' + sub, n_ = (' + boundV.code + (canon.le ? ' + 1' : '') + ' - i0_ + G - 1) / G;'];
+      // `for (i = 0; i < x.length; i++) lp += ld.bern(x[i], p)` over a 0/1 array: with one lane per chain the sequential sum has
+      // two distinct addends and is fast-forwarded exactly (csrc/amwg_twoval.h); with G > 1 lanes the ordinary split loop runs
+      const mb = simple && pend.length === 0 && /^ld_bern_inv01\(A(\d+)\[v_(\w+)\], (k\d+)\)$/.exec(term.code);
+      if (mb && mb[2] === canon.name && startV.cst === 0 && !canon.le && boundV.cst === this.arrays[Number(mb[1])].flat.length && !this.opts.no_fast_forward) {
+        const tabId = this.twoValuedTables(Number(mb[1]));
+        s.fastForwardOneLane = true;     // workEstimate(true) prices this loop as ~log2(n) binades
+        this.oneLaneWork = 1;
+        out.push(indent + '{');
+        for (const ln of L.preamble) out.push(indent + '  ' + ln);
+        out.push(indent + '  if constexpr (G == 1) {');
+        out.push(indent + '    ' + acc + ' = bern_loop_one_lane(' + acc + ', ' + mb[3] + ', A' + tabId + ', ' + boundV.cst + ');');
+        out.push(indent + '  } else {');
+        for (const ln of head.concat(loop)) out.push(indent + '  ' + ln);
+        out.push(indent + '  }');
+        out.push(indent + '}');
+        return;
+      }
       this.emitSplit(out, indent, L.preamble, head, loop);
       return;
     }
@@ -1187,6 +1228,7 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
     this.tmp = 0;
     this.nSplit = 0;
     this.heavyLoop = false;
+    this.oneLaneWork = 0;
     lines = [];
     for (const st of stmts) this.stmt(st, lines, '    ', { inLoop: false, split: false });
     if (!last || last.k !== 'Return') this.fail('log_post must end with a return statement');
@@ -1209,12 +1251,12 @@ Translator.prototype.run = function () {
   // drop data arrays the generated code never reads (constants folded away), renumber the rest
   {
     const used = new Set();
-    for (const ln of body.concat(this.helperSources)) { const re = /\bA(\d+)\[/g; let m; while ((m = re.exec(ln))) used.add(Number(m[1])); }
+    for (const ln of body.concat(this.helperSources)) { const re = /\bA(\d+)\b/g; let m; while ((m = re.exec(ln))) used.add(Number(m[1])); }
     const remap = new Map();
     const kept = [];
     this.arrays.forEach((a, j) => { if (used.has(j)) { remap.set(j, kept.length); kept.push(a); } });
     if (kept.length !== this.arrays.length) {
-      const ren = (ln) => ln.replace(/\bA(\d+)\[/g, (all, j) => 'A' + remap.get(Number(j)) + '[');
+      const ren = (ln) => ln.replace(/\bA(\d+)\b/g, (all, j) => 'A' + remap.get(Number(j)));
       body = body.map(ren);
       this.helperSources = this.helperSources.map(ren);
       this.arrays = kept;
@@ -1226,12 +1268,21 @@ Translator.prototype.run = function () {
   // 160 KB per CU, minus the per-chain stepper state of ~128 chains (24 B per component), minus slack
   const stateBytes = Math.min(24 * (this.P | 1) * 128, 65536);
   const budget = this.opts.lds_budget === undefined ? 163840 - 8192 - stateBytes : this.opts.lds_budget;
-  let off = 0;
-  const plan = this.arrays.map((a) => {
-    const bytes = a.flat.length * a.esize;
-    if (bytes > 0 && off + bytes <= budget) { const o = off; off += (bytes + 15) & ~15; return { lds: true, off: o }; }
-    return { lds: false, off: 0 };
-  });
+  const makePlan = (order) => {
+    let off = 0;
+    const plan = this.arrays.map(() => ({ lds: false, off: 0 }));
+    for (const j of order) {
+      const bytes = this.arrays[j].flat.length * this.arrays[j].esize;
+      if (bytes > 0 && off + bytes <= budget) { plan[j] = { lds: true, off }; off += (bytes + 15) & ~15; }
+    }
+    return { plan, bytes: off };
+  };
+  const all = this.arrays.map((a, j) => j);
+  // two plans: G > 1 lanes per chain (arrays in order of first use), and ONE lane per chain, where a fast-forwarded loop reads
+  // its bit tables instead of the observations (tables first)
+  const PG = makePlan(all), plan = PG.plan, off = PG.bytes;
+  const isTab = (j) => this.arrays[j].key.indexOf('#aux:twoval:') === 0;
+  const P1 = this.oneLaneWork ? makePlan(all.filter(isTab).concat(all.filter((j) => !isTab(j)))) : PG;
   const D = this.derived.length;
   const maxThreads = this.opts.max_threads || (this.heavyLoop ? 256 : 1024);
   const src = [];
@@ -1243,18 +1294,26 @@ Translator.prototype.run = function () {
   src.push('  static constexpr int kDerived = ' + D + ';');
   src.push('  static constexpr int kMaxThreads = ' + maxThreads + ';');
   src.push('#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)');
-  src.push('  __host__ __device__ static size_t lds_bytes(int, int, int) { return ' + off + '; }');
-  src.push('  __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int) {');
-  this.arrays.forEach((a, j) => {
-    if (plan[j].lds) src.push('    { ' + a.ctype + ' *dst = reinterpret_cast<' + a.ctype + ' *>(smem + ' + plan[j].off + '); const ' + a.ctype + ' *src = static_cast<const ' + a.ctype + ' *>(d.arr[' + j + ']); for (int i = tid; i < ' + a.flat.length + '; i += nt) dst[i] = src[i]; }');
-  });
+  const copies = (pl) => this.arrays.map((a, j) => pl[j].lds ? '{ ' + a.ctype + ' *dst = reinterpret_cast<' + a.ctype + ' *>(smem + ' + pl[j].off + '); const ' + a.ctype + ' *src = static_cast<const ' + a.ctype + ' *>(d.arr[' + j + ']); for (int i = tid; i < ' + a.flat.length + '; i += nt) dst[i] = src[i]; }' : '').filter((x) => x);
+  src.push('  __host__ __device__ static size_t lds_bytes(int, int, int lanes) { return lanes == 1 ? ' + P1.bytes + ' : ' + off + '; }');
+  src.push('  __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int lanes) {');
+  if (P1 === PG) for (const c of copies(plan)) src.push('    ' + c);
+  else {
+    src.push('    if (lanes == 1) {');
+    for (const c of copies(P1.plan)) src.push('      ' + c);
+    src.push('    } else {');
+    for (const c of copies(plan)) src.push('      ' + c);
+    src.push('    }');
+  }
   src.push('  }');
   src.push('#endif');
   src.push('  template <int G, bool DERIVE>');
   src.push('  AMWG_HD static double eval(const StateView &S, const DataRef &d, const unsigned char *smem, int sub, double *dv) {');
   src.push('#if defined(__HIP_DEVICE_COMPILE__)');
   this.arrays.forEach((a, j) => {
-    src.push('    const ' + a.ctype + ' *A' + j + ' = ' + (plan[j].lds ? 'reinterpret_cast<const ' + a.ctype + ' *>(smem + ' + plan[j].off + ')' : 'static_cast<const ' + a.ctype + ' *>(d.arr[' + j + '])') + ';');
+    const where = (pl) => pl[j].lds ? 'reinterpret_cast<const ' + a.ctype + ' *>(smem + ' + pl[j].off + ')' : 'static_cast<const ' + a.ctype + ' *>(d.arr[' + j + '])';
+    const one = where(P1.plan), many = where(plan);
+    src.push('    const ' + a.ctype + ' *A' + j + ' = ' + (one === many ? many : '(G == 1) ? ' + one + ' : ' + many) + ';');
   });
   src.push('#else');
   this.arrays.forEach((a, j) => { src.push('    const ' + a.ctype + ' *A' + j + ' = static_cast<const ' + a.ctype + ' *>(d.arr[' + j + ']);'); });
@@ -1271,9 +1330,12 @@ Translator.prototype.run = function () {
     array_keys: this.arrays.map((a) => a.key),
     derived: this.derived.slice(),
     lds_bytes: off,
+    lds_bytes_one_lane: P1.bytes,
     parallel: parallel ? 1 : 0,
     max_threads: maxThreads,
     work_per_eval: this.workEstimate(),
+    // instruction estimate with ONE lane per chain when that enables the exact fast-forward of a two-valued sum (0 = no such loop)
+    work_one_lane: this.oneLaneWork ? this.workEstimate(true) : 0,
     P: this.P,
   };
 };
@@ -1281,7 +1343,7 @@ Translator.prototype.run = function () {
 // Rough instruction count of one evaluation (steers only the lanes-per-chain choice of the host library): operators 1,
 // Math.exp/log 30, pow 80, ld.norm 10 (hoisted form), other ld.* 70, loops multiply by their trip count when it is a
 // translation-time constant (else by 8).
-Translator.prototype.workEstimate = function () {
+Translator.prototype.workEstimate = function (oneLane) {
   const tripOf = (st) => {
     const c = this.canonicalLoop(st);
     if (!c) return 8;
@@ -1298,7 +1360,9 @@ Translator.prototype.workEstimate = function () {
     if (Array.isArray(node)) return node.reduce((t, x) => t + weigh(x), 0);
     let w = 0;
     switch (node.k) {
-      case 'For': return weigh(node.init) + tripOf(node) * (2 + weigh(node.test) + weigh(node.update) + weigh(node.body));
+      case 'For':
+        if (oneLane && node.fastForwardOneLane) return 400 * (1 + Math.log2(tripOf(node) + 2));
+        return weigh(node.init) + tripOf(node) * (2 + weigh(node.test) + weigh(node.update) + weigh(node.body));
       case 'Binary': case 'Unary': case 'Assign': case 'Update': case 'Index': case 'Cond': w = 1; break;
       case 'Call': {
         const c = node.callee;

@@ -124,10 +124,12 @@ typedef struct {
   const int32_t *array_type;     /* device storage per array: AMWG_F64 | AMWG_U8 | AMWG_I32 (values must be exactly representable);
                                     NULL = all AMWG_F64.  Host arrays are always doubles. */
   int32_t n_derived;             /* derived quantities (`state.key = expr`, mcmc.js:961-963, 990-995) recorded after the P components */
-  int32_t lds_bytes;             /* bytes of data the generated stage() keeps in LDS */
+  int32_t lds_bytes;             /* bytes of data the generated stage() keeps in LDS (lanes_per_chain > 1) */
+  int32_t lds_bytes_one_lane;    /* the same for lanes_per_chain == 1 (the generated code may stage other arrays then); 0 = same as lds_bytes */
   int32_t parallel;              /* 1 = the body has lane-split loops, lanes_per_chain > 1 is allowed */
   int32_t max_threads;           /* workgroup-size cap the translator suggests (0 = 1024) */
   double work_per_eval;          /* rough instruction count of one log_post evaluation (0 = unknown); only steers lanes_per_chain */
+  double work_one_lane;          /* the same with ONE lane per chain, when the generated code then fast-forwards a two-valued sum (0 = no) */
 } amwg_user_model;
 
 /* Replaces `new mcmc.AmwgSampler(params, log_post, data, options)` for an arbitrary (translated) closure. */

@@ -24,6 +24,6 @@ for (const name of (want.length ? want : um.names)) {
     for (let i = 0; i < a.length; i++) { buf.writeDoubleLE(a[i], o); o += 8; }
   }
   fs.writeFileSync(path.join(out, name + '.arrays.bin'), buf);
-  fs.writeFileSync(path.join(out, name + '.meta.json'), JSON.stringify({ name, P: tr.P, derived: tr.derived, lds_bytes: tr.lds_bytes,
-    parallel: tr.parallel, max_threads: tr.max_threads, work_per_eval: tr.work_per_eval, array_keys: tr.array_keys, array_types: tr.array_types, array_len: tr.arrays.map((a) => a.length) }));
+  fs.writeFileSync(path.join(out, name + '.meta.json'), JSON.stringify({ name, P: tr.P, derived: tr.derived, lds_bytes: tr.lds_bytes, lds_bytes_one_lane: tr.lds_bytes_one_lane,
+    parallel: tr.parallel, max_threads: tr.max_threads, work_per_eval: tr.work_per_eval, work_one_lane: tr.work_one_lane, array_keys: tr.array_keys, array_types: tr.array_types, array_len: tr.arrays.map((a) => a.length) }));
 }

@@ -34,6 +34,25 @@ CASES.readme_normal = {
   schedule: [{ op: 'burn', n: 300 }, { op: 'sample', n: 300, keep: 60 }], chains: [0, 3],
 };
 
+// ---- README.md:149-164 verbatim (beta-Bernoulli): with one lane per chain the translated data loop is the exact
+// fast-forward of a two-valued sum (csrc/amwg_twoval.h)
+CASES.readme_bern = {
+  params: () => ({ theta: { type: 'real', lower: 0, upper: 1 } }),
+  data: () => synth.bern(2000, 20260925),
+  same_as_golden: 'beta_bern_n2000',
+  log_post: function(state, data) {
+    // Start by defining a variable to hold the log posterior initialized to 0
+    var log_post = 0;
+    log_post += ld.beta(state.theta, 2, 2);
+    var n = data.x.length;
+    for(var i = 0; i < n; i++) {
+      log_post += ld.bern(data.x[i], state.theta)
+    }
+    return log_post;
+  },
+  schedule: [{ op: 'burn', n: 400 }, { op: 'sample', n: 400, keep: 100 }], chains: [0, 1, 2],
+};
+
 // ---- tests/test_data.js:76-91: aliases and a derived quantity
 CASES.norm_post_derived = {
   params: () => ({ mu: { type: 'real' }, sigma: { type: 'real', lower: 0, init: 1 } }),
