@@ -117,11 +117,10 @@ int dev_alloc(amwg_sampler *s, T **p, size_t n) {
 
 // Geometry.  For every lanes-per-chain G take the largest workgroup that still gives every CU a workgroup (more waves
 // share one LDS copy of the data) and price it with a two-term model of one parameter update:
-//     T(G)    = S(G) + W / G           instructions a wave issues: the replicated stepper (Philox, proposal, exp, accept,
-//                                      adaptation; S = 500 + 600/G, measured) plus its 1/G share of the log-likelihood work W
-//     cost(G) = T(G) * rounds * max(w_res, w0)
-// where w_res is the number of waves a SIMD holds at once (limited by LDS and by the number of chains), rounds the
-// number of such batches, and w0 ~ 2.5 the occupancy below which a SIMD is latency- rather than issue-bound.  The cheapest
+//     cost(G) = rounds * [ S(G) * max(w_res, 1.8) + (W / G) * max(w_res, 1.15) * (1 + 0.3 / w_res) ]
+// S(G) = the replicated stepper (Philox, proposal, exp, accept, adaptation), W/G the wave's share of the log-likelihood
+// work, w_res the number of waves a SIMD holds at once (limited by LDS and by the number of chains), rounds the number of
+// such batches; the floors are the occupancies below which each part is latency- rather than issue-bound.  The cheapest
 // G wins, ties go to the smaller G.  The choice depends only on the model, the data size and the chain count, so a
 // given sampler configuration always gets the same G (the lane count fixes the summation order, hence the draws).
 double model_work(const amwg_sampler *s, int G) {
@@ -176,8 +175,16 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     const int64_t resident = blocks < per_cu * n_cus ? blocks : per_cu * n_cus;
     const double w_res = (double)resident * (pick / 64) / (4.0 * n_cus);          // waves a SIMD holds at once
     const double w_total = (double)blocks * (pick / 64) / (4.0 * n_cus);            // waves a SIMD has to run in all
-    const double T = 500.0 + 600.0 / G + model_work(s, G) / G + (G > 64 ? 150.0 : 0.0);   // + the workgroup barrier of every evaluation   // S(G): 540 VALU/update measured at G = 64 (rocprofv3, N = 0), ~1100 at G = 1 (64 chains' rnorm loops diverge)
-    const double cost = T * (w_total / w_res) * (w_res > 2.5 ? w_res : 2.5);
+    // stepper: 540 VALU instructions per update measured at G = 64 (rocprofv3, empty data), ~1100 at G = 1, where the rnorm
+    // rejection loops of the 64/G chains sharing a wave diverge (the expected maximum of 64/G geometric counts grows with
+    // its logarithm); serial dependency chains, so it needs ~1.8 waves per SIMD to stay issue-bound.  Data loop: eight
+    // independent terms in flight per lane, issue-bound already with one wave per SIMD.
+    int lg = 0;
+    for (int g = G; g < 64; g <<= 1) ++lg;
+    const double S = 500.0 + 100.0 * lg;
+    const double Wl = model_work(s, G) / G + (G > 64 ? 150.0 : 0.0);   // + the workgroup barrier of every evaluation
+    const double w1 = w_res > 1.0 ? w_res : 1.0;
+    const double cost = (w_total / w_res) * (S * (w_res > 1.8 ? w_res : 1.8) + Wl * (w_res > 1.15 ? w_res : 1.15) * (1.0 + 0.3 / w1));
     if (bestOcc < 0 || cost < bestOcc * (1.0 - 1e-9)) { bestOcc = cost; bestG = G; bestB = pick; }   // bestOcc holds the best cost
   }
   if (!bestG) return fail(AMWG_EINVAL, "no launch geometry fits: the model needs more than %zu bytes of LDS", max_lds);
