@@ -107,6 +107,24 @@ def cpu_baseline(spec, budget_s=12.0):
                       "the unmodified JS reference measured 3.3e4-3.45e4 on the build container for cfg2 (BASELINE.md §2)" % (spec["n_obs"], n, warm, dt)}
 
 
+def cpu_baseline_all_cores(spec, single_rate, budget_s=6.0):
+    """Optional stronger baseline (ours, not the reference's): the same C oracle, one independent
+    chain per host core (ctypes releases the GIL, so plain threads run them in parallel)."""
+    import concurrent.futures
+    import oracle_lib
+    cores = os.cpu_count() or 1
+    n = max(5, int(single_rate / spec["P"] * budget_s))
+    chains = [oracle_lib.OracleChain(spec, SEED, c, lanes=1) for c in range(cores)]
+    for ch in chains:
+        ch.burn(5)
+    t0 = time.perf_counter()
+    with concurrent.futures.ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda ch: ch.burn(n), chains))
+    dt = time.perf_counter() - t0
+    return {"value": cores * n * spec["P"] / dt, "unit": "param-updates/s", "cores": cores, "kind": "port",
+            "sample": "oracle/amwg_oracle.c, %d independent chains on %d threads, %d steps each (%.1f s)" % (cores, cores, n, dt)}
+
+
 def parity_gate(A, spec):
     """next to the speed, the proof that this build reproduces the reference.  One lane per chain
     (the reference's summation order) for the first and the last chain id of the bench job, same seed and data, against the
@@ -274,6 +292,7 @@ def main():
             out["parity"] = parity_gate(A, spec)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(spec, out["cpu_baseline"]["value"])
             out["chains_equiv"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     s.close()
