@@ -119,15 +119,23 @@ AMWG_HD_OUTLINE double two_valued_sum(double acc, double l1, double l0, const Bi
       }
     }
     if (mulA == 0 && mulB == 0 && mode == 0) break;   // the addends are below half an ulp of acc: nothing changes any more
-    const uint64_t kA = mulA ? (limit - 1) / mulA : kSat, kB = mulB ? (limit - 1) / mulB : kSat;
+    // n * mul for n < 2^31 observations and mul < 2^53, saturating: (n * mul_hi) << 32 + n * mul_lo with two 32x32->64 products;
+    // anything >= 2^53 certainly reaches `limit` (<= 2^52)
+    const uint32_t aH = (uint32_t)(mulA >> 32), aL = (uint32_t)mulA, bH = (uint32_t)(mulB >> 32), bL = (uint32_t)mulB;
+    auto scaled = [&](uint32_t n, uint32_t mh, uint32_t ml) -> uint64_t {
+      const uint64_t hi = (uint64_t)n * mh;
+      if (hi >> 21) return kSat;
+      return (hi << 32) + (uint64_t)n * ml;       // < 2^53 + 2^63
+    };
     const uint32_t bit_i = (B.w[i >> 5] >> (i & 31)) & 1u;
     const uint32_t *om = tsym ? B.om1 : B.om0, *po = tsym ? B.po1 : B.po0;
     const int odd_j = (mode == 3 && jt < N) ? odd_before(om, po, jt + 1) : 0;
     const int cnt_j = (mode == 3 && jt < N) ? (tsym ? ones_before(B, jt + 1) : (jt + 1 - ones_before(B, jt + 1))) : 0;
     auto growth = [&](int m) -> uint64_t {
-      const uint64_t n1 = (uint64_t)(ones_before(B, m) - c1_i), n0 = (uint64_t)(m - i) - n1;
-      if (n1 > kA || n0 > kB) return kSat;
-      uint64_t T = n1 * mulA + n0 * mulB;               // each product <= limit - 1 < 2^53
+      const uint32_t n1 = (uint32_t)(ones_before(B, m) - c1_i), n0 = (uint32_t)(m - i) - n1;
+      const uint64_t t1 = scaled(n1, aH, aL), t0 = scaled(n0, bH, bL);
+      if (t1 >= limit || t0 >= limit) return kSat;      // also catches the saturated products
+      uint64_t T = t1 + t0;                              // < 2^54
       if (mode == 1) {
         // the first addition rounds by the parity of A; every later one finds A even
         if (m > i) { const uint64_t qf = bit_i ? q1 : q0; T = T - (qf + (qf & 1ull)) + qf + ((p + qf) & 1ull); }
