@@ -319,6 +319,42 @@ CASES.mixture_arrays = {
   schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 60 }], chains: [0, 1],
 };
 
+// ---- JavaScript number semantics the translator has to keep: integer-looking arithmetic beyond 2^31, % with negative
+// operands, Math.round on halves, NaN comparisons, ternaries, compound assignment, ** (right-associative), while loops,
+// early return, truthiness of numbers, decrementing loops, constants folded at translation time
+CASES.semantics_probe = {
+  params: () => ({ a: { type: 'real', init: 1.25 }, b: { type: 'real', init: -0.75 }, k: { type: 'int', lower: -5, upper: 9, init: 2 } }),
+  data: () => ({ v: [3, -7, 0.5, 1e6, -2.5, 65536, 8], n: 7, big: 50000 }),
+  log_post: function(s, d) {
+    var lp = 0;
+    if (s.a > 1e3) return -Infinity;
+    var big = d.big * d.big * d.big;                   // 1.25e14: exact in a double, overflows int32
+    lp += big * 1e-15;
+    for (var i = 0; i < d.n; i++) {
+      var w = i * 60000 * 60000;                       // up to 2.16e10
+      lp -= (w % 7) * 1e-3 + (d.v[i] % 3) * 1e-2 + ((-d.v[i]) % 2.5) * 1e-2;
+      lp += Math.round(d.v[i] * s.b) * 1e-3 + Math.round(-0.5) + Math.round(2.5) * 1e-3 + Math.floor(-d.v[i] / 2) * 1e-4;
+      lp += (d.v[i] > s.a ? 1 : -1) * 1e-3 + (d.v[i] >= 0 && s.b < 0 ? 2e-3 : 0) + (!(d.v[i] < 0) || s.k > 3 ? 1e-3 : -1e-3);
+    }
+    var j = d.n - 1, acc = 0;
+    while (j >= 0) { acc += d.v[j] * (j + 1); j -= 2; }
+    lp += acc * 1e-7;
+    for (var m = 5; m > 0; m--) { lp += m * s.a * 1e-3; }
+    var z = 2 ** 3 ** 2;                               // 512
+    lp += z * 1e-4 + s.a ** 2 * 1e-2 + (-s.b) ** 0.5 * 1e-2 + Math.pow(s.a + 2, s.b) * 1e-2;
+    var nan = Math.sqrt(s.b);                          // NaN for b < 0
+    lp += (nan > 0 ? 1 : 0) + (nan < 0 ? 1 : 0) + (nan == nan ? 1 : 0) + (nan != nan ? 1e-3 : 0);
+    if (s.k) { lp += 1e-3; }                           // truthiness of a number
+    if (s.k % 2 === 0) lp += s.k / 2 * 1e-3; else lp -= (s.k - 1) / 2 * 1e-3;
+    lp *= 1.0000001;
+    lp /= 1.0000001;
+    lp -= Math.abs(s.k) * 1e-3 + Math.max(s.a, s.b, 0.3) * 1e-3 + Math.min(s.a, -s.b) * 1e-3 + Math.sign(s.b) * 1e-3 + Math.trunc(s.a * 3) * 1e-3 + Math.ceil(s.b) * 1e-3;
+    lp += ld.norm(s.a, 1, 2) + ld.norm(s.b, -1, 2) + ld.unif(s.k, -5, 9);
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+
 // ---- more than 8 named parameters (the shuffled order of the named steppers is sixteen 4-bit fields per chain)
 CASES.many_named = {
   params: () => ({ b0: {}, b1: {}, b2: {}, b3: {}, b4: {}, b5: {}, b6: {}, b7: {}, b8: {}, b9: {}, tau: { lower: 0, init: 1 }, k: { type: 'int', lower: 0, upper: 9, init: 3 } }),
