@@ -616,7 +616,18 @@ Translator.prototype.cond = function (e) {
   return { t: 'bool', code: this.asB(v), cst: v.cst !== undefined ? !!v.cst : undefined };
 };
 
+// Pure calls (Math.exp/log/pow/sqrt, ld.*, helpers) whose arguments cannot change inside the enclosing loop(s) are
+// evaluated once, just before the outermost such loop -- the same value, computed by the same code.
 Translator.prototype.call = function (e) {
+  const v = this.callInner(e);
+  if (v.t !== 'num' || v.cst !== undefined || v.int || !this.loops.length || this.noHoist || this.pending.length) return v;
+  if (!/^(exp_v8|log_v8|pow_v8|__builtin_sqrt|ld_\w+|lgamma_js|lfactorial_js|lchoose_js|lbeta_js|h_\w+)\(/.test(v.code)) return v;
+  if (/NORMCALL|_inv\(|_inv01\(|_pre\(/.test(v.code)) return v;            // already specialised for the loop
+  const k = this.hoist(e, 'double', '', v.code, '');
+  return k ? num(k, false) : v;
+};
+
+Translator.prototype.callInner = function (e) {
   const f = this.expr(e.callee);
   if (f.t !== 'fn') this.fail('calling a ' + this.describe(f));
   const args = e.args.map((a) => this.expr(a));
