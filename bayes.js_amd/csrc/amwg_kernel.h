@@ -140,7 +140,49 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
   return acc;
 }
 
-__device__ __forceinline__ double rnorm_js(ChainStream &rng, double mean, double sd) {  // mcmc.js:43-54
+// The chain's uniform stream, shared by the L = min(G, 64) lanes that run the chain inside one wave.  Every lane needs every
+// uniform (the scalar logic is replicated), but a Philox block is ~90 instructions: instead of all L lanes computing the SAME
+// block, lane j computes block b0 + j, and uniform #n is fetched from the lane that holds block n >> 1 with a cross-lane
+// permute -- one Philox evaluation per lane buys 2L uniforms for the chain.  Same stream as ChainStream (amwg_philox.h), the
+// persisted state is still just the number of uniforms consumed.
+template <int G>
+struct CoopStream {
+  static constexpr int L = G < 64 ? G : 64;
+  uint32_t k0, k1, c2, c3;
+  uint64_t n, b0;
+  uint32_t w0, w1, w2, w3;
+  int lane_in_chain, base_lane;
+  __device__ __forceinline__ void fill() {
+    const uint64_t b = b0 + (uint64_t)lane_in_chain;
+    const Philox4 w = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), c2, c3, k0, k1);
+    w0 = w.w0; w1 = w.w1; w2 = w.w2; w3 = w.w3;
+  }
+  __device__ __forceinline__ void init(uint64_t seed, uint64_t chain, uint64_t consumed, int tid) {
+    k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+    c2 = (uint32_t)chain; c3 = (uint32_t)(chain >> 32);
+    n = consumed;
+    lane_in_chain = tid & (L - 1);
+    base_lane = (tid & 63) & ~(L - 1);
+    b0 = n >> 1;
+    fill();
+  }
+  __device__ __forceinline__ double next() {
+    const uint64_t blk = n >> 1;
+    if (blk - b0 >= (uint64_t)L) { b0 = blk; fill(); }
+    const bool second = (n & 1) != 0;
+    uint32_t hi = second ? w2 : w0, lo = second ? w3 : w1;
+    if constexpr (L > 1) {
+      const int src = base_lane + (int)(blk - b0);
+      hi = (uint32_t)__shfl((int)hi, src, 64);
+      lo = (uint32_t)__shfl((int)lo, src, 64);
+    }
+    ++n;
+    return u53(hi, lo);
+  }
+};
+
+template <class Rng>
+__device__ __forceinline__ double rnorm_js(Rng &rng, double mean, double sd) {  // mcmc.js:43-54
   double u, v, q;
   do {
     u = rng.next();
@@ -210,8 +252,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   }
   const StateView S{Sme};
   uint64_t perm = a.ch.perm[cl];
-  ChainStream rng;
-  rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl]);
+  CoopStream<G> rng;
+  rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid);
   double lp_curr = a.ch.lp_curr[cl];
   __syncthreads();
   if (a.init_lp) lp_curr = log_post<Model, G>(S, a, data_lds, sub, xw);  // ctor warm-up call, mcmc.js:961-963
