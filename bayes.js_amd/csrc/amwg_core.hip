@@ -175,13 +175,13 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     const int64_t resident = blocks < per_cu * n_cus ? blocks : per_cu * n_cus;
     const double w_res = (double)resident * (pick / 64) / (4.0 * n_cus);          // waves a SIMD holds at once
     const double w_total = (double)blocks * (pick / 64) / (4.0 * n_cus);            // waves a SIMD has to run in all
-    // stepper: 540 VALU instructions per update measured at G = 64 (rocprofv3, empty data), ~1100 at G = 1, where the rnorm
+    // stepper: 394 VALU instructions per update measured at G = 64 (rocprofv3, empty data), ~980 at G = 1, where the rnorm
     // rejection loops of the 64/G chains sharing a wave diverge (the expected maximum of 64/G geometric counts grows with
     // its logarithm); serial dependency chains, so it needs ~1.8 waves per SIMD to stay issue-bound.  Data loop: eight
     // independent terms in flight per lane, issue-bound already with one wave per SIMD.
     int lg = 0;
     for (int g = G; g < 64; g <<= 1) ++lg;
-    const double S = 500.0 + 100.0 * lg;
+    const double S = 400.0 + 97.0 * lg;
     const double Wl = model_work(s, G) / G + (G > 64 ? 150.0 : 0.0);   // + the workgroup barrier of every evaluation
     const double w1 = w_res > 1.0 ? w_res : 1.0;
     const double cost = (w_total / w_res) * (S * (w_res > 1.8 ? w_res : 1.8) + Wl * (w_res > 1.15 ? w_res : 1.15) * (1.0 + 0.3 / w1));
