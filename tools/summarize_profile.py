@@ -11,6 +11,11 @@ src, dst = os.path.join(ROOT, "gpurun_out", "prof_" + tag), os.path.join(ROOT, "
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, tag + "_bench_under_trace.json"))
+bench = json.load(open(os.path.join(src, "bench_under_trace.json")))
+# the kernel the bench line is about (the parity gate of bench.py also launches one-lane kernels: not those)
+import re
+m = re.match(r"amwg_step_kernel<(\w+),(\d+)>", bench["roofline"]["kernel"])
+is_bench_kernel = lambda name: ("amwg_step_kernel" in name and re.search(r"%s,\s*%s>" % (m.group(1), m.group(2)), name) is not None)
 pmc = {}
 meta = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
@@ -19,14 +24,13 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "amwg_step_kernel" in r["Kernel_Name"]:
+        if is_bench_kernel(r["Kernel_Name"]):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
     for k, v in agg.items():
         pmc[k] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
 stats = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
-step = [r for r in stats if "amwg_step_kernel" in r["Name"]][0]
-bench = json.load(open(os.path.join(src, "bench_under_trace.json")))
+step = [r for r in stats if is_bench_kernel(r["Name"])][0]
 traffic = None
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
