@@ -128,3 +128,16 @@ def test_hiprtc_errors_surface_with_the_compiler_log():
     assert L.amwg_compile_user(bad, 1, 256, b"gfx950", C.byref(n)) == -1
     msg = L.amwg_last_error().decode()
     assert "did not compile" in msg and "error" in msg
+
+
+def test_two_valued_sum_host_fuzz(tmp_path):
+    """csrc/amwg_twoval.h compiled for the host: 200 000 random / adversarial (data, acc0, l1, l0) cases -- trailing-zero
+    significands (ties), either sign of acc0, non-finite and positive addends -- against the plain fp64 loop, bit for bit."""
+    import os
+    import subprocess
+    exe = str(tmp_path / "twoval_fuzz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(root, "bayes.js_amd", "csrc"),
+                           os.path.join(root, "tests", "host", "twoval_fuzz.cpp"), "-o", exe])
+    p = subprocess.run([exe, "200000"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "mismatches=0" in p.stdout, p.stdout[-2000:]
