@@ -141,3 +141,16 @@ def test_two_valued_sum_host_fuzz(tmp_path):
                            os.path.join(root, "tests", "host", "twoval_fuzz.cpp"), "-o", exe])
     p = subprocess.run([exe, "200000"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "mismatches=0" in p.stdout, p.stdout[-2000:]
+
+
+def test_division_by_invariant_host_fuzz(tmp_path):
+    """csrc/amwg_div.h compiled for the host: 8 million quotients (divisor 2^-200..2^200, numerator 2^-600..2^600 or 0, all-ones and
+    power-of-two significands among them) equal IEEE division bit for bit."""
+    import os
+    import subprocess
+    exe = str(tmp_path / "div_fuzz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(root, "bayes.js_amd", "csrc"),
+                           os.path.join(root, "tests", "host", "div_fuzz.cpp"), "-o", exe])
+    p = subprocess.run([exe, "2000000"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "mismatches=0" in p.stdout, p.stdout[-2000:]
