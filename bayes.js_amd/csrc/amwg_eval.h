@@ -60,6 +60,8 @@ __global__ void amwg_eval_kernel(int op, int64_t n, const double *a, const doubl
     case 11: r = ld_bern(x, y); break;
     case 12: r = ld_unif(x, y, z); break;
     case 13: r = pow_v8(x, y); break;
+    case 14: r = log1p_v8(x); break;
+    case 15: r = expm1_v8(x); break;
   }
   out[i] = r;
 }

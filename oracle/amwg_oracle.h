@@ -78,6 +78,8 @@ double orc_ld_bern(double x, double p);
 double orc_ld_pois(double x, double lambda);
 double orc_lgamma(double x);
 double orc_pow(double x, double y);   /* V8 Math.pow */
+double orc_log1p(double x);          /* V8 Math.log1p */
+double orc_expm1(double x);          /* V8 Math.expm1 */
 /* every scalar density / helper of distributions.js by id (oracle/gen_ld_golden.js lists the ids) */
 double orc_ld(int id, double x, double a, double b, double c);
 

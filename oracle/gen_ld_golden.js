@@ -53,4 +53,17 @@ for (let i = 0; i < N; i++) {
   pb.writeDoubleLE(x, i * 24); pb.writeDoubleLE(y, i * 24 + 8); pb.writeDoubleLE(Math.pow(x, y), i * 24 + 16);
 }
 fs.writeFileSync(path.join(OUT, 'v8_pow_pairs.bin'), pb);
+// ---- Math.log1p / Math.expm1 of this V8
+{
+  const M = 60000, lb = Buffer.alloc(M * 24);
+  const spx = [0, -0, 1, -1, -0.5, 0.41421356237309503, -0.2928932188134524, 1e-10, -1e-10, 1e-20, Infinity, -Infinity, NaN, -2, 709.78, 710, -40, -38.8, 38.8, 0.5, -0.35, 1.04, -1.04, 56 * Math.LN2, 1e18, Math.pow(2, 52), Math.pow(2, 53)];
+  for (let i = 0; i < M; i++) {
+    let x; const m = i % 6;
+    if (i < spx.length) x = spx[i];
+    else if (m === 0) x = (rnd() - 0.5) * 4; else if (m === 1) x = (rnd() - 0.5) * 2e-3; else if (m === 2) x = (rnd() - 0.5) * 1500;
+    else if (m === 3) x = Math.exp((rnd() - 0.5) * 80) * (rnd() < 0.5 ? -1 : 1); else if (m === 4) x = (rnd() - 0.3) * 3; else x = -1 + Math.exp(-rnd() * 40);
+    lb.writeDoubleLE(x, i * 24); lb.writeDoubleLE(Math.log1p(x), i * 24 + 8); lb.writeDoubleLE(Math.expm1(x), i * 24 + 16);
+  }
+  fs.writeFileSync(path.join(OUT, 'v8_log1p_expm1_pairs.bin'), lb);
+}
 console.log('ld_values.bin:', recs.length, 'records; v8_pow_pairs.bin:', N, 'pairs');

@@ -355,6 +355,28 @@ CASES.semantics_probe = {
   schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
 };
 
+// ---- logistic regression written with softplus / log-sum-exp (Math.log1p, Math.expm1), a helper with its own locals
+CASES.logistic_softplus = {
+  params: () => ({ b0: { init: 0 }, b1: { init: 0 }, b2: { init: 0 }, tau: { lower: 0, init: 1 } }),
+  data: (seed) => { const r = lcg(seed), x1 = [], x2 = [], y = []; for (let i = 0; i < 80; i++) { const a = r() * 4 - 2, b = r() * 2 - 1; x1.push(a); x2.push(b); y.push(r() < 1 / (1 + Math.exp(-(0.3 + 1.1 * a - 0.7 * b))) ? 1 : 0); } return { x1, x2, y }; },
+  helpers: { softplus: function(t) {
+    var big = t > 30;
+    if (big) { return t; }
+    return Math.log1p(Math.exp(t));
+  } },
+  log_post: function(s, d) {
+    var lp = ld.gamma(s.tau, 2, 2);
+    lp += ld.norm(s.b0, 0, 1 / Math.sqrt(s.tau)) + ld.norm(s.b1, 0, 1 / Math.sqrt(s.tau)) + ld.norm(s.b2, 0, 1 / Math.sqrt(s.tau));
+    for (var i = 0; i < d.y.length; i++) {
+      var eta = s.b0 + s.b1 * d.x1[i] + s.b2 * d.x2[i];
+      lp += d.y[i] * eta - softplus(eta);                 // log Bernoulli(y | logistic(eta))
+    }
+    lp += Math.expm1(-s.tau) * 1e-3 + Math.log1p(s.tau) * 1e-3;
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+
 // ---- more than 8 named parameters (the shuffled order of the named steppers is sixteen 4-bit fields per chain)
 CASES.many_named = {
   params: () => ({ b0: {}, b1: {}, b2: {}, b3: {}, b4: {}, b5: {}, b6: {}, b7: {}, b8: {}, b9: {}, tau: { lower: 0, init: 1 }, k: { type: 'int', lower: 0, upper: 9, init: 3 } }),

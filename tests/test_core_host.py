@@ -82,3 +82,9 @@ def test_host_build_of_every_ld_function_and_pow_equals_the_reference():
     p = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_pow_pairs.bin"), dtype="<f8").reshape(-1, 3)
     assert p.shape[0] == 60000
     assert sum(not _same(L.amwg_pow(x, y), w) for x, y, w in p) == 0
+
+
+def test_host_build_of_log1p_expm1_equals_v8():
+    L = amwg_ctypes.lib()
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_log1p_expm1_pairs.bin"), dtype="<f8").reshape(-1, 3)
+    assert sum((not _same(L.amwg_log1p(x), l)) + (not _same(L.amwg_expm1(x), e)) for x, l, e in a) == 0

@@ -123,3 +123,13 @@ def test_two_valued_sum_fast_forward_is_exact_including_ties():
         same = (ff.view(np.uint64) == seq.view(np.uint64)) | (np.isnan(ff) & np.isnan(seq))
         bad = np.where(~same)[0]
         assert bad.size == 0, (n, bad[:5], acc0[bad[:5]], l1[bad[:5]].view(np.uint64), l0[bad[:5]].view(np.uint64), ff[bad[:5]], seq[bad[:5]])
+
+
+def test_device_log1p_expm1_equal_v8():
+    import os
+    import golden_io
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_log1p_expm1_pairs.bin"), dtype="<f8").reshape(-1, 3)
+    for op, col in ((14, 1), (15, 2)):
+        got = A.device_eval(op, a[:, 0])
+        ok = (got.view(np.uint64) == a[:, col].view(np.uint64)) | (np.isnan(got) & np.isnan(a[:, col]))
+        assert ok.all(), (op, a[~ok][:3], got[~ok][:3])

@@ -89,3 +89,10 @@ def test_every_ld_function_and_pow_pinned_against_the_reference():
         assert _same(L.orc_ld(int(r[0]), r[1], r[2], r[3], r[4]), r[5]), r.tolist()
     p = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_pow_pairs.bin"), dtype="<f8").reshape(-1, 3)
     assert sum(not _same(L.orc_pow(x, y), w) for x, y, w in p) == 0
+
+
+def test_log1p_expm1_pinned_against_v8():
+    L = oracle_lib.lib()
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_log1p_expm1_pairs.bin"), dtype="<f8").reshape(-1, 3)
+    assert a.shape[0] == 60000
+    assert sum((not _same(L.orc_log1p(x), l)) + (not _same(L.orc_expm1(x), e)) for x, l, e in a) == 0

@@ -21,7 +21,7 @@ import user_host
 pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
 
 NAMES = ["readme_normal", "readme_bern", "norm_post_derived", "complex_model", "hier_binomial", "multi_bern", "multivar_poisson",
-         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe"]
+         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus"]
 
 
 def same(a, b):
