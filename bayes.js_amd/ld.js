@@ -13,85 +13,83 @@
  */
 const LANCZOS = [76.18009172947146, -86.50532032941677, 24.01409824083091,
   -1.231739572450155, 0.1208650973866179e-2, -0.5395239384953e-5];
+const L = Math.log, NEG = -Infinity, PI = Math.PI;
+const sq = (t) => t * t;          // V8 evaluates Math.pow(t, 2) as exactly t*t (pinned by the goldens)
 
+// Lanczos approximation with g = 5 and six coefficients (Numerical Recipes gammln), as the reference carries it
 function lgamma(x) {
   let y = x, t = x + 5.5, ser = 1.000000000190015;
-  t -= (x + 0.5) * Math.log(t);
+  t -= (x + 0.5) * L(t);
   for (let j = 0; j < 6; j++) ser += LANCZOS[j] / ++y;
-  return Math.log(2.5066282746310005 * ser / x) - t;
+  return L(2.5066282746310005 * ser / x) - t;
 }
 const lfactorial = (n) => (n < 0 ? NaN : lgamma(n + 1));
 const lchoose = (n, k) => lfactorial(n) - lfactorial(k) - lfactorial(n - k);
 const lbeta = (a, b) => lgamma(a) + lgamma(b) - lgamma(a + b);
-const log = Math.log, exp = Math.exp, abs = Math.abs, pow = Math.pow, sqrt = Math.sqrt, pi = Math.PI;
 
+// Every density returns its terms in the reference's left-to-right order (fp64 addition is not associative).
 const ld = {
   lgamma, lfactorial, lchoose, lbeta,
-  cauchy(x, location, scale) { return log(scale) - log(pow(x - location, 2) + pow(scale, 2)) - log(pi); },
-  bivarnorm(x, mean, sd, corr) {
-    const z = pow(x[0] - mean[0], 2) / pow(sd[0], 2) + pow(x[1] - mean[1], 2) / pow(sd[1], 2) -
-              (2 * corr * (x[0] - mean[0]) * (x[1] - mean[1])) / (sd[0] * sd[1]);
-    const normalizing_factor = -(log(2) + log(pi) + log(sd[0]) + log(sd[1]) + 0.5 * log(1 - pow(corr, 2)));
-    return normalizing_factor - z / (2 * (1 - pow(corr, 2)));
+
+  // ---- continuous
+  norm: (x, m, s) => -0.5 * L(2 * PI) - L(s) - sq(x - m) / (2 * s * s),
+  unif: (x, lo, hi) => ((x < lo || x > hi) ? NEG : L(1 / (hi - lo))),
+  beta(x, a, b) {
+    if (x > 1 || x < 0) return NEG;
+    return (a === 1 && b === 1) ? 0 : (a - 1) * L(x) + (b - 1) * L(1 - x) - lbeta(a, b);
   },
-  laplace(x, location, scale) { return (-abs(x - location) / scale) - log(2 * scale); },
-  gamma(x, shape, rate) {
-    const scale = 1 / rate;
-    if (x < 0) return -Infinity;
-    if (x === 0 && shape === 1) return -log(scale);
-    return (shape - 1) * log(x) - x / scale - lgamma(shape) - shape * log(scale);
+  cauchy: (x, loc, s) => L(s) - L(sq(x - loc) + sq(s)) - L(PI),
+  bivarnorm(x, m, s, rho) {
+    const d0 = x[0] - m[0], d1 = x[1] - m[1];
+    const z = sq(d0) / sq(s[0]) + sq(d1) / sq(s[1]) - (2 * rho * d0 * d1) / (s[0] * s[1]);
+    const norm_const = -(L(2) + L(PI) + L(s[0]) + L(s[1]) + 0.5 * L(1 - sq(rho)));
+    return norm_const - z / (2 * (1 - sq(rho)));
   },
-  invgamma(x, shape, scale) { return x <= 0 ? -Infinity : -(shape + 1) * log(x) - scale / x - lgamma(shape) + shape * log(scale); },
-  lnorm(x, meanlog, sdlog) {
-    if (x <= 0) return -Infinity;
-    return -log(x) - 0.5 * log(2 * pi) - log(sdlog) - pow(log(x) - meanlog, 2) / (2 * sdlog * sdlog);
+  laplace: (x, loc, s) => (-Math.abs(x - loc) / s) - L(2 * s),
+  gamma(x, k, rate) {
+    const theta = 1 / rate;
+    if (x < 0) return NEG;
+    return (x === 0 && k === 1) ? -L(theta) : (k - 1) * L(x) - x / theta - lgamma(k) - k * L(theta);
   },
-  pareto(x, scale, shape) { return x < scale ? -Infinity : log(shape) + shape * log(scale) - (shape + 1) * log(x); },
-  t(x, location, scale, df) {
-    df = df > 1e100 ? 1e100 : df;
-    return lgamma((df + 1) / 2) - lgamma(df / 2) - log(sqrt(pi * df) * scale) +
-           log(pow(1 + (1 / df) * pow((x - location) / scale, 2), -(df + 1) / 2));
+  invgamma: (x, k, s) => (x <= 0 ? NEG : -(k + 1) * L(x) - s / x - lgamma(k) + k * L(s)),
+  lnorm: (x, m, s) => (x <= 0 ? NEG : -L(x) - 0.5 * L(2 * PI) - L(s) - sq(L(x) - m) / (2 * s * s)),
+  pareto: (x, xm, k) => (x < xm ? NEG : L(k) + k * L(xm) - (k + 1) * L(x)),
+  t(x, loc, s, nu) {
+    if (nu > 1e100) nu = 1e100;
+    return lgamma((nu + 1) / 2) - lgamma(nu / 2) - L(Math.sqrt(PI * nu) * s) + L(Math.pow(1 + (1 / nu) * sq((x - loc) / s), -(nu + 1) / 2));
   },
-  weibull(x, shape, scale) {
-    if (x < 0) return -Infinity;
-    if (x === 0 && shape < 1) return Infinity;
-    const tmp1 = pow(x / scale, shape - 1);
-    const tmp2 = tmp1 * (x / scale);
-    return -tmp2 + log(shape * tmp1 / scale);
+  weibull(x, k, lambda) {      // R's dweibull(log = TRUE)
+    if (x < 0) return NEG;
+    if (x === 0 && k < 1) return Infinity;
+    const r = x / lambda, a = Math.pow(r, k - 1);
+    return -(a * r) + L(k * a / lambda);
   },
-  logis(x, location, scale) {
-    x = abs((x - location) / scale);
-    const e = exp(-x);
-    const f = 1.0 + e;
-    return -(x + log(scale * f * f));
+  logis(x, loc, s) {           // R's dlogis(log = TRUE)
+    const z = Math.abs((x - loc) / s), f = 1.0 + Math.exp(-z);
+    return -(z + L(s * f * f));
   },
   dirichlet(x, alpha) {
-    let sum_alpha = 0, sum_lgamma_alpha = 0, sum_alpha_sub_1_log_x = 0;
+    let a_sum = 0, lg_sum = 0, w_sum = 0;
     for (let i = 0; i < alpha.length; i++) {
-      sum_alpha += alpha[i];
-      sum_lgamma_alpha += lgamma(alpha[i]);
-      sum_alpha_sub_1_log_x += (alpha[i] - 1) * log(x[i]);
+      a_sum += alpha[i];
+      lg_sum += lgamma(alpha[i]);
+      w_sum += (alpha[i] - 1) * L(x[i]);
     }
-    return lgamma(sum_alpha) - sum_lgamma_alpha + sum_alpha_sub_1_log_x;
+    return lgamma(a_sum) - lg_sum + w_sum;
   },
-  exp(x, rate) { return x < 0 ? -Infinity : log(rate) - rate * x; },
-  cat(x, probs) { return (x < 1 || x > probs.length) ? -Infinity : log(probs[x - 1]); },
-  binom(x, size, prob) {
-    if (x > size || x < 0) return -Infinity;
-    if (prob === 0 || prob === 1) return (size * prob) === x ? 0 : -Infinity;
-    return lchoose(size, x) + x * log(prob) + (size - x) * log(1 - prob);
+  exp: (x, rate) => (x < 0 ? NEG : L(rate) - rate * x),
+
+  // ---- discrete
+  bern: (x, p) => (!(x === 0 || x === 1) ? NEG : L(x * p + (1 - x) * (1 - p))),
+  cat: (x, p) => ((x < 1 || x > p.length) ? NEG : L(p[x - 1])),
+  binom(x, n, p) {
+    if (x > n || x < 0) return NEG;
+    if (p === 0 || p === 1) return (n * p) === x ? 0 : NEG;
+    return lchoose(n, x) + x * L(p) + (n - x) * L(1 - p);
   },
-  nbinom(x, size, prob) { return x < 0 ? -Infinity : lchoose(x + size - 1, size - 1) + x * log(1 - prob) + size * log(prob); },
-  hyper(x, m, n, k) { return (x < 0 || x > k) ? -Infinity : lchoose(m, x) + lchoose(n, k - x) - lchoose(m + n, k); },
-  norm(x, mean, sd) { return -0.5 * Math.log(2 * Math.PI) - Math.log(sd) - Math.pow(x - mean, 2) / (2 * sd * sd); },
-  unif(x, min, max) { return (x < min || x > max) ? -Infinity : Math.log(1 / (max - min)); },
-  beta(x, a, b) {
-    if (x > 1 || x < 0) return -Infinity;
-    if (a === 1 && b === 1) return 0;
-    return (a - 1) * Math.log(x) + (b - 1) * Math.log(1 - x) - lbeta(a, b);
-  },
-  bern(x, p) { return !(x === 0 || x === 1) ? -Infinity : Math.log(x * p + (1 - x) * (1 - p)); },
-  pois(x, lambda) { return x < 0 ? -Infinity : Math.log(lambda) * x - lambda - lfactorial(x); },
+  nbinom: (x, r, p) => (x < 0 ? NEG : lchoose(x + r - 1, r - 1) + x * L(1 - p) + r * L(p)),
+  hyper: (x, m, n, k) => ((x < 0 || x > k) ? NEG : lchoose(m, x) + lchoose(n, k - x) - lchoose(m + n, k)),
+  pois: (x, lambda) => (x < 0 ? NEG : L(lambda) * x - lambda - lfactorial(x)),
 };
 ld.dexp = ld.laplace;
 module.exports = ld;
