@@ -345,6 +345,7 @@ double amwg_log(double x) { return log_v8(x); }
 double amwg_pow(double x, double y) { return pow_v8(x, y); }
 double amwg_log1p(double x) { return log1p_v8(x); }
 double amwg_expm1(double x) { return expm1_v8(x); }
+double amwg_math1(int32_t fn, double x) { return fn == 0 ? tanh_v8(x) : (fn == 1 ? atan_v8(x) : (fn == 2 ? log10_v8(x) : __builtin_nan(""))); }
 double amwg_ld_host(int32_t id, double x, double a, double b, double c) { return ld_by_id(id, x, a, b, c); }
 double amwg_uniform(uint64_t seed, uint64_t chain, uint64_t index) {
   ChainStream s;

@@ -62,6 +62,9 @@ __global__ void amwg_eval_kernel(int op, int64_t n, const double *a, const doubl
     case 13: r = pow_v8(x, y); break;
     case 14: r = log1p_v8(x); break;
     case 15: r = expm1_v8(x); break;
+    case 16: r = tanh_v8(x); break;
+    case 17: r = atan_v8(x); break;
+    case 18: r = log10_v8(x); break;
   }
   out[i] = r;
 }

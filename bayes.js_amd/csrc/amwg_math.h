@@ -439,6 +439,77 @@ AMWG_HD double expm1_v8(double x) {
   return y;
 }
 
+// ---- tanh, atan, log10: V8's Math.tanh / Math.atan / Math.log10 (fdlibm s_tanh.c, s_atan.c, e_log10.c), for user closures.
+// Bit-identical to Node on 200 000 arguments each (tests/golden/v8_math2_pairs.bin).
+AMWG_HD double tanh_v8(double x) {
+  const double one = 1.0, two = 2.0, tiny = 1.0e-300, huge = 1.0e300;
+  double t, z;
+  int32_t jx = hi_word(x), ix = jx & 0x7fffffff;
+  if (ix >= 0x7ff00000) { if (jx >= 0) return one / x + one; else return one / x - one; }
+  if (ix < 0x40360000) {            /* |x| < 22 */
+    if (ix < 0x3e300000) { if (huge + x > one) return x; }   /* |x| < 2**-28 */
+    if (ix >= 0x3ff00000) { t = expm1_v8(two * __builtin_fabs(x)); z = one - two / (t + two); }
+    else { t = expm1_v8(-two * __builtin_fabs(x)); z = -t / (t + two); }
+  } else z = one - tiny;
+  return (jx >= 0) ? z : -z;
+}
+AMWG_HD double atan_v8(double x) {
+  const double atanhi[] = {4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01, 1.57079632679489655800e+00};
+  const double atanlo[] = {2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17, 6.12323399573676603587e-17};
+  const double aT[] = {3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01, -1.11111104054623557880e-01,
+    9.09088713343650656196e-02, -7.69187620504482999495e-02, 6.66107313738753120669e-02, -5.83357013379057348645e-02,
+    4.97687799461593236017e-02, -3.65315727442169155270e-02, 1.62858201153657823623e-02};
+  const double one = 1.0, huge = 1.0e300;
+  double w, s1, s2, z;
+  int32_t ix, hx, id;
+  hx = hi_word(x); ix = hx & 0x7fffffff;
+  if (ix >= 0x44100000) {
+    if (ix > 0x7ff00000 || (ix == 0x7ff00000 && (lo_word(x) != 0))) return x + x;
+    if (hx > 0) return atanhi[3] + atanlo[3]; else return -atanhi[3] - atanlo[3];
+  }
+  if (ix < 0x3fdc0000) {
+    if (ix < 0x3e200000) { if (huge + x > one) return x; }
+    id = -1;
+  } else {
+    x = __builtin_fabs(x);
+    if (ix < 0x3ff30000) {
+      if (ix < 0x3fe60000) { id = 0; x = (2.0 * x - one) / (2.0 + x); }
+      else { id = 1; x = (x - one) / (x + one); }
+    } else {
+      if (ix < 0x40038000) { id = 2; x = (x - 1.5) / (one + 1.5 * x); }
+      else { id = 3; x = -1.0 / x; }
+    }
+  }
+  z = x * x;
+  w = z * z;
+  s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+  s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+  if (id < 0) return x - x * (s1 + s2);
+  z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+  return (hx < 0) ? -z : z;
+}
+AMWG_HD double log10_v8(double x) {
+  const double two54 = 1.80143985094819840000e+16, ivln10 = 4.34294481903251816668e-01, log10_2hi = 3.01029995663611771306e-01, log10_2lo = 3.69423907715893078616e-13, zero = 0.0;
+  double y, z;
+  int32_t i, k, hx;
+  uint32_t lx;
+  hx = hi_word(x); lx = lo_word(x);
+  k = 0;
+  if (hx < 0x00100000) {
+    if (((hx & 0x7fffffff) | lx) == 0) return -two54 / zero;
+    if (hx < 0) return (x - x) / zero;
+    k -= 54; x *= two54; hx = hi_word(x);
+  }
+  if (hx >= 0x7ff00000) return x + x;
+  k += (hx >> 20) - 1023;
+  i = ((uint32_t)k & 0x80000000) >> 31;
+  hx = (hx & 0x000fffff) | ((0x3ff - i) << 20);
+  y = (double)(k + i);
+  x = set_hi_word(x, hx);
+  z = y * log10_2lo + ivln10 * log_v8(x);
+  return z + y * log10_2hi;
+}
+
 // Math.round: nearest integer, ties toward +infinity (mcmc.js:597).
 AMWG_HD double js_round(double x) {
   if (!(__builtin_fabs(x) < 4503599627370496.0)) return x;

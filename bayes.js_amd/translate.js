@@ -7,7 +7,7 @@
  * The closure is read from its own source text (Function.prototype.toString) and must stay
  * inside a numeric subset of JavaScript:
  *     var/let/const, assignments (= += -= *= /=, ++ --), for / while / if / else / return, blocks
- *     numbers, + - * / % **, comparisons, && || !, ?:, Math.{log,exp,log1p,expm1,sqrt,abs,pow,floor,ceil,round,
+ *     numbers, + - * / % **, comparisons, && || !, ?:, Math.{log,exp,log1p,expm1,log10,tanh,atan,sqrt,abs,pow,floor,ceil,round,
  *     min,max,trunc,sign,PI,E,...}, every ld.* of distributions.js with scalar arguments,
  *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, local
  *     aliases of those (var p = par.p[0]), derived quantities (state.key = expr, mcmc.js:961-963),
@@ -318,11 +318,12 @@ const LD_FUNS = {
 const MATH_CONST = { PI: Math.PI, E: Math.E, LN2: Math.LN2, LN10: Math.LN10, LOG2E: Math.LOG2E, LOG10E: Math.LOG10E, SQRT2: Math.SQRT2, SQRT1_2: Math.SQRT1_2 };
 // Math.f -> [device function, arity, host function used for constant folding]
 const MATH_FUNS = {
-  log: ['log_v8', 1, Math.log], exp: ['exp_v8', 1, Math.exp], log1p: ['log1p_v8', 1, Math.log1p], expm1: ['expm1_v8', 1, Math.expm1], sqrt: ['__builtin_sqrt', 1, Math.sqrt], abs: ['__builtin_fabs', 1, Math.abs],
+  log: ['log_v8', 1, Math.log], exp: ['exp_v8', 1, Math.exp], log1p: ['log1p_v8', 1, Math.log1p], expm1: ['expm1_v8', 1, Math.expm1],
+  tanh: ['tanh_v8', 1, Math.tanh], atan: ['atan_v8', 1, Math.atan], log10: ['log10_v8', 1, Math.log10], sqrt: ['__builtin_sqrt', 1, Math.sqrt], abs: ['__builtin_fabs', 1, Math.abs],
   floor: ['__builtin_floor', 1, Math.floor], ceil: ['__builtin_ceil', 1, Math.ceil], round: ['js_round', 1, Math.round],
   trunc: ['js_trunc', 1, Math.trunc], sign: ['js_sign', 1, Math.sign],
 };
-const HEAVY = new Set(['log_v8', 'exp_v8', 'pow_v8', 'log1p_v8', 'expm1_v8', 'ld_norm', 'ld_beta', 'ld_pois', 'ld_bern', 'ld_gamma', 'ld_invgamma', 'ld_lnorm', 'ld_t',
+const HEAVY = new Set(['log_v8', 'exp_v8', 'pow_v8', 'log1p_v8', 'expm1_v8', 'tanh_v8', 'atan_v8', 'log10_v8', 'ld_norm', 'ld_beta', 'ld_pois', 'ld_bern', 'ld_gamma', 'ld_invgamma', 'ld_lnorm', 'ld_t',
   'ld_weibull', 'ld_logis', 'ld_binom', 'ld_nbinom', 'ld_hyper', 'ld_cauchy', 'ld_pareto', 'ld_exp', 'ld_laplace', 'ld_unif', 'lgamma_js', 'lfactorial_js', 'lchoose_js', 'lbeta_js']);
 
 const ld_host = require('./ld.js');
@@ -621,7 +622,7 @@ Translator.prototype.cond = function (e) {
 Translator.prototype.call = function (e) {
   const v = this.callInner(e);
   if (v.t !== 'num' || v.cst !== undefined || v.int || !this.loops.length || this.noHoist || this.pending.length) return v;
-  if (!/^(exp_v8|log_v8|pow_v8|log1p_v8|expm1_v8|__builtin_sqrt|ld_\w+|lgamma_js|lfactorial_js|lchoose_js|lbeta_js|h_\w+)\(/.test(v.code)) return v;
+  if (!/^(exp_v8|log_v8|pow_v8|log1p_v8|expm1_v8|tanh_v8|atan_v8|log10_v8|__builtin_sqrt|ld_\w+|lgamma_js|lfactorial_js|lchoose_js|lbeta_js|h_\w+)\(/.test(v.code)) return v;
   if (/NORMCALL|_inv\(|_inv01\(|_pre\(/.test(v.code)) return v;            // already specialised for the loop
   const k = this.hoist(e, 'double', '', v.code, '');
   return k ? num(k, false) : v;

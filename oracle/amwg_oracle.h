@@ -80,6 +80,9 @@ double orc_lgamma(double x);
 double orc_pow(double x, double y);   /* V8 Math.pow */
 double orc_log1p(double x);          /* V8 Math.log1p */
 double orc_expm1(double x);          /* V8 Math.expm1 */
+double orc_tanh(double x);           /* V8 Math.tanh */
+double orc_atan(double x);           /* V8 Math.atan */
+double orc_log10(double x);          /* V8 Math.log10 */
 /* every scalar density / helper of distributions.js by id (oracle/gen_ld_golden.js lists the ids) */
 double orc_ld(int id, double x, double a, double b, double c);
 

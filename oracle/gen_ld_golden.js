@@ -66,4 +66,17 @@ fs.writeFileSync(path.join(OUT, 'v8_pow_pairs.bin'), pb);
   }
   fs.writeFileSync(path.join(OUT, 'v8_log1p_expm1_pairs.bin'), lb);
 }
+// ---- Math.tanh / Math.atan / Math.log10 of this V8: records (x, tanh x, atan x, log10 |x|)
+{
+  const M = 60000, mb = Buffer.alloc(M * 32);
+  const spx = [0, -0, 1, -1, 0.5, -0.5, 22, -22, 23, 1e-9, -1e-9, 1e-300, Infinity, -Infinity, NaN, 0.4375, 0.6875, 1.1875, 2.4375, 1e20, -1e20, 100, 10, 1000, 1e-5];
+  for (let i = 0; i < M; i++) {
+    let x; const m = i % 5;
+    if (i < spx.length) x = spx[i];
+    else if (m === 0) x = (rnd() - 0.5) * 6; else if (m === 1) x = (rnd() - 0.5) * 60; else if (m === 2) x = (rnd() - 0.5) * 2e-3;
+    else if (m === 3) x = Math.exp((rnd() - 0.5) * 200) * (rnd() < 0.5 ? -1 : 1); else x = (rnd() - 0.5) * 2;
+    mb.writeDoubleLE(x, i * 32); mb.writeDoubleLE(Math.tanh(x), i * 32 + 8); mb.writeDoubleLE(Math.atan(x), i * 32 + 16); mb.writeDoubleLE(Math.log10(Math.abs(x)), i * 32 + 24);
+  }
+  fs.writeFileSync(path.join(OUT, 'v8_math2_pairs.bin'), mb);
+}
 console.log('ld_values.bin:', recs.length, 'records; v8_pow_pairs.bin:', N, 'pairs');

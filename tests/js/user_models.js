@@ -371,7 +371,7 @@ CASES.logistic_softplus = {
       var eta = s.b0 + s.b1 * d.x1[i] + s.b2 * d.x2[i];
       lp += d.y[i] * eta - softplus(eta);                 // log Bernoulli(y | logistic(eta))
     }
-    lp += Math.expm1(-s.tau) * 1e-3 + Math.log1p(s.tau) * 1e-3;
+    lp += Math.expm1(-s.tau) * 1e-3 + Math.log1p(s.tau) * 1e-3 + Math.tanh(s.b1) * 1e-3 + Math.atan(s.b2) * 1e-3 + Math.log10(s.tau + 1) * 1e-3;
     return lp;
   },
   schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],

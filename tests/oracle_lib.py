@@ -63,7 +63,7 @@ def lib():
             getattr(L, f).argtypes = [C.c_double] * n
         L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_set_callback.argtypes = [LOG_POST_FN, C.c_void_p]
-        for f in ("orc_log1p", "orc_expm1"):
+        for f in ("orc_log1p", "orc_expm1", "orc_tanh", "orc_atan", "orc_log10"):
             getattr(L, f).restype = C.c_double
             getattr(L, f).argtypes = [C.c_double]
         L.orc_pow.restype = C.c_double

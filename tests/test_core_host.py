@@ -88,3 +88,9 @@ def test_host_build_of_log1p_expm1_equals_v8():
     L = amwg_ctypes.lib()
     a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_log1p_expm1_pairs.bin"), dtype="<f8").reshape(-1, 3)
     assert sum((not _same(L.amwg_log1p(x), l)) + (not _same(L.amwg_expm1(x), e)) for x, l, e in a) == 0
+
+
+def test_host_build_of_tanh_atan_log10_equals_v8():
+    L = amwg_ctypes.lib()
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_math2_pairs.bin"), dtype="<f8").reshape(-1, 4)
+    assert sum((not _same(L.amwg_math1(0, x), t)) + (not _same(L.amwg_math1(1, x), at)) + (not _same(L.amwg_math1(2, abs(x)), lg)) for x, t, at, lg in a) == 0

@@ -133,3 +133,13 @@ def test_device_log1p_expm1_equal_v8():
         got = A.device_eval(op, a[:, 0])
         ok = (got.view(np.uint64) == a[:, col].view(np.uint64)) | (np.isnan(got) & np.isnan(a[:, col]))
         assert ok.all(), (op, a[~ok][:3], got[~ok][:3])
+
+
+def test_device_tanh_atan_log10_equal_v8():
+    import os
+    import golden_io
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_math2_pairs.bin"), dtype="<f8").reshape(-1, 4)
+    for op, col, arg in ((16, 1, a[:, 0]), (17, 2, a[:, 0]), (18, 3, np.abs(a[:, 0]))):
+        got = A.device_eval(op, arg)
+        ok = (got.view(np.uint64) == a[:, col].view(np.uint64)) | (np.isnan(got) & np.isnan(a[:, col]))
+        assert ok.all(), (op, a[~ok][:3], got[~ok][:3])

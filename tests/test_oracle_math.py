@@ -96,3 +96,10 @@ def test_log1p_expm1_pinned_against_v8():
     a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_log1p_expm1_pairs.bin"), dtype="<f8").reshape(-1, 3)
     assert a.shape[0] == 60000
     assert sum((not _same(L.orc_log1p(x), l)) + (not _same(L.orc_expm1(x), e)) for x, l, e in a) == 0
+
+
+def test_tanh_atan_log10_pinned_against_v8():
+    L = oracle_lib.lib()
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_math2_pairs.bin"), dtype="<f8").reshape(-1, 4)
+    assert a.shape[0] == 60000
+    assert sum((not _same(L.orc_tanh(x), t)) + (not _same(L.orc_atan(x), at)) + (not _same(L.orc_log10(abs(x)), lg)) for x, t, at, lg in a) == 0
