@@ -165,7 +165,9 @@ Parser.prototype = {
       this.endStmt();
       return { k: 'Return', arg };
     }
-    for (const kw of ['break', 'continue', 'do', 'switch', 'throw', 'try', 'function'])
+    if (this.eat('break')) { this.endStmt(); return { k: 'Break' }; }
+    if (this.eat('continue')) { this.endStmt(); return { k: 'Continue' }; }
+    for (const kw of ['do', 'switch', 'throw', 'try', 'function'])
       if (this.peek(kw)) throw "'" + kw + "' statements are not supported inside log_post";
     const expr = this.expression();
     this.endStmt();
@@ -447,6 +449,8 @@ Translator.prototype.lookup = function (name) {
   if (Object.prototype.hasOwnProperty.call(this.localTypes, name)) return num('v_' + name, this.localTypes[name] === 'int', undefined, '(double)v_' + name);
   if (name === 'ld') return { t: 'ns', name: 'ld' };
   if (name === 'Math') return { t: 'ns', name: 'Math' };
+  if (name === 'isNaN' || name === 'isFinite') return { t: 'fn', ns: 'global', name };
+  if (name === 'Number') return { t: 'ns', name: 'Number' };
   if (name === 'Infinity') return cnum(Infinity);
   if (name === 'NaN') return cnum(NaN);
   const consts = this.opts.constants || {};
@@ -634,6 +638,12 @@ Translator.prototype.callInner = function (e) {
   const args = e.args.map((a) => this.expr(a));
   const nums = () => args.map((a) => { if (a.t !== 'num' && a.t !== 'bool') this.fail(f.ns + '.' + f.name + ' got a ' + this.describe(a) + ' argument (only scalar arguments are supported)'); return a; });
   const allConst = () => args.every((a) => a.cst !== undefined && a.t === 'num');
+  if (f.ns === 'global' || (f.ns === 'Number' && (f.name === 'isNaN' || f.name === 'isFinite'))) {
+    if (args.length !== 1 || args[0].t !== 'num') this.fail(f.name + ' takes one number');
+    if (args[0].cst !== undefined) { const r = f.name === 'isNaN' ? Number.isNaN(args[0].cst) : Number.isFinite(args[0].cst); return { t: 'bool', code: r ? 'true' : 'false', cst: r }; }
+    const x = this.temp(this.asD(args[0]));
+    return { t: 'bool', code: f.name === 'isNaN' ? '(' + x + ' != ' + x + ')' : '(__builtin_fabs(' + x + ') < kInf)' };
+  }
   if (f.ns === 'Math') {
     nums();
     if (f.name === 'pow') {
@@ -966,7 +976,7 @@ Translator.prototype.canonicalLoop = function (s) {    // for (i = A; i < B; i++
 // can the iterations of this top-level loop be dealt to the lanes of a chain?
 Translator.prototype.splittable = function (s, canon) {
   if (!this.split || !canon) return false;
-  if (containsKind(s.body, 'Return')) return false;
+  if (containsKind(s.body, 'Return') || containsKind(s.body, 'Break')) return false;   // would have to stop the other lanes too
   let ok = true;
   const written = assignedNames(s.body);
   written.delete(this.acc);
@@ -1026,6 +1036,15 @@ Translator.prototype.stmt = function (s, out, indent, ctx) {
       return;
     }
     case 'For': return this.forLoop(s, out, indent, ctx);
+    case 'Break': case 'Continue': {
+      if (!this.loopLabels.length) this.fail("'" + (s.k === 'Break' ? 'break' : 'continue') + "' outside a loop");
+      const lab = this.loopLabels[this.loopLabels.length - 1];
+      this.flush(out, indent);
+      // real C++ loops take the keyword; the while-form (init; test; body; update) needs the jump past / to its update
+      out.push(indent + (lab.native ? (s.k === 'Break' ? 'break;' : 'continue;') : 'goto ' + (s.k === 'Break' ? 'brk_' : 'cont_') + lab.id + ';'));
+      if (!lab.native) lab[s.k === 'Break' ? 'usedBreak' : 'usedContinue'] = true;
+      return;
+    }
   }
   this.fail('unsupported statement (' + s.k + ')');
 };
@@ -1059,7 +1078,8 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
                       lastSt.expr.target.k === 'Id' && lastSt.expr.target.name === this.acc;
     let accElsewhere = false;
     for (const st of body.slice(0, -1)) walk(st, (x) => { if ((x.k === 'Assign' || x.k === 'Update') && x.target.k === 'Id' && x.target.name === this.acc) accElsewhere = true; });
-    const single = split && isInt && boundV.int && endsInAcc && !accElsewhere && !containsKind(s.body, 'Return');
+    const single = split && isInt && boundV.int && endsInAcc && !accElsewhere && !containsKind(s.body, 'Return') &&
+                   !containsKind(s.body, 'Continue') && !containsKind(s.body, 'Break');
     if (single) {
       const pre = [];
       const heavyBefore = this.heavyLoop;
@@ -1103,7 +1123,9 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
       this.emitSplit(out, indent, L.preamble, head, loop);
       return;
     }
+    this.loopLabels.push({ native: true });
     for (const x of body) this.stmt(x, inner, ind2, bctx);
+    this.loopLabels.pop();
     this.loops.pop();
     out.push(indent + '{');
     for (const p of L.preamble) out.push(indent + '  ' + p);
@@ -1135,14 +1157,23 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
   const t = s.test ? this.cond(s.test) : { code: 'true' };
   if (this.pending.length) this.fail('this loop condition is too complex (it needs temporaries)');
   this.noHoist = false;
-  this.stmt(s.body, inner, ind2, bctx);
-  if (s.update) this.stmt({ k: 'ExprStmt', expr: s.update }, inner, ind2, bctx);
+  const lab = { native: false, id: this.labelSeq++ };
+  this.loopLabels.push(lab);
+  this.stmt(s.body, inner, ind2 + '  ', bctx);
+  this.loopLabels.pop();
+  const upd = [];
+  if (s.update) this.stmt({ k: 'ExprStmt', expr: s.update }, upd, ind2, bctx);
   this.loops.pop();
   out.push(indent + '{');
   for (const p of L.preamble) out.push(indent + '  ' + p);
   out.push(indent + '  while (' + t.code + ') {');
+  out.push(ind2 + '{');                         // own scope: `continue` jumps out of it, past no initialisation
   for (const ln of inner) out.push(ln);
+  out.push(ind2 + '}');
+  if (lab.usedContinue) out.push(ind2 + 'cont_' + lab.id + ': ;');
+  for (const ln of upd) out.push(ln);
   out.push(indent + '  }');
+  if (lab.usedBreak) out.push(indent + '  brk_' + lab.id + ': ;');
   out.push(indent + '}');
 };
 
@@ -1230,6 +1261,8 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
     for (const nm of Object.keys(keepTypes)) if (keepTypes[nm] === 'double') this.forcedDouble.add(nm);
     this.aliases = {};
     this.localArrays = {};
+    this.loopLabels = [];
+    this.labelSeq = 0;
     this.condDepth = 0;
     this.declaredOnly = new Set();
     this.derivedFinal = this.derived.slice();

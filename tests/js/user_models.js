@@ -349,6 +349,20 @@ CASES.semantics_probe = {
     lp *= 1.0000001;
     lp /= 1.0000001;
     lp -= Math.abs(s.k) * 1e-3 + Math.max(s.a, s.b, 0.3) * 1e-3 + Math.min(s.a, -s.b) * 1e-3 + Math.sign(s.b) * 1e-3 + Math.trunc(s.a * 3) * 1e-3 + Math.ceil(s.b) * 1e-3;
+    for (var q = 0; q < d.n; q++) {                   // continue / break in a for loop
+      if (d.v[q] < 0) continue;
+      if (d.v[q] > 1e5) break;
+      lp += d.v[q] * 1e-4;
+    }
+    var r = 0, guard = 0;
+    while (true) {                                     // ... and in a while loop (update must still run after continue)
+      guard += 1;
+      if (guard > 20) break;
+      r += 1;
+      if (r % 3 === 0) continue;
+      lp += r * 1e-5;
+    }
+    lp += (isNaN(nan) ? 1e-3 : 0) + (isFinite(s.a) ? 1e-3 : 0) + (Number.isNaN(s.b) ? 1 : 0) + (isFinite(1 / (s.k - s.k)) ? 1 : 0);
     lp += ld.norm(s.a, 1, 2) + ld.norm(s.b, -1, 2) + ld.unif(s.k, -5, 9);
     return lp;
   },
