@@ -6,9 +6,9 @@
  *
  * The closure is read from its own source text (Function.prototype.toString) and must stay
  * inside a numeric subset of JavaScript:
- *     var/let/const, assignments (= += -= *= /=, ++ --), for / while / if / else / return, blocks
+ *     var/let/const, assignments (= += -= *= /= %=, ++ --), for / while / if / else / break / continue / return, blocks
  *     numbers, + - * / % **, comparisons, && || !, ?:, Math.{log,exp,log1p,expm1,log10,tanh,atan,sqrt,abs,pow,floor,ceil,round,
- *     min,max,trunc,sign,PI,E,...}, every ld.* of distributions.js with scalar arguments,
+ *     min,max,trunc,sign,PI,E,...}, isNaN, isFinite, every ld.* of distributions.js (array-valued ones unrolled),
  *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, local
  *     aliases of those (var p = par.p[0]), derived quantities (state.key = expr, mcmc.js:961-963),
  *     helper functions and constants passed in options.helpers / options.constants.
@@ -23,10 +23,12 @@
  * the returned variable are split G ways (lane j takes iterations j, j+G, ...; lane 0 also adds
  * every term outside those loops) and the kernel adds the lane partial sums with an xor butterfly.
  *
- * Two result-preserving optimisations, both applied only where a value provably does not change
- * inside a loop: ld.norm with a loop-invariant sd uses the hoisted form of csrc/amwg_user.h
- * (same roundings, correctly rounded quotient), ld.bern with a loop-invariant p selects between
- * its two possible values.
+ * Result-preserving optimisations, applied only where a value provably does not change inside a loop: ld.norm with a
+ * loop-invariant sd uses the hoisted form of csrc/amwg_user.h (same roundings, correctly rounded quotient; a straight-line
+ * fast loop plus an IEEE replay if a range precondition failed); ld.bern with a loop-invariant p selects between its two
+ * possible values and, over a whole 0/1 array with one lane per chain, fast-forwards the two-valued sequential sum exactly
+ * (csrc/amwg_twoval.h); pure calls with loop-invariant arguments are evaluated once before the loop; lfactorial / lchoose of
+ * pure data are tabulated on the host by the same formula; integer-valued data arrays are stored as u8 / i32.
  */
 
 // ------------------------------------------------------------------------------------------
