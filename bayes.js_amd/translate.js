@@ -227,7 +227,23 @@ Parser.prototype = {
     const t = this.tk[this.i];
     if (t.t === 'num') { this.i++; return { k: 'Num', v: t.v }; }
     if (t.t === 'str') { this.i++; return { k: 'Str', v: t.v }; }
-    if (this.eat('(')) { const e = this.expression(); this.expect(')'); return e; }
+    if (this.peek('(')) {
+      // (a, b) => ...   -- try the arrow-parameter reading first, fall back to a parenthesised expression
+      const save = this.i;
+      this.i++;
+      const params = [];
+      let ok = true;
+      if (!this.peek(')')) {
+        do { const q = this.tk[this.i]; if (q.t === 'id' && !KEYWORDS.has(q.v)) { params.push(q.v); this.i++; } else { ok = false; break; } } while (this.eat(','));
+      }
+      if (ok && this.eat(')') && this.eat('=>')) {
+        const body = this.peek('{') ? this.block() : { k: 'Block', body: [{ k: 'Return', arg: this.assignment() }] };
+        return { k: 'Func', params, body };
+      }
+      this.i = save;
+      this.i++;
+      const e = this.expression(); this.expect(')'); return e;
+    }
     if (this.eat('[')) {
       const elems = [];
       if (!this.peek(']')) do { elems.push(this.assignment()); } while (this.eat(','));
@@ -236,7 +252,20 @@ Parser.prototype = {
     }
     if (t.t === 'id') {
       if (t.v === 'true' || t.v === 'false') { this.i++; return { k: 'Bool', v: t.v === 'true' }; }
-      if (t.v === 'function') throw 'nested functions are not supported inside log_post; pass helpers in options.helpers';
+      if (t.v === 'function') {          // function expression: only meaningful as `var f = function (...) {...}` (a local helper)
+        this.i++;
+        if (!this.peek('(')) this.ident();
+        this.expect('(');
+        const params = [];
+        if (!this.peek(')')) do { params.push(this.ident()); } while (this.eat(','));
+        this.expect(')');
+        return { k: 'Func', params, body: this.block() };
+      }
+      if (this.peekAt(1, '=>') && !KEYWORDS.has(t.v)) {   // x => ...
+        this.i += 2;
+        const body = this.peek('{') ? this.block() : { k: 'Block', body: [{ k: 'Return', arg: this.assignment() }] };
+        return { k: 'Func', params: [t.v], body };
+      }
       if (KEYWORDS.has(t.v)) throw "'" + t.v + "' is not supported inside log_post";
       this.i++;
       return { k: 'Id', name: t.v };
@@ -346,8 +375,11 @@ const hasNormCall = (lines) => lines.some((ln) => ln.indexOf('NORMCALL') >= 0);
 function Translator(fn, params, data, opts, isHelper) {
   this.opts = opts || {};
   this.isHelper = !!isHelper;
-  this.fnSource = typeof fn === 'string' ? fn : Function.prototype.toString.call(fn);
-  this.ast = parseFunctionSource(this.fnSource);
+  if (fn && fn.k === 'Func') this.ast = { params: fn.params, body: fn.body };     // a function expression inside log_post
+  else {
+    this.fnSource = typeof fn === 'string' ? fn : Function.prototype.toString.call(fn);
+    this.ast = parseFunctionSource(this.fnSource);
+  }
   if (!isHelper && (this.ast.params.length < 1 || this.ast.params.length > 2)) throw 'log_post must take (state) or (state, data)';
   this.stateName = isHelper ? null : this.ast.params[0];
   this.dataName = isHelper ? null : (this.ast.params[1] || null);
@@ -458,6 +490,7 @@ Translator.prototype.lookup = function (name) {
   const consts = this.opts.constants || {};
   if (Object.prototype.hasOwnProperty.call(consts, name)) return this.dataValue('#' + name, consts[name]);
   const helpers = this.opts.helpers || {};
+  if (this.localFuncs && Object.prototype.hasOwnProperty.call(this.localFuncs, name)) return { t: 'fn', ns: 'helper', name };
   if (Object.prototype.hasOwnProperty.call(helpers, name)) return { t: 'fn', ns: 'helper', name };
   this.fail("'" + name + "' is not defined inside log_post (free variables of the closure are invisible to the translator: " +
             'pass numbers/arrays in options.constants and functions in options.helpers)');
@@ -607,6 +640,7 @@ Translator.prototype.expr = function (e) {
       return num('(' + t.code + ' ? ' + this.asD(a) + ' : ' + this.asD(b) + ')', false);
     }
     case 'Call': return this.call(e);
+    case 'Func': this.fail('a function expression can only be assigned to a variable (var f = function (x) {...})');   // eslint-disable-line no-fallthrough
     case 'Assign': case 'Update': this.fail('assignments are only supported as statements');  // eslint-disable-line no-fallthrough
     case 'Str': this.fail('strings are not supported (only as property names: data["x"])');   // eslint-disable-line no-fallthrough
     case 'Seq': this.fail("the ',' operator is not supported");   // eslint-disable-line no-fallthrough
@@ -845,10 +879,11 @@ Translator.prototype.arrayDensity = function (name, args) {
 // ---- helper functions (options.helpers) --------------------------------------------------------
 Translator.prototype.helper = function (name) {
   if (this.helpers[name]) return this.helpers[name];
-  const fn = this.opts.helpers[name];
-  if (typeof fn !== 'function') this.fail('options.helpers.' + name + ' is not a function');
+  const fn = (this.localFuncs && this.localFuncs[name]) || (this.opts.helpers || {})[name];
+  if (!(typeof fn === 'function' || (fn && fn.k === 'Func'))) this.fail('options.helpers.' + name + ' is not a function');
   const sub = new Translator(fn, {}, null, { constants: this.opts.constants, helpers: this.opts.helpers }, true);
   sub.helpers = this.helpers;
+  sub.localFuncs = this.localFuncs;
   sub.arrays = this.arrays; sub.arrayIds = this.arrayIds;
   sub.helperSources = this.helperSources;
   const h = { cname: 'h_' + name, nargs: sub.ast.params.length };
@@ -875,6 +910,14 @@ Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) 
   if (target.k === 'Id') {
     const name = target.name;
     if (name === this.stateName || name === this.dataName) this.fail('assigning to ' + name);
+    if (valueAst.k === 'Func') {
+      // `var f = function (a, b) {...}` / an arrow: a helper that may use its arguments, constants and other helpers (a closure over
+      // the surrounding locals is not supported: the translator would have to capture their values)
+      if (op !== '=' || this.loops.length || this.condDepth) this.fail('function ' + name + ' must be defined by a plain assignment at the top level of log_post');
+      this.localFuncs = this.localFuncs || {};
+      this.localFuncs[name] = valueAst;
+      return;
+    }
     const v = this.expr(valueAst);
     if (v.t === 'localArr' && op === '=') {
       // a variable holding an array of numbers: C array declared at the top, filled here (elements may be reassigned later)

@@ -379,10 +379,12 @@ CASES.logistic_softplus = {
     return Math.log1p(Math.exp(t));
   } },
   log_post: function(s, d) {
+    var inv_sqrt = function (t) { return 1 / Math.sqrt(t); };          // local helpers: a function expression and an arrow
+    var lin = (a, b, c, u, v) => a + b * u + c * v;
     var lp = ld.gamma(s.tau, 2, 2);
-    lp += ld.norm(s.b0, 0, 1 / Math.sqrt(s.tau)) + ld.norm(s.b1, 0, 1 / Math.sqrt(s.tau)) + ld.norm(s.b2, 0, 1 / Math.sqrt(s.tau));
+    lp += ld.norm(s.b0, 0, inv_sqrt(s.tau)) + ld.norm(s.b1, 0, 1 / Math.sqrt(s.tau)) + ld.norm(s.b2, 0, 1 / Math.sqrt(s.tau));
     for (var i = 0; i < d.y.length; i++) {
-      var eta = s.b0 + s.b1 * d.x1[i] + s.b2 * d.x2[i];
+      var eta = lin(s.b0, s.b1, s.b2, d.x1[i], d.x2[i]);
       lp += d.y[i] * eta - softplus(eta);                 // log Bernoulli(y | logistic(eta))
     }
     lp += Math.expm1(-s.tau) * 1e-3 + Math.log1p(s.tau) * 1e-3 + Math.tanh(s.b1) * 1e-3 + Math.atan(s.b2) * 1e-3 + Math.log10(s.tau + 1) * 1e-3;
