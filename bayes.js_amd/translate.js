@@ -492,8 +492,16 @@ Translator.prototype.lookup = function (name) {
   const helpers = this.opts.helpers || {};
   if (this.localFuncs && Object.prototype.hasOwnProperty.call(this.localFuncs, name)) return { t: 'fn', ns: 'helper', name };
   if (Object.prototype.hasOwnProperty.call(helpers, name)) return { t: 'fn', ns: 'helper', name };
-  this.fail("'" + name + "' is not defined inside log_post (free variables of the closure are invisible to the translator: " +
-            'pass numbers/arrays in options.constants and functions in options.helpers)');
+  // script-style code (the reference's README and tests run in a browser page): free names that are GLOBALS are visible -- numbers and
+  // arrays are captured by value now, functions become helpers; module-scoped variables are not reachable, they need options.*
+  if (typeof globalThis !== 'undefined' && name in globalThis && ['ld', 'Math'].indexOf(name) < 0) {
+    const gv = globalThis[name];
+    if (typeof gv === 'function') { this.opts.helpers = Object.assign({}, this.opts.helpers, { [name]: gv }); return { t: 'fn', ns: 'helper', name }; }
+    if (typeof gv === 'number' || typeof gv === 'boolean' || Array.isArray(gv) || ArrayBuffer.isView(gv) || (gv && typeof gv === 'object'))
+      return this.dataValue('#global:' + name, gv);
+  }
+  this.fail("'" + name + "' is not defined inside log_post (free variables of the closure are invisible to the translator unless they are " +
+            'globals: pass numbers/arrays in options.constants and functions in options.helpers)');
 };
 
 Translator.prototype.dataValue = function (path, v) {

@@ -137,6 +137,15 @@ assert.throws(() => new mcmc.AmwgSampler({ mu: { type: 'complex', init: 1 }, sig
     assert.ok(tr.source.indexOf('struct UserModel') > 0, name);
     assert.ok(mcmc.native().compileUser(tr.source, tr.parallel ? 4 : 1, 256, 'gfx950') > 10000, name);
   }
+  // script-style globals (the reference's README / test pages define helpers and constants as globals) are visible to the translator
+  {
+    global.logit_g = function(p) { return Math.log(p / (1 - p)); };
+    global.HYPER_G = [0, 10];
+    const lp = function(par, d) { var s = ld.norm(par.m, HYPER_G[0], HYPER_G[1] * 2); for (var i = 0; i < d.x.length; i++) { s += ld.norm(logit_g(d.x[i]), par.m, 1); } return s; };
+    const trg = mcmc.translate(lp, mcmc.complete_params({ m: {} }, mcmc.param_init_fixed), { x: [0.2, 0.5, 0.7] }, {});
+    assert.ok(trg.source.indexOf('h_logit_g') > 0 && /ld_norm\(S\(0\), 0\.0, 20\.0\)/.test(trg.source));
+    delete global.logit_g; delete global.HYPER_G;
+  }
   // README closures translate to lane-split, LDS-staged, hoisted code
   const tr = mcmc.translate(readme_normal, mcmc.complete_params(params, mcmc.param_init_fixed), data10, {});
   assert.strictEqual(tr.parallel, 1);
