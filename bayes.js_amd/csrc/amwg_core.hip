@@ -101,6 +101,18 @@ int model_max_threads(int model) {
 
 bool value_mid_range(double v) { return v == 0.0 || mid_range(std::fabs(v)); }
 
+// scratch device buffer of the helper entry points: freed on every exit path
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+struct EventPair {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
+
 }  // namespace
 
 
@@ -407,25 +419,40 @@ static int check_options(const amwg_options *options, int max_threads) {
   return AMWG_OK;
 }
 
-// completed params (mcmc.js:357-403) -> flat layout
-static int build_layout(amwg_sampler *s, const amwg_param_desc *params, int n_params) {
+// completed params (mcmc.js:357-403) -> flat layout.  Stepped parameters first (s->n_params of them, at most kMaxNamed); trailing
+// AMWG_FIXED entries only add state slots.
+static int build_layout(amwg_sampler *s, const amwg_param_desc *params, int n_params, bool allow_fixed) {
   ParamLayout &pl = s->pl;
-  pl.n_params = n_params;
   pl.max_top = 1;
-  int P = 0;
+  int P = 0, n_stepped = 0;
+  bool fixed_seen = false;
   for (int p = 0; p < n_params; ++p) {
     const amwg_param_desc &q = params[p];
+    if (q.type == AMWG_FIXED) {
+      if (!allow_fixed) return fail(AMWG_EINVAL, "parameter %d: AMWG_FIXED entries are only supported by amwg_create_user", p);
+      if (q.len < 1) return fail(AMWG_EINVAL, "parameter %d: bad len %d", p, q.len);
+      fixed_seen = true;
+      P += q.len;
+      continue;
+    }
+    if (fixed_seen) return fail(AMWG_EINVAL, "parameter %d: stepped parameters must come before the AMWG_FIXED entries", p);
     if (q.type != AMWG_REAL && q.type != AMWG_INT && q.type != AMWG_BINARY)
       return fail(AMWG_EINVAL, "AmwgStepper can't handle parameter %d with type %d", p, q.type);   // mcmc.js:867
+    if (n_stepped >= kMaxNamed) return fail(AMWG_EINVAL, "more than %d stepped parameters", kMaxNamed);
     if (q.len < 1 || q.top < 1 || q.len % q.top) return fail(AMWG_EINVAL, "parameter %d: bad dim (len %d, top %d)", p, q.len, q.top);
     if (q.top > kMaxTop) return fail(AMWG_EINVAL, "parameter %d: leading dimension %d > %d", p, q.top, kMaxTop);
     if (!q.multidim && q.len != 1) return fail(AMWG_EINVAL, "parameter %d: dim [1] but len %d", p, q.len);
-    pl.base[p] = P; pl.len[p] = q.len; pl.top[p] = q.top; pl.multidim[p] = q.multidim ? 1 : 0;
+    pl.base[n_stepped] = P; pl.len[n_stepped] = q.len; pl.top[n_stepped] = q.top; pl.multidim[n_stepped] = q.multidim ? 1 : 0;
     if (q.multidim && q.top > pl.max_top) pl.max_top = q.top;
     P += q.len;
+    ++n_stepped;
+    pl.P_stepped = P;
   }
+  if (n_stepped < 1) return fail(AMWG_EINVAL, "no parameter to step");
+  pl.n_params = n_stepped;
   pl.P = P;
   s->P = P;
+  s->n_params = n_stepped;
   return AMWG_OK;
 }
 
@@ -564,14 +591,13 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   s->opt = *options;
   s->model = m->model;
   s->C = options->chains;
-  s->n_params = n_params;
   s->device = options->device;
   auto bail = [&](int rc) { amwg_destroy(s); return rc; };
 #undef TRYB
 #undef HIPB
 #define TRYB(x) do { int rc_ = (x); if (rc_ != AMWG_OK) return bail(rc_); } while (0)
 #define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(AMWG_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
-  TRYB(build_layout(s, params, n_params));
+  TRYB(build_layout(s, params, n_params, false));
   const int P = s->P;
 
   // ---- model / data checks
@@ -594,6 +620,7 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
       if (n_params != 2 || params[0].len != 8 || P != 9 || m->K != 7)
         return bail(fail(AMWG_EINVAL, "pois_glm model expects params {beta[8], cp} and K = 7"));
       if ((!m->x || !m->y) && N) return bail(fail(AMWG_EINVAL, "pois_glm model: X or y is null"));
+      if (N > (1 << 28)) return bail(fail(AMWG_EINVAL, "pois_glm model: %d observations (supported: up to 2^28; the kernel addresses a column with 32-bit byte offsets)", N));
       break;
     default: return bail(fail(AMWG_EINVAL, "unknown model id %d", m->model));
   }
@@ -702,7 +729,7 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
 int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, int32_t n_params, const double *init,
                      const amwg_comp_opt *comp_opts, const amwg_options *options, amwg_sampler **out) {
   if (!m || !m->source || !params || !init || !comp_opts || !options || !out) return fail(AMWG_EINVAL, "amwg_create_user: null argument");
-  if (n_params < 1 || n_params > kMaxNamed) return fail(AMWG_EINVAL, "amwg_create_user: %d named parameters (supported: 1..%d)", n_params, kMaxNamed);
+  if (n_params < 1 || n_params > 4096) return fail(AMWG_EINVAL, "amwg_create_user: %d parameter entries (supported: 1..4096, of which at most %d stepped)", n_params, kMaxNamed);
   if (m->n_arrays < 0 || m->n_arrays > kMaxUserArrays) return fail(AMWG_EINVAL, "amwg_create_user: %d data arrays (supported: 0..%d)", m->n_arrays, kMaxUserArrays);
   if (m->n_arrays && (!m->arrays || !m->array_len)) return fail(AMWG_EINVAL, "amwg_create_user: arrays is null");
   if (m->n_derived < 0 || m->lds_bytes < 0) return fail(AMWG_EINVAL, "amwg_create_user: negative size");
@@ -724,10 +751,9 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
   s->user_work = m->work_per_eval;
   s->user_work_one_lane = m->work_one_lane;
   s->C = options->chains;
-  s->n_params = n_params;
   s->device = options->device;
   auto bail = [&](int rc) { amwg_destroy(s); return rc; };
-  TRYB(build_layout(s, params, n_params));
+  TRYB(build_layout(s, params, n_params, true));
   hipDeviceProp_t prop;
   TRYB(open_device(s, &prop));
 
@@ -844,7 +870,10 @@ int amwg_sample_async(amwg_sampler *s, int64_t n, int64_t thin) {
   const size_t need = (size_t)rows * (size_t)(s->P + s->D) * (size_t)s->C * 8;
   HIP_TRY(hipSetDevice(s->device));
   if (need > s->d_draws_cap) {
-    if (s->d_draws) { (void)hipFree(s->d_draws); s->d_draws = nullptr; s->d_draws_cap = 0; }
+    if (s->d_draws) {
+      if (s->last_draws == s->d_draws) { s->last_draws = nullptr; s->last_rows = 0; }
+      (void)hipFree(s->d_draws); s->d_draws = nullptr; s->d_draws_cap = 0;
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_draws), need ? need : 8));
     s->d_draws_cap = need;
   }
@@ -922,15 +951,13 @@ int amwg_last_sample_diagnostics(amwg_sampler *s, double *rhat, double *ess) {
   HIP_TRY(hipSetDevice(s->device));
   const int PR = s->P + s->D;
   const size_t C = (size_t)s->C, n_out = 4 * (size_t)PR * C;
-  double *dout = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dout), n_out * 8));
-  hipLaunchKernelGGL(chain_halves_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)PR), dim3(256), 0, s->stream, s->last_draws, s->last_rows, PR, s->C, dout);
+  DevBuf dout;
+  HIP_TRY(dout.alloc(n_out * 8));
+  hipLaunchKernelGGL(chain_halves_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)PR), dim3(256), 0, s->stream, s->last_draws, s->last_rows, PR, s->C, dout.as<double>());
   std::vector<double> h(n_out);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), dout, n_out * 8, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-  (void)hipFree(dout);
-  if (e != hipSuccess) return fail(AMWG_EHIP, "diagnostics kernel failed: %s", hipGetErrorString(e));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h.data(), dout.p, n_out * 8, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   const double n = (double)(s->last_rows / 2), m = 2.0 * (double)C;   // 2C half-chains of n draws
   for (int p = 0; p < PR; ++p) {
     // W = mean within-sequence variance; B/n = variance of the sequence means (over the 2C halves)
@@ -999,16 +1026,15 @@ int amwg_last_sample_moments(amwg_sampler *s, double *mean, double *sd) {
   if (!s || !mean || !sd) return fail(AMWG_EINVAL, "amwg_last_sample_moments: null argument");
   if (!s->last_draws || s->last_rows < 1) return fail(AMWG_EINVAL, "amwg_last_sample_moments: no sample() call yet");
   HIP_TRY(hipSetDevice(s->device));
-  double *dm = nullptr;
+  DevBuf buf;
   const int PR = s->P + s->D;
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dm), (size_t)PR * 16));
+  HIP_TRY(buf.alloc((size_t)PR * 16));
+  double *dm = buf.as<double>();
   hipLaunchKernelGGL(moments_kernel, dim3(PR), dim3(1024), 0, s->stream, s->last_draws, s->last_rows, PR, s->C, dm, dm + PR);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(mean, dm, (size_t)PR * 8, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(sd, dm + PR, (size_t)PR * 8, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-  (void)hipFree(dm);
-  if (e != hipSuccess) return fail(AMWG_EHIP, "moments kernel failed: %s", hipGetErrorString(e));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(mean, dm, (size_t)PR * 8, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(sd, dm + PR, (size_t)PR * 8, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   return AMWG_OK;
 }
 
@@ -1036,22 +1062,21 @@ int amwg_fp64_peak(int32_t device, double *lane_ops_per_s) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   const int blocks = (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * 2, threads = 1024, iters = 20000;
-  double *dout = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dout), (size_t)blocks * threads * 8));
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  DevBuf dout;
+  HIP_TRY(dout.alloc((size_t)blocks * threads * 8));
+  EventPair ev;
+  HIP_TRY(hipEventCreate(&ev.e0));
+  HIP_TRY(hipEventCreate(&ev.e1));
   float best = 1e30f;
   for (int rep = 0; rep < 3; ++rep) {    // first repetition warms the clocks up
-    HIP_TRY(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(fp64_peak_kernel, dim3(blocks), dim3(threads), 0, 0, dout, iters, 0.999999, 1e-7);
-    HIP_TRY(hipEventRecord(e1, 0));
-    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventRecord(ev.e0, 0));
+    hipLaunchKernelGGL(fp64_peak_kernel, dim3(blocks), dim3(threads), 0, 0, dout.as<double>(), iters, 0.999999, 1e-7);
+    HIP_TRY(hipEventRecord(ev.e1, 0));
+    HIP_TRY(hipEventSynchronize(ev.e1));
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
     if (rep > 0 && ms < best) best = ms;
   }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(dout);
   *lane_ops_per_s = (double)blocks * threads * (double)iters * 64.0 / (best * 1e-3);
   return AMWG_OK;
 }
@@ -1066,21 +1091,19 @@ int amwg_two_valued_sum_check(int32_t device, const double *x, int32_t n, int64_
   std::vector<uint8_t> xb((size_t)n);
   for (int i = 0; i < n; ++i) xb[i] = x[i] == 1 ? 1 : 0;
   const std::vector<uint32_t> tab = two_valued_tables(xb.data(), n);
-  uint32_t *dtab = nullptr;
-  double *d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dtab), tab.size() * 4));
-  HIP_TRY(hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  DevBuf dtab, d[5];
+  HIP_TRY(dtab.alloc(tab.size() * 4));
+  HIP_TRY(hipMemcpy(dtab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
   const double *src[3] = {acc0, l1, l0};
   for (int k = 0; k < 5; ++k) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d[k]), m ? (size_t)m * 8 : 8));
-    if (k < 3 && m) HIP_TRY(hipMemcpy(d[k], src[k], (size_t)m * 8, hipMemcpyHostToDevice));
+    HIP_TRY(d[k].alloc((size_t)m * 8));
+    if (k < 3 && m) HIP_TRY(hipMemcpy(d[k].p, src[k], (size_t)m * 8, hipMemcpyHostToDevice));
   }
-  if (m) hipLaunchKernelGGL(two_valued_check_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, 0, dtab, n, m, d[0], d[1], d[2], d[3], d[4]);
+  if (m) hipLaunchKernelGGL(two_valued_check_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, 0, dtab.as<uint32_t>(), n, m,
+                            d[0].as<double>(), d[1].as<double>(), d[2].as<double>(), d[3].as<double>(), d[4].as<double>());
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(out_fast_forward, d[3], (size_t)m * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_term_by_term, d[4], (size_t)m * 8, hipMemcpyDeviceToHost));
-  (void)hipFree(dtab);
-  for (int k = 0; k < 5; ++k) (void)hipFree(d[k]);
+  HIP_TRY(hipMemcpy(out_fast_forward, d[3].p, (size_t)m * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_term_by_term, d[4].p, (size_t)m * 8, hipMemcpyDeviceToHost));
   return AMWG_OK;
 }
 
@@ -1090,14 +1113,13 @@ int amwg_ld_device(int32_t device, int64_t n, const double *records, double *out
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev < 1) return fail(AMWG_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
   HIP_TRY(hipSetDevice(device));
-  double *dr = nullptr, *dout = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dr), n ? (size_t)n * 40 : 8));
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dout), n ? (size_t)n * 8 : 8));
-  HIP_TRY(hipMemcpy(dr, records, (size_t)n * 40, hipMemcpyHostToDevice));
-  if (n) hipLaunchKernelGGL(amwg_ld_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, dr, dout);
+  DevBuf dr, dout;
+  HIP_TRY(dr.alloc((size_t)n * 40));
+  HIP_TRY(dout.alloc((size_t)n * 8));
+  HIP_TRY(hipMemcpy(dr.p, records, (size_t)n * 40, hipMemcpyHostToDevice));
+  if (n) hipLaunchKernelGGL(amwg_ld_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, dr.as<double>(), dout.as<double>());
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
-  (void)hipFree(dr); (void)hipFree(dout);
+  HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost));
   return AMWG_OK;
 }
 
@@ -1107,19 +1129,16 @@ int amwg_device_eval(int32_t device, int32_t op, int64_t n, const double *a, con
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev < 1) return fail(AMWG_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
   HIP_TRY(hipSetDevice(device));
-  double *da = nullptr, *db = nullptr, *dc = nullptr, *dout = nullptr;
+  DevBuf da, db, dc, dout;
   const size_t bytes = (size_t)n * 8;
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&da), bytes ? bytes : 8));
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dout), bytes ? bytes : 8));
-  HIP_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
-  if (b) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&db), bytes ? bytes : 8)); HIP_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice)); }
-  if (c) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dc), bytes ? bytes : 8)); HIP_TRY(hipMemcpy(dc, c, bytes, hipMemcpyHostToDevice)); }
-  if (n) hipLaunchKernelGGL(amwg_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, n, da, db, dc, dout);
+  HIP_TRY(da.alloc(bytes));
+  HIP_TRY(dout.alloc(bytes));
+  HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+  if (b) { HIP_TRY(db.alloc(bytes)); HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice)); }
+  if (c) { HIP_TRY(dc.alloc(bytes)); HIP_TRY(hipMemcpy(dc.p, c, bytes, hipMemcpyHostToDevice)); }
+  if (n) hipLaunchKernelGGL(amwg_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, n, da.as<double>(), db.as<double>(), dc.as<double>(), dout.as<double>());
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
-  (void)hipFree(da); (void)hipFree(dout);
-  if (db) (void)hipFree(db);
-  if (dc) (void)hipFree(dc);
+  HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
   return AMWG_OK;
 }
 

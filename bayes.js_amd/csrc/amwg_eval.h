@@ -65,6 +65,7 @@ __global__ void amwg_eval_kernel(int op, int64_t n, const double *a, const doubl
     case 16: r = tanh_v8(x); break;
     case 17: r = atan_v8(x); break;
     case 18: r = log10_v8(x); break;
+    case 19: r = quot_plain(x, y); break;
   }
   out[i] = r;
 }

@@ -288,7 +288,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     }
     // ---- every scalar component exactly once; `slot` is uniform across the block
     int np = 0, e = 0;
-    for (int slot = 0; slot < P; ++slot) {
+    const int P_stepped = pl->P_stepped;   // < P when the state has entries this sampler only reads (AMWG_FIXED)
+    for (int slot = 0; slot < P_stepped; ++slot) {
       const int p = (int)perm_get(perm, np);
       const int len = pl->len[p];
       int comp = pl->base[p];

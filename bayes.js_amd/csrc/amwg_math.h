@@ -129,6 +129,27 @@ AMWG_HD double log_v8_full(double x) {
 // lo = 0, hi = x resp. dk = 0: x/(c-2) == -(x/(2-c)), 0 - a == -a, a + 0 == a, all exact), and
 // everything else (|x| >= 708, |x| < 2^-28, exp(1); log of <= 0, subnormal, inf/NaN, |f| < 2^-20)
 // leaves through ONE rarely-taken branch.
+//
+// quot_plain(a, b): a / b for operands that need none of the exponent juggling of the general fp64 division -- b within
+// [1, 4), a zero or of magnitude in [2^-900, 2^100].  On gfx950 `/` expands to v_div_scale x2, v_rcp_f64, two Newton
+// steps, a quotient, a residual, v_div_fmas and v_div_fixup; for such operands the two v_div_scale are the identity and
+// v_div_fixup returns its first operand, so the same reciprocal / Newton / residual instructions without them give the
+// same bits (tests/test_gpu_math.py compares with `/` on the device).  The host build divides.
+AMWG_HD double quot_plain(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  const double q = a * y;
+  const double r = __builtin_fma(-b, q, a);
+  return __builtin_fma(r, y, q);
+#else
+  return a / b;
+#endif
+}
+
 AMWG_HD double exp_v8(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const double inv_ln2 = 1.44269504088896338700e+00;
@@ -143,13 +164,15 @@ AMWG_HD double exp_v8(double x) {
   const int32_t kb = (int32_t)(inv_ln2 * x + (neg ? -0.5 : 0.5));
   const int32_t k = mid ? (big ? kb : (neg ? -1 : 1)) : 0;
   const double t = (double)k;
-  // k = +-1: x -+ ln2_hi and +-ln2_lo are exactly t*ln2_hi / t*ln2_lo subtracted/used below
-  const double hi = mid ? x - t * ln2_hi : x;
-  const double lo = mid ? t * ln2_lo : 0.0;
-  const double r = mid ? hi - lo : x;
+  // k = +-1: x -+ ln2_hi and +-ln2_lo are exactly t*ln2_hi / t*ln2_lo subtracted/used below;
+  // k = 0: t = +0, so hi = x - 0 = x, lo = +0, r = x - 0 = x -- the unreduced case needs no selects
+  const double hi = x - t * ln2_hi;
+  const double lo = t * ln2_lo;
+  const double r = hi - lo;
   const double rr = r * r;
   const double c = r - rr * (P1 + rr * (P2 + rr * (P3 + rr * (P4 + rr * P5))));
-  const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  // 2 - c in (1.6, 2.4); r*c is 0 or >= 2^-150 in magnitude (|r| >= ulp(ln2-multiple) of a |x| >= 2^-28)
+  const double y = 1.0 - ((lo - quot_plain(r * c, 2.0 - c)) - hi);
   return set_hi_word(y, hi_word(y) + (k << 20));
 }
 
@@ -167,7 +190,7 @@ AMWG_HD double log_v8(double x) {
   const int32_t k = (hx0 >> 20) - 1023 + (i >> 20);
   const double f = m - 1.0;
   const double dk = (double)k;
-  const double s = f / (2.0 + f);
+  const double s = quot_plain(f, 2.0 + f);      // |f| in [2^-20, 0.42), 2 + f in (1.7, 2.42)
   const double z = s * s;
   const double w = z * z;
   const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));

@@ -289,7 +289,9 @@ struct PoisGlmModel {
   static constexpr int kDerived = 0;
   static constexpr int kMaxThreads = 256;    // exp+log per observation want > 128 VGPRs; no LDS tile to share anyway
   static constexpr int kUnroll = 2;   // exp+log per term: more would spill
-  struct Pass { double b[8]; double cp; const double *X, *y, *lfact; int N; };
+  // col[k]: column k of the design matrix, then y and lfactorial(y) -- nine wave-uniform base pointers (scalar registers); an
+  // observation is addressed by ONE 32-bit byte offset per lane (global_load ... vOffset, sBase) instead of nine 64-bit adds
+  struct Pass { double b[8]; double cp; const char *col[9]; };
   __host__ __device__ static size_t lds_bytes(int, int, int) { return 0; }
   __device__ static void stage(unsigned char *, const DataRef &, int, int, int) {}
   // closure order: `for k` over the 8 coefficients (dealt to the lanes), then the change point's prior (lane 0), then the data
@@ -310,17 +312,22 @@ struct PoisGlmModel {
 #pragma unroll
     for (int k = 0; k < 8; ++k) ps.b[k] = S(k);
     ps.cp = S(8);
-    ps.X = d.x; ps.y = d.y; ps.lfact = d.lfact; ps.N = d.n_obs;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) ps.col[k] = reinterpret_cast<const char *>(d.x + (size_t)k * (size_t)d.n_obs);
+    ps.col[7] = reinterpret_cast<const char *>(d.y);
+    ps.col[8] = reinterpret_cast<const char *>(d.lfact);
     return ps;
   }
   template <bool FAST>
   __device__ __forceinline__ static double term(const Pass &ps, int i) {
+    const uint32_t off = (uint32_t)i * 8u;     // n_obs <= 2^28 (amwg_create)
+    auto at = [&](int k) { return *reinterpret_cast<const double *>(ps.col[k] + off); };
     double eta = 0;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) eta += ps.X[(size_t)k * ps.N + i] * ps.b[k];
+    for (int k = 0; k < 7; ++k) eta += at(k) * ps.b[k];
     if ((double)i >= ps.cp) eta += ps.b[7];
     const double lam = exp_v8(eta);
-    return log_v8(lam) * ps.y[i] - lam - ps.lfact[i];
+    return log_v8(lam) * at(7) - lam - at(8);
   }
 };
 

@@ -7,7 +7,7 @@ namespace amwg {
 constexpr int kMaxNamed = 16;    // named parameters per model (their shuffled order is sixteen 4-bit fields of one u64)
 constexpr int kMaxTop = 256;     // largest shuffled dimension (index bytes)
 constexpr int kMaxUserArrays = 16;   // data arrays of a translated (user) log_post
-constexpr int kTypeReal = 0, kTypeInt = 1, kTypeBinary = 2;   // AMWG_REAL / AMWG_INT / AMWG_BINARY
+constexpr int kTypeReal = 0, kTypeInt = 1, kTypeBinary = 2, kTypeFixed = 3;   // AMWG_REAL / AMWG_INT / AMWG_BINARY / AMWG_FIXED
 
 // LDS-resident view of this chain's state: component p at S.base[p].  Chains are laid out
 // [chain][stride] with an ODD stride (in doubles): lanes that own different chains and read the
@@ -31,8 +31,10 @@ struct CompConst {
 };
 
 // Completed parameter layout (mcmc.js:357-403), flattened.
+// The first n_params named parameters (P_stepped scalar components) are stepped; state entries P_stepped..P-1 are only read
+// by log_post (AMWG_FIXED: the rest of the shared state object of a stand-alone stepper).
 struct ParamLayout {
-  int32_t n_params, P, max_top, pad;
+  int32_t n_params, P, max_top, P_stepped;
   int32_t base[kMaxNamed], len[kMaxNamed], top[kMaxNamed], multidim[kMaxNamed];
 };
 

@@ -171,18 +171,23 @@ function nest(flat, offset, dim) {          // row-major flat values -> nested a
   return out;
 }
 
+// module-private option key: the stand-alone stepper classes (below) build their engine through the same constructor and hand it
+// the state object they share with the caller, {state, fixed: [{name, dim, len, flat}]}
+const SHARED = Symbol('amwg.shared_state');
+
 function AmwgSampler(params, log_post, data, options) {
   options = options || {};
   const opt = (k, d) => (options.hasOwnProperty(k) && options[k] !== undefined && options[k] !== null) ? options[k] : d;
+  const shared = options[SHARED] || null;
   this.param_names = Object.keys(params);
   this.param_init_fun = opt('param_init_fun', param_init_fixed);
   this.thin(opt('thin', 1));
   this.monitor(opt('monitor', null));
   this.options = options;
   this.data = data;
-  this.params = complete_params(params, this.param_init_fun);
+  this.params = shared ? params : complete_params(params, this.param_init_fun);   // steppers take completed params (mcmc.js:419-421)
 
-  const recog = opt('translate', false) ? null : models.recognise(log_post);
+  const recog = (shared || opt('translate', false)) ? null : models.recognise(log_post);
   this.model = recog ? recog.family : 'translated';
   if (recog && recog.paramNames && recog.paramNames.join() !== this.param_names.join())
     throw 'AmwgSampler (MI355X): the ' + recog.family + ' model expects params declared as {' + recog.paramNames.join(', ') +
@@ -206,6 +211,16 @@ function AmwgSampler(params, log_post, data, options) {
     this._layout.push({ name, base, len, dim: p.dim, scalar: isScalarDim(p.dim) });
     base += len;
   }
+  this.P_stepped = base;
+  // the entries of a shared state object that no parameter of this stepper owns: state slots log_post reads, never stepped
+  const translatedParams = Object.assign({}, this.params);
+  if (shared) for (const f of shared.fixed) {
+    descs.push({ type: 3 /* AMWG_FIXED */, len: f.len, top: f.len, multidim: 1, lower: -Infinity, upper: Infinity });
+    f.flat.forEach((v) => init.push(v));
+    for (let e = 0; e < f.len; e++) compOpts.push(Object.assign({}, OPTION_DEFAULTS));
+    translatedParams[f.name] = { dim: f.dim };
+    base += f.len;
+  }
   this.P = base;
   this.chains = opt('chains', 1);
   if (!(this.chains >= 1) || Math.floor(this.chains) !== this.chains) throw 'options.chains must be a positive integer';
@@ -216,8 +231,8 @@ function AmwgSampler(params, log_post, data, options) {
   this.derived = [];
   if (recog) desc = buildModelDesc(recog, data);
   else {
-    const tr = translator.translate(log_post, this.params, data, { constants: options.constants, helpers: options.helpers,
-      lds_budget: options.lds_budget, max_threads: options.max_threads, unroll: options.unroll });
+    const tr = translator.translate(log_post, translatedParams, data, { constants: options.constants, helpers: options.helpers,
+      lds_budget: options.lds_budget, max_threads: options.max_threads, unroll: options.unroll, state_object: shared ? shared.state : undefined });
     this.derived = tr.derived;
     this.translation = tr;
     user = { source: tr.source, arrays: tr.arrays, array_types: tr.array_types, n_derived: tr.derived.length, lds_bytes: tr.lds_bytes, lds_bytes_one_lane: tr.lds_bytes_one_lane, parallel: tr.parallel,
@@ -411,4 +426,181 @@ function rnorm(mean, sd) {      // Leva's ratio-of-uniforms, the same constants 
   return (v / u) * sd + mean;
 }
 
-module.exports = { runif, runif_discrete, rnorm, AmwgSampler, complete_params, param_init_fixed, componentOptions, models, ld, native, translate: translator.translate };
+// ---------------------------------------------------------------------------------------------
+// Stand-alone steppers (mcmc.js:1109-1115 exports them; tests/test_mcmc_js.R:52-140 drives them directly):
+//     new mcmc.RealMetropolisStepper(params, state, log_post, options)   .step() .info() .start_adaptation() .stop_adaptation()
+// `params` is a COMPLETE definition (dim, lower, upper -- mcmc.js:417-421) of the parameter(s) the stepper moves, `state` the object
+// it shares with the caller (and with other steppers), `log_post` a function of NO arguments that reads that object (mcmc.js:428-431).
+// Here every stepper owns a one-chain device sampler whose state holds ALL numeric entries of `state`: the stepper's own parameters
+// are stepped, the others are read-only slots (AMWG_FIXED) refreshed from the host object before each step, so several steppers --
+// or the caller -- may move different entries of the same object, as with the reference.  log_post is translated like a sampler's
+// closure; the free name through which it reaches `state` is recognised by identity (a global, or options.constants).
+// One step() is one kernel launch plus two small copies (tens of microseconds): the classes exist for drop-in compatibility;
+// steps(n) (not in the reference) runs n steps in one launch.
+function stateEntry(v) {
+  if (typeof v === 'number' || typeof v === 'boolean') return { dim: [1], flat: [Number(v)], scalar: true };
+  if (!Array.isArray(v) || v.length === 0) return null;
+  const flat = flatten(v, []);
+  if (!flat.every((e) => typeof e === 'number' || typeof e === 'boolean')) return null;
+  let dim;
+  try { dim = shapeOf(v); } catch (e) { return null; }
+  if (dim.reduce((a, b) => a * b, 1) !== flat.length) return null;
+  return { dim, flat: flat.map(Number), scalar: false };
+}
+function writeNested(target, flat, offset) {     // in place, row-major; returns the next offset
+  for (let i = 0; i < target.length; i++) {
+    if (Array.isArray(target[i])) offset = writeNested(target[i], flat, offset);
+    else target[i] = flat[offset++];
+  }
+  return offset;
+}
+
+function Stepper(params, state, log_post) {      // mcmc.js:432-437
+  this.params = params;
+  this.state = state;
+  this.log_post = log_post;
+}
+Stepper.prototype.step = function () { throw 'Every Stepper need to implement step()'; };
+Stepper.prototype.start_adaptation = function () {};
+Stepper.prototype.stop_adaptation = function () {};
+Stepper.prototype.info = function () { return {}; };
+
+// shared constructor body: `types` maps a parameter name to the type its stepper class implies
+function openEngine(self, types, options) {
+  options = options || {};
+  const names = Object.keys(self.params);
+  const completed = {};
+  for (const name of names) {
+    const p = self.params[name], type = types[name];
+    const dim = typeof p.dim === 'number' ? [p.dim] : (p.dim || [1]).slice();
+    const cur = stateEntry(self.state[name]);
+    if (!cur) throw 'the state has no numeric entry for parameter ' + name;
+    if (cur.flat.length !== dim.reduce((a, b) => a * b, 1)) throw 'state.' + name + ' does not match dim [' + dim + ']';
+    completed[name] = { type, dim, lower: type === 'binary' ? 0 : (p.lower === undefined ? -Infinity : p.lower),
+      upper: type === 'binary' ? 1 : (p.upper === undefined ? Infinity : p.upper), init: isScalarDim(dim) ? cur.flat[0] : nest(cur.flat, 0, dim) };
+  }
+  let skip = {};
+  for (let attempt = 0; ; attempt++) {
+    const fixed = [];
+    for (const key of Object.keys(self.state)) {
+      if (completed.hasOwnProperty(key) || skip[key]) continue;
+      const e = stateEntry(self.state[key]);
+      if (e) fixed.push({ name: key, dim: e.dim, len: e.flat.length, flat: e.flat, scalar: e.scalar });
+    }
+    // one lane per chain: the closure's own summation order, so a seeded stepper reproduces the reference bit for bit
+    const engineOptions = Object.assign({ lanes_per_chain: 1 }, options, { chains: 1, devices: undefined, [SHARED]: { state: self.state, fixed } });
+    try {
+      self._engine = new AmwgSampler(completed, self.log_post, undefined, engineOptions);
+      self._fixed = fixed;
+      break;
+    } catch (e) {
+      // a derived quantity (`state.key = ...` inside log_post) that an earlier evaluation already left in the state object is not a slot
+      const m = /assigns to the parameter state\.(\w+)/.exec(String(e));
+      if (!m || completed.hasOwnProperty(m[1]) || skip[m[1]] || attempt > 16) throw e;
+      skip[m[1]] = true;
+    }
+  }
+  const E = self._engine;
+  self._mirror = Float64Array.from(flatten(names.map((n) => self.state[n]), []).concat(flatten(self._fixed.map((f) => f.flat), [])));
+  self._adapting = E._layout.map((L) => flatten(componentOptions(L.name, E.params[L.name], options).map((o) => !!o.is_adapting), []));
+}
+
+// host object -> device, if anybody moved an entry since the device last saw it
+Stepper.prototype._push = function () {
+  const E = this._engine, cur = new Float64Array(E.P);
+  let k = 0;
+  for (const L of E._layout) for (const v of flatten([this.state[L.name]], [])) cur[k++] = Number(v);
+  for (const f of this._fixed) for (const v of flatten([this.state[f.name]], [])) cur[k++] = Number(v);
+  if (k !== E.P) throw 'the shape of the state object changed since the stepper was created';
+  let same = true;
+  for (let i = 0; i < k && same; i++) same = Object.is(cur[i], this._mirror[i]);
+  if (!same) { native().setState(E._shards[0].handle, cur); this._mirror = cur; }
+};
+// device -> host object (only the entries this stepper owns can have moved)
+Stepper.prototype._pull = function () {
+  const E = this._engine, flat = native().getState(E._shards[0].handle);
+  for (const L of E._layout) {
+    if (Array.isArray(this.state[L.name])) writeNested(this.state[L.name], flat, L.base);
+    else this.state[L.name] = flat[L.base];
+  }
+  this._mirror = Float64Array.from(flat);
+  if (E.derived.length) this.log_post();    // the closure itself refreshes its derived keys at the new state
+};
+Stepper.prototype._value = function (name) {
+  const L = this._engine._layout.find((l) => l.name === name), flat = this._mirror;
+  return Array.isArray(this.state[name]) ? nest(flat, L.base, L.dim) : flat[L.base];
+};
+/** n steps in one launch (not in the reference); returns what step() returns after the last one. */
+Stepper.prototype.steps = function (n) {
+  this._push();
+  this._engine.burn(n);
+  this._pull();
+  return this._result();
+};
+Stepper.prototype.close = function () { if (this._engine) this._engine.close(); };
+
+function deviceStepper(className, type, shape) {
+  const oneParam = { scalar: className + ' can only handle one parameter.', multi: className + " can't handle more than one parameter." };
+  const C = function (params, state, log_post, options) {
+    Stepper.call(this, params, state, log_post);
+    const names = Object.keys(this.params);
+    if (names.length !== 1) throw (shape === 'scalar' && type !== 'binary') ? oneParam.scalar : oneParam.multi;    // mcmc.js:489, 634, 746, 788
+    this.param_name = names[0];
+    const dim = this.params[this.param_name].dim;
+    if (shape === 'scalar' && type !== 'binary' && !(Array.isArray(dim) && isScalarDim(dim)))
+      throw className + ' can only handle one one-dimensional parameter.';                                      // mcmc.js:494
+    openEngine(this, { [this.param_name]: type }, options);
+  };
+  C.prototype = Object.create(Stepper.prototype);
+  C.prototype.constructor = C;
+  C.prototype._result = function () { return this._value(this.param_name); };
+  C.prototype.step = function () { return this.steps(1); };
+  if (type !== 'binary') {
+    C.prototype.start_adaptation = function () { this._engine.start_adaptation(); this._adapting = this._adapting.map((a) => a.map(() => true)); };
+    C.prototype.stop_adaptation = function () { this._engine.stop_adaptation(); this._adapting = this._adapting.map((a) => a.map(() => false)); };
+    C.prototype.info = function () { return stepperInfo(this, this._engine._layout[0], 0); };
+  }
+  return C;
+}
+
+// the content of OnedimMetropolisStepper.info (mcmc.js:563-571), per component, nested like the parameter (mcmc.js:700-704)
+function stepperInfo(self, L, li) {
+  const raw = native().info(self._engine._shards[0].handle);
+  const one = (e) => ({ prop_log_scale: raw.prop_log_scale[L.base + e], is_adapting: self._adapting[li][e], acceptance_count: raw.acceptance_count[L.base + e],
+    iterations_since_adaption: raw.iterations_since_adaption[L.base + e], batch_count: raw.batch_count[L.base + e] });
+  return L.scalar ? one(0) : nest(Array.from({ length: L.len }, (_, e) => one(e)), 0, L.dim);
+}
+
+const RealMetropolisStepper = deviceStepper('OnedimMetropolisStepper', 'real', 'scalar');
+const IntMetropolisStepper = deviceStepper('OnedimMetropolisStepper', 'int', 'scalar');
+const MultiRealComponentMetropolisStepper = deviceStepper('MultidimComponentMetropolisStepper', 'real', 'multi');
+const MultiIntComponentMetropolisStepper = deviceStepper('MultidimComponentMetropolisStepper', 'int', 'multi');
+const BinaryStepper = deviceStepper('BinaryStepper', 'binary', 'scalar');
+const BinaryComponentStepper = deviceStepper('BinaryComponentStepper', 'binary', 'multi');
+
+/** mcmc.js:837-916: one sub-stepper per parameter, picked by type and dim, visited in a shuffled order that persists. */
+function AmwgStepper(params, state, log_post, options) {
+  Stepper.call(this, params, state, log_post);
+  this.param_names = Object.keys(this.params);
+  const types = {};
+  for (const name of this.param_names) {
+    const t = params[name].type;
+    if (t !== 'real' && t !== 'int' && t !== 'binary') throw "AmwgStepper can't handle parameter " + name + ' with type ' + t;   // mcmc.js:867
+    types[name] = t;
+  }
+  openEngine(this, types, options);
+}
+AmwgStepper.prototype = Object.create(Stepper.prototype);
+AmwgStepper.prototype.constructor = AmwgStepper;
+AmwgStepper.prototype._result = function () { return this.state; };
+AmwgStepper.prototype.step = function () { return this.steps(1); };
+AmwgStepper.prototype.start_adaptation = function () { this._engine.start_adaptation(); this._adapting = this._adapting.map((a) => a.map(() => true)); };
+AmwgStepper.prototype.stop_adaptation = function () { this._engine.stop_adaptation(); this._adapting = this._adapting.map((a) => a.map(() => false)); };
+AmwgStepper.prototype.info = function () {     // keyed by the parameter each entry really belongs to (the reference's labels go stale
+  const out = {};                              // after the first shuffle, mcmc.js:887 vs :909)
+  this._engine._layout.forEach((L, li) => { out[L.name] = this._engine.params[L.name].type === 'binary' ? (L.scalar ? {} : nest(Array.from({ length: L.len }, () => ({})), 0, L.dim)) : stepperInfo(this, L, li); });
+  return out;
+};
+
+module.exports = { runif, runif_discrete, rnorm, AmwgSampler, complete_params, param_init_fixed, componentOptions, models, ld, native, translate: translator.translate,
+  RealMetropolisStepper, IntMetropolisStepper, MultiRealComponentMetropolisStepper, MultiIntComponentMetropolisStepper, BinaryStepper, BinaryComponentStepper, AmwgStepper };

@@ -380,10 +380,19 @@ function Translator(fn, params, data, opts, isHelper) {
     this.fnSource = typeof fn === 'string' ? fn : Function.prototype.toString.call(fn);
     this.ast = parseFunctionSource(this.fnSource);
   }
-  if (!isHelper && (this.ast.params.length < 1 || this.ast.params.length > 2)) throw 'log_post must take (state) or (state, data)';
-  this.stateName = isHelper ? null : this.ast.params[0];
-  this.dataName = isHelper ? null : (this.ast.params[1] || null);
   this.data = data;
+  if (!isHelper && this.opts.state_object) {
+    // a stepper's log_post (mcmc.js:424-431: called with NO arguments, it reads the state object it closes over): the state is whatever
+    // free name holds opts.state_object; `function () { return dens(state); }` just hands it on, so `dens` is what gets translated
+    if (this.ast.params.length > 0) throw 'the log_post of a stepper takes no arguments (it reads the state object it closes over)';
+    this.stateName = null;
+    this.dataName = null;
+    this.resolveForwarding();
+  } else {
+    if (!isHelper && (this.ast.params.length < 1 || this.ast.params.length > 2)) throw 'log_post must take (state) or (state, data)';
+    this.stateName = isHelper ? null : this.ast.params[0];
+    this.dataName = isHelper ? null : (this.ast.params[1] || null);
+  }
   // parameter layout in Object.keys order (mcmc.js:839), flattened row-major
   this.layout = {};
   let base = 0;
@@ -406,6 +415,44 @@ function Translator(fn, params, data, opts, isHelper) {
 }
 
 Translator.prototype.fail = function (msg) { throw 'AmwgSampler (MI355X): cannot translate log_post: ' + msg; };
+
+// the value a free name of the closure has, as far as the translator can see it: options.constants / options.helpers, then globals
+Translator.prototype.freeValue = function (name) {
+  const consts = this.opts.constants || {}, helpers = this.opts.helpers || {};
+  if (Object.prototype.hasOwnProperty.call(consts, name)) return consts[name];
+  if (Object.prototype.hasOwnProperty.call(helpers, name)) return helpers[name];
+  if (typeof globalThis !== 'undefined' && name in globalThis) return globalThis[name];
+  return undefined;
+};
+Translator.prototype.isStateName = function (name) {
+  if (this.stateName !== null && this.stateName !== undefined) return name === this.stateName;
+  return !!this.opts.state_object && this.freeValue(name) === this.opts.state_object;
+};
+
+// `function () { return f(state); }` (and chains of such): continue with f, its parameter bound to the state
+Translator.prototype.resolveForwarding = function () {
+  for (let depth = 0; depth < 8; depth++) {
+    const body = this.ast.body.body;
+    if (body.length !== 1 || body[0].k !== 'Return' || !body[0].arg || body[0].arg.k !== 'Call') return;
+    const call = body[0].arg;
+    if (call.callee.k !== 'Id' || !call.args.every((a) => a.k === 'Id')) return;
+    const f = this.freeValue(call.callee.name);
+    if (typeof f !== 'function') return;
+    const statePos = call.args.findIndex((a) => this.isStateName(a.name));
+    if (statePos < 0 || call.args.length > 2) return;
+    const dataPos = call.args.length === 2 ? 1 - statePos : -1;
+    if (dataPos >= 0) {
+      const dv = call.args[dataPos].name === this.dataName ? this.data : this.freeValue(call.args[dataPos].name);
+      if (dv === undefined) return;
+      this.data = dv;
+    }
+    this.fnSource = Function.prototype.toString.call(f);
+    this.ast = parseFunctionSource(this.fnSource);
+    if (this.ast.params.length <= statePos) throw 'log_post forwards the state to ' + call.callee.name + '(), which takes fewer arguments';
+    this.stateName = this.ast.params[statePos];
+    this.dataName = dataPos >= 0 ? (this.ast.params[dataPos] || null) : null;
+  }
+};
 
 // ---- data arrays -----------------------------------------------------------------------------
 function shapeOfData(v) {
@@ -478,6 +525,8 @@ Translator.prototype.describe = function (v) {
 // ---- expressions -----------------------------------------------------------------------------------
 Translator.prototype.lookup = function (name) {
   if (name === this.stateName) return { t: 'stateObj' };
+  if (this.stateName === null && !this.isHelper && this.opts.state_object && !Object.prototype.hasOwnProperty.call(this.aliases, name) &&
+      !Object.prototype.hasOwnProperty.call(this.localTypes, name) && this.freeValue(name) === this.opts.state_object) return { t: 'stateObj' };
   if (this.dataName && name === this.dataName) return this.dataValue('', this.data);
   if (Object.prototype.hasOwnProperty.call(this.aliases, name)) return this.aliases[name];
   if (Object.prototype.hasOwnProperty.call(this.localTypes, name)) return num('v_' + name, this.localTypes[name] === 'int', undefined, '(double)v_' + name);
@@ -917,7 +966,7 @@ Translator.prototype.flush = function (out, indent) { for (const p of this.pendi
 Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) {
   if (target.k === 'Id') {
     const name = target.name;
-    if (name === this.stateName || name === this.dataName) this.fail('assigning to ' + name);
+    if (this.isStateName(name) || (this.dataName && name === this.dataName)) this.fail('assigning to ' + name);
     if (valueAst.k === 'Func') {
       // `var f = function (a, b) {...}` / an arrow: a helper that may use its arguments, constants and other helpers (a closure over
       // the surrounding locals is not supported: the translator would have to capture their values)
@@ -993,7 +1042,7 @@ Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) 
     out.push(indent + lhs + ' = ' + (op === '=' ? this.asD(v) : '(' + lhs + ' ' + op[0] + ' ' + this.asD(v) + ')') + ';');
     return;
   }
-  if (target.k === 'Member' && target.obj.k === 'Id' && target.obj.name === this.stateName) {
+  if (target.k === 'Member' && target.obj.k === 'Id' && this.isStateName(target.obj.name)) {
     const key = target.prop;
     if (Object.prototype.hasOwnProperty.call(this.layout, key)) this.fail('log_post assigns to the parameter state.' + key + ' (only derived quantities may be assigned)');
     if (this.loops.length) this.fail('the derived quantity state.' + key + ' is assigned inside a loop');

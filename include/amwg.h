@@ -48,12 +48,15 @@ enum {
   AMWG_MODEL_POIS_GLM = 4     /* beta_k ~ norm(0,10); cp ~ unif(0,N-1); y_i ~ pois(exp(X_i.beta[0:K] + [i>=cp] beta[7])) */
 };
 
-enum { AMWG_REAL = 0, AMWG_INT = 1, AMWG_BINARY = 2 };
+enum { AMWG_REAL = 0, AMWG_INT = 1, AMWG_BINARY = 2, AMWG_FIXED = 3 };
 
 /* One named parameter AFTER complete_params() (mcmc.js:357-403), flattened row-major.
  * The order of the array is Object.keys(params) order (mcmc.js:839). */
 typedef struct {
-  int32_t type;      /* AMWG_REAL | AMWG_INT (Metropolis steppers, mcmc.js:517-553) | AMWG_BINARY (BinaryStepper, mcmc.js:753-767) */
+  int32_t type;      /* AMWG_REAL | AMWG_INT (Metropolis steppers, mcmc.js:517-553) | AMWG_BINARY (BinaryStepper, mcmc.js:753-767) |
+                        AMWG_FIXED: a state entry log_post reads but this sampler never steps -- the rest of the shared state
+                        object of a stand-alone stepper (mcmc.js:424-431, 1109-1115: every stepper class takes the whole state and
+                        moves one parameter of it).  Fixed entries come after all stepped ones; amwg_create_user only. */
   int32_t len;       /* prod(dim) */
   int32_t top;       /* dim[0]: the only dimension whose visiting order is shuffled (mcmc.js:244-258) */
   int32_t multidim;  /* 0 iff dim equals [1]  (stepper dispatch rule, mcmc.js:846-857) */

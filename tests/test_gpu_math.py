@@ -41,6 +41,30 @@ def test_division_by_invariant_equals_ieee():
     assert fast.tobytes() == ieee.tobytes()
 
 
+def test_unscaled_quotient_of_exp_and_log_equals_ieee():
+    """quot_plain (amwg_math.h): the division sequence without v_div_scale / v_div_fixup, used for (r*c)/(2-c) of exp and
+    f/(2+f) of log, against `/` on the device -- denominators in (1.6, 2.45), numerators from 2^-160 up to 0.5 in magnitude,
+    zero, and significands of all ones / one bit."""
+    rng = np.random.default_rng(99)
+    n = 2_000_000
+    den = rng.uniform(1.6, 2.45, n)
+    num = np.ldexp(rng.uniform(0.5, 1.0, n), rng.integers(-160, 0, n)) * rng.choice([-1.0, 1.0], n)
+    num[:1000] = 0.0
+    num[1000:2000] = np.ldexp(1.0 - 2.0 ** -53, rng.integers(-60, 0, 1000))       # all-ones significands
+    den[2000:3000] = np.nextafter(2.0, 0) * np.ones(1000)
+    den[3000:4000] = 2.0
+    num[4000:5000] = np.ldexp(1.0, rng.integers(-60, 0, 1000))
+    # the operands log really produces: f = m - 1 over the whole significand range
+    m = np.ldexp(rng.uniform(1.0, 2.0, n // 2), 0)
+    m = np.where(m > np.sqrt(2.0), m / 2, m)
+    f = m - 1.0
+    num = np.concatenate([num, f]); den = np.concatenate([den, 2.0 + f])
+    fast = A.device_eval(19, num, den)
+    ieee = A.device_eval(5, num, den)
+    assert fast.tobytes() == ieee.tobytes()
+    assert ieee.tobytes() == (num / den).tobytes()
+
+
 def test_device_ld_and_helpers_match_oracle():
     L = oracle_lib.lib()
     rng = np.random.default_rng(3)

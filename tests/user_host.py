@@ -25,6 +25,25 @@ def workdir():
     return _dir
 
 
+_stepper_names = None
+
+
+def stepper_models():
+    """Translates the zero-argument log_post closures of tests/js/stepper_cases.js (stand-alone steppers) into the same
+    work directory; -> their names (stepper_<case>_<k>)."""
+    global _stepper_names
+    if _stepper_names is None:
+        d = workdir()
+        p = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "translate_steppers_cli.js"), d], cwd=ROOT, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stdout + "\n" + p.stderr
+        _stepper_names = json.load(open(os.path.join(d, "steppers.index.json")))
+    return _stepper_names
+
+
+def stepper_states(name):
+    return json.load(open(os.path.join(workdir(), name + ".states.json")))
+
+
 def translate_extra(name):
     """Translates one closure that is not in user_models.names (the full-size bench_* closures)."""
     d = workdir()
