@@ -11,7 +11,11 @@
  *     min,max,trunc,sign,PI,E,...}, isNaN, isFinite, every ld.* of distributions.js (array-valued ones unrolled),
  *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, local
  *     aliases of those (var p = par.p[0]), derived quantities (state.key = expr, mcmc.js:961-963),
- *     helper functions and constants passed in options.helpers / options.constants.
+ *     helper functions and constants passed in options.helpers / options.constants (or globals);
+ *     post-ES5 spellings, rewritten into the above while parsing: destructuring in parameters and declarations
+ *     (`({mu, sigma}, {x}) => ...`, `const [a, , b] = state.theta`), `for (const x of arr)`, `arr.forEach(cb)` as a statement
+ *     (`return` inside the callback = continue), `arr.reduce(cb, init)` anywhere in the expressions of a statement
+ *     (callback parameters and locals are renamed apart; the reduce becomes its own sequential accumulator, as in JS).
  * Anything else throws a string that says what is not supported (no CPU fallback).  Array reads are not bounds-checked
  * (JavaScript yields undefined -> NaN for an out-of-range index; here only run-time indices into local arrays are checked).
  *
@@ -113,27 +117,91 @@ Parser.prototype = {
     if (t.t === 'eof' || this.peek('}') || t.nl) return;
     throw "expected ';' but found '" + t.v + "' in log_post";
   },
+  fresh(stem) { this.uniq = (this.uniq || 0) + 1; return '__' + stem + this.uniq; },
+  // a binding pattern: a name, {a, b: c, d: {e}} or [a, , b] (no defaults, no rest) -> {name} | {props: [[key, pattern]]} | {elems: [pattern|null]}
+  pattern() {
+    if (this.eat('{')) {
+      const props = [];
+      if (!this.peek('}')) do {
+        if (this.peek('}')) break;
+        const t = this.tk[this.i];
+        if (t.t !== 'id' && t.t !== 'str') throw "expected a property name in a destructuring pattern but found '" + t.v + "'";
+        this.i++;
+        if (this.eat(':')) props.push([t.v, this.pattern()]);
+        else { if (KEYWORDS.has(t.v)) throw "expected a name but found '" + t.v + "'"; props.push([t.v, { name: t.v }]); }
+        if (this.peek('=')) throw 'default values in destructuring patterns are not supported';
+      } while (this.eat(','));
+      this.expect('}');
+      return { props };
+    }
+    if (this.eat('[')) {
+      const elems = [];
+      while (!this.peek(']')) {
+        if (this.peek(',')) { this.i++; elems.push(null); continue; }
+        if (this.peek('.')) throw 'rest elements in destructuring patterns are not supported';
+        elems.push(this.pattern());
+        if (this.peek('=')) throw 'default values in destructuring patterns are not supported';
+        if (!this.peek(']')) this.expect(',');
+      }
+      this.expect(']');
+      return { elems };
+    }
+    return { name: this.ident() };
+  },
+  // declarations binding `pat` to the (side-effect free) expression `src`
+  bind(pat, src, decls) {
+    if (pat.name) { decls.push({ name: pat.name, init: src }); return; }
+    if (pat.props) for (const [key, sub] of pat.props) this.bind(sub, { k: 'Member', obj: src, prop: key }, decls);
+    else pat.elems.forEach((sub, i) => { if (sub) this.bind(sub, { k: 'Index', obj: src, idx: { k: 'Num', v: i } }, decls); });
+  },
+  // parameter list -> names; destructured parameters get a synthetic name and declarations that go in front of the body
+  paramList(prologue) {
+    const params = [];
+    if (!this.peek(')')) do {
+      const pat = this.pattern();
+      if (pat.name) params.push(pat.name);
+      else { const nm = this.fresh('arg'); params.push(nm); const decls = []; this.bind(pat, { k: 'Id', name: nm }, decls); prologue.push({ k: 'VarDecl', kind: 'var', decls }); }
+      if (this.peek('=')) throw 'default parameter values are not supported';
+    } while (this.eat(','));
+    return params;
+  },
+  functionBody(arrow, prologue) {
+    let body;
+    if (this.peek('{')) body = this.block();
+    else if (arrow) body = { k: 'Block', body: [{ k: 'Return', arg: this.assignment() }] };
+    else throw 'log_post must be a function expression or an arrow function';
+    if (prologue.length) body = { k: 'Block', body: prologue.concat(body.body) };
+    return body;
+  },
   parseFunction() {
     let params = [];
+    const prologue = [];
     if (this.eat('function')) { if (!this.peek('(')) this.ident(); }
     if (this.eat('(')) {
-      if (!this.peek(')')) do { params.push(this.ident()); } while (this.eat(','));
+      params = this.paramList(prologue);
       this.expect(')');
     } else {
       params.push(this.ident());    // x => ...
     }
     const arrow = this.eat('=>');
-    let body;
-    if (this.peek('{')) body = this.block();
-    else if (arrow) body = { k: 'Block', body: [{ k: 'Return', arg: this.assignment() }] };
-    else throw 'log_post must be a function expression or an arrow function';
+    const body = this.functionBody(arrow, prologue);
     if (this.tk[this.i].t !== 'eof') throw "unexpected '" + this.tk[this.i].v + "' after the end of the function";
-    return { params, body };
+    return { params, body: desugarBlock(body, this) };
   },
   block() { this.expect('{'); const body = []; while (!this.peek('}')) body.push(this.statement()); this.expect('}'); return { k: 'Block', body }; },
   varDecl() {
     const kind = this.tk[this.i++].v, decls = [];
-    do { const name = this.ident(); let init = null; if (this.eat('=')) init = this.assignment(); decls.push({ name, init }); } while (this.eat(','));
+    do {
+      if (this.peek('{') || this.peek('[')) {      // const {mu, sigma} = state;  const [a, b] = state.theta;
+        const pat = this.pattern();
+        this.expect('=');
+        const src = this.assignment();
+        if (!isPath(src)) throw 'the right-hand side of a destructuring declaration must be a name or a property/element of one';
+        this.bind(pat, src, decls);
+        continue;
+      }
+      const name = this.ident(); let init = null; if (this.eat('=')) init = this.assignment(); decls.push({ name, init });
+    } while (this.eat(','));
     return { k: 'VarDecl', kind, decls };
   },
   statement() {
@@ -143,8 +211,24 @@ Parser.prototype = {
     if (this.eat('for')) {
       this.expect('(');
       let init = null, test = null, update = null;
+      if ((this.peek('var') || this.peek('let') || this.peek('const')) && (this.peekAt(2, 'of') || this.peekAt(1, '{') || this.peekAt(1, '['))) {
+        // for (const x of arr) body   ->   for (var k = 0; k < arr.length; k++) { var x = arr[k]; body }
+        const save = this.i;
+        this.i++;
+        const pat = this.pattern();
+        if (this.eat('of')) {
+          const arr = this.assignment();
+          this.expect(')');
+          if (!isPath(arr)) throw 'for-of needs a name or a property/element of one to iterate over';
+          const k = this.fresh('k'), decls = [];
+          this.bind(pat, { k: 'Index', obj: arr, idx: { k: 'Id', name: k } }, decls);
+          const body = this.statement();
+          return countedLoop(k, arr, [{ k: 'VarDecl', kind: 'var', decls }].concat(body.k === 'Block' ? body.body : [body]));
+        }
+        this.i = save;
+      }
       if (!this.peek(';')) init = (this.peek('var') || this.peek('let') || this.peek('const')) ? this.varDecl() : { k: 'ExprStmt', expr: this.expression() };
-      if (this.peek('in') || this.peek('of')) throw 'for-in / for-of loops are not supported; use for (var i = 0; i < n; i++)';
+      if (this.peek('in') || this.peek('of')) throw 'for-in loops (and for-of over anything but a declared name) are not supported; use for (var i = 0; i < n; i++)';
       this.expect(';');
       if (!this.peek(';')) test = this.expression();
       this.expect(';');
@@ -256,10 +340,10 @@ Parser.prototype = {
         this.i++;
         if (!this.peek('(')) this.ident();
         this.expect('(');
-        const params = [];
-        if (!this.peek(')')) do { params.push(this.ident()); } while (this.eat(','));
+        const prologue = [];
+        const params = this.paramList(prologue);
         this.expect(')');
-        return { k: 'Func', params, body: this.block() };
+        return { k: 'Func', params, body: this.functionBody(false, prologue) };
       }
       if (this.peekAt(1, '=>') && !KEYWORDS.has(t.v)) {   // x => ...
         this.i += 2;
@@ -275,6 +359,134 @@ Parser.prototype = {
 };
 
 function parseFunctionSource(src) { return new Parser(tokenize(src)).parseFunction(); }
+
+// ---- modern-JavaScript sugar, rewritten into the core subset before translation ---------------------------------------
+// a side-effect free path: name, name.prop, name[i] ...
+function isPath(e) {
+  if (e.k === 'Id') return true;
+  if (e.k === 'Member') return isPath(e.obj);
+  if (e.k === 'Index') return isPath(e.obj) && (e.idx.k === 'Num' || e.idx.k === 'Id' || isPath(e.idx));
+  return false;
+}
+function countedLoop(k, arr, body) {
+  return { k: 'For', init: { k: 'VarDecl', kind: 'var', decls: [{ name: k, init: { k: 'Num', v: 0 } }] },
+    test: { k: 'Binary', op: '<', l: { k: 'Id', name: k }, r: { k: 'Member', obj: arr, prop: 'length' } },
+    update: { k: 'Update', op: '++', prefix: false, target: { k: 'Id', name: k } }, body: { k: 'Block', body } };
+}
+function cloneRenamed(node, map) {      // deep copy with the names in `map` replaced (a nested function that re-declares one shadows it)
+  if (!node || typeof node !== 'object') return node;
+  if (Array.isArray(node)) return node.map((x) => cloneRenamed(x, map));
+  if (node.k === 'Id') return { k: 'Id', name: Object.prototype.hasOwnProperty.call(map, node.name) ? map[node.name] : node.name };
+  if (node.k === 'Func') {
+    const inner = Object.assign({}, map);
+    for (const q of node.params) delete inner[q];
+    return { k: 'Func', params: node.params.slice(), body: cloneRenamed(node.body, inner) };
+  }
+  const out = {};
+  for (const key of Object.keys(node)) {
+    if (key === 'decls') out.decls = node.decls.map((d) => ({ name: Object.prototype.hasOwnProperty.call(map, d.name) ? map[d.name] : d.name, init: cloneRenamed(d.init, map) }));
+    else out[key] = cloneRenamed(node[key], map);
+  }
+  return out;
+}
+function declaredIn(node, out) {        // var/let/const names of a function body (not of nested functions)
+  if (!node || typeof node !== 'object') return out;
+  if (Array.isArray(node)) { node.forEach((x) => declaredIn(x, out)); return out; }
+  if (node.k === 'Func') return out;
+  if (node.k === 'VarDecl') node.decls.forEach((d) => out.add(d.name));
+  for (const key of Object.keys(node)) if (key !== 'k') declaredIn(node[key], out);
+  return out;
+}
+// the body of a callback as statements of the enclosing function: parameters and locals renamed apart, `return` rewritten by `onReturn`
+function inlineCallback(fn, argNames, P, onReturn, what) {
+  if (!fn || fn.k !== 'Func') throw what + ' needs a function expression or an arrow function as its argument';
+  const map = {}, tag = P.fresh('cb') + '_';
+  fn.params.forEach((q, i) => { map[q] = i < argNames.length ? argNames[i] : tag + q; });
+  if (fn.params.length > argNames.length) throw what + ': the callback takes more parameters than ' + what + ' passes';
+  for (const nm of declaredIn(fn.body, new Set())) if (!Object.prototype.hasOwnProperty.call(map, nm)) map[nm] = tag + nm;
+  const body = cloneRenamed(fn.body, map);
+  const fix = (st, depth) => {
+    if (!st || typeof st !== 'object') return st;
+    if (Array.isArray(st)) { const o = []; st.forEach((x) => { const r = fix(x, depth); if (Array.isArray(r)) o.push(...r); else o.push(r); }); return o; }
+    if (st.k === 'Return') return onReturn(st.arg, depth);
+    if (st.k === 'Block') return { k: 'Block', body: fix(st.body, depth) };
+    if (st.k === 'If') { const w = (x) => { const r = fix(x, depth); return Array.isArray(r) ? { k: 'Block', body: r } : r; }; return { k: 'If', test: st.test, cons: w(st.cons), alt: st.alt ? w(st.alt) : null }; }
+    if (st.k === 'For') { const r = fix(st.body, depth + 1); return Object.assign({}, st, { body: Array.isArray(r) ? { k: 'Block', body: r } : r }); }
+    return st;
+  };
+  return fix(body.body, 0);
+}
+function isMethodCall(e, name) { return e && e.k === 'Call' && e.callee.k === 'Member' && e.callee.prop === name && isPath(e.callee.obj); }
+
+// arr.forEach(cb) as a statement, and arr.reduce(cb, init) anywhere in the expressions of a statement
+function desugarBlock(block, P) {
+  const out = [];
+  for (const st of block.body) desugarStatement(st, P, out);
+  return { k: 'Block', body: out };
+}
+function desugarStatement(st, P, out) {
+  const sub = (x) => { if (!x) return x; const o = []; desugarStatement(x, P, o); return o.length === 1 ? o[0] : { k: 'Block', body: o }; };
+  if (st.k === 'Block') { out.push(desugarBlock(st, P)); return; }
+  if (st.k === 'If') { const test = hoistReduce(st.test, P, out); out.push({ k: 'If', test, cons: sub(st.cons), alt: sub(st.alt) }); return; }
+  if (st.k === 'For') {
+    for (const part of [st.init, st.test, st.update]) walk(part, (x) => { if (isMethodCall(x, 'reduce') || isMethodCall(x, 'forEach')) throw 'reduce()/forEach() inside the header of a loop is not supported'; });
+    out.push(Object.assign({}, st, { body: sub(st.body) }));
+    return;
+  }
+  if (st.k === 'ExprStmt' && isMethodCall(st.expr, 'forEach')) {
+    const arr = st.expr.callee.obj, k = P.fresh('k'), x = P.fresh('x');
+    if (st.expr.args.length !== 1) throw 'forEach takes one argument here (no thisArg)';
+    const cb = st.expr.args[0];
+    const names = cb && cb.params ? [cb.params.length > 0 ? P.fresh('cb') + '_' + cb.params[0] : x, k] : [x, k];
+    const body = inlineCallback(cb, names, P, (arg, depth) => {
+      if (depth > 0) throw 'a return inside a loop inside a forEach callback is not supported';
+      return (arg ? [{ k: 'ExprStmt', expr: arg }] : []).concat([{ k: 'Continue' }]);
+    }, 'forEach');
+    const inner = [];
+    desugarStatement({ k: 'Block', body }, P, inner);
+    out.push(countedLoop(k, arr, [{ k: 'VarDecl', kind: 'var', decls: [{ name: names[0], init: { k: 'Index', obj: arr, idx: { k: 'Id', name: k } } }] }].concat(inner[0].body)));
+    return;
+  }
+  if (st.k === 'VarDecl') { out.push({ k: 'VarDecl', kind: st.kind, decls: st.decls.map((d) => ({ name: d.name, init: d.init && d.init.k === 'Func' ? desugarFunc(d.init, P) : hoistReduce(d.init, P, out) })) }); return; }
+  if (st.k === 'ExprStmt') { out.push({ k: 'ExprStmt', expr: st.expr.k === 'Assign' && st.expr.value.k === 'Func' ? Object.assign({}, st.expr, { value: desugarFunc(st.expr.value, P) }) : hoistReduce(st.expr, P, out) }); return; }
+  if (st.k === 'Return') { out.push({ k: 'Return', arg: hoistReduce(st.arg, P, out) }); return; }
+  out.push(st);
+}
+function desugarFunc(fn, P) { return { k: 'Func', params: fn.params, body: desugarBlock(fn.body, P) }; }
+// replaces every arr.reduce(cb, init) inside `e` by a fresh variable and emits `var acc = init; for (...) acc = <cb>` in front
+function hoistReduce(e, P, out) {
+  if (!e || typeof e !== 'object') return e;
+  if (Array.isArray(e)) return e.map((x) => hoistReduce(x, P, out));
+  if (e.k === 'Func') return e;
+  if (e.k === 'Logical' || e.k === 'Cond') {      // conditionally evaluated operands: a hoisted loop would run unconditionally (harmless, pure) -- keep it simple, refuse
+    let found = false;
+    walk(e, (x) => { if (isMethodCall(x, 'reduce')) found = true; });
+    if (found) throw 'reduce() inside a conditional expression is not supported; assign it to a variable first';
+    return e;
+  }
+  if (isMethodCall(e, 'reduce')) {
+    if (e.args.length !== 2) throw 'reduce needs an initial value here: arr.reduce(function (acc, x) {...}, init)';
+    const arr = e.callee.obj, cb = e.args[0], k = P.fresh('k'), acc = P.fresh('acc'), x = P.fresh('x');
+    const init = hoistReduce(e.args[1], P, out);
+    const body = inlineCallback(cb, [acc, x, k], P, (arg, depth) => {
+      if (!arg) throw 'the reduce callback must return a value';
+      if (depth > 0) throw 'a return inside a loop inside a reduce callback is not supported';
+      // acc = acc + t  is spelled  acc += t  (the same operation; the form the lane-splitting analysis knows)
+      const asg = (arg.k === 'Binary' && arg.op === '+' && arg.l.k === 'Id' && arg.l.name === acc) ? { k: 'Assign', op: '+=', target: { k: 'Id', name: acc }, value: arg.r }
+        : { k: 'Assign', op: '=', target: { k: 'Id', name: acc }, value: arg };
+      return [{ k: 'ExprStmt', expr: asg }, { k: 'Continue' }];
+    }, 'reduce');
+    if (body.length && body[body.length - 1].k === 'Continue') body.pop();      // a trailing continue is a no-op
+    const inner = [];
+    desugarStatement({ k: 'Block', body }, P, inner);
+    out.push({ k: 'VarDecl', kind: 'var', decls: [{ name: acc, init }] });
+    out.push(countedLoop(k, arr, [{ k: 'VarDecl', kind: 'var', decls: [{ name: x, init: { k: 'Index', obj: arr, idx: { k: 'Id', name: k } } }] }].concat(inner[0].body)));
+    return { k: 'Id', name: acc };
+  }
+  const o = {};
+  for (const key of Object.keys(e)) o[key] = key === 'k' ? e.k : hoistReduce(e[key], P, out);
+  return o;
+}
 
 // ------------------------------------------------------------------------------------------
 // AST helpers

@@ -66,5 +66,45 @@ for (const name of Object.keys(cases)) {
   assert.deepStrictEqual(a.info(), b.info());
   made.push(a, b);
 }
+// the reference's distributional checks (tests/test_mcmc_js.R:55-142), restated with fixed seeds and wide margins
+{
+  const mean = (a) => a.reduce((x, y) => x + y, 0) / a.length;
+  const variance = (a) => { const m = mean(a); return a.reduce((x, y) => x + (y - m) * (y - m), 0) / (a.length - 1); };
+  const every = (a, k) => a.filter((_, i) => i % k === 0);
+  {   // RealMetropolisStepper on Normal(10, 5)
+    const state = { x: 0 }, posterior = function () { return ld.norm(state.x, 10, 5); };
+    const st = new mcmc.RealMetropolisStepper({ x: { lower: -Infinity, upper: Infinity, dim: [1] } }, state, posterior, { seed: 101, constants: { state } });
+    st.steps(2000);
+    const xs = []; for (let i = 0; i < 10000; i++) xs.push(st.step());
+    assert.ok(Math.abs(mean(xs) - 10) < 0.6 && Math.abs(Math.sqrt(variance(xs)) - 5) < 0.6, 'Normal(10,5): ' + mean(xs) + ' ' + Math.sqrt(variance(xs)));
+    made.push(st);
+  }
+  {   // IntMetropolisStepper on Poisson(10)
+    const state = { x: 1 }, posterior = function () { return ld.pois(state.x, 10); };
+    const st = new mcmc.IntMetropolisStepper({ x: { lower: 0, upper: Infinity, dim: [1] } }, state, posterior, { seed: 102, constants: { state } });
+    st.steps(2000);
+    const xs = []; for (let i = 0; i < 10000; i++) xs.push(st.step());
+    assert.ok(xs.every((v) => Number.isInteger(v) && v >= 0));
+    assert.ok(Math.abs(mean(xs) - 10) < 0.4 && Math.abs(variance(xs) - 10) < 2.0, 'Poisson(10): ' + mean(xs) + ' ' + variance(xs));
+    made.push(st);
+  }
+  {   // BinaryStepper on Bernoulli(0.85): independent draws
+    const state = { x: 0 }, posterior = function () { return ld.bern(state.x, 0.85); };
+    const st = new mcmc.BinaryStepper({ x: { type: 'binary' } }, state, posterior, { seed: 103, constants: { state } });
+    const xs = []; for (let i = 0; i < 4000; i++) xs.push(st.step());
+    assert.ok(Math.abs(mean(xs) - 0.85) < 0.03, 'Bernoulli(0.85): ' + mean(xs));
+    made.push(st);
+  }
+  {   // BinaryComponentStepper: P(x1 = 1) = (0.85 + 0.15) / (0.85 + 3 * 0.15), P(x4 = 1) = (0.75 + 0.25) / (0.75 + 3 * 0.25)
+    const state = { x: [[0, 0], [0, 0]] };
+    const posterior = function () { return Math.log(state.x[0][0] * state.x[0][1] * 0.85 + (1 - state.x[0][0] * state.x[0][1]) * 0.15) + Math.log(state.x[1][0] * state.x[1][1] * 0.75 + (1 - state.x[1][0] * state.x[1][1]) * 0.25); };
+    const st = new mcmc.BinaryComponentStepper({ x: { type: 'binary', dim: [2, 2] } }, state, posterior, { seed: 104, constants: { state } });
+    st.steps(200);
+    const x1 = [], x4 = []; for (let i = 0; i < 6000; i++) { const v = st.step(); x1.push(v[0][0]); x4.push(v[1][1]); }
+    assert.ok(Math.abs(mean(every(x1, 3)) - 1.0 / 1.3) < 0.05 && Math.abs(mean(every(x4, 3)) - 1.0 / 1.5) < 0.05, 'multi-Bernoulli: ' + mean(x1) + ' ' + mean(x4));
+    made.push(st);
+  }
+  console.log('  distributional checks ok');
+}
 made.forEach((s) => s.close());
 console.log('gpu steppers ok');

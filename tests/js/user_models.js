@@ -412,6 +412,29 @@ CASES.many_named = {
   schedule: [{ op: 'burn', n: 120 }, { op: 'sample', n: 120, keep: 40 }], chains: [0, 1],
 };
 
+// ---- the same kind of model written in post-ES5 JavaScript: destructured parameters and declarations, for-of, forEach with an
+// early return, reduce (twice, one over a parameter array with the index argument), an arrow helper, const/let
+CASES.modern_js = {
+  params: () => ({ mu: {}, sigma: { lower: 0, init: 1.5 }, rate: { dim: [3], lower: 0, init: 2 }, flip: { type: 'binary' } }),
+  data: (seed) => { const r = lcg(seed), x = [], counts = [], w = []; for (let i = 0; i < 30; i++) { x.push(2 + 3 * (r() - 0.5)); w.push(i % 4 === 0 ? 0 : 1 + (i % 3)); } for (let j = 0; j < 3; j++) counts.push(Math.floor(r() * 9)); return { x, counts, w }; },
+  log_post: ({ mu, sigma, rate, flip }, { x, counts, w }) => {
+    const sq = (t) => t * t;
+    let lp = ld.norm(mu, 0, 10) + ld.cauchy(sigma, 0, 5) + ld.bern(flip, 0.3);
+    for (const r of rate) lp += ld.gamma(r, 2, 1);
+    lp += rate.reduce((acc, r, j) => acc + ld.pois(counts[j], r), 0);
+    const [r0, , r2] = rate;
+    const spread = flip === 1 ? sigma + sq(r0 - r2) / 10 : sigma;
+    x.forEach((xi, i) => {
+      if (w[i] === 0) return;
+      const z = (xi - mu) / spread;
+      lp += w[i] * (ld.norm(xi, mu, spread) - 1e-3 * sq(z));
+    });
+    const total = x.reduce(function (a, xi) { return a + xi; }, 0);
+    return lp + ld.norm(total / x.length, mu, 1);
+  },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+
 function build(name, seed) {
   const c = CASES[name] || BENCH[name];
   if (!c) throw new Error('unknown user model ' + name);
