@@ -533,11 +533,12 @@ AMWG_HD double log10_v8(double x) {
   return z + y * log10_2hi;
 }
 
-// Math.round: nearest integer, ties toward +infinity (mcmc.js:597).
+// Math.round: nearest integer, ties toward +infinity (mcmc.js:597); a result of zero keeps the sign of x (ECMA-262: -0 for
+// -0.5 <= x <= -0), which the state then carries: an int parameter proposed in [-0.5, 0) sits at -0, as in the reference.
 AMWG_HD double js_round(double x) {
   if (!(__builtin_fabs(x) < 4503599627370496.0)) return x;
   const double f = __builtin_floor(x);
-  return (x - f >= 0.5) ? f + 1.0 : f;
+  return __builtin_copysign((x - f >= 0.5) ? f + 1.0 : f, x);
 }
 
 }  // namespace amwg

@@ -123,9 +123,9 @@ function runCase(c) {
   return res;
 }
 
-// JSON has no Infinity/NaN: encode them as tagged strings (tests/golden_io.py decodes)
+// JSON has no Infinity/NaN/-0: encode them as tagged strings (tests/golden_io.py decodes)
 function stringify(o) {
-  return JSON.stringify(o, (k, v) => (typeof v === 'number' && !isFinite(v)) ? (isNaN(v) ? '__nan' : (v > 0 ? '__inf' : '__-inf')) : v);
+  return JSON.stringify(o, (k, v) => (typeof v === 'number' && !isFinite(v)) ? (isNaN(v) ? '__nan' : (v > 0 ? '__inf' : '__-inf')) : (Object.is(v, -0) ? '__-0' : v));
 }
 
 module.exports = { stringify, runCase, runChain, makeData, models, mcmc, ld };

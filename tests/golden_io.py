@@ -3,7 +3,7 @@ import json
 import os
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-_TAGS = {"__inf": float("inf"), "__-inf": float("-inf"), "__nan": float("nan")}
+_TAGS = {"__inf": float("inf"), "__-inf": float("-inf"), "__nan": float("nan"), "__-0": -0.0}
 
 
 def _untag(o):

@@ -1,0 +1,115 @@
+'use strict';
+// fuzz_translate_cli.js -- test helper (no GPU): random closures for the translator.
+//   node tests/js/fuzz_translate_cli.js <outdir> <seed> <n_models>
+// Every model is one closure with 48 derived quantities `s.qK = <random expression>` (arithmetic, comparisons, ?:, && ||, Math.*, ld.*,
+// integer and double operands, -0, NaN, Infinity), a few random statement blocks (loops over the data with if/else, continue, local
+// arrays, integer counters) and a random return expression.  The closure is evaluated by V8 at 40 random states (with this package's
+// ld.js, itself pinned bit for bit against the reference's distributions.js) and translated with the PRODUCT's translator; the test
+// (tests/test_translate.py) compiles the generated text for the host and compares all 49 values per state bit for bit.
+// writes <outdir>/fuzz_<seed>_<k>.{hip,arrays.bin,meta.json,states.json,js}
+const fs = require('fs');
+const path = require('path');
+const { mcmc, ld } = require('../../bayes.js_amd');
+global.ld = ld;
+const out = process.argv[2], seed0 = Number(process.argv[3] || 1), nModels = Number(process.argv[4] || 3);
+
+function rng(seed) { let s = seed >>> 0; return () => { s = (Math.imul(s, 1664525) + 1013904223) >>> 0; return s / 4294967296; }; }
+const bits = (v) => { const b = Buffer.alloc(8); b.writeDoubleBE(v); return b.toString('hex'); };
+
+function generator(rnd) {
+  const pick = (a) => a[Math.floor(rnd() * a.length)];
+  const lit = () => pick(['0', '1', '2', '3', '(-1)', '0.5', '(-2.5)', '1e-3', '7', '10', '0.1', '1.5', '100', '(-0)', '3.25', '1e10', '4', '6', '0.25']);
+  // leaves: real params a, b (b > 0), int param k in 0..6, binary z, vector v[3]; data x[8] doubles, n[8] small ints, m[2][3] doubles
+  const leafD = (ctx) => pick(['s.a', 's.b', 's.v[0]', 's.v[1]', 's.v[2]', 'd.x[' + Math.floor(rnd() * 8) + ']', 'd.m[' + Math.floor(rnd() * 2) + '][' + Math.floor(rnd() * 3) + ']', lit(), lit()]
+    .concat(ctx.i ? ['d.x[' + ctx.i + ']', 'd.x[' + ctx.i + ']', 't'] : []));
+  const leafI = (ctx) => pick(['s.k', 's.z', 'd.n[' + Math.floor(rnd() * 8) + ']', String(Math.floor(rnd() * 9)), 'd.x.length'].concat(ctx.i ? [ctx.i, ctx.i, 'd.n[' + ctx.i + ']'] : []));
+  function num(depth, ctx) {
+    if (depth <= 0 || rnd() < 0.18) return rnd() < 0.7 ? leafD(ctx) : leafI(ctx);
+    const r = rnd();
+    const a = () => num(depth - 1, ctx);
+    if (r < 0.30) return '(' + a() + ' ' + pick(['+', '-', '*', '+', '-', '*', '/']) + ' ' + a() + ')';
+    if (r < 0.34) return '(' + a() + ' % ' + pick(['3', '2.5', '(s.k + 1)', '7', leafI(ctx) + ' + 1']) + ')';
+    if (r < 0.40) return '(- ' + a() + ')';
+    if (r < 0.50) return '(' + cond(depth - 1, ctx) + ' ? ' + a() + ' : ' + a() + ')';
+    if (r < 0.72) {
+      const f = pick(['abs', 'floor', 'ceil', 'round', 'trunc', 'sign', 'sqrt', 'exp', 'log', 'log1p', 'expm1', 'tanh', 'atan', 'log10', 'abs', 'sqrt', 'exp', 'log']);
+      if (f === 'exp' || f === 'expm1') return 'Math.' + f + '(' + a() + ' * 0.1)';
+      return 'Math.' + f + '(' + a() + ')';
+    }
+    if (r < 0.78) return 'Math.' + pick(['min', 'max']) + '(' + a() + ', ' + a() + (rnd() < 0.3 ? ', ' + a() : '') + ')';
+    if (r < 0.83) return 'Math.pow(' + a() + ', ' + pick(['2', '0.5', '3', '-1', '1.5', leafD(ctx), 's.k']) + ')';
+    if (r < 0.97) {
+      const pos = () => 'Math.abs(' + a() + ') + 0.1';
+      return pick([
+        () => 'ld.norm(' + a() + ', ' + a() + ', ' + pos() + ')', () => 'ld.unif(' + a() + ', -3, 9)', () => 'ld.pois(' + leafI(ctx) + ', ' + pos() + ')',
+        () => 'ld.gamma(' + pos() + ', ' + pos() + ', ' + pos() + ')', () => 'ld.beta(Math.abs(Math.tanh(' + a() + ')), 2, ' + pos() + ')', () => 'ld.bern(s.z, 0.3)',
+        () => 'ld.binom(' + leafI(ctx) + ', 12, Math.abs(Math.tanh(' + a() + ')))', () => 'ld.cauchy(' + a() + ', ' + a() + ', ' + pos() + ')', () => 'ld.laplace(' + a() + ', 1, ' + pos() + ')',
+        () => 'ld.t(' + a() + ', ' + a() + ', ' + pos() + ', ' + pos() + ')', () => 'ld.exp(' + pos() + ', ' + pos() + ')', () => 'ld.lnorm(' + pos() + ', ' + a() + ', ' + pos() + ')',
+        () => 'ld.logis(' + a() + ', ' + a() + ', ' + pos() + ')', () => 'ld.weibull(' + pos() + ', ' + pos() + ', ' + pos() + ')', () => 'ld.nbinom(' + leafI(ctx) + ', ' + pos() + ', 0.4)',
+      ])();
+    }
+    return '(' + cond(depth - 1, ctx) + ' ? 1 : 0)';
+  }
+  function cond(depth, ctx) {
+    const r = rnd();
+    if (depth <= 0 || r < 0.55) return '(' + num(depth - 1, ctx) + ' ' + pick(['<', '>', '<=', '>=', '===', '!==', '==', '!=']) + ' ' + num(depth - 1, ctx) + ')';
+    if (r < 0.75) return '(' + cond(depth - 1, ctx) + ' ' + pick(['&&', '||']) + ' ' + cond(depth - 1, ctx) + ')';
+    if (r < 0.85) return '(!' + cond(depth - 1, ctx) + ')';
+    if (r < 0.92) return pick(['isNaN', 'isFinite']) + '(' + num(depth - 1, ctx) + ')';
+    return '(s.z === ' + pick(['0', '1']) + ')';
+  }
+  function block(k) {     // statement templates around random expressions
+    const ctx = { i: 'i' }, r = rnd(), q = 'acc' + k;
+    const e = () => num(3, ctx), c = () => '(' + cond(2, ctx) + ')';
+    if (r < 0.35) return 'var ' + q + ' = ' + lit() + ';\n  for (var i = 0; i < d.x.length; i++) { var t = ' + num(2, { }) + '; if ' + c() + ' { ' + q + ' += ' + e() + '; } else { ' + q + ' -= ' + e() + ' * 0.5; } }\n  s.b' + k + ' = ' + q + ';';
+    if (r < 0.55) return 'var ' + q + ' = 0;\n  for (var i = 0; i < 8; i++) { var t = d.x[i] * ' + lit() + '; if ' + c() + ' continue; ' + q + ' += ' + e() + '; if (' + q + ' > 1e6) break; }\n  s.b' + k + ' = ' + q + ';';
+    if (r < 0.75) return 'var arr' + k + ' = [' + num(2, {}) + ', ' + num(2, {}) + ', ' + num(2, {}) + '];\n  var ' + q + ' = 0, cnt' + k + ' = 0;\n  for (var i = 0; i < 3; i++) { var t = arr' + k + '[i]; if ' + c() + ' { cnt' + k + '++; ' + q + ' += arr' + k + '[(i + s.k) % 3] * ' + e() + '; } }\n  s.b' + k + ' = ' + q + ' + cnt' + k + ';';
+    return 'var ' + q + ' = 1, j' + k + ' = 0;\n  while (j' + k + ' < s.k + 2) { var i = j' + k + ' % 8; var t = ' + q + '; ' + q + ' = ' + q + ' * 0.5 + ' + e() + ' * 1e-3; j' + k + ' += 1; }\n  s.b' + k + ' = ' + q + ';';
+  }
+  return { num, cond, block };
+}
+
+function stateFrom(rnd, t) {
+  const special = [0, -0, 1, -1, 0.5, 2, 1e-8, 30, -30, 3];
+  const real = () => (rnd() < 0.15 ? special[Math.floor(rnd() * special.length)] : (rnd() - 0.5) * (rnd() < 0.3 ? 40 : 4));
+  return { a: t === 0 ? 0.5 : real(), b: Math.abs(real()) + (rnd() < 0.1 ? 0 : 0.05), v: [real(), real(), real()], k: Math.floor(rnd() * 7), z: rnd() < 0.5 ? 0 : 1 };
+}
+
+const names = [];
+for (let mk = 0; mk < nModels; mk++) {
+  const seed = seed0 * 1000 + mk, rnd = rng(seed), G = generator(rnd);
+  const lines = [];
+  const NQ = 48, NB = 5;
+  for (let q = 0; q < NQ; q++) lines.push('  s.q' + q + ' = ' + G.num(4, {}) + ';');
+  for (let b = 0; b < NB; b++) lines.push('  ' + G.block(b));
+  lines.push('  return ' + G.num(3, {}) + ' + ld.norm(s.a, 0, 10);');
+  const src = 'return function (s, d) {\n' + lines.join('\n') + '\n};';
+  const fn = new Function('ld', src)(ld);
+  const data = { x: [], n: [], m: [[0.5, -1.25, 3], [2, 0, -0.75]] };
+  for (let i = 0; i < 8; i++) { data.x.push(i === 3 ? 0 : (rnd() - 0.4) * 6); data.n.push(Math.floor(rnd() * 11)); }
+  const params = mcmc.complete_params({ a: {}, b: { lower: 0 }, v: { dim: [3] }, k: { type: 'int', lower: 0, upper: 6 }, z: { type: 'binary' } }, mcmc.param_init_fixed);
+  const name = 'fuzz_' + seed0 + '_' + mk;
+  fs.writeFileSync(path.join(out, name + '.js'), src);
+  let tr;
+  try { tr = mcmc.translate(fn, params, data, {}); } catch (e) { console.error('TRANSLATE FAILED for ' + name + ': ' + e); process.exit(3); }
+  fs.writeFileSync(path.join(out, name + '.hip'), tr.source);
+  let bytes = 4;
+  for (const a of tr.arrays) bytes += 8 + a.length * 8;
+  const buf = Buffer.alloc(bytes);
+  let o = 0;
+  buf.writeUInt32LE(tr.arrays.length, o); o += 4;
+  for (const a of tr.arrays) { buf.writeBigUInt64LE(BigInt(a.length), o); o += 8; for (let i = 0; i < a.length; i++) { buf.writeDoubleLE(a[i], o); o += 8; } }
+  fs.writeFileSync(path.join(out, name + '.arrays.bin'), buf);
+  fs.writeFileSync(path.join(out, name + '.meta.json'), JSON.stringify({ name, P: tr.P, derived: tr.derived, lds_bytes: tr.lds_bytes, lds_bytes_one_lane: tr.lds_bytes_one_lane, parallel: tr.parallel,
+    max_threads: tr.max_threads, work_per_eval: tr.work_per_eval, work_one_lane: tr.work_one_lane, array_keys: tr.array_keys, array_types: tr.array_types, array_len: tr.arrays.map((a) => a.length) }));
+  const pts = [];
+  for (let t = 0; t < 40; t++) {
+    const st = stateFrom(rnd, t);
+    const flat = [st.a, st.b, st.v[0], st.v[1], st.v[2], st.k, st.z];
+    const lp = fn(st, data);
+    pts.push({ state: flat.map(bits), lp: bits(lp), derived: tr.derived.map((k) => bits(st[k])) });
+  }
+  fs.writeFileSync(path.join(out, name + '.states.json'), JSON.stringify(pts));
+  names.push(name);
+}
+console.log(names.join(' '));

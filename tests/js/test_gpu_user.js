@@ -11,7 +11,7 @@ const um = require('./user_models.js');
 global.ld = ld;
 
 function golden(name) {
-  const untag = (k, v) => (v === '__inf' ? Infinity : v === '__-inf' ? -Infinity : v === '__nan' ? NaN : v);
+  const untag = (k, v) => (v === '__inf' ? Infinity : v === '__-inf' ? -Infinity : v === '__nan' ? NaN : v === '__-0' ? -0 : v);
   return JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'golden', name + '.json'), 'utf8'), untag);
 }
 const flat = (v) => { const o = []; (function r(x) { Array.isArray(x) ? x.forEach(r) : o.push(x); })(v); return o; };
