@@ -1299,6 +1299,20 @@ Translator.prototype.splittable = function (s, canon) {
   if (!definitelyAssigned(s.body.k === 'Block' ? s.body.body : [s.body], written, new Set(), this.acc)) ok = false;
   for (const nm of written) if (this.topLevelRefs.has(nm)) ok = false;
   if (this.topLevelRefs.has(canon.name)) ok = false;
+  // ... nor inside any LATER loop, unless that loop assigns them itself before it reads them (`var` is function-scoped: a temporary
+  // of this loop read by a later loop would carry the value of the LAST iteration, which only one lane has)
+  for (const other of this.topLoops.slice(this.topLoops.indexOf(s) + 1)) {      // top-level loops run once each, in source order
+    const refs = idsOf(other);
+    for (const nm of Array.from(written).concat([canon.name])) {
+      if (!refs.has(nm)) continue;
+      const initAssigns = other.init && assignedNames(other.init).has(nm);
+      const header = new Set();
+      if (!initAssigns) for (const part of [other.init, other.test, other.update]) if (part) idsOf(part).forEach((n) => header.add(n));
+      if (header.has(nm)) { ok = false; continue; }
+      if (initAssigns) continue;       // the other loop's own counter: assigned by its header before anything reads it
+      if (!definitelyAssigned(other.body.k === 'Block' ? other.body.body : [other.body], new Set([nm]), new Set(), this.acc)) ok = false;
+    }
+  }
   walk(s.body, (x) => {
     if (x.k === 'Assign' && x.target.k === 'Id' && x.target.name === this.acc && x.op !== '+=') ok = false;
     if (x.k === 'Assign' && x.target.k !== 'Id') ok = false;   // derived quantities inside a loop
@@ -1549,13 +1563,14 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
   this.topLevelRefs = new Set();
   const scanTop = (list) => {
     for (const st of list) {
-      if (st.k === 'For') continue;          // everything inside a loop statement counts as "inside the loop"
+      if (st.k === 'For') { this.topLoops.push(st); continue; }          // everything inside a loop statement counts as "inside the loop"
       if (st.k === 'Block') { scanTop(st.body); continue; }
       if (st.k === 'If') { idsOf(st.test).forEach((n) => this.topLevelRefs.add(n)); scanTop([st.cons]); if (st.alt) scanTop([st.alt]); continue; }
       if (st.k === 'VarDecl') { st.decls.forEach((d) => { if (d.init) idsOf(d.init).forEach((n) => this.topLevelRefs.add(n)); }); continue; }
       idsOf(st).forEach((n) => this.topLevelRefs.add(n));
     }
   };
+  this.topLoops = [];
   scanTop(stmts);
   if (this.acc) this.topLevelRefs.delete(this.acc);
 

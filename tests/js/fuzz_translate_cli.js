@@ -21,8 +21,8 @@ function generator(rnd) {
   const lit = () => pick(['0', '1', '2', '3', '(-1)', '0.5', '(-2.5)', '1e-3', '7', '10', '0.1', '1.5', '100', '(-0)', '3.25', '1e10', '4', '6', '0.25']);
   // leaves: real params a, b (b > 0), int param k in 0..6, binary z, vector v[3]; data x[8] doubles, n[8] small ints, m[2][3] doubles
   const leafD = (ctx) => pick(['s.a', 's.b', 's.v[0]', 's.v[1]', 's.v[2]', 'd.x[' + Math.floor(rnd() * 8) + ']', 'd.m[' + Math.floor(rnd() * 2) + '][' + Math.floor(rnd() * 3) + ']', lit(), lit()]
-    .concat(ctx.i ? ['d.x[' + ctx.i + ']', 'd.x[' + ctx.i + ']', 't'] : []));
-  const leafI = (ctx) => pick(['s.k', 's.z', 'd.n[' + Math.floor(rnd() * 8) + ']', String(Math.floor(rnd() * 9)), 'd.x.length'].concat(ctx.i ? [ctx.i, ctx.i, 'd.n[' + ctx.i + ']'] : []));
+    .concat(ctx.i ? ['d.x[' + ctx.i + ']', 'd.x[' + ctx.i + ']', 't', 'd.x[(' + ctx.i + ' * 3 + 1) % 8]', 'd.m[' + ctx.i + ' % 2][(' + ctx.i + ' + s.k) % 3]', 's.v[' + ctx.i + ' % 3]'] : []));
+  const leafI = (ctx) => pick(['s.k', 's.z', 'd.n[' + Math.floor(rnd() * 8) + ']', String(Math.floor(rnd() * 9)), 'd.x.length'].concat(ctx.i ? [ctx.i, ctx.i, 'd.n[' + ctx.i + ']', '(' + ctx.i + ' * d.n[7 - ' + ctx.i + '])', '(d.n[' + ctx.i + '] % 3)'] : []));
   function num(depth, ctx) {
     if (depth <= 0 || rnd() < 0.18) return rnd() < 0.7 ? leafD(ctx) : leafI(ctx);
     const r = rnd();
@@ -66,7 +66,16 @@ function generator(rnd) {
     if (r < 0.75) return 'var arr' + k + ' = [' + num(2, {}) + ', ' + num(2, {}) + ', ' + num(2, {}) + '];\n  var ' + q + ' = 0, cnt' + k + ' = 0;\n  for (var i = 0; i < 3; i++) { var t = arr' + k + '[i]; if ' + c() + ' { cnt' + k + '++; ' + q + ' += arr' + k + '[(i + s.k) % 3] * ' + e() + '; } }\n  s.b' + k + ' = ' + q + ' + cnt' + k + ';';
     return 'var ' + q + ' = 1, j' + k + ' = 0;\n  while (j' + k + ' < s.k + 2) { var i = j' + k + ' % 8; var t = ' + q + '; ' + q + ' = ' + q + ' * 0.5 + ' + e() + ' * 1e-3; j' + k + ' += 1; }\n  s.b' + k + ' = ' + q + ';';
   }
-  return { num, cond, block };
+  function lpBlock() {
+    const ctx = { i: 'i' }, r = rnd();
+    const e = () => num(3, ctx), c = () => '(' + cond(2, ctx) + ')';
+    if (r < 0.3) return 'for (var i = 0; i < d.x.length; i++) { lp += ' + e() + ' * 1e-2; }';
+    if (r < 0.55) return 'for (var i = 0; i < d.x.length; i++) { var t = ' + num(2, { i: 'i' }).replace(/(^|[^.\w])t\b/g, '$1s.a') + '; if ' + c() + ' { lp += ' + e() + ' * 1e-2; } else { lp -= ' + e() + ' * 1e-2; } }';
+    if (r < 0.75) return 'for (var i = 0; i < 8; i++) { var t = d.x[i] - ' + lit() + '; var u = t * t; if ' + c() + ' continue; lp += (u + ' + e() + ') * 1e-2; }';
+    if (r < 0.9) return 'for (var i = 0; i < d.n.length; i++) { var t = 0; for (var j = 0; j <= d.n[i] % 4; j++) { t += d.x[(i + j) % 8] * ' + lit() + '; } lp += ld.norm(t, s.a, s.b + 0.5) * 1e-2; }';
+    return 'lp += ' + num(3, {}) + ' * 1e-2;';
+  }
+  return { num, cond, block, lpBlock };
 }
 
 function stateFrom(rnd, t) {
@@ -82,7 +91,9 @@ for (let mk = 0; mk < nModels; mk++) {
   const NQ = 48, NB = 5;
   for (let q = 0; q < NQ; q++) lines.push('  s.q' + q + ' = ' + G.num(4, {}) + ';');
   for (let b = 0; b < NB; b++) lines.push('  ' + G.block(b));
-  lines.push('  return ' + G.num(3, {}) + ' + ld.norm(s.a, 0, 10);');
+  lines.push('  var lp = ' + G.num(3, {}) + ' + ld.norm(s.a, 0, 10);');
+  for (let b = 0; b < 4; b++) lines.push('  ' + G.lpBlock());
+  lines.push('  return lp;');
   const src = 'return function (s, d) {\n' + lines.join('\n') + '\n};';
   const fn = new Function('ld', src)(ld);
   const data = { x: [], n: [], m: [[0.5, -1.25, 3], [2, 0, -0.75]] };

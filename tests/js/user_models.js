@@ -435,6 +435,21 @@ CASES.modern_js = {
   schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
 };
 
+// ---- `var` is function-scoped: a later loop reads the temporary and the counter an earlier loop left behind (the value of its LAST
+// iteration).  The first loop must therefore not be dealt to the lanes of a chain; the second one may.  (Found by the translator fuzz test.)
+CASES.live_out_temp = {
+  params: () => ({ mu: {}, sigma: { lower: 0, init: 1 } }),
+  data: (seed) => { const r = lcg(seed), x = [], w = []; for (let i = 0; i < 37; i++) x.push(1 + 2 * (r() - 0.5)); for (let j = 0; j < 11; j++) w.push(r()); return { x, w }; },
+  log_post: function (s, d) {
+    var lp = ld.norm(s.mu, 0, 10) + ld.unif(s.sigma, 0, 10);
+    for (var i = 0; i < d.x.length; i++) { var t = d.x[i] - s.mu; lp += ld.norm(t, 0, s.sigma); }
+    for (var j = 0; j < d.w.length; j++) { lp += d.w[j] * t * 1e-3 + i * 1e-6; }
+    for (var i = 0; i < d.w.length; i++) { var t = d.w[i] * s.sigma; lp += ld.norm(t, s.mu, 3) * 1e-2; }
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 120 }, { op: 'sample', n: 120, keep: 40 }], chains: [0, 1],
+};
+
 function build(name, seed) {
   const c = CASES[name] || BENCH[name];
   if (!c) throw new Error('unknown user model ' + name);

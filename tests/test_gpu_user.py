@@ -40,7 +40,7 @@ def spec_for(name):
 
 @pytest.mark.parametrize("name,lanes", [("readme_normal", 1), ("readme_normal", 4), ("norm_post_derived", 8), ("complex_model", 2),
                                         ("hier_binomial", 2), ("hier_normal_closure", 16), ("pois_glm_closure", 4), ("pois_glm_closure", 64),
-                                        ("spike_slab", 4), ("survival_mix", 2), ("discrete_mix", 1), ("multi_bern", 1), ("multivar_poisson", 1), ("mixture_arrays", 2), ("many_named", 4), ("readme_bern", 1), ("readme_bern", 4), ("semantics_probe", 1), ("logistic_softplus", 4), ("modern_js", 1)])
+                                        ("spike_slab", 4), ("survival_mix", 2), ("discrete_mix", 1), ("multi_bern", 1), ("multivar_poisson", 1), ("mixture_arrays", 2), ("many_named", 4), ("readme_bern", 1), ("readme_bern", 4), ("semantics_probe", 1), ("logistic_softplus", 4), ("modern_js", 1), ("live_out_temp", 4)])
 def test_device_lane_sum_equals_host_emulation(name, lanes):
     spec, m, gold = spec_for(name)
     s = A.Sampler(spec, chains=96, seed=gold["case"]["seed"], lanes_per_chain=lanes)
@@ -160,3 +160,38 @@ def test_translated_normal_samples_the_analytic_posterior():
     assert abs(mu.mean() - x.mean()) < 0.08 * x.std()
     assert abs(var.mean() / (x.var(ddof=1) * (n - 1) / (n - 4)) - 1) < 0.12   # E[sigma^2 | x] under p(sigma) uniform
     s.close()
+
+
+@pytest.mark.parametrize("lanes", [1, 4])
+def test_fuzzed_closures_on_the_device_equal_v8(lanes):
+    """Random closures (tests/js/fuzz_translate_cli.js, see test_translate.py) compiled with hiprtc and evaluated by the step kernel itself:
+    40 chains start at the 40 random states; the cached log_post (the constructor's warm-up evaluation) and the derived quantities of
+    the first recorded draw are, at one lane per chain, bit for bit what V8 returned, and at four lanes bit for bit what the host
+    build of the same text returns in that lane order."""
+    for name in user_host.fuzz_models(3, 2):
+        m = user_host.host_model(name)
+        if lanes > 1 and not m.meta["parallel"]:
+            continue
+        pts = user_host.stepper_states(name)
+        f64 = lambda h: float(np.frombuffer(bytes.fromhex(h), dtype=">f8")[0])
+        states = np.array([[f64(h) for h in pt["state"]] for pt in pts])            # [40][7]: a, b, v[3], k, z
+        params = [{"type": 0, "len": 1, "top": 1, "multidim": 0, "lower": -INF, "upper": INF}, {"type": 0, "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": INF},
+                  {"type": 0, "len": 3, "top": 3, "multidim": 1, "lower": -INF, "upper": INF}, {"type": 1, "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": 6.0},
+                  {"type": 2, "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": 1.0}]
+        opts = [{"prop_log_scale": 0.0, "max_adaptation": 0.33, "initial_adaptation": 1.0, "target_accept_rate": 0.44, "batch_size": 50, "is_adapting": True}] * 7
+        spec = {"user": user_host.user_spec_part(m.source, m.arrays, m.meta), "params": params, "P": 7, "init": states[0].tolist(), "comp_opts": opts}
+        s = A.Sampler(spec, chains=len(pts), seed=1, lanes_per_chain=lanes)
+        s.set_state(np.ascontiguousarray(states.T))
+        lp = s.diag()["log_post"]
+        draws = s.sample(1, 1)
+        assert draws[0, :7, :].tobytes() == np.ascontiguousarray(states.T).tobytes()
+        for c, pt in enumerate(pts):
+            if lanes == 1:
+                want_lp, want_dv = f64(pt["lp"]), [f64(h) for h in pt["derived"]]
+            else:
+                want_lp, want_dv = m.eval(states[c], lanes, derived=True)
+            same = lambda a, b: (a != a and b != b) or np.float64(a).tobytes() == np.float64(b).tobytes()
+            assert same(lp[c], want_lp), (name, lanes, c, lp[c], want_lp)
+            got_dv = draws[0, 7:, c].tolist()
+            assert len(got_dv) == len(want_dv) and all(same(a, b) for a, b in zip(got_dv, want_dv)), (name, lanes, c)
+        s.close()

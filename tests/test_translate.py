@@ -21,7 +21,7 @@ import user_host
 pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
 
 NAMES = ["readme_normal", "readme_bern", "norm_post_derived", "complex_model", "hier_binomial", "multi_bern", "multivar_poisson",
-         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js"]
+         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js", "live_out_temp"]
 
 
 def same(a, b):
@@ -158,18 +158,24 @@ def test_division_by_invariant_host_fuzz(tmp_path):
 
 @pytest.mark.parametrize("seed", [3, 5])
 def test_fuzzed_closures_equal_v8_on_host(seed):
-    """Random closures (tests/js/fuzz_translate_cli.js: 53 derived quantities + a return value each, built from random arithmetic,
-    comparisons, ?:, && ||, Math.*, ld.*, loops with if/else/continue/break, local arrays, integer counters, -0 / NaN / Infinity operands):
-    the translator's text, compiled for the host, returns bit for bit what V8 returns at 40 random states.  (Seeds 3 and 5 are the
-    ones that exposed Math.round's -0; a campaign over seeds 1..29 is clean.)"""
+    """Random closures (tests/js/fuzz_translate_cli.js: 53 derived quantities and an accumulated return value each, built from random
+    arithmetic, comparisons, ?:, && ||, Math.*, ld.*, loops with if/else/continue/break, nested loops, local arrays, integer counters and
+    index arithmetic, -0 / NaN / Infinity operands): the translator's text, compiled for the host, returns bit for bit what V8 returns at
+    40 random states; evaluated in the order of 2, 4 and 64 lanes per chain the derived quantities stay identical and the sum agrees to
+    rounding.  (This test found Math.round's -0; campaigns over some 60 further seeds are clean.)"""
     checked = 0
     for name in user_host.fuzz_models(seed, 2):
         m = user_host.host_model(name)
-        for pt in user_host.stepper_states(name):
+        for t, pt in enumerate(user_host.stepper_states(name)):
             state = [float(np.frombuffer(bytes.fromhex(h), dtype=">f8")[0]) for h in pt["state"]]
             got, dv = m.eval(state, 1, derived=True)
             want = [float(np.frombuffer(bytes.fromhex(h), dtype=">f8")[0]) for h in pt["derived"] + [pt["lp"]]]
             for key, a, b in zip(m.meta["derived"] + ["return"], dv + [got], want):
                 assert same(a, b), (name, key, state, a, b)
                 checked += 1
+            if m.meta["parallel"] and t < 12:
+                for lanes in (2, 4, 64):
+                    v, dvl = m.eval(state, lanes, derived=True)
+                    assert all(same(a, b) for a, b in zip(dvl, dv)), (name, lanes, state)
+                    assert same(v, got) or (math.isfinite(got) and abs(v - got) <= 1e-9 * max(1.0, abs(got))), (name, lanes, state, v, got)
     assert checked == 2 * 40 * 54
