@@ -28,7 +28,7 @@ for (const name of um.names) {
   const m = um.build(name, SEED);
   for (const k of Object.keys(m.helpers || {})) global[k] = m.helpers[k];
   for (const k of Object.keys(m.constants || {})) global[k] = m.constants[k];
-  const c = { name: 'user_' + name, model: name, seed: SEED, chains: m.chains, schedule: m.schedule };
+  const c = { name: 'user_' + name, model: name, seed: SEED, chains: m.chains, schedule: m.schedule, options: m.options };
   const model = { params: () => m.params, log_post: m.log_post };
   const res = { case: c, chains: m.chains.map((ch) => h.runChain(c, m.data, ch, model)) };
   // log_post at states the chains visited, and at perturbations of them (bounds violations included)

@@ -137,6 +137,27 @@ assert.throws(() => new mcmc.AmwgSampler({ mu: { type: 'complex', init: 1 }, sig
     assert.ok(tr.source.indexOf('struct UserModel') > 0, name);
     assert.ok(mcmc.native().compileUser(tr.source, tr.parallel ? 4 : 1, 256, 'gfx950') > 10000, name);
   }
+  // parameter completion and option merging on randomly drawn configurations: what this front-end hands to the C ABI equals what the
+  // reference's constructor built (recorded from the live reference objects in tests/golden/user_cfgfuzz_*.json)
+  {
+    const untag = (k, v) => (v === '__inf' ? Infinity : v === '__-inf' ? -Infinity : v === '__nan' ? NaN : v === '__-0' ? -0 : v);
+    const flat = (v) => { const o = []; (function r(x) { Array.isArray(x) ? x.forEach(r) : o.push(x); })(v); return o; };
+    let checked = 0;
+    for (const name of um.names.filter((n) => /^cfgfuzz_/.test(n))) {
+      const m = um.build(name), rec = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'golden', 'user_' + name + '.json'), 'utf8'), untag).chains[0];
+      const done = mcmc.complete_params(m.params, mcmc.param_init_fixed);
+      assert.deepStrictEqual(Object.keys(done).map((k) => ({ name: k, type: done[k].type, dim: done[k].dim, lower: done[k].lower, upper: done[k].upper, init: flat(done[k].init) })), rec.params_completed, name);
+      let ci = 0;
+      for (const k of Object.keys(done)) for (const o of mcmc.componentOptions(k, done[k], m.options)) {
+        const want = rec.comp_opts[ci++];
+        if (done[k].type === 'binary') continue;       // BinarySteppers hold no options (mcmc.js:745-752)
+        assert.deepStrictEqual(o, want, name + ' ' + k);
+        checked++;
+      }
+      assert.strictEqual(ci, rec.comp_opts.length);
+    }
+    assert.ok(checked >= 40);
+  }
   // script-style globals (the reference's README / test pages define helpers and constants as globals) are visible to the translator
   {
     global.logit_g = function(p) { return Math.log(p / (1 - p)); };

@@ -25,12 +25,14 @@ for (const name of um.names) {
   const g = golden('user_' + name);
   const names = Object.keys(m.params);
   for (const rec of g.chains) {
-    const s = new mcmc.AmwgSampler(m.params, m.log_post, m.data,
-      { seed: g.case.seed, chain_offset: rec.chain, lanes_per_chain: 1, translate: true, helpers: m.helpers, constants: m.constants });
+    const s = new mcmc.AmwgSampler(m.params, m.log_post, m.data, Object.assign({}, m.options,      // m.options: the fixture's stepper options (global / per parameter / per component)
+      { seed: g.case.seed, chain_offset: rec.chain, lanes_per_chain: 1, translate: true, helpers: m.helpers, constants: m.constants }));
     assert.strictEqual(s.model, 'translated');
     const segs = [];
     for (const seg of g.case.schedule) {
       if (seg.op === 'burn') s.burn(seg.n);
+      else if (seg.op === 'stop') s.stop_adaptation();
+      else if (seg.op === 'start') s.start_adaptation();
       else { if (seg.thin) s.thin(seg.thin); segs.push(s.sample(seg.n)); }
     }
     segs.forEach((smp, k) => {

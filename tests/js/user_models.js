@@ -450,11 +450,81 @@ CASES.live_out_temp = {
   schedule: [{ op: 'burn', n: 120 }, { op: 'sample', n: 120, keep: 40 }], chains: [0, 1],
 };
 
+// ---- randomly drawn sampler CONFIGURATIONS (deterministic per index): parameter types, dims up to three levels, bounds, inits given
+// as scalars / arrays / not at all, global and per-parameter stepper options incl. arrays shaped like the parameter and falsy overrides
+// (the `||` merge of mcmc.js:873-878), schedules with stop/start_adaptation and thinning -- around a closure generated for that spec.
+function makeConfigCase(index) {
+  const r = lcg(7919 * (index + 1));
+  const pick = (a) => a[Math.floor(r() * a.length)];
+  const nNamed = 1 + Math.floor(r() * 4);
+  const params = {}, elems = { real: [], int: [], binary: [] }, options = {}, perParam = {};
+  const shapeFill = (dim, f) => (dim.length === 1 ? Array.from({ length: dim[0] }, f) : Array.from({ length: dim[0] }, () => shapeFill(dim.slice(1), f)));
+  for (let p = 0; p < nNamed; p++) {
+    const name = ['alpha', 'beta', 'gam', 'delta'][p];
+    const type = p === 0 ? 'real' : pick(['real', 'real', 'int', 'binary']);
+    const dim = pick([[1], [1], [3], [2], [2, 2], [1, 3], [2, 1, 2], [4]]);
+    const spec = {};
+    if (type !== 'real' || r() < 0.5) spec.type = type;
+    if (!(dim.length === 1 && dim[0] === 1) || r() < 0.3) spec.dim = dim.length === 1 && r() < 0.5 ? dim[0] : dim;
+    let intLower0 = false;
+    if (type === 'real') { const b = pick(['none', 'none', 'lower0', 'box', 'upper']); if (b === 'lower0') spec.lower = 0; if (b === 'box') { spec.lower = -2; spec.upper = 5; } if (b === 'upper') spec.upper = 3; }
+    if (type === 'int') { const b = pick(['lower0', 'box', 'none']); if (b === 'lower0') { spec.lower = 0; intLower0 = true; } if (b === 'box') { spec.lower = 0; spec.upper = 9; intLower0 = true; } }
+    const initKind = pick(['none', 'none', 'scalar', 'array']);
+    const one = () => (type === 'binary' ? (r() < 0.5 ? 0 : 1) : (type === 'int' ? 1 + Math.floor(r() * 4) : 0.25 + r()));
+    if (initKind === 'scalar') spec.init = one();
+    if (initKind === 'array' && !(dim.length === 1 && dim[0] === 1)) spec.init = shapeFill(dim, one);
+    params[name] = spec;
+    // element access expressions, row-major
+    const acc = [];
+    (function rec(d, prefix) { if (d.length === 0) { acc.push(prefix); return; } for (let i = 0; i < d[0]; i++) rec(d.slice(1), prefix + '[' + i + ']'); })(dim.length === 1 && dim[0] === 1 ? [] : dim, 's.' + name);
+    acc.forEach((e) => elems[type].push({ e, intLower0 }));
+    // per-parameter stepper options (only Metropolis steppers read them)
+    if (type !== 'binary' && r() < 0.6) {
+      const o = {};
+      const arrOr = (f) => ((dim.length === 1 && dim[0] === 1) || r() < 0.5 ? f() : shapeFill(dim, f));
+      if (r() < 0.6) o.prop_log_scale = arrOr(() => pick([-1, 0.5, 1.5, 0]));
+      if (r() < 0.4) o.batch_size = arrOr(() => pick([5, 7, 20]));
+      if (r() < 0.3) o.target_accept_rate = arrOr(() => pick([0.2, 0.3, 0.6]));
+      if (r() < 0.3) o.is_adapting = pick([false, true]);
+      if (r() < 0.3) o.max_adaptation = pick([0.1, 0.5]);
+      if (r() < 0.3) o.initial_adaptation = pick([0.4, 2]);
+      perParam[name] = o;
+    }
+  }
+  if (r() < 0.7) options.batch_size = pick([5, 10, 25]);
+  if (r() < 0.5) options.prop_log_scale = pick([-0.5, 1, 0]);
+  if (r() < 0.3) options.max_adaptation = 0.2;
+  if (r() < 0.3) options.initial_adaptation = 0.5;
+  if (r() < 0.3) options.target_accept_rate = 0.3;
+  if (r() < 0.2) options.is_adapting = false;
+  if (Object.keys(perParam).length) options.params = perParam;
+  // the closure, written for this spec
+  const L = ['var lp = 0;'];
+  elems.real.forEach((x, i) => L.push('lp += ld.norm(' + x.e + ', ' + (0.5 + 0.25 * i) + ', ' + (1.5 + 0.5 * (i % 3)) + ');'));
+  elems.int.forEach((x, i) => L.push(x.intLower0 ? 'lp += ld.pois(' + x.e + ', ' + (2.5 + i) + ');' : 'lp += ld.norm(' + x.e + ', 1, ' + (2 + i) + ');'));
+  elems.binary.forEach((x, i) => L.push('lp += ld.bern(' + x.e + ', ' + (0.3 + 0.1 * (i % 4)) + ');'));
+  const R = elems.real, I = elems.int, B = elems.binary;
+  const r0 = R[0].e, r1 = R[R.length - 1].e;
+  L.push('lp += ld.norm(' + r0 + ' * (1 + ' + (B.length ? B[0].e : '0') + '), ' + (I.length ? I[0].e + ' * 0.2' : '0.3') + ', 1.5);');
+  L.push('for (var i = 0; i < d.y.length; i++) { lp += ld.norm(d.y[i], ' + r1 + (I.length ? ' + 0.1 * ' + I[I.length - 1].e : '') + ', 1 + Math.abs(' + r0 + ')' + (B.length ? ' + ' + B[B.length - 1].e : '') + '); }');
+  if (r() < 0.5) L.push('s.derived_sum = ' + r0 + ' + ' + r1 + ';');
+  L.push('return lp;');
+  const log_post = new Function('return function (s, d) {\n  ' + L.join('\n  ') + '\n};')();
+  const y = []; for (let i = 0; i < 6; i++) y.push(Math.round((r() * 4 - 1) * 100) / 100);
+  const schedule = [{ op: 'burn', n: 40 + Math.floor(r() * 40) }];
+  if (r() < 0.5) { schedule.push({ op: 'stop' }); schedule.push({ op: 'burn', n: 23 }); if (r() < 0.7) schedule.push({ op: 'start' }); }
+  schedule.push({ op: 'sample', n: 60 + Math.floor(r() * 30), thin: pick([1, 1, 2, 3]), keep: 40 });
+  if (r() < 0.4) schedule.push({ op: 'sample', n: 31, thin: 5 });
+  return { params: () => params, data: () => ({ y }), log_post, options, schedule, chains: [0, 2] };
+}
+const N_CONFIG_CASES = 16;
+for (let k = 0; k < N_CONFIG_CASES; k++) CASES['cfgfuzz_' + k] = makeConfigCase(k);
+
 function build(name, seed) {
   const c = CASES[name] || BENCH[name];
   if (!c) throw new Error('unknown user model ' + name);
   const data = c.data(seed === undefined ? 20260925 : seed);
-  return { name, params: c.params(data), log_post: c.log_post, data, helpers: c.helpers, constants: c.constants,
+  return { name, params: c.params(data), log_post: c.log_post, data, helpers: c.helpers, constants: c.constants, options: c.options,
            schedule: c.schedule, chains: c.chains, same_as_golden: c.same_as_golden };
 }
 

@@ -21,7 +21,7 @@ import user_host
 pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
 
 NAMES = ["readme_normal", "readme_bern", "norm_post_derived", "complex_model", "hier_binomial", "multi_bern", "multivar_poisson",
-         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js", "live_out_temp"]
+         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js", "live_out_temp"] + ["cfgfuzz_%d" % k for k in range(16)]
 
 
 def same(a, b):
@@ -32,14 +32,14 @@ def same(a, b):
 def test_translated_closure_equals_reference_on_host(name):
     gold = golden_io.load("user_" + name)
     m = user_host.host_model(name)
-    assert len(gold["log_post_checks"]) >= 30
+    assert len(gold["log_post_checks"]) >= (15 if name.startswith("cfgfuzz") else 30)
     finite = 0
     for chk in gold["log_post_checks"]:
         got, dv = m.eval(chk["state"], 1, derived=True)
         assert same(got, chk["log_post"]), (name, chk["state"], got, chk["log_post"])
         assert len(dv) == len(chk["derived"]) and all(same(a, b) for a, b in zip(dv, chk["derived"]))
         finite += math.isfinite(chk["log_post"])
-    assert finite >= 10
+    assert finite >= (5 if name.startswith("cfgfuzz") else 10)
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -95,10 +95,13 @@ def oracle_spec(name):
     return {"log_post_fn": lambda st, lanes: m.eval(st, lanes), "params": params, "P": len(init), "init": init, "comp_opts": opts}, gold, m
 
 
-@pytest.mark.parametrize("name", ["complex_model", "spike_slab", "multi_bern", "hier_binomial", "discrete_mix", "modern_js", "multivar_poisson", "semantics_probe"])
+@pytest.mark.parametrize("name", ["complex_model", "spike_slab", "multi_bern", "hier_binomial", "discrete_mix", "modern_js", "multivar_poisson", "semantics_probe"]
+                         + ["cfgfuzz_%d" % k for k in range(16)])
 def test_oracle_stepper_with_translated_closure_reproduces_reference(name):
     """Pins the oracle's BinaryStepper (mcmc.js:753-767) and int/real steppers on user models: the C oracle, stepping with the
-    host build of the translated closure as log_post, reproduces the seeded reference run bit for bit."""
+    host build of the translated closure as log_post, reproduces the seeded reference run bit for bit.  cfgfuzz_*: randomly drawn
+    sampler configurations (types, dims up to three levels, bounds, inits, global / per-parameter / per-component options, schedules
+    with stop/start_adaptation and thinning; tests/js/user_models.js makeConfigCase)."""
     import oracle_lib
     spec, gold, m = oracle_spec(name)
     P = spec["P"]
@@ -108,6 +111,8 @@ def test_oracle_stepper_with_translated_closure_reproduces_reference(name):
         for seg in gold["case"]["schedule"]:
             if seg["op"] == "burn":
                 o.burn(seg["n"])
+            elif seg["op"] in ("stop", "start"):
+                o.set_adapting(seg["op"] == "start")
             else:
                 got = o.sample(seg["n"], seg.get("thin", 1))
                 want = rec["samples"][k]
