@@ -346,9 +346,11 @@ AmwgSampler.prototype.info = function () {
   }
   const steppers = {};
   for (const L of this._layout) {
-    const one = (e) => { const o = {}; for (const k of keys) o[k] = merged[k][(L.base + e) * C]; return o; };
+    const binary = this.params[L.name].type === 'binary';      // BinarySteppers keep no proposal scale or adaptation state (mcmc.js:745-767): run totals only
+    const shown = binary ? ['accepts', 'inbounds'] : keys;
+    const one = (e) => { const o = {}; for (const k of shown) o[k] = merged[k][(L.base + e) * C]; return o; };
     if (C === 1) steppers[L.name] = L.scalar ? one(0) : nest(Array.from({ length: L.len }, (_, e) => one(e)), 0, L.dim);
-    else { const o = {}; for (const k of keys) o[k] = merged[k].subarray(L.base * C, (L.base + L.len) * C); steppers[L.name] = o; }
+    else { const o = {}; for (const k of shown) o[k] = merged[k].subarray(L.base * C, (L.base + L.len) * C); steppers[L.name] = o; }
   }
   return { state: this.state, thin: this.thinning_interval, monitor: this.monitored_params, steppers,
            launch: this._each((sh) => Object.assign({ device: sh.device, chains: sh.count }, N.launchInfo(sh.handle))) };

@@ -175,9 +175,9 @@ def test_fuzzed_closures_on_the_device_equal_v8(lanes):
         pts = user_host.stepper_states(name)
         f64 = lambda h: float(np.frombuffer(bytes.fromhex(h), dtype=">f8")[0])
         states = np.array([[f64(h) for h in pt["state"]] for pt in pts])            # [40][7]: a, b, v[3], k, z
-        params = [{"type": 0, "len": 1, "top": 1, "multidim": 0, "lower": -INF, "upper": INF}, {"type": 0, "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": INF},
-                  {"type": 0, "len": 3, "top": 3, "multidim": 1, "lower": -INF, "upper": INF}, {"type": 1, "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": 6.0},
-                  {"type": 2, "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": 1.0}]
+        params = [{"type": "real", "len": 1, "top": 1, "multidim": 0, "lower": -INF, "upper": INF}, {"type": "real", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": INF},
+                  {"type": "real", "len": 3, "top": 3, "multidim": 1, "lower": -INF, "upper": INF}, {"type": "int", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": 6.0},
+                  {"type": "binary", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": 1.0}]
         opts = [{"prop_log_scale": 0.0, "max_adaptation": 0.33, "initial_adaptation": 1.0, "target_accept_rate": 0.44, "batch_size": 50, "is_adapting": True}] * 7
         spec = {"user": user_host.user_spec_part(m.source, m.arrays, m.meta), "params": params, "P": 7, "init": states[0].tolist(), "comp_opts": opts}
         s = A.Sampler(spec, chains=len(pts), seed=1, lanes_per_chain=lanes)
