@@ -517,7 +517,7 @@ function makeConfigCase(index) {
   if (r() < 0.4) schedule.push({ op: 'sample', n: 31, thin: 5 });
   return { params: () => params, data: () => ({ y }), log_post, options, schedule, chains: [0, 2] };
 }
-const N_CONFIG_CASES = 16;
+const N_CONFIG_CASES = Number(process.env.AMWG_CFGFUZZ_N || 16);
 for (let k = 0; k < N_CONFIG_CASES; k++) CASES['cfgfuzz_' + k] = makeConfigCase(k);
 
 function build(name, seed) {
