@@ -27,7 +27,7 @@ using namespace amwg;
 // together with the very same step kernel source the built-in models are compiled from.
 extern "C" {
 extern const char amwg_hdr_stdint[], amwg_hdr_types[], amwg_hdr_math[], amwg_hdr_div[], amwg_hdr_ld[], amwg_hdr_philox[],
-    amwg_hdr_kernel[], amwg_hdr_user[], amwg_hdr_twoval[];
+    amwg_hdr_kernel[], amwg_hdr_user[], amwg_hdr_twoval[], amwg_hdr_trig[];
 }
 
 namespace {
@@ -357,7 +357,9 @@ double amwg_log(double x) { return log_v8(x); }
 double amwg_pow(double x, double y) { return pow_v8(x, y); }
 double amwg_log1p(double x) { return log1p_v8(x); }
 double amwg_expm1(double x) { return expm1_v8(x); }
-double amwg_math1(int32_t fn, double x) { return fn == 0 ? tanh_v8(x) : (fn == 1 ? atan_v8(x) : (fn == 2 ? log10_v8(x) : __builtin_nan(""))); }
+double amwg_math1(int32_t fn, double x) { return math1_by_id(fn, x); }
+double amwg_math2(int32_t fn, double x, double y) { return fn == 0 ? atan2_v8(x, y) : (fn == 1 ? hypot2_v8(x, y) : __builtin_nan("")); }
+double amwg_hypot3(double x, double y, double z) { return hypot3_v8(x, y, z); }
 double amwg_ld_host(int32_t id, double x, double a, double b, double c) { return ld_by_id(id, x, a, b, c); }
 double amwg_uniform(uint64_t seed, uint64_t chain, uint64_t index) {
   ChainStream s;
@@ -537,12 +539,12 @@ static std::string user_program(const char *source, int lanes, int block) {
 
 static int compile_user(const char *source, int lanes, int block, const char *arch, std::vector<char> *code) {
   static const char *names[] = {"amwg_stdint.h", "amwg_types.h", "amwg_math.h", "amwg_div.h", "amwg_ld.h", "amwg_philox.h",
-                                "amwg_kernel.h", "amwg_user.h", "amwg_twoval.h"};
+                                "amwg_kernel.h", "amwg_user.h", "amwg_twoval.h", "amwg_trig.h"};
   const char *texts[] = {amwg_hdr_stdint, amwg_hdr_types, amwg_hdr_math, amwg_hdr_div, amwg_hdr_ld, amwg_hdr_philox,
-                         amwg_hdr_kernel, amwg_hdr_user, amwg_hdr_twoval};
+                         amwg_hdr_kernel, amwg_hdr_user, amwg_hdr_twoval, amwg_hdr_trig};
   const std::string prog_src = user_program(source, lanes, block);
   hiprtcProgram prog = nullptr;
-  hiprtcResult r = hiprtcCreateProgram(&prog, prog_src.c_str(), "amwg_user_model.hip", 9, texts, names);
+  hiprtcResult r = hiprtcCreateProgram(&prog, prog_src.c_str(), "amwg_user_model.hip", 10, texts, names);
   if (r != HIPRTC_SUCCESS) return fail(AMWG_EHIP, "hiprtcCreateProgram failed: %s", hiprtcGetErrorString(r));
   const std::string arch_opt = std::string("--offload-arch=") + arch;
   // same floating-point contract as the Makefile: one rounding per operation, no fused contraction

@@ -34,6 +34,28 @@ AMWG_HD double ld_by_id(int id, double x, double a, double b, double c) {
   return __builtin_nan("");
 }
 
+// the one-argument Math.* twins by the ids of amwg_math1 (include/amwg.h)
+AMWG_HD double math1_by_id(int fn, double x) {
+  switch (fn) {
+    case 0: return tanh_v8(x);
+    case 1: return atan_v8(x);
+    case 2: return log10_v8(x);
+    case 3: return sin_v8(x);
+    case 4: return cos_v8(x);
+    case 5: return tan_v8(x);
+    case 6: return asin_v8(x);
+    case 7: return acos_v8(x);
+    case 8: return sinh_v8(x);
+    case 9: return cosh_v8(x);
+    case 10: return asinh_v8(x);
+    case 11: return acosh_v8(x);
+    case 12: return atanh_v8(x);
+    case 13: return cbrt_v8(x);
+    case 14: return log2_v8(x);
+  }
+  return __builtin_nan("");
+}
+
 __global__ void amwg_ld_eval_kernel(int64_t n, const double *rec /* [n][5]: id, x, a, b, c */, double *out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -66,6 +88,10 @@ __global__ void amwg_eval_kernel(int op, int64_t n, const double *a, const doubl
     case 17: r = atan_v8(x); break;
     case 18: r = log10_v8(x); break;
     case 19: r = quot_plain(x, y); break;
+    case 20: r = math1_by_id((int)y, x); break;      // y = function id
+    case 21: r = atan2_v8(x, y); break;
+    case 22: r = hypot3_v8(x, y, z); break;
+    case 23: r = hypot2_v8(x, y); break;
   }
   out[i] = r;
 }

@@ -17,8 +17,10 @@
 
 #if defined(__HIPCC__)
 #define AMWG_HD __host__ __device__ __forceinline__
+#define AMWG_HD_OUTLINE __host__ __device__ __attribute__((noinline))   // large, rarely executed bodies: one copy per kernel
 #else
 #define AMWG_HD inline
+#define AMWG_HD_OUTLINE inline
 #endif
 
 namespace amwg {
@@ -542,3 +544,5 @@ AMWG_HD double js_round(double x) {
 }
 
 }  // namespace amwg
+
+#include "amwg_trig.h"

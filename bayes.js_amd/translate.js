@@ -7,8 +7,8 @@
  * The closure is read from its own source text (Function.prototype.toString) and must stay
  * inside a numeric subset of JavaScript:
  *     var/let/const, assignments (= += -= *= /= %=, ++ --), for / while / if / else / break / continue / return, blocks
- *     numbers, + - * / % **, comparisons, && || !, ?:, Math.{log,exp,log1p,expm1,log10,tanh,atan,sqrt,abs,pow,floor,ceil,round,
- *     min,max,trunc,sign,PI,E,...}, isNaN, isFinite, every ld.* of distributions.js (array-valued ones unrolled),
+ *     numbers, + - * / % **, comparisons, && || !, ?:, Math.{log,exp,log1p,expm1,log10,log2,pow,sqrt,cbrt,hypot,abs,floor,ceil,round,trunc,sign,
+ *     min,max,sin,cos,tan,asin,acos,atan,atan2,sinh,cosh,tanh,asinh,acosh,atanh,PI,E,...}, isNaN, isFinite, every ld.* of distributions.js (array-valued ones unrolled),
  *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, local
  *     aliases of those (var p = par.p[0]), derived quantities (state.key = expr, mcmc.js:961-963),
  *     helper functions and constants passed in options.helpers / options.constants (or globals);
@@ -567,8 +567,11 @@ const MATH_FUNS = {
   tanh: ['tanh_v8', 1, Math.tanh], atan: ['atan_v8', 1, Math.atan], log10: ['log10_v8', 1, Math.log10], sqrt: ['__builtin_sqrt', 1, Math.sqrt], abs: ['__builtin_fabs', 1, Math.abs],
   floor: ['__builtin_floor', 1, Math.floor], ceil: ['__builtin_ceil', 1, Math.ceil], round: ['js_round', 1, Math.round],
   trunc: ['js_trunc', 1, Math.trunc], sign: ['js_sign', 1, Math.sign],
+  sin: ['sin_v8', 1, Math.sin], cos: ['cos_v8', 1, Math.cos], tan: ['tan_v8', 1, Math.tan], asin: ['asin_v8', 1, Math.asin], acos: ['acos_v8', 1, Math.acos],
+  sinh: ['sinh_v8', 1, Math.sinh], cosh: ['cosh_v8', 1, Math.cosh], asinh: ['asinh_v8', 1, Math.asinh], acosh: ['acosh_v8', 1, Math.acosh], atanh: ['atanh_v8', 1, Math.atanh],
+  cbrt: ['cbrt_v8', 1, Math.cbrt], log2: ['log2_v8', 1, Math.log2],
 };
-const HEAVY = new Set(['log_v8', 'exp_v8', 'pow_v8', 'log1p_v8', 'expm1_v8', 'tanh_v8', 'atan_v8', 'log10_v8', 'ld_norm', 'ld_beta', 'ld_pois', 'ld_bern', 'ld_gamma', 'ld_invgamma', 'ld_lnorm', 'ld_t',
+const HEAVY = new Set(['log_v8', 'exp_v8', 'pow_v8', 'log1p_v8', 'expm1_v8', 'tanh_v8', 'atan_v8', 'log10_v8', 'sin_v8', 'cos_v8', 'tan_v8', 'asin_v8', 'acos_v8', 'sinh_v8', 'cosh_v8', 'asinh_v8', 'acosh_v8', 'atanh_v8', 'cbrt_v8', 'log2_v8', 'atan2_v8', 'hypot', 'ld_norm', 'ld_beta', 'ld_pois', 'ld_bern', 'ld_gamma', 'ld_invgamma', 'ld_lnorm', 'ld_t',
   'ld_weibull', 'ld_logis', 'ld_binom', 'ld_nbinom', 'ld_hyper', 'ld_cauchy', 'ld_pareto', 'ld_exp', 'ld_laplace', 'ld_unif', 'lgamma_js', 'lfactorial_js', 'lchoose_js', 'lbeta_js']);
 
 const ld_host = require('./ld.js');
@@ -967,6 +970,19 @@ Translator.prototype.callInner = function (e) {
       let code = this.asD(args[0]);
       for (let k = 1; k < args.length; k++) code = 'js_' + f.name + '(' + code + ', ' + this.asD(args[k]) + ')';
       return num(code, false);
+    }
+    if (f.name === 'atan2') {
+      if (args.length !== 2) this.fail('Math.atan2 takes two arguments');
+      if (allConst()) return cnum(Math.atan2(args[0].cst, args[1].cst));
+      if (this.loops.length) this.heavyLoop = true;
+      return num('atan2_v8(' + this.asD(args[0]) + ', ' + this.asD(args[1]) + ')', false);
+    }
+    if (f.name === 'hypot') {
+      if (args.length < 1 || args.length > 4) this.fail('Math.hypot takes 1 to 4 arguments here');
+      if (allConst()) return cnum(Math.hypot.apply(null, args.map((a) => a.cst)));
+      if (this.loops.length) this.heavyLoop = true;
+      if (args.length === 1) return num('hypot2_v8(' + this.asD(args[0]) + ', 0.0)', false);     // sqrt(1) * |x|
+      return num('hypot' + args.length + '_v8(' + args.map((a) => this.asD(a)).join(', ') + ')', false);
     }
     const M = MATH_FUNS[f.name];
     if (!M) this.fail('Math.' + f.name + ' is not supported');

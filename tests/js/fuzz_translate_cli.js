@@ -32,11 +32,14 @@ function generator(rnd) {
     if (r < 0.40) return '(- ' + a() + ')';
     if (r < 0.50) return '(' + cond(depth - 1, ctx) + ' ? ' + a() + ' : ' + a() + ')';
     if (r < 0.72) {
-      const f = pick(['abs', 'floor', 'ceil', 'round', 'trunc', 'sign', 'sqrt', 'exp', 'log', 'log1p', 'expm1', 'tanh', 'atan', 'log10', 'abs', 'sqrt', 'exp', 'log']);
+      const f = pick(['abs', 'floor', 'ceil', 'round', 'trunc', 'sign', 'sqrt', 'exp', 'log', 'log1p', 'expm1', 'tanh', 'atan', 'log10', 'abs', 'sqrt', 'exp', 'log',
+        'sin', 'cos', 'tan', 'asin', 'acos', 'sinh', 'cosh', 'asinh', 'acosh', 'atanh', 'cbrt', 'log2']);
+      if (f === 'sinh' || f === 'cosh') return 'Math.' + f + '(' + a() + ' * 0.05)';
       if (f === 'exp' || f === 'expm1') return 'Math.' + f + '(' + a() + ' * 0.1)';
       return 'Math.' + f + '(' + a() + ')';
     }
-    if (r < 0.78) return 'Math.' + pick(['min', 'max']) + '(' + a() + ', ' + a() + (rnd() < 0.3 ? ', ' + a() : '') + ')';
+    if (r < 0.76) return 'Math.' + pick(['min', 'max']) + '(' + a() + ', ' + a() + (rnd() < 0.3 ? ', ' + a() : '') + ')';
+    if (r < 0.78) return rnd() < 0.5 ? 'Math.atan2(' + a() + ', ' + a() + ')' : 'Math.hypot(' + a() + ', ' + a() + (rnd() < 0.4 ? ', ' + a() : '') + ')';
     if (r < 0.83) return 'Math.pow(' + a() + ', ' + pick(['2', '0.5', '3', '-1', '1.5', leafD(ctx), 's.k']) + ')';
     if (r < 0.97) {
       const pos = () => 'Math.abs(' + a() + ') + 0.1';
@@ -75,7 +78,20 @@ function generator(rnd) {
     if (r < 0.9) return 'for (var i = 0; i < d.n.length; i++) { var t = 0; for (var j = 0; j <= d.n[i] % 4; j++) { t += d.x[(i + j) % 8] * ' + lit() + '; } lp += ld.norm(t, s.a, s.b + 0.5) * 1e-2; }';
     return 'lp += ' + num(3, {}) + ' * 1e-2;';
   }
-  return { num, cond, block, lpBlock };
+  // post-ES5 spellings (rewritten by the parser into the core subset): for-of, forEach with an early return, reduce inside an
+  // expression, destructuring declarations, an arrow helper
+  function sugarBlock(k) {
+    const r = rnd(), ctxX = { i: null };
+    const e = (ctx) => num(2, ctx || {}), c = (ctx) => '(' + cond(2, ctx || {}) + ')';
+    const withT = (str, v) => str.replace(/(^|[^.\w])t\b/g, '$1' + v);
+    if (r < 0.2) return 'for (const xv' + k + ' of d.x) { lp += (xv' + k + ' * ' + withT(e(), 'xv' + k) + ') * 1e-3; }';
+    if (r < 0.4) return 'd.x.forEach(function (xe, ie) { if ' + withT(c({ i: 'ie' }), 'xe') + ' return; lp += (xe + ' + withT(e({ i: 'ie' }), 'xe') + ') * 1e-3; });';
+    if (r < 0.6) return 'lp += d.x.reduce((ac, xe, ie) => ac + ' + withT(e({ i: 'ie' }), 'xe') + ' * 1e-3, ' + withT(e(), 's.a') + ') * 1e-2;';
+    if (r < 0.75) return 'const { a: pa' + k + ', v: [pv' + k + ', , pw' + k + '] } = s;\n  lp += (pa' + k + ' * pv' + k + ' - pw' + k + ') * 1e-3;';
+    if (r < 0.9) return 'const hf' + k + ' = (p, q) => p * ' + lit() + ' + Math.abs(q);\n  for (const nv' + k + ' of d.n) lp += hf' + k + '(nv' + k + ', ' + withT(e(), 's.b') + ') * 1e-3;';
+    return 's.r' + k + ' = s.v.reduce(function (ac, ve) { var sq = ve * ve; return ac + sq; }, 0) + d.m[1].reduce((ac, me) => Math.max(ac, me), -Infinity);';
+  }
+  return { num, cond, block, lpBlock, sugarBlock };
 }
 
 function stateFrom(rnd, t) {
@@ -93,6 +109,7 @@ for (let mk = 0; mk < nModels; mk++) {
   for (let b = 0; b < NB; b++) lines.push('  ' + G.block(b));
   lines.push('  var lp = ' + G.num(3, {}) + ' + ld.norm(s.a, 0, 10);');
   for (let b = 0; b < 4; b++) lines.push('  ' + G.lpBlock());
+  for (let b = 0; b < 3; b++) lines.push('  ' + G.sugarBlock(b));
   lines.push('  return lp;');
   const src = 'return function (s, d) {\n' + lines.join('\n') + '\n};';
   const fn = new Function('ld', src)(ld);

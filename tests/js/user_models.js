@@ -520,6 +520,27 @@ function makeConfigCase(index) {
 const N_CONFIG_CASES = Number(process.env.AMWG_CFGFUZZ_N || 16);
 for (let k = 0; k < N_CONFIG_CASES; k++) CASES['cfgfuzz_' + k] = makeConfigCase(k);
 
+// ---- circular data: wrapped-Cauchy likelihood (cos, sinh, cosh), mean direction on the whole circle through atan2 of two real
+// parameters, a cbrt/log2/hypot/asinh-flavoured prior -- the trigonometric and hyperbolic twins of csrc/amwg_trig.h inside a sampler
+CASES.circular_wrapped_cauchy = {
+  params: () => ({ u: { init: 0.6 }, v: { init: 0.3 }, rho: { lower: 0, init: 0.8 } }),
+  data: (seed) => { const r = lcg(seed), th = []; for (let i = 0; i < 48; i++) { const t = 1.1 + Math.tan(Math.PI * (r() - 0.5)) * 0.35; th.push(Math.atan2(Math.sin(t), Math.cos(t))); } return { th }; },
+  log_post: function (s, d) {
+    var mu = Math.atan2(s.v, s.u);
+    var len = Math.hypot(s.u, s.v);
+    var lp = ld.norm(len, 1, 0.5) + ld.gamma(s.rho, 2, 1.5) - 1e-3 * Math.cbrt(s.rho) + 1e-3 * Math.log2(1 + len) - 1e-3 * Math.asinh(s.u * s.v);
+    var c0 = Math.log(Math.sinh(s.rho)) - Math.log(2 * Math.PI);
+    var ch = Math.cosh(s.rho);
+    for (var i = 0; i < d.th.length; i++) {
+      lp += c0 - Math.log(ch - Math.cos(d.th[i] - mu));
+    }
+    s.mean_direction = mu;
+    s.concentration = Math.tanh(s.rho / 2) + 1e-6 * (Math.asin(Math.sin(mu)) + Math.acos(Math.cos(mu)) + Math.tan(mu / 4) + Math.acosh(1 + s.rho) + Math.atanh(Math.tanh(s.rho) / 2));
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+
 function build(name, seed) {
   const c = CASES[name] || BENCH[name];
   if (!c) throw new Error('unknown user model ' + name);

@@ -94,3 +94,19 @@ def test_host_build_of_tanh_atan_log10_equals_v8():
     L = amwg_ctypes.lib()
     a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_math2_pairs.bin"), dtype="<f8").reshape(-1, 4)
     assert sum((not _same(L.amwg_math1(0, x), t)) + (not _same(L.amwg_math1(1, x), at)) + (not _same(L.amwg_math1(2, abs(x)), lg)) for x, t, at, lg in a) == 0
+
+
+def test_host_build_of_the_trigonometric_hyperbolic_and_root_twins_equals_v8():
+    """csrc/amwg_trig.h (sin cos tan asin acos atan2 sinh cosh asinh acosh atanh cbrt log2 hypot) against 24 000 outputs each of this
+    Node's V8 (oracle/gen_math3_golden.js), arguments up to 1e300 (Payne-Hanek reduction), subnormals, +-0, NaN, infinities."""
+    L = amwg_ctypes.lib()
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_math3_pairs.bin"), dtype="<f8").reshape(-1, 15)
+    cols = {"sin": (3, 3, 0), "cos": (4, 4, 0), "tan": (5, 5, 0), "sinh": (8, 6, 0), "cosh": (9, 7, 0), "asinh": (10, 8, 0), "cbrt": (13, 9, 0), "log2": (14, 10, 0),
+            "asin": (6, 11, 1), "acos": (7, 12, 1), "atanh": (12, 13, 1), "acosh": (11, 14, 2)}
+    for name, (fn, col, argc) in cols.items():
+        bad = sum(not _same(L.amwg_math1(fn, abs(r[argc]) if name == "log2" else r[argc]), r[col]) for r in a)
+        assert bad == 0, name
+    b = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_atan2_pairs.bin"), dtype="<f8").reshape(-1, 3)
+    assert sum(not _same(L.amwg_math2(0, y, x), w) for y, x, w in b) == 0
+    h = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_hypot_pairs.bin"), dtype="<f8").reshape(-1, 5)
+    assert sum((not _same(L.amwg_math2(1, p, q), h2)) + (not _same(L.amwg_hypot3(p, q, r), h3)) for p, q, r, h2, h3 in h) == 0

