@@ -94,5 +94,25 @@ AMWG_HD double js_min(double a, double b) {
 }
 AMWG_HD double js_sign(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
 AMWG_HD double js_trunc(double x) { return __builtin_trunc(x); }
+// ToInt32 (ECMA-262 7.1.6): truncate, reduce modulo 2^32 into [-2^31, 2^31); NaN and infinities give 0.  Bitwise operators, Math.imul and
+// Math.clz32 work on this value (`x | 0`, `~~x`, `x >>> 0` are the usual integer-truncation idioms).
+AMWG_HD int32_t js_toint32(double x) {
+  if (!(__builtin_fabs(x) < __builtin_inf())) return 0;
+  const double t = __builtin_trunc(x);
+  if (t >= -2147483648.0 && t <= 2147483647.0) return (int32_t)t;
+  double m = __builtin_fmod(t, 4294967296.0);           // exact; sign of t
+  if (m < 0) m += 4294967296.0;
+  return (int32_t)(uint32_t)m;
+}
+AMWG_HD double js_bitor(double a, double b) { return (double)(js_toint32(a) | js_toint32(b)); }
+AMWG_HD double js_bitand(double a, double b) { return (double)(js_toint32(a) & js_toint32(b)); }
+AMWG_HD double js_bitxor(double a, double b) { return (double)(js_toint32(a) ^ js_toint32(b)); }
+AMWG_HD double js_bitnot(double a) { return (double)(~js_toint32(a)); }
+AMWG_HD double js_shl(double a, double b) { return (double)(int32_t)((uint32_t)js_toint32(a) << ((uint32_t)js_toint32(b) & 31u)); }
+AMWG_HD double js_shr(double a, double b) { return (double)(js_toint32(a) >> ((uint32_t)js_toint32(b) & 31u)); }
+AMWG_HD double js_ushr(double a, double b) { return (double)((uint32_t)js_toint32(a) >> ((uint32_t)js_toint32(b) & 31u)); }
+AMWG_HD double js_imul(double a, double b) { return (double)(int32_t)((uint32_t)js_toint32(a) * (uint32_t)js_toint32(b)); }
+AMWG_HD double js_clz32(double a) { const uint32_t u = (uint32_t)js_toint32(a); return u == 0 ? 32.0 : (double)__builtin_clz(u); }
+AMWG_HD double js_fround(double a) { return (double)(float)a; }
 
 }  // namespace amwg

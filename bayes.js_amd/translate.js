@@ -7,8 +7,8 @@
  * The closure is read from its own source text (Function.prototype.toString) and must stay
  * inside a numeric subset of JavaScript:
  *     var/let/const, assignments (= += -= *= /= %=, ++ --), for / while / if / else / break / continue / return, blocks
- *     numbers, + - * / % **, comparisons, && || !, ?:, Math.{log,exp,log1p,expm1,log10,log2,pow,sqrt,cbrt,hypot,abs,floor,ceil,round,trunc,sign,
- *     min,max,sin,cos,tan,asin,acos,atan,atan2,sinh,cosh,tanh,asinh,acosh,atanh,PI,E,...}, isNaN, isFinite, every ld.* of distributions.js (array-valued ones unrolled),
+ *     numbers, + - * / % **, | & ^ ~ << >> >>> (ToInt32 semantics), comparisons, && || !, ?:, Math.{log,exp,log1p,expm1,log10,log2,pow,sqrt,cbrt,hypot,abs,floor,ceil,round,trunc,sign,
+ *     min,max,sin,cos,tan,asin,acos,atan,atan2,sinh,cosh,tanh,asinh,acosh,atanh,imul,clz32,fround,PI,E,...}, isNaN, isFinite, every ld.* of distributions.js (array-valued ones unrolled),
  *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, local
  *     aliases of those (var p = par.p[0]), derived quantities (state.key = expr, mcmc.js:961-963),
  *     helper functions and constants passed in options.helpers / options.constants (or globals);
@@ -57,8 +57,8 @@ function hexFloat(v) {
 
 // ------------------------------------------------------------------------------------------
 // tokenizer
-const PUNCT = ['===', '!==', '>>>', '**', '==', '!=', '<=', '>=', '&&', '||', '++', '--', '+=', '-=', '*=', '/=', '%=', '=>',
-  '{', '}', '(', ')', '[', ']', ';', ',', '.', '?', ':', '<', '>', '+', '-', '*', '/', '%', '!', '='];
+const PUNCT = ['===', '!==', '>>>', '**', '==', '!=', '<=', '>=', '&&', '||', '++', '--', '+=', '-=', '*=', '/=', '%=', '=>', '<<', '>>',
+  '{', '}', '(', ')', '[', ']', ';', ',', '.', '?', ':', '<', '>', '+', '-', '*', '/', '%', '!', '=', '|', '&', '^', '~'];
 
 function tokenize(src) {
   const out = [];
@@ -271,7 +271,7 @@ Parser.prototype = {
     return test;
   },
   binary(level) {
-    const LEVELS = [['||'], ['&&'], ['===', '!==', '==', '!='], ['<=', '>=', '<', '>'], ['+', '-'], ['*', '/', '%']];
+    const LEVELS = [['||'], ['&&'], ['|'], ['^'], ['&'], ['===', '!==', '==', '!='], ['<=', '>=', '<', '>'], ['>>>', '<<', '>>'], ['+', '-'], ['*', '/', '%']];
     if (level === LEVELS.length) return this.unary();
     let left = this.binary(level + 1);
     for (;;) {
@@ -284,7 +284,7 @@ Parser.prototype = {
     }
   },
   unary() {
-    for (const op of ['-', '+', '!']) if (this.peek(op)) { this.i++; return { k: 'Unary', op, arg: this.unary() }; }
+    for (const op of ['-', '+', '!', '~']) if (this.peek(op)) { this.i++; return { k: 'Unary', op, arg: this.unary() }; }
     for (const op of ['++', '--']) if (this.peek(op)) { this.i++; return { k: 'Update', op, prefix: true, target: this.unary() }; }
     if (this.peek('typeof') || this.peek('new')) throw "'" + this.tk[this.i].v + "' is not supported inside log_post";
     const base = this.postfix();
@@ -569,7 +569,7 @@ const MATH_FUNS = {
   trunc: ['js_trunc', 1, Math.trunc], sign: ['js_sign', 1, Math.sign],
   sin: ['sin_v8', 1, Math.sin], cos: ['cos_v8', 1, Math.cos], tan: ['tan_v8', 1, Math.tan], asin: ['asin_v8', 1, Math.asin], acos: ['acos_v8', 1, Math.acos],
   sinh: ['sinh_v8', 1, Math.sinh], cosh: ['cosh_v8', 1, Math.cosh], asinh: ['asinh_v8', 1, Math.asinh], acosh: ['acosh_v8', 1, Math.acosh], atanh: ['atanh_v8', 1, Math.atanh],
-  cbrt: ['cbrt_v8', 1, Math.cbrt], log2: ['log2_v8', 1, Math.log2],
+  cbrt: ['cbrt_v8', 1, Math.cbrt], log2: ['log2_v8', 1, Math.log2], clz32: ['js_clz32', 1, Math.clz32], fround: ['js_fround', 1, Math.fround],
 };
 const HEAVY = new Set(['log_v8', 'exp_v8', 'pow_v8', 'log1p_v8', 'expm1_v8', 'tanh_v8', 'atan_v8', 'log10_v8', 'sin_v8', 'cos_v8', 'tan_v8', 'asin_v8', 'acos_v8', 'sinh_v8', 'cosh_v8', 'asinh_v8', 'acosh_v8', 'atanh_v8', 'cbrt_v8', 'log2_v8', 'atan2_v8', 'hypot', 'ld_norm', 'ld_beta', 'ld_pois', 'ld_bern', 'ld_gamma', 'ld_invgamma', 'ld_lnorm', 'ld_t',
   'ld_weibull', 'ld_logis', 'ld_binom', 'ld_nbinom', 'ld_hyper', 'ld_cauchy', 'ld_pareto', 'ld_exp', 'ld_laplace', 'ld_unif', 'lgamma_js', 'lfactorial_js', 'lchoose_js', 'lbeta_js']);
@@ -842,7 +842,9 @@ Translator.prototype.index = function (objV, idxV) {
   return num('S(' + sum + ')', false);
 };
 
-const ARITH = { '+': (a, b) => a + b, '-': (a, b) => a - b, '*': (a, b) => a * b, '/': (a, b) => a / b, '%': (a, b) => a % b };
+const ARITH = { '+': (a, b) => a + b, '-': (a, b) => a - b, '*': (a, b) => a * b, '/': (a, b) => a / b, '%': (a, b) => a % b,
+  '|': (a, b) => a | b, '&': (a, b) => a & b, '^': (a, b) => a ^ b, '<<': (a, b) => a << b, '>>': (a, b) => a >> b, '>>>': (a, b) => a >>> b };
+const BITOPS = { '|': 'js_bitor', '&': 'js_bitand', '^': 'js_bitxor', '<<': 'js_shl', '>>': 'js_shr', '>>>': 'js_ushr' };
 const CMP = { '<': (a, b) => a < b, '<=': (a, b) => a <= b, '>': (a, b) => a > b, '>=': (a, b) => a >= b, '===': (a, b) => a === b, '==': (a, b) => a === b, '!==': (a, b) => a !== b, '!=': (a, b) => a !== b };
 
 Translator.prototype.expr = function (e) {
@@ -868,6 +870,7 @@ Translator.prototype.expr = function (e) {
       if (e.op === '!') { if (a.cst !== undefined) return { t: 'bool', code: a.cst ? 'false' : 'true', cst: !a.cst }; return { t: 'bool', code: '!(' + this.asB(a) + ')' }; }
       if (a.t !== 'num') this.fail("unary '" + e.op + "' on a " + this.describe(a));
       if (e.op === '+') return a;
+      if (e.op === '~') return a.cst !== undefined ? cnum(~a.cst) : num('js_bitnot(' + this.asD(a) + ')', false);
       if (a.cst !== undefined) return cnum(-a.cst);
       return a.int ? num('(-(' + a.code + '))', true, undefined, '(-(' + a.dcode + '))') : num('(-(' + a.code + '))', false);
     }
@@ -888,6 +891,7 @@ Translator.prototype.expr = function (e) {
       }
       if (l.cst !== undefined && r.cst !== undefined) return cnum(ARITH[e.op](l.cst, r.cst));   // folded by V8 itself
       if (e.op === '/') return num('(' + this.asD(l) + ' / ' + this.asD(r) + ')', false);
+      if (BITOPS[e.op]) return num(BITOPS[e.op] + '(' + this.asD(l) + ', ' + this.asD(r) + ')', false);     // ToInt32 of both operands, as in JS
       if (e.op === '%') {
         if (l.int && r.int && r.cst !== undefined && r.cst !== 0) return num('(' + l.code + ' % ' + r.code + ')', true, undefined, 'js_mod(' + this.asD(l) + ', ' + this.asD(r) + ')');
         return num('js_mod(' + this.asD(l) + ', ' + this.asD(r) + ')', false);
@@ -970,6 +974,11 @@ Translator.prototype.callInner = function (e) {
       let code = this.asD(args[0]);
       for (let k = 1; k < args.length; k++) code = 'js_' + f.name + '(' + code + ', ' + this.asD(args[k]) + ')';
       return num(code, false);
+    }
+    if (f.name === 'imul') {
+      if (args.length !== 2) this.fail('Math.imul takes two arguments');
+      if (allConst()) return cnum(Math.imul(args[0].cst, args[1].cst));
+      return num('js_imul(' + this.asD(args[0]) + ', ' + this.asD(args[1]) + ')', false);
     }
     if (f.name === 'atan2') {
       if (args.length !== 2) this.fail('Math.atan2 takes two arguments');
