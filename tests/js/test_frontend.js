@@ -118,7 +118,7 @@ assert.strictEqual(models.normal()({ mu: 180, sigma: 5 }, data10), readme_normal
 // ---- errors (thrown as strings, like the reference) before any device is touched
 const params = { mu: { type: 'real' }, sigma: { type: 'real', lower: 0 } };
 // a closure outside the translatable subset is refused with a string that says why (no CPU fallback)
-assert.throws(() => new mcmc.AmwgSampler(params, (s, d) => Math.fround(s.mu), data10), (e) => typeof e === 'string' && /cannot translate log_post: Math\.fround is not supported/.test(e));
+assert.throws(() => new mcmc.AmwgSampler(params, (s, d) => Math.random() * s.mu, data10), (e) => typeof e === 'string' && /cannot translate log_post: Math\.random is not supported/.test(e));
 assert.throws(() => new mcmc.AmwgSampler(params, function (s, d) { return helper(s.mu); }, data10), (e) => typeof e === 'string' && /'helper' is not defined inside log_post/.test(e));
 assert.throws(() => new mcmc.AmwgSampler(params, function (s, d) { s.mu = 1; return 0; }, data10), (e) => typeof e === 'string' && /assigns to the parameter state\.mu/.test(e));
 assert.throws(() => new mcmc.AmwgSampler(params, function (s, d) { return s.tau; }, data10), (e) => typeof e === 'string' && /state\.tau is read but it is neither a parameter nor a derived quantity/.test(e));
