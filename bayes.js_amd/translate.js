@@ -15,7 +15,8 @@
  *     post-ES5 spellings, rewritten into the above while parsing: destructuring in parameters and declarations
  *     (`({mu, sigma}, {x}) => ...`, `const [a, , b] = state.theta`), `for (const x of arr)`, `arr.forEach(cb)` as a statement
  *     (`return` inside the callback = continue), `arr.reduce(cb, init)` anywhere in the expressions of a statement
- *     (callback parameters and locals are renamed apart; the reduce becomes its own sequential accumulator, as in JS).
+ *     (callback parameters and locals are renamed apart; the reduce becomes its own sequential accumulator, as in JS),
+ *     `arr.map(cb)`, `Array(n)`, `new Array(n)`, `Array(n).fill(v)` as local arrays of a length known when the sampler is built (<= 2048).
  * Anything else throws a string that says what is not supported (no CPU fallback).  Array reads are not bounds-checked
  * (JavaScript yields undefined -> NaN for an out-of-range index; here only run-time indices into local arrays are checked).
  *
@@ -286,7 +287,11 @@ Parser.prototype = {
   unary() {
     for (const op of ['-', '+', '!', '~']) if (this.peek(op)) { this.i++; return { k: 'Unary', op, arg: this.unary() }; }
     for (const op of ['++', '--']) if (this.peek(op)) { this.i++; return { k: 'Update', op, prefix: true, target: this.unary() }; }
-    if (this.peek('typeof') || this.peek('new')) throw "'" + this.tk[this.i].v + "' is not supported inside log_post";
+    if (this.peek('typeof')) throw "'typeof' is not supported inside log_post";
+    if (this.peek('new')) {           // only `new Array(n)`: a local array of n numbers (see NewArray)
+      this.i++;
+      if (!(this.tk[this.i].t === 'id' && this.tk[this.i].v === 'Array')) throw "'new' is only supported as new Array(n) inside log_post";
+    }
     const base = this.postfix();
     if (this.eat('**')) return { k: 'Call', callee: { k: 'Member', obj: { k: 'Id', name: 'Math' }, prop: 'pow' }, args: [base, this.unary()] };   // right-associative
     return base;
@@ -417,6 +422,7 @@ function inlineCallback(fn, argNames, P, onReturn, what) {
   return fix(body.body, 0);
 }
 function isMethodCall(e, name) { return e && e.k === 'Call' && e.callee.k === 'Member' && e.callee.prop === name && isPath(e.callee.obj); }
+function isMapCall(e) { return e && e.k === 'Call' && e.callee.k === 'Member' && e.callee.prop === 'map' && e.args.length === 1 && e.args[0].k === 'Func'; }
 
 // arr.forEach(cb) as a statement, and arr.reduce(cb, init) anywhere in the expressions of a statement
 function desugarBlock(block, P) {
@@ -431,6 +437,11 @@ function desugarStatement(st, P, out) {
   if (st.k === 'For') {
     for (const part of [st.init, st.test, st.update]) walk(part, (x) => { if (isMethodCall(x, 'reduce') || isMethodCall(x, 'forEach')) throw 'reduce()/forEach() inside the header of a loop is not supported'; });
     out.push(Object.assign({}, st, { body: sub(st.body) }));
+    return;
+  }
+  if (st.k === 'ExprStmt' && st.expr.k === 'Call' && st.expr.callee.k === 'Member' && st.expr.callee.prop === 'forEach' && isMapCall(st.expr.callee.obj)) {
+    const id = hoistReduce(st.expr.callee.obj, P, out);
+    desugarStatement({ k: 'ExprStmt', expr: { k: 'Call', callee: { k: 'Member', obj: id, prop: 'forEach' }, args: st.expr.args } }, P, out);
     return;
   }
   if (st.k === 'ExprStmt' && isMethodCall(st.expr, 'forEach')) {
@@ -458,11 +469,38 @@ function hoistReduce(e, P, out) {
   if (!e || typeof e !== 'object') return e;
   if (Array.isArray(e)) return e.map((x) => hoistReduce(x, P, out));
   if (e.k === 'Func') return e;
+  // x.map(f).reduce(g, init) / x.map(f).map(g): materialise the inner map first, then treat the outer call on its name
+  if (e.k === 'Call' && e.callee.k === 'Member' && (e.callee.prop === 'reduce' || e.callee.prop === 'map') && isMapCall(e.callee.obj))
+    return hoistReduce({ k: 'Call', callee: { k: 'Member', obj: hoistReduce(e.callee.obj, P, out), prop: e.callee.prop }, args: e.args }, P, out);
   if (e.k === 'Logical' || e.k === 'Cond') {      // conditionally evaluated operands: a hoisted loop would run unconditionally (harmless, pure) -- keep it simple, refuse
     let found = false;
-    walk(e, (x) => { if (isMethodCall(x, 'reduce')) found = true; });
-    if (found) throw 'reduce() inside a conditional expression is not supported; assign it to a variable first';
+    walk(e, (x) => { if (isMethodCall(x, 'reduce') || isMapCall(x)) found = true; });
+    if (found) throw 'reduce()/map() inside a conditional expression is not supported; assign it to a variable first';
     return e;
+  }
+  // Array(n), new Array(n), Array(n).fill(v): a local array of n numbers (n a translation-time constant)
+  if (e.k === 'Call' && e.callee.k === 'Id' && e.callee.name === 'Array' && e.args.length === 1) return { k: 'NewArray', len: hoistReduce(e.args[0], P, out), fill: null };
+  if (e.k === 'Call' && e.callee.k === 'Member' && e.callee.prop === 'fill' && e.args.length === 1) {
+    const base = hoistReduce(e.callee.obj, P, out);
+    if (base.k === 'NewArray') return { k: 'NewArray', len: base.len, fill: hoistReduce(e.args[0], P, out) };
+    throw 'fill() is only supported directly on Array(n)';
+  }
+  // arr.map(cb): a new local array filled by a loop (the callback inlined; parameters and locals renamed apart)
+  if (e.k === 'Call' && e.callee.k === 'Member' && e.callee.prop === 'map' && e.args.length === 1 && e.args[0].k === 'Func') {
+    let arr = hoistReduce(e.callee.obj, P, out);
+    if (!isPath(arr)) throw 'map() needs a name or a property/element of one to iterate over';
+    const k = P.fresh('k'), x = P.fresh('x'), z = P.fresh('map');
+    const body = inlineCallback(e.args[0], [x, k], P, (arg, depth) => {
+      if (!arg) throw 'the map callback must return a value';
+      if (depth > 0) throw 'a return inside a loop inside a map callback is not supported';
+      return [{ k: 'ExprStmt', expr: { k: 'Assign', op: '=', target: { k: 'Index', obj: { k: 'Id', name: z }, idx: { k: 'Id', name: k } }, value: arg } }, { k: 'Continue' }];
+    }, 'map');
+    if (body.length && body[body.length - 1].k === 'Continue') body.pop();
+    const inner = [];
+    desugarStatement({ k: 'Block', body }, P, inner);
+    out.push({ k: 'VarDecl', kind: 'var', decls: [{ name: z, init: { k: 'NewArray', len: { k: 'Member', obj: arr, prop: 'length' }, fill: { k: 'Num', v: 0 } } }] });
+    out.push(countedLoop(k, arr, [{ k: 'VarDecl', kind: 'var', decls: [{ name: x, init: { k: 'Index', obj: arr, idx: { k: 'Id', name: k } } }] }].concat(inner[0].body)));
+    return { k: 'Id', name: z };
   }
   if (isMethodCall(e, 'reduce')) {
     if (e.args.length !== 2) throw 'reduce needs an initial value here: arr.reduce(function (acc, x) {...}, init)';
@@ -865,6 +903,15 @@ Translator.prototype.expr = function (e) {
       if (vs.length > 64) this.fail('array literal with more than 64 elements');
       return { t: 'localArr', elems: vs.map((v) => num(this.asD(v), false)) };
     }
+    case 'NewArray': {
+      const n = this.expr(e.len);
+      if (n.t !== 'num' || n.cst === undefined || !Number.isInteger(n.cst) || n.cst < 1 || n.cst > 2048)
+        this.fail('the length of a local array (Array(n), map()) must be a constant between 1 and 2048 known when the sampler is built' + (n.cst > 2048 ? ' (got ' + n.cst + ': every lane would carry its own copy; write the loop with a scalar temporary instead)' : ''));
+      const fill = e.fill ? this.expr(e.fill) : cnum(NaN);          // holes read as undefined -> NaN in arithmetic
+      if (fill.t !== 'num' && fill.t !== 'bool') this.fail('Array(n).fill(v) needs a number');
+      const one = num(this.asD(fill), false);
+      return { t: 'localArr', elems: Array.from({ length: n.cst }, () => one), fillOnly: true };
+    }
     case 'Unary': {
       const a = this.expr(e.arg);
       if (e.op === '!') { if (a.cst !== undefined) return { t: 'bool', code: a.cst ? 'false' : 'true', cst: !a.cst }; return { t: 'bool', code: '!(' + this.asB(a) + ')' }; }
@@ -1213,6 +1260,10 @@ Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) 
       return;
     }
     const v = this.expr(valueAst);
+    if (v.t === 'localArr' && op === '=' && v.name && !this.loops.length && !this.condDepth && !Object.prototype.hasOwnProperty.call(this.localTypes, name)) {
+      this.aliases[name] = v;        // `var z = otherArray`: arrays are references in JavaScript, both names mean the same storage
+      return;
+    }
     if (v.t === 'localArr' && op === '=') {
       // a variable holding an array of numbers: C array declared at the top, filled here (elements may be reassigned later)
       if (Object.prototype.hasOwnProperty.call(this.localTypes, name)) this.fail(name + ' holds a number elsewhere and an array here');
@@ -1221,7 +1272,8 @@ Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) 
       const cname = 'va_' + name;
       this.localArrays[cname] = v.elems.length;
       this.flush(out, indent);
-      v.elems.forEach((el, i) => out.push(indent + cname + '[' + i + '] = ' + el.code + ';'));
+      if (v.fillOnly && v.elems.length > 8) { const f = this.temp(v.elems[0].code); out.push(indent + 'for (int fi_ = 0; fi_ < ' + v.elems.length + '; ++fi_) ' + cname + '[fi_] = ' + f + ';'); }
+      else v.elems.forEach((el, i) => out.push(indent + cname + '[' + i + '] = ' + el.code + ';'));
       this.aliases[name] = { t: 'localArr', elems: v.elems, name: cname };
       return;
     }

@@ -86,12 +86,17 @@ function generator(rnd) {
     const r = rnd(), ctxX = { i: null };
     const e = (ctx) => num(2, ctx || {}), c = (ctx) => '(' + cond(2, ctx || {}) + ')';
     const withT = (str, v) => str.replace(/(^|[^.\w])t\b/g, '$1' + v);
-    if (r < 0.2) return 'for (const xv' + k + ' of d.x) { lp += (xv' + k + ' * ' + withT(e(), 'xv' + k) + ') * 1e-3; }';
-    if (r < 0.4) return 'd.x.forEach(function (xe, ie) { if ' + withT(c({ i: 'ie' }), 'xe') + ' return; lp += (xe + ' + withT(e({ i: 'ie' }), 'xe') + ') * 1e-3; });';
-    if (r < 0.6) return 'lp += d.x.reduce((ac, xe, ie) => ac + ' + withT(e({ i: 'ie' }), 'xe') + ' * 1e-3, ' + withT(e(), 's.a') + ') * 1e-2;';
-    if (r < 0.75) return 'const { a: pa' + k + ', v: [pv' + k + ', , pw' + k + '] } = s;\n  lp += (pa' + k + ' * pv' + k + ' - pw' + k + ') * 1e-3;';
-    if (r < 0.9) return 'const hf' + k + ' = (p, q) => p * ' + lit() + ' + Math.abs(q);\n  for (const nv' + k + ' of d.n) lp += hf' + k + '(nv' + k + ', ' + withT(e(), 's.b') + ') * 1e-3;';
-    return 's.r' + k + ' = s.v.reduce(function (ac, ve) { var sq = ve * ve; return ac + sq; }, 0) + d.m[1].reduce((ac, me) => Math.max(ac, me), -Infinity);';
+    if (r < 0.15) return 'for (const xv' + k + ' of d.x) { lp += (xv' + k + ' * ' + withT(e(), 'xv' + k) + ') * 1e-3; }';
+    if (r < 0.3) return 'd.x.forEach(function (xe, ie) { if ' + withT(c({ i: 'ie' }), 'xe') + ' return; lp += (xe + ' + withT(e({ i: 'ie' }), 'xe') + ') * 1e-3; });';
+    if (r < 0.45) return 'lp += d.x.reduce((ac, xe, ie) => ac + ' + withT(e({ i: 'ie' }), 'xe') + ' * 1e-3, ' + withT(e(), 's.a') + ') * 1e-2;';
+    if (r < 0.55) return 'const { a: pa' + k + ', v: [pv' + k + ', , pw' + k + '] } = s;\n  lp += (pa' + k + ' * pv' + k + ' - pw' + k + ') * 1e-3;';
+    if (r < 0.65) return 'const hf' + k + ' = (p, q) => p * ' + lit() + ' + Math.abs(q);\n  for (const nv' + k + ' of d.n) lp += hf' + k + '(nv' + k + ', ' + withT(e(), 's.b') + ') * 1e-3;';
+    if (r < 0.72) return 's.r' + k + ' = s.v.reduce(function (ac, ve) { var sq = ve * ve; return ac + sq; }, 0) + d.m[1].reduce((ac, me) => Math.max(ac, me), -Infinity);';
+    return pick([
+      'var mz' + k + ' = d.x.map(function (xe, ie) { return ' + withT(e({ i: 'ie' }), 'xe') + '; });\n  for (var i = 0; i < mz' + k + '.length; i++) { lp += mz' + k + '[i] * 1e-3; }\n  s.r' + k + ' = mz' + k + '[' + Math.floor(rnd() * 8) + '];',
+      'lp += d.n.map((ne) => ne * ' + e() + ').reduce((ac, q) => ac + q, 0) * 1e-3;',
+      'var cn' + k + ' = new Array(3).fill(' + lit() + '); for (var i = 0; i < 8; i++) { cn' + k + '[d.n[i] % 3] += d.x[i]; }\n  s.r' + k + ' = cn' + k + '[0] - cn' + k + '[1] * cn' + k + '[2];',
+      's.v.map((ve) => ve * ' + e() + ').forEach((q, j) => { lp += q * (j + 1) * 1e-3; });']);
   }
   return { num, cond, block, lpBlock, sugarBlock };
 }

@@ -413,7 +413,7 @@ CASES.many_named = {
 };
 
 // ---- the same kind of model written in post-ES5 JavaScript: destructured parameters and declarations, for-of, forEach with an
-// early return, reduce (twice, one over a parameter array with the index argument), an arrow helper, const/let
+// early return, reduce (one over a parameter array with the index argument), map, new Array(n).fill(v), an arrow helper, const/let
 CASES.modern_js = {
   params: () => ({ mu: {}, sigma: { lower: 0, init: 1.5 }, rate: { dim: [3], lower: 0, init: 2 }, flip: { type: 'binary' } }),
   data: (seed) => { const r = lcg(seed), x = [], counts = [], w = []; for (let i = 0; i < 30; i++) { x.push(2 + 3 * (r() - 0.5)); w.push(i % 4 === 0 ? 0 : 1 + (i % 3)); } for (let j = 0; j < 3; j++) counts.push(Math.floor(r() * 9)); return { x, counts, w }; },
@@ -430,6 +430,11 @@ CASES.modern_js = {
       lp += w[i] * (ld.norm(xi, mu, spread) - 1e-3 * sq(z));
     });
     const total = x.reduce(function (a, xi) { return a + xi; }, 0);
+    // map / new Array(n).fill(v): local arrays whose length is known when the sampler is built
+    const centred = x.map((xi) => xi - mu);
+    const tally = new Array(3).fill(0);
+    centred.forEach((c, i) => { tally[i % 3] += c * c; });
+    lp -= 1e-4 * tally.reduce((a, t) => a + t, 0) + 1e-5 * rate.map((r) => r * r).reduce((a, q) => Math.max(a, q), 0);
     return lp + ld.norm(total / x.length, mu, 1);
   },
   schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
