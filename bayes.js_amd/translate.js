@@ -11,7 +11,9 @@
  *     min,max,sin,cos,tan,asin,acos,atan,atan2,sinh,cosh,tanh,asinh,acosh,atanh,imul,clz32,fround,PI,E,...}, isNaN, isFinite, every ld.* of distributions.js (array-valued ones unrolled),
  *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, local
  *     aliases of those (var p = par.p[0]), derived quantities (state.key = expr, mcmc.js:961-963),
- *     helper functions and constants passed in options.helpers / options.constants (or globals);
+ *     helper functions and constants passed in options.helpers / options.constants (or globals); helpers that take numbers become
+ *     device functions, helpers that are handed the state, the data or arrays of them (`log_prior(state) + log_lik(state, data)`) are
+ *     inlined (they need a single return at their end);
  *     post-ES5 spellings, rewritten into the above while parsing: destructuring in parameters and declarations
  *     (`({mu, sigma}, {x}) => ...`, `const [a, , b] = state.theta`), `for (const x of arr)`, `arr.forEach(cb)` as a statement
  *     (`return` inside the callback = continue), `arr.reduce(cb, init)` anywhere in the expressions of a statement
@@ -381,7 +383,11 @@ function countedLoop(k, arr, body) {
 function cloneRenamed(node, map) {      // deep copy with the names in `map` replaced (a nested function that re-declares one shadows it)
   if (!node || typeof node !== 'object') return node;
   if (Array.isArray(node)) return node.map((x) => cloneRenamed(x, map));
-  if (node.k === 'Id') return { k: 'Id', name: Object.prototype.hasOwnProperty.call(map, node.name) ? map[node.name] : node.name };
+  if (node.k === 'Id') {
+    if (!Object.prototype.hasOwnProperty.call(map, node.name)) return { k: 'Id', name: node.name };
+    const to = map[node.name];
+    return typeof to === 'string' ? { k: 'Id', name: to } : cloneRenamed(to, {});      // a path substituted for a parameter
+  }
   if (node.k === 'Func') {
     const inner = Object.assign({}, map);
     for (const q of node.params) delete inner[q];
@@ -389,7 +395,7 @@ function cloneRenamed(node, map) {      // deep copy with the names in `map` rep
   }
   const out = {};
   for (const key of Object.keys(node)) {
-    if (key === 'decls') out.decls = node.decls.map((d) => ({ name: Object.prototype.hasOwnProperty.call(map, d.name) ? map[d.name] : d.name, init: cloneRenamed(d.init, map) }));
+    if (key === 'decls') out.decls = node.decls.map((d) => ({ name: (Object.prototype.hasOwnProperty.call(map, d.name) && typeof map[d.name] === 'string') ? map[d.name] : d.name, init: cloneRenamed(d.init, map) }));
     else out[key] = cloneRenamed(node[key], map);
   }
   return out;
@@ -477,6 +483,35 @@ function hoistReduce(e, P, out) {
     walk(e, (x) => { if (isMethodCall(x, 'reduce') || isMapCall(x)) found = true; });
     if (found) throw 'reduce()/map() inside a conditional expression is not supported; assign it to a variable first';
     return e;
+  }
+  // f(state), f(state, data), f(state.theta, data.x): a function that is handed objects cannot become a scalar device function; its body
+  // is inlined here (parameters bound to the argument paths, numbers to temporaries, locals renamed apart).  P.env is set by the translator.
+  if (P.env && e.k === 'Call' && e.callee.k === 'Id' && e.args.some((a) => P.env.isObject(a))) {
+    const fn = P.env.funcOf(e.callee.name);
+    if (fn) {
+      if ((P.inlineDepth || 0) > 8) throw e.callee.name + '() is inlined more than 8 levels deep (recursion is not supported)';
+      if (fn.params.length < e.args.length) throw e.callee.name + '() takes ' + fn.params.length + ' argument(s)';
+      const map = {}, tag = P.fresh('fn') + '_', pre = [];
+      const written = assignedNames(fn.body);
+      fn.params.forEach((q, i) => {
+        if (i >= e.args.length) { map[q] = tag + q; pre.push({ k: 'VarDecl', kind: 'var', decls: [{ name: tag + q, init: { k: 'Id', name: 'NaN' } }] }); return; }     // missing argument: undefined
+        const arg = hoistReduce(e.args[i], P, out);
+        if (P.env.isObject(arg)) { if (written.has(q)) throw e.callee.name + '() assigns to its parameter ' + q + ', which is bound to an object here'; map[q] = arg; }
+        else { map[q] = tag + q; pre.push({ k: 'VarDecl', kind: 'var', decls: [{ name: tag + q, init: arg }] }); }
+      });
+      for (const nm of declaredIn(fn.body, new Set())) if (!Object.prototype.hasOwnProperty.call(map, nm)) map[nm] = tag + nm;
+      const stmts = cloneRenamed(fn.body, map).body;
+      const lastSt = stmts[stmts.length - 1];
+      let returns = 0;
+      (function count(n) { if (!n || typeof n !== 'object') return; if (Array.isArray(n)) { n.forEach(count); return; } if (n.k === 'Func') return; if (n.k === 'Return') returns++; for (const key of Object.keys(n)) if (key !== 'k') count(n[key]); })(stmts);
+      if (!lastSt || lastSt.k !== 'Return' || !lastSt.arg || returns !== 1)
+        throw e.callee.name + '() is handed an object (the state, the data, or an array of them) and has to be inlined, which needs a single return at its end';
+      P.inlineDepth = (P.inlineDepth || 0) + 1;
+      for (const st of pre.concat(stmts.slice(0, -1))) desugarStatement(st, P, out);
+      const result = hoistReduce(lastSt.arg, P, out);
+      P.inlineDepth--;
+      return result;
+    }
   }
   // Array(n), new Array(n), Array(n).fill(v): a local array of n numbers (n a translation-time constant)
   if (e.k === 'Call' && e.callee.k === 'Id' && e.callee.name === 'Array' && e.args.length === 1) return { k: 'NewArray', len: hoistReduce(e.args[0], P, out), fill: null };
@@ -680,6 +715,56 @@ Translator.prototype.freeValue = function (name) {
 Translator.prototype.isStateName = function (name) {
   if (this.stateName !== null && this.stateName !== undefined) return name === this.stateName;
   return !!this.opts.state_object && this.freeValue(name) === this.opts.state_object;
+};
+
+// 'number' | 'object' | null for a path rooted at the state or the data, from the parameter layout and the data itself (no code is emitted)
+Translator.prototype.staticKind = function (e) {
+  const chain = [];
+  let root = e;
+  while (root && (root.k === 'Member' || root.k === 'Index')) { chain.unshift(root); root = root.obj; }
+  if (!root || root.k !== 'Id') return null;
+  if (this.isStateName(root.name)) {
+    if (!chain.length) return 'object';
+    const first = chain[0];
+    if (first.k !== 'Member' || !Object.prototype.hasOwnProperty.call(this.layout, first.prop)) return null;
+    const L = this.layout[first.prop], depth = chain.length - 1;
+    if (L.scalar) return depth === 0 ? 'number' : null;
+    return depth >= L.dim.length ? 'number' : 'object';
+  }
+  if (this.dataName && root.name === this.dataName) {
+    let v = this.data;
+    for (const step of chain) {
+      if (v === null || v === undefined) return null;
+      if (step.k === 'Member') { if (step.prop === 'length') return 'number'; v = v[step.prop]; }
+      else v = (Array.isArray(v) || ArrayBuffer.isView(v)) ? v[0] : undefined;
+    }
+    if (typeof v === 'number' || typeof v === 'boolean') return 'number';
+    return (v && typeof v === 'object') ? 'object' : null;
+  }
+  return null;
+};
+
+// functions of the surrounding program that are handed the state / the data (`return log_prior(s) + log_lik(s, d)`) are inlined
+Translator.prototype.inlineObjectCalls = function () {
+  const own = declaredIn(this.ast.body, new Set(this.ast.params));
+  const cache = {};
+  const P = { uniq: 1000, fresh(stem) { this.uniq++; return '__' + stem + this.uniq; } };
+  P.env = {
+    isObject: (a) => this.staticKind(a) === 'object',
+    funcOf: (name) => {
+      if (own.has(name)) return null;
+      if (!Object.prototype.hasOwnProperty.call(cache, name)) {
+        const f = this.freeValue(name);
+        cache[name] = typeof f === 'function' ? parseFunctionSource(Function.prototype.toString.call(f)) : null;
+      }
+      return cache[name];
+    },
+  };
+  let needed = false;
+  walk(this.ast.body, (x) => { if (x.k === 'Call' && x.callee.k === 'Id' && x.args.some((a) => P.env.isObject(a)) && P.env.funcOf(x.callee.name)) needed = true; });
+  if (!needed) return;
+  try { this.ast = { params: this.ast.params, body: desugarBlock(this.ast.body, P) }; }
+  catch (e) { if (typeof e === 'string' && e.indexOf('AmwgSampler') !== 0) this.fail(e); throw e; }
 };
 
 // `function () { return f(state); }` (and chains of such): continue with f, its parameter bound to the state
@@ -1698,6 +1783,7 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
 };
 
 Translator.prototype.run = function () {
+  this.inlineObjectCalls();
   let body = this.functionBody([], true);
   // drop data arrays the generated code never reads (constants folded away), renumber the rest
   {

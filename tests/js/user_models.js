@@ -546,6 +546,27 @@ CASES.circular_wrapped_cauchy = {
   schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
 };
 
+// ---- a log posterior split into functions that are handed the state and the data (a common way to structure one): such helpers cannot
+// become scalar device functions, the translator inlines them -- nested (log_lik calls sumsq with a parameter array), with a derived
+// quantity assigned inside one, a number argument next to the objects, and a call inside a loop body
+CASES.structured_helpers = {
+  params: () => ({ mu: {}, sigma: { lower: 0, init: 1 }, th: { dim: [3], init: 0.2 } }),
+  data: (seed) => { const r = lcg(seed), x = [], g = []; for (let i = 0; i < 27; i++) { g.push(i % 3); x.push(1 + (i % 3) * 0.4 + 1.5 * (r() - 0.5)); } return { x, g, scale: 1.5 }; },
+  helpers: {
+    log_prior: function (s) { var lp = ld.norm(s.mu, 0, 10) + ld.unif(s.sigma, 0, 10); for (var j = 0; j < s.th.length; j++) lp += ld.norm(s.th[j], 0, 1); return lp; },
+    sumsq: function (v, w) { var t = 0; for (var i = 0; i < v.length; i++) { t += v[i] * v[i] * w; } return t; },
+    group_mean: function (s, k) { return s.mu + s.th[k]; },
+    log_lik: function (s, d) {
+      var lp = 0;
+      for (var i = 0; i < d.x.length; i++) lp += ld.norm(d.x[i], group_mean(s, d.g[i]), s.sigma * d.scale);
+      s.ss = sumsq(s.th, 0.5);
+      return lp - 1e-3 * sumsq(d.x, s.sigma);
+    },
+  },
+  log_post: function (s, d) { return log_prior(s) + log_lik(s, d); },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+
 function build(name, seed) {
   const c = CASES[name] || BENCH[name];
   if (!c) throw new Error('unknown user model ' + name);
