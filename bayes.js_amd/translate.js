@@ -9,7 +9,7 @@
  *     var/let/const, assignments (= += -= *= /= %=, ++ --), for / while / if / else / break / continue / return, blocks
  *     numbers, + - * / % **, | & ^ ~ << >> >>> (ToInt32 semantics), comparisons, && || !, ?:, Math.{log,exp,log1p,expm1,log10,log2,pow,sqrt,cbrt,hypot,abs,floor,ceil,round,trunc,sign,
  *     min,max,sin,cos,tan,asin,acos,atan,atan2,sinh,cosh,tanh,asinh,acosh,atanh,imul,clz32,fround,PI,E,...}, isNaN, isFinite, every ld.* of distributions.js (array-valued ones unrolled),
- *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, local
+ *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, arrays of records (data[i].x, var row = data[i]), local
  *     aliases of those (var p = par.p[0]), derived quantities (state.key = expr, mcmc.js:961-963),
  *     helper functions and constants passed in options.helpers / options.constants (or globals); helpers that take numbers become
  *     device functions, helpers that are handed the state, the data or arrays of them (`log_prior(state) + log_lik(state, data)`) are
@@ -857,7 +857,7 @@ Translator.prototype.asB = function (v) {
   this.fail('a ' + this.describe(v) + ' is used as a condition');
 };
 Translator.prototype.describe = function (v) {
-  return { localArr: 'local array', stateObj: 'state object', stateArr: 'parameter array', dataObj: 'data object', dataArr: 'data array', ns: 'namespace', fn: 'function', bool: 'boolean', num: 'number' }[v.t] || v.t;
+  return { localArr: 'local array', recArr: 'array of records', rec: 'record', stateObj: 'state object', stateArr: 'parameter array', dataObj: 'data object', dataArr: 'data array', ns: 'namespace', fn: 'function', bool: 'boolean', num: 'number' }[v.t] || v.t;
 };
 
 // ---- expressions -----------------------------------------------------------------------------------
@@ -894,6 +894,8 @@ Translator.prototype.lookup = function (name) {
 Translator.prototype.dataValue = function (path, v) {
   if (typeof v === 'number') return cnum(v);
   if (typeof v === 'boolean') return cnum(v ? 1 : 0);
+  // an array of records ([{x: 1.2, y: 0}, ...], rows of a table): element i's field f is element i of the column f (built on demand)
+  if (Array.isArray(v) && v.length > 0 && v.every((e) => e && typeof e === 'object' && !Array.isArray(e) && !ArrayBuffer.isView(e))) return { t: 'recArr', path, value: v };
   if (Array.isArray(v) || ArrayBuffer.isView(v)) {
     const id = this.registerArray(path, v);
     return { t: 'dataArr', id, off: '0', dims: this.arrays[id].dims.slice() };
@@ -917,6 +919,15 @@ Translator.prototype.member = function (objV, prop) {
     return this.dataValue(objV.path + '.' + prop, objV.value[prop]);
   }
   if (objV.t === 'localArr') { if (prop === 'length') return cnum(objV.elems.length); this.fail("property '" + prop + "' of an array is not supported"); }
+  if (objV.t === 'recArr') { if (prop === 'length') return cnum(objV.value.length); this.fail("property '" + prop + "' of an array of records is not supported"); }
+  if (objV.t === 'rec') {
+    const rows = objV.arr.value, path = objV.arr.path + '[].' + prop;
+    const col = rows.map((r, i) => { if (!Object.prototype.hasOwnProperty.call(r, prop)) this.fail('data' + objV.arr.path + '[' + i + '].' + prop + ' does not exist'); return r[prop]; });
+    if (col.every((c) => c && typeof c === 'object' && !Array.isArray(c) && !ArrayBuffer.isView(c))) return { t: 'rec', arr: { t: 'recArr', path, value: col }, idx: objV.idx };   // nested records
+    const colV = this.dataValue(path, col);
+    if (colV.t !== 'dataArr') this.fail('data' + path + ' is not a column of numbers or of equally shaped arrays');
+    return this.index(colV, objV.idx);
+  }
   if (objV.t === 'dataArr' || objV.t === 'stateArr') {
     if (prop === 'length') return cnum(objV.dims[0]);
     this.fail("property '" + prop + "' of an array is not supported");
@@ -937,6 +948,11 @@ Translator.prototype.index = function (objV, idxV) {
     // run-time index into a small local array: out of range reads give NaN, as `undefined` does in arithmetic
     const nm = this.materialize(objV), ix = this.temp_int(this.asI(idxV));
     return num('((unsigned)' + ix + ' < ' + objV.elems.length + 'u ? ' + nm + '[' + ix + '] : __builtin_nan(""))', false);
+  }
+  if (objV.t === 'recArr') {
+    if (idxV.t !== 'num') this.fail('a ' + this.describe(idxV) + ' is used as an array index');
+    if (idxV.cst !== undefined && (!Number.isInteger(idxV.cst) || idxV.cst < 0 || idxV.cst >= objV.value.length)) this.fail('constant index ' + idxV.cst + ' is outside an array of length ' + objV.value.length);
+    return { t: 'rec', arr: objV, idx: idxV.cst !== undefined ? idxV : num(this.temp_int(this.asI(idxV)), true) };
   }
   if (objV.t !== 'dataArr' && objV.t !== 'stateArr') this.fail('indexing a ' + this.describe(objV));
   const dims = objV.dims, inner = dims.slice(1).reduce((a, b) => a * b, 1);
@@ -1344,7 +1360,7 @@ Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) 
       this.localFuncs[name] = valueAst;
       return;
     }
-    const v = this.expr(valueAst);
+    let v = this.expr(valueAst);
     if (v.t === 'localArr' && op === '=' && v.name && !this.loops.length && !this.condDepth && !Object.prototype.hasOwnProperty.call(this.localTypes, name)) {
       this.aliases[name] = v;        // `var z = otherArray`: arrays are references in JavaScript, both names mean the same storage
       return;
@@ -1364,7 +1380,15 @@ Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) 
     }
     if (v.t !== 'num' && v.t !== 'bool') {
       if (op !== '=') this.fail("'" + op + "' with a " + this.describe(v));
-      if (this.loops.length || this.condDepth) this.fail('aliasing an array or object (' + name + ') inside a loop or an if');
+      if (this.loops.length || this.condDepth) {
+        // `var row = data[i]` / `var xi = d.X[i]` inside a loop: fine when this is the name's only assignment (it then always means "element i
+        // as of here"; the index is frozen in a block-scoped temporary, so a use outside the loop does not compile instead of misreading)
+        if (!(this.assignCount[name] === 1 && (v.t === 'rec' || v.t === 'dataArr' || v.t === 'stateArr')))
+          this.fail('aliasing an array or object (' + name + ') inside a loop or an if is only supported for a row / record assigned once (var row = data[i])');
+        if (v.t === 'dataArr' && !/^\d+$/.test(v.off)) v = { t: 'dataArr', id: v.id, off: this.temp_int(v.off), dims: v.dims };
+        if (v.t === 'stateArr' && !/^\d+$/.test(v.base)) v = { t: 'stateArr', base: this.temp_int(v.base), dims: v.dims };
+        this.flush(out, indent);
+      }
       if (Object.prototype.hasOwnProperty.call(this.localTypes, name)) this.fail(name + ' holds a number elsewhere and an array/object here');
       this.aliases[name] = v;
       return;

@@ -567,6 +567,33 @@ CASES.structured_helpers = {
   schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
 };
 
+// ---- data as an array of records (rows of a table, as parsed from JSON / CSV): field access by row, a row alias inside the loop, a
+// nested record used as an index into a parameter matrix, records destructured by for-of, rows of a matrix and of a parameter by for-of,
+// reduce over the records
+CASES.records_logistic = {
+  params: () => ({ a: { init: 0 }, b: { init: 0 }, th: { dim: [3, 2], init: 0.1 } }),
+  data: (seed) => {
+    const r = lcg(seed), rows = [];
+    for (let i = 0; i < 33; i++) { const x = r() * 4 - 2; rows.push({ x, y: r() < 1 / (1 + Math.exp(-(0.4 + 0.9 * x))) ? 1 : 0, w: [0.5 + r(), 2], g: { k: i % 3 } }); }
+    return { rows, X: [[1, 2, 3], [4, 5, 6], [7, 8, 9]] };
+  },
+  log_post: function (s, d) {
+    var lp = ld.norm(s.a, 0, 5) + ld.norm(s.b, 0, 5);
+    for (var i = 0; i < d.rows.length; i++) {
+      var row = d.rows[i];
+      var eta = s.a + s.b * row.x * row.w[0] + s.th[row.g.k][1];
+      lp += row.y * eta - Math.log1p(Math.exp(eta));
+    }
+    for (const { x, y, w: [w0] } of d.rows) lp += 1e-2 * ld.norm(y, s.a + s.b * x, w0);
+    for (const r of d.X) lp += 1e-3 * ld.norm(r[0] + r[2], s.a, 3);
+    for (const t of s.th) lp += ld.norm(t[0], t[1], 2) + ld.norm(t[1], 0, 1);
+    lp += 1e-2 * d.rows.reduce((acc, r) => acc + ld.norm(r.x, s.a, 1 + r.y), 0);
+    s.first_eta = s.a + s.b * d.rows[0].x;
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+
 function build(name, seed) {
   const c = CASES[name] || BENCH[name];
   if (!c) throw new Error('unknown user model ' + name);
