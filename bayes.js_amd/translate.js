@@ -9,7 +9,7 @@
  *     var/let/const, assignments (= += -= *= /= %=, ++ --), for / while / if / else / break / continue / return, blocks
  *     numbers, + - * / % **, | & ^ ~ << >> >>> (ToInt32 semantics), comparisons, && || !, ?:, Math.{log,exp,log1p,expm1,log10,log2,pow,sqrt,cbrt,hypot,abs,floor,ceil,round,trunc,sign,
  *     min,max,sin,cos,tan,asin,acos,atan,atan2,sinh,cosh,tanh,asinh,acosh,atanh,imul,clz32,fround,PI,E,...}, isNaN, isFinite, every ld.* of distributions.js (array-valued ones unrolled),
- *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, arrays of records (data[i].x, var row = data[i]), local
+ *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, arrays of records (data[i].x, var row = data[i]), categorical strings in the data (only compared: row.group === 'control'), local
  *     aliases of those (var p = par.p[0]), derived quantities (state.key = expr, mcmc.js:961-963),
  *     helper functions and constants passed in options.helpers / options.constants (or globals); helpers that take numbers become
  *     device functions, helpers that are handed the state, the data or arrays of them (`log_prior(state) + log_lik(state, data)`) are
@@ -857,7 +857,7 @@ Translator.prototype.asB = function (v) {
   this.fail('a ' + this.describe(v) + ' is used as a condition');
 };
 Translator.prototype.describe = function (v) {
-  return { localArr: 'local array', recArr: 'array of records', rec: 'record', stateObj: 'state object', stateArr: 'parameter array', dataObj: 'data object', dataArr: 'data array', ns: 'namespace', fn: 'function', bool: 'boolean', num: 'number' }[v.t] || v.t;
+  return { localArr: 'local array', recArr: 'array of records', rec: 'record', strlit: 'string', strv: 'string', strArr: 'array of strings', stateObj: 'state object', stateArr: 'parameter array', dataObj: 'data object', dataArr: 'data array', ns: 'namespace', fn: 'function', bool: 'boolean', num: 'number' }[v.t] || v.t;
 };
 
 // ---- expressions -----------------------------------------------------------------------------------
@@ -894,6 +894,14 @@ Translator.prototype.lookup = function (name) {
 Translator.prototype.dataValue = function (path, v) {
   if (typeof v === 'number') return cnum(v);
   if (typeof v === 'boolean') return cnum(v ? 1 : 0);
+  if (typeof v === 'string') return { t: 'strlit', v };
+  // categorical data: an array of strings is stored as integer codes (order of first appearance); it can only be compared
+  if (Array.isArray(v) && v.length > 0 && v.every((e) => typeof e === 'string')) {
+    const table = [];
+    const codes = v.map((e) => { let k = table.indexOf(e); if (k < 0) { k = table.length; table.push(e); } return k; });
+    const id = this.registerArray(path + '#codes', codes);
+    return { t: 'strArr', id, table, n: v.length };
+  }
   // an array of records ([{x: 1.2, y: 0}, ...], rows of a table): element i's field f is element i of the column f (built on demand)
   if (Array.isArray(v) && v.length > 0 && v.every((e) => e && typeof e === 'object' && !Array.isArray(e) && !ArrayBuffer.isView(e))) return { t: 'recArr', path, value: v };
   if (Array.isArray(v) || ArrayBuffer.isView(v)) {
@@ -920,12 +928,13 @@ Translator.prototype.member = function (objV, prop) {
   }
   if (objV.t === 'localArr') { if (prop === 'length') return cnum(objV.elems.length); this.fail("property '" + prop + "' of an array is not supported"); }
   if (objV.t === 'recArr') { if (prop === 'length') return cnum(objV.value.length); this.fail("property '" + prop + "' of an array of records is not supported"); }
+  if (objV.t === 'strArr') { if (prop === 'length') return cnum(objV.n); this.fail("property '" + prop + "' of an array of strings is not supported"); }
   if (objV.t === 'rec') {
     const rows = objV.arr.value, path = objV.arr.path + '[].' + prop;
     const col = rows.map((r, i) => { if (!Object.prototype.hasOwnProperty.call(r, prop)) this.fail('data' + objV.arr.path + '[' + i + '].' + prop + ' does not exist'); return r[prop]; });
     if (col.every((c) => c && typeof c === 'object' && !Array.isArray(c) && !ArrayBuffer.isView(c))) return { t: 'rec', arr: { t: 'recArr', path, value: col }, idx: objV.idx };   // nested records
     const colV = this.dataValue(path, col);
-    if (colV.t !== 'dataArr') this.fail('data' + path + ' is not a column of numbers or of equally shaped arrays');
+    if (colV.t !== 'dataArr' && colV.t !== 'strArr') this.fail('data' + path + ' is not a column of numbers, of strings or of equally shaped arrays');
     return this.index(colV, objV.idx);
   }
   if (objV.t === 'dataArr' || objV.t === 'stateArr') {
@@ -948,6 +957,10 @@ Translator.prototype.index = function (objV, idxV) {
     // run-time index into a small local array: out of range reads give NaN, as `undefined` does in arithmetic
     const nm = this.materialize(objV), ix = this.temp_int(this.asI(idxV));
     return num('((unsigned)' + ix + ' < ' + objV.elems.length + 'u ? ' + nm + '[' + ix + '] : __builtin_nan(""))', false);
+  }
+  if (objV.t === 'strArr') {
+    const code = this.index({ t: 'dataArr', id: objV.id, off: '0', dims: [objV.n] }, idxV);
+    return code.cst !== undefined ? { t: 'strlit', v: objV.table[code.cst] } : { t: 'strv', code, table: objV.table, id: objV.id };
   }
   if (objV.t === 'recArr') {
     if (idxV.t !== 'num') this.fail('a ' + this.describe(idxV) + ' is used as an array index');
@@ -1024,6 +1037,24 @@ Translator.prototype.expr = function (e) {
     }
     case 'Binary': {
       const l = this.expr(e.l), r = this.expr(e.r);
+      if (CMP[e.op] && (l.t === 'strlit' || l.t === 'strv' || r.t === 'strlit' || r.t === 'strv')) {
+        // categorical values: equality only, as integer codes
+        const eq = e.op === '===' || e.op === '==', ne = e.op === '!==' || e.op === '!=';
+        if (!eq && !ne) this.fail("strings can only be compared with === / !==, not '" + e.op + "'");
+        const isStr = (v) => v.t === 'strlit' || v.t === 'strv';
+        if (!isStr(l) || !isStr(r)) {       // a string against a number / boolean: never equal under === (== would coerce: refused)
+          if (e.op === '==' || e.op === '!=') this.fail("'" + e.op + "' between a string and a " + this.describe(isStr(l) ? r : l) + ' (use === )');
+          return { t: 'bool', code: ne ? 'true' : 'false', cst: ne };
+        }
+        if (l.t === 'strlit' && r.t === 'strlit') { const v = (l.v === r.v) === eq; return { t: 'bool', code: v ? 'true' : 'false', cst: v }; }
+        if (l.t === 'strv' && r.t === 'strv') {
+          if (l.id !== r.id) this.fail('comparing elements of two different arrays of strings is not supported');
+          return { t: 'bool', code: '(' + l.code.code + (eq ? ' == ' : ' != ') + r.code.code + ')' };
+        }
+        const sv = l.t === 'strv' ? l : r, lit = l.t === 'strv' ? r : l, k = sv.table.indexOf(lit.v);
+        if (k < 0) return { t: 'bool', code: ne ? 'true' : 'false', cst: ne };      // a label that never occurs
+        return { t: 'bool', code: '(' + sv.code.code + (eq ? ' == ' : ' != ') + k + ')' };
+      }
       if (CMP[e.op]) {
         if (l.t === 'bool' && r.t === 'bool') return { t: 'bool', code: '((' + l.code + ') ' + (e.op[0] === '!' ? '!=' : '==') + ' (' + r.code + '))' };
         if (l.t !== 'num' || r.t !== 'num') this.fail("comparison '" + e.op + "' between a " + this.describe(l) + ' and a ' + this.describe(r));
@@ -1066,7 +1097,7 @@ Translator.prototype.expr = function (e) {
     case 'Call': return this.call(e);
     case 'Func': this.fail('a function expression can only be assigned to a variable (var f = function (x) {...})');   // eslint-disable-line no-fallthrough
     case 'Assign': case 'Update': this.fail('assignments are only supported as statements');  // eslint-disable-line no-fallthrough
-    case 'Str': this.fail('strings are not supported (only as property names: data["x"])');   // eslint-disable-line no-fallthrough
+    case 'Str': return { t: 'strlit', v: e.v };      // only ever compared (=== !== == !=) with categorical data
     case 'Seq': this.fail("the ',' operator is not supported");   // eslint-disable-line no-fallthrough
   }
   this.fail('unsupported expression (' + e.k + ')');
@@ -1383,7 +1414,7 @@ Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) 
       if (this.loops.length || this.condDepth) {
         // `var row = data[i]` / `var xi = d.X[i]` inside a loop: fine when this is the name's only assignment (it then always means "element i
         // as of here"; the index is frozen in a block-scoped temporary, so a use outside the loop does not compile instead of misreading)
-        if (!(this.assignCount[name] === 1 && (v.t === 'rec' || v.t === 'dataArr' || v.t === 'stateArr')))
+        if (!(this.assignCount[name] === 1 && (v.t === 'rec' || v.t === 'dataArr' || v.t === 'stateArr' || v.t === 'strv' || v.t === 'strlit')))
           this.fail('aliasing an array or object (' + name + ') inside a loop or an if is only supported for a row / record assigned once (var row = data[i])');
         if (v.t === 'dataArr' && !/^\d+$/.test(v.off)) v = { t: 'dataArr', id: v.id, off: this.temp_int(v.off), dims: v.dims };
         if (v.t === 'stateArr' && !/^\d+$/.test(v.base)) v = { t: 'stateArr', base: this.temp_int(v.base), dims: v.dims };

@@ -594,6 +594,31 @@ CASES.records_logistic = {
   schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
 };
 
+// ---- categorical columns kept as strings in the data (treatment arm, site, a model switch): the translator stores them as integer
+// codes and only ever compares them (=== / !==) -- with literals (one that never occurs among them), with each other, through an alias
+CASES.categorical_arms = {
+  params: () => ({ mu: {}, d_low: {}, d_high: {}, sigma: { lower: 0, init: 1 } }),
+  data: (seed) => {
+    const r = lcg(seed), rows = [];
+    for (let i = 0; i < 30; i++) { const arm = ['control', 'low', 'high'][i % 3]; rows.push({ y: 1 + (arm === 'low' ? 0.5 : arm === 'high' ? 1.1 : 0) + (r() - 0.5) * 2, arm, site: r() < 0.5 ? 'A' : 'B' }); }
+    return { rows, family: 'normal', labels: ['x', 'y', 'x', 'z'] };
+  },
+  log_post: function (s, d) {
+    var lp = ld.norm(s.mu, 0, 10) + ld.norm(s.d_low, 0, 2) + ld.norm(s.d_high, 0, 2) + ld.unif(s.sigma, 0, 10);
+    for (var i = 0; i < d.rows.length; i++) {
+      var row = d.rows[i];
+      var arm = row.arm;
+      var m = s.mu;
+      if (arm === 'low') m += s.d_low; else if (arm === "high") { m += s.d_high; }
+      if (row.site !== 'A' && arm !== 'placebo') m += 0.1;
+      if (d.family === 'normal') lp += ld.norm(row.y, m, s.sigma); else lp += ld.cauchy(row.y, m, s.sigma);
+    }
+    for (var j = 0; j < d.labels.length; j++) lp += (d.labels[j] === d.labels[0] ? 1e-3 : -1e-3) * (d.labels[j] === 3 ? 100 : 1);
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+
 function build(name, seed) {
   const c = CASES[name] || BENCH[name];
   if (!c) throw new Error('unknown user model ' + name);

@@ -21,7 +21,7 @@ import user_host
 pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
 
 NAMES = ["readme_normal", "readme_bern", "norm_post_derived", "complex_model", "hier_binomial", "multi_bern", "multivar_poisson",
-         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js", "live_out_temp", "circular_wrapped_cauchy", "structured_helpers", "records_logistic"] + ["cfgfuzz_%d" % k for k in range(16)]
+         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js", "live_out_temp", "circular_wrapped_cauchy", "structured_helpers", "records_logistic", "categorical_arms"] + ["cfgfuzz_%d" % k for k in range(16)]
 
 
 def same(a, b):
@@ -95,7 +95,7 @@ def oracle_spec(name):
     return {"log_post_fn": lambda st, lanes: m.eval(st, lanes), "params": params, "P": len(init), "init": init, "comp_opts": opts}, gold, m
 
 
-@pytest.mark.parametrize("name", ["complex_model", "spike_slab", "multi_bern", "hier_binomial", "discrete_mix", "modern_js", "multivar_poisson", "semantics_probe", "circular_wrapped_cauchy", "structured_helpers", "records_logistic"]
+@pytest.mark.parametrize("name", ["complex_model", "spike_slab", "multi_bern", "hier_binomial", "discrete_mix", "modern_js", "multivar_poisson", "semantics_probe", "circular_wrapped_cauchy", "structured_helpers", "records_logistic", "categorical_arms"]
                          + ["cfgfuzz_%d" % k for k in range(16)])
 def test_oracle_stepper_with_translated_closure_reproduces_reference(name):
     """Pins the oracle's BinaryStepper (mcmc.js:753-767) and int/real steppers on user models: the C oracle, stepping with the
