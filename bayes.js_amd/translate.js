@@ -6,7 +6,7 @@
  *
  * The closure is read from its own source text (Function.prototype.toString) and must stay
  * inside a numeric subset of JavaScript:
- *     var/let/const, assignments (= += -= *= /= %=, ++ --), for / while / if / else / break / continue / return, blocks
+ *     var/let/const, assignments (= += -= *= /= %=, ++ --), for / while / do-while / if / else / switch (no fall-through) / break / continue / return, blocks
  *     numbers, + - * / % **, | & ^ ~ << >> >>> (ToInt32 semantics), comparisons, && || !, ?:, Math.{log,exp,log1p,expm1,log10,log2,pow,sqrt,cbrt,hypot,abs,floor,ceil,round,trunc,sign,
  *     min,max,sin,cos,tan,asin,acos,atan,atan2,sinh,cosh,tanh,asinh,acosh,atanh,imul,clz32,fround,PI,E,...}, isNaN, isFinite, every ld.* of distributions.js (array-valued ones unrolled),
  *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, arrays of records (data[i].x, var row = data[i]), categorical strings in the data (only compared: row.group === 'control'), local
@@ -105,7 +105,7 @@ function tokenize(src) {
 // ------------------------------------------------------------------------------------------
 // parser (recursive descent, JavaScript precedence)
 const KEYWORDS = new Set(['var', 'let', 'const', 'for', 'while', 'if', 'else', 'return', 'function', 'true', 'false',
-  'break', 'continue', 'do', 'switch', 'new', 'typeof', 'in', 'of', 'this', 'null', 'undefined', 'throw', 'try']);
+  'break', 'continue', 'do', 'switch', 'case', 'default', 'new', 'typeof', 'in', 'of', 'this', 'null', 'undefined', 'throw', 'try']);
 
 function Parser(tokens) { this.tk = tokens; this.i = 0; }
 Parser.prototype = {
@@ -256,7 +256,52 @@ Parser.prototype = {
     }
     if (this.eat('break')) { this.endStmt(); return { k: 'Break' }; }
     if (this.eat('continue')) { this.endStmt(); return { k: 'Continue' }; }
-    for (const kw of ['do', 'switch', 'throw', 'try', 'function'])
+    if (this.eat('do')) {          // do body while (c);   ->   for (;;) { body; if (!(c)) break; }
+      const body = this.statement();
+      this.expect('while'); this.expect('('); const test = this.expression(); this.expect(')'); this.endStmt();
+      if (hasOwnJump(body, 'Continue')) throw "'continue' inside a do...while body is not supported";
+      const stmts = body.k === 'Block' ? body.body.slice() : [body];
+      stmts.push({ k: 'If', test: { k: 'Unary', op: '!', arg: test }, cons: { k: 'Break' }, alt: null });
+      return { k: 'For', init: null, test: null, update: null, body: { k: 'Block', body: stmts } };
+    }
+    if (this.eat('switch')) {      // switch without fall-through -> if / else if chain on a temporary
+      this.expect('('); const disc = this.expression(); this.expect(')'); this.expect('{');
+      const groups = [];           // {tests: [expr], isDefault, body: [stmt]}
+      let cur = null;
+      while (!this.peek('}')) {
+        if (this.peek('case') || this.peek('default')) {
+          if (!cur || cur.body.length) { cur = { tests: [], isDefault: false, body: [] }; groups.push(cur); }
+          if (this.eat('default')) cur.isDefault = true; else { this.i++; cur.tests.push(this.expression()); }
+          this.expect(':');
+        } else {
+          if (!cur) throw "expected 'case' inside switch";
+          cur.body.push(this.statement());
+        }
+      }
+      this.expect('}');
+      const tmp = this.fresh('sw');
+      let chain = null, dflt = null;
+      groups.forEach((g, gi) => {
+        const isLast = gi === groups.length - 1;
+        const strip = (list) => {      // removes the case's closing break (also from a trailing block); true if the case cannot fall through
+          const q = list[list.length - 1];
+          if (!q) return false;
+          if (q.k === 'Break') { list.pop(); return true; }
+          if (q.k === 'Block') return strip(q.body);
+          return q.k === 'Return' || q.k === 'Continue';
+        };
+        if (!strip(g.body) && !isLast) throw 'a switch case that falls through into the next one is not supported (end it with break)';
+        if (g.body.some((st) => hasOwnJump(st, 'Break'))) throw "'break' nested inside a switch case is not supported (only as the last statement of the case)";
+      });
+      for (let gi = groups.length - 1; gi >= 0; gi--) {
+        const g = groups[gi], blk = { k: 'Block', body: g.body };
+        if (g.isDefault) { if (gi !== groups.length - 1) throw "'default' must be the last clause of the switch"; dflt = blk; continue; }
+        const test = g.tests.map((t) => ({ k: 'Binary', op: '===', l: { k: 'Id', name: tmp }, r: t })).reduce((a, b) => ({ k: 'Logical', op: '||', l: a, r: b }));
+        chain = { k: 'If', test, cons: blk, alt: chain || dflt };
+      }
+      return { k: 'Block', body: [{ k: 'VarDecl', kind: 'var', decls: [{ name: tmp, init: disc }] }].concat(chain ? [chain] : (dflt ? [dflt] : [])) };
+    }
+    for (const kw of ['throw', 'try', 'function'])
       if (this.peek(kw)) throw "'" + kw + "' statements are not supported inside log_post";
     const expr = this.expression();
     this.endStmt();
@@ -365,6 +410,15 @@ Parser.prototype = {
   },
 };
 
+function hasOwnJump(st, kind) {
+  if (!st || typeof st !== 'object') return false;
+  if (Array.isArray(st)) return st.some((x) => hasOwnJump(x, kind));
+  if (st.k === kind) return true;
+  if (st.k === 'For' || st.k === 'Func') return false;
+  if (st.k === 'Block') return hasOwnJump(st.body, kind);
+  if (st.k === 'If') return hasOwnJump(st.cons, kind) || hasOwnJump(st.alt, kind);
+  return false;
+}
 function parseFunctionSource(src) { return new Parser(tokenize(src)).parseFunction(); }
 
 // ---- modern-JavaScript sugar, rewritten into the core subset before translation ---------------------------------------

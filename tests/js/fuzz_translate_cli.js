@@ -86,7 +86,11 @@ function generator(rnd) {
     const r = rnd(), ctxX = { i: null };
     const e = (ctx) => num(2, ctx || {}), c = (ctx) => '(' + cond(2, ctx || {}) + ')';
     const withT = (str, v) => str.replace(/(^|[^.\w])t\b/g, '$1' + v);
-    if (r < 0.15) return 'for (const xv' + k + ' of d.x) { lp += (xv' + k + ' * ' + withT(e(), 'xv' + k) + ') * 1e-3; }';
+    if (r < 0.05) return 'for (var i = 0; i < 8; i++) { switch (d.n[i] % 4) { case 0: lp += ' + e({ i: 'i' }) + ' * 1e-3; break; case 1: case 2: { lp -= ' + e({ i: 'i' }) + ' * 1e-3; break; } default: lp += 1e-3; } }';
+    if (r < 0.10) return 'var jd' + k + ' = 0; do { lp += ' + e() + ' * 1e-3; jd' + k + '++; } while (jd' + k + ' < s.k);';
+    if (r < 0.18) return 'for (const rw of d.rows) { if (rw.tag === "u") lp += rw.val * ' + e() + ' * 1e-3; else if (rw.tag !== "w") { lp -= rw.sub.q * 1e-3; } switch (rw.tag) { case "v": lp += 1e-4; break; case "zz": lp += 1; break; default: lp -= 1e-4; } }';
+    if (r < 0.22) return 'for (var i = 0; i < d.rows.length; i++) { var rr' + k + ' = d.rows[i]; lp += (rr' + k + '.val - ' + e({ i: 'i' }) + ') * rr' + k + '.sub.q * 1e-3; }';
+    if (r < 0.28) return 'for (const xv' + k + ' of d.x) { lp += (xv' + k + ' * ' + withT(e(), 'xv' + k) + ') * 1e-3; }';
     if (r < 0.3) return 'd.x.forEach(function (xe, ie) { if ' + withT(c({ i: 'ie' }), 'xe') + ' return; lp += (xe + ' + withT(e({ i: 'ie' }), 'xe') + ') * 1e-3; });';
     if (r < 0.45) return 'lp += d.x.reduce((ac, xe, ie) => ac + ' + withT(e({ i: 'ie' }), 'xe') + ' * 1e-3, ' + withT(e(), 's.a') + ') * 1e-2;';
     if (r < 0.55) return 'const { a: pa' + k + ', v: [pv' + k + ', , pw' + k + '] } = s;\n  lp += (pa' + k + ' * pv' + k + ' - pw' + k + ') * 1e-3;';
@@ -120,8 +124,8 @@ for (let mk = 0; mk < nModels; mk++) {
   lines.push('  return lp;');
   const src = 'return function (s, d) {\n' + lines.join('\n') + '\n};';
   const fn = new Function('ld', src)(ld);
-  const data = { x: [], n: [], m: [[0.5, -1.25, 3], [2, 0, -0.75]] };
-  for (let i = 0; i < 8; i++) { data.x.push(i === 3 ? 0 : (rnd() - 0.4) * 6); data.n.push(Math.floor(rnd() * 11)); }
+  const data = { x: [], n: [], m: [[0.5, -1.25, 3], [2, 0, -0.75]], rows: [] };
+  for (let i = 0; i < 8; i++) { data.x.push(i === 3 ? 0 : (rnd() - 0.4) * 6); data.n.push(Math.floor(rnd() * 11)); data.rows.push({ val: (rnd() - 0.5) * 3, tag: ['u', 'v', 'w'][Math.floor(rnd() * 3)], sub: { q: Math.floor(rnd() * 5) } }); }
   const params = mcmc.complete_params({ a: {}, b: { lower: 0 }, v: { dim: [3] }, k: { type: 'int', lower: 0, upper: 6 }, z: { type: 'binary' } }, mcmc.param_init_fixed);
   const name = 'fuzz_' + seed0 + '_' + mk;
   fs.writeFileSync(path.join(out, name + '.js'), src);
