@@ -593,7 +593,7 @@ function definitelyAssigned(stmts, tracked, defined, acc) {
         const e = st.expr;
         if (e.k === 'Assign' && e.target.k === 'Id') {
           if (!reads(e.value)) return false;
-          if (e.target.name === acc) break;
+          if (acc instanceof Set ? acc.has(e.target.name) : e.target.name === acc) break;
           if (e.op === '=') defined.add(e.target.name);
           else if (tracked.has(e.target.name) && !defined.has(e.target.name)) return false;
         } else if (e.k === 'Update' && e.target.k === 'Id') {

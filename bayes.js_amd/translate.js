@@ -827,6 +827,22 @@ Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) 
       this.localFuncs[name] = valueAst;
       return;
     }
+    if (this.linear && this.accSet.has(name)) {
+      if (Object.prototype.hasOwnProperty.call(this.aliases, name)) this.fail(name + ' holds an array/object elsewhere and a number here');
+      this.setLocal(name, num('', false));
+      const v_ = 'v_' + name;
+      if (this.loops.length) {          // inside a loop: += / -= of an accumulator-free term (linearAccumulators)
+        const t = this.expr(valueAst);
+        this.flush(out, indent);
+        out.push(indent + (ctx.split ? '' : 'if (sub == 0) ') + v_ + ' ' + op + ' ' + this.asD(t) + ';');
+        return;
+      }
+      const lc = this.linearCode(valueAst);
+      this.flush(out, indent);
+      if (op === '=') out.push(indent + v_ + ' = ' + (lc.hasA ? lc.code : '(sub == 0) ? ' + lc.code + ' : 0.0') + ';');
+      else out.push(indent + (lc.hasA ? '' : 'if (sub == 0) ') + v_ + ' ' + op + ' ' + lc.code + ';');
+      return;
+    }
     let v = this.expr(valueAst);
     if (v.t === 'localArr' && op === '=' && v.name && !this.loops.length && !this.condDepth && !Object.prototype.hasOwnProperty.call(this.localTypes, name)) {
       this.aliases[name] = v;        // `var z = otherArray`: arrays are references in JavaScript, both names mean the same storage
@@ -946,10 +962,10 @@ Translator.prototype.splittable = function (s, canon) {
   if (containsKind(s.body, 'Return') || containsKind(s.body, 'Break')) return false;   // would have to stop the other lanes too
   let ok = true;
   const written = assignedNames(s.body);
-  written.delete(this.acc);
+  for (const a of this.accSet) written.delete(a);
   // every other variable written in the body must be private to one iteration: definitely assigned
   // before it is read in every iteration, and not referenced outside loops
-  if (!definitelyAssigned(s.body.k === 'Block' ? s.body.body : [s.body], written, new Set(), this.acc)) ok = false;
+  if (!definitelyAssigned(s.body.k === 'Block' ? s.body.body : [s.body], written, new Set(), this.accSet)) ok = false;
   for (const nm of written) if (this.topLevelRefs.has(nm)) ok = false;
   if (this.topLevelRefs.has(canon.name)) ok = false;
   // ... nor inside any LATER loop, unless that loop assigns them itself before it reads them (`var` is function-scoped: a temporary
@@ -963,11 +979,11 @@ Translator.prototype.splittable = function (s, canon) {
       if (!initAssigns) for (const part of [other.init, other.test, other.update]) if (part) idsOf(part).forEach((n) => header.add(n));
       if (header.has(nm)) { ok = false; continue; }
       if (initAssigns) continue;       // the other loop's own counter: assigned by its header before anything reads it
-      if (!definitelyAssigned(other.body.k === 'Block' ? other.body.body : [other.body], new Set([nm]), new Set(), this.acc)) ok = false;
+      if (!definitelyAssigned(other.body.k === 'Block' ? other.body.body : [other.body], new Set([nm]), new Set(), this.accSet)) ok = false;
     }
   }
   walk(s.body, (x) => {
-    if (x.k === 'Assign' && x.target.k === 'Id' && x.target.name === this.acc && x.op !== '+=') ok = false;
+    if (x.k === 'Assign' && x.target.k === 'Id' && this.accSet.has(x.target.name) && x.op !== '+=' && !(this.linear && x.op === '-=')) ok = false;
     if (x.k === 'Assign' && x.target.k !== 'Id') ok = false;   // derived quantities inside a loop
   });
   return ok;
@@ -1010,6 +1026,13 @@ Translator.prototype.stmt = function (s, out, indent, ctx) {
         return;
       }
       if (ctx.split) this.fail('return inside a lane-split loop');   // excluded by splittable()
+      if (this.linear) {
+        const lc = this.linearCode(s.arg);
+        this.flush(out, indent);
+        out.push(indent + this.deriveStore());
+        out.push(indent + 'return ' + (lc.hasA ? lc.code : '(sub == 0) ? ' + lc.code + ' : 0.0') + ';');
+        return;
+      }
       const v = this.expr(s.arg);
       this.flush(out, indent);
       out.push(indent + this.deriveStore());
@@ -1056,9 +1079,10 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
     // independently (their temporaries are private, proved by splittable()), then the U terms are added in order
     const lastSt = body[body.length - 1];
     const endsInAcc = lastSt && lastSt.k === 'ExprStmt' && lastSt.expr.k === 'Assign' && lastSt.expr.op === '+=' &&
-                      lastSt.expr.target.k === 'Id' && lastSt.expr.target.name === this.acc;
+                      lastSt.expr.target.k === 'Id' && this.accSet.has(lastSt.expr.target.name);
+    const loopAcc = endsInAcc ? lastSt.expr.target.name : this.acc;
     let accElsewhere = false;
-    for (const st of body.slice(0, -1)) walk(st, (x) => { if ((x.k === 'Assign' || x.k === 'Update') && x.target.k === 'Id' && x.target.name === this.acc) accElsewhere = true; });
+    for (const st of body.slice(0, -1)) walk(st, (x) => { if ((x.k === 'Assign' || x.k === 'Update') && x.target.k === 'Id' && this.accSet.has(x.target.name)) accElsewhere = true; });
     const single = split && isInt && boundV.int && endsInAcc && !accElsewhere && !containsKind(s.body, 'Return') &&
                    !containsKind(s.body, 'Continue') && !containsKind(s.body, 'Break');
     if (single) {
@@ -1071,7 +1095,7 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
       const simple = body.length === 1;
       // plain arithmetic bodies keep 8 terms in flight; bodies with exp/log/ld.* calls 4 (register pressure)
       const U = this.opts.unroll || ((this.heavyLoop && !simple) || (this.heavyLoop && !heavyBefore && pend.length > 4) ? 4 : 8);
-      const acc = 'v_' + this.acc, iv = 'v_' + canon.name;
+      const acc = 'v_' + loopAcc, iv = 'v_' + canon.name;
       const bodyText = pre.map((ln) => ln.trim()).concat(pend).join(' ');
       const loop = [];
       loop.push('  int it_ = 0;');
@@ -1101,7 +1125,7 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
         out.push(indent + '}');
         return;
       }
-      this.emitSplit(out, indent, L.preamble, head, loop);
+      this.emitSplit(out, indent, L.preamble, head, loop, [loopAcc]);
       return;
     }
     this.loopLabels.push({ native: true });
@@ -1121,7 +1145,7 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
       loop.push('  }');
       out.pop();   // the '{' pushed above: emitSplit writes its own block
       L.preamble.forEach(() => out.pop());
-      this.emitSplit(out, indent, L.preamble, [], loop);
+      this.emitSplit(out, indent, L.preamble, [], loop, Array.from(this.accSet).filter((a) => assigned.has(a)));
       return;
     }
     out.push(indent + '  for (' + v + ' = ' + start + '; ' + lhs + cmp + bound + '; ' + v + ' += 1) {');
@@ -1161,8 +1185,9 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
 // A lane-split loop.  If it evaluates ld.norm with a hoisted sd, it is emitted twice: the fast form (4-operation
 // quotient, exponent range of the numerators recorded) and, run only if a range precondition failed, the slow form
 // (IEEE division) from the saved accumulator -- the two give the same bits, the second is the proof obligation.
-Translator.prototype.emitSplit = function (out, indent, preamble, head, loop) {
-  const acc = 'v_' + this.acc;
+Translator.prototype.emitSplit = function (out, indent, preamble, head, loop, accNames) {
+  // accNames: the accumulators this loop adds to (saved before the fast pass, restored before the IEEE replay)
+  const accs = (accNames && accNames.length ? accNames : [this.acc]).map((a) => 'v_' + a);
   const all = preamble.concat(head, loop);
   out.push(indent + '{');
   if (!hasNormCall(all)) {
@@ -1170,7 +1195,7 @@ Translator.prototype.emitSplit = function (out, indent, preamble, head, loop) {
     out.push(indent + '}');
     return;
   }
-  out.push(indent + '  const double acc_save_ = ' + acc + ';');
+  accs.forEach((acc, k) => out.push(indent + '  const double acc_save' + (k ? k : '') + '_ = ' + acc + ';'));
   out.push(indent + '  uint32_t rlo_ = 0xffffffffu, rhi_ = 0u;');
   for (const ln of renderNorm(preamble.map((p) => '  ' + p), 'fast')) out.push(indent + ln);
   for (const ln of head) out.push(indent + ln);
@@ -1178,10 +1203,99 @@ Translator.prototype.emitSplit = function (out, indent, preamble, head, loop) {
   for (const ln of renderNorm(loop, 'fast')) out.push(indent + '  ' + ln);
   out.push(indent + '  }');
   out.push(indent + '  if (!norm_range_ok(rlo_, rhi_)) {');
-  out.push(indent + '    ' + acc + ' = acc_save_;');
+  accs.forEach((acc, k) => out.push(indent + '    ' + acc + ' = acc_save' + (k ? k : '') + '_;'));
   for (const ln of renderNorm(loop, 'slow')) out.push(indent + '  ' + ln);
   out.push(indent + '  }');
   out.push(indent + '}');
+};
+
+// The largest set of locals that (1) are written only by `=`, `+=`, `-=` (inside loops only `+=` / `-=` of accumulator-free terms),
+// (2) are read only in linear positions (sums, differences, products with / quotients by accumulator-free factors, negation) of
+// assignments to members of the set or of a return, and (3) actually accumulate (`+=`) or collect other members; empty unless a
+// return depends on it.  Lanes then hold partial values whose sum over the lanes is the sequential value.
+Translator.prototype.linearAccumulators = function (body) {
+  const writes = {};                      // name -> [{op, value, depth}]
+  const bad = new Set();
+  const noteWrite = (name, op, value, depth) => { (writes[name] = writes[name] || []).push({ op, value, depth }); };
+  const scanW = (node, depth) => {
+    if (!node || typeof node !== 'object') return;
+    if (Array.isArray(node)) { node.forEach((x) => scanW(x, depth)); return; }
+    if (node.k === 'Func') return;
+    if (node.k === 'VarDecl') node.decls.forEach((d) => { if (d.init) noteWrite(d.name, '=', d.init, depth); });
+    if (node.k === 'Assign' && node.target.k === 'Id') noteWrite(node.target.name, node.op, node.value, depth);
+    if (node.k === 'Update' && node.target.k === 'Id') bad.add(node.target.name);
+    if (node.k === 'For') { scanW(node.init, depth); scanW(node.test, depth + 1); scanW(node.update, depth + 1); scanW(node.body, depth + 1); return; }
+    for (const key of Object.keys(node)) if (key !== 'k') scanW(node[key], depth);
+  };
+  scanW(body, 0);
+  let C = new Set(Object.keys(writes).filter((n) => !bad.has(n) && writes[n].every((w) => w.op === '=' || w.op === '+=' || w.op === '-=')));
+  if (this.ast.params) for (const q of this.ast.params) C.delete(q);
+  const members = (e) => { const o = []; for (const nm of idsOf(e)) if (C.has(nm)) o.push(nm); return o; };
+  // linear(e): null if some member of C sits in a non-linear position of e, else whether e contains members at all
+  const linear = (e) => {
+    if (!e || !members(e).length) return false;
+    if (e.k === 'Id') return true;
+    if (e.k === 'Unary' && (e.op === '-' || e.op === '+')) return linear(e.arg);
+    if (e.k === 'Binary' && (e.op === '+' || e.op === '-')) { const l = linear(e.l), r = linear(e.r); return (l === null || r === null) ? null : (l || r); }
+    if (e.k === 'Binary' && e.op === '*') { const ml = members(e.l).length, mr = members(e.r).length; if (ml && mr) return null; return ml ? linear(e.l) : linear(e.r); }
+    if (e.k === 'Binary' && e.op === '/') { if (members(e.r).length) return null; return linear(e.l); }
+    return null;
+  };
+  for (let changed = true; changed;) {
+    changed = false;
+    const drop = (names) => { for (const nm of names) if (C.delete(nm)) changed = true; };
+    // reads
+    const visit = (node, depth) => {
+      if (!node || typeof node !== 'object') return;
+      if (Array.isArray(node)) { node.forEach((x) => visit(x, depth)); return; }
+      switch (node.k) {
+        case 'Func': drop(members(node.body)); return;
+        case 'VarDecl': node.decls.forEach((d) => { if (d.init) assignTo(d.name, '=', d.init, depth); }); return;
+        case 'ExprStmt':
+          if (node.expr.k === 'Assign' && node.expr.target.k === 'Id') { assignTo(node.expr.target.name, node.expr.op, node.expr.value, depth); return; }
+          drop(members(node.expr)); return;
+        case 'Return': if (node.arg && linear(node.arg) === null) drop(members(node.arg)); if (node.arg && depth > 0) drop(members(node.arg)); return;
+        case 'If': drop(members(node.test)); visit(node.cons, depth); visit(node.alt, depth); return;
+        case 'For': visit(node.init, depth); if (node.test) drop(members(node.test)); if (node.update) drop(members(node.update)); visit(node.body, depth + 1); return;
+        case 'Block': visit(node.body, depth); return;
+        default: drop(members(node));
+      }
+    };
+    const assignTo = (name, op, value, depth) => {
+      if (!C.has(name)) { drop(members(value)); return; }
+      const lin = linear(value);
+      if (lin === null) { drop(members(value)); return; }
+      if (depth > 0) { if (op === '=') drop([name]); if (lin) drop(members(value)); }        // inside loops: only += / -= of accumulator-free terms
+    };
+    visit(body.body, 0);
+    // (3) a member accumulates, or collects other members
+    for (const nm of Array.from(C)) {
+      const w = writes[nm];
+      if (!w.some((x) => x.op !== '=' || members(x.value).length)) drop([nm]);
+    }
+  }
+  if (!C.size) return C;
+  // does a return depend on a member?  (otherwise there is nothing to share between the lanes)
+  let used = false;
+  walk(body, (x) => { if (x.k === 'Return' && x.arg && members(x.arg).length) used = true; });
+  return used ? C : new Set();
+};
+
+// code of an expression that is linear in the accumulators: accumulator-free addends count once (lane 0), factors stay whole
+Translator.prototype.linearCode = function (e) {
+  const has = (n) => { for (const nm of idsOf(n)) if (this.accSet.has(nm)) return true; return false; };
+  if (!has(e)) return { code: this.asD(this.expr(e)), hasA: false };
+  const guard = (x) => (x.hasA ? x.code : '((sub == 0) ? ' + x.code + ' : 0.0)');
+  if (e.k === 'Id') return { code: this.asD(this.expr(e)), hasA: true };
+  if (e.k === 'Unary' && e.op === '+') return this.linearCode(e.arg);
+  if (e.k === 'Unary' && e.op === '-') return { code: '(-(' + this.linearCode(e.arg).code + '))', hasA: true };
+  if (e.k === 'Binary' && (e.op === '+' || e.op === '-')) { const l = this.linearCode(e.l), r = this.linearCode(e.r); return { code: '(' + guard(l) + ' ' + e.op + ' ' + guard(r) + ')', hasA: true }; }
+  if (e.k === 'Binary' && e.op === '*') {
+    if (has(e.l)) { const l = this.linearCode(e.l); return { code: '(' + l.code + ' * ' + this.asD(this.expr(e.r)) + ')', hasA: true }; }
+    const l = this.asD(this.expr(e.l)); return { code: '(' + l + ' * ' + this.linearCode(e.r).code + ')', hasA: true };
+  }
+  if (e.k === 'Binary' && e.op === '/') { const l = this.linearCode(e.l); return { code: '(' + l.code + ' / ' + this.asD(this.expr(e.r)) + ')', hasA: true }; }
+  this.fail('internal: an accumulator in a non-linear position');
 };
 
 // Generates the body (declarations + statements) with a fix-point over the inferred local types.
@@ -1212,6 +1326,14 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
     // other lanes restart from 0, which is what overwriting the running total means for the sum over lanes
     if (ok && decls <= 1 && reads === writes + returns && returns === 1) { this.acc = name; this.split = true; }
   }
+  // several accumulators that are only ever combined linearly (`return log_prior + log_lik - 1e-3 * penalty`, helpers inlined into
+  // their own running sums, reduce()): every lane keeps partial values of all of them; terms free of accumulators are added by lane 0
+  this.accSet = new Set(this.acc ? [this.acc] : []);
+  this.linear = false;
+  if (allowSplit && !this.acc && !this.opts.single_accumulator) {
+    const A = this.linearAccumulators(body);
+    if (A.size) { this.accSet = A; this.linear = true; this.split = true; }
+  }
   // names referenced at the top level of the function (outside every loop): lane-split loops may not leak into them
   this.topLevelRefs = new Set();
   const scanTop = (list) => {
@@ -1225,7 +1347,7 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
   };
   this.topLoops = [];
   scanTop(stmts);
-  if (this.acc) this.topLevelRefs.delete(this.acc);
+  for (const a of this.accSet) this.topLevelRefs.delete(a);
 
   this.assignCount = {};
   walk(body, (x) => {

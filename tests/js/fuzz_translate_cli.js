@@ -121,7 +121,19 @@ for (let mk = 0; mk < nModels; mk++) {
   lines.push('  var lp = ' + G.num(3, {}) + ' + ld.norm(s.a, 0, 10);');
   for (let b = 0; b < 4; b++) lines.push('  ' + G.lpBlock());
   for (let b = 0; b < 3; b++) lines.push('  ' + G.sugarBlock(b));
-  lines.push('  return lp;');
+  // half of the models return a linear combination of several running sums (the translator's multi-accumulator lane splitting)
+  if (mk % 2 === 1) {
+    const ctxI = { i: 'i' };
+    lines.push('  var la0 = ' + G.num(2, {}) + ' * 1e-3, la1 = 0, la2 = 1;');
+    lines.push('  for (var i = 0; i < d.x.length; i++) { la0 += ' + G.num(3, ctxI) + ' * 1e-3; }');
+    lines.push('  for (var i = 0; i < 8; i++) { var t = d.x[i] * 0.5; if (' + G.cond(2, ctxI) + ') { la1 -= ' + G.num(2, ctxI) + ' * 1e-3; } else { la1 += t * 1e-3; la0 -= 1e-4; } }');
+    lines.push('  for (var i = 0; i < d.n.length; i++) { la2 += d.n[i] * ' + G.num(2, {}) + ' * 1e-4; }');
+    lines.push('  s.la2seen = la2;');           // la2 is read outside the linear forms: it must stay an ordinary (unsplit) variable
+    lines.push('  la1 += la0 * 0.25 + ' + G.num(2, {}) + ' * 1e-3;');
+    lines.push('  return lp + 0.5 * la1 - la0 / 3 + la2 * 1e-3 + ' + G.num(2, {}) + ' * 1e-3;');
+  } else {
+    lines.push('  return lp;');
+  }
   const src = 'return function (s, d) {\n' + lines.join('\n') + '\n};';
   const fn = new Function('ld', src)(ld);
   const data = { x: [], n: [], m: [[0.5, -1.25, 3], [2, 0, -0.75]], rows: [] };
