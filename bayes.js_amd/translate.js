@@ -27,7 +27,8 @@
  * twins of csrc/amwg_math.h; constant sub-expressions are folded HERE, by V8 itself.  With one lane
  * per chain the generated body is the closure's own evaluation order, so a seeded run reproduces
  * the reference bit for bit.  With G lanes per chain the top-level loops that only accumulate into
- * the returned variable are split G ways (lane j takes iterations j, j+G, ...; lane 0 also adds
+ * the returned variable -- or into any of several running sums that are only ever combined linearly
+ * (linearAccumulators) -- are split G ways (lane j takes iterations j, j+G, ...; lane 0 also adds
  * every term outside those loops) and the kernel adds the lane partial sums with an xor butterfly.
  *
  * Result-preserving optimisations, applied only where a value provably does not change inside a loop: ld.norm with a
