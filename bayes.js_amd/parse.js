@@ -163,7 +163,7 @@ Parser.prototype = {
       let init = null, test = null, update = null;
       if ((this.peek('var') || this.peek('let') || this.peek('const')) && (this.peekAt(2, 'of') || this.peekAt(1, '{') || this.peekAt(1, '['))) {
         // for (const x of arr) body   ->   for (var k = 0; k < arr.length; k++) { var x = arr[k]; body }
-        const save = this.i;
+        const save = this.i, declKind = this.tk[this.i].v;
         this.i++;
         const pat = this.pattern();
         if (this.eat('of')) {
@@ -173,7 +173,7 @@ Parser.prototype = {
           const k = this.fresh('k'), decls = [];
           this.bind(pat, { k: 'Index', obj: arr, idx: { k: 'Id', name: k } }, decls);
           const body = this.statement();
-          return countedLoop(k, arr, [{ k: 'VarDecl', kind: 'var', decls }].concat(body.k === 'Block' ? body.body : [body]));
+          return countedLoop(k, arr, [{ k: 'VarDecl', kind: declKind, decls }].concat(body.k === 'Block' ? body.body : [body]));
         }
         this.i = save;
       }
@@ -366,7 +366,57 @@ function hasOwnJump(st, kind) {
   if (st.k === 'If') return hasOwnJump(st.cons, kind) || hasOwnJump(st.alt, kind);
   return false;
 }
-function parseFunctionSource(src) { return new Parser(tokenize(src)).parseFunction(); }
+// `let` / `const` are block-scoped: the same name may be declared again in another block (for (...) { const row = a[i]; } twice) or
+// shadow an outer one.  The translator works with function-scoped locals, so every such re-declaration gets a name of its own here.
+function uniquifyBlockScoped(fn, P) {
+  const seen = new Set(fn.params);
+  const declare = (st, env) => {       // let/const declared directly by this statement -> entries of env
+    if (!st || st.k !== 'VarDecl') return;
+    for (const d of st.decls) {
+      if (st.kind === 'var') { seen.add(d.name); continue; }
+      if (seen.has(d.name)) env[d.name] = P.fresh('b') + '_' + d.name; else { seen.add(d.name); delete env[d.name]; }
+    }
+  };
+  (function hoistVars(n) {             // `var` declarations are visible in the whole function, wherever they stand
+    if (!n || typeof n !== 'object') return;
+    if (Array.isArray(n)) { n.forEach(hoistVars); return; }
+    if (n.k === 'Func') return;
+    if (n.k === 'VarDecl' && n.kind === 'var') n.decls.forEach((d) => seen.add(d.name));
+    for (const key of Object.keys(n)) if (key !== 'k') hoistVars(n[key]);
+  })(fn.body);
+  const go = (node, env) => {
+    if (!node || typeof node !== 'object') return node;
+    if (Array.isArray(node)) return node.map((x) => go(x, env));
+    switch (node.k) {
+      case 'Id': return Object.prototype.hasOwnProperty.call(env, node.name) ? { k: 'Id', name: env[node.name] } : node;
+      case 'Block': {
+        const inner = Object.assign({}, env);
+        node.body.forEach((st) => declare(st, inner));
+        return { k: 'Block', body: node.body.map((st) => go(st, inner)) };
+      }
+      case 'For': {
+        const inner = Object.assign({}, env);
+        declare(node.init, inner);
+        return { k: 'For', init: go(node.init, inner), test: go(node.test, inner), update: go(node.update, inner), body: go(node.body, inner) };
+      }
+      case 'VarDecl': return { k: 'VarDecl', kind: node.kind, decls: node.decls.map((d) => ({ name: (node.kind !== 'var' && Object.prototype.hasOwnProperty.call(env, d.name)) ? env[d.name] : d.name, init: go(d.init, env) })) };
+      case 'Func': {
+        const inner = Object.assign({}, env);
+        node.params.forEach((q) => delete inner[q]);
+        return { k: 'Func', params: node.params, body: go(node.body, inner) };
+      }
+      case 'Member': return { k: 'Member', obj: go(node.obj, env), prop: node.prop };
+      default: {
+        const o = {};
+        for (const key of Object.keys(node)) o[key] = key === 'k' ? node.k : go(node[key], env);
+        return o;
+      }
+    }
+  };
+  return { params: fn.params, body: go(fn.body, {}) };
+}
+
+function parseFunctionSource(src) { const P = new Parser(tokenize(src)); return uniquifyBlockScoped(P.parseFunction(), P); }
 
 // ---- modern-JavaScript sugar, rewritten into the core subset before translation ---------------------------------------
 // a side-effect free path: name, name.prop, name[i] ...

@@ -89,8 +89,9 @@ function generator(rnd) {
     if (r < 0.05) return 'for (var i = 0; i < 8; i++) { switch (d.n[i] % 4) { case 0: lp += ' + e({ i: 'i' }) + ' * 1e-3; break; case 1: case 2: { lp -= ' + e({ i: 'i' }) + ' * 1e-3; break; } default: lp += 1e-3; } }';
     if (r < 0.10) return 'var jd' + k + ' = 0; do { lp += ' + e() + ' * 1e-3; jd' + k + '++; } while (jd' + k + ' < s.k);';
     if (r < 0.18) return 'for (const rw of d.rows) { if (rw.tag === "u") lp += rw.val * ' + e() + ' * 1e-3; else if (rw.tag !== "w") { lp -= rw.sub.q * 1e-3; } switch (rw.tag) { case "v": lp += 1e-4; break; case "zz": lp += 1; break; default: lp -= 1e-4; } }';
-    if (r < 0.22) return 'for (var i = 0; i < d.rows.length; i++) { var rr' + k + ' = d.rows[i]; lp += (rr' + k + '.val - ' + e({ i: 'i' }) + ') * rr' + k + '.sub.q * 1e-3; }';
-    if (r < 0.28) return 'for (const xv' + k + ' of d.x) { lp += (xv' + k + ' * ' + withT(e(), 'xv' + k) + ') * 1e-3; }';
+    if (r < 0.22) return 'for (let i = 0; i < d.rows.length; i++) { const rw = d.rows[i]; const q = [rw.val, ' + e({ i: 'i' }) + ']; lp += (q[0] - q[1]) * rw.sub.q * 1e-3; }';    // block-scoped names reused across blocks
+    if (r < 0.25) return '{ const q = ' + e() + '; let rw = q * 2; lp += (q + rw) * 1e-4; }';
+    if (r < 0.30) return 'for (const xv' + k + ' of d.x) { lp += (xv' + k + ' * ' + withT(e(), 'xv' + k) + ') * 1e-3; }';
     if (r < 0.3) return 'd.x.forEach(function (xe, ie) { if ' + withT(c({ i: 'ie' }), 'xe') + ' return; lp += (xe + ' + withT(e({ i: 'ie' }), 'xe') + ') * 1e-3; });';
     if (r < 0.45) return 'lp += d.x.reduce((ac, xe, ie) => ac + ' + withT(e({ i: 'ie' }), 'xe') + ' * 1e-3, ' + withT(e(), 's.a') + ') * 1e-2;';
     if (r < 0.55) return 'const { a: pa' + k + ', v: [pv' + k + ', , pw' + k + '] } = s;\n  lp += (pa' + k + ' * pv' + k + ' - pw' + k + ') * 1e-3;';
