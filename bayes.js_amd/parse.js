@@ -416,7 +416,51 @@ function uniquifyBlockScoped(fn, P) {
   return { params: fn.params, body: go(fn.body, {}) };
 }
 
-function parseFunctionSource(src) { const P = new Parser(tokenize(src)); return uniquifyBlockScoped(P.parseFunction(), P); }
+// `var a = []; for (var g = 0; g < n; g++) a.push(v);` -- an array grown by exactly one push per iteration of a counted loop that starts
+// at 0 has length n and element g at index g: rewritten to `var a = Array(n)` and `a[g] = v` (the only form of push that is supported).
+function rewritePushLoops(fn) {
+  const body = fn.body;
+  const empties = new Set();
+  walk(body, (x) => { if (x.k === 'VarDecl') x.decls.forEach((d) => { if (d.init && d.init.k === 'ArrayLit' && d.init.elems.length === 0) empties.add(d.name); }); });
+  if (!empties.size) return fn;
+  const isPush = (st, name) => st && st.k === 'ExprStmt' && st.expr.k === 'Call' && st.expr.callee.k === 'Member' && st.expr.callee.prop === 'push' &&
+    st.expr.callee.obj.k === 'Id' && st.expr.callee.obj.name === name && st.expr.args.length === 1;
+  const plan = {};        // array name -> {loop, counter, bound}
+  for (const name of empties) {
+    let pushes = 0, where = null;
+    walk(body, (x) => { if (x.k === 'Call' && x.callee.k === 'Member' && x.callee.prop === 'push' && x.callee.obj.k === 'Id' && x.callee.obj.name === name) pushes++; });
+    walk(body, (x) => {
+      if (x.k !== 'For' || !x.init || !x.test || !x.update) return;
+      const stmts = x.body.k === 'Block' ? x.body.body : [x.body];
+      if (!stmts.some((st) => isPush(st, name))) return;
+      const init = x.init.k === 'VarDecl' ? (x.init.decls.length === 1 ? { name: x.init.decls[0].name, v: x.init.decls[0].init } : null)
+        : (x.init.k === 'ExprStmt' && x.init.expr.k === 'Assign' && x.init.expr.op === '=' && x.init.expr.target.k === 'Id' ? { name: x.init.expr.target.name, v: x.init.expr.value } : null);
+      const t = x.test, u = x.update;
+      const step1 = (u.k === 'Update' && u.op === '++' && u.target.k === 'Id') || (u.k === 'Assign' && u.op === '+=' && u.target.k === 'Id' && u.value.k === 'Num' && u.value.v === 1);
+      if (!init || !init.v || init.v.k !== 'Num' || init.v.v !== 0 || !step1 || u.target.name !== init.name) return;
+      if (t.k !== 'Binary' || t.op !== '<' || t.l.k !== 'Id' || t.l.name !== init.name) return;
+      if (stmts.filter((st) => isPush(st, name)).length !== 1 || containsKind(x.body, 'Break') || containsKind(x.body, 'Continue') || containsKind(x.body, 'Return')) return;
+      if (assignedNames(x.body).has(init.name)) return;
+      where = { loop: x, counter: init.name, bound: t.r };
+    });
+    if (where && pushes === 1) plan[name] = where;
+  }
+  const names = Object.keys(plan);
+  if (!names.length) return fn;
+  const go = (node) => {
+    if (!node || typeof node !== 'object') return node;
+    if (Array.isArray(node)) return node.map(go);
+    if (node.k === 'VarDecl') return { k: 'VarDecl', kind: node.kind, decls: node.decls.map((d) => (plan[d.name] && d.init && d.init.k === 'ArrayLit' && d.init.elems.length === 0)
+      ? { name: d.name, init: { k: 'NewArray', len: plan[d.name].bound, fill: null } } : { name: d.name, init: go(d.init) }) };
+    for (const nm of names) if (isPush(node, nm)) return { k: 'ExprStmt', expr: { k: 'Assign', op: '=', target: { k: 'Index', obj: { k: 'Id', name: nm }, idx: { k: 'Id', name: plan[nm].counter } }, value: go(node.expr.args[0]) } };
+    const o = {};
+    for (const key of Object.keys(node)) o[key] = key === 'k' ? node.k : go(node[key]);
+    return o;
+  };
+  return { params: fn.params, body: go(body) };
+}
+
+function parseFunctionSource(src) { const P = new Parser(tokenize(src)); return uniquifyBlockScoped(rewritePushLoops(P.parseFunction()), P); }
 
 // ---- modern-JavaScript sugar, rewritten into the core subset before translation ---------------------------------------
 // a side-effect free path: name, name.prop, name[i] ...

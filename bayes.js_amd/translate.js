@@ -18,7 +18,8 @@
  *     (`({mu, sigma}, {x}) => ...`, `const [a, , b] = state.theta`), `for (const x of arr)`, `arr.forEach(cb)` as a statement
  *     (`return` inside the callback = continue), `arr.reduce(cb, init)` anywhere in the expressions of a statement
  *     (callback parameters and locals are renamed apart; the reduce becomes its own sequential accumulator, as in JS),
- *     `arr.map(cb)`, `Array(n)`, `new Array(n)`, `Array(n).fill(v)` as local arrays of a length known when the sampler is built (<= 2048).
+ *     `arr.map(cb)`, `Array(n)`, `new Array(n)`, `Array(n).fill(v)` as local arrays of a length known when the sampler is built (<= 2048);
+ *     `var a = []` grown by one `a.push(v)` per iteration of a counted loop from 0 (the same thing); let/const block scoping.
  * Anything else throws a string that says what is not supported (no CPU fallback).  Array reads are not bounds-checked
  * (JavaScript yields undefined -> NaN for an out-of-range index; here only run-time indices into local arrays are checked).
  *

@@ -91,7 +91,8 @@ function generator(rnd) {
     if (r < 0.18) return 'for (const rw of d.rows) { if (rw.tag === "u") lp += rw.val * ' + e() + ' * 1e-3; else if (rw.tag !== "w") { lp -= rw.sub.q * 1e-3; } switch (rw.tag) { case "v": lp += 1e-4; break; case "zz": lp += 1; break; default: lp -= 1e-4; } }';
     if (r < 0.22) return 'for (let i = 0; i < d.rows.length; i++) { const rw = d.rows[i]; const q = [rw.val, ' + e({ i: 'i' }) + ']; lp += (q[0] - q[1]) * rw.sub.q * 1e-3; }';    // block-scoped names reused across blocks
     if (r < 0.25) return '{ const q = ' + e() + '; let rw = q * 2; lp += (q + rw) * 1e-4; }';
-    if (r < 0.30) return 'for (const xv' + k + ' of d.x) { lp += (xv' + k + ' * ' + withT(e(), 'xv' + k) + ') * 1e-3; }';
+    if (r < 0.29) return 'var pa' + k + ' = []; for (var i = 0; i < d.x.length; i++) { var t = d.x[i] * 2; pa' + k + '.push(' + e({ i: 'i' }) + ' + t); }\n  lp += pa' + k + '[d.n[3] % 8] * 1e-3; s.r' + k + ' = pa' + k + '[2] - pa' + k + '.length;';
+    if (r < 0.33) return 'for (const xv' + k + ' of d.x) { lp += (xv' + k + ' * ' + withT(e(), 'xv' + k) + ') * 1e-3; }';
     if (r < 0.3) return 'd.x.forEach(function (xe, ie) { if ' + withT(c({ i: 'ie' }), 'xe') + ' return; lp += (xe + ' + withT(e({ i: 'ie' }), 'xe') + ') * 1e-3; });';
     if (r < 0.45) return 'lp += d.x.reduce((ac, xe, ie) => ac + ' + withT(e({ i: 'ie' }), 'xe') + ' * 1e-3, ' + withT(e(), 's.a') + ') * 1e-2;';
     if (r < 0.55) return 'const { a: pa' + k + ', v: [pv' + k + ', , pw' + k + '] } = s;\n  lp += (pa' + k + ' * pv' + k + ' - pw' + k + ') * 1e-3;';
