@@ -381,6 +381,7 @@ Translator.prototype.member = function (objV, prop) {
   }
   if (objV.t === 'ns') {
     if (objV.name === 'Math' && Object.prototype.hasOwnProperty.call(MATH_CONST, prop)) return cnum(MATH_CONST[prop]);
+    if (objV.name === 'Number' && ['EPSILON', 'MAX_VALUE', 'MIN_VALUE', 'MAX_SAFE_INTEGER', 'MIN_SAFE_INTEGER', 'POSITIVE_INFINITY', 'NEGATIVE_INFINITY', 'NaN'].indexOf(prop) >= 0) return cnum(Number[prop]);
     return { t: 'fn', ns: objV.name, name: prop };
   }
   this.fail("cannot read property '" + prop + "' of a " + this.describe(objV));
@@ -567,6 +568,13 @@ Translator.prototype.callInner = function (e) {
   const args = e.args.map((a) => this.expr(a));
   const nums = () => args.map((a) => { if (a.t !== 'num' && a.t !== 'bool') this.fail(f.ns + '.' + f.name + ' got a ' + this.describe(a) + ' argument (only scalar arguments are supported)'); return a; });
   const allConst = () => args.every((a) => a.cst !== undefined && a.t === 'num');
+  if (f.ns === 'Number' && (f.name === 'isInteger' || f.name === 'isSafeInteger')) {
+    if (args.length !== 1 || (args[0].t !== 'num' && args[0].t !== 'bool')) this.fail('Number.' + f.name + ' takes one number');
+    if (args[0].t === 'bool') return { t: 'bool', code: 'false', cst: false };
+    if (args[0].cst !== undefined) { const r = Number[f.name](args[0].cst); return { t: 'bool', code: r ? 'true' : 'false', cst: r }; }
+    const x = this.temp(this.asD(args[0]));
+    return { t: 'bool', code: '(__builtin_fabs(' + x + ') < ' + (f.name === 'isInteger' ? 'kInf' : '9007199254740992.0') + ' && __builtin_trunc(' + x + ') == ' + x + ')' };
+  }
   if (f.ns === 'global' || (f.ns === 'Number' && (f.name === 'isNaN' || f.name === 'isFinite'))) {
     if (args.length !== 1 || args[0].t !== 'num') this.fail(f.name + ' takes one number');
     if (args[0].cst !== undefined) { const r = f.name === 'isNaN' ? Number.isNaN(args[0].cst) : Number.isFinite(args[0].cst); return { t: 'bool', code: r ? 'true' : 'false', cst: r }; }

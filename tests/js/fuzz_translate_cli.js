@@ -18,7 +18,7 @@ const bits = (v) => { const b = Buffer.alloc(8); b.writeDoubleBE(v); return b.to
 
 function generator(rnd) {
   const pick = (a) => a[Math.floor(rnd() * a.length)];
-  const lit = () => pick(['0', '1', '2', '3', '(-1)', '0.5', '(-2.5)', '1e-3', '7', '10', '0.1', '1.5', '100', '(-0)', '3.25', '1e10', '4', '6', '0.25']);
+  const lit = () => pick(['Number.EPSILON', 'Number.MAX_SAFE_INTEGER', '0', '1', '2', '3', '(-1)', '0.5', '(-2.5)', '1e-3', '7', '10', '0.1', '1.5', '100', '(-0)', '3.25', '1e10', '4', '6', '0.25']);
   // leaves: real params a, b (b > 0), int param k in 0..6, binary z, vector v[3]; data x[8] doubles, n[8] small ints, m[2][3] doubles
   const leafD = (ctx) => pick(['s.a', 's.b', 's.v[0]', 's.v[1]', 's.v[2]', 'd.x[' + Math.floor(rnd() * 8) + ']', 'd.m[' + Math.floor(rnd() * 2) + '][' + Math.floor(rnd() * 3) + ']', lit(), lit()]
     .concat(ctx.i ? ['d.x[' + ctx.i + ']', 'd.x[' + ctx.i + ']', 't', 'd.x[(' + ctx.i + ' * 3 + 1) % 8]', 'd.m[' + ctx.i + ' % 2][(' + ctx.i + ' + s.k) % 3]', 's.v[' + ctx.i + ' % 3]'] : []));
@@ -60,7 +60,7 @@ function generator(rnd) {
     if (depth <= 0 || r < 0.55) return '(' + num(depth - 1, ctx) + ' ' + pick(['<', '>', '<=', '>=', '===', '!==', '==', '!=']) + ' ' + num(depth - 1, ctx) + ')';
     if (r < 0.75) return '(' + cond(depth - 1, ctx) + ' ' + pick(['&&', '||']) + ' ' + cond(depth - 1, ctx) + ')';
     if (r < 0.85) return '(!' + cond(depth - 1, ctx) + ')';
-    if (r < 0.92) return pick(['isNaN', 'isFinite']) + '(' + num(depth - 1, ctx) + ')';
+    if (r < 0.92) return pick(['isNaN', 'isFinite', 'Number.isInteger', 'Number.isSafeInteger', 'Number.isNaN']) + '(' + num(depth - 1, ctx) + ')';
     return '(s.z === ' + pick(['0', '1']) + ')';
   }
   function block(k) {     // statement templates around random expressions
