@@ -619,6 +619,28 @@ CASES.categorical_arms = {
   schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
 };
 
+// ---- edge-of-the-domain sampler configurations: degenerate bounds, proposal scales that overflow, batch size 1, accept-rate targets 0
+// and 1, a closure that is -Infinity / NaN on part of the space, thinning longer than the run, empty burn / sample calls.  Pinned against
+// the reference through the oracle on the CPU (tests/test_translate.py); the GPU run of these is for the next round (tests/js/test_gpu_user.js
+// skips names starting with cfgedge_).
+function makeEdgeCase(index) {
+  const cases = [
+    { params: { a: { lower: 2, upper: 2, init: 2 }, b: {} }, body: 'var lp = ld.norm(s.b, s.a, 1); return lp;', options: {} },
+    { params: { a: {}, k: { type: 'int', lower: 0, upper: 3 } }, body: 'var lp = ld.norm(s.a, 0, 1) + ld.pois(s.k, 0.2); return lp;', options: { prop_log_scale: 700 } },
+    { params: { a: {}, b: { lower: 0 } }, body: 'var lp = ld.norm(s.a, 0, 1) + ld.gamma(s.b, 2, 1); return lp;', options: { prop_log_scale: 720, batch_size: 1 } },
+    { params: { a: { init: -1 } }, body: 'if (s.a < 0) return -Infinity; return ld.exp(s.a, 1);', options: { batch_size: 1, target_accept_rate: 1 } },
+    { params: { a: { init: 0.5 }, z: { type: 'binary' } }, body: 'var lp = ld.unif(s.a, 0, 1) + ld.bern(s.z, 0.5); if (s.z === 1 && s.a > 0.9) return NaN; return lp + Math.log(s.a);', options: { target_accept_rate: 0, initial_adaptation: 5, max_adaptation: 4 } },
+    { params: { v: { dim: [2, 2], lower: -1, upper: 1, init: 0 } }, body: 'var lp = 0; for (var i = 0; i < 2; i++) for (var j = 0; j < 2; j++) lp += ld.norm(s.v[i][j], 0, 0.1) - 1e300 * (s.v[i][j] > 0.99 ? 1 : 0); return lp;', options: { prop_log_scale: [[5, -5], [0, 50]], batch_size: 3 } },
+    { params: { k: { type: 'int', lower: -1, upper: 1, init: 0 }, a: {} }, body: 'var lp = ld.norm(s.a, s.k, 1) + (s.k === 0 ? 0 : -0.5); return lp;', options: { prop_log_scale: -3, batch_size: 2, is_adapting: false } },
+    { params: { a: { lower: 0, init: 1e-300 } }, body: 'return ld.lnorm(s.a, 0, 3);', options: { prop_log_scale: -690 } },
+  ];
+  const c = cases[index];
+  const log_post = new Function('return function (s, d) {\n  ' + c.body + '\n};')();
+  const schedule = [{ op: 'burn', n: 0 }, { op: 'burn', n: 37 }, { op: 'sample', n: 0 }, { op: 'sample', n: 25, thin: 40 }, { op: 'stop' }, { op: 'sample', n: 30, thin: 7 }, { op: 'start' }, { op: 'sample', n: 41, thin: 1, keep: 41 }];
+  return { params: () => c.params, data: () => ({}), log_post, options: c.options, schedule, chains: [0, 5] };
+}
+for (let k = 0; k < 8; k++) CASES['cfgedge_' + k] = makeEdgeCase(k);
+
 function build(name, seed) {
   const c = CASES[name] || BENCH[name];
   if (!c) throw new Error('unknown user model ' + name);
