@@ -143,7 +143,7 @@ assert.throws(() => new mcmc.AmwgSampler({ mu: { type: 'complex', init: 1 }, sig
     const untag = (k, v) => (v === '__inf' ? Infinity : v === '__-inf' ? -Infinity : v === '__nan' ? NaN : v === '__-0' ? -0 : v);
     const flat = (v) => { const o = []; (function r(x) { Array.isArray(x) ? x.forEach(r) : o.push(x); })(v); return o; };
     let checked = 0;
-    for (const name of um.names.filter((n) => /^cfgfuzz_/.test(n))) {
+    for (const name of um.names.filter((n) => /^cfg(fuzz|edge)_/.test(n))) {
       const m = um.build(name), rec = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'golden', 'user_' + name + '.json'), 'utf8'), untag).chains[0];
       const done = mcmc.complete_params(m.params, mcmc.param_init_fixed);
       assert.deepStrictEqual(Object.keys(done).map((k) => ({ name: k, type: done[k].type, dim: done[k].dim, lower: done[k].lower, upper: done[k].upper, init: flat(done[k].init) })), rec.params_completed, name);
