@@ -19,7 +19,6 @@ const only = process.argv.slice(2);
 
 for (const name of um.names) {
   if (only.length && only.indexOf(name) < 0) continue;
-  if (!only.length && /^cfgedge_/.test(name)) continue;      // edge-of-the-domain configurations: pinned through the oracle on the CPU this round (see user_models.js)
   const m = um.build(name);
   for (const k of Object.keys(m.helpers || {})) global[k] = m.helpers[k];      // the host-side closure needs them too
   for (const k of Object.keys(m.constants || {})) global[k] = m.constants[k];

@@ -620,9 +620,7 @@ CASES.categorical_arms = {
 };
 
 // ---- edge-of-the-domain sampler configurations: degenerate bounds, proposal scales that overflow, batch size 1, accept-rate targets 0
-// and 1, a closure that is -Infinity / NaN on part of the space, thinning longer than the run, empty burn / sample calls.  Pinned against
-// the reference through the oracle on the CPU (tests/test_translate.py); the GPU run of these is for the next round (tests/js/test_gpu_user.js
-// skips names starting with cfgedge_).
+// and 1, a closure that is -Infinity / NaN on part of the space, thinning longer than the run, empty burn / sample calls.
 function makeEdgeCase(index) {
   const cases = [
     { params: { a: { lower: 2, upper: 2, init: 2 }, b: {} }, body: 'var lp = ld.norm(s.b, s.a, 1); return lp;', options: {} },
