@@ -325,8 +325,18 @@ Translator.prototype.lookup = function (name) {
     if (typeof gv === 'number' || typeof gv === 'boolean' || Array.isArray(gv) || ArrayBuffer.isView(gv) || (gv && typeof gv === 'object'))
       return this.dataValue('#global:' + name, gv);
   }
+  // name every free variable of the closure at once (the user fixes them in one go)
+  const known = new Set(['ld', 'Math', 'Number', 'isNaN', 'isFinite', 'Infinity', 'NaN', 'Array', name]);
+  const declared = declaredIn(this.ast.body, new Set(this.ast.params));
+  walk(this.ast.body, (x) => { if (x.k === 'Assign' && x.target.k === 'Id') declared.add(x.target.name); if (x.k === 'Func') x.params.forEach((q) => declared.add(q)); });
+  const callees = new Set();
+  walk(this.ast.body, (x) => { if (x.k === 'Call' && x.callee.k === 'Id') callees.add(x.callee.name); });
+  const missing = [name];
+  for (const nm of idsOf(this.ast.body)) if (!known.has(nm) && !declared.has(nm) && !this.isStateName(nm) && nm !== this.dataName && this.freeValue(nm) === undefined) missing.push(nm);
+  const fns = missing.filter((nm) => callees.has(nm)), vals = missing.filter((nm) => !callees.has(nm));
   this.fail("'" + name + "' is not defined inside log_post (free variables of the closure are invisible to the translator unless they are " +
-            'globals: pass numbers/arrays in options.constants and functions in options.helpers)');
+            'globals: pass numbers/arrays in options.constants and functions in options.helpers)' +
+            (missing.length > 1 || fns.length ? '; this closure needs ' + [vals.length ? 'constants: {' + vals.join(', ') + '}' : '', fns.length ? 'helpers: {' + fns.join(', ') + '}' : ''].filter(Boolean).join(', ') : ''));
 };
 
 Translator.prototype.dataValue = function (path, v) {
