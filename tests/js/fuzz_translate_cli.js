@@ -20,8 +20,8 @@ function generator(rnd) {
   const pick = (a) => a[Math.floor(rnd() * a.length)];
   const lit = () => pick(['Number.EPSILON', 'Number.MAX_SAFE_INTEGER', '0', '1', '2', '3', '(-1)', '0.5', '(-2.5)', '1e-3', '7', '10', '0.1', '1.5', '100', '(-0)', '3.25', '1e10', '4', '6', '0.25']);
   // leaves: real params a, b (b > 0), int param k in 0..6, binary z, vector v[3]; data x[8] doubles, n[8] small ints, m[2][3] doubles
-  const leafD = (ctx) => pick(['s.a', 's.b', 's.v[0]', 's.v[1]', 's.v[2]', 'd.x[' + Math.floor(rnd() * 8) + ']', 'd.m[' + Math.floor(rnd() * 2) + '][' + Math.floor(rnd() * 3) + ']', lit(), lit()]
-    .concat(ctx.i ? ['d.x[' + ctx.i + ']', 'd.x[' + ctx.i + ']', 't', 'd.x[(' + ctx.i + ' * 3 + 1) % 8]', 'd.m[' + ctx.i + ' % 2][(' + ctx.i + ' + s.k) % 3]', 's.v[' + ctx.i + ' % 3]'] : []));
+  const leafD = (ctx) => pick(['s.a', 's.b', 's.v[0]', 's.v[1]', 's.v[2]', 's.w[1][2]', 's.w[s.z][s.k % 3]', 's.w[0][' + Math.floor(rnd() * 3) + ']', 'd.x[' + Math.floor(rnd() * 8) + ']', 'd.m[' + Math.floor(rnd() * 2) + '][' + Math.floor(rnd() * 3) + ']', lit(), lit()]
+    .concat(ctx.i ? ['s.w[' + ctx.i + ' % 2][(' + ctx.i + ' + s.k) % 3]', 'd.x[' + ctx.i + ']', 'd.x[' + ctx.i + ']', 't', 'd.x[(' + ctx.i + ' * 3 + 1) % 8]', 'd.m[' + ctx.i + ' % 2][(' + ctx.i + ' + s.k) % 3]', 's.v[' + ctx.i + ' % 3]'] : []));
   const leafI = (ctx) => pick(['s.k', 's.z', 'd.n[' + Math.floor(rnd() * 8) + ']', String(Math.floor(rnd() * 9)), 'd.x.length'].concat(ctx.i ? [ctx.i, ctx.i, 'd.n[' + ctx.i + ']', '(' + ctx.i + ' * d.n[7 - ' + ctx.i + '])', '(d.n[' + ctx.i + '] % 3)'] : []));
   function num(depth, ctx) {
     if (depth <= 0 || rnd() < 0.18) return rnd() < 0.7 ? leafD(ctx) : leafI(ctx);
@@ -110,7 +110,7 @@ function generator(rnd) {
 function stateFrom(rnd, t) {
   const special = [0, -0, 1, -1, 0.5, 2, 1e-8, 30, -30, 3];
   const real = () => (rnd() < 0.15 ? special[Math.floor(rnd() * special.length)] : (rnd() - 0.5) * (rnd() < 0.3 ? 40 : 4));
-  return { a: t === 0 ? 0.5 : real(), b: Math.abs(real()) + (rnd() < 0.1 ? 0 : 0.05), v: [real(), real(), real()], k: Math.floor(rnd() * 7), z: rnd() < 0.5 ? 0 : 1 };
+  return { a: t === 0 ? 0.5 : real(), b: Math.abs(real()) + (rnd() < 0.1 ? 0 : 0.05), v: [real(), real(), real()], k: Math.floor(rnd() * 7), z: rnd() < 0.5 ? 0 : 1, w: [[real(), real(), real()], [real(), real(), real()]] };
 }
 
 const names = [];
@@ -140,7 +140,7 @@ for (let mk = 0; mk < nModels; mk++) {
   const fn = new Function('ld', src)(ld);
   const data = { x: [], n: [], m: [[0.5, -1.25, 3], [2, 0, -0.75]], rows: [] };
   for (let i = 0; i < 8; i++) { data.x.push(i === 3 ? 0 : (rnd() - 0.4) * 6); data.n.push(Math.floor(rnd() * 11)); data.rows.push({ val: (rnd() - 0.5) * 3, tag: ['u', 'v', 'w'][Math.floor(rnd() * 3)], sub: { q: Math.floor(rnd() * 5) } }); }
-  const params = mcmc.complete_params({ a: {}, b: { lower: 0 }, v: { dim: [3] }, k: { type: 'int', lower: 0, upper: 6 }, z: { type: 'binary' } }, mcmc.param_init_fixed);
+  const params = mcmc.complete_params({ a: {}, b: { lower: 0 }, v: { dim: [3] }, k: { type: 'int', lower: 0, upper: 6 }, z: { type: 'binary' }, w: { dim: [2, 3] } }, mcmc.param_init_fixed);
   const name = 'fuzz_' + seed0 + '_' + mk;
   fs.writeFileSync(path.join(out, name + '.js'), src);
   let tr;
@@ -158,7 +158,7 @@ for (let mk = 0; mk < nModels; mk++) {
   const pts = [];
   for (let t = 0; t < 40; t++) {
     const st = stateFrom(rnd, t);
-    const flat = [st.a, st.b, st.v[0], st.v[1], st.v[2], st.k, st.z];
+    const flat = [st.a, st.b, st.v[0], st.v[1], st.v[2], st.k, st.z, st.w[0][0], st.w[0][1], st.w[0][2], st.w[1][0], st.w[1][1], st.w[1][2]];
     const lp = fn(st, data);
     pts.push({ state: flat.map(bits), lp: bits(lp), derived: tr.derived.map((k) => bits(st[k])) });
   }

@@ -174,17 +174,19 @@ def test_fuzzed_closures_on_the_device_equal_v8(lanes):
             continue
         pts = user_host.stepper_states(name)
         f64 = lambda h: float(np.frombuffer(bytes.fromhex(h), dtype=">f8")[0])
-        states = np.array([[f64(h) for h in pt["state"]] for pt in pts])            # [40][7]: a, b, v[3], k, z
+        states = np.array([[f64(h) for h in pt["state"]] for pt in pts])            # [40][13]: a, b, v[3], k, z, w[2][3]
         params = [{"type": "real", "len": 1, "top": 1, "multidim": 0, "lower": -INF, "upper": INF}, {"type": "real", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": INF},
                   {"type": "real", "len": 3, "top": 3, "multidim": 1, "lower": -INF, "upper": INF}, {"type": "int", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": 6.0},
-                  {"type": "binary", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": 1.0}]
-        opts = [{"prop_log_scale": 0.0, "max_adaptation": 0.33, "initial_adaptation": 1.0, "target_accept_rate": 0.44, "batch_size": 50, "is_adapting": True}] * 7
-        spec = {"user": user_host.user_spec_part(m.source, m.arrays, m.meta), "params": params, "P": 7, "init": states[0].tolist(), "comp_opts": opts}
+                  {"type": "binary", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": 1.0},
+                  {"type": "real", "len": 6, "top": 2, "multidim": 1, "lower": -INF, "upper": INF}]
+        NP = 13
+        opts = [{"prop_log_scale": 0.0, "max_adaptation": 0.33, "initial_adaptation": 1.0, "target_accept_rate": 0.44, "batch_size": 50, "is_adapting": True}] * NP
+        spec = {"user": user_host.user_spec_part(m.source, m.arrays, m.meta), "params": params, "P": NP, "init": states[0].tolist(), "comp_opts": opts}
         s = A.Sampler(spec, chains=len(pts), seed=1, lanes_per_chain=lanes)
         s.set_state(np.ascontiguousarray(states.T))
         lp = s.diag()["log_post"]
         draws = s.sample(1, 1)
-        assert draws[0, :7, :].tobytes() == np.ascontiguousarray(states.T).tobytes()
+        assert draws[0, :NP, :].tobytes() == np.ascontiguousarray(states.T).tobytes()
         for c, pt in enumerate(pts):
             if lanes == 1:
                 want_lp, want_dv = f64(pt["lp"]), [f64(h) for h in pt["derived"]]
@@ -192,6 +194,6 @@ def test_fuzzed_closures_on_the_device_equal_v8(lanes):
                 want_lp, want_dv = m.eval(states[c], lanes, derived=True)
             same = lambda a, b: (a != a and b != b) or np.float64(a).tobytes() == np.float64(b).tobytes()
             assert same(lp[c], want_lp), (name, lanes, c, lp[c], want_lp)
-            got_dv = draws[0, 7:, c].tolist()
+            got_dv = draws[0, NP:, c].tolist()
             assert len(got_dv) == len(want_dv) and all(same(a, b) for a, b in zip(got_dv, want_dv)), (name, lanes, c)
         s.close()
