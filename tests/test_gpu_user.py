@@ -70,7 +70,8 @@ def test_device_lane_sum_equals_host_emulation(name, lanes):
 
 
 @pytest.mark.parametrize("name,lanes", [("complex_model", 4), ("spike_slab", 8), ("hier_binomial", 2), ("norm_post_derived", 16), ("survival_mix", 4),
-                                        ("complex_model", 128), ("norm_post_derived", 256), ("spike_slab", 256)])
+                                        ("complex_model", 128), ("norm_post_derived", 256), ("spike_slab", 256),
+                                        ("structured_helpers", 8), ("records_logistic", 2), ("modern_js", 1)])
 def test_g_lane_trajectories_equal_oracle_stepper_with_same_lane_order(name, lanes):
     """Whole trajectories with G lanes per chain: the device == the C oracle's stepper calling the host build of the same
     generated text in the same lane order (test_translate.py pins that pair against the reference at one lane)."""
