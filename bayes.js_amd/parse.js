@@ -3,7 +3,15 @@
  * parse.js -- the front half of the log_post translator (translate.js): tokenizer, recursive-descent parser for the numeric
  * JavaScript subset, the rewriting of post-ES5 spellings (destructuring, for-of, forEach / reduce / map, Array(n).fill(v), switch,
  * do-while, helpers that are handed objects) into the core subset, and the AST walks the translator's analyses use.
- * AST nodes are plain objects {k: kind, ...}; see Parser.prototype for the kinds.
+ * AST nodes are plain objects {k: kind, ...}:
+ *   statements   Block{body} VarDecl{kind, decls:[{name, init}]} ExprStmt{expr} If{test, cons, alt} For{init, test, update, body}
+ *                (while and do-while are For nodes) Return{arg} Break Continue Empty
+ *   expressions  Num{v} Str{v} Bool{v} Id{name} Member{obj, prop} Index{obj, idx} Call{callee, args} Unary{op, arg}
+ *                Binary{op, l, r} Logical{op, l, r} Cond{test, a, b} Assign{op, target, value} Update{op, prefix, target}
+ *                Seq{l, r} ArrayLit{elems} Func{params, body} NewArray{len, fill}
+ * Order of the passes in parseFunctionSource: parse (destructuring, for-of, switch, do-while are rewritten on the fly) ->
+ * desugarBlock (forEach / reduce / map / Array(n) hoisting) -> rewritePushLoops -> uniquifyBlockScoped.  The translator runs
+ * desugarBlock once more with P.env set, to inline helpers that are handed the state or the data.
  */
 // ------------------------------------------------------------------------------------------
 // tokenizer
