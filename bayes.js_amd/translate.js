@@ -20,8 +20,9 @@
  *     (callback parameters and locals are renamed apart; the reduce becomes its own sequential accumulator, as in JS),
  *     `arr.map(cb)`, `Array(n)`, `new Array(n)`, `Array(n).fill(v)` as local arrays of a length known when the sampler is built (<= 2048);
  *     `var a = []` grown by one `a.push(v)` per iteration of a counted loop from 0 (the same thing); let/const block scoping.
- * Anything else throws a string that says what is not supported (no CPU fallback).  Array reads are not bounds-checked
- * (JavaScript yields undefined -> NaN for an out-of-range index; here only run-time indices into local arrays are checked).
+ * Anything else throws a string that says what is not supported (no CPU fallback).  A read outside an array, or with a non-integer
+ * index, yields NaN as in JavaScript (undefined in arithmetic) and touches no memory; indices that provably stay inside (loop counters,
+ * elements of integer data arrays, + - * % of those) are not checked at run time.
  *
  * Fidelity.  Every JavaScript number operation becomes the same IEEE fp64 operation in the same
  * order (the kernel is compiled with -ffp-contract=off); Math.exp/log are the bit-identical V8
@@ -277,6 +278,10 @@ const cnum = (v) => {
   const isInt = Number.isInteger(v) && Math.abs(v) < 2147483648 && !(v === 0 && 1 / v < 0);
   return { t: 'num', code: isInt ? String(v) : hexFloat(v), int: isInt, cst: v };
 };
+// integer interval a value is known to lie in at translation time (loop counters of constant bounds, elements of integer data arrays,
+// + - * % of those); null = unknown.  Array reads whose index provably stays inside need no run-time check.
+const rangeOf = (v) => (v && v.t === 'num' ? (v.cst !== undefined ? (Number.isInteger(v.cst) ? [v.cst, v.cst] : null) : (v.int && v.range ? v.range : null)) : null);
+const withRange = (v, r) => { if (r && Number.isFinite(r[0]) && Number.isFinite(r[1]) && Math.abs(r[0]) < 2147483648 && Math.abs(r[1]) < 2147483648) v.range = r; return v; };
 Translator.prototype.asD = function (v) {
   if (v.t === 'num') {
     if (v.cst !== undefined) return hexFloat(v.cst);
@@ -305,7 +310,8 @@ Translator.prototype.lookup = function (name) {
       !Object.prototype.hasOwnProperty.call(this.localTypes, name) && this.freeValue(name) === this.opts.state_object) return { t: 'stateObj' };
   if (this.dataName && name === this.dataName) return this.dataValue('', this.data);
   if (Object.prototype.hasOwnProperty.call(this.aliases, name)) return this.aliases[name];
-  if (Object.prototype.hasOwnProperty.call(this.localTypes, name)) return num('v_' + name, this.localTypes[name] === 'int', undefined, '(double)v_' + name);
+  if (Object.prototype.hasOwnProperty.call(this.localTypes, name))
+    return withRange(num('v_' + name, this.localTypes[name] === 'int', undefined, '(double)v_' + name), this.counterRange && this.counterRange[name]);
   if (name === 'ld') return { t: 'ns', name: 'ld' };
   if (name === 'Math') return { t: 'ns', name: 'Math' };
   if (name === 'isNaN' || name === 'isFinite') return { t: 'fn', ns: 'global', name };
@@ -414,16 +420,34 @@ Translator.prototype.index = function (objV, idxV) {
   if (objV.t === 'recArr') {
     if (idxV.t !== 'num') this.fail('a ' + this.describe(idxV) + ' is used as an array index');
     if (idxV.cst !== undefined && (!Number.isInteger(idxV.cst) || idxV.cst < 0 || idxV.cst >= objV.value.length)) this.fail('constant index ' + idxV.cst + ' is outside an array of length ' + objV.value.length);
-    return { t: 'rec', arr: objV, idx: idxV.cst !== undefined ? idxV : num(this.temp_int(this.asI(idxV)), true) };
+    if (idxV.cst !== undefined) return { t: 'rec', arr: objV, idx: idxV };
+    if (idxV.int) return { t: 'rec', arr: objV, idx: withRange(num(this.temp_int(this.asI(idxV)), true), rangeOf(idxV)) };
+    return { t: 'rec', arr: objV, idx: idxV };        // a non-integer-typed index: checked (range, integrality) when a field is read
   }
   if (objV.t !== 'dataArr' && objV.t !== 'stateArr') this.fail('indexing a ' + this.describe(objV));
   const dims = objV.dims, inner = dims.slice(1).reduce((a, b) => a * b, 1);
   let off;
+  let guards = objV.guards || [];
   if (idxV.cst !== undefined && Number.isInteger(idxV.cst)) {
-    if (idxV.cst < 0 || idxV.cst >= dims[0]) this.fail('constant index ' + idxV.cst + ' is outside an array of length ' + dims[0]);
+    if (idxV.cst < 0 || idxV.cst >= dims[0]) {
+      if (dims.length === 1) return cnum(NaN);         // x[n] is undefined in JavaScript: NaN in arithmetic
+      this.fail('constant index ' + idxV.cst + ' is outside an array of ' + dims[0] + ' rows (JavaScript would throw on the next index)');
+    }
     off = idxV.cst * inner;
   } else {
-    const i = this.asI(idxV);
+    // JavaScript reads `undefined` (NaN in arithmetic) outside the array and for a non-integer index; nothing is read from memory then.
+    // Indices that provably stay inside (loop counters, elements of integer data arrays, + - * % of those) need no check.
+    if (idxV.t !== 'num') this.fail('a ' + this.describe(idxV) + ' is used as an array index');
+    const rg = rangeOf(idxV);
+    let i;
+    if (idxV.int) {
+      i = this.asI(idxV);
+      if (!(rg && rg[0] >= 0 && rg[1] < dims[0])) { i = this.temp_int(i); guards = guards.concat(['(unsigned)' + i + ' < ' + dims[0] + 'u']); }
+    } else {
+      const dv = this.temp(this.asD(idxV));
+      guards = guards.concat(['(' + dv + ' >= 0.0 && ' + dv + ' < ' + dims[0] + '.0 && ' + dv + ' == __builtin_trunc(' + dv + '))']);
+      i = this.temp_int('(' + guards[guards.length - 1] + ' ? (int)' + dv + ' : 0)');
+    }
     off = inner === 1 ? i : '(' + i + ') * ' + inner;
   }
   const base = objV.t === 'dataArr' ? objV.off : objV.base;
@@ -431,16 +455,23 @@ Translator.prototype.index = function (objV, idxV) {
   if (typeof off === 'number' && /^\d+$/.test(base)) sum = String(Number(base) + off);
   else if (base === '0') sum = String(off);
   else sum = base + ' + ' + off;
-  if (dims.length > 1) return objV.t === 'dataArr' ? { t: 'dataArr', id: objV.id, off: sum, dims: dims.slice(1) } : { t: 'stateArr', base: sum, dims: dims.slice(1) };
+  const G = guards.length ? guards : undefined;
+  if (dims.length > 1) return objV.t === 'dataArr' ? { t: 'dataArr', id: objV.id, off: sum, dims: dims.slice(1), guards: G } : { t: 'stateArr', base: sum, dims: dims.slice(1), guards: G };
+  const guarded = (code) => num('((' + guards.join(' && ') + ') ? ' + code + ' : __builtin_nan(""))', false);
   if (objV.t === 'dataArr') {
     // a constant element of a data array is a constant
-    if (/^\d+$/.test(sum)) return cnum(this.arrays[objV.id].flat[Number(sum)]);
+    if (/^\d+$/.test(sum) && !G) return cnum(this.arrays[objV.id].flat[Number(sum)]);
     const A = this.arrays[objV.id];
+    if (G) return guarded((A.type === 0 ? '' : '(double)') + 'A' + objV.id + '[' + sum + ']');
     const v = A.type === 0 ? num('A' + objV.id + '[' + sum + ']', false) : num('(int)A' + objV.id + '[' + sum + ']', true, undefined, '(double)A' + objV.id + '[' + sum + ']');
+    if (A.type !== 0) {        // an element of an integer array lies between the array's extremes
+      if (!A.range) { let lo = Infinity, hi = -Infinity; for (let q = 0; q < A.flat.length; q++) { if (A.flat[q] < lo) lo = A.flat[q]; if (A.flat[q] > hi) hi = A.flat[q]; } A.range = A.flat.length ? [lo, hi] : null; }
+      withRange(v, A.range);
+    }
     v.src = { id: objV.id, off: sum };
     return v;
   }
-  return num('S(' + sum + ')', false);
+  return G ? guarded('S(' + sum + ')') : num('S(' + sum + ')', false);
 };
 
 const ARITH = { '+': (a, b) => a + b, '-': (a, b) => a - b, '*': (a, b) => a * b, '/': (a, b) => a / b, '%': (a, b) => a % b,
@@ -482,7 +513,7 @@ Translator.prototype.expr = function (e) {
       if (e.op === '+') return a;
       if (e.op === '~') return a.cst !== undefined ? cnum(~a.cst) : num('js_bitnot(' + this.asD(a) + ')', false);
       if (a.cst !== undefined) return cnum(-a.cst);
-      return a.int ? num('(-(' + a.code + '))', true, undefined, '(-(' + a.dcode + '))') : num('(-(' + a.code + '))', false);
+      return a.int ? withRange(num('(-(' + a.code + '))', true, undefined, '(-(' + a.dcode + '))'), rangeOf(a) && [-rangeOf(a)[1], -rangeOf(a)[0]]) : num('(-(' + a.code + '))', false);
     }
     case 'Binary': {
       const l = this.expr(e.l), r = this.expr(e.r);
@@ -521,10 +552,23 @@ Translator.prototype.expr = function (e) {
       if (e.op === '/') return num('(' + this.asD(l) + ' / ' + this.asD(r) + ')', false);
       if (BITOPS[e.op]) return num(BITOPS[e.op] + '(' + this.asD(l) + ', ' + this.asD(r) + ')', false);     // ToInt32 of both operands, as in JS
       if (e.op === '%') {
-        if (l.int && r.int && r.cst !== undefined && r.cst !== 0) return num('(' + l.code + ' % ' + r.code + ')', true, undefined, 'js_mod(' + this.asD(l) + ', ' + this.asD(r) + ')');
+        if (l.int && r.int && r.cst !== undefined && r.cst !== 0) {
+          const a = rangeOf(l), c = Math.abs(r.cst);      // the sign of % follows the dividend
+          const rg = a && a[0] >= 0 ? [0, Math.min(a[1], c - 1)] : [-(c - 1), c - 1];
+          return withRange(num('(' + l.code + ' % ' + r.code + ')', true, undefined, 'js_mod(' + this.asD(l) + ', ' + this.asD(r) + ')'), rg);
+        }
         return num('js_mod(' + this.asD(l) + ', ' + this.asD(r) + ')', false);
       }
-      if (l.int && r.int) return num('(' + l.code + ' ' + e.op + ' ' + r.code + ')', true, undefined, '(' + this.asD(l) + ' ' + e.op + ' ' + this.asD(r) + ')');
+      if (l.int && r.int) {
+        const a = rangeOf(l), b = rangeOf(r);
+        let rg = null;
+        if (a && b) {
+          if (e.op === '+') rg = [a[0] + b[0], a[1] + b[1]];
+          else if (e.op === '-') rg = [a[0] - b[1], a[1] - b[0]];
+          else if (e.op === '*') { const c = [a[0] * b[0], a[0] * b[1], a[1] * b[0], a[1] * b[1]]; rg = [Math.min.apply(null, c), Math.max.apply(null, c)]; }
+        }
+        return withRange(num('(' + l.code + ' ' + e.op + ' ' + r.code + ')', true, undefined, '(' + this.asD(l) + ' ' + e.op + ' ' + this.asD(r) + ')'), rg);
+      }
       return num('(' + this.asD(l) + ' ' + e.op + ' ' + this.asD(r) + ')', false);
     }
     case 'Logical': {
@@ -540,7 +584,8 @@ Translator.prototype.expr = function (e) {
       if (t.cst !== undefined) return t.cst ? a : b;
       if (a.t === 'bool' && b.t === 'bool') return { t: 'bool', code: '(' + t.code + ' ? ' + a.code + ' : ' + b.code + ')' };
       if (a.t !== 'num' || b.t !== 'num') this.fail('both branches of ?: must be numbers');
-      if (a.int && b.int) return num('(' + t.code + ' ? ' + a.code + ' : ' + b.code + ')', true, undefined, '(' + t.code + ' ? ' + this.asD(a) + ' : ' + this.asD(b) + ')');
+      if (a.int && b.int) return withRange(num('(' + t.code + ' ? ' + a.code + ' : ' + b.code + ')', true, undefined, '(' + t.code + ' ? ' + this.asD(a) + ' : ' + this.asD(b) + ')'),
+        rangeOf(a) && rangeOf(b) && [Math.min(rangeOf(a)[0], rangeOf(b)[0]), Math.max(rangeOf(a)[1], rangeOf(b)[1])]);
       return num('(' + t.code + ' ? ' + this.asD(a) + ' : ' + this.asD(b) + ')', false);
     }
     case 'Call': return this.call(e);
@@ -1092,6 +1137,11 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
     this.flush(out, indent);
     this.setLocal(canon.name, startV);
     const isInt = this.localTypes[canon.name] === 'int';
+    this.counterRange = this.counterRange || {};
+    const hadRange = this.counterRange[canon.name];
+    if (isInt && Number.isInteger(startV.cst) && Number.isInteger(boundV.cst)) this.counterRange[canon.name] = [startV.cst, canon.le ? boundV.cst : boundV.cst - 1];
+    else delete this.counterRange[canon.name];
+    L.restoreRange = () => { if (hadRange) this.counterRange[canon.name] = hadRange; else delete this.counterRange[canon.name]; };
     this.loops.push(L);
     const body = s.body.k === 'Block' ? s.body.body : [s.body];
     const bctx = { inLoop: true, split: split || ctx.split };
@@ -1112,6 +1162,7 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
       const term = this.expr(lastSt.expr.value);
       const pend = this.pending; this.pending = [];
       this.loops.pop();
+      L.restoreRange();
       const simple = body.length === 1;
       // plain arithmetic bodies keep 8 terms in flight; bodies with exp/log/ld.* calls 4 (register pressure)
       const U = this.opts.unroll || ((this.heavyLoop && !simple) || (this.heavyLoop && !heavyBefore && pend.length > 4) ? 4 : 8);
@@ -1152,6 +1203,7 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
     for (const x of body) this.stmt(x, inner, ind2, bctx);
     this.loopLabels.pop();
     this.loops.pop();
+    L.restoreRange();
     out.push(indent + '{');
     for (const p of L.preamble) out.push(indent + '  ' + p);
     const v = 'v_' + canon.name;

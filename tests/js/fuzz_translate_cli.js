@@ -20,7 +20,10 @@ function generator(rnd) {
   const pick = (a) => a[Math.floor(rnd() * a.length)];
   const lit = () => pick(['Number.EPSILON', 'Number.MAX_SAFE_INTEGER', '0', '1', '2', '3', '(-1)', '0.5', '(-2.5)', '1e-3', '7', '10', '0.1', '1.5', '100', '(-0)', '3.25', '1e10', '4', '6', '0.25']);
   // leaves: real params a, b (b > 0), int param k in 0..6, binary z, vector v[3]; data x[8] doubles, n[8] small ints, m[2][3] doubles
-  const leafD = (ctx) => pick(['s.a', 's.b', 's.v[0]', 's.v[1]', 's.v[2]', 's.w[1][2]', 's.w[s.z][s.k % 3]', 's.w[0][' + Math.floor(rnd() * 3) + ']', 'd.x[' + Math.floor(rnd() * 8) + ']', 'd.m[' + Math.floor(rnd() * 2) + '][' + Math.floor(rnd() * 3) + ']', lit(), lit()]
+  // reads that may fall outside the array or use a non-integer index: undefined in JavaScript, NaN in arithmetic
+  const wild = (ctx) => pick(['d.x[s.k + 4]', 'd.x[s.k - 2]', 'd.x[s.a]', 'd.x[s.v[0] * 2]', 's.v[d.n[' + Math.floor(rnd() * 8) + ']]', 'd.n[d.n[0]]', 's.v[s.k]', 'd.m[1][s.k]']
+    .concat(ctx.i ? ['d.x[' + ctx.i + ' + 3]', 'd.x[' + ctx.i + ' - 1]', 's.v[d.n[' + ctx.i + ']]', 'd.x[' + ctx.i + ' * 2]', 'd.x[' + ctx.i + ' / 2]'] : []));
+  const leafD = (ctx) => (rnd() < 0.06 && !ctx.calm) ? wild(ctx) : pick(['s.a', 's.b', 's.v[0]', 's.v[1]', 's.v[2]', 's.w[1][2]', 's.w[s.z][s.k % 3]', 's.w[0][' + Math.floor(rnd() * 3) + ']', 'd.x[' + Math.floor(rnd() * 8) + ']', 'd.m[' + Math.floor(rnd() * 2) + '][' + Math.floor(rnd() * 3) + ']', lit(), lit()]
     .concat(ctx.i ? ['s.w[' + ctx.i + ' % 2][(' + ctx.i + ' + s.k) % 3]', 'd.x[' + ctx.i + ']', 'd.x[' + ctx.i + ']', 't', 'd.x[(' + ctx.i + ' * 3 + 1) % 8]', 'd.m[' + ctx.i + ' % 2][(' + ctx.i + ' + s.k) % 3]', 's.v[' + ctx.i + ' % 3]'] : []));
   const leafI = (ctx) => pick(['s.k', 's.z', 'd.n[' + Math.floor(rnd() * 8) + ']', String(Math.floor(rnd() * 9)), 'd.x.length'].concat(ctx.i ? [ctx.i, ctx.i, 'd.n[' + ctx.i + ']', '(' + ctx.i + ' * d.n[7 - ' + ctx.i + '])', '(d.n[' + ctx.i + '] % 3)'] : []));
   function num(depth, ctx) {
@@ -56,6 +59,9 @@ function generator(rnd) {
     return '(' + cond(depth - 1, ctx) + ' ? 1 : 0)';
   }
   function cond(depth, ctx) {
+    // no possibly-undefined reads inside comparisons: `undefined == undefined` is true in JavaScript, NaN == NaN is not (the translator
+    // stands NaN in for undefined, which is exact in arithmetic and in every comparison with a number)
+    ctx = Object.assign({}, ctx, { calm: true });
     const r = rnd();
     if (depth <= 0 || r < 0.55) return '(' + num(depth - 1, ctx) + ' ' + pick(['<', '>', '<=', '>=', '===', '!==', '==', '!=']) + ' ' + num(depth - 1, ctx) + ')';
     if (r < 0.75) return '(' + cond(depth - 1, ctx) + ' ' + pick(['&&', '||']) + ' ' + cond(depth - 1, ctx) + ')';
