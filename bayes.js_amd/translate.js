@@ -983,9 +983,17 @@ Translator.prototype.assign = function (target, op, valueAst, out, indent, ctx) 
     const idx = this.expr(target.idx), v = this.expr(valueAst);
     if (v.t !== 'num' && v.t !== 'bool') this.fail('array elements must be numbers');
     if (idx.cst !== undefined && !(Number.isInteger(idx.cst) && idx.cst >= 0 && idx.cst < arr.elems.length)) this.fail('index ' + idx.cst + ' is outside ' + target.obj.name);
+    // a write outside the array would grow it in JavaScript; here the array has the length it was built with, such a write is dropped
+    // (never performed on memory).  Indices that provably stay inside are not checked.
+    const rg = rangeOf(idx);
+    const safe = idx.cst !== undefined || (idx.int && rg && rg[0] >= 0 && rg[1] < arr.elems.length);
+    let ix, guard = '';
+    if (safe) ix = this.asI(idx);
+    else if (idx.int) { ix = this.temp_int(this.asI(idx)); guard = 'if ((unsigned)' + ix + ' < ' + arr.elems.length + 'u) '; }
+    else { const dv = this.temp(this.asD(idx)); const c = '(' + dv + ' >= 0.0 && ' + dv + ' < ' + arr.elems.length + '.0 && ' + dv + ' == __builtin_trunc(' + dv + '))'; ix = this.temp_int('(' + c + ' ? (int)' + dv + ' : 0)'); guard = 'if ' + c + ' '; }
     this.flush(out, indent);
-    const lhs = arr.name + '[' + this.asI(idx) + ']';
-    out.push(indent + lhs + ' = ' + (op === '=' ? this.asD(v) : '(' + lhs + ' ' + op[0] + ' ' + this.asD(v) + ')') + ';');
+    const lhs = arr.name + '[' + ix + ']';
+    out.push(indent + guard + lhs + ' = ' + (op === '=' ? this.asD(v) : '(' + lhs + ' ' + op[0] + ' ' + this.asD(v) + ')') + ';');
     return;
   }
   if (target.k === 'Member' && target.obj.k === 'Id' && this.isStateName(target.obj.name)) {
