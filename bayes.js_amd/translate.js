@@ -410,7 +410,13 @@ Translator.prototype.index = function (objV, idxV) {
       return objV.name ? num(objV.name + '[' + idxV.cst + ']', false) : objV.elems[idxV.cst];
     }
     // run-time index into a small local array: out of range reads give NaN, as `undefined` does in arithmetic
-    const nm = this.materialize(objV), ix = this.temp_int(this.asI(idxV));
+    const nm = this.materialize(objV), rgL = rangeOf(idxV);
+    if (idxV.int && rgL && rgL[0] >= 0 && rgL[1] < objV.elems.length) return num(nm + '[' + this.asI(idxV) + ']', false);
+    if (idxV.t === 'num' && !idxV.int) {      // a number that may not be an integer: undefined (NaN) unless it is one, and inside
+      const dv = this.temp(this.asD(idxV));
+      return num('((' + dv + ' >= 0.0 && ' + dv + ' < ' + objV.elems.length + '.0 && ' + dv + ' == __builtin_trunc(' + dv + ')) ? ' + nm + '[(int)' + dv + '] : __builtin_nan(""))', false);
+    }
+    const ix = this.temp_int(this.asI(idxV));
     return num('((unsigned)' + ix + ' < ' + objV.elems.length + 'u ? ' + nm + '[' + ix + '] : __builtin_nan(""))', false);
   }
   if (objV.t === 'strArr') {
