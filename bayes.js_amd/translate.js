@@ -566,14 +566,18 @@ Translator.prototype.expr = function (e) {
         return num('js_mod(' + this.asD(l) + ', ' + this.asD(r) + ')', false);
       }
       if (l.int && r.int) {
+        const span = (a, b) => {
+          if (e.op === '+') return [a[0] + b[0], a[1] + b[1]];
+          if (e.op === '-') return [a[0] - b[1], a[1] - b[0]];
+          const c = [a[0] * b[0], a[0] * b[1], a[1] * b[0], a[1] * b[1]];
+          return [Math.min.apply(null, c), Math.max.apply(null, c)];
+        };
         const a = rangeOf(l), b = rangeOf(r);
-        let rg = null;
-        if (a && b) {
-          if (e.op === '+') rg = [a[0] + b[0], a[1] + b[1]];
-          else if (e.op === '-') rg = [a[0] - b[1], a[1] - b[0]];
-          else if (e.op === '*') { const c = [a[0] * b[0], a[0] * b[1], a[1] * b[0], a[1] * b[1]]; rg = [Math.min.apply(null, c), Math.max.apply(null, c)]; }
-        }
-        return withRange(num('(' + l.code + ' ' + e.op + ' ' + r.code + ')', true, undefined, '(' + this.asD(l) + ' ' + e.op + ' ' + this.asD(r) + ')'), rg);
+        // 32-bit int arithmetic is only used while it cannot overflow (values of unknown range -- counters of loops whose bounds are not
+        // constants -- are taken to stay below 2^30); otherwise the operation is done on doubles, exactly as JavaScript does it
+        const W = [-1073741824, 1073741824], wide = span(a || W, b || W);
+        if (!(wide[0] > -2147483648 && wide[1] < 2147483648)) return num('(' + this.asD(l) + ' ' + e.op + ' ' + this.asD(r) + ')', false);
+        return withRange(num('(' + l.code + ' ' + e.op + ' ' + r.code + ')', true, undefined, '(' + this.asD(l) + ' ' + e.op + ' ' + this.asD(r) + ')'), a && b ? span(a, b) : null);
       }
       return num('(' + this.asD(l) + ' ' + e.op + ' ' + this.asD(r) + ')', false);
     }
