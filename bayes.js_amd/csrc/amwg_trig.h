@@ -3,7 +3,8 @@
 // algorithms (src/base/ieee754.cc: Sun fdlibm, cbrt/log2 in their FreeBSD msun form), restated operation for operation so that a
 // translated closure returns the bits V8 returns; tests/golden/v8_math3_pairs.bin and v8_atan2_pairs.bin (oracle/gen_math3_golden.js,
 // 24 000 arguments each incl. huge ones for the Payne-Hanek reduction) pin the host build, tests/test_gpu_math.py the device build.
-// Included at the end of amwg_math.h.
+// Included at the end of amwg_math.h.  The public functions are not force-inlined (AMWG_HD_OUTLINE): a closure that calls Math.sin in five places
+// gets one copy, which keeps hiprtc compile times of large closures in seconds.
 #pragma once
 
 namespace amwg {
@@ -140,7 +141,7 @@ AMWG_HD_OUTLINE int kernel_rem_pio2(const double *x, double *y, int e0, int nx) 
 }
 
 // fdlibm e_rem_pio2.c: y[0] + y[1] = x - n*pi/2, |y| <= pi/4; returns n (only its low bits matter to the callers)
-AMWG_HD int rem_pio2_v8(double x, double *y) {
+AMWG_HD_OUTLINE int rem_pio2_v8(double x, double *y) {
   const double half = 0.5, two24 = 1.67772160000000000000e+07, invpio2 = 6.36619772367581382433e-01,
                pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11, pio2_2 = 6.07710050630396597660e-11,
                pio2_2t = 2.02226624879595063154e-21, pio2_3 = 2.02226624871116645580e-21, pio2_3t = 8.47842766036889956997e-32;
@@ -289,7 +290,7 @@ AMWG_HD double kernel_tan(double x, double y, int iy) {
   return t + a * (s + t * v);
 }
 
-AMWG_HD double sin_v8(double x) {
+AMWG_HD_OUTLINE double sin_v8(double x) {
   const int32_t ix = hi_word(x) & 0x7fffffff;
   if (ix <= 0x3fe921fb) return kernel_sin(x, 0.0, 0);
   if (ix >= 0x7ff00000) return x - x;
@@ -303,7 +304,7 @@ AMWG_HD double sin_v8(double x) {
   }
 }
 
-AMWG_HD double cos_v8(double x) {
+AMWG_HD_OUTLINE double cos_v8(double x) {
   const int32_t ix = hi_word(x) & 0x7fffffff;
   if (ix <= 0x3fe921fb) return kernel_cos(x, 0.0);
   if (ix >= 0x7ff00000) return x - x;
@@ -317,7 +318,7 @@ AMWG_HD double cos_v8(double x) {
   }
 }
 
-AMWG_HD double tan_v8(double x) {
+AMWG_HD_OUTLINE double tan_v8(double x) {
   const int32_t ix = hi_word(x) & 0x7fffffff;
   if (ix <= 0x3fe921fb) return kernel_tan(x, 0.0, 1);
   if (ix >= 0x7ff00000) return x - x;
@@ -336,7 +337,7 @@ AMWG_HD double asin_acos_ratio(double t) {   // p(t)/q(t) of e_asin.c / e_acos.c
   return p / q;
 }
 
-AMWG_HD double asin_v8(double x) {
+AMWG_HD_OUTLINE double asin_v8(double x) {
   const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, pio4_hi = 7.85398163397448278999e-01;
   const int32_t hx = hi_word(x), ix = hx & 0x7fffffff;
   if (ix >= 0x3ff00000) {  // |x| >= 1
@@ -364,7 +365,7 @@ AMWG_HD double asin_v8(double x) {
   return hx > 0 ? t : -t;
 }
 
-AMWG_HD double acos_v8(double x) {
+AMWG_HD_OUTLINE double acos_v8(double x) {
   const double pi = 3.14159265358979311600e+00, pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
   const int32_t hx = hi_word(x), ix = hx & 0x7fffffff;
   if (ix >= 0x3ff00000) {
@@ -393,7 +394,7 @@ AMWG_HD double acos_v8(double x) {
   return 2.0 * (df + w);
 }
 
-AMWG_HD double atan2_v8(double y, double x) {
+AMWG_HD_OUTLINE double atan2_v8(double y, double x) {
   const double tiny = 1.0e-300, pi_o_4 = 7.8539816339744827900E-01, pi_o_2 = 1.5707963267948965580E+00, pi = 3.1415926535897931160E+00,
                pi_lo = 1.2246467991473531772E-16;
   const int32_t hx = hi_word(x), hy = hi_word(y);
@@ -441,7 +442,7 @@ AMWG_HD double atan2_v8(double y, double x) {
 }
 
 // ---- hyperbolic ------------------------------------------------------------------------------------------------------------------
-AMWG_HD double sinh_v8(double x) {
+AMWG_HD_OUTLINE double sinh_v8(double x) {
   const double KSINH_OVERFLOW = 710.4758600739439, TWO_M28 = 3.725290298461914e-9, LOG_MAXD = 709.7822265625, shuge = 1.0e307;
   const double h = (x < 0) ? -0.5 : 0.5;
   const double ax = __builtin_fabs(x);
@@ -460,7 +461,7 @@ AMWG_HD double sinh_v8(double x) {
   return x * shuge;   // overflow, inf or NaN
 }
 
-AMWG_HD double cosh_v8(double x) {
+AMWG_HD_OUTLINE double cosh_v8(double x) {
   const double KCOSH_OVERFLOW = 710.4758600739439, huge = 1.0e+300;
   const int32_t ix = hi_word(x) & 0x7fffffff;
   if (ix < 0x3fd62e43) {  // |x| < 0.5 ln 2
@@ -483,7 +484,7 @@ AMWG_HD double cosh_v8(double x) {
   return huge * huge;
 }
 
-AMWG_HD double asinh_v8(double x) {
+AMWG_HD_OUTLINE double asinh_v8(double x) {
   const double ln2 = 6.93147180559945286227e-01;
   const int32_t hx = hi_word(x), ix = hx & 0x7fffffff;
   if (ix >= 0x7ff00000) return x + x;
@@ -501,7 +502,7 @@ AMWG_HD double asinh_v8(double x) {
   return hx > 0 ? w : -w;
 }
 
-AMWG_HD double acosh_v8(double x) {
+AMWG_HD_OUTLINE double acosh_v8(double x) {
   const double ln2 = 6.93147180559945286227e-01;
   const int32_t hx = hi_word(x);
   if (hx < 0x3ff00000) return (x - x) / (x - x);   // x < 1
@@ -518,7 +519,7 @@ AMWG_HD double acosh_v8(double x) {
   return log1p_v8(t + __builtin_sqrt(2.0 * t + t * t));
 }
 
-AMWG_HD double atanh_v8(double x) {
+AMWG_HD_OUTLINE double atanh_v8(double x) {
   const int32_t hx = hi_word(x), ix = hx & 0x7fffffff;
   const uint32_t lx = lo_word(x);
   if (((uint32_t)ix | ((lx | (0u - lx)) >> 31)) > 0x3ff00000u) return (x - x) / (x - x);   // |x| > 1
@@ -536,7 +537,7 @@ AMWG_HD double atanh_v8(double x) {
 }
 
 // ---- cbrt, log2 (FreeBSD msun s_cbrt.c / e_log2.c, as V8 carries them) ---------------------------------------------------------------
-AMWG_HD double cbrt_v8(double x) {
+AMWG_HD_OUTLINE double cbrt_v8(double x) {
   const uint32_t B1 = 715094163u, B2 = 696219795u;
   const double P0 = 1.87595182427177009643, P1 = -1.88497979543377169875, P2 = 1.621429720105354466140, P3 = -0.758397934778766047437,
                P4 = 0.145996192886612446982;
@@ -565,7 +566,7 @@ AMWG_HD double cbrt_v8(double x) {
   return t + t * r;
 }
 
-AMWG_HD double log2_v8(double x) {
+AMWG_HD_OUTLINE double log2_v8(double x) {
   const double two54 = 1.80143985094819840000e+16, ivln2hi = 1.44269504072144627571e+00, ivln2lo = 1.67517131648865118353e-10;
   const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
                Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01, Lg7 = 1.479819860511658591e-01;
@@ -607,7 +608,7 @@ AMWG_HD double log2_v8(double x) {
 }
 
 // ---- Math.hypot (V8 builtins-math.cc: largest magnitude factored out, Kahan-compensated sum of the squared ratios) -------------------------
-AMWG_HD double hypot_v8(const double *v, int n) {
+AMWG_HD_OUTLINE double hypot_v8(const double *v, int n) {
   bool any_nan = false;
   double mx = 0.0;
   for (int i = 0; i < n; i++) {

@@ -1,6 +1,6 @@
 'use strict';
 // fuzz_translate_cli.js -- test helper (no GPU): random closures for the translator.
-//   node tests/js/fuzz_translate_cli.js <outdir> <seed> <n_models>
+//   node tests/js/fuzz_translate_cli.js <outdir> <seed> <n_models> [n_derived = 48]
 // Every model is one closure with 48 derived quantities `s.qK = <random expression>` (arithmetic, comparisons, ?:, && ||, Math.*, ld.*,
 // integer and double operands, -0, NaN, Infinity), a few random statement blocks (loops over the data with if/else, continue, local
 // arrays, integer counters) and a random return expression.  The closure is evaluated by V8 at 40 random states (with this package's
@@ -11,7 +11,7 @@ const fs = require('fs');
 const path = require('path');
 const { mcmc, ld } = require('../../bayes.js_amd');
 global.ld = ld;
-const out = process.argv[2], seed0 = Number(process.argv[3] || 1), nModels = Number(process.argv[4] || 3);
+const out = process.argv[2], seed0 = Number(process.argv[3] || 1), nModels = Number(process.argv[4] || 3), NQ_ARG = Number(process.argv[5] || 48);
 
 function rng(seed) { let s = seed >>> 0; return () => { s = (Math.imul(s, 1664525) + 1013904223) >>> 0; return s / 4294967296; }; }
 const bits = (v) => { const b = Buffer.alloc(8); b.writeDoubleBE(v); return b.toString('hex'); };
@@ -123,7 +123,7 @@ const names = [];
 for (let mk = 0; mk < nModels; mk++) {
   const seed = seed0 * 1000 + mk, rnd = rng(seed), G = generator(rnd);
   const lines = [];
-  const NQ = 48, NB = 5;
+  const NQ = NQ_ARG, NB = NQ_ARG >= 48 ? 5 : 2;     // a smaller model for the device test: hiprtc compiles it in seconds
   for (let q = 0; q < NQ; q++) lines.push('  s.q' + q + ' = ' + G.num(4, {}) + ';');
   for (let b = 0; b < NB; b++) lines.push('  ' + G.block(b));
   lines.push('  var lp = ' + G.num(3, {}) + ' + ld.norm(s.a, 0, 10);');
@@ -147,7 +147,7 @@ for (let mk = 0; mk < nModels; mk++) {
   const data = { x: [], n: [], m: [[0.5, -1.25, 3], [2, 0, -0.75]], rows: [] };
   for (let i = 0; i < 8; i++) { data.x.push(i === 3 ? 0 : (rnd() - 0.4) * 6); data.n.push(Math.floor(rnd() * 11)); data.rows.push({ val: (rnd() - 0.5) * 3, tag: ['u', 'v', 'w'][Math.floor(rnd() * 3)], sub: { q: Math.floor(rnd() * 5) } }); }
   const params = mcmc.complete_params({ a: {}, b: { lower: 0 }, v: { dim: [3] }, k: { type: 'int', lower: 0, upper: 6 }, z: { type: 'binary' }, w: { dim: [2, 3] } }, mcmc.param_init_fixed);
-  const name = 'fuzz_' + seed0 + '_' + mk;
+  const name = 'fuzz_' + seed0 + '_' + mk + (NQ_ARG === 48 ? '' : '_q' + NQ_ARG);
   fs.writeFileSync(path.join(out, name + '.js'), src);
   let tr;
   try { tr = mcmc.translate(fn, params, data, {}); } catch (e) { console.error('TRANSLATE FAILED for ' + name + ': ' + e); process.exit(3); }

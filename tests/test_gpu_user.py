@@ -169,7 +169,8 @@ def test_fuzzed_closures_on_the_device_equal_v8(lanes):
     40 chains start at the 40 random states; the cached log_post (the constructor's warm-up evaluation) and the derived quantities of
     the first recorded draw are, at one lane per chain, bit for bit what V8 returned, and at four lanes bit for bit what the host
     build of the same text returns in that lane order."""
-    for name in user_host.fuzz_models(3, 2):
+    # 12 derived quantities per model, seeds whose programs hiprtc compiles in seconds (the 48-quantity models of the host test take a minute each)
+    for name in user_host.fuzz_models(3, 1, 12) + user_host.fuzz_models(7, 1, 12):
         m = user_host.host_model(name)
         if lanes > 1 and not m.meta["parallel"]:
             continue

@@ -40,10 +40,10 @@ def stepper_models():
     return _stepper_names
 
 
-def fuzz_models(seed, count):
+def fuzz_models(seed, count, n_derived=48):
     """Random closures (tests/js/fuzz_translate_cli.js) translated into the work directory; -> their names."""
     d = workdir()
-    p = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "fuzz_translate_cli.js"), d, str(seed), str(count)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    p = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "fuzz_translate_cli.js"), d, str(seed), str(count), str(n_derived)], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + "\n" + p.stderr
     return p.stdout.split()
 
