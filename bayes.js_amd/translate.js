@@ -485,7 +485,17 @@ const ARITH = { '+': (a, b) => a + b, '-': (a, b) => a - b, '*': (a, b) => a * b
 const BITOPS = { '|': 'js_bitor', '&': 'js_bitand', '^': 'js_bitxor', '<<': 'js_shl', '>>': 'js_shr', '>>>': 'js_ushr' };
 const CMP = { '<': (a, b) => a < b, '<=': (a, b) => a <= b, '>': (a, b) => a > b, '>=': (a, b) => a >= b, '===': (a, b) => a === b, '==': (a, b) => a === b, '!==': (a, b) => a !== b, '!=': (a, b) => a !== b };
 
+// Only the operands of && || ! inherit "this is a condition" from cond(); the operands of everything else are values
+// (`(a || b) < c` selects a value although it stands inside a condition).
 Translator.prototype.expr = function (e) {
+  const saved = this.inCondition;
+  if (saved && !(e.k === 'Logical' || (e.k === 'Unary' && e.op === '!'))) {
+    this.inCondition = false;
+    try { return this.exprInner(e, true); } finally { this.inCondition = saved; }
+  }
+  return this.exprInner(e, false);
+};
+Translator.prototype.exprInner = function (e, wasCondition) {
   switch (e.k) {
     case 'Num': return cnum(e.v);
     case 'Bool': return { t: 'bool', code: e.v ? 'true' : 'false', cst: e.v };
@@ -584,8 +594,12 @@ Translator.prototype.expr = function (e) {
     case 'Logical': {
       const l = this.expr(e.l), r = this.expr(e.r);
       if ((l.t !== 'bool' && l.t !== 'num') || (r.t !== 'bool' && r.t !== 'num')) this.fail("'" + e.op + "' on a " + this.describe(l.t !== 'bool' ? l : r));
-      if (l.t === 'num' || r.t === 'num') {
-        if (!this.inCondition) this.fail("'" + e.op + "' is only supported between conditions (value-selecting a || b is not)");
+      if ((l.t === 'num' || r.t === 'num') && !this.inCondition) {
+        // value-selecting `a || b` / `a && b` on numbers (var n = opts.n || 10): a number is falsy when it is 0, -0 or NaN
+        if (l.t !== 'num' || r.t !== 'num') this.fail("'" + e.op + "' between a number and a condition is only supported inside conditions");
+        if (l.cst !== undefined) { const truthy = l.cst !== 0 && l.cst === l.cst; return (e.op === '||') === truthy ? l : r; }
+        const a = this.temp(this.asD(l)), tr = '(' + a + ' != 0.0 && ' + a + ' == ' + a + ')';
+        return num('(' + tr + ' ? ' + (e.op === '||' ? a + ' : ' + this.asD(r) : this.asD(r) + ' : ' + a) + ')', false);
       }
       return { t: 'bool', code: '(' + this.asB(l) + ' ' + e.op + ' ' + this.asB(r) + ')' };
     }

@@ -32,7 +32,8 @@ function generator(rnd) {
     const a = () => num(depth - 1, ctx);
     if (r < 0.30) return '(' + a() + ' ' + pick(['+', '-', '*', '+', '-', '*', '/']) + ' ' + a() + ')';
     if (r < 0.34) return '(' + a() + ' % ' + pick(['3', '2.5', '(s.k + 1)', '7', leafI(ctx) + ' + 1']) + ')';
-    if (r < 0.37) return '(- ' + a() + ')';
+    if (r < 0.355) return '(- ' + a() + ')';
+    if (r < 0.37) return '(' + a() + ' ' + pick(['||', '&&']) + ' ' + a() + ')';      // value-selecting, on numbers
     if (r < 0.40) return pick([() => '(' + a() + ' ' + pick(['|', '&', '^', '<<', '>>', '>>>']) + ' ' + pick([leafI(ctx), '0', '3', '31', a()]) + ')', () => '(~' + a() + ')', () => '(~~' + a() + ')',
       () => 'Math.imul(' + a() + ', ' + a() + ')', () => 'Math.clz32(' + a() + ')', () => 'Math.fround(' + a() + ')', () => '((' + a() + ' * 1e9) | 0)', () => '((' + a() + ' * 1e10) >>> 0)'])();
     if (r < 0.50) return '(' + cond(depth - 1, ctx) + ' ? ' + a() + ' : ' + a() + ')';
