@@ -9,7 +9,7 @@
  *     var/let/const, assignments (= += -= *= /= %=, ++ --), for / while / do-while / if / else / switch (no fall-through) / break / continue / return, blocks
  *     numbers, + - * / % **, | & ^ ~ << >> >>> (ToInt32 semantics), comparisons, && || !, ?:, Math.{log,exp,log1p,expm1,log10,log2,pow,sqrt,cbrt,hypot,abs,floor,ceil,round,trunc,sign,
  *     min,max,sin,cos,tan,asin,acos,atan,atan2,sinh,cosh,tanh,asinh,acosh,atanh,imul,clz32,fround,PI,E,...}, isNaN, isFinite, every ld.* of distributions.js (array-valued ones unrolled),
- *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, arrays of records (data[i].x, var row = data[i]), categorical strings in the data (only compared: row.group === 'control'), local
+ *     state.name, state.name[i][j], data.field, data.field[i][j], data.field.length, arrays of records (data[i].x, var row = data[i]), categorical strings in the data (only compared: row.group === 'control', or looked up: LEVELS.indexOf(row.group)), local
  *     aliases of those (var p = par.p[0]), derived quantities (state.key = expr, mcmc.js:961-963),
  *     helper functions and constants passed in options.helpers / options.constants (or globals); helpers that take numbers become
  *     device functions, helpers that are handed the state, the data or arrays of them (`log_prior(state) + log_lik(state, data)`) are
@@ -300,7 +300,7 @@ Translator.prototype.asB = function (v) {
   this.fail('a ' + this.describe(v) + ' is used as a condition');
 };
 Translator.prototype.describe = function (v) {
-  return { localArr: 'local array', recArr: 'array of records', rec: 'record', strlit: 'string', strv: 'string', strArr: 'array of strings', stateObj: 'state object', stateArr: 'parameter array', dataObj: 'data object', dataArr: 'data array', ns: 'namespace', fn: 'function', bool: 'boolean', num: 'number' }[v.t] || v.t;
+  return { localArr: 'local array', recArr: 'array of records', rec: 'record', strlit: 'string', strv: 'string', strArr: 'array of strings', strList: 'array of strings', stateObj: 'state object', stateArr: 'parameter array', dataObj: 'data object', dataArr: 'data array', ns: 'namespace', fn: 'function', bool: 'boolean', num: 'number' }[v.t] || v.t;
 };
 
 // ---- expressions -----------------------------------------------------------------------------------
@@ -354,7 +354,7 @@ Translator.prototype.dataValue = function (path, v) {
     const table = [];
     const codes = v.map((e) => { let k = table.indexOf(e); if (k < 0) { k = table.length; table.push(e); } return k; });
     const id = this.registerArray(path + '#codes', codes);
-    return { t: 'strArr', id, table, n: v.length };
+    return { t: 'strArr', id, table, n: v.length, values: v.slice() };
   }
   // an array of records ([{x: 1.2, y: 0}, ...], rows of a table): element i's field f is element i of the column f (built on demand)
   if (Array.isArray(v) && v.length > 0 && v.every((e) => e && typeof e === 'object' && !Array.isArray(e) && !ArrayBuffer.isView(e))) return { t: 'recArr', path, value: v };
@@ -382,7 +382,11 @@ Translator.prototype.member = function (objV, prop) {
   }
   if (objV.t === 'localArr') { if (prop === 'length') return cnum(objV.elems.length); this.fail("property '" + prop + "' of an array is not supported"); }
   if (objV.t === 'recArr') { if (prop === 'length') return cnum(objV.value.length); this.fail("property '" + prop + "' of an array of records is not supported"); }
-  if (objV.t === 'strArr') { if (prop === 'length') return cnum(objV.n); this.fail("property '" + prop + "' of an array of strings is not supported"); }
+  if (objV.t === 'strArr' || objV.t === 'strList') {
+    if (prop === 'length') return cnum(objV.values.length);
+    if (prop === 'indexOf' || prop === 'includes') return { t: 'fn', ns: 'strlist', name: prop, list: objV.values };
+    this.fail("property '" + prop + "' of an array of strings is not supported");
+  }
   if (objV.t === 'rec') {
     const rows = objV.arr.value, path = objV.arr.path + '[].' + prop;
     const col = rows.map((r, i) => { if (!Object.prototype.hasOwnProperty.call(r, prop)) this.fail('data' + objV.arr.path + '[' + i + '].' + prop + ' does not exist'); return r[prop]; });
@@ -509,6 +513,7 @@ Translator.prototype.exprInner = function (e, wasCondition) {
         const id = this.registerArray('#lit' + JSON.stringify(vals), vals);
         return { t: 'dataArr', id, off: '0', dims: [vals.length] };
       }
+      if (vs.length && vs.every((v) => v.t === 'strlit')) return { t: 'strList', values: vs.map((v) => v.v) };      // ['control', 'low', 'high']: only for indexOf / includes
       for (const v of vs) if (v.t !== 'num' && v.t !== 'bool') this.fail('array literals may only hold numbers (nested arrays of expressions are not supported)');
       if (vs.length > 64) this.fail('array literal with more than 64 elements');
       return { t: 'localArr', elems: vs.map((v) => num(this.asD(v), false)) };
@@ -607,7 +612,11 @@ Translator.prototype.exprInner = function (e, wasCondition) {
       const t = this.cond(e.test), a = this.expr(e.a), b = this.expr(e.b);
       if (t.cst !== undefined) return t.cst ? a : b;
       if (a.t === 'bool' && b.t === 'bool') return { t: 'bool', code: '(' + t.code + ' ? ' + a.code + ' : ' + b.code + ')' };
-      if (a.t !== 'num' || b.t !== 'num') this.fail('both branches of ?: must be numbers');
+      if (a.t === 'strlit' && b.t === 'strlit') {       // c ? 'x' : 'z': a categorical value over the two labels
+        if (a.v === b.v) return a;
+        return { t: 'strv', code: withRange(num('(' + t.code + ' ? 0 : 1)', true), [0, 1]), table: [a.v, b.v], id: 'cond:' + (this.tmp++) };
+      }
+      if (a.t !== 'num' || b.t !== 'num') this.fail('both branches of ?: must be numbers (or both string literals)');
       if (a.int && b.int) return withRange(num('(' + t.code + ' ? ' + a.code + ' : ' + b.code + ')', true, undefined, '(' + t.code + ' ? ' + this.asD(a) + ' : ' + this.asD(b) + ')'),
         rangeOf(a) && rangeOf(b) && [Math.min(rangeOf(a)[0], rangeOf(b)[0]), Math.max(rangeOf(a)[1], rangeOf(b)[1])]);
       return num('(' + t.code + ' ? ' + this.asD(a) + ' : ' + this.asD(b) + ')', false);
@@ -647,6 +656,19 @@ Translator.prototype.callInner = function (e) {
   const args = e.args.map((a) => this.expr(a));
   const nums = () => args.map((a) => { if (a.t !== 'num' && a.t !== 'bool') this.fail(f.ns + '.' + f.name + ' got a ' + this.describe(a) + ' argument (only scalar arguments are supported)'); return a; });
   const allConst = () => args.every((a) => a.cst !== undefined && a.t === 'num');
+  if (f.ns === 'strlist') {
+    // LEVELS.indexOf(row.group) / LEVELS.includes(row.group): the position of a categorical value in a constant list of labels, through a
+    // table from the column's integer codes to positions (built here, once)
+    if (args.length !== 1) this.fail(f.name + ' takes one argument here');
+    const a = args[0];
+    if (a.t === 'strlit') { const k = f.list.indexOf(a.v); return f.name === 'indexOf' ? cnum(k) : { t: 'bool', code: k >= 0 ? 'true' : 'false', cst: k >= 0 }; }
+    if (a.t !== 'strv') { if (f.name === 'includes') return { t: 'bool', code: 'false', cst: false }; return cnum(-1); }     // a number is never === a string
+    const map = a.table.map((label) => f.list.indexOf(label));
+    const tab = this.dataValue('#indexOf:' + JSON.stringify([a.id, f.list]), map);
+    const pos = this.index(tab, a.code);
+    if (f.name === 'indexOf') return pos;
+    return { t: 'bool', code: '(' + this.asD(pos) + ' >= 0.0)' };
+  }
   if (f.ns === 'Number' && (f.name === 'isInteger' || f.name === 'isSafeInteger')) {
     if (args.length !== 1 || (args[0].t !== 'num' && args[0].t !== 'bool')) this.fail('Number.' + f.name + ' takes one number');
     if (args[0].t === 'bool') return { t: 'bool', code: 'false', cst: false };

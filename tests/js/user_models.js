@@ -614,6 +614,11 @@ CASES.categorical_arms = {
       if (d.family === 'normal') lp += ld.norm(row.y, m, s.sigma); else lp += ld.cauchy(row.y, m, s.sigma);
     }
     for (var j = 0; j < d.labels.length; j++) lp += (d.labels[j] === d.labels[0] ? 1e-3 : -1e-3) * (d.labels[j] === 3 ? 100 : 1);
+    // positions of labels in constant lists: a literal list, a list in the data, a label that is in neither
+    const ARMS = ['high', 'control', 'low'], shift = [0.01, 0.02, 0.03];
+    for (const row of d.rows) {
+      lp += shift[ARMS.indexOf(row.arm)] * 1e-2 + d.labels.indexOf(row.site === 'A' ? 'x' : 'z') * 1e-3 + (d.labels.includes(row.arm) ? 1 : 0) + ARMS.indexOf('nowhere') * 1e-4;
+    }
     return lp;
   },
   schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
