@@ -478,8 +478,8 @@ function isPath(e) {
   if (e.k === 'Index') return isPath(e.obj) && (e.idx.k === 'Num' || e.idx.k === 'Id' || isPath(e.idx));
   return false;
 }
-function countedLoop(k, arr, body) {
-  return { k: 'For', init: { k: 'VarDecl', kind: 'var', decls: [{ name: k, init: { k: 'Num', v: 0 } }] },
+function countedLoop(k, arr, body, start) {
+  return { k: 'For', init: { k: 'VarDecl', kind: 'var', decls: [{ name: k, init: { k: 'Num', v: start || 0 } }] },
     test: { k: 'Binary', op: '<', l: { k: 'Id', name: k }, r: { k: 'Member', obj: arr, prop: 'length' } },
     update: { k: 'Update', op: '++', prefix: false, target: { k: 'Id', name: k } }, body: { k: 'Block', body } };
 }
@@ -641,9 +641,11 @@ function hoistReduce(e, P, out) {
     return { k: 'Id', name: z };
   }
   if (isMethodCall(e, 'reduce')) {
-    if (e.args.length !== 2) throw 'reduce needs an initial value here: arr.reduce(function (acc, x) {...}, init)';
+    if (e.args.length !== 1 && e.args.length !== 2) throw 'reduce takes a callback and an optional initial value';
     const arr = e.callee.obj, cb = e.args[0], k = P.fresh('k'), acc = P.fresh('acc'), x = P.fresh('x');
-    const init = hoistReduce(e.args[1], P, out);
+    // without an initial value the first element is the start and the loop begins at the second (an empty array throws in JavaScript)
+    const noInit = e.args.length === 1;
+    const init = noInit ? { k: 'Index', obj: arr, idx: { k: 'Num', v: 0 } } : hoistReduce(e.args[1], P, out);
     const body = inlineCallback(cb, [acc, x, k], P, (arg, depth) => {
       if (!arg) throw 'the reduce callback must return a value';
       if (depth > 0) throw 'a return inside a loop inside a reduce callback is not supported';
@@ -656,7 +658,7 @@ function hoistReduce(e, P, out) {
     const inner = [];
     desugarStatement({ k: 'Block', body }, P, inner);
     out.push({ k: 'VarDecl', kind: 'var', decls: [{ name: acc, init }] });
-    out.push(countedLoop(k, arr, [{ k: 'VarDecl', kind: 'var', decls: [{ name: x, init: { k: 'Index', obj: arr, idx: { k: 'Id', name: k } } }] }].concat(inner[0].body)));
+    out.push(countedLoop(k, arr, [{ k: 'VarDecl', kind: 'var', decls: [{ name: x, init: { k: 'Index', obj: arr, idx: { k: 'Id', name: k } } }] }].concat(inner[0].body), noInit ? 1 : 0));
     return { k: 'Id', name: acc };
   }
   const o = {};

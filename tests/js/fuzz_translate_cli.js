@@ -104,7 +104,7 @@ function generator(rnd) {
     if (r < 0.45) return 'lp += d.x.reduce((ac, xe, ie) => ac + ' + withT(e({ i: 'ie' }), 'xe') + ' * 1e-3, ' + withT(e(), 's.a') + ') * 1e-2;';
     if (r < 0.55) return 'const { a: pa' + k + ', v: [pv' + k + ', , pw' + k + '] } = s;\n  lp += (pa' + k + ' * pv' + k + ' - pw' + k + ') * 1e-3;';
     if (r < 0.65) return 'const hf' + k + ' = (p, q) => p * ' + lit() + ' + Math.abs(q);\n  for (const nv' + k + ' of d.n) lp += hf' + k + '(nv' + k + ', ' + withT(e(), 's.b') + ') * 1e-3;';
-    if (r < 0.72) return 's.r' + k + ' = s.v.reduce(function (ac, ve) { var sq = ve * ve; return ac + sq; }, 0) + d.m[1].reduce((ac, me) => Math.max(ac, me), -Infinity);';
+    if (r < 0.72) return 's.r' + k + ' = s.v.reduce(function (ac, ve) { var sq = ve * ve; return ac + sq; }, 0) + d.m[1].reduce((ac, me) => Math.max(ac, me), -Infinity) + d.x.reduce((p, q) => p + q * ' + lit() + ') - s.w[1].reduce((p, q) => Math.min(p, q));';
     return pick([
       'var mz' + k + ' = d.x.map(function (xe, ie) { return ' + withT(e({ i: 'ie' }), 'xe') + '; });\n  for (var i = 0; i < mz' + k + '.length; i++) { lp += mz' + k + '[i] * 1e-3; }\n  s.r' + k + ' = mz' + k + '[' + Math.floor(rnd() * 8) + '];',
       'lp += d.n.map((ne) => ne * ' + e() + ').reduce((ac, q) => ac + q, 0) * 1e-3;',
