@@ -581,12 +581,8 @@ function hoistReduce(e, P, out) {
   // x.map(f).reduce(g, init) / x.map(f).map(g): materialise the inner map first, then treat the outer call on its name
   if (e.k === 'Call' && e.callee.k === 'Member' && (e.callee.prop === 'reduce' || e.callee.prop === 'map') && isMapCall(e.callee.obj))
     return hoistReduce({ k: 'Call', callee: { k: 'Member', obj: hoistReduce(e.callee.obj, P, out), prop: e.callee.prop }, args: e.args }, P, out);
-  if (e.k === 'Logical' || e.k === 'Cond') {      // conditionally evaluated operands: a hoisted loop would run unconditionally (harmless, pure) -- keep it simple, refuse
-    let found = false;
-    walk(e, (x) => { if (isMethodCall(x, 'reduce') || isMapCall(x)) found = true; });
-    if (found) throw 'reduce()/map() inside a conditional expression is not supported; assign it to a variable first';
-    return e;
-  }
+  // (operands of ?: && || are evaluated conditionally in JavaScript; a loop hoisted out of one runs regardless, which changes nothing: the
+  // subset is pure, terminates, and reads outside arrays are NaN rather than faults)
   // f(state), f(state, data), f(state.theta, data.x): a function that is handed objects cannot become a scalar device function; its body
   // is inlined here (parameters bound to the argument paths, numbers to temporaries, locals renamed apart).  P.env is set by the translator.
   if (P.env && e.k === 'Call' && e.callee.k === 'Id' && e.args.some((a) => P.env.isObject(a))) {
@@ -639,6 +635,22 @@ function hoistReduce(e, P, out) {
     out.push({ k: 'VarDecl', kind: 'var', decls: [{ name: z, init: { k: 'NewArray', len: { k: 'Member', obj: arr, prop: 'length' }, fill: { k: 'Num', v: 0 } } }] });
     out.push(countedLoop(k, arr, [{ k: 'VarDecl', kind: 'var', decls: [{ name: x, init: { k: 'Index', obj: arr, idx: { k: 'Id', name: k } } }] }].concat(inner[0].body)));
     return { k: 'Id', name: z };
+  }
+  // arr.some(cb) / arr.every(cb): a 0/1 flag set by a loop that stops at the first decisive element
+  if ((isMethodCall(e, 'some') || isMethodCall(e, 'every')) && e.args.length === 1 && e.args[0].k === 'Func') {
+    const some = e.callee.prop === 'some', arr = e.callee.obj, k = P.fresh('k'), x = P.fresh('x'), flag = P.fresh(some ? 'some' : 'every');
+    const set = { k: 'Block', body: [{ k: 'ExprStmt', expr: { k: 'Assign', op: '=', target: { k: 'Id', name: flag }, value: { k: 'Num', v: some ? 1 : 0 } } }, { k: 'Break' }] };
+    const body = inlineCallback(e.args[0], [x, k], P, (arg, depth) => {
+      if (!arg) throw 'the ' + e.callee.prop + ' callback must return a value';
+      if (depth > 0) throw 'a return inside a loop inside a ' + e.callee.prop + ' callback is not supported';
+      return [{ k: 'If', test: some ? arg : { k: 'Unary', op: '!', arg }, cons: set, alt: null }, { k: 'Continue' }];
+    }, e.callee.prop);
+    if (body.length && body[body.length - 1].k === 'Continue') body.pop();
+    const inner = [];
+    desugarStatement({ k: 'Block', body }, P, inner);
+    out.push({ k: 'VarDecl', kind: 'var', decls: [{ name: flag, init: { k: 'Num', v: some ? 0 : 1 } }] });
+    out.push(countedLoop(k, arr, [{ k: 'VarDecl', kind: 'var', decls: [{ name: x, init: { k: 'Index', obj: arr, idx: { k: 'Id', name: k } } }] }].concat(inner[0].body)));
+    return { k: 'Binary', op: '!==', l: { k: 'Id', name: flag }, r: { k: 'Num', v: 0 } };
   }
   if (isMethodCall(e, 'reduce')) {
     if (e.args.length !== 1 && e.args.length !== 2) throw 'reduce takes a callback and an optional initial value';

@@ -16,7 +16,7 @@
  *     inlined (they need a single return at their end);
  *     post-ES5 spellings, rewritten into the above while parsing: destructuring in parameters and declarations
  *     (`({mu, sigma}, {x}) => ...`, `const [a, , b] = state.theta`), `for (const x of arr)`, `arr.forEach(cb)` as a statement
- *     (`return` inside the callback = continue), `arr.reduce(cb, init)` anywhere in the expressions of a statement
+ *     (`return` inside the callback = continue), `arr.reduce(cb[, init])`, `arr.some(cb)`, `arr.every(cb)` anywhere in the expressions of a statement
  *     (callback parameters and locals are renamed apart; the reduce becomes its own sequential accumulator, as in JS),
  *     `arr.map(cb)`, `Array(n)`, `new Array(n)`, `Array(n).fill(v)` as local arrays of a length known when the sampler is built (<= 2048);
  *     `var a = []` grown by one `a.push(v)` per iteration of a counted loop from 0 (the same thing); let/const block scoping.

@@ -67,7 +67,8 @@ function generator(rnd) {
     if (depth <= 0 || r < 0.55) return '(' + num(depth - 1, ctx) + ' ' + pick(['<', '>', '<=', '>=', '===', '!==', '==', '!=']) + ' ' + num(depth - 1, ctx) + ')';
     if (r < 0.75) return '(' + cond(depth - 1, ctx) + ' ' + pick(['&&', '||']) + ' ' + cond(depth - 1, ctx) + ')';
     if (r < 0.85) return '(!' + cond(depth - 1, ctx) + ')';
-    if (r < 0.92) return pick(['isNaN', 'isFinite', 'Number.isInteger', 'Number.isSafeInteger', 'Number.isNaN']) + '(' + num(depth - 1, ctx) + ')';
+    if (r < 0.90) return pick(['isNaN', 'isFinite', 'Number.isInteger', 'Number.isSafeInteger', 'Number.isNaN']) + '(' + num(depth - 1, ctx) + ')';
+    if (r < 0.92 && !ctx.i && !ctx.noLoops) return pick(['d.x', 'd.n', 's.v', 's.w[0]']) + '.' + pick(['some', 'every']) + '((qq, jj) => qq ' + pick(['<', '>', '>=', '!==']) + ' ' + num(1, { calm: true, noLoops: true }) + ' + jj)';
     return '(s.z === ' + pick(['0', '1']) + ')';
   }
   function block(k) {     // statement templates around random expressions
