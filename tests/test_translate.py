@@ -172,7 +172,7 @@ def test_fuzzed_closures_equal_v8_on_host(seed):
     40 random states; evaluated in the order of 2, 4 and 64 lanes per chain the derived quantities stay identical and the sum agrees to
     rounding.  (This test found Math.round's -0; campaigns over some 60 further seeds are clean.)"""
     checked = 0
-    for name in user_host.fuzz_models(seed, 2):
+    for name in user_host.fuzz_models(seed, 2, 24):      # 24 derived quantities per program here (tools/fuzz_campaign.py runs the 48-quantity ones)
         m = user_host.host_model(name)
         for t, pt in enumerate(user_host.stepper_states(name)):
             state = [float(np.frombuffer(bytes.fromhex(h), dtype=">f8")[0]) for h in pt["state"]]
@@ -186,4 +186,4 @@ def test_fuzzed_closures_equal_v8_on_host(seed):
                     v, dvl = m.eval(state, lanes, derived=True)
                     assert all(same(a, b) for a, b in zip(dvl, dv)), (name, lanes, state)
                     assert same(v, got) or (math.isfinite(got) and abs(v - got) <= 1e-9 * max(1.0, abs(got))), (name, lanes, state, v, got)
-    assert checked >= 2 * 40 * 54
+    assert checked >= 2 * 40 * 26
