@@ -234,7 +234,8 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
   Roctx &rx = roctx();
   if (rx.push) rx.push(d_draws ? "amwg_sample" : "amwg_burn");
   struct PopOnExit { Roctx &r; ~PopOnExit() { if (r.pop) r.pop(); } } pop_on_exit{rx};
-  const int64_t chunk = s->opt.steps_per_launch > 0 ? s->opt.steps_per_launch : (1 << 20);
+  // a launch counts its accepted / evaluated proposals in 16-bit fields (amwg_kernel.h, TOTme): at most 65535 steps per launch
+  const int64_t chunk = (s->opt.steps_per_launch > 0 && s->opt.steps_per_launch < 65535) ? s->opt.steps_per_launch : 65535;
   StepArgs a{};
   a.C = s->C;
   a.seed = s->opt.seed;
@@ -358,7 +359,15 @@ double amwg_pow(double x, double y) { return pow_v8(x, y); }
 double amwg_log1p(double x) { return log1p_v8(x); }
 double amwg_expm1(double x) { return expm1_v8(x); }
 double amwg_math1(int32_t fn, double x) { return math1_by_id(fn, x); }
-double amwg_math2(int32_t fn, double x, double y) { return fn == 0 ? atan2_v8(x, y) : (fn == 1 ? hypot2_v8(x, y) : __builtin_nan("")); }
+double amwg_math2(int32_t fn, double x, double y) {
+  switch (fn) {
+    case 0: return atan2_v8(x, y);
+    case 1: return hypot2_v8(x, y);
+    case 2: return js_mod(x, y);                 // JavaScript's `%`
+    case 3: return (double)js_toint32(x);        // `x | 0`
+  }
+  return __builtin_nan("");
+}
 double amwg_hypot3(double x, double y, double z) { return hypot3_v8(x, y, z); }
 double amwg_ld_host(int32_t id, double x, double a, double b, double c) { return ld_by_id(id, x, a, b, c); }
 double amwg_uniform(uint64_t seed, uint64_t chain, uint64_t index) {

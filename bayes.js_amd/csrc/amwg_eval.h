@@ -1,6 +1,7 @@
 // amwg_eval.h -- device evaluation of the arithmetic building blocks (tests only; amwg_device_eval).
 #pragma once
 #include "amwg_kernel.h"
+#include "amwg_user.h"
 
 namespace amwg {
 
@@ -92,6 +93,8 @@ __global__ void amwg_eval_kernel(int op, int64_t n, const double *a, const doubl
     case 21: r = atan2_v8(x, y); break;
     case 22: r = hypot3_v8(x, y, z); break;
     case 23: r = hypot2_v8(x, y); break;
+    case 24: r = js_mod(x, y); break;                // the `%` of translated closures
+    case 25: r = (double)js_toint32(x); break;       // `x | 0`
   }
   out[i] = r;
 }

@@ -39,7 +39,7 @@
 namespace amwg {
 
 struct LdsLayout {
-  uint32_t data, state, pls, cnt, cc, adapt, pl, idx, total, stride, logpls, bc, xw;
+  uint32_t data, state, pls, cnt, tot, cc, adapt, pl, idx, total, stride, logpls, bc, xw;
 };
 // CPB = per-chain state copies in the workgroup: chains per workgroup (lanes per chain <= 64), or -- when one chain spans
 // several wavefronts -- one private replica per wavefront (`multi`, see step_body).
@@ -51,6 +51,7 @@ __host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CP
   L.state = o; o += L.stride * CPB * 8;
   L.pls = o;   o += L.stride * CPB * 8;   // proposal sd = exp(prop_log_scale), same [chain][stride] layout as the state
   L.cnt = o;   o += L.stride * CPB * 8;   // {acceptance_count, iterations_since_adaption} int32 pairs
+  L.tot = o;   o += (L.stride * CPB * 4 + 15) & ~15u;   // this launch's run totals, packed: accepts << 16 | evaluated (in-bounds) proposals
   L.cc = o;    o += (uint32_t)P * sizeof(CompConst);
   L.adapt = o; o += ((uint32_t)P + 7) & ~7u;
   L.pl = o;    o += (uint32_t)((sizeof(ParamLayout) + 7) & ~(size_t)7);
@@ -62,9 +63,8 @@ __host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CP
   return L;
 }
 
-template <class Model, bool FAST, int G>
+template <class Model, bool FAST, int G, int U = Model::kUnroll>
 __device__ __forceinline__ double pass_over_data(const typename Model::Pass &ps, int n_obs, int sub, double acc) {
-  constexpr int U = Model::kUnroll;
   const int n_full = n_obs / G, rem = n_obs % G;
   int k = 0;
   for (; k + U <= n_full; k += U) {
@@ -104,8 +104,8 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
     acc = (sub == 0) ? prior : 0.0;
     if constexpr (Model::kSplitPrior) acc = Model::template prior_split<G>(S, a.mc, a.d, sub, acc);
     if constexpr (Model::kHasFast) {
-      if (ps.fast) acc = pass_over_data<Model, true, G>(ps, a.d.n_obs, sub, acc);
-      else acc = pass_over_data<Model, false, G>(ps, a.d.n_obs, sub, acc);
+      if (ps.fast) acc = Model::template pass_fast<G>(ps, a.d.n_obs, sub, acc);   // hand-pipelined (amwg_models.h norm_pass_staged)
+      else acc = pass_over_data<Model, false, G, 2>(ps, a.d.n_obs, sub, acc);      // IEEE '/': rare, kept small
     } else if constexpr (Model::kOneLanePass && G == 1) {
       acc = Model::pass_one_lane(ps, a.d.n_obs, acc);
     } else {
@@ -227,6 +227,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   uint8_t *idx = smem + L.idx + c_in;  // this chain's shuffle indices at idx[t * CPB]
   double *SDme = reinterpret_cast<double *>(smem + L.pls) + (size_t)c_in * L.stride;   // exp(prop_log_scale), mcmc.js:578
   int2 *CNTme = reinterpret_cast<int2 *>(smem + L.cnt) + (size_t)c_in * L.stride;
+  // run totals of THIS launch (accepted << 16 | evaluated): kept in LDS and added to the HBM totals once, when the launch ends
+  // (round 1 issued two no-return atomics per update: 17x the bytes of the recorded draws).  The host keeps launches <= 65535 steps.
+  uint32_t *TOTme = reinterpret_cast<uint32_t *>(smem + L.tot) + (size_t)c_in * L.stride;
   double *LOGPLSme = reinterpret_cast<double *>(smem + L.logpls) + (size_t)c_in * L.stride;   // multi only
   int32_t *BCme = reinterpret_cast<int32_t *>(smem + L.bc) + (size_t)c_in * L.stride;         // multi only
   CrossWave xw{reinterpret_cast<double *>(smem + L.xw), 0};
@@ -248,6 +251,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     Sme[p] = a.ch.state[p * C + cl];
     SDme[p] = exp_v8(a.ch.prop_log_scale[p * C + cl]);   // the log scale itself stays in HBM: it only changes at batch boundaries
     CNTme[p] = make_int2(a.ch.acceptance_count[p * C + cl], a.ch.iterations_since_adaption[p * C + cl]);
+    TOTme[p] = 0u;
     if constexpr (kMulti) { LOGPLSme[p] = a.ch.prop_log_scale[p * C + cl]; BCme[p] = a.ch.batch_count[p * C + cl]; }
   }
   const StateView S{Sme};
@@ -325,10 +329,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         double now = 1.0;
         lp_curr = one_ld;
         if (rng.next() < zero_prob) { Sme[comp] = 0.0; now = 0.0; lp_curr = zero_ld; }
-        if (writer) {   // run totals: evaluations and flips (no-return atomics on chain-private words: nothing to wait for)
-          atomicAdd(&a.ch.inbounds[gi], 1);
-          if (now != old) atomicAdd(&a.ch.accepts[gi], 1);
-        }
+        TOTme[comp] += 1u + ((now != old) ? 0x10000u : 0u);   // run totals: evaluations and flips
         continue;
       }
       // ---- OnedimMetropolisStepper.step (mcmc.js:517-553)
@@ -348,6 +349,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           Sme[comp] = cur;
         }
       }
+      if (inb) TOTme[comp] += 1u + (accepted ? 0x10000u : 0u);   // run totals (not in the reference; parity tests compare them with the oracle's)
       if (adapt[comp] != 0) {
         int2 cnt = CNTme[comp];
         cnt.x += accepted ? 1 : 0;      // acceptance_count (mcmc.js:530)
@@ -366,10 +368,6 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         }
         CNTme[comp] = cnt;
       }
-      if (writer && inb) {   // run totals (not in the reference; parity tests compare them with the oracle's):
-        atomicAdd(&a.ch.inbounds[gi], 1);   // no-return atomics on chain-private words: the wave does not wait for L2
-        if (accepted) atomicAdd(&a.ch.accepts[gi], 1);
-      }
     }
   }
 
@@ -378,6 +376,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       a.ch.state[p * C + cl] = S(p);
       a.ch.acceptance_count[p * C + cl] = CNTme[p].x;
       a.ch.iterations_since_adaption[p * C + cl] = CNTme[p].y;
+      a.ch.accepts[p * C + cl] += (int32_t)(TOTme[p] >> 16);
+      a.ch.inbounds[p * C + cl] += (int32_t)(TOTme[p] & 0xffffu);
       if constexpr (kMulti) { a.ch.prop_log_scale[p * C + cl] = LOGPLSme[p]; a.ch.batch_count[p * C + cl] = BCme[p]; }
     }
     a.ch.perm[cl] = perm;

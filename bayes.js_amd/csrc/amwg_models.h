@@ -19,6 +19,149 @@ __device__ __forceinline__ double norm_const_sd(double v, double m, double c_sd,
   return c_sd - (t * t) / den;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The pass over the data of a normal likelihood with loop-invariant sd -- sum_i [ c - (x_i - m_i)^2 / den ] added term by term
+// to `acc` in increasing i -- software-pipelined by hand.  Per observation it is the same eight fp64 operations, with the same
+// roundings in the same order, as NormalModel::term<true> / div_by_invariant (amwg_div.h):
+//     t = x - m;  tt = t*t;  q0 = tt*y.lo;  q1 = fma(tt, y.hi, q0);  r = fma(-den, q1, tt);  q = fma(r, y.hi, q1);  term = c - q;  acc += term
+// and the terms are added in the same order, so the sum is bit-identical to the plain loop (pass_over_data).  What changes is the
+// SCHEDULE: the compiler's own schedule of the plain loop waits for every LDS read right after issuing it and works through the
+// terms two at a time, i.e. one long dependent chain per wave (rocprofv3, round 1: 0.74 of the fp64 issue rate at 4 waves per
+// SIMD, 39 % of wave cycles waiting).  Here a block of U observations moves through the eight steps as eight STAGES of U
+// independent instructions each (sched_barrier between stages keeps the compiler from re-serialising them), the LDS reads of
+// block k+1 (and, for a gathered mean, the index reads of block k+2) are issued before the arithmetic of block k starts, and the
+// U dependent `acc +=` of block k-1 are spread one per stage over block k -- no instruction waits for the one before it.
+// Mean = a functor: m(i) for a per-observation mean gathered from LDS (HierNormalModel), or a constant (NormalModel).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AMWG_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define AMWG_STAGE_FENCE() ((void)0)
+#endif
+
+template <int U>
+struct NormBlock { double v[U]; };     // x, then t, tt, r in place
+
+template <int U, bool ADD_PREV>
+__device__ __forceinline__ void norm_block_stages(NormBlock<U> &b, const double (&m)[U], NormBlock<U> &q, const NormBlock<U> &prev, double &acc,
+                                                  double c, double den, Reciprocal y) {
+  // prev = the finished terms of the block before this one; its U additions are dealt over the seven stages (U = 8: one per
+  // stage, two in the last)
+  int a = 0;
+  auto add_prev = [&](int upto) {
+    if constexpr (ADD_PREV) { for (; a < upto && a < U; ++a) acc = acc + prev.v[a]; }
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) b.v[u] = b.v[u] - m[u];
+  add_prev(1 * U / 7);
+  AMWG_STAGE_FENCE();
+#pragma unroll
+  for (int u = 0; u < U; ++u) b.v[u] = b.v[u] * b.v[u];
+  add_prev(2 * U / 7);
+  AMWG_STAGE_FENCE();
+#pragma unroll
+  for (int u = 0; u < U; ++u) q.v[u] = b.v[u] * y.lo;
+  add_prev(3 * U / 7);
+  AMWG_STAGE_FENCE();
+#pragma unroll
+  for (int u = 0; u < U; ++u) q.v[u] = __builtin_fma(b.v[u], y.hi, q.v[u]);
+  add_prev(4 * U / 7);
+  AMWG_STAGE_FENCE();
+#pragma unroll
+  for (int u = 0; u < U; ++u) b.v[u] = __builtin_fma(-den, q.v[u], b.v[u]);
+  add_prev(5 * U / 7);
+  AMWG_STAGE_FENCE();
+#pragma unroll
+  for (int u = 0; u < U; ++u) q.v[u] = __builtin_fma(b.v[u], y.hi, q.v[u]);
+  add_prev(6 * U / 7);
+  AMWG_STAGE_FENCE();
+#pragma unroll
+  for (int u = 0; u < U; ++u) q.v[u] = c - q.v[u];
+  add_prev(U);
+  AMWG_STAGE_FENCE();
+}
+
+// x: LDS (or global) array of the observations; lane `sub` of the chain's G lanes takes observations sub, sub + G, ...
+// MeanOf::gather == false: constant mean;  true: index array g (u8) and the chain's state S, mean of observation i = S(g[i])
+template <int G, int U, bool GATHER>
+__device__ __forceinline__ double norm_pass_staged(const double *x, const uint8_t *g, const StateView S, double mean, double c, double den,
+                                                   Reciprocal y, int n_obs, int sub, double acc) {
+  const int n_full = n_obs / G, rem = n_obs % G;
+  const int n_blocks = n_full / U;
+  int k = 0;
+  if (n_blocks > 0) {
+    NormBlock<U> xa, xb, qa, qb;
+    double ma[U], mb[U];
+    int ga[U], gb[U];     // GATHER: group indices, read one block further ahead than the values
+    const double *px = x + sub;
+    const uint8_t *pg = g + sub;
+    auto load_idx = [&](int blk, int (&gi)[U]) {
+      if constexpr (GATHER) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) gi[u] = pg[(blk * U + u) * G];
+      }
+    };
+    auto load_val = [&](int blk, NormBlock<U> &xv, double (&mv)[U], const int (&gi)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) xv.v[u] = px[(blk * U + u) * G];
+#pragma unroll
+      for (int u = 0; u < U; ++u) mv[u] = GATHER ? S(gi[u]) : mean;
+    };
+    // prologue: block 0 loaded, indices of block 1 on their way
+    load_idx(0, ga);
+    load_val(0, xa, ma, ga);
+    if (n_blocks > 1) load_idx(1, gb);
+    AMWG_STAGE_FENCE();
+    // block 0: nothing to add yet
+    if (n_blocks > 1) { load_val(1, xb, mb, gb); if (n_blocks > 2) load_idx(2, ga); }
+    AMWG_STAGE_FENCE();
+    norm_block_stages<U, false>(xa, ma, qa, qa, acc, c, den, y);
+    int blk = 1;
+    // steady state, two blocks per trip (A/B register sets swap roles, no copies): on entry the terms of block blk-1 sit in qa,
+    // the values of block blk in xb/mb, the indices of block blk+1 in ga
+    for (; blk + 2 < n_blocks; blk += 2) {
+      load_val(blk + 1, xa, ma, ga);
+      load_idx(blk + 2, gb);
+      AMWG_STAGE_FENCE();
+      norm_block_stages<U, true>(xb, mb, qb, qa, acc, c, den, y);
+      load_val(blk + 2, xb, mb, gb);
+      if (blk + 3 < n_blocks) load_idx(blk + 3, ga);
+      AMWG_STAGE_FENCE();
+      norm_block_stages<U, true>(xa, ma, qa, qb, acc, c, den, y);
+    }
+    // epilogue: one or two blocks left (blk, and maybe blk + 1), terms of blk-1 pending in qa
+    if (blk < n_blocks) {
+      if (blk + 1 < n_blocks) load_val(blk + 1, xa, ma, ga);
+      AMWG_STAGE_FENCE();
+      norm_block_stages<U, true>(xb, mb, qb, qa, acc, c, den, y);
+      if (blk + 1 < n_blocks) {
+        norm_block_stages<U, true>(xa, ma, qa, qb, acc, c, den, y);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = acc + qa.v[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = acc + qb.v[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc = acc + qa.v[u];
+    }
+    k = n_blocks * U;
+  }
+  // ragged tail: fewer than U rounds, then the lanes below n_obs % G take one more observation
+  for (; k < n_full; ++k) {
+    const int i = k * G + sub;
+    const double t = x[i] - (GATHER ? S(g[i]) : mean);
+    acc += c - div_by_invariant(t * t, den, y);
+  }
+  if (sub < rem) {
+    const int i = n_full * G + sub;
+    const double t = x[i] - (GATHER ? S(g[i]) : mean);
+    acc += c - div_by_invariant(t * t, den, y);
+  }
+  return acc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // x_i ~ norm(mu, sigma); mu ~ norm(m0,s0); sigma ~ unif(a,b)              README.md:22-36
 struct NormalModel {
@@ -58,6 +201,12 @@ struct NormalModel {
     const double t = ps.x[i] - ps.mu;
     const double tt = t * t;
     return ps.c - (FAST ? div_by_invariant(tt, ps.den, ps.y) : tt / ps.den);
+  }
+  // the fast pass, hand-pipelined (same operations and order as term<true> summed by pass_over_data)
+  static constexpr bool kStagedFast = true;
+  template <int G>
+  __device__ __forceinline__ static double pass_fast(const Pass &ps, int n_obs, int sub, double acc) {
+    return norm_pass_staged<G, 8, false>(ps.x, nullptr, StateView{nullptr}, ps.mu, ps.c, ps.den, ps.y, n_obs, sub, acc);
   }
 };
 
@@ -275,6 +424,12 @@ struct HierNormalModel {
     const double t = ps.x[i] - ps.S(ps.g[i]);
     const double tt = t * t;
     return ps.c - (FAST ? div_by_invariant(tt, ps.den, ps.y) : tt / ps.den);
+  }
+  // the fast pass, hand-pipelined: group indices two blocks ahead, y and theta[g] one block ahead of the arithmetic
+  static constexpr bool kStagedFast = true;
+  template <int G>
+  __device__ __forceinline__ static double pass_fast(const Pass &ps, int n_obs, int sub, double acc) {
+    return norm_pass_staged<G, 4, true>(ps.x, ps.g, ps.S, 0.0, ps.c, ps.den, ps.y, n_obs, sub, acc);
   }
 };
 

@@ -79,8 +79,36 @@ AMWG_HD double bern_loop_one_lane(double acc, const BernInv &k, const int32_t *t
 }
 
 // JavaScript operators that differ from C++
-AMWG_HD double js_mod(double a, double b) {   // % on numbers: sign of the dividend (fmod); exact
-  return __builtin_fmod(a, b);
+// `%` on numbers (ECMA-262 6.1.6.1.6): the exact remainder of the truncating division, with the sign of the DIVIDEND -- also when
+// the result is zero (-0 % 3 is -0, -6 % 3 is -0); NaN for a NaN operand, an infinite dividend or a zero divisor; the dividend
+// itself for an infinite divisor.  Written out on the bit patterns (restoring shift-subtract division of the significands, one
+// quotient bit per exponent step) instead of __builtin_fmod: that lowers to a toolchain-specific `frem` expansion / ocml call on
+// the device, whose zero results lost the sign on the GPU box in round 1, and to glibc on the host.  Same code on both here.
+AMWG_HD double js_mod(double a, double b) {
+  const uint64_t ua = f64_bits(a), ub = f64_bits(b);
+  const uint64_t sign = ua & 0x8000000000000000ull;
+  uint64_t ma = ua & 0x7fffffffffffffffull, mb = ub & 0x7fffffffffffffffull;
+  if (ma >= 0x7ff0000000000000ull || mb > 0x7ff0000000000000ull || mb == 0) return __builtin_nan("");
+  if (ma < mb) return a;                      // includes b = +-inf and a = +-0
+  if (ma == mb) return bits_f64(sign);        // +-0 with the dividend's sign
+  int ea = (int)(ma >> 52), eb = (int)(mb >> 52);
+  // significands with the hidden bit at position 52 (subnormals are shifted up, exponent counted down)
+  if (ea == 0) { const int sh = __builtin_clzll(ma) - 11; ma <<= sh; ea = 1 - sh; }
+  else ma = (ma & 0x000fffffffffffffull) | 0x0010000000000000ull;
+  if (eb == 0) { const int sh = __builtin_clzll(mb) - 11; mb <<= sh; eb = 1 - sh; }
+  else mb = (mb & 0x000fffffffffffffull) | 0x0010000000000000ull;
+  for (; ea > eb; --ea) {
+    if (ma >= mb) ma -= mb;
+    ma <<= 1;
+  }
+  if (ma >= mb) ma -= mb;
+  if (ma == 0) return bits_f64(sign);
+  const int sh = __builtin_clzll(ma) - 11;    // renormalise; the remainder is < b so it fits
+  ma <<= sh;
+  ea -= sh;
+  if (ea > 0) ma = (ma & 0x000fffffffffffffull) | ((uint64_t)ea << 52);
+  else ma >>= (1 - ea);                       // subnormal result (exact: the low bits shifted out are zero)
+  return bits_f64(ma | sign);
 }
 AMWG_HD double js_max(double a, double b) {   // Math.max: NaN if either is NaN, +0 > -0
   if (a != a || b != b) return __builtin_nan("");
@@ -100,7 +128,7 @@ AMWG_HD int32_t js_toint32(double x) {
   if (!(__builtin_fabs(x) < __builtin_inf())) return 0;
   const double t = __builtin_trunc(x);
   if (t >= -2147483648.0 && t <= 2147483647.0) return (int32_t)t;
-  double m = __builtin_fmod(t, 4294967296.0);           // exact; sign of t
+  double m = js_mod(t, 4294967296.0);                   // exact; sign of t
   if (m < 0) m += 4294967296.0;
   return (int32_t)(uint32_t)m;
 }

@@ -228,7 +228,7 @@ double amwg_log1p(double x);           /* bit-identical to V8 Math.log1p */
 double amwg_expm1(double x);           /* bit-identical to V8 Math.expm1 */
 double amwg_math1(int32_t fn, double x); /* fn 0 tanh, 1 atan, 2 log10, 3 sin, 4 cos, 5 tan, 6 asin, 7 acos, 8 sinh, 9 cosh, 10 asinh, 11 acosh, 12 atanh, 13 cbrt, 14 log2:
                                             bit-identical to V8's Math.* (host build of the kernel source, csrc/amwg_math.h + amwg_trig.h) */
-double amwg_math2(int32_t fn, double x, double y); /* fn 0: Math.atan2(x, y), 1: Math.hypot(x, y) */
+double amwg_math2(int32_t fn, double x, double y); /* fn 0: Math.atan2(x, y), 1: Math.hypot(x, y), 2: x % y (JavaScript), 3: x | 0 (ToInt32; y ignored) */
 double amwg_hypot3(double x, double y, double z);   /* Math.hypot(x, y, z) */
 /* Every scalar ld.* density and helper of distributions.js by id (0 norm 1 unif 2 beta 3 bern 4 pois 5 cauchy
  * 6 laplace 7 gamma 8 invgamma 9 lnorm 10 pareto 11 t 12 weibull 13 logis 14 exp 15 binom 16 nbinom 17 hyper

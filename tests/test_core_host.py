@@ -110,3 +110,15 @@ def test_host_build_of_the_trigonometric_hyperbolic_and_root_twins_equals_v8():
     assert sum(not _same(L.amwg_math2(0, y, x), w) for y, x, w in b) == 0
     h = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_hypot_pairs.bin"), dtype="<f8").reshape(-1, 5)
     assert sum((not _same(L.amwg_math2(1, p, q), h2)) + (not _same(L.amwg_hypot3(p, q, r), h3)) for p, q, r, h2, h3 in h) == 0
+
+
+def test_host_js_mod_and_toint32_equal_v8():
+    """`%` and `x | 0` of translated closures (csrc/amwg_user.h js_mod / js_toint32, host build of the same header the device
+    compiles) against 40 000 pairs recorded from V8 (oracle/gen_mod_golden.js): every +-0 / inf / NaN combination, exact
+    multiples (sign of a zero result = sign of the dividend), subnormals, exponent gaps of thousands of bits."""
+    L = amwg_ctypes.lib()
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_mod_pairs.bin"), dtype="<f8").reshape(-1, 4)
+    bad = [(x, y, w, L.amwg_math2(2, x, y)) for x, y, w, _ in a if not _same(L.amwg_math2(2, x, y), w)]
+    assert not bad, bad[:5]
+    bad = [(x, w, L.amwg_math2(3, x, 0.0)) for x, _, _, w in a if not _same(L.amwg_math2(3, x, 0.0), w)]
+    assert not bad, bad[:5]

@@ -188,3 +188,15 @@ def test_device_trigonometric_hyperbolic_and_root_twins_equal_v8():
     g2 = A.device_eval(23, np.ascontiguousarray(h[:, 0]), np.ascontiguousarray(h[:, 1]))
     assert ((g3.view(np.uint64) == np.ascontiguousarray(h[:, 4]).view(np.uint64)) | (np.isnan(g3) & np.isnan(h[:, 4]))).all()
     assert ((g2.view(np.uint64) == np.ascontiguousarray(h[:, 3]).view(np.uint64)) | (np.isnan(g2) & np.isnan(h[:, 3]))).all()
+
+
+def test_device_js_mod_and_toint32_equal_v8():
+    """`%` (js_mod) and `x | 0` (js_toint32) ON THE DEVICE against V8's own results (tests/golden/v8_mod_pairs.bin,
+    oracle/gen_mod_golden.js): -0 % 3 = -0, -6 % 3 = -0, 5.5 % 0.1, 1e20 % 3, subnormals, +-inf, NaN.  Round 1's device
+    `%` was the toolchain's frem expansion and returned +0 for a -0 dividend on the GPU box."""
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_mod_pairs.bin"), dtype="<f8").reshape(-1, 4)
+    x, y = np.ascontiguousarray(a[:, 0]), np.ascontiguousarray(a[:, 1])
+    for op, want in ((24, np.ascontiguousarray(a[:, 2])), (25, np.ascontiguousarray(a[:, 3]))):
+        got = A.device_eval(op, x, y)
+        ok = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+        assert ok.all(), (op, x[~ok][:5], y[~ok][:5], got[~ok][:5], want[~ok][:5])
