@@ -45,7 +45,7 @@ class UserModel(C.Structure):
                 ("parallel", C.c_int32), ("max_threads", C.c_int32), ("work_per_eval", C.c_double), ("work_one_lane", C.c_double)]
 
 
-EXPORTS = ["amwg_math1", "amwg_math2", "amwg_hypot3", "amwg_log1p", "amwg_expm1", "amwg_two_valued_sum_check", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
+EXPORTS = ["amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_math1", "amwg_math2", "amwg_hypot3", "amwg_log1p", "amwg_expm1", "amwg_two_valued_sum_check", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
            "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components",
            "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp",
            "amwg_log", "amwg_uniform", "amwg_device_eval"]
@@ -99,6 +99,10 @@ def lib():
         L.amwg_two_valued_sum_check.argtypes = [i32, pd, i32, i64, pd, pd, pd, pd, pd]
         L.amwg_last_sample_quantiles.argtypes = [vp, pd, i32, pd]
         L.amwg_last_sample_diagnostics.argtypes = [vp, pd, pd]
+        pvp = C.POINTER(vp)
+        L.amwg_group_moments.argtypes = [pvp, i32, pd, pd]
+        L.amwg_group_diagnostics.argtypes = [pvp, i32, pd, pd]
+        L.amwg_group_quantiles.argtypes = [pvp, i32, pd, i32, pd]
         L.amwg_pow.restype = dbl
         L.amwg_pow.argtypes = [dbl, dbl]
         L.amwg_math1.restype = dbl
@@ -300,6 +304,34 @@ class Sampler:
         _check(lib().amwg_launch_info(self.h, *[C.byref(x) for x in v], C.byref(ms)))
         return {"lanes_per_chain": v[0].value, "block_threads": v[1].value, "grid_blocks": v[2].value,
                 "lds_bytes": v[3].value, "n_launches": v[4].value, "kernel_ms": ms.value}
+
+
+def _group(samplers):
+    arr = (C.c_void_p * len(samplers))(*[s.h for s in samplers])
+    return arr, len(samplers), samplers[0].PR
+
+
+def group_moments(samplers):
+    """mean, sd over the pooled draws of several samplers (the shards of one job): amwg_group_moments (RCCL all-reduce)"""
+    arr, n, PR = _group(samplers)
+    m, sd = np.empty(PR), np.empty(PR)
+    _check(lib().amwg_group_moments(arr, n, _dp(m), _dp(sd)))
+    return m, sd
+
+
+def group_convergence(samplers):
+    arr, n, PR = _group(samplers)
+    r, e = np.empty(PR), np.empty(PR)
+    _check(lib().amwg_group_diagnostics(arr, n, _dp(r), _dp(e)))
+    return r, e
+
+
+def group_quantiles(samplers, probs):
+    arr, n, PR = _group(samplers)
+    pr = np.ascontiguousarray(probs, dtype=np.float64)
+    out = np.empty((PR, pr.size))
+    _check(lib().amwg_group_quantiles(arr, n, _dp(pr), pr.size, _dp(out)))
+    return out
 
 
 def fp64_peak(device=0):

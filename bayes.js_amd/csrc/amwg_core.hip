@@ -152,7 +152,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const amwg_options &o = s->opt;
   auto layout = [&](int bt, int G) {
     const size_t data_bytes = s->user ? (size_t)(G == 1 ? s->user_lds_one_lane : s->user_lds) : model_lds_bytes(s->model, s->d.n_obs, s->d.G, G);
-    return G > 64 ? lds_layout(data_bytes, s->P, G / 64, s->pl.max_top, true) : lds_layout(data_bytes, s->P, bt / G, s->pl.max_top);
+    return G > 64 ? lds_layout(data_bytes, s->P, G / 64, s->pl.max_top, s->n_params, true) : lds_layout(data_bytes, s->P, bt / G, s->pl.max_top, s->n_params);
   };
   const int max_bt = s->user ? s->user_max_threads : model_max_threads(s->model);
   auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds; };
@@ -160,14 +160,16 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     return fail(AMWG_EINVAL, "this closure has no loop that can be split over lanes: lanes_per_chain must be 1 (or 0 = auto), got %d", o.lanes_per_chain);
   const int bts[5] = {1024, 512, 256, 128, 64};
   int bestG = 0, bestB = 0;
-  double bestOcc = -1.0;
+  double bestOcc = -1.0, cost1 = -1.0;
+  int block1 = 0;
+  const bool fixed_lanes = o.lanes_per_chain > 0;
   for (int G = 1; G <= 1024; G <<= 1) {
-    if (o.lanes_per_chain && G != o.lanes_per_chain) continue;
+    if (fixed_lanes && G != o.lanes_per_chain) continue;
     if (s->user && !s->user_parallel && G > 1) break;   // nothing to split: one lane per chain
     // translated closures: with one lane per chain every data index is wave-uniform and the compiler moves the
     // per-observation integer logic to the scalar unit, which issues 4x slower than the vector lanes (measured 2.5x on
     // the beta-Bernoulli closure); two lanes per chain keep it on the vector path at no measurable cost elsewhere
-    if (s->user && s->user_parallel && !o.lanes_per_chain && G == 1 && !(s->user_work_one_lane > 0)) continue;
+    if (s->user && s->user_parallel && !fixed_lanes && G == 1 && !(s->user_work_one_lane > 0)) continue;
     int pick = 0;
     for (int bi = 0; bi < 5; ++bi) {   // largest workgroup with >= one workgroup per CU, else the smallest that fits
       const int bt = bts[bi];
@@ -195,10 +197,18 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     for (int g = G; g < 64; g <<= 1) ++lg;
     const double S = 400.0 + 97.0 * lg;
     const double Wl = model_work(s, G) / G + (G > 64 ? 150.0 : 0.0);   // + the workgroup barrier of every evaluation
+    // (round 2, hand-pipelined data loops: one wave per SIMD already issues back to back; what a lone wave loses is the issue slots
+    // of its own non-arithmetic instructions, 10 % at cfg2 with one lane per chain vs four waves -- measured 3.64e8 vs 4.03e8)
     const double w1 = w_res > 1.0 ? w_res : 1.0;
-    const double cost = (w_total / w_res) * (S * (w_res > 1.8 ? w_res : 1.8) + Wl * (w_res > 1.15 ? w_res : 1.15) * (1.0 + 0.3 / w1));
+    const double cost = (w_total / w_res) * (S * (w_res > 1.8 ? w_res : 1.8) + Wl * w1 * (1.0 + 0.14 / w1));
+    if (G == 1) { cost1 = cost; block1 = pick; }
     if (bestOcc < 0 || cost < bestOcc * (1.0 - 1e-9)) { bestOcc = cost; bestG = G; bestB = pick; }   // bestOcc holds the best cost
   }
+  // Reference order first: with ONE lane per chain a chain's log_post is summed exactly as the reference sums it (`lp += term`,
+  // mcmc.js:958-960), so every draw of a seeded run is the reference's bit for bit; with more lanes only the decisions are
+  // (tested), the doubles are those of the G-lane order.  Unless the caller asked for a lane count (or for AMWG_LANES_FASTEST),
+  // take one lane per chain whenever the model prices it within 12 % of the cheapest geometry.
+  if (o.lanes_per_chain == 0 && bestG > 1 && cost1 > 0 && cost1 <= 1.12 * bestOcc) { bestG = 1; bestB = block1; }
   if (!bestG) return fail(AMWG_EINVAL, "no launch geometry fits: the model needs more than %zu bytes of LDS", max_lds);
   s->lanes = bestG;
   s->block = bestB;
@@ -419,7 +429,8 @@ __global__ void two_valued_check_kernel(const uint32_t *tab, int N, int64_t m, c
 static int check_options(const amwg_options *options, int max_threads) {
   if (options->chains < 1) return fail(AMWG_EINVAL, "amwg_create: chains must be >= 1");
   const int G_opt = options->lanes_per_chain;
-  if (G_opt && (G_opt < 1 || G_opt > 1024 || (G_opt & (G_opt - 1)))) return fail(AMWG_EINVAL, "lanes_per_chain must be a power of two in 1..1024");
+  if (G_opt && G_opt != AMWG_LANES_FASTEST && (G_opt < 1 || G_opt > 1024 || (G_opt & (G_opt - 1))))
+    return fail(AMWG_EINVAL, "lanes_per_chain must be a power of two in 1..1024 (or 0 = auto, AMWG_LANES_FASTEST = -1)");
   if (G_opt > 64 && options->block_threads && options->block_threads != G_opt)
     return fail(AMWG_EINVAL, "a chain on %d lanes is one workgroup of %d threads: block_threads must be 0 or %d", G_opt, G_opt, G_opt);
   if (G_opt > max_threads) return fail(AMWG_EINVAL, "lanes_per_chain %d exceeds this model's workgroup limit %d", G_opt, max_threads);
@@ -430,12 +441,13 @@ static int check_options(const amwg_options *options, int max_threads) {
   return AMWG_OK;
 }
 
-// completed params (mcmc.js:357-403) -> flat layout.  Stepped parameters first (s->n_params of them, at most kMaxNamed); trailing
-// AMWG_FIXED entries only add state slots.
+// completed params (mcmc.js:357-403) -> flat layout.  Stepped parameters first (s->n_params of them, any number up to kMaxIndex);
+// trailing AMWG_FIXED entries only add state slots.  The per-parameter table goes to the device (upload_layout).
 static int build_layout(amwg_sampler *s, const amwg_param_desc *params, int n_params, bool allow_fixed) {
   ParamLayout &pl = s->pl;
   pl.max_top = 1;
   int P = 0, n_stepped = 0;
+  std::vector<int32_t> base, len, top, multidim;
   bool fixed_seen = false;
   for (int p = 0; p < n_params; ++p) {
     const amwg_param_desc &q = params[p];
@@ -449,11 +461,11 @@ static int build_layout(amwg_sampler *s, const amwg_param_desc *params, int n_pa
     if (fixed_seen) return fail(AMWG_EINVAL, "parameter %d: stepped parameters must come before the AMWG_FIXED entries", p);
     if (q.type != AMWG_REAL && q.type != AMWG_INT && q.type != AMWG_BINARY)
       return fail(AMWG_EINVAL, "AmwgStepper can't handle parameter %d with type %d", p, q.type);   // mcmc.js:867
-    if (n_stepped >= kMaxNamed) return fail(AMWG_EINVAL, "more than %d stepped parameters", kMaxNamed);
+    if (n_stepped >= kMaxIndex) return fail(AMWG_EINVAL, "more than %d stepped parameters", kMaxIndex);
     if (q.len < 1 || q.top < 1 || q.len % q.top) return fail(AMWG_EINVAL, "parameter %d: bad dim (len %d, top %d)", p, q.len, q.top);
-    if (q.top > kMaxTop) return fail(AMWG_EINVAL, "parameter %d: leading dimension %d > %d", p, q.top, kMaxTop);
+    if (q.top > kMaxIndex) return fail(AMWG_EINVAL, "parameter %d: leading dimension %d > %d", p, q.top, kMaxIndex);
     if (!q.multidim && q.len != 1) return fail(AMWG_EINVAL, "parameter %d: dim [1] but len %d", p, q.len);
-    pl.base[n_stepped] = P; pl.len[n_stepped] = q.len; pl.top[n_stepped] = q.top; pl.multidim[n_stepped] = q.multidim ? 1 : 0;
+    base.push_back(P); len.push_back(q.len); top.push_back(q.top); multidim.push_back(q.multidim ? 1 : 0);
     if (q.multidim && q.top > pl.max_top) pl.max_top = q.top;
     P += q.len;
     ++n_stepped;
@@ -464,6 +476,8 @@ static int build_layout(amwg_sampler *s, const amwg_param_desc *params, int n_pa
   pl.P = P;
   s->P = P;
   s->n_params = n_stepped;
+  s->h_layout.clear();
+  for (const std::vector<int32_t> *v : {&base, &len, &top, &multidim}) s->h_layout.insert(s->h_layout.end(), v->begin(), v->end());
   return AMWG_OK;
 }
 
@@ -498,6 +512,12 @@ static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int
   HIPB(hipMemcpy(s->d_cc, hcc.data(), (size_t)P * sizeof(CompConst), hipMemcpyHostToDevice));
   TRYB(dev_alloc(s, &s->d_adapt, (size_t)P));
   HIPB(hipMemcpy(s->d_adapt, s->h_adapt.data(), (size_t)P, hipMemcpyHostToDevice));
+  {
+    int32_t *d_tab = nullptr;
+    TRYB(dev_alloc(s, &d_tab, s->h_layout.size()));
+    HIPB(hipMemcpy(d_tab, s->h_layout.data(), s->h_layout.size() * 4, hipMemcpyHostToDevice));
+    s->pl.tab = d_tab;
+  }
 
   const size_t PC = (size_t)P * (size_t)s->C, C = (size_t)s->C;
   ChainArrays &ch = s->ch;
@@ -508,7 +528,10 @@ static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int
   TRYB(dev_alloc(s, &ch.batch_count, PC));
   TRYB(dev_alloc(s, &ch.accepts, PC));
   TRYB(dev_alloc(s, &ch.inbounds, PC));
+  const bool wide_perm = s->n_params > kPackedNamed;
   TRYB(dev_alloc(s, &ch.perm, C));
+  ch.perm16 = nullptr;
+  if (wide_perm) TRYB(dev_alloc(s, &ch.perm16, (size_t)s->n_params * C));
   TRYB(dev_alloc(s, &ch.rng_n, C));
   TRYB(dev_alloc(s, &ch.lp_curr, C));
   {
@@ -518,9 +541,14 @@ static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int
     for (int p = 0; p < P; ++p) for (size_t c = 0; c < C; ++c) tmp[(size_t)p * C + c] = comp_opts[p].prop_log_scale;
     HIPB(hipMemcpy(ch.prop_log_scale, tmp.data(), PC * 8, hipMemcpyHostToDevice));
     uint64_t ident = 0;
-    for (int i = 0; i < kMaxNamed; ++i) ident |= (uint64_t)i << (4 * i);
+    for (int i = 0; i < kPackedNamed; ++i) ident |= (uint64_t)i << (4 * i);
     std::vector<uint64_t> pv(C, ident);
     HIPB(hipMemcpy(ch.perm, pv.data(), C * 8, hipMemcpyHostToDevice));
+    if (wide_perm) {   // initial order = Object.keys(params) (mcmc.js:839)
+      std::vector<uint16_t> p16((size_t)s->n_params * C);
+      for (int k = 0; k < s->n_params; ++k) for (size_t c = 0; c < C; ++c) p16[(size_t)k * C + c] = (uint16_t)k;
+      HIPB(hipMemcpy(ch.perm16, p16.data(), p16.size() * 2, hipMemcpyHostToDevice));
+    }
   }
   HIPB(hipMemset(ch.acceptance_count, 0, PC * 4));
   HIPB(hipMemset(ch.iterations_since_adaption, 0, PC * 4));
@@ -592,7 +620,7 @@ int amwg_compile_user(const char *source, int32_t lanes_per_chain, int32_t block
 int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t n_params, const double *init,
                 const amwg_comp_opt *comp_opts, const amwg_options *options, amwg_sampler **out) {
   if (!m || !params || !init || !comp_opts || !options || !out) return fail(AMWG_EINVAL, "amwg_create: null argument");
-  if (n_params < 1 || n_params > kMaxNamed) return fail(AMWG_EINVAL, "amwg_create: %d named parameters (supported: 1..%d)", n_params, kMaxNamed);
+  if (n_params < 1 || n_params > kMaxIndex) return fail(AMWG_EINVAL, "amwg_create: %d named parameters (supported: 1..%d)", n_params, kMaxIndex);
   if (m->n_obs < 0) return fail(AMWG_EINVAL, "amwg_create: n_obs < 0");
   {
     int rc = check_options(options, model_max_threads(m->model));
@@ -623,8 +651,8 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
       if (!m->x && N) return bail(fail(AMWG_EINVAL, "beta_bern model: x is null"));
       break;
     case AMWG_MODEL_HIER_NORMAL:
-      if (n_params != 3 || m->G < 1 || m->G > 256 || params[0].len != m->G || P != m->G + 2)
-        return bail(fail(AMWG_EINVAL, "hier_normal model expects params {theta[G], mu, sigma}, 1 <= G <= 256"));
+      if (n_params != 3 || m->G < 1 || m->G > 256 || params[0].len != m->G || P != m->G + 2)   // group ids are bytes in LDS
+        return bail(fail(AMWG_EINVAL, "hier_normal model expects params {theta[G], mu, sigma}, 1 <= G <= 256 (more groups: write the closure, it is translated)"));
       if ((!m->x || !m->g) && N) return bail(fail(AMWG_EINVAL, "hier_normal model: y or g is null"));
       break;
     case AMWG_MODEL_POIS_GLM:
@@ -658,6 +686,11 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   if (m->model == AMWG_MODEL_BETA_BERN) {
     mc.ba = h[0]; mc.bb = h[1];
     mc.lbeta_ab = lbeta_js(h[0], h[1]);
+  }
+  {   // reciprocals of the constant prior divisors, as the kernel's own make_reciprocal computes them
+    const Reciprocal y0 = make_reciprocal(mc.den0), y1 = make_reciprocal(mc.den1);
+    mc.y0_hi = y0.hi; mc.y0_lo = y0.lo; mc.den0_ok = (!options->exact_division && mid_range(mc.den0)) ? 1 : 0;
+    mc.y1_hi = y1.hi; mc.y1_lo = y1.lo; mc.den1_ok = (!options->exact_division && mid_range(mc.den1)) ? 1 : 0;
   }
   mc.cp_upper = (double)(N - 1);
   mc.lunif_cp = log_v8(1 / (mc.cp_upper - 0.0));
@@ -740,8 +773,8 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
 int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, int32_t n_params, const double *init,
                      const amwg_comp_opt *comp_opts, const amwg_options *options, amwg_sampler **out) {
   if (!m || !m->source || !params || !init || !comp_opts || !options || !out) return fail(AMWG_EINVAL, "amwg_create_user: null argument");
-  if (n_params < 1 || n_params > 4096) return fail(AMWG_EINVAL, "amwg_create_user: %d parameter entries (supported: 1..4096, of which at most %d stepped)", n_params, kMaxNamed);
-  if (m->n_arrays < 0 || m->n_arrays > kMaxUserArrays) return fail(AMWG_EINVAL, "amwg_create_user: %d data arrays (supported: 0..%d)", m->n_arrays, kMaxUserArrays);
+  if (n_params < 1 || n_params > (1 << 20)) return fail(AMWG_EINVAL, "amwg_create_user: %d parameter entries (supported: 1..%d, of which at most %d stepped)", n_params, 1 << 20, kMaxIndex);
+  if (m->n_arrays < 0) return fail(AMWG_EINVAL, "amwg_create_user: %d data arrays", m->n_arrays);
   if (m->n_arrays && (!m->arrays || !m->array_len)) return fail(AMWG_EINVAL, "amwg_create_user: arrays is null");
   if (m->n_derived < 0 || m->lds_bytes < 0) return fail(AMWG_EINVAL, "amwg_create_user: negative size");
   const int max_threads = m->max_threads > 0 ? (m->max_threads / 64) * 64 : 1024;
@@ -771,6 +804,8 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
   // ---- data: every array the closure reads, as f64, row-major
   DataRef &d = s->d;
   d.n_obs = 0;
+  std::vector<const void *> ext;      // arrays beyond the kInlineUserArrays pointers of the kernel arguments
+  auto set_arr = [&](int j, const void *p) { if (j < kInlineUserArrays) d.arr[j] = p; else ext.push_back(p); };
   for (int j = 0; j < m->n_arrays; ++j) {
     const int64_t n = m->array_len[j];
     if (n < 0 || (n && !m->arrays[j])) return bail(fail(AMWG_EINVAL, "amwg_create_user: array %d is null or has a negative length", j));
@@ -779,7 +814,7 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
       double *p = nullptr;
       TRYB(dev_alloc(s, &p, (size_t)n));
       if (n) HIPB(hipMemcpy(p, m->arrays[j], (size_t)n * 8, hipMemcpyHostToDevice));
-      d.arr[j] = p;
+      set_arr(j, p);
     } else if (ty == AMWG_U8) {
       std::vector<uint8_t> tmp((size_t)n);
       for (int64_t i = 0; i < n; ++i) {
@@ -790,7 +825,7 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
       uint8_t *p = nullptr;
       TRYB(dev_alloc(s, &p, (size_t)n + 16));
       if (n) HIPB(hipMemcpy(p, tmp.data(), (size_t)n, hipMemcpyHostToDevice));
-      d.arr[j] = p;
+      set_arr(j, p);
     } else if (ty == AMWG_I32) {
       std::vector<int32_t> tmp((size_t)n);
       for (int64_t i = 0; i < n; ++i) {
@@ -801,10 +836,16 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
       int32_t *p = nullptr;
       TRYB(dev_alloc(s, &p, (size_t)n + 4));
       if (n) HIPB(hipMemcpy(p, tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-      d.arr[j] = p;
+      set_arr(j, p);
     } else {
       return bail(fail(AMWG_EINVAL, "amwg_create_user: array %d has unknown storage type %d", j, ty));
     }
+  }
+  if (!ext.empty()) {
+    const void **d_ext = nullptr;
+    TRYB(dev_alloc(s, &d_ext, ext.size()));
+    HIPB(hipMemcpy(d_ext, ext.data(), ext.size() * sizeof(void *), hipMemcpyHostToDevice));
+    d.arr_ext = d_ext;
   }
   TRYB(alloc_chain_state(s, params, n_params, init, comp_opts));
 
@@ -1024,7 +1065,12 @@ int amwg_chain_diag(amwg_sampler *s, uint64_t *uniforms, double *log_post_out, i
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (uniforms) HIP_TRY(hipMemcpy(uniforms, s->ch.rng_n, C * 8, hipMemcpyDeviceToHost));
   if (log_post_out) HIP_TRY(hipMemcpy(log_post_out, s->ch.lp_curr, C * 8, hipMemcpyDeviceToHost));
-  if (named_order) {
+  if (named_order && s->ch.perm16) {
+    std::vector<uint16_t> p16((size_t)s->n_params * C);
+    HIP_TRY(hipMemcpy(p16.data(), s->ch.perm16, p16.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < C; ++c)
+      for (int k = 0; k < s->n_params; ++k) named_order[c * s->n_params + k] = (int32_t)p16[(size_t)k * C + c];
+  } else if (named_order) {
     std::vector<uint64_t> pv(C);
     HIP_TRY(hipMemcpy(pv.data(), s->ch.perm, C * 8, hipMemcpyDeviceToHost));
     for (size_t c = 0; c < C; ++c)

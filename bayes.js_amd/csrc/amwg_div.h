@@ -42,4 +42,10 @@ AMWG_HD bool mid_range(double v) {
   return (h - 0x33700000u) <= (0x4C700000u - 0x33700000u);
 }
 
+// |a| in 2^-600..2^600 (exactly zero is NOT included: 0 takes the IEEE path, it is rare)
+AMWG_HD bool wide_range(double a) {
+  const uint32_t h = (uint32_t)hi_word(a) & 0x7fffffffu;
+  return (h - 0x1A700000u) <= (0x65700000u - 0x1A700000u);
+}
+
 }  // namespace amwg

@@ -39,11 +39,11 @@
 namespace amwg {
 
 struct LdsLayout {
-  uint32_t data, state, pls, cnt, tot, cc, adapt, pl, idx, total, stride, logpls, bc, xw;
+  uint32_t data, state, pls, cnt, tot, cc, adapt, pl, idx, perm, total, stride, logpls, bc, xw;
 };
 // CPB = per-chain state copies in the workgroup: chains per workgroup (lanes per chain <= 64), or -- when one chain spans
 // several wavefronts -- one private replica per wavefront (`multi`, see step_body).
-__host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CPB, int max_top, bool multi = false) {
+__host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CPB, int max_top, int n_named, bool multi = false) {
   LdsLayout L;
   uint32_t o = 0;
   L.stride = (uint32_t)P | 1u;  // doubles per chain, odd (see StateView)
@@ -54,8 +54,10 @@ __host__ __device__ inline LdsLayout lds_layout(size_t data_bytes, int P, int CP
   L.tot = o;   o += (L.stride * CPB * 4 + 15) & ~15u;   // this launch's run totals, packed: accepts << 16 | evaluated (in-bounds) proposals
   L.cc = o;    o += (uint32_t)P * sizeof(CompConst);
   L.adapt = o; o += ((uint32_t)P + 7) & ~7u;
-  L.pl = o;    o += (uint32_t)((sizeof(ParamLayout) + 7) & ~(size_t)7);
-  L.idx = o;   o += (max_top > 1) ? (((uint32_t)max_top * CPB + 15) & ~15u) : 0;
+  L.pl = o;    o += (uint32_t)n_named * 20u;            // base | len | top | multidim | inner (= len / top), int32 each
+  o = (o + 15) & ~15u;
+  L.idx = o;   o += (max_top > 1) ? (((uint32_t)max_top * CPB * (max_top > kByteTop ? 2u : 1u) + 15) & ~15u) : 0;   // shuffle indices, u8 or u16
+  L.perm = o;  o += (n_named > kPackedNamed) ? (((uint32_t)n_named * CPB * 2u + 15) & ~15u) : 0;                  // order of the named steppers, u16
   L.logpls = o; o += multi ? L.stride * CPB * 8 : 0;   // prop_log_scale replicas (single-wave chains keep it in HBM)
   L.bc = o;     o += multi ? ((L.stride * CPB * 4 + 15) & ~15u) : 0;   // batch_count replicas
   L.xw = o;     o += multi ? 2u * 16u * 8u : 0;        // cross-wave partial sums, double buffered, <= 16 waves
@@ -91,15 +93,22 @@ struct CrossWave {
   int parity;
 };
 
+// per-chain values a model keeps from one log_post evaluation to the next (Model::Cache; translated closures have none)
+struct NoCache {};
+template <class...> using void_of = void;
+template <class M, class = void> struct CacheOf { using type = NoCache; static __device__ __forceinline__ type init() { return type{}; } };
+template <class M> struct CacheOf<M, void_of<typename M::Cache>> { using type = typename M::Cache; static __device__ __forceinline__ type init() { return M::cache_init(); } };
+
 template <class Model, int G>
-__device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a, const unsigned char *smem, int sub, CrossWave &xw) {
+__device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a, const unsigned char *smem, int sub, CrossWave &xw,
+                                           typename CacheOf<Model>::type &cache) {
   double acc;
   if constexpr (Model::kUser) {
     // translated closure: the generated body returns this lane's partial sum (lane 0 carries every
     // term outside the lane-split loops), see bayes.js_amd/translate.js
     acc = Model::template eval<G, false>(S, a.d, smem, sub, nullptr);
   } else {
-    const typename Model::Pass ps = Model::begin(S, a.mc, a.d, smem);
+    const typename Model::Pass ps = Model::template begin<G>(S, a.mc, a.d, smem, cache);
     const double prior = Model::prior(S, a.mc, a.d);
     acc = (sub == 0) ? prior : 0.0;
     if constexpr (Model::kSplitPrior) acc = Model::template prior_split<G>(S, a.mc, a.d, sub, acc);
@@ -194,6 +203,19 @@ __device__ __forceinline__ double rnorm_js(Rng &rng, double mean, double sd) {  
   return (v / u) * sd + mean;
 }
 
+// Shuffle index tables in LDS, one column per chain of the workgroup (entry t of this chain at [t * CPB]); bytes while every index
+// fits one, 16-bit entries otherwise (a leading dimension > 256, more than 16 named parameters).  `wide` is uniform over the launch.
+struct IndexColumn {
+  unsigned char *base;    // already offset to this chain's column
+  int CPB;
+  bool wide;
+  __device__ __forceinline__ int get(int t) const {
+    return wide ? (int)reinterpret_cast<const uint16_t *>(base)[t * CPB] : (int)base[t * CPB];
+  }
+  __device__ __forceinline__ void set(int t, int v) const {
+    if (wide) reinterpret_cast<uint16_t *>(base)[t * CPB] = (uint16_t)v; else base[t * CPB] = (uint8_t)v;
+  }
+};
 __device__ __forceinline__ uint32_t perm_get(uint64_t perm, int i) { return (uint32_t)(perm >> (4 * i)) & 0xFu; }
 __device__ __forceinline__ uint64_t perm_swap(uint64_t perm, int i, int j) {
   const uint64_t d = ((perm >> (4 * i)) ^ (perm >> (4 * j))) & 0xFull;
@@ -217,14 +239,17 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   const int CPB = kMulti ? G / 64 : nt / G;                 // state copies in this workgroup
   const int c_in = kMulti ? tid / 64 : tid / G, sub = tid % G;
   const int P = a.pl.P;
-  const LdsLayout L = lds_layout(Model::lds_bytes(a.d.n_obs, a.d.G, G), P, CPB, a.pl.max_top, kMulti);
+  const int n_named = a.pl.n_params;
+  const LdsLayout L = lds_layout(Model::lds_bytes(a.d.n_obs, a.d.G, G), P, CPB, a.pl.max_top, n_named, kMulti);
 
   const unsigned char *data_lds = smem + L.data;
   double *Sblk = reinterpret_cast<double *>(smem + L.state);
   CompConst *cc = reinterpret_cast<CompConst *>(smem + L.cc);
   uint8_t *adapt = smem + L.adapt;
-  ParamLayout *pl = reinterpret_cast<ParamLayout *>(smem + L.pl);
-  uint8_t *idx = smem + L.idx + c_in;  // this chain's shuffle indices at idx[t * CPB]
+  int32_t *pl_base = reinterpret_cast<int32_t *>(smem + L.pl), *pl_len = pl_base + n_named, *pl_top = pl_len + n_named, *pl_multidim = pl_top + n_named, *pl_inner = pl_multidim + n_named;
+  const bool wide_idx = a.pl.max_top > kByteTop, wide_perm = n_named > kPackedNamed;
+  const IndexColumn idx{smem + L.idx + (wide_idx ? 2 * c_in : c_in), CPB, wide_idx};      // this chain's shuffle indices
+  const IndexColumn pcol{smem + L.perm + 2 * c_in, CPB, true};                             // order of the named steppers (wide_perm only)
   double *SDme = reinterpret_cast<double *>(smem + L.pls) + (size_t)c_in * L.stride;   // exp(prop_log_scale), mcmc.js:578
   int2 *CNTme = reinterpret_cast<int2 *>(smem + L.cnt) + (size_t)c_in * L.stride;
   // run totals of THIS launch (accepted << 16 | evaluated): kept in LDS and added to the HBM totals once, when the launch ends
@@ -233,11 +258,13 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   double *LOGPLSme = reinterpret_cast<double *>(smem + L.logpls) + (size_t)c_in * L.stride;   // multi only
   int32_t *BCme = reinterpret_cast<int32_t *>(smem + L.bc) + (size_t)c_in * L.stride;         // multi only
   CrossWave xw{reinterpret_cast<double *>(smem + L.xw), 0};
+  typename CacheOf<Model>::type cache = CacheOf<Model>::init();
 
   // ---- stage chain-shared data and per-component constants (coalesced, once per launch)
   Model::stage(smem + L.data, a.d, tid, nt, G);
   for (int p = tid; p < P; p += nt) { cc[p] = a.cc[p]; adapt[p] = a.is_adapting[p]; }
-  if (tid == 0) *pl = a.pl;
+  for (int i = tid; i < 4 * n_named; i += nt) pl_base[i] = a.pl.tab[i];
+  for (int i = tid; i < n_named; i += nt) pl_inner[i] = a.pl.tab[n_named + i] / a.pl.tab[2 * n_named + i];   // len / top: elements per top-level entry
 
   const int64_t chain_raw = kMulti ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * CPB + c_in;
   const bool live = chain_raw < a.C;
@@ -255,14 +282,15 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     if constexpr (kMulti) { LOGPLSme[p] = a.ch.prop_log_scale[p * C + cl]; BCme[p] = a.ch.batch_count[p * C + cl]; }
   }
   const StateView S{Sme};
-  uint64_t perm = a.ch.perm[cl];
+  uint64_t perm = wide_perm ? 0ull : a.ch.perm[cl];
+  if (wide_perm)
+    for (int k = 0; k < n_named; ++k) pcol.set(k, (int)a.ch.perm16[(int64_t)k * C + cl]);
   CoopStream<G> rng;
   rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid);
   double lp_curr = a.ch.lp_curr[cl];
   __syncthreads();
-  if (a.init_lp) lp_curr = log_post<Model, G>(S, a, data_lds, sub, xw);  // ctor warm-up call, mcmc.js:961-963
+  if (a.init_lp) lp_curr = log_post<Model, G>(S, a, data_lds, sub, xw, cache);  // ctor warm-up call, mcmc.js:961-963
 
-  const int n_named = pl->n_params;
   constexpr int D = Model::kDerived;
   const int PR = P + D;   // recorded values per draw: the parameters, then the closure's derived quantities
   int64_t row = a.row0;
@@ -288,30 +316,32 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     // ---- AmwgStepper.step: in-place Durstenfeld shuffle of the named sub-steppers (mcmc.js:887, 228-236)
     for (int i = n_named - 1; i > 0; --i) {
       const int j = (int)__builtin_floor(rng.next() * (double)(i + 1));
-      perm = perm_swap(perm, i, j);
+      if (wide_perm) { const int ti = pcol.get(i); pcol.set(i, pcol.get(j)); pcol.set(j, ti); }
+      else perm = perm_swap(perm, i, j);
     }
     // ---- every scalar component exactly once; `slot` is uniform across the block
-    int np = 0, e = 0;
-    const int P_stepped = pl->P_stepped;   // < P when the state has entries this sampler only reads (AMWG_FIXED)
+    int np = 0, e = 0, e_top = 0, e_in = 0;   // position inside the current parameter: e = e_top * inner + e_in (no division per slot)
+    const int P_stepped = a.pl.P_stepped;  // < P when the state has entries this sampler only reads (AMWG_FIXED)
     for (int slot = 0; slot < P_stepped; ++slot) {
-      const int p = (int)perm_get(perm, np);
-      const int len = pl->len[p];
-      int comp = pl->base[p];
-      if (pl->multidim[p]) {
-        const int top = pl->top[p];
+      const int p = wide_perm ? pcol.get(np) : (int)perm_get(perm, np);
+      const int len = pl_len[p];
+      int comp = pl_base[p];
+      if (pl_multidim[p]) {
+        const int top = pl_top[p];
         if (e == 0) {  // fresh shuffle of the top dimension (mcmc.js:248-252)
-          for (int t = 0; t < top; ++t) idx[t * CPB] = (uint8_t)t;
+          for (int t = 0; t < top; ++t) idx.set(t, t);
           for (int i = top - 1; i > 0; --i) {
             const int j = (int)__builtin_floor(rng.next() * (double)(i + 1));
-            const uint8_t ti = idx[i * CPB];
-            idx[i * CPB] = idx[j * CPB];
-            idx[j * CPB] = ti;
+            const int ti = idx.get(i);
+            idx.set(i, idx.get(j));
+            idx.set(j, ti);
           }
         }
-        const int inner = len / top;
-        comp += (int)idx[(e / inner) * CPB] * inner + (e % inner);
+        const int inner = pl_inner[p];
+        comp += idx.get(e_top) * inner + e_in;
+        if (++e_in == inner) { e_in = 0; ++e_top; }
       }
-      if (++e == len) { e = 0; ++np; }
+      if (++e == len) { e = 0; e_top = 0; e_in = 0; ++np; }
 
       const CompConst k = cc[comp];
       const int64_t gi = (int64_t)comp * C + cl;
@@ -320,9 +350,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         // probability exp(z - log(exp(z) + exp(o))) after subtracting the larger log density
         const double old = S(comp);
         Sme[comp] = 0.0;
-        const double zero_ld = log_post<Model, G>(S, a, data_lds, sub, xw);
+        const double zero_ld = log_post<Model, G>(S, a, data_lds, sub, xw, cache);
         Sme[comp] = 1.0;
-        const double one_ld = log_post<Model, G>(S, a, data_lds, sub, xw);
+        const double one_ld = log_post<Model, G>(S, a, data_lds, sub, xw, cache);
         const double mx = js_max2(zero_ld, one_ld);
         const double z = zero_ld - mx, o = one_ld - mx;
         const double zero_prob = exp_v8(z - log_v8(exp_v8(z) + exp_v8(o)));
@@ -340,7 +370,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       bool accepted = false;
       if (inb) {
         Sme[comp] = prop;
-        const double prop_lp = log_post<Model, G>(S, a, data_lds, sub, xw);
+        const double prop_lp = log_post<Model, G>(S, a, data_lds, sub, xw, cache);
         const double accept_prob = exp_v8(prop_lp - lp_curr);
         if (accept_prob > rng.next()) {
           accepted = true;
@@ -380,7 +410,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       a.ch.inbounds[p * C + cl] += (int32_t)(TOTme[p] & 0xffffu);
       if constexpr (kMulti) { a.ch.prop_log_scale[p * C + cl] = LOGPLSme[p]; a.ch.batch_count[p * C + cl] = BCme[p]; }
     }
-    a.ch.perm[cl] = perm;
+    if (wide_perm) { for (int k = 0; k < n_named; ++k) a.ch.perm16[(int64_t)k * C + cl] = (uint16_t)pcol.get(k); }
+    else a.ch.perm[cl] = perm;
     a.ch.rng_n[cl] = rng.n;
     a.ch.lp_curr[cl] = lp_curr;
   }

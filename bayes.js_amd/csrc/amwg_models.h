@@ -13,10 +13,33 @@
 
 namespace amwg {
 
-// ld.norm(v, 0|m, sd) with constant sd (a prior): c_sd - (v-m)^2 / (2*sd*sd)
-__device__ __forceinline__ double norm_const_sd(double v, double m, double c_sd, double den) {
+// ld.norm(v, 0|m, sd) with constant sd (a prior): c_sd - (v-m)^2 / (2*sd*sd).  The divisor is a hyper-parameter, so its
+// double-double reciprocal comes from the host (ModelConsts) and the quotient is the 4-operation correctly rounded one of
+// amwg_div.h whenever divisor and numerator are inside its range -- the same bits as '/', 13 instructions less per prior term.
+__device__ __forceinline__ double norm_const_sd(double v, double m, double c_sd, double den, double y_hi, double y_lo, int den_ok) {
   const double t = v - m;
-  return c_sd - (t * t) / den;
+  const double tt = t * t;
+  const double q = (den_ok && wide_range(tt)) ? div_by_invariant(tt, den, Reciprocal{y_hi, y_lo}) : tt / den;
+  return c_sd - q;
+}
+
+// The sd-dependent invariants of a pass -- c = -0.5*log(2*pi) - log(sd), den = 2*sd*sd, 1/den as a double-double -- kept per
+// chain across evaluations: most updates of a hierarchical model propose another component, sd is unchanged and so are these
+// (pure functions of sd; ~80 instructions incl. V8's log and an IEEE division).  sd starts as NaN, which never compares equal.
+struct NormCache {
+  double sd, c, den;
+  Reciprocal y;
+  bool den_ok;
+};
+__device__ __forceinline__ NormCache norm_cache_init() { return NormCache{__builtin_nan(""), 0.0, 0.0, Reciprocal{0.0, 0.0}, false}; }
+__device__ __forceinline__ void norm_cache_update(NormCache &k, double sd, double neg_half_log_2pi) {
+  if (sd != k.sd) {
+    k.sd = sd;
+    k.c = norm_c(neg_half_log_2pi, sd);
+    k.den = norm_den(sd);
+    k.y = make_reciprocal(k.den);
+    k.den_ok = mid_range(k.den);
+  }
 }
 
 
@@ -41,6 +64,17 @@ __device__ __forceinline__ double norm_const_sd(double v, double m, double c_sd,
 
 template <int U>
 struct NormBlock { double v[U]; };     // x, then t, tt, r in place
+
+// "the loads of THIS block have landed": with a constant mean a block is four LDS reads (ds_read2_b64 / ds_read_b128 pairs of the
+// U = 8 observations) and the four reads of the NEXT block were issued just before, so lgkmcnt <= 4 is exactly that.  Saying it
+// once keeps the compiler from placing one s_waitcnt in front of every pair of subtractions (with one wave per SIMD -- one lane
+// per chain at cfg2 -- every s_waitcnt is an issue slot the fp64 pipe idles through).  Only a hint: the compiler's own counter
+// tracking still inserts whatever wait a different instruction selection would need.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AMWG_WAIT_LDS_LE(n) __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8))   // vmcnt / expcnt untouched
+#else
+#define AMWG_WAIT_LDS_LE(n) ((void)0)
+#endif
 
 template <int U, bool ADD_PREV>
 __device__ __forceinline__ void norm_block_stages(NormBlock<U> &b, const double (&m)[U], NormBlock<U> &q, const NormBlock<U> &prev, double &acc,
@@ -95,8 +129,11 @@ __device__ __forceinline__ double norm_pass_staged(const double *x, const uint8_
     int ga[U], gb[U];     // GATHER: group indices, read one block further ahead than the values
     const double *px = x + sub;
     const uint8_t *pg = g + sub;
+    // (index prefetches past the end re-read the last block: harmless, and the loop body stays ONE basic block -- a conditional
+    // load splits it, the stage fences stop holding across the pieces and the register sets get copied instead of swapped)
     auto load_idx = [&](int blk, int (&gi)[U]) {
       if constexpr (GATHER) {
+        blk = blk < n_blocks ? blk : n_blocks - 1;
 #pragma unroll
         for (int u = 0; u < U; ++u) gi[u] = pg[(blk * U + u) * G];
       }
@@ -110,10 +147,10 @@ __device__ __forceinline__ double norm_pass_staged(const double *x, const uint8_
     // prologue: block 0 loaded, indices of block 1 on their way
     load_idx(0, ga);
     load_val(0, xa, ma, ga);
-    if (n_blocks > 1) load_idx(1, gb);
+    load_idx(1, gb);
     AMWG_STAGE_FENCE();
     // block 0: nothing to add yet
-    if (n_blocks > 1) { load_val(1, xb, mb, gb); if (n_blocks > 2) load_idx(2, ga); }
+    if (n_blocks > 1) { load_val(1, xb, mb, gb); load_idx(2, ga); }
     AMWG_STAGE_FENCE();
     norm_block_stages<U, false>(xa, ma, qa, qa, acc, c, den, y);
     int blk = 1;
@@ -123,10 +160,12 @@ __device__ __forceinline__ double norm_pass_staged(const double *x, const uint8_
       load_val(blk + 1, xa, ma, ga);
       load_idx(blk + 2, gb);
       AMWG_STAGE_FENCE();
+      if constexpr (!GATHER && U == 8) { AMWG_WAIT_LDS_LE(4); AMWG_STAGE_FENCE(); }
       norm_block_stages<U, true>(xb, mb, qb, qa, acc, c, den, y);
       load_val(blk + 2, xb, mb, gb);
-      if (blk + 3 < n_blocks) load_idx(blk + 3, ga);
+      load_idx(blk + 3, ga);
       AMWG_STAGE_FENCE();
+      if constexpr (!GATHER && U == 8) { AMWG_WAIT_LDS_LE(4); AMWG_STAGE_FENCE(); }
       norm_block_stages<U, true>(xa, ma, qa, qb, acc, c, den, y);
     }
     // epilogue: one or two blocks left (blk, and maybe blk + 1), terms of blk-1 pending in qa
@@ -162,6 +201,87 @@ __device__ __forceinline__ double norm_pass_staged(const double *x, const uint8_
   return acc;
 }
 
+// ONE lane per chain (the reference's own summation order): all 64 lanes of a wave -- 64 different chains -- need the SAME
+// observation at the same time, so the observations are wave-uniform.  They are then read through the SCALAR path (s_load_dwordx16 =
+// eight observations per instruction, from global memory through the scalar cache / L2, no LDS tile at all) and enter the fp64
+// pipe as SGPR operands.  With one wave per SIMD (65 536 chains = 1024 waves on 1024 SIMDs) every instruction that is not an fp64
+// operation is an issue slot the pipe idles through: the LDS version spends 8 ds_read + 9 others per 128 fp64 operations, this
+// one 2 s_load + ~8.  Scalar loads return out of order, so the only wait is lgkmcnt(0): a chunk of 16 observations is requested
+// one whole chunk (~520 cycles of arithmetic) before it is needed.  Same operations, same order, same bits as the plain loop.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const double __attribute__((address_space(4))) *amwg_uniform_f64_ptr;
+#else
+typedef const double *amwg_uniform_f64_ptr;
+#endif
+
+struct StagedFirst { static constexpr bool value = true; };
+struct StagedLater { static constexpr bool value = false; };
+
+template <int U>
+__device__ __forceinline__ double norm_pass_uniform(const double *x_global, double mean, double c, double den, Reciprocal y, int n_obs, double acc) {
+  constexpr int CH = 2 * U;                       // observations per chunk (two blocks of U)
+  const int n_chunks = n_obs / CH;
+  int k = 0;
+  if (n_chunks > 0) {
+    amwg_uniform_f64_ptr px = (amwg_uniform_f64_ptr)(uintptr_t)x_global;
+    double ma[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) ma[u] = mean;
+    NormBlock<CH> sa, sb;                         // the two chunks in flight (wave-uniform: scalar registers)
+    NormBlock<U> ta, tb, qa, qb;
+    auto load_chunk = [&](int ch, NormBlock<CH> &dst) {
+      ch = ch < n_chunks ? ch : n_chunks - 1;     // prefetches past the end re-read the last chunk (keeps the loop one basic block)
+#pragma unroll
+      for (int u = 0; u < CH; ++u) dst.v[u] = px[ch * CH + u];
+    };
+    auto lo = [&](const NormBlock<CH> &src, NormBlock<U> &t) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) t.v[u] = src.v[u];
+    };
+    auto hi = [&](const NormBlock<CH> &src, NormBlock<U> &t) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) t.v[u] = src.v[U + u];
+    };
+    // A scalar wait drains EVERY outstanding scalar load, so a new request must be issued right AFTER the wait for the previous
+    // one, never before it: per chunk  { wait (the chunk requested one chunk ago has landed) ; request the next chunk into the
+    // other register set ; 2 x 7 stages on this chunk }.
+    auto compute = [&](const NormBlock<CH> &src, auto first) {
+      lo(src, ta);
+      norm_block_stages<U, !decltype(first)::value>(ta, ma, qa, qb, acc, c, den, y);
+      hi(src, tb);
+      norm_block_stages<U, true>(tb, ma, qb, qa, acc, c, den, y);
+    };
+    load_chunk(0, sb);
+    AMWG_WAIT_LDS_LE(0); AMWG_STAGE_FENCE();
+    load_chunk(1, sa);
+    AMWG_STAGE_FENCE();
+    compute(sb, StagedFirst{});                           // chunk 0: its first block has no earlier terms to add
+    int ch = 1;
+    for (; ch + 1 < n_chunks; ch += 2) {          // chunk ch is on its way into sa
+      AMWG_WAIT_LDS_LE(0); AMWG_STAGE_FENCE();
+      load_chunk(ch + 1, sb);
+      AMWG_STAGE_FENCE();
+      compute(sa, StagedLater{});
+      AMWG_WAIT_LDS_LE(0); AMWG_STAGE_FENCE();
+      load_chunk(ch + 2, sa);
+      AMWG_STAGE_FENCE();
+      compute(sb, StagedLater{});
+    }
+    if (ch < n_chunks) {                          // one chunk left, on its way into sa
+      AMWG_WAIT_LDS_LE(0); AMWG_STAGE_FENCE();
+      compute(sa, StagedLater{});
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = acc + qb.v[u];
+    k = n_chunks * CH;
+  }
+  for (; k < n_obs; ++k) {                        // ragged tail
+    const double t = x_global[k] - mean;
+    acc += c - div_by_invariant(t * t, den, y);
+  }
+  return acc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // x_i ~ norm(mu, sigma); mu ~ norm(m0,s0); sigma ~ unif(a,b)              README.md:22-36
 struct NormalModel {
@@ -171,29 +291,34 @@ struct NormalModel {
   static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
   static constexpr int kUnroll = 8;   // independent terms in flight per lane (ILP across the division chains)
   struct Pass { double mu, c, den; Reciprocal y; bool fast; const double *x; };
-  __host__ __device__ static size_t lds_bytes(int n_obs, int, int) { return (size_t)n_obs * 8; }
-  __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int) {
+  // one lane per chain reads the observations through the scalar cache (norm_pass_uniform): no LDS tile
+  __host__ __device__ static size_t lds_bytes(int n_obs, int, int lanes) { return lanes == 1 ? 0 : (size_t)n_obs * 8; }
+  __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int lanes) {
+    if (lanes == 1) return;
     double *dst = reinterpret_cast<double *>(smem);
     for (int i = tid; i < d.n_obs; i += nt) dst[i] = d.x[i];
   }
   __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &) {
     double lp = 0;
-    lp += norm_const_sd(S(0), mc.m0, mc.c0, mc.den0);
+    lp += norm_const_sd(S(0), mc.m0, mc.c0, mc.den0, mc.y0_hi, mc.y0_lo, mc.den0_ok);
     const double sigma = S(1);
     lp += (sigma < mc.ua || sigma > mc.ub) ? -kInf : mc.lunif;
     return lp;
   }
-  __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &mc, const DataRef &,
-                                               const unsigned char *smem) {
+  using Cache = NormCache;
+  __device__ __forceinline__ static Cache cache_init() { return norm_cache_init(); }
+  template <int GL>
+  __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &mc, const DataRef &d,
+                                               const unsigned char *smem, Cache &k) {
     Pass ps;
     ps.mu = S(0);
-    const double sd = S(1);
-    ps.c = norm_c(mc.neg_half_log_2pi, sd);
-    ps.den = norm_den(sd);
-    ps.y = make_reciprocal(ps.den);
-    ps.fast = !mc.exact_division && mc.data_mid_range && mid_range(ps.den) &&
+    norm_cache_update(k, S(1), mc.neg_half_log_2pi);
+    ps.c = k.c;
+    ps.den = k.den;
+    ps.y = k.y;
+    ps.fast = !mc.exact_division && mc.data_mid_range && k.den_ok &&
               (ps.mu == 0 || mid_range(__builtin_fabs(ps.mu)));
-    ps.x = reinterpret_cast<const double *>(smem);
+    ps.x = GL == 1 ? d.x : reinterpret_cast<const double *>(smem);
     return ps;
   }
   template <bool FAST>
@@ -206,7 +331,8 @@ struct NormalModel {
   static constexpr bool kStagedFast = true;
   template <int G>
   __device__ __forceinline__ static double pass_fast(const Pass &ps, int n_obs, int sub, double acc) {
-    return norm_pass_staged<G, 8, false>(ps.x, nullptr, StateView{nullptr}, ps.mu, ps.c, ps.den, ps.y, n_obs, sub, acc);
+    if constexpr (G == 1) return norm_pass_uniform<8>(ps.x, ps.mu, ps.c, ps.den, ps.y, n_obs, acc);   // ps.x = the global array
+    else return norm_pass_staged<G, 8, false>(ps.x, nullptr, StateView{nullptr}, ps.mu, ps.c, ps.den, ps.y, n_obs, sub, acc);
   }
 };
 
@@ -247,8 +373,11 @@ struct BetaBernModel {
     else lp += (mc.ba - 1) * log_v8(th) + (mc.bb - 1) * log_v8(1 - th) - mc.lbeta_ab;
     return lp;
   }
+  struct Cache {};
+  __device__ __forceinline__ static Cache cache_init() { return Cache{}; }
+  template <int GL>
   __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &mc, const DataRef &d,
-                                               const unsigned char *smem) {
+                                               const unsigned char *smem, Cache &) {
     Pass ps;
     const double th = S(0);
     ps.l1 = log_v8(th);       // x = 1: log(1*th + 0*(1-th))
@@ -394,25 +523,41 @@ struct HierNormalModel {
   __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &d) {
     const double mu = S(d.G), sigma = S(d.G + 1);
     double lp = 0;
-    lp += norm_const_sd(mu, mc.m0, mc.c0, mc.den0);
+    lp += norm_const_sd(mu, mc.m0, mc.c0, mc.den0, mc.y0_hi, mc.y0_lo, mc.den0_ok);
     lp += (sigma < mc.ua || sigma > mc.ub) ? -kInf : mc.lunif;
     return lp;
   }
   template <int G>
   __device__ __forceinline__ static double prior_split(const StateView &S, const ModelConsts &mc, const DataRef &d, int sub, double acc) {
     const double mu = S(d.G);
-    for (int k = sub; k < d.G; k += G) acc += norm_const_sd(S(k), mu, mc.c1, mc.den1);
+    for (int k = sub; k < d.G; k += G) acc += norm_const_sd(S(k), mu, mc.c1, mc.den1, mc.y1_hi, mc.y1_lo, mc.den1_ok);
     return acc;
   }
+  using Cache = NormCache;
+  __device__ __forceinline__ static Cache cache_init() { return norm_cache_init(); }
+  template <int GL>
   __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &mc, const DataRef &d,
-                                               const unsigned char *smem) {
+                                               const unsigned char *smem, Cache &kc) {
     Pass ps;
-    const double sd = S(d.G + 1);
-    ps.c = norm_c(mc.neg_half_log_2pi, sd);
-    ps.den = norm_den(sd);
-    ps.y = make_reciprocal(ps.den);
-    bool ok = !mc.exact_division && mc.data_mid_range && mid_range(ps.den);
-    for (int k = 0; k < d.G; ++k) { const double th = S(k); ok = ok && (th == 0 || mid_range(__builtin_fabs(th))); }
+    norm_cache_update(kc, S(d.G + 1), mc.neg_half_log_2pi);
+    ps.c = kc.c;
+    ps.den = kc.den;
+    ps.y = kc.y;
+    bool ok = !mc.exact_division && mc.data_mid_range && kc.den_ok;
+    // every group mean must be inside the range amwg_div.h needs: the L lanes that run this chain inside the wave check L means
+    // at a time and agree through a ballot (round 1 had every lane walk all the means: 32 dependent LDS reads per evaluation)
+    {
+      constexpr int L = GL < 64 ? GL : 64;
+      const int lane = (int)(threadIdx.x & 63u), sub_in_wave = lane & (L - 1);
+      bool mine = true;
+      for (int k = sub_in_wave; k < d.G; k += L) { const double th = S(k); mine = mine && (th == 0 || mid_range(__builtin_fabs(th))); }
+      if constexpr (L == 1) ok = ok && mine;
+      else {
+        const uint64_t all = __ballot(mine);
+        const uint64_t group = (L == 64 ? ~0ull : ((1ull << (L & 63)) - 1ull)) << (lane & ~(L - 1));
+        ok = ok && ((all & group) == group);
+      }
+    }
     ps.fast = ok;
     ps.x = reinterpret_cast<const double *>(smem);
     ps.g = smem + (size_t)d.n_obs * 8;
@@ -454,15 +599,18 @@ struct PoisGlmModel {
   __device__ __forceinline__ static double prior(const StateView &, const ModelConsts &, const DataRef &) { return 0.0; }
   template <int G>
   __device__ __forceinline__ static double prior_split(const StateView &S, const ModelConsts &mc, const DataRef &, int sub, double acc) {
-    for (int k = sub; k < 8; k += G) acc += norm_const_sd(S(k), mc.m0, mc.c0, mc.den0);
+    for (int k = sub; k < 8; k += G) acc += norm_const_sd(S(k), mc.m0, mc.c0, mc.den0, mc.y0_hi, mc.y0_lo, mc.den0_ok);
     if (sub == 0) {
       const double cp = S(8);
       acc += (cp < 0 || cp > mc.cp_upper) ? -kInf : mc.lunif_cp;
     }
     return acc;
   }
+  struct Cache {};
+  __device__ __forceinline__ static Cache cache_init() { return Cache{}; }
+  template <int GL>
   __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &, const DataRef &d,
-                                               const unsigned char *) {
+                                               const unsigned char *, Cache &) {
     Pass ps;
 #pragma unroll
     for (int k = 0; k < 8; ++k) ps.b[k] = S(k);

@@ -231,20 +231,20 @@ static napi_value CreateUser(napi_env env, napi_callback_info info) {
   if (napi_get_value_string_utf8(env, v, NULL, 0, &slen) != napi_ok) { napi_throw_type_error(env, NULL, "amwg_napi.createUser: source must be a string"); return NULL; }
   char *src = (char *)malloc(slen + 1);
   napi_get_value_string_utf8(env, v, src, slen + 1, &slen);
-  const double *arrs[AMWG_MAX_USER_ARRAYS];
-  int64_t lens[AMWG_MAX_USER_ARRAYS];
-  int32_t types[AMWG_MAX_USER_ARRAYS];
-  memset(types, 0, sizeof types);
   uint32_t n_arr = 0;
   if (prop(env, a[0], "arrays", &v)) napi_get_array_length(env, v, &n_arr);
-  if (n_arr > AMWG_MAX_USER_ARRAYS) { free(src); napi_throw_range_error(env, NULL, "amwg_napi.createUser: too many data arrays"); return NULL; }
+  /* any number of data arrays (a closure over an array of records reads one per column) */
+  const double **arrs = (const double **)calloc(n_arr ? n_arr : 1, sizeof *arrs);
+  int64_t *lens = (int64_t *)calloc(n_arr ? n_arr : 1, sizeof *lens);
+  int32_t *types = (int32_t *)calloc(n_arr ? n_arr : 1, sizeof *types);
+  if (!arrs || !lens || !types) { free(src); free(arrs); free(lens); free(types); napi_throw_error(env, NULL, "amwg_napi.createUser: out of memory"); return NULL; }
   for (uint32_t i = 0; i < n_arr; i++) {
     napi_value e;
     size_t n = 0;
     napi_get_element(env, v, i, &e);
     arrs[i] = (const double *)typed_data(env, e, napi_float64_array, &n);
     lens[i] = (int64_t)n;
-    if (!arrs[i] && n) { free(src); napi_throw_type_error(env, NULL, "amwg_napi.createUser: arrays must be Float64Arrays"); return NULL; }
+    if (!arrs[i] && n) { free(src); free(arrs); free(lens); free(types); napi_throw_type_error(env, NULL, "amwg_napi.createUser: arrays must be Float64Arrays"); return NULL; }
   }
   amwg_user_model um;
   memset(&um, 0, sizeof um);
@@ -267,12 +267,15 @@ static napi_value CreateUser(napi_env env, napi_callback_info info) {
   um.work_per_eval = prop_double(env, a[0], "work_per_eval", 0.0);
   um.work_one_lane = prop_double(env, a[0], "work_one_lane", 0.0);
   amwg_param_desc *pd; amwg_comp_opt *co; uint32_t n_params; const double *init; amwg_options op;
-  if (!parse_common(env, a, &pd, &co, &n_params, &init, &op)) { free(src); return NULL; }
+  if (!parse_common(env, a, &pd, &co, &n_params, &init, &op)) { free(src); free(arrs); free(lens); free(types); return NULL; }
   amwg_sampler *s = NULL;
   int rc = amwg_create_user(&um, pd, (int32_t)n_params, init, co, &op, &s);
   free(pd);
   free(co);
   free(src);
+  free(arrs);
+  free(lens);
+  free(types);
   if (rc != AMWG_OK) return throw_amwg(env, rc);
   return wrap_sampler(env, s);
 }
@@ -523,6 +526,84 @@ static napi_value Quantiles(napi_env env, napi_callback_info info) {
   return rc == AMWG_OK ? out : throw_amwg(env, rc);
 }
 
+/* the shards of a multi-device sampler: JS array of handles -> C array (caller frees) */
+static amwg_sampler **unwrap_group(napi_env env, napi_value arr, uint32_t *n) {
+  *n = 0;
+  bool is_arr = false;
+  if (napi_is_array(env, arr, &is_arr) != napi_ok || !is_arr) { napi_throw_type_error(env, NULL, "amwg_napi: expected an array of sampler handles"); return NULL; }
+  napi_get_array_length(env, arr, n);
+  if (*n < 1) { napi_throw_type_error(env, NULL, "amwg_napi: empty array of sampler handles"); return NULL; }
+  amwg_sampler **g = (amwg_sampler **)calloc(*n, sizeof *g);
+  if (!g) { napi_throw_error(env, NULL, "amwg_napi: out of memory"); return NULL; }
+  for (uint32_t i = 0; i < *n; i++) {
+    napi_value e;
+    napi_get_element(env, arr, i, &e);
+    g[i] = unwrap(env, e);
+    if (!g[i]) { free(g); return NULL; }
+  }
+  return g;
+}
+
+/* groupMoments([handles]) -> {mean, sd}: all shards' draws pooled (per-device reduction + RCCL all-reduce) */
+static napi_value GroupMoments(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  uint32_t n = 0;
+  amwg_sampler **g = unwrap_group(env, a[0], &n);
+  if (!g) return NULL;
+  const size_t P = (size_t)amwg_num_recorded(g[0]);
+  double *m, *sd;
+  napi_value vm = new_f64(env, P, &m), vsd = new_f64(env, P, &sd);
+  if (!vm || !vsd) { free(g); return NULL; }
+  int rc = amwg_group_moments(g, (int32_t)n, m, sd);
+  free(g);
+  if (rc != AMWG_OK) return throw_amwg(env, rc);
+  napi_value o;
+  NAPI_OK(napi_create_object(env, &o));
+  napi_set_named_property(env, o, "mean", vm);
+  napi_set_named_property(env, o, "sd", vsd);
+  return o;
+}
+
+/* groupConvergence([handles]) -> {rhat, ess} over the chains of all shards */
+static napi_value GroupConvergence(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  uint32_t n = 0;
+  amwg_sampler **g = unwrap_group(env, a[0], &n);
+  if (!g) return NULL;
+  const size_t P = (size_t)amwg_num_recorded(g[0]);
+  double *r, *e;
+  napi_value vr = new_f64(env, P, &r), ve = new_f64(env, P, &e);
+  if (!vr || !ve) { free(g); return NULL; }
+  int rc = amwg_group_diagnostics(g, (int32_t)n, r, e);
+  free(g);
+  if (rc != AMWG_OK) return throw_amwg(env, rc);
+  napi_value o;
+  NAPI_OK(napi_create_object(env, &o));
+  napi_set_named_property(env, o, "rhat", vr);
+  napi_set_named_property(env, o, "ess", ve);
+  return o;
+}
+
+/* groupQuantiles([handles], Float64Array probs) -> Float64Array [P][n_probs] over the pooled draws of all shards */
+static napi_value GroupQuantiles(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  uint32_t n = 0;
+  amwg_sampler **g = unwrap_group(env, a[0], &n);
+  if (!g) return NULL;
+  size_t np = 0;
+  const double *probs = (const double *)typed_data(env, a[1], napi_float64_array, &np);
+  if (!probs || np < 1) { free(g); napi_throw_type_error(env, NULL, "amwg_napi.groupQuantiles: probs must be a non-empty Float64Array"); return NULL; }
+  double *q = NULL;
+  napi_value out = new_f64(env, (size_t)amwg_num_recorded(g[0]) * np, &q);
+  if (!out) { free(g); return NULL; }
+  int rc = amwg_group_quantiles(g, (int32_t)n, probs, (int32_t)np, q);
+  free(g);
+  return rc == AMWG_OK ? out : throw_amwg(env, rc);
+}
+
 static napi_value LaunchInfo(napi_env env, napi_callback_info info) {
   napi_value a[1];
   if (!get_args(env, info, 1, a)) return NULL;
@@ -581,7 +662,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   static const struct { const char *name; napi_callback fn; } fns[] = {
       {"create", Create}, {"createUser", CreateUser}, {"compileUser", CompileUser}, {"destroy", Destroy}, {"burn", Burn}, {"burnAsync", BurnAsync}, {"sync", Sync},
       {"sample", Sample}, {"sampleAsync", SampleAsync}, {"fetchDraws", FetchDraws}, {"setAdapting", SetAdapting},
-      {"getState", GetState}, {"setState", SetState}, {"convergence", Convergence}, {"quantiles", Quantiles}, {"info", Info}, {"diag", Diag}, {"moments", Moments}, {"launchInfo", LaunchInfo},
+      {"getState", GetState}, {"setState", SetState}, {"convergence", Convergence}, {"quantiles", Quantiles}, {"groupMoments", GroupMoments}, {"groupConvergence", GroupConvergence}, {"groupQuantiles", GroupQuantiles}, {"info", Info}, {"diag", Diag}, {"moments", Moments}, {"launchInfo", LaunchInfo},
       {"version", Version}, {"mathExp", MathExp}, {"mathLog", MathLog}, {"uniform", Uniform}};
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

@@ -27,6 +27,7 @@ struct amwg_sampler {
   amwg::CompConst *d_cc = nullptr;
   uint8_t *d_adapt = nullptr;
   std::vector<uint8_t> h_adapt;
+  std::vector<int32_t> h_layout;   // [4][n_params] base | len | top | multidim (ParamLayout::tab on the device)
   // geometry
   int lanes = 0, block = 0, grid = 0, lds = 0;
   step_kernel_t kernel = nullptr;

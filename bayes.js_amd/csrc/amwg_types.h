@@ -4,9 +4,14 @@
 
 namespace amwg {
 
-constexpr int kMaxNamed = 16;    // named parameters per model (their shuffled order is sixteen 4-bit fields of one u64)
-constexpr int kMaxTop = 256;     // largest shuffled dimension (index bytes)
-constexpr int kMaxUserArrays = 16;   // data arrays of a translated (user) log_post
+// No fixed limits on the model's shape (the reference has none: mcmc.js:837-881 takes any number of named parameters, mcmc.js:631-680
+// any dim); only the layout's fast paths have sizes:
+constexpr int kPackedNamed = 16;     // up to 16 named parameters: their shuffled order is sixteen 4-bit fields of one u64 in a register;
+                                     // more: 16-bit entries in LDS (ChainArrays::perm16)
+constexpr int kByteTop = 256;        // a shuffled leading dimension up to 256: index bytes in LDS; longer: 16-bit entries
+constexpr int kMaxIndex = 65535;     // 16-bit entries: at most 65535 named parameters / leading dimension (LDS capacity binds long before)
+constexpr int kInlineUserArrays = 16;   // data arrays of a translated (user) log_post passed in the kernel arguments; further ones
+                                        // through DataRef::arr_ext (a pointer table in device memory)
 constexpr int kTypeReal = 0, kTypeInt = 1, kTypeBinary = 2, kTypeFixed = 3;   // AMWG_REAL / AMWG_INT / AMWG_BINARY / AMWG_FIXED
 
 // LDS-resident view of this chain's state: component p at S.base[p].  Chains are laid out
@@ -35,7 +40,7 @@ struct CompConst {
 // by log_post (AMWG_FIXED: the rest of the shared state object of a stand-alone stepper).
 struct ParamLayout {
   int32_t n_params, P, max_top, P_stepped;
-  int32_t base[kMaxNamed], len[kMaxNamed], top[kMaxNamed], multidim[kMaxNamed];
+  const int32_t *tab;     // device: [4][n_params] = base | len | top | multidim of every stepped parameter (staged into LDS per launch)
 };
 
 // Loop-invariant constants of the built-in models, computed ON THE HOST with the same
@@ -52,6 +57,9 @@ struct ModelConsts {
   double ba, bb, lbeta_ab;
   // ld.unif(cp, 0, N-1)
   double cp_upper, lunif_cp;
+  // double-double reciprocals of the constant prior divisors den0 / den1 (amwg_div.h; {hi, lo}) and whether they are usable
+  double y0_hi, y0_lo, y1_hi, y1_lo;
+  int32_t den0_ok, den1_ok;
   int32_t data_mid_range;           // every data value is 0 or within 2^-200..2^200 in magnitude
   int32_t exact_division;           // 1 = always use IEEE '/'
   int32_t has_invalid;              // BETA_BERN: some x_i is neither 0 nor 1 => that term is -inf (distributions.js:229)
@@ -66,8 +74,9 @@ struct DataRef {
   const double *lfact;  // GLM lfactorial(y_i) (+inf encodes y_i < 0, i.e. term = -inf)
   const uint8_t *xb;    // BETA_BERN x as bytes (invalid values stored as 0, see has_invalid) | HIER group index
   const uint32_t *xw;   // BETA_BERN x as bits: observation i = bit (i & 31) of word (i >> 5)
-  const void *arr[kMaxUserArrays];     // translated models: the data arrays the closure reads (row-major; f64, or u8 / i32
+  const void *arr[kInlineUserArrays];  // translated models: the data arrays the closure reads (row-major; f64, or u8 / i32
                                        // when every value of the array is a small integer -- the translator picks the type)
+  const void *const *arr_ext;          // arrays kInlineUserArrays, kInlineUserArrays + 1, ... (device table), see user_arr()
 };
 
 // Per-chain state, structure-of-arrays with the chain index fastest: element (p, c) at p*C + c.
@@ -76,7 +85,8 @@ struct ChainArrays {
   double *prop_log_scale;   // [P][C]
   int32_t *acceptance_count, *iterations_since_adaption, *batch_count;  // [P][C]  (mcmc.js:509-511)
   int32_t *accepts, *inbounds;   // [P][C] run totals (not in the reference; for parity checks)
-  uint64_t *perm;           // [C] order of the named sub-steppers, 4 bits each (mcmc.js:887 shuffles in place)
+  uint64_t *perm;           // [C] order of the named sub-steppers, 4 bits each (mcmc.js:887 shuffles in place); n_params <= kPackedNamed
+  uint16_t *perm16;         // [n_params][C] the same order as 16-bit entries when n_params > kPackedNamed (else null)
   uint64_t *rng_n;          // [C] uniforms consumed
   double *lp_curr;          // [C] log_post(state)
 };

@@ -8,6 +8,13 @@
 
 namespace amwg {
 
+// data array J of the closure: the first kInlineUserArrays pointers travel in the kernel arguments, further ones in a device table
+template <int J>
+AMWG_HD const void *user_arr(const DataRef &d) {
+  if constexpr (J < kInlineUserArrays) return d.arr[J];
+  else return d.arr_ext[J - kInlineUserArrays];
+}
+
 // Loop-invariant part of ld.norm(x, mean, sd) for a loop in which sd does not change
 // (distributions.js:119-121): c = -0.5*log(2*pi) - log(sd), den = 2*sd*sd -- the same roundings,
 // in the same order, as the full expression -- plus the double-double reciprocal of amwg_div.h.
@@ -19,11 +26,6 @@ AMWG_HD NormInv norm_inv(double sd) {
   k.y = make_reciprocal(k.den);
   k.fast = mid_range(k.den);
   return k;
-}
-// |a| in 2^-600..2^600 (or exactly zero is NOT included: 0 takes the IEEE path, it is rare)
-AMWG_HD bool wide_range(double a) {
-  const uint32_t h = (uint32_t)hi_word(a) & 0x7fffffffu;
-  return (h - 0x1A700000u) <= (0x65700000u - 0x1A700000u);
 }
 AMWG_HD double ld_norm_inv(double x, double mean, const NormInv &k) {
   const double t = x - mean;

@@ -356,22 +356,22 @@ AmwgSampler.prototype.info = function () {
            launch: this._each((sh) => Object.assign({ device: sh.device, chains: sh.count }, N.launchInfo(sh.handle))) };
 };
 
-/** Posterior mean / sd per scalar component over all chains x kept draws of the last sample() (device-side reduction, single shard). */
+/** Posterior mean / sd per scalar component over all chains x kept draws of the last sample(): device-side reduction; with
+ *  `options.devices` every device reduces its shard and the partial sums meet in an RCCL all-reduce (amwg_group_moments). */
 AmwgSampler.prototype.moments = function () {
   const N = native();
-  if (this._shards.length !== 1) throw 'moments(): only available on a single-device sampler';
-  const m = N.moments(this._shards[0].handle), out = {};
+  const m = this._shards.length === 1 ? N.moments(this._shards[0].handle) : N.groupMoments(this._shards.map((sh) => sh.handle)), out = {};
   for (const L of this._layout) out[L.name] = { mean: Array.from(m.mean.subarray(L.base, L.base + L.len)), sd: Array.from(m.sd.subarray(L.base, L.base + L.len)) };
   this.derived.forEach((name, q) => { out[name] = { mean: [m.mean[this.P + q]], sd: [m.sd[this.P + q]] }; });
   return out;
 };
 
 /** Split-R-hat and effective sample size per scalar component (and derived quantity) over the last sample(): device-side
- *  per-chain reduction, chains >= 2, single shard. */
+ *  per-chain reduction, chains >= 2; with `options.devices` over the chains of all devices (RCCL all-reduce of the per-device
+ *  sums, amwg_group_diagnostics). */
 AmwgSampler.prototype.convergence = function () {
   const N = native();
-  if (this._shards.length !== 1) throw 'convergence(): only available on a single-device sampler';
-  const d = N.convergence(this._shards[0].handle), out = {};
+  const d = this._shards.length === 1 ? N.convergence(this._shards[0].handle) : N.groupConvergence(this._shards.map((sh) => sh.handle)), out = {};
   for (const L of this._layout) out[L.name] = { rhat: Array.from(d.rhat.subarray(L.base, L.base + L.len)), ess: Array.from(d.ess.subarray(L.base, L.base + L.len)) };
   this.derived.forEach((name, q) => { out[name] = { rhat: [d.rhat[this.P + q]], ess: [d.ess[this.P + q]] }; });
   return out;
@@ -381,8 +381,8 @@ AmwgSampler.prototype.convergence = function () {
  *  device radix sort, R's default (type 7) interpolation.  quantiles([0.025, 0.5, 0.975]) -> {name: [[q...] per element]} */
 AmwgSampler.prototype.quantiles = function (probs) {
   const N = native();
-  if (this._shards.length !== 1) throw 'quantiles(): only available on a single-device sampler';
-  const pr = Float64Array.from(probs), q = N.quantiles(this._shards[0].handle, pr), out = {};
+  const pr = Float64Array.from(probs), out = {};
+  const q = this._shards.length === 1 ? N.quantiles(this._shards[0].handle, pr) : N.groupQuantiles(this._shards.map((sh) => sh.handle), pr);   // several devices: RCCL gather to the first, sorted there
   const row = (c) => Array.from(q.subarray(c * pr.length, (c + 1) * pr.length));
   for (const L of this._layout) out[L.name] = Array.from({ length: L.len }, (_, e) => row(L.base + e));
   this.derived.forEach((name, k) => { out[name] = [row(this.P + k)]; });

@@ -252,7 +252,6 @@ Translator.prototype.registerArray = function (key, value) {
   const dims = shapeOfData(value);
   if (!dims) this.fail('data' + key + ' is not a rectangular array of numbers');
   const flat = Float64Array.from(flattenData(value, []));
-  if (this.arrays.length >= 16) this.fail('more than 16 data arrays');
   const id = this.arrays.length;
   // device storage: small non-negative integers as u8, other 32-bit integers as i32 (exact), everything else f64
   let u8 = flat.length > 0, i32 = flat.length > 0, is01 = flat.length > 0;
@@ -1570,7 +1569,7 @@ Translator.prototype.run = function () {
   src.push('  static constexpr int kDerived = ' + D + ';');
   src.push('  static constexpr int kMaxThreads = ' + maxThreads + ';');
   src.push('#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)');
-  const copies = (pl) => this.arrays.map((a, j) => pl[j].lds ? '{ ' + a.ctype + ' *dst = reinterpret_cast<' + a.ctype + ' *>(smem + ' + pl[j].off + '); const ' + a.ctype + ' *src = static_cast<const ' + a.ctype + ' *>(d.arr[' + j + ']); for (int i = tid; i < ' + a.flat.length + '; i += nt) dst[i] = src[i]; }' : '').filter((x) => x);
+  const copies = (pl) => this.arrays.map((a, j) => pl[j].lds ? '{ ' + a.ctype + ' *dst = reinterpret_cast<' + a.ctype + ' *>(smem + ' + pl[j].off + '); const ' + a.ctype + ' *src = static_cast<const ' + a.ctype + ' *>(user_arr<' + j + '>(d)); for (int i = tid; i < ' + a.flat.length + '; i += nt) dst[i] = src[i]; }' : '').filter((x) => x);
   src.push('  __host__ __device__ static size_t lds_bytes(int, int, int lanes) { return lanes == 1 ? ' + P1.bytes + ' : ' + off + '; }');
   src.push('  __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int lanes) {');
   if (P1 === PG) for (const c of copies(plan)) src.push('    ' + c);
@@ -1587,12 +1586,12 @@ Translator.prototype.run = function () {
   src.push('  AMWG_HD static double eval(const StateView &S, const DataRef &d, const unsigned char *smem, int sub, double *dv) {');
   src.push('#if defined(__HIP_DEVICE_COMPILE__)');
   this.arrays.forEach((a, j) => {
-    const where = (pl) => pl[j].lds ? 'reinterpret_cast<const ' + a.ctype + ' *>(smem + ' + pl[j].off + ')' : 'static_cast<const ' + a.ctype + ' *>(d.arr[' + j + '])';
+    const where = (pl) => pl[j].lds ? 'reinterpret_cast<const ' + a.ctype + ' *>(smem + ' + pl[j].off + ')' : 'static_cast<const ' + a.ctype + ' *>(user_arr<' + j + '>(d))';
     const one = where(P1.plan), many = where(plan);
     src.push('    const ' + a.ctype + ' *A' + j + ' = ' + (one === many ? many : '(G == 1) ? ' + one + ' : ' + many) + ';');
   });
   src.push('#else');
-  this.arrays.forEach((a, j) => { src.push('    const ' + a.ctype + ' *A' + j + ' = static_cast<const ' + a.ctype + ' *>(d.arr[' + j + ']);'); });
+  this.arrays.forEach((a, j) => { src.push('    const ' + a.ctype + ' *A' + j + ' = static_cast<const ' + a.ctype + ' *>(user_arr<' + j + '>(d));'); });
   src.push('#endif');
   src.push('    (void)smem; (void)sub; (void)d;');
   for (const ln of body) src.push(ln);

@@ -302,7 +302,7 @@ def main():
         s.sample_device(K, thin, draws.data_ptr(), draws.numel() * 8)
         s.sync()
         if dist is not None:
-            gather_draws(dist, draws if coll_dev == "cuda" else draws.cpu(), gathered, rank)
+            gather_draws(dist, draws if coll_dev == "cuda" else draws.cpu(), gathered, rank, equal_sizes=True)
         barrier()
         dt = time.perf_counter() - t0
         kms = s.launch_info()["kernel_ms"]
@@ -323,6 +323,10 @@ def main():
     order = sorted(range(len(regions)), key=lambda r: regions[r][0])
     dt, kernel_ms = regions[order[len(order) // 2]]
     li = s.launch_info()
+    # posterior moments over the recorded draws of ALL ranks: per-rank sums + all-reduce (RCCL for N > 1; bayes.js_amd/shard.py,
+    # the one-process-per-GPU twin of the library's amwg_group_moments) -- outside the timed regions
+    from shard import pooled_moments
+    pooled = pooled_moments(dist, draws if (dist is None or coll_dev == "cuda") else draws.cpu())
 
     if rank == 0:
         total_chains = chains * world
@@ -331,7 +335,9 @@ def main():
         launch_s = kernel_ms * 1e-3 / launches
         updates_per_launch = chains * (K / launches) * P
         eff_gbps = updates_per_launch * b_alg / launch_s / 1e9
-        mean, sd = s.moments()
+        mean, sd = (s.moments() if dist is None else (pooled[0].cpu().numpy(), pooled[1].cpu().numpy()))
+        pm = pooled[0].cpu().numpy()
+        assert dist is not None or np.allclose(pm, mean, rtol=1e-10, atol=0), "library moments differ from the pooled restatement"
         measured_peak = A.fp64_peak(dev_index)      # register-only fma kernel: what the chip sustains under fp64 load
         x = spec["data"]["x"]
         traffic, traffic_src = measured_traffic(chains, args.steps_per_launch, args.workload)
@@ -381,7 +387,7 @@ def main():
                          "note": roof_note},
             "kernel_only_value": chains * K * P / (kernel_ms * 1e-3),
             "posterior": {"mean": mean.tolist()[:8], "sd": sd.tolist()[:8], "data_mean": float(np.mean(x)), "data_sd": float(np.std(x, ddof=1)),
-                          "note": "moments over the recorded draws of rank 0's last region (after %d warm-up + %d timed steps)" % (W, K * (len(regions) - 1))},
+                          "note": "moments over the recorded draws of the last region on ALL ranks (all-reduce of per-rank sums for N > 1; after %d warm-up + %d timed steps)" % (W, K * (len(regions) - 1))},
         }
         if world == 1 and args.workload == "cfg2":
             out["parity"] = parity_gate(A, spec, li["lanes_per_chain"])

@@ -91,15 +91,20 @@ typedef struct {
   double hyper[8];
 } amwg_model_desc;
 
+#define AMWG_LANES_FASTEST (-1)
 typedef struct {
   int64_t chains;          /* independent chains on this sampler (>= 1) */
   uint64_t seed;           /* Philox key */
   uint64_t chain_offset;   /* global id of local chain 0 (multi-GPU sharding) */
   int32_t device;          /* HIP device ordinal */
-  int32_t lanes_per_chain; /* 0 = auto; else a power of two 1..1024: lanes that split one chain's observation loop (above 64 the chain is one
-                              workgroup of several wavefronts, each a replica of the scalar logic; few chains, long data loops) */
+  int32_t lanes_per_chain; /* lanes that split one chain's observation loop: a power of two 1..1024 (above 64 the chain is one workgroup of
+                              several wavefronts, each a replica of the scalar logic; few chains, long data loops), or
+                              0 = auto, REFERENCE ORDER FIRST: one lane per chain -- the reference's own sequential `lp += term`, every draw of a
+                                  seeded run bit-identical to the reference -- whenever the cost model prices it within 12 % of the cheapest
+                                  geometry, else the cheapest (decisions identical to the reference, doubles in the G-lane order);
+                              AMWG_LANES_FASTEST (-1) = the cheapest geometry regardless of summation order */
   int32_t block_threads;   /* 0 = auto; else multiple of 64, <= 1024 */
-  int32_t steps_per_launch;/* 0 = auto (one launch per burn/sample call up to 2^20 steps) */
+  int32_t steps_per_launch;/* 0 = auto (one launch per burn/sample call up to 65535 steps) */
   int32_t exact_division;  /* 0 = default: result-preserving shortcuts (hoisted-reciprocal division, fast-forward of two-valued sums), bit-identical
                               to the plain schedule and tested against it; 1 = the reference's operation schedule: IEEE '/', term-by-term sums */
   int32_t reserved[3];
@@ -117,11 +122,10 @@ int amwg_create(const amwg_model_desc *model, const amwg_param_desc *params, int
  * "translated closure"); amwg_create_user compiles it with hiprtc for the device's gfx target,
  * together with the same step kernel the built-in models use.  Arrays are the numeric arrays of
  * the closure's `data` argument that the body reads, flattened row-major. */
-#define AMWG_MAX_USER_ARRAYS 16
 enum { AMWG_F64 = 0, AMWG_U8 = 1, AMWG_I32 = 2 };
 typedef struct {
   const char *source;            /* HIP C++ text (NUL-terminated) */
-  int32_t n_arrays;              /* <= AMWG_MAX_USER_ARRAYS */
+  int32_t n_arrays;              /* any number (the first 16 pointers travel in the kernel arguments, the rest in a device table) */
   const double *const *arrays;   /* host pointers; copied to the device by amwg_create_user */
   const int64_t *array_len;      /* elements per array */
   const int32_t *array_type;     /* device storage per array: AMWG_F64 | AMWG_U8 | AMWG_I32 (values must be exactly representable);
@@ -199,6 +203,17 @@ int amwg_last_sample_diagnostics(amwg_sampler *s, double *rhat, double *ess);
 /* Posterior quantiles over the draws of the LAST amwg_sample* call (all chains x kept draws pooled), per recorded value:
  * radix sort on the device, R's default interpolation (type 7).  probs[n_probs] in [0,1]; out[P][n_probs]. */
 int amwg_last_sample_quantiles(amwg_sampler *s, const double *probs, int32_t n_probs, double *out);
+
+/* The same three summaries over SEVERAL samplers that are the shards of one logical job (chains split over the devices of a node
+ * with amwg_options.chain_offset; `options.devices` of the JavaScript front-end): every device reduces its own draws and the
+ * partial results are combined with an RCCL all-reduce over xGMI (quantiles: grouped ncclSend/ncclRecv of one component's
+ * values to the first shard's device, sorted there) -- SURVEY.md section 8(e) "all-gather of per-chain moment summaries".
+ * One process, ncclCommInitAll over the shards' devices (cached); RCCL is loaded on first use.  Shards may share a device
+ * (they are summed on the device before the collective).  All shards must hold a sample() of the same number of kept draws.
+ * Output sizes as for the single-sampler calls. */
+int amwg_group_moments(amwg_sampler *const *shards, int32_t n_shards, double *mean, double *sd);
+int amwg_group_diagnostics(amwg_sampler *const *shards, int32_t n_shards, double *rhat, double *ess);
+int amwg_group_quantiles(amwg_sampler *const *shards, int32_t n_shards, const double *probs, int32_t n_probs, double *out);
 
 int amwg_sync(amwg_sampler *s);
 int amwg_num_components(const amwg_sampler *s);   /* P: scalar parameter components */

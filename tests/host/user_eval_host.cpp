@@ -26,7 +26,8 @@ extern "C" int user_num_derived() { return amwg::UserModel::kDerived; }
 // arrays[j]: device-typed storage (f64 / u8 / i32 as the translator chose, see meta.array_types)
 extern "C" double user_eval(const double *state, const void *const *arrays, int n_arrays, int G, double *dv) {
   amwg::DataRef d{};
-  for (int j = 0; j < n_arrays && j < amwg::kMaxUserArrays; ++j) d.arr[j] = arrays[j];
+  for (int j = 0; j < n_arrays && j < amwg::kInlineUserArrays; ++j) d.arr[j] = arrays[j];
+  d.arr_ext = n_arrays > amwg::kInlineUserArrays ? arrays + amwg::kInlineUserArrays : nullptr;   // same split as the device (user_arr)
   switch (G) {
     case 1: return lanes<1>(state, d, dv);
     case 2: return lanes<2>(state, d, dv);

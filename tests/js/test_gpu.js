@@ -116,6 +116,16 @@ checkAgainstGolden('glm_small', (g, rec) => new mcmc.AmwgSampler(
   assert.deepStrictEqual(Array.from(s1.sigma), Array.from(s2.sigma));
   assert.deepStrictEqual(Array.from(one.state.mu), Array.from(two.state.mu));
   assert.deepStrictEqual(Array.from(one.info().steppers.sigma.prop_log_scale), Array.from(two.info().steppers.sigma.prop_log_scale));
+  // summaries of the sharded sampler (per-shard reductions + RCCL all-reduce, amwg_group_*) == those of the single shard
+  {
+    const close = (a, b, tol) => Math.abs(a - b) <= tol * Math.max(1, Math.abs(b));
+    const m1 = one.moments(), m2 = two.moments(), c1 = one.convergence(), c2 = two.convergence(), q1 = one.quantiles([0.025, 0.5, 0.975]), q2 = two.quantiles([0.025, 0.5, 0.975]);
+    for (const nm of ['mu', 'sigma']) {
+      assert.ok(close(m2[nm].mean[0], m1[nm].mean[0], 1e-13) && close(m2[nm].sd[0], m1[nm].sd[0], 1e-11), 'sharded moments ' + nm);
+      assert.ok(close(c2[nm].rhat[0], c1[nm].rhat[0], 1e-10) && close(c2[nm].ess[0], c1[nm].ess[0], 1e-9), 'sharded convergence ' + nm);
+      assert.deepStrictEqual(q2[nm], q1[nm], 'sharded quantiles ' + nm);          // the same multiset sorted: identical
+    }
+  }
   // chain 7 of the many-chain run == a single-chain sampler with chain_offset 7 (reference-shaped output)
   const solo = new mcmc.AmwgSampler(params, models.normal(), g.data.x, { seed: 77, chain_offset: 7, lanes_per_chain: 4, thin: 4 });
   solo.burn(60);

@@ -44,30 +44,51 @@ def _worker(rank, world, port, total, rows, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     off, cnt = shard.chain_shard(rank, world, total)
     mine = torch.from_numpy(_draws_for(off, cnt, rows))
-    glist = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+    if rank == 0:          # unequal shards: gather by point-to-point, as shard.gather_draws does when the sizes differ
+        glist = [torch.empty((rows, mine.shape[1], shard.chain_shard(r, world, total)[1]), dtype=mine.dtype) for r in range(world)]
+    else:
+        glist = None
     shard.gather_draws(dist, mine, glist, rank)
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)        # the bench's max-over-ranks timing reduction
+    mean, sd = shard.pooled_moments(dist, mine)       # the collective summaries: every rank ends up with the pooled statistics
+    rhat, ess = shard.pooled_convergence(dist, mine)
     if rank == 0:
-        q.put((shard.merge_gathered(glist).numpy(), float(t[0])))
+        q.put((shard.merge_gathered(glist).numpy(), float(t[0]), mean.numpy(), sd.numpy(), rhat.numpy(), ess.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_rank_gather_equals_single_process():
-    world, total, rows = 2, 6, 5
+    world, total, rows = 2, 7, 8                      # 7 chains over 2 ranks: unequal shards (4 + 3)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, rows, q)) for r in range(world)]
     for p in procs:
         p.start()
-    merged, tmax = q.get(timeout=120)
+    merged, tmax, mean, sd, rhat, ess = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert tmax == 2.0
-    assert merged.tobytes() == _draws_for(0, total, rows).tobytes()
+    want = _draws_for(0, total, rows)
+    assert merged.tobytes() == want.tobytes()
+    # pooled summaries through the all-reduces == numpy on the pooled draws == the one-process formulas without a collective
+    flat = np.moveaxis(want, 1, 0).reshape(want.shape[1], -1)
+    np.testing.assert_allclose(mean, flat.mean(axis=1), rtol=1e-13)
+    np.testing.assert_allclose(sd, flat.std(axis=1, ddof=1), rtol=1e-12)
+    sys.path[:0] = [os.path.join(ROOT, "bayes.js_amd")]
+    import shard
+    r1, e1 = shard.pooled_convergence(None, torch.from_numpy(want))
+    np.testing.assert_allclose(rhat, r1.numpy(), rtol=1e-12)
+    np.testing.assert_allclose(ess, e1.numpy(), rtol=1e-11)
+    half = rows // 2                                  # split-R-hat restated with numpy (BDA3 section 11.4)
+    hm = np.stack([want[:half].mean(axis=0), want[half:2 * half].mean(axis=0)])          # [2][P][C]
+    hv = np.stack([want[:half].var(axis=0, ddof=1), want[half:2 * half].var(axis=0, ddof=1)])
+    W = hv.mean(axis=(0, 2))
+    B_over_n = np.moveaxis(hm, 1, 0).reshape(hm.shape[1], -1).var(axis=1, ddof=1)
+    np.testing.assert_allclose(rhat, np.sqrt(((half - 1) / half * W + B_over_n) / W), rtol=1e-12)
 
 
 def test_chain_shard_covers_everything_once():

@@ -15,27 +15,57 @@ bench = json.load(open(os.path.join(src, "bench_under_trace.json")))
 # the kernel the bench line is about (the parity gate of bench.py also launches one-lane kernels: not those)
 import re
 m = re.match(r"amwg_step_kernel<(\w+),(\d+)>", bench["roofline"]["kernel"])
+workload = re.search(r"--workload (\w+)", open(os.path.join(src, "command.txt")).read() if os.path.exists(os.path.join(src, "command.txt")) else "")
+workload = workload.group(1) if workload else "cfg2"
 is_bench_kernel = lambda name: ("amwg_step_kernel" in name and re.search(r"%s,\s*%s>" % (m.group(1), m.group(2)), name) is not None)
 pmc = {}
 meta = {}
-for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     f = os.path.join(src, name, "pmc_counter_collection.csv")
     if not os.path.exists(f):
         continue
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if is_bench_kernel(r["Kernel_Name"]):
+    rows = [r for r in csv.DictReader(open(f)) if is_bench_kernel(r["Kernel_Name"])]
+    # the parity block of bench.py launches the same kernel on ONE chain (tiny grids): only the full-size launches are the bench's
+    full = max((int(r["Grid_Size"]) for r in rows), default=0)
+    for r in rows:
+        if int(r["Grid_Size"]) == full:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
     for k, v in agg.items():
         pmc[k] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
 stats = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
 step = [r for r in stats if is_bench_kernel(r["Name"])][0]
+# per-launch durations of the full-size launches from the kernel trace (the stats table averages the one-chain parity launches in)
+tr = [r for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv"))) if is_bench_kernel(r["Kernel_Name"])]
+full_grid = max(int(r["Grid_Size_X"]) for r in tr)
+dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in tr if int(r["Grid_Size_X"]) == full_grid]
+step = dict(step, Calls=len(dur), AverageNs=sum(dur) / len(dur), MinNs=min(dur), MaxNs=max(dur))
 traffic = None
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
-out = {"tag": tag, "command": "python bench.py --no-cpu-baseline --steps 500 --warmup 1000 (100 steps per launch)",
+derived = {}
+g = lambda k: pmc[k]["mean"] if k in pmc else None
+launch_s = float(step["AverageNs"]) * 1e-9
+if g("GRBM_GUI_ACTIVE"):
+    derived["effective_clock_ghz"] = g("GRBM_GUI_ACTIVE") / 8.0 / launch_s / 1e9      # MI355X_MICROARCH.md "DVFS give-back"; the counter is summed over the 8 XCDs
+    derived["effective_clock_note"] = "GRBM_GUI_ACTIVE / 8 XCDs / rocprofv3 launch duration (of the PMC pass average)"
+if g("SQ_WAVE_CYCLES") and g("SQ_ACTIVE_INST_VALU"):
+    derived["valu_active_share_of_wave_cycles"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES")
+    derived["wait_inst_any_share_of_wave_cycles"] = (g("SQ_WAIT_INST_ANY") or 0) / g("SQ_WAVE_CYCLES")
+    derived["wait_any_share_of_wave_cycles"] = (g("SQ_WAIT_ANY") or 0) / g("SQ_WAVE_CYCLES")
+if g("SQ_BUSY_CYCLES") and g("SQ_ACTIVE_INST_VALU"):
+    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; SQ_BUSY_CYCLES counts cycles per SE/XCC: report the raw ratio only
+    derived["active_inst_valu_per_busy_cycle"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_BUSY_CYCLES")
+units = bench["roofline"].get("updates_per_launch") or (bench["config"]["chains_per_gpu"] * bench["config"]["steps_per_launch"] * bench["config"]["components"])
+if g("SQ_INSTS_VALU"):
+    derived["valu_instructions_per_update_per_wave64"] = g("SQ_INSTS_VALU") / (units * bench["config"]["lanes_per_chain"] / 64.0)
+    derived["valu_instructions_per_observation_lane"] = g("SQ_INSTS_VALU") * 64.0 / (units * bench["config"]["n_obs"])
+out = {"tag": tag, "workload": workload, "command": open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "python bench.py --no-cpu-baseline --steps 500 --warmup 1000 (100 steps per launch)",
+       "derived": derived,
        "kernel": step["Name"], "rocprof_calls": int(step["Calls"]), "rocprof_avg_launch_ms": float(step["AverageNs"]) / 1e6,
+       "rocprof_min_launch_ms": step["MinNs"] / 1e6, "rocprof_max_launch_ms": step["MaxNs"] / 1e6,
+       "rocprof_note": "full-size launches only (grid %d); the kernel_stats.csv row also averages the one-chain launches of bench.py's parity block" % full_grid,
        "bench_launch_ms": bench["roofline"]["launch_ms"], "steps_per_launch": bench["config"]["steps_per_launch"],
        "chains": bench["config"]["chains_per_gpu"], "kernel_resources": meta, "pmc_per_launch": pmc,
        "hbm_traffic_bytes_per_launch": traffic,
