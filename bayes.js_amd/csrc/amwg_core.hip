@@ -150,18 +150,20 @@ double model_work(const amwg_sampler *s, int G) {
 
 int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const amwg_options &o = s->opt;
-  auto layout = [&](int bt, int G) {
+  // cpb: chains per workgroup; 0 = blockDim / G.  A smaller value (one-wavefront workgroups only) is the fallback for models
+  // whose per-chain state is so large that 64 / G copies do not fit LDS: the spare lane groups replicate the last chain.
+  auto layout = [&](int bt, int G, int cpb = 0) {
     const size_t data_bytes = s->user ? (size_t)(G == 1 ? s->user_lds_one_lane : s->user_lds) : model_lds_bytes(s->model, s->d.n_obs, s->d.G, G);
-    return G > 64 ? lds_layout(data_bytes, s->P, G / 64, s->pl.max_top, s->n_params, true) : lds_layout(data_bytes, s->P, bt / G, s->pl.max_top, s->n_params);
+    return G > 64 ? lds_layout(data_bytes, s->P, G / 64, s->pl.max_top, s->n_params, true) : lds_layout(data_bytes, s->P, cpb ? cpb : bt / G, s->pl.max_top, s->n_params);
   };
   const int max_bt = s->user ? s->user_max_threads : model_max_threads(s->model);
   auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds; };
   if (s->user && !s->user_parallel && o.lanes_per_chain > 1)
     return fail(AMWG_EINVAL, "this closure has no loop that can be split over lanes: lanes_per_chain must be 1 (or 0 = auto), got %d", o.lanes_per_chain);
   const int bts[5] = {1024, 512, 256, 128, 64};
-  int bestG = 0, bestB = 0;
+  int bestG = 0, bestB = 0, bestCpb = 0;
   double bestOcc = -1.0, cost1 = -1.0;
-  int block1 = 0;
+  int block1 = 0, cpb1 = 0;
   const bool fixed_lanes = o.lanes_per_chain > 0;
   for (int G = 1; G <= 1024; G <<= 1) {
     if (fixed_lanes && G != o.lanes_per_chain) continue;
@@ -179,10 +181,15 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
       pick = bt;
       if ((s->C + bt / G - 1) / (bt / G) >= n_cus) break;
     }
+    int cpb = 0;
+    if (!pick && G < 64 && max_bt >= 64 && (!o.block_threads || o.block_threads == 64)) {
+      for (int c = 32 / G; c >= 1; c >>= 1)      // fewer chains than lane groups in a one-wavefront workgroup
+        if (layout(64, G, c).total <= max_lds) { pick = 64; cpb = c; break; }
+    }
     if (!pick) continue;
-    const int CPB = pick / G;
+    const int CPB = cpb ? cpb : pick / G;
     const int64_t blocks = (s->C + CPB - 1) / CPB;
-    const uint32_t lds = layout(pick, G).total;
+    const uint32_t lds = layout(pick, G, cpb).total;
     int64_t per_cu = 2048 / pick;                                  // 32 waves per CU
     if (lds > 0 && (int64_t)(max_lds / lds) < per_cu) per_cu = (int64_t)(max_lds / lds);
     if (per_cu < 1) per_cu = 1;
@@ -201,20 +208,21 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     // of its own non-arithmetic instructions, 10 % at cfg2 with one lane per chain vs four waves -- measured 3.64e8 vs 4.03e8)
     const double w1 = w_res > 1.0 ? w_res : 1.0;
     const double cost = (w_total / w_res) * (S * (w_res > 1.8 ? w_res : 1.8) + Wl * w1 * (1.0 + 0.14 / w1));
-    if (G == 1) { cost1 = cost; block1 = pick; }
-    if (bestOcc < 0 || cost < bestOcc * (1.0 - 1e-9)) { bestOcc = cost; bestG = G; bestB = pick; }   // bestOcc holds the best cost
+    if (G == 1) { cost1 = cost; block1 = pick; cpb1 = cpb; }
+    if (bestOcc < 0 || cost < bestOcc * (1.0 - 1e-9)) { bestOcc = cost; bestG = G; bestB = pick; bestCpb = cpb; }   // bestOcc holds the best cost
   }
   // Reference order first: with ONE lane per chain a chain's log_post is summed exactly as the reference sums it (`lp += term`,
   // mcmc.js:958-960), so every draw of a seeded run is the reference's bit for bit; with more lanes only the decisions are
   // (tested), the doubles are those of the G-lane order.  Unless the caller asked for a lane count (or for AMWG_LANES_FASTEST),
   // take one lane per chain whenever the model prices it within 12 % of the cheapest geometry.
-  if (o.lanes_per_chain == 0 && bestG > 1 && cost1 > 0 && cost1 <= 1.12 * bestOcc) { bestG = 1; bestB = block1; }
+  if (o.lanes_per_chain == 0 && bestG > 1 && cost1 > 0 && cost1 <= 1.12 * bestOcc) { bestG = 1; bestB = block1; bestCpb = cpb1; }
   if (!bestG) return fail(AMWG_EINVAL, "no launch geometry fits: the model needs more than %zu bytes of LDS", max_lds);
   s->lanes = bestG;
   s->block = bestB;
-  const int CPB = bestB / bestG;
+  s->cpb = bestCpb;
+  const int CPB = bestG > 64 ? 1 : (bestCpb ? bestCpb : bestB / bestG);
   s->grid = (int)((s->C + CPB - 1) / CPB);
-  s->lds = (int)layout(bestB, bestG).total;
+  s->lds = (int)layout(bestB, bestG, bestCpb).total;
   if (s->user) return AMWG_OK;    // the kernel is compiled for this geometry afterwards
   s->kernel = pick_kernel(s->model, s->lanes);
   if (!s->kernel) return fail(AMWG_EINVAL, "no kernel for model %d with %d lanes per chain", s->model, s->lanes);
@@ -255,6 +263,7 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
   a.cc = s->d_cc;
   a.is_adapting = s->d_adapt;
   a.pl = s->pl;
+  a.cpb = s->cpb;
   a.mc = s->mc;
   a.d = s->d;
   a.ch = s->ch;
@@ -503,7 +512,6 @@ static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int
   for (int p = 0, ci = 0; p < n_params; ++p)
     for (int e2 = 0; e2 < params[p].len; ++e2, ++ci) {
       const amwg_comp_opt &o = comp_opts[ci];
-      if (o.batch_size < 1) return fail(AMWG_EINVAL, "component %d: batch_size %d < 1", ci, o.batch_size);
       hcc[ci] = CompConst{params[p].lower, params[p].upper, o.max_adaptation, o.initial_adaptation, o.target_accept_rate,
                           o.batch_size, params[p].type};
       s->h_adapt[ci] = o.is_adapting ? 1 : 0;

@@ -236,8 +236,12 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // waves; every wave is a full replica of the chain's scalar logic (same Philox stream => same proposals and decisions)
   // with its own copy of the stepper state in LDS, so waves share nothing but the data tile and the partial sums.
   constexpr bool kMulti = G > 64;
-  const int CPB = kMulti ? G / 64 : nt / G;                 // state copies in this workgroup
-  const int c_in = kMulti ? tid / 64 : tid / G, sub = tid % G;
+  // state copies in this workgroup.  A model with hundreds of components and few lanes per chain may not fit blockDim / G copies in
+  // LDS (dim [300] with one lane per chain: 64 x 301 x 28 B): the host then passes a smaller a.cpb, and the lane groups beyond it
+  // replicate the workgroup's last chain -- same chain id, hence the same stream, decisions and stores: redundant, never different.
+  const int CPB = kMulti ? G / 64 : ((a.cpb > 0 && a.cpb < nt / G) ? a.cpb : nt / G);
+  const int c_raw = kMulti ? tid / 64 : tid / G;
+  const int c_in = c_raw < CPB ? c_raw : CPB - 1, sub = tid % G;
   const int P = a.pl.P;
   const int n_named = a.pl.n_params;
   const LdsLayout L = lds_layout(Model::lds_bytes(a.d.n_obs, a.d.G, G), P, CPB, a.pl.max_top, n_named, kMulti);
@@ -384,13 +388,13 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         int2 cnt = CNTme[comp];
         cnt.x += accepted ? 1 : 0;      // acceptance_count (mcmc.js:530)
         cnt.y += 1;                     // iterations_since_adaption (mcmc.js:537)
-        if (cnt.y >= k.batch_size) {    // batch boundary: the only time batch_count is touched (it stays in HBM)
+        if ((double)cnt.y >= k.batch_size) {    // batch boundary: the only time batch_count is touched (it stays in HBM)
           // single-wave chains: batch_count and the log scale live in HBM (all lanes of the chain are in lockstep, so they
           // read the old value together before the writer lane stores the new one); multi-wave chains keep per-wave replicas
           const int32_t bc = (kMulti ? BCme[comp] : a.ch.batch_count[gi]) + 1;
           const double adj = __builtin_fmin(k.max_adaptation, k.initial_adaptation / __builtin_sqrt((double)bc));
           double pls = kMulti ? LOGPLSme[comp] : a.ch.prop_log_scale[gi];
-          if ((double)cnt.x / (double)k.batch_size > k.target_accept_rate) pls += adj; else pls -= adj;
+          if ((double)cnt.x / k.batch_size > k.target_accept_rate) pls += adj; else pls -= adj;
           cnt = make_int2(0, 0);
           SDme[comp] = exp_v8(pls);
           if constexpr (kMulti) { BCme[comp] = bc; LOGPLSme[comp] = pls; }

@@ -162,7 +162,7 @@ static int parse_common(napi_env env, napi_value *a /* [1]=params [2]=init [3]=c
     co[i].max_adaptation = prop_double(env, e, "max_adaptation", 0.33);
     co[i].initial_adaptation = prop_double(env, e, "initial_adaptation", 1.0);
     co[i].target_accept_rate = prop_double(env, e, "target_accept_rate", 0.44);
-    co[i].batch_size = (int32_t)prop_i64(env, e, "batch_size", 50);
+    co[i].batch_size = prop_double(env, e, "batch_size", 50.0);
     co[i].is_adapting = (int32_t)prop_i64(env, e, "is_adapting", 1);
   }
   memset(op, 0, sizeof *op);

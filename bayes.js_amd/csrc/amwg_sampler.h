@@ -29,7 +29,7 @@ struct amwg_sampler {
   std::vector<uint8_t> h_adapt;
   std::vector<int32_t> h_layout;   // [4][n_params] base | len | top | multidim (ParamLayout::tab on the device)
   // geometry
-  int lanes = 0, block = 0, grid = 0, lds = 0;
+  int lanes = 0, block = 0, grid = 0, lds = 0, cpb = 0;   // cpb: chains per workgroup if fewer than block / lanes (StepArgs::cpb)
   step_kernel_t kernel = nullptr;
   bool lp_ready = false;
   // translated closure (amwg_create_user): hiprtc module function instead of a built-in kernel

@@ -31,7 +31,7 @@ struct StateView {
 // Per scalar component, identical for all chains (mcmc.js:497-505).
 struct CompConst {
   double lower, upper, max_adaptation, initial_adaptation, target_accept_rate;
-  int32_t batch_size;
+  double batch_size;   // a JavaScript number (mcmc.js:538, 543 compare and divide by it as such)
   int32_t type;  // AMWG_REAL / AMWG_INT / AMWG_BINARY
 };
 
@@ -101,7 +101,8 @@ struct StepArgs {
   const CompConst *cc;      // [P]
   const uint8_t *is_adapting;  // [P]
   int32_t init_lp;          // 1 = first launch: compute lp_curr = log_post(init) (the ctor's warm-up call, mcmc.js:961-963)
-  int32_t pad;
+  int32_t cpb;              // chains per workgroup when the per-chain state of blockDim / lanes chains does not fit LDS (0 = all of them);
+                            // the lane groups beyond cpb then replicate the workgroup's last chain (same stream, same stores)
   ParamLayout pl;
   ModelConsts mc;
   DataRef d;

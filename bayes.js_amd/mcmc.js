@@ -187,11 +187,11 @@ function AmwgSampler(params, log_post, data, options) {
   this.data = data;
   this.params = shared ? params : complete_params(params, this.param_init_fun);   // steppers take completed params (mcmc.js:419-421)
 
-  const recog = (shared || opt('translate', false)) ? null : models.recognise(log_post);
+  let recog = (shared || opt('translate', false)) ? null : models.recognise(log_post);
+  // a recognised family whose parameters are declared in another order than the hand-written kernel lays them out (the reference
+  // accepts any order, only the stepper order depends on it, mcmc.js:839): translate the closure like any other
+  if (recog && recog.paramNames && recog.paramNames.join() !== this.param_names.join()) recog = null;
   this.model = recog ? recog.family : 'translated';
-  if (recog && recog.paramNames && recog.paramNames.join() !== this.param_names.join())
-    throw 'AmwgSampler (MI355X): the ' + recog.family + ' model expects params declared as {' + recog.paramNames.join(', ') +
-          '} (in that order), got {' + this.param_names.join(', ') + '}';
 
   // flatten params / init / options in Object.keys order (the stepper order of mcmc.js:839)
   const descs = [], init = [], compOpts = [];
@@ -225,6 +225,10 @@ function AmwgSampler(params, log_post, data, options) {
   this.chains = opt('chains', 1);
   if (!(this.chains >= 1) || Math.floor(this.chains) !== this.chains) throw 'options.chains must be a positive integer';
   this.seed = opt('seed', Math.floor(Math.random() * 9007199254740992));
+  // the Philox key is an unsigned 64-bit integer: a non-negative safe integer or a BigInt below 2^64 (anything else would
+  // silently become another key)
+  if (!(typeof this.seed === 'bigint' ? (this.seed >= 0n && this.seed < 18446744073709551616n) : (Number.isSafeInteger(this.seed) && this.seed >= 0)))
+    throw 'AmwgSampler (MI355X): options.seed must be a non-negative integer (number up to 2^53 - 1, or BigInt below 2^64), got ' + String(this.seed);
   const devices = opt('devices', [opt('device', 0)]);
   // the model: a built-in family, or the closure translated to HIP (compiled by the addon with hiprtc)
   let desc = null, user = null;

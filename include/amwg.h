@@ -70,7 +70,7 @@ typedef struct {
   double max_adaptation;      /* default 0.33 */
   double initial_adaptation;  /* default 1.0  */
   double target_accept_rate;  /* default 0.44 */
-  int32_t batch_size;         /* default 50   */
+  double batch_size;          /* default 50; a JS number: compared and divided as such (mcmc.js:538, 543), so 50.5 or 0 behave as in the reference */
   int32_t is_adapting;        /* default 1    */
 } amwg_comp_opt;
 

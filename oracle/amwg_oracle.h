@@ -29,7 +29,8 @@ typedef struct {
 /* Per scalar component stepper options (mcmc.js:500-505), already merged. */
 typedef struct {
   double prop_log_scale, max_adaptation, initial_adaptation, target_accept_rate;
-  int32_t batch_size, is_adapting;
+  double batch_size;       /* a JS number, compared / divided as such (mcmc.js:538, 543) */
+  int32_t is_adapting;
 } orc_comp_opt;
 
 typedef struct {

@@ -123,7 +123,12 @@ assert.throws(() => new mcmc.AmwgSampler(params, function (s, d) { return helper
 assert.throws(() => new mcmc.AmwgSampler(params, function (s, d) { s.mu = 1; return 0; }, data10), (e) => typeof e === 'string' && /assigns to the parameter state\.mu/.test(e));
 assert.throws(() => new mcmc.AmwgSampler(params, function (s, d) { return s.tau; }, data10), (e) => typeof e === 'string' && /state\.tau is read but it is neither a parameter nor a derived quantity/.test(e));
 assert.throws(() => new mcmc.AmwgSampler(params, function (s, d) { for (var k in d) { } return 0; }, data10), (e) => typeof e === 'string' && /for-in/.test(e));
-assert.throws(() => new mcmc.AmwgSampler({ sigma: { lower: 0 }, mu: {} }, readme_normal, data10), (e) => typeof e === 'string' && /expects params declared as/.test(e));
+// a recognised family declared in another order than the hand-written kernel's is not refused (the reference takes any order,
+// mcmc.js:839): it goes through the translator and gets as far as opening the device, which this CPU-only test does not have
+assert.throws(() => new mcmc.AmwgSampler({ sigma: { lower: 0 }, mu: {} }, readme_normal, data10), (e) => e instanceof Error && e.code === 'AMWG_EHIP');
+// the Philox key must be an unsigned integer: anything else would silently become another key
+for (const bad of [-1, 1.5, NaN, Infinity, 2 ** 53, -5n, 2n ** 64n])
+  assert.throws(() => new mcmc.AmwgSampler(params, readme_normal, data10, { seed: bad }), (e) => typeof e === 'string' && /options\.seed must be a non-negative integer/.test(e));
 assert.throws(() => new mcmc.AmwgSampler({ mu: { type: 'binary' }, sigma: {} }, readme_normal, data10), (e) => typeof e === 'string' && /has no binary parameters/.test(e));
 assert.throws(() => new mcmc.AmwgSampler({ mu: { type: 'complex', init: 1 }, sigma: {} }, readme_normal, data10), (e) => e === "AmwgStepper can't handle parameter mu with type complex");
 

@@ -34,6 +34,26 @@ CASES.readme_normal = {
   schedule: [{ op: 'burn', n: 300 }, { op: 'sample', n: 300, keep: 60 }], chains: [0, 3],
 };
 
+// ---- the same closure with the parameters declared the other way round: the reference does not care (only the stepper order,
+// Object.keys(params), changes: mcmc.js:839); here the closure is still recognised as the Normal family but the hand-written kernel
+// lays out {mu, sigma}, so the front-end hands it to the translator instead (tests/js/test_gpu.js runs it WITHOUT `translate: true`)
+CASES.readme_normal_swapped = {
+  params: () => ({ sigma: { type: 'real', lower: 0 }, mu: { type: 'real' } }),
+  data: () => [183, 192, 182, 183, 177, 185, 188, 188, 182, 185],
+  log_post: function(state, data) {
+    var log_post = 0;
+    // Priors
+    log_post += ld.norm(state.mu, 0, 100);
+    log_post += ld.unif(state.sigma, 0, 100);
+    // Likelihood
+    for(var i = 0; i < data.length; i++) {
+      log_post += ld.norm(data[i], state.mu, state.sigma);
+    }
+    return log_post;
+  },
+  schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 40 }], chains: [0, 3],
+};
+
 // ---- README.md:149-164 verbatim (beta-Bernoulli): with one lane per chain the translated data loop is the exact
 // fast-forward of a two-valued sum (csrc/amwg_twoval.h)
 CASES.readme_bern = {
@@ -672,13 +692,17 @@ function makeEdgeCase(index) {
     { params: { v: { dim: [2, 2], lower: -1, upper: 1, init: 0 } }, body: 'var lp = 0; for (var i = 0; i < 2; i++) for (var j = 0; j < 2; j++) lp += ld.norm(s.v[i][j], 0, 0.1) - 1e300 * (s.v[i][j] > 0.99 ? 1 : 0); return lp;', options: { prop_log_scale: [[5, -5], [0, 50]], batch_size: 3 } },
     { params: { k: { type: 'int', lower: -1, upper: 1, init: 0 }, a: {} }, body: 'var lp = ld.norm(s.a, s.k, 1) + (s.k === 0 ? 0 : -0.5); return lp;', options: { prop_log_scale: -3, batch_size: 2, is_adapting: false } },
     { params: { a: { lower: 0, init: 1e-300 } }, body: 'return ld.lnorm(s.a, 0, 3);', options: { prop_log_scale: -690 } },
+    // batch_size is a JS number the reference compares and divides by as it stands (mcmc.js:538, 543): a non-integer one adapts after ceil(2.5) = 3
+    // iterations with acceptance_count / 2.5; zero adapts every iteration with count / 0 = Infinity (or 0 / 0 = NaN, which is not > the target)
+    { params: { a: {}, b: { lower: 0 } }, body: 'var lp = ld.norm(s.a, 1, 2) + ld.gamma(s.b, 3, 1); return lp;', options: { batch_size: 2.5 } },
+    { params: { a: {}, k: { type: 'int', lower: -5, upper: 5 } }, body: 'var lp = ld.norm(s.a, 0, 1) + ld.norm(s.k, 1, 2); return lp;', options: { params: { a: { batch_size: 0 }, k: { batch_size: 7.25 } } } },
   ];
   const c = cases[index];
   const log_post = new Function('return function (s, d) {\n  ' + c.body + '\n};')();
   const schedule = [{ op: 'burn', n: 0 }, { op: 'burn', n: 37 }, { op: 'sample', n: 0 }, { op: 'sample', n: 25, thin: 40 }, { op: 'stop' }, { op: 'sample', n: 30, thin: 7 }, { op: 'start' }, { op: 'sample', n: 41, thin: 1, keep: 41 }];
   return { params: () => c.params, data: () => ({}), log_post, options: c.options, schedule, chains: [0, 5] };
 }
-for (let k = 0; k < 8; k++) CASES['cfgedge_' + k] = makeEdgeCase(k);
+for (let k = 0; k < 10; k++) CASES['cfgedge_' + k] = makeEdgeCase(k);
 
 function build(name, seed) {
   const c = CASES[name] || BENCH[name];

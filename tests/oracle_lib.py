@@ -15,7 +15,7 @@ class OrcParam(C.Structure):
 
 class OrcCompOpt(C.Structure):
     _fields_ = [("prop_log_scale", C.c_double), ("max_adaptation", C.c_double), ("initial_adaptation", C.c_double),
-                ("target_accept_rate", C.c_double), ("batch_size", C.c_int32), ("is_adapting", C.c_int32)]
+                ("target_accept_rate", C.c_double), ("batch_size", C.c_double), ("is_adapting", C.c_int32)]
 
 
 class OrcData(C.Structure):
@@ -128,7 +128,7 @@ class OracleChain:
             oa[i].max_adaptation = o["max_adaptation"]
             oa[i].initial_adaptation = o["initial_adaptation"]
             oa[i].target_accept_rate = o["target_accept_rate"]
-            oa[i].batch_size = int(o["batch_size"])
+            oa[i].batch_size = float(o["batch_size"])
             oa[i].is_adapting = int(bool(o["is_adapting"]))
         init = np.ascontiguousarray(spec["init"], dtype=np.float64)
         self.n_params = n

@@ -97,7 +97,7 @@ def oracle_spec(name):
 
 
 @pytest.mark.parametrize("name", ["complex_model", "spike_slab", "multi_bern", "hier_binomial", "discrete_mix", "modern_js", "multivar_poisson", "semantics_probe", "circular_wrapped_cauchy", "structured_helpers", "records_logistic", "categorical_arms"]
-                         + ["cfgfuzz_%d" % k for k in range(16)] + ["cfgedge_%d" % k for k in range(8)])
+                         + ["cfgfuzz_%d" % k for k in range(16)] + ["cfgedge_%d" % k for k in range(10)])
 def test_oracle_stepper_with_translated_closure_reproduces_reference(name):
     """Pins the oracle's BinaryStepper (mcmc.js:753-767) and int/real steppers on user models: the C oracle, stepping with the
     host build of the translated closure as log_post, reproduces the seeded reference run bit for bit.  cfgfuzz_*: randomly drawn
