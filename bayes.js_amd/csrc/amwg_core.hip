@@ -27,7 +27,7 @@ using namespace amwg;
 // together with the very same step kernel source the built-in models are compiled from.
 extern "C" {
 extern const char amwg_hdr_stdint[], amwg_hdr_types[], amwg_hdr_math[], amwg_hdr_div[], amwg_hdr_ld[], amwg_hdr_philox[],
-    amwg_hdr_kernel[], amwg_hdr_user[], amwg_hdr_twoval[], amwg_hdr_trig[];
+    amwg_hdr_kernel[], amwg_hdr_user[], amwg_hdr_twoval[], amwg_hdr_trig[], amwg_hdr_pass[];
 }
 
 namespace {
@@ -584,12 +584,12 @@ static std::string user_program(const char *source, int lanes, int block) {
 
 static int compile_user(const char *source, int lanes, int block, const char *arch, std::vector<char> *code) {
   static const char *names[] = {"amwg_stdint.h", "amwg_types.h", "amwg_math.h", "amwg_div.h", "amwg_ld.h", "amwg_philox.h",
-                                "amwg_kernel.h", "amwg_user.h", "amwg_twoval.h", "amwg_trig.h"};
+                                "amwg_kernel.h", "amwg_user.h", "amwg_twoval.h", "amwg_trig.h", "amwg_pass.h"};
   const char *texts[] = {amwg_hdr_stdint, amwg_hdr_types, amwg_hdr_math, amwg_hdr_div, amwg_hdr_ld, amwg_hdr_philox,
-                         amwg_hdr_kernel, amwg_hdr_user, amwg_hdr_twoval, amwg_hdr_trig};
+                         amwg_hdr_kernel, amwg_hdr_user, amwg_hdr_twoval, amwg_hdr_trig, amwg_hdr_pass};
   const std::string prog_src = user_program(source, lanes, block);
   hiprtcProgram prog = nullptr;
-  hiprtcResult r = hiprtcCreateProgram(&prog, prog_src.c_str(), "amwg_user_model.hip", 10, texts, names);
+  hiprtcResult r = hiprtcCreateProgram(&prog, prog_src.c_str(), "amwg_user_model.hip", 11, texts, names);
   if (r != HIPRTC_SUCCESS) return fail(AMWG_EHIP, "hiprtcCreateProgram failed: %s", hiprtcGetErrorString(r));
   const std::string arch_opt = std::string("--offload-arch=") + arch;
   // same floating-point contract as the Makefile: one rounding per operation, no fused contraction
@@ -772,6 +772,11 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   // launch (StepArgs.init_lp); amwg_chain_diag forces it with a 0-step launch if asked earlier.
   const size_t max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
   TRYB(choose_geometry(s, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, max_lds));
+  if (m->model == AMWG_MODEL_HIER_NORMAL && !options->exact_division) {   // do the group labels repeat with the lane stride? (HierNormalModel::pass_fast)
+    bool periodic = N > 0;
+    for (int i = s->lanes; i < N && periodic; ++i) periodic = m->g[i] == m->g[i % s->lanes];
+    mc.group_lane_const = periodic ? 1 : 0;
+  }
   HIPB(hipFuncSetAttribute(reinterpret_cast<const void *>(s->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds));
   HIPB(hipStreamSynchronize(s->stream));
   *out = s;

@@ -1,0 +1,248 @@
+// amwg_pass.h -- the hand-scheduled pass over the data of a normal likelihood with loop-invariant sd, shared by the built-in
+// families (amwg_models.h) and by translated closures (amwg_user.h: `for (i...) lp += ld.norm(x[i], mean, sd)` compiles to it).
+#pragma once
+#include "amwg_div.h"
+#include "amwg_types.h"
+
+namespace amwg {
+
+// ---------------------------------------------------------------------------------------------
+// The pass over the data of a normal likelihood with loop-invariant sd -- sum_i [ c - (x_i - m_i)^2 / den ] added term by term
+// to `acc` in increasing i -- software-pipelined by hand.  Per observation it is the same eight fp64 operations, with the same
+// roundings in the same order, as NormalModel::term<true> / div_by_invariant (amwg_div.h):
+//     t = x - m;  tt = t*t;  q0 = tt*y.lo;  q1 = fma(tt, y.hi, q0);  r = fma(-den, q1, tt);  q = fma(r, y.hi, q1);  term = c - q;  acc += term
+// and the terms are added in the same order, so the sum is bit-identical to the plain loop (pass_over_data).  What changes is the
+// SCHEDULE: the compiler's own schedule of the plain loop waits for every LDS read right after issuing it and works through the
+// terms two at a time, i.e. one long dependent chain per wave (rocprofv3, round 1: 0.74 of the fp64 issue rate at 4 waves per
+// SIMD, 39 % of wave cycles waiting).  Here a block of U observations moves through the eight steps as eight STAGES of U
+// independent instructions each (sched_barrier between stages keeps the compiler from re-serialising them), the LDS reads of
+// block k+1 (and, for a gathered mean, the index reads of block k+2) are issued before the arithmetic of block k starts, and the
+// U dependent `acc +=` of block k-1 are spread one per stage over block k -- no instruction waits for the one before it.
+// Mean = a functor: m(i) for a per-observation mean gathered from LDS (HierNormalModel), or a constant (NormalModel).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AMWG_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define AMWG_STAGE_FENCE() ((void)0)
+#endif
+
+template <int U>
+struct NormBlock { double v[U]; };     // x, then t, tt, r in place
+
+// "the loads of THIS block have landed": with a constant mean a block is four LDS reads (ds_read2_b64 / ds_read_b128 pairs of the
+// U = 8 observations) and the four reads of the NEXT block were issued just before, so lgkmcnt <= 4 is exactly that.  Saying it
+// once keeps the compiler from placing one s_waitcnt in front of every pair of subtractions (with one wave per SIMD -- one lane
+// per chain at cfg2 -- every s_waitcnt is an issue slot the fp64 pipe idles through).  Only a hint: the compiler's own counter
+// tracking still inserts whatever wait a different instruction selection would need.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AMWG_WAIT_LDS_LE(n) __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8))   // vmcnt / expcnt untouched
+#else
+#define AMWG_WAIT_LDS_LE(n) ((void)0)
+#endif
+
+template <int U, bool ADD_PREV>
+AMWG_HD void norm_block_stages(NormBlock<U> &b, const double (&m)[U], NormBlock<U> &q, const NormBlock<U> &prev, double &acc,
+                                                  double c, double den, Reciprocal y) {
+  // prev = the finished terms of the block before this one; its U additions are dealt over the seven stages (U = 8: one per
+  // stage, two in the last)
+  int a = 0;
+  auto add_prev = [&](int upto) {
+    if constexpr (ADD_PREV) { for (; a < upto && a < U; ++a) acc = acc + prev.v[a]; }
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) b.v[u] = b.v[u] - m[u];
+  add_prev(1 * U / 7);
+  AMWG_STAGE_FENCE();
+#pragma unroll
+  for (int u = 0; u < U; ++u) b.v[u] = b.v[u] * b.v[u];
+  add_prev(2 * U / 7);
+  AMWG_STAGE_FENCE();
+#pragma unroll
+  for (int u = 0; u < U; ++u) q.v[u] = b.v[u] * y.lo;
+  add_prev(3 * U / 7);
+  AMWG_STAGE_FENCE();
+#pragma unroll
+  for (int u = 0; u < U; ++u) q.v[u] = __builtin_fma(b.v[u], y.hi, q.v[u]);
+  add_prev(4 * U / 7);
+  AMWG_STAGE_FENCE();
+#pragma unroll
+  for (int u = 0; u < U; ++u) b.v[u] = __builtin_fma(-den, q.v[u], b.v[u]);
+  add_prev(5 * U / 7);
+  AMWG_STAGE_FENCE();
+#pragma unroll
+  for (int u = 0; u < U; ++u) q.v[u] = __builtin_fma(b.v[u], y.hi, q.v[u]);
+  add_prev(6 * U / 7);
+  AMWG_STAGE_FENCE();
+#pragma unroll
+  for (int u = 0; u < U; ++u) q.v[u] = c - q.v[u];
+  add_prev(U);
+  AMWG_STAGE_FENCE();
+}
+
+// x: LDS (or global) array of the observations; lane `sub` of the chain's G lanes takes observations sub, sub + G, ...
+// MeanOf::gather == false: constant mean;  true: index array g (u8) and the chain's state S, mean of observation i = S(g[i])
+template <int G, int U, bool GATHER>
+AMWG_HD double norm_pass_staged(const double *x, const uint8_t *g, const StateView S, double mean, double c, double den,
+                                                   Reciprocal y, int n_obs, int sub, double acc) {
+  const int n_full = n_obs / G, rem = n_obs % G;
+  const int n_blocks = n_full / U;
+  int k = 0;
+  if (n_blocks > 0) {
+    NormBlock<U> xa, xb, qa, qb;
+    double ma[U], mb[U];
+    int ga[U], gb[U];     // GATHER: group indices, read one block further ahead than the values
+    const double *px = x + sub;
+    const uint8_t *pg = g + sub;
+    // (index prefetches past the end re-read the last block: harmless, and the loop body stays ONE basic block -- a conditional
+    // load splits it, the stage fences stop holding across the pieces and the register sets get copied instead of swapped)
+    auto load_idx = [&](int blk, int (&gi)[U]) {
+      if constexpr (GATHER) {
+        blk = blk < n_blocks ? blk : n_blocks - 1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) gi[u] = pg[(blk * U + u) * G];
+      }
+    };
+    auto load_val = [&](int blk, NormBlock<U> &xv, double (&mv)[U], const int (&gi)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) xv.v[u] = px[(blk * U + u) * G];
+#pragma unroll
+      for (int u = 0; u < U; ++u) mv[u] = GATHER ? S(gi[u]) : mean;
+    };
+    // prologue: block 0 loaded, indices of block 1 on their way
+    load_idx(0, ga);
+    load_val(0, xa, ma, ga);
+    load_idx(1, gb);
+    AMWG_STAGE_FENCE();
+    // block 0: nothing to add yet
+    if (n_blocks > 1) { load_val(1, xb, mb, gb); load_idx(2, ga); }
+    AMWG_STAGE_FENCE();
+    norm_block_stages<U, false>(xa, ma, qa, qa, acc, c, den, y);
+    int blk = 1;
+    // steady state, two blocks per trip (A/B register sets swap roles, no copies): on entry the terms of block blk-1 sit in qa,
+    // the values of block blk in xb/mb, the indices of block blk+1 in ga
+    for (; blk + 2 < n_blocks; blk += 2) {
+      load_val(blk + 1, xa, ma, ga);
+      load_idx(blk + 2, gb);
+      AMWG_STAGE_FENCE();
+      if constexpr (!GATHER && U == 8) { AMWG_WAIT_LDS_LE(4); AMWG_STAGE_FENCE(); }
+      norm_block_stages<U, true>(xb, mb, qb, qa, acc, c, den, y);
+      load_val(blk + 2, xb, mb, gb);
+      load_idx(blk + 3, ga);
+      AMWG_STAGE_FENCE();
+      if constexpr (!GATHER && U == 8) { AMWG_WAIT_LDS_LE(4); AMWG_STAGE_FENCE(); }
+      norm_block_stages<U, true>(xa, ma, qa, qb, acc, c, den, y);
+    }
+    // epilogue: one or two blocks left (blk, and maybe blk + 1), terms of blk-1 pending in qa
+    if (blk < n_blocks) {
+      if (blk + 1 < n_blocks) load_val(blk + 1, xa, ma, ga);
+      AMWG_STAGE_FENCE();
+      norm_block_stages<U, true>(xb, mb, qb, qa, acc, c, den, y);
+      if (blk + 1 < n_blocks) {
+        norm_block_stages<U, true>(xa, ma, qa, qb, acc, c, den, y);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = acc + qa.v[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = acc + qb.v[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc = acc + qa.v[u];
+    }
+    k = n_blocks * U;
+  }
+  // ragged tail: fewer than U rounds, then the lanes below n_obs % G take one more observation
+  for (; k < n_full; ++k) {
+    const int i = k * G + sub;
+    const double t = x[i] - (GATHER ? S(g[i]) : mean);
+    acc += c - div_by_invariant(t * t, den, y);
+  }
+  if (sub < rem) {
+    const int i = n_full * G + sub;
+    const double t = x[i] - (GATHER ? S(g[i]) : mean);
+    acc += c - div_by_invariant(t * t, den, y);
+  }
+  return acc;
+}
+
+// ONE lane per chain (the reference's own summation order): all 64 lanes of a wave -- 64 different chains -- need the SAME
+// observation at the same time, so the observations are wave-uniform.  They are then read through the SCALAR path (s_load_dwordx16 =
+// eight observations per instruction, from global memory through the scalar cache / L2, no LDS tile at all) and enter the fp64
+// pipe as SGPR operands.  With one wave per SIMD (65 536 chains = 1024 waves on 1024 SIMDs) every instruction that is not an fp64
+// operation is an issue slot the pipe idles through: the LDS version spends 8 ds_read + 9 others per 128 fp64 operations, this
+// one 2 s_load + ~8.  Scalar loads return out of order, so the only wait is lgkmcnt(0): a chunk of 16 observations is requested
+// one whole chunk (~520 cycles of arithmetic) before it is needed.  Same operations, same order, same bits as the plain loop.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const double __attribute__((address_space(4))) *amwg_uniform_f64_ptr;
+#else
+typedef const double *amwg_uniform_f64_ptr;
+#endif
+
+struct StagedFirst { static constexpr bool value = true; };
+struct StagedLater { static constexpr bool value = false; };
+
+template <int U>
+AMWG_HD double norm_pass_uniform(const double *x_global, double mean, double c, double den, Reciprocal y, int n_obs, double acc) {
+  constexpr int CH = 2 * U;                       // observations per chunk (two blocks of U)
+  const int n_chunks = n_obs / CH;
+  int k = 0;
+  if (n_chunks > 0) {
+    amwg_uniform_f64_ptr px = (amwg_uniform_f64_ptr)(uintptr_t)x_global;
+    double ma[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) ma[u] = mean;
+    NormBlock<CH> sa, sb;                         // the two chunks in flight (wave-uniform: scalar registers)
+    NormBlock<U> ta, tb, qa, qb;
+    auto load_chunk = [&](int ch, NormBlock<CH> &dst) {
+      ch = ch < n_chunks ? ch : n_chunks - 1;     // prefetches past the end re-read the last chunk (keeps the loop one basic block)
+#pragma unroll
+      for (int u = 0; u < CH; ++u) dst.v[u] = px[ch * CH + u];
+    };
+    auto lo = [&](const NormBlock<CH> &src, NormBlock<U> &t) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) t.v[u] = src.v[u];
+    };
+    auto hi = [&](const NormBlock<CH> &src, NormBlock<U> &t) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) t.v[u] = src.v[U + u];
+    };
+    // A scalar wait drains EVERY outstanding scalar load, so a new request must be issued right AFTER the wait for the previous
+    // one, never before it: per chunk  { wait (the chunk requested one chunk ago has landed) ; request the next chunk into the
+    // other register set ; 2 x 7 stages on this chunk }.
+    auto compute = [&](const NormBlock<CH> &src, auto first) {
+      lo(src, ta);
+      norm_block_stages<U, !decltype(first)::value>(ta, ma, qa, qb, acc, c, den, y);
+      hi(src, tb);
+      norm_block_stages<U, true>(tb, ma, qb, qa, acc, c, den, y);
+    };
+    load_chunk(0, sb);
+    AMWG_WAIT_LDS_LE(0); AMWG_STAGE_FENCE();
+    load_chunk(1, sa);
+    AMWG_STAGE_FENCE();
+    compute(sb, StagedFirst{});                           // chunk 0: its first block has no earlier terms to add
+    int ch = 1;
+    for (; ch + 1 < n_chunks; ch += 2) {          // chunk ch is on its way into sa
+      AMWG_WAIT_LDS_LE(0); AMWG_STAGE_FENCE();
+      load_chunk(ch + 1, sb);
+      AMWG_STAGE_FENCE();
+      compute(sa, StagedLater{});
+      AMWG_WAIT_LDS_LE(0); AMWG_STAGE_FENCE();
+      load_chunk(ch + 2, sa);
+      AMWG_STAGE_FENCE();
+      compute(sb, StagedLater{});
+    }
+    if (ch < n_chunks) {                          // one chunk left, on its way into sa
+      AMWG_WAIT_LDS_LE(0); AMWG_STAGE_FENCE();
+      compute(sa, StagedLater{});
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = acc + qb.v[u];
+    k = n_chunks * CH;
+  }
+  for (; k < n_obs; ++k) {                        // ragged tail
+    const double t = x_global[k] - mean;
+    acc += c - div_by_invariant(t * t, den, y);
+  }
+  return acc;
+}
+
+}  // namespace amwg

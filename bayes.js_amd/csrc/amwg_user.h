@@ -3,6 +3,7 @@
 #pragma once
 #include "amwg_div.h"
 #include "amwg_ld.h"
+#include "amwg_pass.h"
 #include "amwg_twoval.h"
 #include "amwg_types.h"
 
@@ -53,6 +54,28 @@ AMWG_HD double ld_norm_slow(double x, double mean, const NormInv &k) {
   return k.c - (t * t) / k.den;
 }
 AMWG_HD bool norm_range_ok(uint32_t rlo, uint32_t rhi) { return rlo >= 0x1A700000u && rhi <= 0x65700000u; }   // 2^-600 .. 2^600, zero excluded
+
+// `for (i = 0; i < n; i++) lp += ld.norm(x[i], mean, sd)` over a whole f64 data array with loop-invariant mean and sd -- the likelihood
+// loop of the README's model and of most closures -- compiles to the hand-scheduled pass of amwg_pass.h, the one the built-in Normal
+// family runs: with G lanes per chain the staged pass over the array in LDS (x_staged), with ONE lane per chain the scalar-load pass over
+// the array in global memory (x_global: the observations are wave-uniform).  Same operations in the same order as the closure's own loop
+// (t = x - mean; t*t / (2*sd*sd); c - q; lp += term), the quotient by the 4-operation form of amwg_div.h when its range preconditions hold
+// (divisor, mean and -- checked by the translator on the host -- every data value inside 2^-200..2^200 or zero) and by IEEE '/' otherwise.
+template <int G>
+AMWG_HD double norm_data_loop(const double *x_staged, const double *x_global, int n, double mean, const NormInv &k, bool data_mid_range, int sub, double acc) {
+  if (k.fast && data_mid_range && (mean == 0 || mid_range(__builtin_fabs(mean)))) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (G == 1) return norm_pass_uniform<8>(x_global, mean, k.c, k.den, k.y, n, acc);
+    else return norm_pass_staged<G, 8, false>(x_staged, nullptr, StateView{nullptr}, mean, k.c, k.den, k.y, n, sub, acc);
+#else
+    for (int i = sub; i < n; i += G) { const double t = x_global[i] - mean; acc += k.c - div_by_invariant(t * t, k.den, k.y); }
+    return acc;
+#endif
+  }
+  const double *x = (G == 1) ? x_global : x_staged;
+  for (int i = sub; i < n; i += G) { const double t = x[i] - mean; acc += k.c - (t * t) / k.den; }
+  return acc;
+}
 
 // ld.bern(x, p) for a loop in which p does not change (distributions.js:228-230): the two values
 // log(1*p + 0*(1-p)) and log(0*p + 1*(1-p)) the expression can take, selected per observation.

@@ -1249,6 +1249,23 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
         out.push(indent + '}');
         return;
       }
+      // `for (i = 0; i < x.length; i++) lp += ld.norm(x[i], mean, sd)` over a whole f64 data array, mean and sd loop-invariant: the
+      // hand-scheduled pass the built-in Normal family runs (csrc/amwg_pass.h via norm_data_loop, amwg_user.h) -- staged LDS reads
+      // with G lanes, scalar loads with one lane per chain; same operations in the same order as the generic loop below
+      const mn = simple && pend.length === 0 && /^NORMCALL\(A(\d+)\[v_(\w+)\], (.+), (k\d+) RANGEARGS\)$/.exec(term.code);
+      if (mn && mn[2] === canon.name && startV.cst === 0 && !canon.le && this.arrays[Number(mn[1])].ctype === 'double' &&
+          boundV.cst === this.arrays[Number(mn[1])].flat.length && mn[3].indexOf('v_' + canon.name) < 0 && mn[3].indexOf('NORMCALL') < 0 && !this.opts.no_staged_norm) {
+        const arr = this.arrays[Number(mn[1])];
+        let mid = true;
+        for (let i = 0; i < arr.flat.length && mid; i++) { const v = Math.abs(arr.flat[i]); mid = v === 0 || (v >= Math.pow(2, -200) && v <= Math.pow(2, 200)); }
+        this.uniformNormLoops = (this.uniformNormLoops || 0) + 1;
+        out.push(indent + '{');
+        for (const ln of renderNorm(L.preamble.map((q) => '  ' + q), 'inv')) out.push(indent + ln);
+        out.push(indent + '  ' + acc + ' = norm_data_loop<G>(A' + mn[1] + ', static_cast<const double *>(user_arr<' + mn[1] + '>(d)), ' + boundV.cst + ', ' + mn[3] + ', ' + mn[4] + ', ' + (mid ? 'true' : 'false') + ', sub, ' + acc + ');');
+        out.push(indent + '}');
+        return;
+      }
+      this.otherSplitLoops = (this.otherSplitLoops || 0) + 1;
       this.emitSplit(out, indent, L.preamble, head, loop, [loopAcc]);
       return;
     }
@@ -1270,6 +1287,7 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
       loop.push('  }');
       out.pop();   // the '{' pushed above: emitSplit writes its own block
       L.preamble.forEach(() => out.pop());
+      this.otherSplitLoops = (this.otherSplitLoops || 0) + 1;
       this.emitSplit(out, indent, L.preamble, [], loop, Array.from(this.accSet).filter((a) => assigned.has(a)));
       return;
     }
@@ -1503,6 +1521,8 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
     this.nSplit = 0;
     this.heavyLoop = false;
     this.oneLaneWork = 0;
+    this.uniformNormLoops = 0;
+    this.otherSplitLoops = 0;
     lines = [];
     for (const st of stmts) this.stmt(st, lines, '    ', { inLoop: false, split: false });
     if (!last || last.k !== 'Return') this.fail('log_post must end with a return statement');
@@ -1610,7 +1630,9 @@ Translator.prototype.run = function () {
     max_threads: maxThreads,
     work_per_eval: this.workEstimate(),
     // instruction estimate with ONE lane per chain when that enables the exact fast-forward of a two-valued sum (0 = no such loop)
-    work_one_lane: this.oneLaneWork ? this.workEstimate(true) : 0,
+    // ... or when every lane-split loop is the wave-uniform normal pass (scalar loads: one lane per chain costs nothing extra, and it is
+    // the reference's own summation order, which the host library prefers when it is priced within 12 % of the cheapest geometry)
+    work_one_lane: (this.oneLaneWork || (this.uniformNormLoops > 0 && !this.otherSplitLoops)) ? this.workEstimate(true) : 0,
     P: this.P,
   };
 };

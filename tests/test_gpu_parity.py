@@ -209,3 +209,24 @@ def test_two_valued_sum_fast_forward_equals_the_term_by_term_pass(n_obs, hyper):
     assert a.info()["accepts"].tolist() == b.info()["accepts"].tolist()
     assert a.diag()["log_post"].tobytes() == b.diag()["log_post"].tobytes()
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("groups,lanes,n_obs", [(4, 4, 1000), (4, 8, 999), (8, 64, 3000), (32, 64, 10000), (4, 128, 2000), (6, 64, 900)])
+def test_hierarchical_pass_with_lane_constant_groups_equals_the_gathered_pass(groups, lanes, n_obs):
+    """When the group labels repeat with the lane stride (g_i = i mod groups, lanes a multiple of groups) every lane of a chain meets
+    one group only and HierNormalModel reads its mean once per evaluation instead of gathering it per observation (constant-mean pass,
+    ModelConsts::group_lane_const).  Same values, same order: the trajectories must equal the oracle's in that lane order, and the
+    term-by-term IEEE schedule (exact_division = 1, which never takes the shortcut); (6, 64) is a layout that must NOT take it."""
+    data = model_spec.make_data("hier_normal", n_obs, 321, G=groups)
+    spec = model_spec.build_spec("hier_normal", data)
+    sched = [{"op": "burn", "n": 110}, {"op": "sample", "n": 40, "thin": 4}]
+    s = A.Sampler(spec, chains=6, seed=8, chain_offset=3, lanes_per_chain=lanes)
+    e = A.Sampler(spec, chains=6, seed=8, chain_offset=3, lanes_per_chain=lanes, exact_division=1)
+    gs, ge = run_schedule(s, sched), run_schedule(e, sched)
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(gs, ge))
+    assert s.state().tobytes() == e.state().tobytes()
+    for local in (0, 5):
+        o = oracle_lib.OracleChain(spec, 8, 3 + local, lanes=lanes)
+        assert_chain_equals_oracle(s, local, o, gs, run_schedule(o, sched))
+    s.close()
+    e.close()
