@@ -439,7 +439,7 @@ Translator.prototype.index = function (objV, idxV) {
   let guards = objV.guards || [];
   if (idxV.cst !== undefined && Number.isInteger(idxV.cst)) {
     if (idxV.cst < 0 || idxV.cst >= dims[0]) {
-      if (dims.length === 1) return cnum(NaN);         // x[n] is undefined in JavaScript: NaN in arithmetic
+      if (dims.length === 1) { const u = cnum(NaN); u.undef = 'true'; return u; }      // x[n] is undefined in JavaScript: NaN in arithmetic (and === another undefined)
       this.fail('constant index ' + idxV.cst + ' is outside an array of ' + dims[0] + ' rows (JavaScript would throw on the next index)');
     }
     off = idxV.cst * inner;
@@ -466,7 +466,8 @@ Translator.prototype.index = function (objV, idxV) {
   else sum = base + ' + ' + off;
   const G = guards.length ? guards : undefined;
   if (dims.length > 1) return objV.t === 'dataArr' ? { t: 'dataArr', id: objV.id, off: sum, dims: dims.slice(1), guards: G } : { t: 'stateArr', base: sum, dims: dims.slice(1), guards: G };
-  const guarded = (code) => num('((' + guards.join(' && ') + ') ? ' + code + ' : __builtin_nan(""))', false);
+  // (`undef`: the condition under which this read is JavaScript's `undefined` -- it matters to == / != only, see the comparison below)
+  const guarded = (code) => { const v = num('((' + guards.join(' && ') + ') ? ' + code + ' : __builtin_nan(""))', false); v.undef = '!(' + guards.join(' && ') + ')'; return v; };
   if (objV.t === 'dataArr') {
     // a constant element of a data array is a constant
     if (/^\d+$/.test(sum) && !G) return cnum(this.arrays[objV.id].flat[Number(sum)]);
@@ -558,6 +559,12 @@ Translator.prototype.exprInner = function (e, wasCondition) {
       if (CMP[e.op]) {
         if (l.t === 'bool' && r.t === 'bool') return { t: 'bool', code: '((' + l.code + ') ' + (e.op[0] === '!' ? '!=' : '==') + ' (' + r.code + '))' };
         if (l.t !== 'num' || r.t !== 'num') this.fail("comparison '" + e.op + "' between a " + this.describe(l) + ' and a ' + this.describe(r));
+        // two reads outside their arrays are both `undefined`, and undefined == undefined (=== too) although each is NaN in arithmetic
+        if (l.undef && r.undef && (e.op === '==' || e.op === '===' || e.op === '!=' || e.op === '!==')) {
+          const both = (l.undef === 'true' && r.undef === 'true') ? 'true' : '((' + l.undef + ') && (' + r.undef + '))';
+          const eqc = '((' + this.asD(l) + ' == ' + this.asD(r) + ') || ' + both + ')';
+          return { t: 'bool', code: e.op[0] === '!' ? '(!' + eqc + ')' : eqc };
+        }
         if (l.cst !== undefined && r.cst !== undefined) { const v = CMP[e.op](l.cst, r.cst); return { t: 'bool', code: v ? 'true' : 'false', cst: v }; }
         const op = e.op === '===' ? '==' : (e.op === '!==' ? '!=' : e.op);
         // loop counters against integer bounds compare as ints; everything else as JavaScript numbers

@@ -90,7 +90,7 @@ def other_spec(name, exp):
     return model_spec.build_spec(fam, model_spec.make_data(fam, n_obs, DATA_SEED, G=32, exp=exp))
 
 
-def measured_traffic(chains, steps_per_launch, workload="cfg2"):
+def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_summary.json, written by
     tools/profile.sh + tools/summarize_profile.py for this same command); None if no matching profile."""
     import glob
@@ -100,6 +100,8 @@ def measured_traffic(chains, steps_per_launch, workload="cfg2"):
         except (OSError, ValueError):
             continue
         if p.get("workload", "cfg2") != workload:
+            continue
+        if lanes is not None and (", %d>" % lanes) not in p.get("kernel", ""):      # the profile must be of the same kernel instantiation
             continue
         if p.get("chains") == chains and p.get("steps_per_launch") == steps_per_launch and p.get("hbm_traffic_bytes_per_launch"):
             return p["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
@@ -340,7 +342,7 @@ def main():
         assert dist is not None or np.allclose(pm, mean, rtol=1e-10, atol=0), "library moments differ from the pooled restatement"
         measured_peak = A.fp64_peak(dev_index)      # register-only fma kernel: what the chip sustains under fp64 load
         x = spec["data"]["x"]
-        traffic, traffic_src = measured_traffic(chains, args.steps_per_launch, args.workload)
+        traffic, traffic_src = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"])
         kname = {"normal": "NormalModel", "beta_bern": "BetaBernModel", "hier_normal": "HierNormalModel", "pois_glm": "PoisGlmModel"}[spec["model"]]
         kernel = "amwg_step_kernel<%s,%d>" % (kname, li["lanes_per_chain"])
         roof_launch_s, roof_updates, roof_note = launch_s, updates_per_launch, None

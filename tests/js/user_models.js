@@ -468,6 +468,27 @@ CASES.long_dim = {
   schedule: [{ op: 'burn', n: 12 }, { op: 'sample', n: 12, keep: 4 }], chains: [0, 1],
 };
 
+// ---- reads outside an array are `undefined`: NaN in arithmetic, but equal to another `undefined` under == and === (round 2: the
+// direct comparison of two such reads follows JavaScript; round 1 documented it as a divergence).  The indices depend on the state.
+CASES.undefined_reads = {
+  params: () => ({ a: { init: 0.2 }, k: { type: 'int', lower: -3, upper: 9, init: 2 } }),
+  data: () => ({ x: [1.5, 2.5, 3.5, 4.5, 5.5, 6.5], y: [1.5, 2.5, 3.5, 9.5, 5.5, 6.5, 7.5, 8.5] }),
+  log_post: function(s, d) {
+    var lp = ld.norm(s.a, 0, 2) + ld.unif(s.k, -3, 9);
+    var n = Math.floor(s.a * 3) + 4, m = s.k;
+    if (d.x[n] == d.y[m]) lp += 0.25;             // both outside => undefined == undefined => true
+    if (d.x[n] !== d.y[m]) lp -= 0.125;
+    if (d.x[40] === d.y[50]) lp += 0.0625;        // two constant reads outside: always true
+    if (d.x[n] === d.y[2]) lp += 0.5;             // undefined against a number: false
+    if (d.x[m] != d.x[n]) lp -= 0.03125;
+    var w = d.y[m];                                // NaN in arithmetic
+    s.seen = (w > -1e300) ? w : -1;                // a comparison with undefined is false (a VARIABLE holding undefined still compares as NaN here: DESIGN.md section 7)
+    if (w > 8) lp -= 0.75;
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+
 // ---- the same kind of model written in post-ES5 JavaScript: destructured parameters and declarations, for-of, forEach with an
 // early return, reduce (one over a parameter array with the index argument), map, new Array(n).fill(v), an arrow helper, const/let
 CASES.modern_js = {
