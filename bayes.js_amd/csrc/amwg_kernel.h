@@ -93,9 +93,15 @@ struct CrossWave {
   int parity;
 };
 
+template <class...> using void_of = void;
+
+// Does the model have binary parameters (BinaryStepper, two more inlined log_post evaluations per slot)?  The built-in families have
+// none; a translated closure says so (UserModel::kHasBinary, from its params); absent means "may have".
+template <class M, class = void> struct BinaryOf { static constexpr bool value = true; };
+template <class M> struct BinaryOf<M, void_of<decltype(M::kHasBinary)>> { static constexpr bool value = M::kHasBinary; };
+
 // per-chain values a model keeps from one log_post evaluation to the next (Model::Cache; translated closures have none)
 struct NoCache {};
-template <class...> using void_of = void;
 template <class M, class = void> struct CacheOf { using type = NoCache; static __device__ __forceinline__ type init() { return type{}; } };
 template <class M> struct CacheOf<M, void_of<typename M::Cache>> { using type = typename M::Cache; static __device__ __forceinline__ type init() { return M::cache_init(); } };
 
@@ -349,7 +355,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
 
       const CompConst k = cc[comp];
       const int64_t gi = (int64_t)comp * C + cl;
-      if (k.type == kTypeBinary) {
+      if (BinaryOf<Model>::value && k.type == kTypeBinary) {   // compiled in only for models that may have binary parameters
         // ---- BinaryStepper.step (mcmc.js:753-767): both states evaluated, 0 chosen with
         // probability exp(z - log(exp(z) + exp(o))) after subtracting the larger log density
         const double old = S(comp);

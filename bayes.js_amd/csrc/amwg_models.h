@@ -50,6 +50,7 @@ struct NormalModel {
   static constexpr bool kSplitPrior = false;
   static constexpr bool kUser = false, kHasFast = true, kOneLanePass = false;
   static constexpr int kDerived = 0;
+  static constexpr bool kHasBinary = false;   // real / int parameters only: the BinaryStepper branch is not compiled in
   static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
   static constexpr int kUnroll = 8;   // independent terms in flight per lane (ILP across the division chains)
   struct Pass { double mu, c, den; Reciprocal y; bool fast; const double *x; };
@@ -106,6 +107,7 @@ struct BetaBernModel {
   static constexpr bool kSplitPrior = false;
   static constexpr bool kUser = false, kHasFast = false, kOneLanePass = true;
   static constexpr int kDerived = 0;
+  static constexpr bool kHasBinary = false;   // real / int parameters only: the BinaryStepper branch is not compiled in
   static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
   static constexpr int kUnroll = 8;
   struct Pass { double l1, l0; const uint8_t *x; const uint32_t *bits; bool has_invalid, fast_forward; BitData B; };
@@ -270,6 +272,7 @@ struct BetaBernModel {
 struct HierNormalModel {
   static constexpr bool kUser = false, kHasFast = true, kOneLanePass = false;
   static constexpr int kDerived = 0;
+  static constexpr bool kHasBinary = false;   // real / int parameters only: the BinaryStepper branch is not compiled in
   static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
   static constexpr int kUnroll = 8;
   struct Pass { double c, den; Reciprocal y; bool fast, lane_const; const double *x; const uint8_t *g; StateView S; };
@@ -358,6 +361,7 @@ struct HierNormalModel {
 struct PoisGlmModel {
   static constexpr bool kUser = false, kHasFast = false, kOneLanePass = false;
   static constexpr int kDerived = 0;
+  static constexpr bool kHasBinary = false;   // real / int parameters only: the BinaryStepper branch is not compiled in
   static constexpr int kMaxThreads = 256;    // exp+log per observation want > 128 VGPRs; no LDS tile to share anyway
   static constexpr int kUnroll = 2;   // exp+log per term: more would spill
   // col[k]: column k of the design matrix, then y and lfactorial(y) -- nine wave-uniform base pointers (scalar registers); an

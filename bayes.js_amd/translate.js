@@ -130,6 +130,9 @@ function Translator(fn, params, data, opts, isHelper) {
     base += len;
   }
   this.P = base;
+  // binary parameters need the BinaryStepper branch of the step kernel (two more inlined log_post evaluations per slot); a stand-alone
+  // stepper's parameter list may not carry the types of everything it steps, so it always keeps the branch
+  this.hasBinary = !!this.opts.state_object || Object.keys(params).some((n) => params[n].type === 'binary');
   this.arrays = [];          // {key, flat: Float64Array, dims}
   this.arrayIds = new Map();
   this.derived = [];         // names, in order of first assignment
@@ -1593,6 +1596,7 @@ Translator.prototype.run = function () {
   for (const h of this.helperSources) src.push(h);
   src.push('struct UserModel {');
   src.push('  static constexpr bool kUser = true, kHasFast = false, kOneLanePass = false;');
+  src.push('  static constexpr bool kHasBinary = ' + (this.hasBinary ? 'true' : 'false') + ';   // BinaryStepper branch of the step kernel');
   src.push('  static constexpr int kDerived = ' + D + ';');
   src.push('  static constexpr int kMaxThreads = ' + maxThreads + ';');
   src.push('#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)');
