@@ -362,7 +362,7 @@ struct PoisGlmModel {
   static constexpr bool kUser = false, kHasFast = false, kOneLanePass = false;
   static constexpr int kDerived = 0;
   static constexpr bool kHasBinary = false;   // real / int parameters only: the BinaryStepper branch is not compiled in
-  static constexpr int kMaxThreads = 256;    // exp+log per observation want > 128 VGPRs; no LDS tile to share anyway
+  static constexpr int kMaxThreads = 256;    // exp+log per observation want > 128 VGPRs (capped at 128 -- 4 waves per SIMD -- the kernel is 30 % slower: measured, round 2); no LDS tile to share anyway
   static constexpr int kUnroll = 2;   // exp+log per term: more would spill
   // col[k]: column k of the design matrix, then y and lfactorial(y) -- nine wave-uniform base pointers (scalar registers); an
   // observation is addressed by ONE 32-bit byte offset per lane (global_load ... vOffset, sBase) instead of nine 64-bit adds

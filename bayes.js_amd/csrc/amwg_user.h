@@ -77,6 +77,49 @@ AMWG_HD double norm_data_loop(const double *x_staged, const double *x_global, in
   return acc;
 }
 
+// The same for a GATHERED mean -- `for (i...) lp += ld.norm(y[i], state.theta[g[i]], sd)`, the likelihood loop of a model with group
+// means (random effects): g a data array of small integers (stored as bytes), theta a parameter vector at state offset `base` with
+// `n_groups` entries that g can reach.  PERIODIC (worked out by the translator for this lane count): g[i] == g[i % G] for every i, so a
+// lane meets ONE group and reads its mean once (constant-mean pass); otherwise the pass that reads the indices two blocks and the means
+// one block ahead.  Fast form only while every reachable mean is inside the range amwg_div.h needs (agreed on by a ballot of the chain's
+// lanes); IEEE '/' otherwise.  Same operations in the same order as the closure's loop.
+template <int G, bool PERIODIC>
+AMWG_HD double norm_data_loop_gather(const double *x, const uint8_t *g, const StateView &S, int base, int n_groups, int n, const NormInv &k,
+                                     bool data_mid_range, int sub, double acc) {
+  bool ok = k.fast && data_mid_range;
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    constexpr int L = G < 64 ? G : 64;
+    const int lane = (int)(threadIdx.x & 63u);
+    bool mine = true;
+    for (int j = lane & (L - 1); j < n_groups; j += L) { const double th = S(base + j); mine = mine && (th == 0 || mid_range(__builtin_fabs(th))); }
+    if constexpr (L == 1) ok = ok && mine;
+    else {
+      const uint64_t all = __ballot(mine);
+      const uint64_t group = (L == 64 ? ~0ull : ((1ull << (L & 63)) - 1ull)) << (lane & ~(L - 1));
+      ok = ok && ((all & group) == group);
+    }
+  }
+  if (ok) {
+    const StateView T{S.base + base};
+    if constexpr (PERIODIC) {
+      const double m = sub < n ? T(g[sub]) : 0.0;
+      return norm_pass_staged<G, 8, false>(x, nullptr, T, m, k.c, k.den, k.y, n, sub, acc);
+    } else {
+      return norm_pass_staged<G, 4, true>(x, g, T, 0.0, k.c, k.den, k.y, n, sub, acc);
+    }
+  }
+#else
+  for (int j = 0; j < n_groups; ++j) { const double th = S(base + j); ok = ok && (th == 0 || mid_range(__builtin_fabs(th))); }
+  if (ok) {
+    for (int i = sub; i < n; i += G) { const double t = x[i] - S(base + g[i]); acc += k.c - div_by_invariant(t * t, k.den, k.y); }
+    return acc;
+  }
+#endif
+  for (int i = sub; i < n; i += G) { const double t = x[i] - S(base + g[i]); acc += k.c - (t * t) / k.den; }
+  return acc;
+}
+
 // ld.bern(x, p) for a loop in which p does not change (distributions.js:228-230): the two values
 // log(1*p + 0*(1-p)) and log(0*p + 1*(1-p)) the expression can take, selected per observation.
 struct BernInv { double l1, l0; };

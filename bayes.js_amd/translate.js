@@ -1275,6 +1275,25 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
         out.push(indent + '}');
         return;
       }
+      // ... and with a GATHERED mean, `lp += ld.norm(y[i], state.theta[g[i]], sd)`: g a byte-typed data array whose values index a
+      // parameter vector (provably in range: no guard in the generated read).  norm_data_loop_gather (amwg_user.h) runs the staged pass;
+      // for lane counts at which the labels repeat with the lane stride (g[i] == g[i % G]) a lane reads its one mean once.
+      const mg = simple && pend.length === 0 && /^NORMCALL\(A(\d+)\[v_(\w+)\], S\((?:(\d+) \+ )?\(int\)A(\d+)\[v_(\w+)\]\), (k\d+) RANGEARGS\)$/.exec(term.code);
+      if (mg && mg[2] === canon.name && mg[5] === canon.name && startV.cst === 0 && !canon.le && this.arrays[Number(mg[1])].ctype === 'double' &&
+          this.arrays[Number(mg[4])].ctype === 'uint8_t' && boundV.cst === this.arrays[Number(mg[1])].flat.length &&
+          boundV.cst <= this.arrays[Number(mg[4])].flat.length && !this.opts.no_staged_norm) {
+        const arr = this.arrays[Number(mg[1])], gl = this.arrays[Number(mg[4])].flat, n = boundV.cst;
+        let mid = true, ng = 0, mask = 0;
+        for (let i = 0; i < n && mid; i++) { const v = Math.abs(arr.flat[i]); mid = v === 0 || (v >= Math.pow(2, -200) && v <= Math.pow(2, 200)); }
+        for (let i = 0; i < n; i++) ng = Math.max(ng, gl[i] + 1);
+        for (let j = 0; j <= 10; j++) { const Gj = 1 << j; let per = n > 0; for (let i = Gj; i < n && per; i++) per = gl[i] === gl[i % Gj]; if (per) mask |= 1 << j; }
+        out.push(indent + '{');
+        for (const ln of renderNorm(L.preamble.map((q) => '  ' + q), 'inv')) out.push(indent + ln);
+        out.push(indent + '  ' + acc + ' = norm_data_loop_gather<G, ((' + mask + 'u >> __builtin_ctz((unsigned)G)) & 1u) != 0u>(A' + mg[1] + ', A' + mg[4] + ', S, ' + (mg[3] || '0') + ', ' + ng + ', ' + n + ', ' + mg[6] + ', ' + (mid ? 'true' : 'false') + ', sub, ' + acc + ');');
+        out.push(indent + '}');
+        this.otherSplitLoops = (this.otherSplitLoops || 0) + 1;      // (one lane per chain gains nothing here: the data stays in LDS)
+        return;
+      }
       this.otherSplitLoops = (this.otherSplitLoops || 0) + 1;
       this.emitSplit(out, indent, L.preamble, head, loop, [loopAcc]);
       return;
