@@ -80,8 +80,9 @@ AMWG_HD void norm_block_stages(NormBlock<U> &b, const double (&m)[U], NormBlock<
 
 // x: LDS (or global) array of the observations; lane `sub` of the chain's G lanes takes observations sub, sub + G, ...
 // MeanOf::gather == false: constant mean;  true: index array g (u8) and the chain's state S, mean of observation i = S(g[i])
-template <int G, int U, bool GATHER>
-AMWG_HD double norm_pass_staged(const double *x, const uint8_t *g, const StateView S, double mean, double c, double den,
+// XT: storage type of the observations (double, or the u8 / i32 the translator picks for all-integer data arrays: exact conversions)
+template <int G, int U, bool GATHER, class XT = double>
+AMWG_HD double norm_pass_staged(const XT *x, const uint8_t *g, const StateView S, double mean, double c, double den,
                                                    Reciprocal y, int n_obs, int sub, double acc) {
   const int n_full = n_obs / G, rem = n_obs % G;
   const int n_blocks = n_full / U;
@@ -90,7 +91,7 @@ AMWG_HD double norm_pass_staged(const double *x, const uint8_t *g, const StateVi
     NormBlock<U> xa, xb, qa, qb;
     double ma[U], mb[U];
     int ga[U], gb[U];     // GATHER: group indices, read one block further ahead than the values
-    const double *px = x + sub;
+    const XT *px = x + sub;
     const uint8_t *pg = g + sub;
     // (index prefetches past the end re-read the last block: harmless, and the loop body stays ONE basic block -- a conditional
     // load splits it, the stage fences stop holding across the pieces and the register sets get copied instead of swapped)
@@ -103,7 +104,7 @@ AMWG_HD double norm_pass_staged(const double *x, const uint8_t *g, const StateVi
     };
     auto load_val = [&](int blk, NormBlock<U> &xv, double (&mv)[U], const int (&gi)[U]) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) xv.v[u] = px[(blk * U + u) * G];
+      for (int u = 0; u < U; ++u) xv.v[u] = (double)px[(blk * U + u) * G];
 #pragma unroll
       for (int u = 0; u < U; ++u) mv[u] = GATHER ? S(gi[u]) : mean;
     };
@@ -123,12 +124,12 @@ AMWG_HD double norm_pass_staged(const double *x, const uint8_t *g, const StateVi
       load_val(blk + 1, xa, ma, ga);
       load_idx(blk + 2, gb);
       AMWG_STAGE_FENCE();
-      if constexpr (!GATHER && U == 8) { AMWG_WAIT_LDS_LE(4); AMWG_STAGE_FENCE(); }
+      if constexpr (!GATHER && U == 8 && sizeof(XT) == 8) { AMWG_WAIT_LDS_LE(4); AMWG_STAGE_FENCE(); }
       norm_block_stages<U, true>(xb, mb, qb, qa, acc, c, den, y);
       load_val(blk + 2, xb, mb, gb);
       load_idx(blk + 3, ga);
       AMWG_STAGE_FENCE();
-      if constexpr (!GATHER && U == 8) { AMWG_WAIT_LDS_LE(4); AMWG_STAGE_FENCE(); }
+      if constexpr (!GATHER && U == 8 && sizeof(XT) == 8) { AMWG_WAIT_LDS_LE(4); AMWG_STAGE_FENCE(); }
       norm_block_stages<U, true>(xa, ma, qa, qb, acc, c, den, y);
     }
     // epilogue: one or two blocks left (blk, and maybe blk + 1), terms of blk-1 pending in qa
@@ -153,12 +154,12 @@ AMWG_HD double norm_pass_staged(const double *x, const uint8_t *g, const StateVi
   // ragged tail: fewer than U rounds, then the lanes below n_obs % G take one more observation
   for (; k < n_full; ++k) {
     const int i = k * G + sub;
-    const double t = x[i] - (GATHER ? S(g[i]) : mean);
+    const double t = (double)x[i] - (GATHER ? S(g[i]) : mean);
     acc += c - div_by_invariant(t * t, den, y);
   }
   if (sub < rem) {
     const int i = n_full * G + sub;
-    const double t = x[i] - (GATHER ? S(g[i]) : mean);
+    const double t = (double)x[i] - (GATHER ? S(g[i]) : mean);
     acc += c - div_by_invariant(t * t, den, y);
   }
   return acc;

@@ -61,19 +61,22 @@ AMWG_HD bool norm_range_ok(uint32_t rlo, uint32_t rhi) { return rlo >= 0x1A70000
 // the array in global memory (x_global: the observations are wave-uniform).  Same operations in the same order as the closure's own loop
 // (t = x - mean; t*t / (2*sd*sd); c - q; lp += term), the quotient by the 4-operation form of amwg_div.h when its range preconditions hold
 // (divisor, mean and -- checked by the translator on the host -- every data value inside 2^-200..2^200 or zero) and by IEEE '/' otherwise.
-template <int G>
-AMWG_HD double norm_data_loop(const double *x_staged, const double *x_global, int n, double mean, const NormInv &k, bool data_mid_range, int sub, double acc) {
+template <class T, class U> struct SameType { static constexpr bool value = false; };
+template <class T> struct SameType<T, T> { static constexpr bool value = true; };
+// XT = double, or the u8 / i32 storage the translator picks for all-integer data (conversions are exact; the scalar-load pass is for doubles)
+template <int G, class XT>
+AMWG_HD double norm_data_loop(const XT *x_staged, const XT *x_global, int n, double mean, const NormInv &k, bool data_mid_range, int sub, double acc) {
   if (k.fast && data_mid_range && (mean == 0 || mid_range(__builtin_fabs(mean)))) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (G == 1) return norm_pass_uniform<8>(x_global, mean, k.c, k.den, k.y, n, acc);
-    else return norm_pass_staged<G, 8, false>(x_staged, nullptr, StateView{nullptr}, mean, k.c, k.den, k.y, n, sub, acc);
+    if constexpr (G == 1 && SameType<XT, double>::value) return norm_pass_uniform<8>(x_global, mean, k.c, k.den, k.y, n, acc);
+    else return norm_pass_staged<G, 8, false, XT>(x_staged, nullptr, StateView{nullptr}, mean, k.c, k.den, k.y, n, sub, acc);
 #else
-    for (int i = sub; i < n; i += G) { const double t = x_global[i] - mean; acc += k.c - div_by_invariant(t * t, k.den, k.y); }
+    for (int i = sub; i < n; i += G) { const double t = (double)x_global[i] - mean; acc += k.c - div_by_invariant(t * t, k.den, k.y); }
     return acc;
 #endif
   }
-  const double *x = (G == 1) ? x_global : x_staged;
-  for (int i = sub; i < n; i += G) { const double t = x[i] - mean; acc += k.c - (t * t) / k.den; }
+  const XT *x = (G == 1 && SameType<XT, double>::value) ? x_global : x_staged;
+  for (int i = sub; i < n; i += G) { const double t = (double)x[i] - mean; acc += k.c - (t * t) / k.den; }
   return acc;
 }
 
@@ -83,8 +86,8 @@ AMWG_HD double norm_data_loop(const double *x_staged, const double *x_global, in
 // lane meets ONE group and reads its mean once (constant-mean pass); otherwise the pass that reads the indices two blocks and the means
 // one block ahead.  Fast form only while every reachable mean is inside the range amwg_div.h needs (agreed on by a ballot of the chain's
 // lanes); IEEE '/' otherwise.  Same operations in the same order as the closure's loop.
-template <int G, bool PERIODIC>
-AMWG_HD double norm_data_loop_gather(const double *x, const uint8_t *g, const StateView &S, int base, int n_groups, int n, const NormInv &k,
+template <int G, bool PERIODIC, class XT>
+AMWG_HD double norm_data_loop_gather(const XT *x, const uint8_t *g, const StateView &S, int base, int n_groups, int n, const NormInv &k,
                                      bool data_mid_range, int sub, double acc) {
   bool ok = k.fast && data_mid_range;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -104,19 +107,19 @@ AMWG_HD double norm_data_loop_gather(const double *x, const uint8_t *g, const St
     const StateView T{S.base + base};
     if constexpr (PERIODIC) {
       const double m = sub < n ? T(g[sub]) : 0.0;
-      return norm_pass_staged<G, 8, false>(x, nullptr, T, m, k.c, k.den, k.y, n, sub, acc);
+      return norm_pass_staged<G, 8, false, XT>(x, nullptr, T, m, k.c, k.den, k.y, n, sub, acc);
     } else {
-      return norm_pass_staged<G, 4, true>(x, g, T, 0.0, k.c, k.den, k.y, n, sub, acc);
+      return norm_pass_staged<G, 4, true, XT>(x, g, T, 0.0, k.c, k.den, k.y, n, sub, acc);
     }
   }
 #else
   for (int j = 0; j < n_groups; ++j) { const double th = S(base + j); ok = ok && (th == 0 || mid_range(__builtin_fabs(th))); }
   if (ok) {
-    for (int i = sub; i < n; i += G) { const double t = x[i] - S(base + g[i]); acc += k.c - div_by_invariant(t * t, k.den, k.y); }
+    for (int i = sub; i < n; i += G) { const double t = (double)x[i] - S(base + g[i]); acc += k.c - div_by_invariant(t * t, k.den, k.y); }
     return acc;
   }
 #endif
-  for (int i = sub; i < n; i += G) { const double t = x[i] - S(base + g[i]); acc += k.c - (t * t) / k.den; }
+  for (int i = sub; i < n; i += G) { const double t = (double)x[i] - S(base + g[i]); acc += k.c - (t * t) / k.den; }
   return acc;
 }
 

@@ -1262,24 +1262,25 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
       // `for (i = 0; i < x.length; i++) lp += ld.norm(x[i], mean, sd)` over a whole f64 data array, mean and sd loop-invariant: the
       // hand-scheduled pass the built-in Normal family runs (csrc/amwg_pass.h via norm_data_loop, amwg_user.h) -- staged LDS reads
       // with G lanes, scalar loads with one lane per chain; same operations in the same order as the generic loop below
-      const mn = simple && pend.length === 0 && /^NORMCALL\(A(\d+)\[v_(\w+)\], (.+), (k\d+) RANGEARGS\)$/.exec(term.code);
-      if (mn && mn[2] === canon.name && startV.cst === 0 && !canon.le && this.arrays[Number(mn[1])].ctype === 'double' &&
+      const mn = simple && pend.length === 0 && /^NORMCALL\((?:\(double\))?A(\d+)\[v_(\w+)\], (.+), (k\d+) RANGEARGS\)$/.exec(term.code);
+      if (mn && mn[2] === canon.name && startV.cst === 0 && !canon.le &&
           boundV.cst === this.arrays[Number(mn[1])].flat.length && mn[3].indexOf('v_' + canon.name) < 0 && mn[3].indexOf('NORMCALL') < 0 && !this.opts.no_staged_norm) {
         const arr = this.arrays[Number(mn[1])];
         let mid = true;
         for (let i = 0; i < arr.flat.length && mid; i++) { const v = Math.abs(arr.flat[i]); mid = v === 0 || (v >= Math.pow(2, -200) && v <= Math.pow(2, 200)); }
-        this.uniformNormLoops = (this.uniformNormLoops || 0) + 1;
+        if (arr.ctype === 'double') this.uniformNormLoops = (this.uniformNormLoops || 0) + 1;      // scalar-load pass with one lane per chain
+        else this.otherSplitLoops = (this.otherSplitLoops || 0) + 1;
         out.push(indent + '{');
         for (const ln of renderNorm(L.preamble.map((q) => '  ' + q), 'inv')) out.push(indent + ln);
-        out.push(indent + '  ' + acc + ' = norm_data_loop<G>(A' + mn[1] + ', static_cast<const double *>(user_arr<' + mn[1] + '>(d)), ' + boundV.cst + ', ' + mn[3] + ', ' + mn[4] + ', ' + (mid ? 'true' : 'false') + ', sub, ' + acc + ');');
+        out.push(indent + '  ' + acc + ' = norm_data_loop<G>(A' + mn[1] + ', static_cast<const ' + arr.ctype + ' *>(user_arr<' + mn[1] + '>(d)), ' + boundV.cst + ', ' + mn[3] + ', ' + mn[4] + ', ' + (mid ? 'true' : 'false') + ', sub, ' + acc + ');');
         out.push(indent + '}');
         return;
       }
       // ... and with a GATHERED mean, `lp += ld.norm(y[i], state.theta[g[i]], sd)`: g a byte-typed data array whose values index a
       // parameter vector (provably in range: no guard in the generated read).  norm_data_loop_gather (amwg_user.h) runs the staged pass;
       // for lane counts at which the labels repeat with the lane stride (g[i] == g[i % G]) a lane reads its one mean once.
-      const mg = simple && pend.length === 0 && /^NORMCALL\(A(\d+)\[v_(\w+)\], S\((?:(\d+) \+ )?\(int\)A(\d+)\[v_(\w+)\]\), (k\d+) RANGEARGS\)$/.exec(term.code);
-      if (mg && mg[2] === canon.name && mg[5] === canon.name && startV.cst === 0 && !canon.le && this.arrays[Number(mg[1])].ctype === 'double' &&
+      const mg = simple && pend.length === 0 && /^NORMCALL\((?:\(double\))?A(\d+)\[v_(\w+)\], S\((?:(\d+) \+ )?\(int\)A(\d+)\[v_(\w+)\]\), (k\d+) RANGEARGS\)$/.exec(term.code);
+      if (mg && mg[2] === canon.name && mg[5] === canon.name && startV.cst === 0 && !canon.le &&
           this.arrays[Number(mg[4])].ctype === 'uint8_t' && boundV.cst === this.arrays[Number(mg[1])].flat.length &&
           boundV.cst <= this.arrays[Number(mg[4])].flat.length && !this.opts.no_staged_norm) {
         const arr = this.arrays[Number(mg[1])], gl = this.arrays[Number(mg[4])].flat, n = boundV.cst;

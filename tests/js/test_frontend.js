@@ -176,7 +176,11 @@ assert.throws(() => new mcmc.AmwgSampler({ mu: { type: 'complex', init: 1 }, sig
   const tr = mcmc.translate(readme_normal, mcmc.complete_params(params, mcmc.param_init_fixed), data10, {});
   assert.strictEqual(tr.parallel, 1);
   assert.strictEqual(tr.lds_bytes, 16);            // ten integer heights: stored as u8
-  assert.ok(/norm_inv\(S\(1\)\)/.test(tr.source) && /ld_norm_fast\(\(double\)A0\[v_i\], S\(0\), k0, rlo_, rhi_\)/.test(tr.source) && /ld_norm_slow/.test(tr.source));
+  // the canonical likelihood loop compiles to the hand-scheduled pass (csrc/amwg_pass.h via norm_data_loop) with the hoisted sd-invariants
+  assert.ok(/norm_inv\(S\(1\)\)/.test(tr.source) && /norm_data_loop<G>\(A0, static_cast<const uint8_t \*>\(user_arr<0>\(d\)\), 10, S\(0\), k0, true, sub, v_log_post\)/.test(tr.source));
+  // ... unless asked not to: then the generic lane-split loop with its fast / IEEE pair
+  const trg2 = mcmc.translate(readme_normal, mcmc.complete_params(params, mcmc.param_init_fixed), data10, { no_staged_norm: true });
+  assert.ok(/ld_norm_fast\(\(double\)A0\[v_i\], S\(0\), k0, rlo_, rhi_\)/.test(trg2.source) && /ld_norm_slow/.test(trg2.source));
   // every host-side ld.* equals the reference's value on the committed argument sets (tests/golden/ld_values.bin)
   const b = fs.readFileSync(path.join(__dirname, '..', 'golden', 'ld_values.bin'));
   const fnames = ['norm', 'unif', 'beta', 'bern', 'pois', 'cauchy', 'laplace', 'gamma', 'invgamma', 'lnorm', 'pareto', 't', 'weibull', 'logis', 'exp', 'binom', 'nbinom', 'hyper', 'lgamma', 'lfactorial', 'lchoose', 'lbeta'];
