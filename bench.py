@@ -104,8 +104,8 @@ def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None):
         if lanes is not None and (", %d>" % lanes) not in p.get("kernel", ""):      # the profile must be of the same kernel instantiation
             continue
         if p.get("chains") == chains and p.get("steps_per_launch") == steps_per_launch and p.get("hbm_traffic_bytes_per_launch"):
-            return p["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
-    return None, None
+            return p["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT), p.get("algorithmic_bytes_per_launch")
+    return None, None, None
 
 
 def cpu_baseline_reference(workload):
@@ -342,7 +342,7 @@ def main():
         assert dist is not None or np.allclose(pm, mean, rtol=1e-10, atol=0), "library moments differ from the pooled restatement"
         measured_peak = A.fp64_peak(dev_index)      # register-only fma kernel: what the chip sustains under fp64 load
         x = spec["data"]["x"]
-        traffic, traffic_src = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"])
+        traffic, traffic_src, traffic_alg = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"])
         kname = {"normal": "NormalModel", "beta_bern": "BetaBernModel", "hier_normal": "HierNormalModel", "pois_glm": "PoisGlmModel"}[spec["model"]]
         kernel = "amwg_step_kernel<%s,%d>" % (kname, li["lanes_per_chain"])
         roof_launch_s, roof_updates, roof_note = launch_s, updates_per_launch, None
@@ -381,7 +381,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 --pmc passes",
                          "algorithmic_bytes_per_launch": updates_per_launch * b_alg, "algorithmic_bytes_per_update": b_alg,
-                         "traffic_ratio": (traffic / (updates_per_launch * b_alg)) if traffic else None,
+                         "traffic_ratio": (traffic / traffic_alg) if (traffic and traffic_alg) else None,
+                         "traffic_note": "traffic and traffic_ratio are per launch of the PROFILED command (%d steps per launch, profiles/): measured HBM bytes / algorithmic bytes of that launch" % args.steps_per_launch,
                          "effective_hbm": {"achieved": eff_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": eff_gbps / HBM_PEAK_GBPS, "lds_resident": True,
                                            "note": "SURVEY.md section 8(d) contract figure: algorithmic bytes (one pass over the data per update) / launch time.  "
                                                    "The data vector is staged once per launch into LDS (L2/MALL for cfg5) and re-read from there, so this is an "
