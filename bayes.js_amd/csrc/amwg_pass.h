@@ -151,16 +151,27 @@ AMWG_HD double norm_pass_staged(const XT *x, const uint8_t *g, const StateView S
     }
     k = n_blocks * U;
   }
-  // ragged tail: fewer than U rounds, then the lanes below n_obs % G take one more observation
-  for (; k < n_full; ++k) {
-    const int i = k * G + sub;
-    const double t = (double)x[i] - (GATHER ? S(g[i]) : mean);
-    acc += c - div_by_invariant(t * t, den, y);
-  }
-  if (sub < rem) {
-    const int i = n_full * G + sub;
-    const double t = (double)x[i] - (GATHER ? S(g[i]) : mean);
-    acc += c - div_by_invariant(t * t, den, y);
+  // ragged tail: fewer than U whole rounds are left, and the lanes below n_obs % G take one more observation.  ONE masked block instead
+  // of a loop of dependent single terms (with a handful of chains and short data loops that loop was a fifth of an update): every lane
+  // runs the eight stages on U slots, slots beyond its own count re-read its last valid observation, and only the first cnt terms are
+  // added -- in the same order as before (whole rounds first, the remainder observation last).
+  const int left = n_full - k;                              // 0 .. U-1, uniform
+  if (left > 0 || rem > 0) {
+    const int cnt = left + (sub < rem ? 1 : 0);             // this lane's terms: 0 .. U
+    NormBlock<U> xt, qt;
+    double mt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int r = u < cnt ? u : (cnt > 0 ? cnt - 1 : 0);
+      int i = (k + r) * G + sub;
+      i = i < n_obs ? i : n_obs - 1;                        // (a lane without any term: any valid address)
+      xt.v[u] = (double)x[i];
+      mt[u] = GATHER ? S(g[i]) : mean;
+    }
+    AMWG_STAGE_FENCE();
+    norm_block_stages<U, false>(xt, mt, qt, qt, acc, c, den, y);
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = u < cnt ? acc + qt.v[u] : acc;
   }
   return acc;
 }
