@@ -45,7 +45,7 @@ class UserModel(C.Structure):
                 ("parallel", C.c_int32), ("max_threads", C.c_int32), ("work_per_eval", C.c_double), ("work_one_lane", C.c_double)]
 
 
-EXPORTS = ["amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_math1", "amwg_math2", "amwg_hypot3", "amwg_log1p", "amwg_expm1", "amwg_two_valued_sum_check", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
+EXPORTS = ["amwg_tuning", "amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_math1", "amwg_math2", "amwg_hypot3", "amwg_log1p", "amwg_expm1", "amwg_two_valued_sum_check", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
            "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components",
            "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp",
            "amwg_log", "amwg_uniform", "amwg_device_eval"]
@@ -297,6 +297,14 @@ class Sampler:
         out = np.empty((self.PR, pr.size))
         _check(lib().amwg_last_sample_quantiles(self.h, _dp(pr), pr.size, _dp(out)))
         return out
+
+    def tuning(self):
+        """AMWG_LANES_AUTOTUNE (lanes_per_chain=-2): [(lanes per chain, ms of the timing run)] of every candidate timed at construction"""
+        L = lib()
+        L.amwg_tuning.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int32]
+        lanes, ms = (C.c_int32 * 16)(), (C.c_double * 16)()
+        n = L.amwg_tuning(self.h, lanes, ms, 16)
+        return [(lanes[i], ms[i]) for i in range(min(n, 16))]
 
     def launch_info(self):
         v = [C.c_int32() for _ in range(5)]

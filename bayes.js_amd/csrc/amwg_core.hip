@@ -164,7 +164,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   int bestG = 0, bestB = 0, bestCpb = 0;
   double bestOcc = -1.0, cost1 = -1.0;
   int block1 = 0, cpb1 = 0;
-  const bool fixed_lanes = o.lanes_per_chain > 0;
+  const bool fixed_lanes = o.lanes_per_chain > 0;      // (autotune_geometry calls this once per lane count, each time as a fixed one)
   for (int G = 1; G <= 1024; G <<= 1) {
     if (fixed_lanes && G != o.lanes_per_chain) continue;
     if (s->user && !s->user_parallel && G > 1) break;   // nothing to split: one lane per chain
@@ -438,8 +438,8 @@ __global__ void two_valued_check_kernel(const uint32_t *tab, int N, int64_t m, c
 static int check_options(const amwg_options *options, int max_threads) {
   if (options->chains < 1) return fail(AMWG_EINVAL, "amwg_create: chains must be >= 1");
   const int G_opt = options->lanes_per_chain;
-  if (G_opt && G_opt != AMWG_LANES_FASTEST && (G_opt < 1 || G_opt > 1024 || (G_opt & (G_opt - 1))))
-    return fail(AMWG_EINVAL, "lanes_per_chain must be a power of two in 1..1024 (or 0 = auto, AMWG_LANES_FASTEST = -1)");
+  if (G_opt && G_opt != AMWG_LANES_FASTEST && G_opt != AMWG_LANES_AUTOTUNE && (G_opt < 1 || G_opt > 1024 || (G_opt & (G_opt - 1))))
+    return fail(AMWG_EINVAL, "lanes_per_chain must be a power of two in 1..1024 (or 0 = auto, AMWG_LANES_FASTEST = -1, AMWG_LANES_AUTOTUNE = -2)");
   if (G_opt > 64 && options->block_threads && options->block_threads != G_opt)
     return fail(AMWG_EINVAL, "a chain on %d lanes is one workgroup of %d threads: block_threads must be 0 or %d", G_opt, G_opt, G_opt);
   if (G_opt > max_threads) return fail(AMWG_EINVAL, "lanes_per_chain %d exceeds this model's workgroup limit %d", G_opt, max_threads);
@@ -615,6 +615,70 @@ static int compile_user(const char *source, int lanes, int block, const char *ar
   return AMWG_OK;
 }
 
+// ---- AMWG_LANES_AUTOTUNE: measure instead of model.  Every lane count whose geometry fits is prepared (`prepare`: kernel lookup or
+// hiprtc compile + load, plus whatever depends on the lane count), run for a few steps on the real chain state -- which is saved
+// before and restored after, so tuning leaves no trace in the chains -- and timed with HIP events.  The fastest wins, except that one
+// lane per chain (the reference's summation order) is kept whenever it MEASURES within 12 % of the fastest.
+struct TuneCandidate { int lanes, block, grid, lds, cpb; step_kernel_t kernel; hipModule_t module; hipFunction_t fn; float ms; };
+
+template <class Prepare>
+static int autotune_geometry(amwg_sampler *s, int n_cus, size_t max_lds, Prepare prepare) {
+  // the chain state the timing runs touch
+  const size_t PC = (size_t)s->P * (size_t)s->C, C = (size_t)s->C;
+  std::vector<std::pair<void *, size_t>> parts = {
+      {s->ch.state, PC * 8}, {s->ch.prop_log_scale, PC * 8}, {s->ch.acceptance_count, PC * 4}, {s->ch.iterations_since_adaption, PC * 4},
+      {s->ch.batch_count, PC * 4}, {s->ch.accepts, PC * 4}, {s->ch.inbounds, PC * 4}, {s->ch.perm, C * 8}, {s->ch.rng_n, C * 8}, {s->ch.lp_curr, C * 8}};
+  if (s->ch.perm16) parts.push_back({s->ch.perm16, (size_t)s->n_params * C * 2});
+  size_t total = 0;
+  for (auto &p : parts) total += (p.second + 255) & ~(size_t)255;
+  DevBuf save;
+  HIP_TRY(save.alloc(total));
+  auto copy_all = [&](bool restore) -> hipError_t {
+    size_t off = 0;
+    for (auto &p : parts) {
+      char *sv = save.as<char>() + off;
+      hipError_t e = restore ? hipMemcpyAsync(p.first, sv, p.second, hipMemcpyDeviceToDevice, s->stream) : hipMemcpyAsync(sv, p.first, p.second, hipMemcpyDeviceToDevice, s->stream);
+      if (e != hipSuccess) return e;
+      off += (p.second + 255) & ~(size_t)255;
+    }
+    return hipStreamSynchronize(s->stream);
+  };
+  HIP_TRY(copy_all(false));
+  const int32_t wanted = s->opt.lanes_per_chain;
+  std::vector<TuneCandidate> cand;
+  std::string first_error;
+  for (int G = 1; G <= 1024; G <<= 1) {
+    s->opt.lanes_per_chain = G;
+    if (choose_geometry(s, n_cus, max_lds) != AMWG_OK || prepare() != AMWG_OK) { if (first_error.empty()) first_error = g_err; continue; }
+    TuneCandidate c{s->lanes, s->block, s->grid, s->lds, s->cpb, s->kernel, s->user_module, s->user_fn, 0.f};
+    bool ok = true;
+    for (int rep = 0; rep < 2 && ok; ++rep) {          // the first run also evaluates log_post(init) and warms the caches
+      s->lp_ready = false;
+      ok = launch_steps(s, 3, 1, nullptr) == AMWG_OK && finish_timing(s) == AMWG_OK;
+      c.ms = (float)s->kernel_ms;
+      if (copy_all(true) != hipSuccess) ok = false;
+    }
+    s->lp_ready = false;
+    if (ok) cand.push_back(c);
+    else if (c.module) { (void)hipModuleUnload(c.module); }
+    s->user_module = nullptr;
+    s->user_fn = nullptr;
+  }
+  s->opt.lanes_per_chain = wanted;
+  if (cand.empty()) return fail(AMWG_EINVAL, "autotune: no lane count could be run (%s)", first_error.c_str());
+  size_t best = 0;
+  for (size_t i = 1; i < cand.size(); ++i) if (cand[i].ms < cand[best].ms) best = i;
+  if (cand[0].lanes == 1 && cand[0].ms <= 1.12f * cand[best].ms) best = 0;      // reference order first
+  for (size_t i = 0; i < cand.size(); ++i) if (i != best && cand[i].module) (void)hipModuleUnload(cand[i].module);
+  const TuneCandidate &c = cand[best];
+  s->lanes = c.lanes; s->block = c.block; s->grid = c.grid; s->lds = c.lds; s->cpb = c.cpb; s->kernel = c.kernel; s->user_module = c.module; s->user_fn = c.fn;
+  s->tuned.clear();
+  for (auto &q : cand) s->tuned.push_back({q.lanes, q.ms});
+  s->n_launches = 0;
+  s->kernel_ms = 0;
+  return AMWG_OK;
+}
+
 extern "C" {
 
 int amwg_compile_user(const char *source, int32_t lanes_per_chain, int32_t block_threads, const char *arch, size_t *code_bytes) {
@@ -771,13 +835,19 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   // ---- geometry.  The constructor's warm-up log_post (mcmc.js:961-963) is folded into the first
   // launch (StepArgs.init_lp); amwg_chain_diag forces it with a 0-step launch if asked earlier.
   const size_t max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
-  TRYB(choose_geometry(s, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, max_lds));
-  if (m->model == AMWG_MODEL_HIER_NORMAL && !options->exact_division) {   // do the group labels repeat with the lane stride? (HierNormalModel::pass_fast)
-    bool periodic = N > 0;
-    for (int i = s->lanes; i < N && periodic; ++i) periodic = m->g[i] == m->g[i % s->lanes];
-    mc.group_lane_const = periodic ? 1 : 0;
-  }
-  HIPB(hipFuncSetAttribute(reinterpret_cast<const void *>(s->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds));
+  const int n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  auto prepare = [&]() -> int {      // whatever depends on the lane count, once the geometry is fixed
+    if (m->model == AMWG_MODEL_HIER_NORMAL && !options->exact_division) {   // do the group labels repeat with the lane stride? (HierNormalModel::pass_fast)
+      bool periodic = N > 0;
+      for (int i = s->lanes; i < N && periodic; ++i) periodic = m->g[i] == m->g[i % s->lanes];
+      s->mc.group_lane_const = periodic ? 1 : 0;
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(s->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds);
+    return e == hipSuccess ? AMWG_OK : fail(AMWG_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+  };
+  if (options->lanes_per_chain == AMWG_LANES_AUTOTUNE) TRYB(autotune_geometry(s, n_cus, max_lds, prepare));
+  else { TRYB(choose_geometry(s, n_cus, max_lds)); }
+  TRYB(prepare());
   HIPB(hipStreamSynchronize(s->stream));
   *out = s;
   return AMWG_OK;
@@ -863,10 +933,9 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
   TRYB(alloc_chain_state(s, params, n_params, init, comp_opts));
 
   const size_t max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
-  TRYB(choose_geometry(s, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, max_lds));
-
-  // ---- compile for this geometry (cached per process by source text + geometry + arch) and load on this device
-  {
+  const int n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  // ---- compile for the chosen geometry (cached per process by source text + geometry + arch) and load on this device
+  auto prepare = [&]() -> int {
     static std::mutex mu;
     static std::map<std::string, std::vector<char>> cache;
     const std::string key = std::string(prop.gcnArchName) + "|" + std::to_string(s->lanes) + "|" + std::to_string(s->block) + "|" + m->source;
@@ -874,15 +943,22 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
     auto it = cache.find(key);
     if (it == cache.end()) {
       std::vector<char> code;
-      TRYB(compile_user(m->source, s->lanes, s->block, prop.gcnArchName, &code));
+      int rc = compile_user(m->source, s->lanes, s->block, prop.gcnArchName, &code);
+      if (rc != AMWG_OK) return rc;
       it = cache.emplace(key, std::move(code)).first;
     }
-    HIPB(hipModuleLoadData(&s->user_module, it->second.data()));
-    HIPB(hipModuleGetFunction(&s->user_fn, s->user_module, "amwg_user_step"));
-  }
-  // workgroups of this kernel use up to the whole 160 KB LDS of a CU; not every runtime needs (or accepts) the opt-in for module functions
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(s->user_fn), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds);
-  (void)hipGetLastError();
+    if (s->user_module) return AMWG_OK;      // (autotune hands back the module it kept)
+    hipError_t e = hipModuleLoadData(&s->user_module, it->second.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&s->user_fn, s->user_module, "amwg_user_step");
+    if (e != hipSuccess) return fail(AMWG_EHIP, "loading the compiled log_post failed: %s", hipGetErrorString(e));
+    // workgroups of this kernel use up to the whole 160 KB LDS of a CU; not every runtime needs (or accepts) the opt-in for module functions
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(s->user_fn), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds);
+    (void)hipGetLastError();
+    return AMWG_OK;
+  };
+  if (options->lanes_per_chain == AMWG_LANES_AUTOTUNE) TRYB(autotune_geometry(s, n_cus, max_lds, prepare));
+  else { TRYB(choose_geometry(s, n_cus, max_lds)); }
+  TRYB(prepare());
   HIPB(hipStreamSynchronize(s->stream));
   *out = s;
   return AMWG_OK;
@@ -1106,6 +1182,15 @@ int amwg_last_sample_moments(amwg_sampler *s, double *mean, double *sd) {
   HIP_TRY(hipMemcpyAsync(sd, dm + PR, (size_t)PR * 8, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return AMWG_OK;
+}
+
+int amwg_tuning(const amwg_sampler *s, int32_t *lanes, double *ms, int32_t cap) {
+  if (!s) return 0;
+  for (int32_t i = 0; i < cap && i < (int32_t)s->tuned.size(); ++i) {
+    if (lanes) lanes[i] = s->tuned[i].first;
+    if (ms) ms[i] = s->tuned[i].second;
+  }
+  return (int)s->tuned.size();
 }
 
 int amwg_num_components(const amwg_sampler *s) { return s ? s->P : 0; }

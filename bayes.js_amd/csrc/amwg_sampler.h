@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/amwg.h"
@@ -32,6 +33,7 @@ struct amwg_sampler {
   int lanes = 0, block = 0, grid = 0, lds = 0, cpb = 0;   // cpb: chains per workgroup if fewer than block / lanes (StepArgs::cpb)
   step_kernel_t kernel = nullptr;
   bool lp_ready = false;
+  std::vector<std::pair<int, float>> tuned;   // AMWG_LANES_AUTOTUNE: (lanes per chain, ms of the timing run) of every candidate
   // translated closure (amwg_create_user): hiprtc module function instead of a built-in kernel
   bool user = false;
   int D = 0;                       // derived quantities recorded after the P components

@@ -92,6 +92,7 @@ typedef struct {
 } amwg_model_desc;
 
 #define AMWG_LANES_FASTEST (-1)
+#define AMWG_LANES_AUTOTUNE (-2)
 typedef struct {
   int64_t chains;          /* independent chains on this sampler (>= 1) */
   uint64_t seed;           /* Philox key */
@@ -102,7 +103,11 @@ typedef struct {
                               0 = auto, REFERENCE ORDER FIRST: one lane per chain -- the reference's own sequential `lp += term`, every draw of a
                                   seeded run bit-identical to the reference -- whenever the cost model prices it within 12 % of the cheapest
                                   geometry, else the cheapest (decisions identical to the reference, doubles in the G-lane order);
-                              AMWG_LANES_FASTEST (-1) = the cheapest geometry regardless of summation order */
+                              AMWG_LANES_FASTEST (-1) = the cheapest geometry regardless of summation order;
+                              AMWG_LANES_AUTOTUNE (-2) = measured instead of modelled: at construction every lane count that fits runs a few
+                                  steps on the device (the chain state is saved and restored, tuning leaves no trace) and the fastest is kept --
+                                  one lane per chain whenever it measures within 12 % of the fastest.  The pick may differ between machines,
+                                  and with it the summation order (decisions stay the reference's); amwg_tuning reports the timings */
   int32_t block_threads;   /* 0 = auto; else multiple of 64, <= 1024 */
   int32_t steps_per_launch;/* 0 = auto (one launch per burn/sample call up to 65535 steps) */
   int32_t exact_division;  /* 0 = default: result-preserving shortcuts (hoisted-reciprocal division, fast-forward of two-valued sums), bit-identical
@@ -214,6 +219,10 @@ int amwg_last_sample_quantiles(amwg_sampler *s, const double *probs, int32_t n_p
 int amwg_group_moments(amwg_sampler *const *shards, int32_t n_shards, double *mean, double *sd);
 int amwg_group_diagnostics(amwg_sampler *const *shards, int32_t n_shards, double *rhat, double *ess);
 int amwg_group_quantiles(amwg_sampler *const *shards, int32_t n_shards, const double *probs, int32_t n_probs, double *out);
+
+/* AMWG_LANES_AUTOTUNE: the candidates that were timed at construction -- lanes[i] lanes per chain took ms[i] milliseconds for the timing
+ * run.  Returns the number of candidates (0 if the sampler was not autotuned); fills at most `cap` entries. */
+int amwg_tuning(const amwg_sampler *s, int32_t *lanes, double *ms, int32_t cap);
 
 int amwg_sync(amwg_sampler *s);
 int amwg_num_components(const amwg_sampler *s);   /* P: scalar parameter components */

@@ -230,3 +230,29 @@ def test_hierarchical_pass_with_lane_constant_groups_equals_the_gathered_pass(gr
         assert_chain_equals_oracle(s, local, o, gs, run_schedule(o, sched))
     s.close()
     e.close()
+
+
+@pytest.mark.parametrize("model,n_obs,G,chains", [("normal", 2000, 0, 4096), ("hier_normal", 1200, 6, 300), ("beta_bern", 3000, 0, 2000)])
+def test_autotuned_geometry_leaves_no_trace_in_the_chains(model, n_obs, G, chains):
+    """lanes_per_chain = AMWG_LANES_AUTOTUNE (-2): every lane count that fits is run for a few steps at construction and timed; the chain
+    state is saved before and restored after, so the tuned sampler must produce exactly what a sampler constructed with the chosen lane
+    count produces (same draws, counters, uniforms consumed)."""
+    data = model_spec.make_data(model, n_obs, 17, G=G or 32, exp=oracle_lib.lib().orc_exp)
+    spec = model_spec.build_spec(model, data)
+    tuned = A.Sampler(spec, chains=chains, seed=5, chain_offset=7, lanes_per_chain=-2)
+    cands = tuned.tuning()
+    lanes = tuned.launch_info()["lanes_per_chain"]
+    assert len(cands) >= 3 and lanes in [c[0] for c in cands] and all(ms > 0 for _, ms in cands)
+    best = min(ms for _, ms in cands)
+    one = [ms for l, ms in cands if l == 1]
+    assert dict(cands)[lanes] <= 1.12 * best or (lanes == 1 and one and one[0] <= 1.12 * best)
+    plain = A.Sampler(spec, chains=chains, seed=5, chain_offset=7, lanes_per_chain=lanes)
+    sched = [{"op": "burn", "n": 60}, {"op": "sample", "n": 30, "thin": 3}]
+    gt, gp = run_schedule(tuned, sched), run_schedule(plain, sched)
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(gt, gp))
+    it, ip = tuned.info(), plain.info()
+    for k in it:
+        assert it[k].tobytes() == ip[k].tobytes(), k
+    assert tuned.diag()["uniforms"].tobytes() == plain.diag()["uniforms"].tobytes()
+    tuned.close()
+    plain.close()

@@ -200,3 +200,21 @@ def test_fuzzed_closures_on_the_device_equal_v8(lanes):
             got_dv = draws[0, NP:, c].tolist()
             assert len(got_dv) == len(want_dv) and all(same(a, b) for a, b in zip(got_dv, want_dv)), (name, lanes, c)
         s.close()
+
+
+def test_autotuned_translated_closure_equals_the_plain_construction():
+    """AMWG_LANES_AUTOTUNE on a translated closure: one hiprtc compile per candidate lane count, timing runs on the real chain state
+    (saved and restored), the module of the winner kept -- the sampler then behaves exactly like one constructed with that lane count."""
+    spec, m, gold = spec_for("hier_normal_closure")
+    tuned = A.Sampler(spec, chains=256, seed=9, lanes_per_chain=-2)
+    cands = tuned.tuning()
+    lanes = tuned.launch_info()["lanes_per_chain"]
+    assert len(cands) >= 3 and lanes in [c[0] for c in cands]
+    plain = A.Sampler(spec, chains=256, seed=9, lanes_per_chain=lanes)
+    for s_ in (tuned, plain):
+        s_.burn(80)
+    a, b = tuned.sample(30, 3), plain.sample(30, 3)
+    assert a.tobytes() == b.tobytes()
+    assert tuned.info()["accepts"].tobytes() == plain.info()["accepts"].tobytes()
+    tuned.close()
+    plain.close()
