@@ -619,6 +619,22 @@ static napi_value LaunchInfo(napi_env env, napi_callback_info info) {
   for (int i = 0; i < 5; i++) { napi_create_int32(env, v[i], &t); napi_set_named_property(env, o, names[i], t); }
   napi_create_double(env, ms, &t);
   napi_set_named_property(env, o, "kernel_ms", t);
+  /* lanes_per_chain: -2 (AMWG_LANES_AUTOTUNE): what was timed at construction, [{lanes_per_chain, ms}, ...] */
+  int32_t tl[16];
+  double tm[16];
+  int nt = amwg_tuning(s, tl, tm, 16);
+  if (nt > 0) {
+    napi_value arr;
+    NAPI_OK(napi_create_array_with_length(env, (size_t)(nt < 16 ? nt : 16), &arr));
+    for (int i = 0; i < nt && i < 16; i++) {
+      napi_value e, x;
+      napi_create_object(env, &e);
+      napi_create_int32(env, tl[i], &x); napi_set_named_property(env, e, "lanes_per_chain", x);
+      napi_create_double(env, tm[i], &x); napi_set_named_property(env, e, "ms", x);
+      napi_set_element(env, arr, (uint32_t)i, e);
+    }
+    napi_set_named_property(env, o, "tuning", arr);
+  }
   return o;
 }
 
