@@ -1,0 +1,114 @@
+"""-m gpu: BASELINE.json configs 2 and 3 at FULL size (65 536 / 262 144 chains, 1e4 / 1e5 observations) through size-independent
+properties -- the oracle finishes single chains of these sizes only (tests/golden/cfg*_full.json pin two chains each bit for bit):
+  * the pooled draws sample the analytic posterior (means within 0.1 %, standard deviations within 3 %; north_star asks for 1 %),
+  * Roberts-Rosenthal adaptation drives every component's acceptance rate to the 0.44 target (mcmc.js:543),
+  * every chain is a valid run: finite state, accepted <= evaluated <= steps, uniforms consumed >= 3 per in-bounds update,
+  * chains are independent draws of the same process: split-R-hat ~ 1."""
+import math
+
+import numpy as np
+import pytest
+
+import amwg_ctypes as A
+import model_spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(spec, chains, burn, n, thin):
+    s = A.Sampler(spec, chains=chains, seed=20260925)      # auto geometry: reference order where it is priced within 12 %
+    s.burn(burn)
+    acc0, inb0 = s.info()["accepts"].copy(), s.info()["inbounds"].copy()
+    s.sample_async(n, thin)
+    s.sync()
+    return s, acc0, inb0
+
+
+def test_cfg2_full_size_samples_the_analytic_posterior_and_adapts_to_the_target():
+    data = model_spec.make_data("normal", 10_000, 20260925)
+    spec = model_spec.build_spec("normal", data)
+    x = np.asarray(data["x"])
+    n, xbar, s2 = x.size, x.mean(), x.var(ddof=1)
+    C, steps = 65_536, 600
+    smp, acc0, inb0 = _run(spec, C, 1500, steps, 6)
+    assert smp.launch_info()["lanes_per_chain"] == 1                      # the default geometry of cfg2 is the reference's summation order
+    mean, sd = smp.moments()
+    # mu | data ~ t_{n-1}(xbar, s^2/n) (the N(0,100) prior is flat at this scale); sigma^2 | data ~ Inv-Gamma((n-1)/2, (n-1) s^2 / 2) under a uniform prior on sigma
+    assert abs(mean[0] - xbar) < 1e-3 * abs(xbar)
+    assert abs(sd[0] - math.sqrt(s2 / n * (n - 1) / (n - 3))) < 0.03 * math.sqrt(s2 / n)
+    e_sigma = math.sqrt(s2 * (n - 1) / 2) * math.exp(math.lgamma((n - 2) / 2) - math.lgamma((n - 1) / 2))
+    assert abs(mean[1] - e_sigma) < 1e-3 * e_sigma
+    assert abs(sd[1] - math.sqrt(s2 / (2 * n))) < 0.03 * math.sqrt(s2 / (2 * n))
+    info = smp.info()
+    rate = (info["accepts"] - acc0) / float(steps)
+    assert np.all(np.abs(rate.mean(axis=1) - 0.44) < 0.02), rate.mean(axis=1)      # batch adaptation towards target_accept_rate
+    assert np.all(info["accepts"] <= info["inbounds"]) and np.all(info["inbounds"] <= 1500 + steps)
+    assert np.all(np.isfinite(smp.state()))
+    un = smp.diag()["uniforms"].astype(np.int64)
+    assert np.all(un >= 3 * info["inbounds"].sum(axis=0))                  # >= 2 per rnorm pass + 1 per accept test; +1 per step for the shuffle
+    rhat, ess = smp.convergence()
+    assert np.all(np.abs(rhat - 1) < 0.01) and np.all(ess > 0.5 * C)
+    smp.close()
+
+
+def test_cfg3_full_size_samples_the_conjugate_posterior():
+    data = model_spec.make_data("beta_bern", 100_000, 20260925)
+    spec = model_spec.build_spec("beta_bern", data)
+    x = np.asarray(data["x"])
+    a, b = 2 + x.sum(), 2 + x.size - x.sum()                               # Beta(2,2) prior (README.md:149-164) => Beta(2 + sum x, 2 + n - sum x)
+    C, steps = 262_144, 400
+    smp, acc0, _ = _run(spec, C, 1200, steps, 4)
+    assert smp.launch_info()["lanes_per_chain"] == 1
+    mean, sd = smp.moments()
+    assert abs(mean[0] - a / (a + b)) < 1e-3 * a / (a + b)
+    assert abs(sd[0] - math.sqrt(a * b / ((a + b) ** 2 * (a + b + 1)))) < 0.03 * math.sqrt(a * b / ((a + b) ** 2 * (a + b + 1)))
+    rate = (smp.info()["accepts"] - acc0) / float(steps)
+    assert abs(rate.mean() - 0.44) < 0.02
+    q = smp.quantiles([0.025, 0.5, 0.975])[0]
+    from scipy.stats import beta as beta_dist
+    want = beta_dist.ppf([0.025, 0.5, 0.975], a, b)
+    assert np.all(np.abs(q - want) < 2e-4)                                 # posterior sd is 1.4e-3: quantiles to a seventh of it
+    smp.close()
+
+
+def test_cfg4_per_gpu_size_hierarchical_posterior_properties():
+    """cfg4 as one GPU of eight sees it: 2 048 chains, 1e4 observations in 32 groups, 34 components (64 lanes per chain, the group labels
+    repeat with the lane stride: constant-mean pass).  No closed form with sigma unknown; the properties: every component adapts to the
+    0.44 target, chains agree (split-R-hat), the group means sit at the group averages (prior sd 10 vs sigma/sqrt(n_g) = 0.11: shrinkage
+    < 0.02 %), sigma at the pooled within-group sd."""
+    data = model_spec.make_data("hier_normal", 10_000, 20260925, G=32)
+    spec = model_spec.build_spec("hier_normal", data)
+    y, g = np.asarray(data["x"]), np.asarray(data["g"])
+    C, steps = 2_048, 500
+    smp, acc0, _ = _run(spec, C, 2000, steps, 5)
+    assert smp.launch_info()["lanes_per_chain"] == 64
+    mean, sd = smp.moments()
+    gm = np.array([y[g == k].mean() for k in range(32)])
+    ng = np.array([(g == k).sum() for k in range(32)])
+    within = math.sqrt(sum(((y[g == k] - gm[k]) ** 2).sum() for k in range(32)) / (y.size - 32))
+    assert np.all(np.abs(mean[:32] - gm) < 0.25 * within / np.sqrt(ng))            # a quarter of a posterior sd
+    assert np.all(np.abs(sd[:32] - within / np.sqrt(ng)) < 0.05 * within / np.sqrt(ng))
+    assert abs(mean[33] - within) < 0.002 * within and abs(mean[32] - gm.mean()) < 4 * 10 / math.sqrt(32) * 0.25
+    rate = (smp.info()["accepts"] - acc0) / float(steps)
+    assert np.all(np.abs(rate.mean(axis=1) - 0.44) < 0.03), rate.mean(axis=1)
+    rhat, ess = smp.convergence()
+    assert np.all(np.abs(rhat - 1) < 0.02), rhat
+    smp.close()
+
+
+def test_cfg5_poisson_glm_runs_and_moves_towards_the_truth():
+    """cfg5 (8 real coefficients + an int change point, 5e4 observations) on 1 024 chains: a short run cannot be held to posterior
+    accuracy (the change point random-walks over 5e4 integers), so the properties are weak ones: finite states, bounds respected, log_post
+    far above its starting value, the intercept and the change-point coefficient moving to the generating values."""
+    data = model_spec.make_data("pois_glm", 50_000, 20260925, exp=A.lib().amwg_exp)
+    spec = model_spec.build_spec("pois_glm", data)
+    smp = A.Sampler(spec, chains=1_024, seed=20260925)
+    lp0 = smp.diag()["log_post"].copy()
+    smp.burn(400)
+    st, lp1 = smp.state(), smp.diag()["log_post"]
+    assert np.all(np.isfinite(st)) and np.all(st[8] >= 0) and np.all(st[8] <= 49_999) and np.all(st[8] == np.round(st[8]))
+    assert np.all(lp1 > lp0 + 1000)
+    assert abs(np.median(st[0]) - 0.5) < 0.1                                       # beta_true[0] = 0.5 (oracle/synth.js glm)
+    info = smp.info()
+    assert np.all(info["accepts"] <= info["inbounds"]) and np.all(info["inbounds"] <= 400)
+    smp.close()
