@@ -4,10 +4,11 @@
 #include "amwg_math.h"
 #include "amwg_types.h"
 
+// large bodies: one copy per kernel, not one per call site (plain `inline`; amwg_math.h's AMWG_HD_OUTLINE is the noinline flavour)
 #if defined(__HIPCC__)
-#define AMWG_HD_OUTLINE __host__ __device__ inline      // large: one copy per kernel, not one per call site
+#define AMWG_HD_SHARED __host__ __device__ inline
 #else
-#define AMWG_HD_OUTLINE inline
+#define AMWG_HD_SHARED inline
 #endif
 
 namespace amwg {
@@ -62,7 +63,7 @@ AMWG_HD int first_symbol(const BitData &B, int i, uint32_t sym) {
 //   the other (n) does not d_n odd:  every n flips the parity, every t resets it to even, so a later t rounds by the parity
 //                                    of the run of n's right before it (data-only: the odd-run marks), the first one by
 //                                    p plus the distance to it
-AMWG_HD_OUTLINE double two_valued_sum(double acc, double l1, double l0, const BitData &B) {
+AMWG_HD_SHARED double two_valued_sum(double acc, double l1, double l0, const BitData &B) {
   const int N = B.n;
   int i = 0;
   auto step = [&](int idx) { acc = acc + (((B.w[idx >> 5] >> (idx & 31)) & 1u) ? l1 : l0); };
