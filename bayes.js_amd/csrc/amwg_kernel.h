@@ -164,7 +164,8 @@ template <int G>
 struct CoopStream {
   static constexpr int L = G < 64 ? G : 64;
   uint32_t k0, k1, c2, c3;
-  uint64_t n, b0;
+  uint64_t b0;          // first block held by the chain's lanes
+  uint32_t pos;         // uniforms consumed since block b0 (0 .. 2L): the stream position is 2*b0 + pos -- 32-bit bookkeeping per draw
   uint32_t w0, w1, w2, w3;
   int lane_in_chain, base_lane;
   __device__ __forceinline__ void fill() {
@@ -175,23 +176,23 @@ struct CoopStream {
   __device__ __forceinline__ void init(uint64_t seed, uint64_t chain, uint64_t consumed, int tid) {
     k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
     c2 = (uint32_t)chain; c3 = (uint32_t)(chain >> 32);
-    n = consumed;
     lane_in_chain = tid & (L - 1);
     base_lane = (tid & 63) & ~(L - 1);
-    b0 = n >> 1;
+    b0 = consumed >> 1;
+    pos = (uint32_t)(consumed & 1u);
     fill();
   }
+  __device__ __forceinline__ uint64_t consumed() const { return 2 * b0 + (uint64_t)pos; }
   __device__ __forceinline__ double next() {
-    const uint64_t blk = n >> 1;
-    if (blk - b0 >= (uint64_t)L) { b0 = blk; fill(); }
-    const bool second = (n & 1) != 0;
+    if (pos >= 2u * (uint32_t)L) { b0 += (uint64_t)L; pos = 0u; fill(); }      // pos only ever reaches 2L exactly
+    const bool second = (pos & 1u) != 0;
     uint32_t hi = second ? w2 : w0, lo = second ? w3 : w1;
     if constexpr (L > 1) {
-      const int src = base_lane + (int)(blk - b0);
+      const int src = base_lane + (int)(pos >> 1);
       hi = (uint32_t)__shfl((int)hi, src, 64);
       lo = (uint32_t)__shfl((int)lo, src, 64);
     }
-    ++n;
+    ++pos;
     return u53(hi, lo);
   }
 };
@@ -422,7 +423,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     }
     if (wide_perm) { for (int k = 0; k < n_named; ++k) a.ch.perm16[(int64_t)k * C + cl] = (uint16_t)pcol.get(k); }
     else a.ch.perm[cl] = perm;
-    a.ch.rng_n[cl] = rng.n;
+    a.ch.rng_n[cl] = rng.consumed();
     a.ch.lp_curr[cl] = lp_curr;
   }
 }
