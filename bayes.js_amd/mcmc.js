@@ -249,13 +249,17 @@ function AmwgSampler(params, log_post, data, options) {
   this._shards = [];
   const D = Math.min(devices.length, this.chains), per = Math.floor(this.chains / D), rem = this.chains % D;
   let offset = 0;
+  let lanes = opt('lanes_per_chain', 0);
   for (let r = 0; r < D; r++) {
     const count = per + (r < rem ? 1 : 0);
     const handle = (user ? N.createUser : N.create)(user || desc, descs, Float64Array.from(init), compOpts, {
       chains: count, seed: this.seed, chain_offset: opt('chain_offset', 0) + offset, device: devices[r],
-      lanes_per_chain: opt('lanes_per_chain', 0), block_threads: opt('block_threads', 0),
+      lanes_per_chain: lanes, block_threads: opt('block_threads', 0),
       steps_per_launch: opt('steps_per_launch', 0), exact_division: opt('exact_division', 0) });
     this._shards.push({ handle, offset, count, device: devices[r] });
+    // one summation order for the whole job: what the first shard picked (cost model, or the measurement of lanes_per_chain: -2)
+    // is what the other shards get -- a chain's draws must not depend on the shard it landed in
+    if (r === 0 && D > 1 && lanes <= 0) lanes = N.launchInfo(handle).lanes_per_chain;
     offset += count;
   }
   this._host_log_post = (st) => log_post(st, data);
