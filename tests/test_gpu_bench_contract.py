@@ -1,0 +1,45 @@
+"""-m gpu: bench.py's one JSON line carries what the driver's contract asks for (a short run: 5 steps, small chain count)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*extra):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--min-seconds", "0.05", *extra],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_line_has_the_contract_fields_and_an_honest_roofline():
+    d = _bench("--chains-per-gpu", "4096")
+    for key, want in (("unit", "param-updates/s"), ("n_gpus", 1), ("steps", 5), ("warmup", 2), ("higher_is_better", True), ("scaling", "weak"),
+                      ("vs_baseline", None), ("dtype", "f64"), ("data", "synthetic")):
+        assert d[key] == want, key
+    assert "param-updates" in d["metric"] and d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["config"]["workload"].startswith("BASELINE.json configs[1]") and "model" not in d["config"]
+    assert abs(d["value"] - 4096 * 5 * 2 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]          # value = chains x K x P / time of the K steps
+    r = d["roofline"]
+    assert r["bound"] == "fp64_valu" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["effective_hbm"]["lds_resident"] is True and r["effective_hbm"]["unit"] == "GB/s"
+    assert d["timing"]["regions"] >= 3 and len(d["timing"]["region_ms"]) == min(64, d["timing"]["regions"])      # the first 64 regions are listed
+    assert d["parity"]["draws_bit_identical"] and d["parity"]["accept_counts_identical"] and d["parity"]["final_state_bit_identical"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "param-updates/s" and c["sample"]
+    assert c["kind"] == "reference" or c.get("reference_unavailable") is True
+
+
+@pytest.mark.parametrize("workload", ["cfg3", "cfg4"])
+def test_other_workloads_report_a_roofline(workload):
+    d = _bench("--workload", workload, "--no-cpu-baseline", "--chains-per-gpu", "2048")
+    assert d["roofline"]["bound"] == "fp64_valu" and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+    if workload == "cfg3":
+        assert "term-by-term" in d["roofline"]["kernel"]
