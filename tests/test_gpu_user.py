@@ -7,6 +7,8 @@
 """
 import shutil
 
+import os
+
 import numpy as np
 import pytest
 
@@ -171,7 +173,9 @@ def test_fuzzed_closures_on_the_device_equal_v8(lanes):
     the first recorded draw are, at one lane per chain, bit for bit what V8 returned, and at four lanes bit for bit what the host
     build of the same text returns in that lane order."""
     # 12 derived quantities per model, seeds whose programs hiprtc compiles in seconds (the 48-quantity models of the host test take a minute each)
-    for name in user_host.fuzz_models(5, 1, 12) + user_host.fuzz_models(7, 1, 12) + user_host.fuzz_models(25, 1, 12):
+    # (AMWG_FUZZ_SEEDS="30,31,..." runs a one-off campaign over other seeds)
+    seeds = [int(t) for t in os.environ.get("AMWG_FUZZ_SEEDS", "5,7,25").split(",")]
+    for name in [nm for sd in seeds for nm in user_host.fuzz_models(sd, 1, 12)]:
         m = user_host.host_model(name)
         if lanes > 1 and not m.meta["parallel"]:
             continue
