@@ -141,7 +141,14 @@ double model_work(const amwg_sampler *s, int G) {
     case AMWG_MODEL_NORMAL: return 9.0 * N;
     case AMWG_MODEL_BETA_BERN:   // one lane: exact fast-forward over ~log2(N) binades (or the scalar jump-table pass, one add per observation)
       return G == 1 ? (s->mc.exact_division ? 1.8 * N : 400.0 * (1.0 + std::log2(N + 2.0))) : 6.0 * N;
-    case AMWG_MODEL_HIER_NORMAL: return 10.0 * N + 12.0 * s->d.G;
+    case AMWG_MODEL_HIER_NORMAL: {
+      // group labels that repeat with the lane stride: a lane reads its one mean once (constant-mean pass, 8.1 VALU and 1 LDS read per
+      // observation); otherwise the gathered pass (9.4 VALU, 2.5 LDS reads: the LDS pipe, not the VALU, then sets the pace)
+      int lg = 0;
+      for (int g = G; g > 1; g >>= 1) ++lg;
+      const bool periodic = ((s->hier_periodic_mask >> lg) & 1u) != 0;
+      return (periodic ? 8.6 : 12.0) * N + 12.0 * s->d.G;
+    }
     case AMWG_MODEL_POIS_GLM: return 90.0 * N;
   }
   if (G == 1 && s->user_work_one_lane > 0) return s->user_work_one_lane;   // translated closure with a two-valued sum: fast-forwarded
@@ -836,11 +843,19 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   // launch (StepArgs.init_lp); amwg_chain_diag forces it with a 0-step launch if asked earlier.
   const size_t max_lds = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
   const int n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  auto prepare = [&]() -> int {      // whatever depends on the lane count, once the geometry is fixed
-    if (m->model == AMWG_MODEL_HIER_NORMAL && !options->exact_division) {   // do the group labels repeat with the lane stride? (HierNormalModel::pass_fast)
+  if (m->model == AMWG_MODEL_HIER_NORMAL && !options->exact_division) {   // for which lane counts 2^j do the group labels repeat with the lane stride?
+    for (int j = 0; j <= 10; ++j) {
+      const int Gj = 1 << j;
       bool periodic = N > 0;
-      for (int i = s->lanes; i < N && periodic; ++i) periodic = m->g[i] == m->g[i % s->lanes];
-      s->mc.group_lane_const = periodic ? 1 : 0;
+      for (int i = Gj; i < N && periodic; ++i) periodic = m->g[i] == m->g[i % Gj];
+      if (periodic) s->hier_periodic_mask |= 1u << j;
+    }
+  }
+  auto prepare = [&]() -> int {      // whatever depends on the lane count, once the geometry is fixed
+    if (m->model == AMWG_MODEL_HIER_NORMAL) {   // HierNormalModel::pass_fast: constant-mean pass when the labels repeat with the lane stride
+      int lg = 0;
+      for (int g = s->lanes; g > 1; g >>= 1) ++lg;
+      s->mc.group_lane_const = (int32_t)((s->hier_periodic_mask >> lg) & 1u);
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(s->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds);
     return e == hipSuccess ? AMWG_OK : fail(AMWG_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
