@@ -1,3 +1,6 @@
+"""Development tool (GPU box): the lane count the static cost model picks vs the one AMWG_LANES_AUTOTUNE measures as fastest, for a few
+families / sizes / chain counts -- where the two differ by more than the 12 % band the model needs another term (round 2: the hierarchical
+family's lane-periodic group labels).   python tools/tune_probe.py"""
 import sys; sys.path[:0]=["bayes.js_amd","tests"]
 import amwg_ctypes as A, model_spec
 for fam,n,ch in (("hier_normal",10000,16384),("hier_normal",10000,8192),("hier_normal",10000,4096),("pois_glm",50000,8192),("normal",10000,8192),("normal",10000,1024),("normal",1000,65536),("beta_bern",100000,16384)):
