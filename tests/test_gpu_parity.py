@@ -256,3 +256,20 @@ def test_autotuned_geometry_leaves_no_trace_in_the_chains(model, n_obs, G, chain
     assert tuned.diag()["uniforms"].tobytes() == plain.diag()["uniforms"].tobytes()
     tuned.close()
     plain.close()
+
+
+def test_run_totals_survive_launches_longer_than_their_16_bit_launch_counters():
+    """A launch counts accepted / evaluated proposals in 16-bit fields of one LDS word per component and adds them to the 32-bit totals when
+    it ends; the host therefore cuts a burn() into launches of at most 65 535 steps.  70 000 steps of an unbounded parameter: evaluated ==
+    steps, accepted <= evaluated, two launches."""
+    spec = model_spec.build_spec("normal", model_spec.make_data("normal", 16, 3))
+    s = A.Sampler(spec, chains=8, seed=2, lanes_per_chain=1)
+    s.burn(70_000)
+    info = s.info()
+    assert s.launch_info()["n_launches"] == 2
+    assert np.all(info["inbounds"][0] == 70_000)                      # mu is unbounded: every proposal is evaluated
+    assert np.all(info["accepts"] <= info["inbounds"]) and np.all(info["accepts"][0] > 20_000)
+    o = oracle_lib.OracleChain(spec, 2, 0, lanes=1)
+    o.burn(70_000)
+    assert info["accepts"][:, 0].tolist() == o.info()["accepts"].tolist() and s.state()[:, 0].tolist() == o.state().tolist()
+    s.close()
