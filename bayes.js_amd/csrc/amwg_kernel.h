@@ -105,6 +105,39 @@ struct NoCache {};
 template <class M, class = void> struct CacheOf { using type = NoCache; static __device__ __forceinline__ type init() { return type{}; } };
 template <class M> struct CacheOf<M, void_of<typename M::Cache>> { using type = typename M::Cache; static __device__ __forceinline__ type init() { return M::cache_init(); } };
 
+// acc + (the value of lane ^ OFF): the xor butterfly of a chain's partial sums.  Offsets 1, 2 (quad permutes), 4 and 8 (row mirrors) are DPP
+// moves in the VALU -- no trip through the LDS crossbar, whose queue the data passes of the CU's other waves keep full; 16 is a swizzle
+// without an address register; 32 stays a permute.  Every lane still adds the same two numbers in the same order as with __shfl_xor.
+template <int OFF>
+__device__ __forceinline__ double xor_partner(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int lo = (int)(uint32_t)f64_bits(v), hi = (int)(uint32_t)(f64_bits(v) >> 32);
+  if constexpr (OFF == 1) {          // quad_perm [1,0,3,2]
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  } else if constexpr (OFF == 2) {   // quad_perm [2,3,0,1]
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
+  } else if constexpr (OFF == 4) {   // row_half_mirror (i -> 7 - i within 8), then quad_perm [3,2,1,0]: i -> i ^ 4
+    lo = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+  } else if constexpr (OFF == 8) {   // row_mirror (i -> 15 - i within 16), then row_half_mirror: i -> i ^ 8
+    lo = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true), 0x141, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true), 0x141, 0xF, 0xF, true);
+  } else if constexpr (OFF == 16) {  // ds_swizzle, bit-mask mode: lane' = (lane & 0x1f) ^ 0x10 within each half of the wave
+    lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F); hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
+  } else {
+    return __shfl_xor(v, OFF, 64);
+  }
+  return bits_f64(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+#else
+  return v;
+#endif
+}
+template <int OFF, int LIMIT>
+__device__ __forceinline__ double butterfly(double acc) {
+  if constexpr (OFF < LIMIT) { acc = acc + xor_partner<OFF>(acc); return butterfly<OFF * 2, LIMIT>(acc); }
+  else return acc;
+}
+
 template <class Model, int G>
 __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a, const unsigned char *smem, int sub, CrossWave &xw,
                                            typename CacheOf<Model>::type &cache) {
@@ -130,8 +163,7 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
       if (ps.has_invalid) acc = acc + (-kInf);   // some x_i outside {0,1}: that term is -inf wherever it sits in the sum
     }
   }
-#pragma unroll
-  for (int off = 1; off < (G < 64 ? G : 64); off <<= 1) acc = acc + __shfl_xor(acc, off, 64);
+  acc = butterfly<1, (G < 64 ? G : 64)>(acc);
   if constexpr (G > 64) {
     constexpr int WV = G / 64;
     double *slot = xw.buf + xw.parity * 16;
@@ -381,9 +413,12 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       bool accepted = false;
       if (inb) {
         Sme[comp] = prop;
+        // the accept test's uniform (mcmc.js:528) is the next one of the stream whatever log_post returns: drawn now, its cross-lane fetch
+        // is over long before the evaluation ends
+        const double u_accept = rng.next();
         const double prop_lp = log_post<Model, G>(S, a, data_lds, sub, xw, cache);
         const double accept_prob = exp_v8(prop_lp - lp_curr);
-        if (accept_prob > rng.next()) {
+        if (accept_prob > u_accept) {
           accepted = true;
           lp_curr = prop_lp;
         } else {
