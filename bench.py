@@ -23,7 +23,7 @@ roofline: the binding roof of this path is fp64 VALU issue (78.6 TFLOP/s = 3.93e
     "effective bandwidth" (80 024 algorithmic bytes per update / launch time, vs the 8 TB/s HBM peak) is reported beside it as
     roofline.effective_hbm with lds_resident: true -- it exceeds 1 by design.  roofline.traffic = measured HBM bytes per launch
     (rocprofv3 PMC, profiles/), traffic_ratio = traffic / algorithmic bytes.
-cpu_baseline = the UNMODIFIED reference (bench/ref_cpu.js: node + /root/reference or $AMWG_REF_DIR, one thread, median of 5
+cpu_baseline = the UNMODIFIED reference (bench/ref_cpu.js: node + $AMWG_REF_DIR | /root/reference | oracle/_ref, one thread, median of 5
     >= 1 s repeats) when Node and the reference are present ("kind": "reference"); on a box without the reference (the GPU
     box) the C port oracle/amwg_oracle.c on one thread ("kind": "port", "reference_unavailable": true).
 """
@@ -108,13 +108,22 @@ def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None):
     return None, None, None
 
 
+def reference_dir():
+    """Where the unmodified reference can be loaded from: $AMWG_REF_DIR, /root/reference (build container), or oracle/_ref -- the
+    copy `make -C oracle ref` (run by __graft_entry__.build()) leaves beside the oracle; git-ignored, it travels to the GPU box."""
+    for d in (os.environ.get("AMWG_REF_DIR"), "/root/reference", os.path.join(ROOT, "oracle", "_ref")):
+        if d and os.path.exists(os.path.join(d, "mcmc.js")) and os.path.exists(os.path.join(d, "distributions.js")):
+            return d
+    return None
+
+
 def cpu_baseline_reference(workload):
     """The unmodified reference on one host core (bench/ref_cpu.js); None where Node or the reference is missing."""
     import shutil
     import subprocess
     node = shutil.which("node")
-    ref = os.environ.get("AMWG_REF_DIR", "/root/reference")
-    if node is None or not os.path.exists(os.path.join(ref, "mcmc.js")):
+    ref = reference_dir()
+    if node is None or ref is None:
         return None
     try:
         out = subprocess.run([node, os.path.join(ROOT, "bench", "ref_cpu.js"), "--workload", workload, "--ref", ref],
@@ -124,7 +133,7 @@ def cpu_baseline_reference(workload):
         return None
     if not r.get("available"):
         return None
-    return {"value": r["value"], "unit": "param-updates/s", "cores": 1, "kind": "reference",
+    return {"value": r["value"], "unit": "param-updates/s", "cores": 1, "kind": "reference", "unmodified_sha256_ok": r.get("unmodified"),
             "sample": "unmodified %s/mcmc.js under Node %s, same model+data (N=%d), 1 chain, median of 5 burn(%d) repeats (%.2f s each) after "
                       "%d warm-up steps; the reference evaluates log_post twice per update (mcmc.js:524-526)"
                       % (ref, r["node"], r["n_obs"], r["steps_per_repeat"], r["median_s"], r["warmup_steps"]),

@@ -7,7 +7,8 @@
  *
  *   node bench/ref_cpu.js [--workload cfg2|cfg3|cfg4|cfg5|readme] [--ref DIR] [--budget SECONDS]
  *
- * The reference directory is --ref, else $AMWG_REF_DIR, else /root/reference; if it does not exist the script prints
+ * The reference directory is --ref, else oracle/ref_dir.js's search ($AMWG_REF_DIR, /root/reference, oracle/_ref = the copy `make -C oracle ref`
+ * puts beside the oracle so that it travels to the GPU box); its two files are hashed against oracle/ref.sha256 (`unmodified`).  If none exists the script prints
  * {"available": false} and exits 0 (the GPU box has no copy of the reference; bench.py then times the C port instead and says so).
  * Method (BASELINE.md section 3.2): one throw-away warm-up of >= 2000 sampler-steps or 2 s (V8's JIT), then the MEDIAN of 5 timed
  * burn(n) repeats, n sized from the warm-up rate so that each repeat takes >= 1 s; timer process.hrtime.bigint().
@@ -17,7 +18,7 @@ const fs = require('fs'), path = require('path');
 const args = process.argv.slice(2);
 function opt(name, dflt) { const i = args.indexOf('--' + name); return i >= 0 ? args[i + 1] : dflt; }
 const workload = opt('workload', 'cfg2');
-const refDir = opt('ref', process.env.AMWG_REF_DIR || '/root/reference');
+const refDir = path.resolve(opt('ref', require('../oracle/ref_dir.js').refDir() || '/root/reference'));
 const budget = parseFloat(opt('budget', '1.0'));     // seconds per timed repeat
 if (!fs.existsSync(path.join(refDir, 'mcmc.js'))) { console.log(JSON.stringify({ available: false, ref_dir: refDir })); process.exit(0); }
 const mcmc = require(path.join(refDir, 'mcmc.js')), ld = require(path.join(refDir, 'distributions.js'));
@@ -49,5 +50,6 @@ for (let attempt = 0; attempt < 3; attempt++) {      // size a repeat from the b
 console.log(JSON.stringify({
   available: true, workload: workload, model: fam, n_obs: N, components: P, steps_per_repeat: steps, repeats_s: secs, median_s: med,
   value: steps * P / med, unit: 'param-updates/s', cores: 1, node: process.version, ref_dir: refDir, warmup_steps: warmSteps,
+  unmodified: require('../oracle/ref_dir.js').unmodified(refDir),
   reference_algorithmic_bytes_per_update: 2 * N * 8,
 }));

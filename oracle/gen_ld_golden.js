@@ -8,7 +8,7 @@
  *      11 t 12 weibull 13 logis 14 exp 15 binom 16 nbinom 17 hyper 18 lgamma 19 lfactorial 20 lchoose 21 lbeta
  */
 const fs = require('fs'), path = require('path');
-const ld = require(path.join(process.env.AMWG_REF_DIR || '/root/reference', 'distributions.js'));
+const ld = require(path.join(require('./ref_dir.js').refDir() || '/root/reference', 'distributions.js'));
 const OUT = path.join(__dirname, '..', 'tests', 'golden');
 let s = 424242;
 function rnd() { s = (Math.imul(s, 1103515245) + 12345) >>> 0; return s / 4294967296; }

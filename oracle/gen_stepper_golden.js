@@ -6,7 +6,7 @@
  *   node oracle/gen_stepper_golden.js > tests/golden/steppers.json
  */
 const path = require('path');
-const REF_DIR = process.env.AMWG_REF_DIR || '/root/reference';
+const REF_DIR = require('./ref_dir.js').refDir() || '/root/reference';
 const mcmc = require(path.join(REF_DIR, 'mcmc.js'));
 const ld = require(path.join(REF_DIR, 'distributions.js'));
 const { stream } = require('./philox.js');

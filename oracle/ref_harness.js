@@ -15,7 +15,7 @@
  * replayed with the same Math.exp and the uniform the stream just handed out.
  */
 const path = require('path');
-const REF_DIR = process.env.AMWG_REF_DIR || '/root/reference';
+const REF_DIR = require('./ref_dir.js').refDir() || '/root/reference';
 const mcmc = require(path.join(REF_DIR, 'mcmc.js'));
 const ld = require(path.join(REF_DIR, 'distributions.js'));
 const { stream } = require('./philox.js');

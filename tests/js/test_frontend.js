@@ -9,7 +9,7 @@ const fs = require('fs');
 const path = require('path');
 const { mcmc, ld, models } = require('../../bayes.js_amd');
 
-const REF = process.env.AMWG_REF_DIR || '/root/reference';
+const REF = require('../../oracle/ref_dir.js').refDir() || '/root/reference';
 const haveRef = fs.existsSync(path.join(REF, 'mcmc.js'));
 const ref = haveRef ? require(path.join(REF, 'mcmc.js')) : null;
 const refld = haveRef ? require(path.join(REF, 'distributions.js')) : null;
