@@ -30,6 +30,12 @@ extern const char amwg_hdr_stdint[], amwg_hdr_types[], amwg_hdr_math[], amwg_hdr
     amwg_hdr_kernel[], amwg_hdr_user[], amwg_hdr_twoval[], amwg_hdr_trig[], amwg_hdr_pass[];
 }
 
+// the step kernels of the built-in families, one translation unit each (amwg_kernels.hip): kernel for (lanes per chain, workgroup size)
+step_kernel_t amwg_kernels_normal(int lanes, int block);
+step_kernel_t amwg_kernels_beta_bern(int lanes, int block);
+step_kernel_t amwg_kernels_hier_normal(int lanes, int block);
+step_kernel_t amwg_kernels_pois_glm(int lanes, int block);
+
 namespace {
 
 thread_local std::string g_err;
@@ -51,30 +57,12 @@ int fail(int code, const char *fmt, ...) {
   } while (0)
 
 
-template <class Model>
-step_kernel_t kernel_for_lanes(int G) {
-  switch (G) {
-    case 1: return amwg_step_kernel<Model, 1>;
-    case 2: return amwg_step_kernel<Model, 2>;
-    case 4: return amwg_step_kernel<Model, 4>;
-    case 8: return amwg_step_kernel<Model, 8>;
-    case 16: return amwg_step_kernel<Model, 16>;
-    case 32: return amwg_step_kernel<Model, 32>;
-    case 64: return amwg_step_kernel<Model, 64>;
-    case 128: return amwg_step_kernel<Model, 128>;     // one chain on 2..16 wavefronts of one workgroup (few chains, long data loops)
-    case 256: return amwg_step_kernel<Model, 256>;
-    case 512: return amwg_step_kernel<Model, 512>;
-    case 1024: return amwg_step_kernel<Model, 1024>;
-  }
-  return nullptr;
-}
-
-step_kernel_t pick_kernel(int model, int G) {
+step_kernel_t pick_kernel(int model, int G, int block) {
   switch (model) {
-    case AMWG_MODEL_NORMAL: return kernel_for_lanes<NormalModel>(G);
-    case AMWG_MODEL_BETA_BERN: return kernel_for_lanes<BetaBernModel>(G);
-    case AMWG_MODEL_HIER_NORMAL: return kernel_for_lanes<HierNormalModel>(G);
-    case AMWG_MODEL_POIS_GLM: return kernel_for_lanes<PoisGlmModel>(G);
+    case AMWG_MODEL_NORMAL: return amwg_kernels_normal(G, block);
+    case AMWG_MODEL_BETA_BERN: return amwg_kernels_beta_bern(G, block);
+    case AMWG_MODEL_HIER_NORMAL: return amwg_kernels_hier_normal(G, block);
+    case AMWG_MODEL_POIS_GLM: return amwg_kernels_pois_glm(G, block);
   }
   return nullptr;
 }
@@ -231,8 +219,8 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   s->grid = (int)((s->C + CPB - 1) / CPB);
   s->lds = (int)layout(bestB, bestG, bestCpb).total;
   if (s->user) return AMWG_OK;    // the kernel is compiled for this geometry afterwards
-  s->kernel = pick_kernel(s->model, s->lanes);
-  if (!s->kernel) return fail(AMWG_EINVAL, "no kernel for model %d with %d lanes per chain", s->model, s->lanes);
+  s->kernel = pick_kernel(s->model, s->lanes, s->block);
+  if (!s->kernel) return fail(AMWG_EINVAL, "no kernel for model %d with %d lanes per chain in workgroups of %d", s->model, s->lanes, s->block);
   return AMWG_OK;
 }
 

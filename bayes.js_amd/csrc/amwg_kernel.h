@@ -100,6 +100,12 @@ template <class...> using void_of = void;
 template <class M, class = void> struct BinaryOf { static constexpr bool value = true; };
 template <class M> struct BinaryOf<M, void_of<decltype(M::kHasBinary)>> { static constexpr bool value = M::kHasBinary; };
 
+// Does the model mirror the chain's state in registers (Model::kTracksState; translated closures read the LDS copy)?  Such a model is
+// told about every store to the state -- on_set(cache, component, value, lane, data) -- so that its log_post never has to wait for an
+// LDS round trip to learn what the stepper has just written.
+template <class M, class = void> struct TracksState { static constexpr bool value = false; };
+template <class M> struct TracksState<M, void_of<decltype(M::kTracksState)>> { static constexpr bool value = M::kTracksState; };
+
 // per-chain values a model keeps from one log_post evaluation to the next (Model::Cache; translated closures have none)
 struct NoCache {};
 template <class M, class = void> struct CacheOf { using type = NoCache; static __device__ __forceinline__ type init() { return type{}; } };
@@ -132,25 +138,64 @@ __device__ __forceinline__ double xor_partner(double v) {
   return v;
 #endif
 }
+// acc + (the value of lane ^ OFF), every lane.  Offsets 16 and 32 are gfx950's v_permlane16_swap / v_permlane32_swap: with both operands the
+// same register the instruction leaves "my half / row" in one result and "the partner half / row" in the other (which is which depends on
+// the lane, and does not matter: IEEE addition is commutative), so the sum of the two results is acc + partner in every lane -- two VALU
+// moves per 32-bit half and no trip through the LDS crossbar (round 2: ds_swizzle and ds_bpermute, i.e. two dependent LDS round trips per
+// evaluation queued behind the data passes of the CU's other waves).
+template <int OFF>
+__device__ __forceinline__ double xor_sum(double acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (OFF == 16 || OFF == 32) {
+    const uint32_t lo = (uint32_t)f64_bits(acc), hi = (uint32_t)(f64_bits(acc) >> 32);
+    if constexpr (OFF == 32) {
+      const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+      return bits_f64(((uint64_t)h[0] << 32) | (uint64_t)l[0]) + bits_f64(((uint64_t)h[1] << 32) | (uint64_t)l[1]);
+    } else {
+      const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+      return bits_f64(((uint64_t)h[0] << 32) | (uint64_t)l[0]) + bits_f64(((uint64_t)h[1] << 32) | (uint64_t)l[1]);
+    }
+  } else {
+    return acc + xor_partner<OFF>(acc);
+  }
+#else
+  return acc;
+#endif
+}
 template <int OFF, int LIMIT>
 __device__ __forceinline__ double butterfly(double acc) {
-  if constexpr (OFF < LIMIT) { acc = acc + xor_partner<OFF>(acc); return butterfly<OFF * 2, LIMIT>(acc); }
+  if constexpr (OFF < LIMIT) { acc = xor_sum<OFF>(acc); return butterfly<OFF * 2, LIMIT>(acc); }
   else return acc;
 }
 
+// a wave-uniform value the compiler must treat as freshly defined HERE: everything derived from it (loop bounds, block counts, tail masks,
+// base addresses) is then worked out inside the evaluation on the scalar unit -- a few SALU instructions per evaluation, issued beside the
+// other wave's vector work -- instead of being hoisted out of the step loop and carried in scalar registers across all of it
+__device__ __forceinline__ int fresh_uniform(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v = __builtin_amdgcn_readfirstlane(v);      // (folds away when the value is already in a scalar register)
+  asm volatile("" : "+s"(v));
+#endif
+  return v;
+}
+
 template <class Model, int G>
-__device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a, const unsigned char *smem, int sub, CrossWave &xw,
+__device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a0, const unsigned char *smem, int sub, CrossWave &xw,
                                            typename CacheOf<Model>::type &cache) {
+  // (a copy of the argument block's data descriptor with opaque sizes, see fresh_uniform)
+  struct { const ModelConsts &mc; DataRef d; } a{a0.mc, a0.d};
+  a.d.n_obs = fresh_uniform(a0.d.n_obs);
   double acc;
   if constexpr (Model::kUser) {
     // translated closure: the generated body returns this lane's partial sum (lane 0 carries every
     // term outside the lane-split loops), see bayes.js_amd/translate.js
     acc = Model::template eval<G, false>(S, a.d, smem, sub, nullptr);
   } else {
+    if constexpr (TracksState<Model>::value) Model::template load<G>(cache, S, a.mc, a.d, smem, sub);   // first evaluation: fill the register mirror
     const typename Model::Pass ps = Model::template begin<G>(S, a.mc, a.d, smem, cache);
-    const double prior = Model::prior(S, a.mc, a.d);
+    const double prior = Model::prior(S, a.mc, a.d, cache);
     acc = (sub == 0) ? prior : 0.0;
-    if constexpr (Model::kSplitPrior) acc = Model::template prior_split<G>(S, a.mc, a.d, sub, acc);
+    if constexpr (Model::kSplitPrior) acc = Model::template prior_split<G>(S, a.mc, a.d, sub, acc, cache);
     if constexpr (Model::kHasFast) {
       if (ps.fast) acc = Model::template pass_fast<G>(ps, a.d.n_obs, sub, acc);   // hand-pipelined (amwg_models.h norm_pass_staged)
       else acc = pass_over_data<Model, false, G, 2>(ps, a.d.n_obs, sub, acc);      // IEEE '/': rare, kept small
@@ -202,7 +247,13 @@ struct CoopStream {
   int lane_in_chain, base_lane;
   __device__ __forceinline__ void fill() {
     const uint64_t b = b0 + (uint64_t)lane_in_chain;
-    const Philox4 w = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), c2, c3, k0, k1);
+    uint32_t q0 = k0, q1 = k1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the key as an opaque per-lane value: otherwise the compiler precomputes the ten round keys (k + r * W) once and keeps twenty
+    // scalar registers alive across the whole step loop for a function that runs once per 2L uniforms
+    asm volatile("" : "+v"(q0), "+v"(q1));
+#endif
+    const Philox4 w = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), c2, c3, q0, q1);
     w0 = w.w0; w1 = w.w1; w2 = w.w2; w3 = w.w3;
   }
   __device__ __forceinline__ void init(uint64_t seed, uint64_t chain, uint64_t consumed, int tid) {
@@ -216,16 +267,30 @@ struct CoopStream {
   }
   __device__ __forceinline__ uint64_t consumed() const { return 2 * b0 + (uint64_t)pos; }
   __device__ __forceinline__ double next() {
-    if (pos >= 2u * (uint32_t)L) { b0 += (uint64_t)L; pos = 0u; fill(); }      // pos only ever reaches 2L exactly
-    const bool second = (pos & 1u) != 0;
-    uint32_t hi = second ? w2 : w0, lo = second ? w3 : w1;
-    if constexpr (L > 1) {
-      const int src = base_lane + (int)(pos >> 1);
-      hi = (uint32_t)__shfl((int)hi, src, 64);
-      lo = (uint32_t)__shfl((int)lo, src, 64);
+    if constexpr (L == 64) {
+      // the chain IS the wave: the stream position is wave-uniform, so the lane that holds the block is named by a scalar and its words
+      // are read with v_readlane -- no trip through the LDS crossbar (round 2: two ds_bpermute per uniform, a dependent LDS round trip
+      // queued behind the data passes of the CU's other waves, on the critical path of every proposal)
+      uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+      if (p >= 128u) { b0 += 64ull; p = 0u; fill(); }
+      const bool second = (p & 1u) != 0;
+      const int src = (int)(p >> 1);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(second ? w2 : w0), src);
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(second ? w3 : w1), src);
+      pos = p + 1u;
+      return u53(hi, lo);
+    } else {
+      if (pos >= 2u * (uint32_t)L) { b0 += (uint64_t)L; pos = 0u; fill(); }      // pos only ever reaches 2L exactly
+      const bool second = (pos & 1u) != 0;
+      uint32_t hi = second ? w2 : w0, lo = second ? w3 : w1;
+      if constexpr (L > 1) {
+        const int src = base_lane + (int)(pos >> 1);
+        hi = (uint32_t)__shfl((int)hi, src, 64);
+        lo = (uint32_t)__shfl((int)lo, src, 64);
+      }
+      ++pos;
+      return u53(hi, lo);
     }
-    ++pos;
-    return u53(hi, lo);
   }
 };
 
@@ -268,6 +333,36 @@ __device__ __forceinline__ double js_max2(double a, double b) {
   return a > b ? a : b;
 }
 
+// The kernel's argument block, read on demand.  Arguments taken by value are all loaded into scalar registers in the kernel's entry
+// block and stay there until their last use: the dozen per-chain array pointers needed again only by the write-back after the step loop
+// (and at batch boundaries / recorded steps inside it) alone are ~30 SGPRs held across the whole loop, and round 2's kernels carried ~200
+// spilled SGPRs through v_writelane / v_readlane.  cold_args() hands out the same block through the kernarg segment pointer, made opaque
+// at the point of use, so that those fields are fetched (s_load, scalar cache) where they are needed and live nowhere else.
+// Precondition: StepArgs is the kernel's ONLY parameter (true for amwg_step_kernel and for the hiprtc-compiled amwg_user_step).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const StepArgs __attribute__((address_space(4))) *cold_args_ptr;
+__device__ __forceinline__ cold_args_ptr cold_args() {
+  cold_args_ptr p = (cold_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+#else
+typedef const StepArgs *cold_args_ptr;
+__device__ inline cold_args_ptr cold_args() { return nullptr; }
+#endif
+
+// What a slot needs to know about its component, fetched from LDS ONE SLOT AHEAD: which component the next slot updates does not
+// depend on the current accept decision (within a step every component is visited exactly once), so its constants, current value,
+// proposal sd and batch counters are requested before the current evaluation starts and have landed long before they are used --
+// round 2 looked them up at the top of the slot, three dependent LDS round trips on the critical path of every update.
+struct SlotPre {
+  int comp;
+  CompConst k;
+  double cur, sd;
+  int2 cnt;
+  bool adapting;
+};
+
 template <class Model, int G>
 __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem) {
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -278,6 +373,10 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // state copies in this workgroup.  A model with hundreds of components and few lanes per chain may not fit blockDim / G copies in
   // LDS (dim [300] with one lane per chain: 64 x 301 x 28 B): the host then passes a smaller a.cpb, and the lane groups beyond it
   // replicate the workgroup's last chain -- same chain id, hence the same stream, decisions and stores: redundant, never different.
+  // (Replicas are only sound in lockstep, i.e. inside ONE wavefront: the host pairs cpb with 64-thread workgroups, and a launch that
+  // does not is refused here rather than left to race.)
+  if (!kMulti && a.cpb > 0 && nt != 64) return;
+  if (a.n_steps > 65535) return;      // run totals of a launch are 16-bit fields (TOTme); the host chunks launches accordingly
   const int CPB = kMulti ? G / 64 : ((a.cpb > 0 && a.cpb < nt / G) ? a.cpb : nt / G);
   const int c_raw = kMulti ? tid / 64 : tid / G;
   const int c_in = c_raw < CPB ? c_raw : CPB - 1, sub = tid % G;
@@ -313,6 +412,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   const bool live = chain_raw < a.C;
   const int64_t cl = live ? chain_raw : a.C - 1;  // dead lanes shadow the last chain and never store
   const bool writer = live && sub == 0;
+  // the one lane that counts this chain's run totals in LDS (a no-return ds_add: the stepper never waits for the old value); the
+  // replicas of the cpb fallback and the other waves of a multi-wave chain do not count (wave 0's totals are the ones stored)
+  const bool counter = sub == 0 && c_raw < CPB;
   const int64_t C = a.C;
 
   double *Sme = Sblk + (size_t)c_in * L.stride;
@@ -334,16 +436,27 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   __syncthreads();
   if (a.init_lp) lp_curr = log_post<Model, G>(S, a, data_lds, sub, xw, cache);  // ctor warm-up call, mcmc.js:961-963
 
+  // every store to the state goes through here: the LDS copy (what translated closures, gathers and the final write-back read) and,
+  // for models that mirror the state in registers, the mirror
+  auto set_state = [&](int comp, double v) {
+    Sme[comp] = v;
+    if constexpr (TracksState<Model>::value) Model::on_set(cache, comp, v, sub, a.d);
+  };
+
   constexpr int D = Model::kDerived;
   const int PR = P + D;   // recorded values per draw: the parameters, then the closure's derived quantities
   int64_t row = a.row0;
   int32_t next_rec = (int32_t)a.step0;  // host passes steps-until-first-recorded-step here
+  const int P_stepped = a.pl.P_stepped;  // < P when the state has entries this sampler only reads (AMWG_FIXED)
+  const bool recording = a.draws != nullptr;
+  const int n_steps = a.n_steps;
 
-  for (int step = 0; step < a.n_steps; ++step) {
+  for (int step = 0; step < n_steps; ++step) {
     // ---- Sampler.sample: record the state BEFORE the step (mcmc.js:1020-1027)
-    if (a.draws != nullptr && step == next_rec) {
+    if (recording && step == next_rec) {
+      double *const draws = cold_args()->draws;
       if (writer)
-        for (int p = 0; p < P; ++p) a.draws[(row * PR + p) * C + cl] = S(p);
+        for (int p = 0; p < P; ++p) draws[(row * PR + p) * C + cl] = S(p);
       if constexpr (D > 0) {
         // derived quantities (`state.var = ...` inside log_post, mcmc.js:961-963, 990-995): the
         // reference re-evaluates log_post at the end of every step, so what sample() records is the
@@ -351,10 +464,10 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         double dv[D];
         (void)Model::template eval<G, true>(S, a.d, data_lds, sub, dv);
         if (writer)
-          for (int q = 0; q < D; ++q) a.draws[(row * PR + P + q) * C + cl] = dv[q];
+          for (int q = 0; q < D; ++q) draws[(row * PR + P + q) * C + cl] = dv[q];
       }
       ++row;
-      next_rec += a.thin;
+      next_rec += cold_args()->thin;
     }
     // ---- AmwgStepper.step: in-place Durstenfeld shuffle of the named sub-steppers (mcmc.js:887, 228-236)
     for (int i = n_named - 1; i > 0; --i) {
@@ -364,14 +477,15 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     }
     // ---- every scalar component exactly once; `slot` is uniform across the block
     int np = 0, e = 0, e_top = 0, e_in = 0;   // position inside the current parameter: e = e_top * inner + e_in (no division per slot)
-    const int P_stepped = a.pl.P_stepped;  // < P when the state has entries this sampler only reads (AMWG_FIXED)
-    for (int slot = 0; slot < P_stepped; ++slot) {
+    // the component the next slot updates.  Performs the fresh shuffle when a multidimensional parameter begins (mcmc.js:248-252), which
+    // consumes uniforms: it must be called in stream order, i.e. after everything the previous slot draws.
+    auto next_comp = [&]() -> int {
       const int p = wide_perm ? pcol.get(np) : (int)perm_get(perm, np);
       const int len = pl_len[p];
       int comp = pl_base[p];
       if (pl_multidim[p]) {
         const int top = pl_top[p];
-        if (e == 0) {  // fresh shuffle of the top dimension (mcmc.js:248-252)
+        if (e == 0) {
           for (int t = 0; t < top; ++t) idx.set(t, t);
           for (int i = top - 1; i > 0; --i) {
             const int j = (int)__builtin_floor(rng.next() * (double)(i + 1));
@@ -385,62 +499,84 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         if (++e_in == inner) { e_in = 0; ++e_top; }
       }
       if (++e == len) { e = 0; e_top = 0; e_in = 0; ++np; }
-
-      const CompConst k = cc[comp];
-      const int64_t gi = (int64_t)comp * C + cl;
+      return comp;
+    };
+    auto prefetch = [&](int comp) -> SlotPre {
+      SlotPre q;
+      q.comp = comp;
+      q.k = cc[comp];
+      q.cur = Sme[comp];
+      q.sd = SDme[comp];
+      q.cnt = CNTme[comp];
+      q.adapting = adapt[comp] != 0;
+      return q;
+    };
+    SlotPre nx{};
+    if (P_stepped > 0) nx = prefetch(next_comp());
+    for (int slot = 0; slot < P_stepped; ++slot) {
+      const SlotPre me = nx;
+      const int comp = me.comp;
+      const CompConst &k = me.k;
       if (BinaryOf<Model>::value && k.type == kTypeBinary) {   // compiled in only for models that may have binary parameters
         // ---- BinaryStepper.step (mcmc.js:753-767): both states evaluated, 0 chosen with
         // probability exp(z - log(exp(z) + exp(o))) after subtracting the larger log density
-        const double old = S(comp);
-        Sme[comp] = 0.0;
+        const double old = me.cur;
+        set_state(comp, 0.0);
         const double zero_ld = log_post<Model, G>(S, a, data_lds, sub, xw, cache);
-        Sme[comp] = 1.0;
+        set_state(comp, 1.0);
         const double one_ld = log_post<Model, G>(S, a, data_lds, sub, xw, cache);
         const double mx = js_max2(zero_ld, one_ld);
         const double z = zero_ld - mx, o = one_ld - mx;
         const double zero_prob = exp_v8(z - log_v8(exp_v8(z) + exp_v8(o)));
         double now = 1.0;
         lp_curr = one_ld;
-        if (rng.next() < zero_prob) { Sme[comp] = 0.0; now = 0.0; lp_curr = zero_ld; }
-        TOTme[comp] += 1u + ((now != old) ? 0x10000u : 0u);   // run totals: evaluations and flips
+        if (rng.next() < zero_prob) { set_state(comp, 0.0); now = 0.0; lp_curr = zero_ld; }
+        if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + ((now != old) ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // evaluations and flips
+        if (slot + 1 < P_stepped) nx = prefetch(next_comp());
         continue;
       }
       // ---- OnedimMetropolisStepper.step (mcmc.js:517-553)
-      const double cur = S(comp);
-      double prop = rnorm_js(rng, cur, SDme[comp]);
+      const double cur = me.cur;
+      double prop = rnorm_js(rng, cur, me.sd);
       if (k.type == kTypeInt) prop = js_round(prop);
       const bool inb = !(prop < k.lower || prop > k.upper);
+      // the accept test's uniform (mcmc.js:528) is the next one of the stream whatever log_post returns: drawn now
+      double u_accept = 0.0;
+      if (inb) { set_state(comp, prop); u_accept = rng.next(); }
+      // everything this slot draws is drawn: the next slot's component is known (and, if a multidimensional parameter begins there,
+      // shuffled), and what the stepper needs of it is requested NOW, under the evaluation below
+      if (slot + 1 < P_stepped) nx = prefetch(next_comp());
       bool accepted = false;
       if (inb) {
-        Sme[comp] = prop;
-        // the accept test's uniform (mcmc.js:528) is the next one of the stream whatever log_post returns: drawn now, its cross-lane fetch
-        // is over long before the evaluation ends
-        const double u_accept = rng.next();
         const double prop_lp = log_post<Model, G>(S, a, data_lds, sub, xw, cache);
-        const double accept_prob = exp_v8(prop_lp - lp_curr);
-        if (accept_prob > u_accept) {
-          accepted = true;
-          lp_curr = prop_lp;
-        } else {
-          Sme[comp] = cur;
-        }
+        // Math.exp(prop - curr) > Math.random() (mcmc.js:527-528).  For a difference >= 0 (incl. +inf) the exponential is >= 1 > u, below
+        // -746 it is exactly 0 (never > u): the decision is the reference's without evaluating it; NaN takes the general path (false).
+        const double diff = prop_lp - lp_curr;
+        if (diff >= 0.0) accepted = true;
+        else if (diff < -746.0) accepted = false;
+        else accepted = exp_v8(diff) > u_accept;
+        if (accepted) lp_curr = prop_lp;
+        else set_state(comp, cur);
+        if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // run totals (not in the reference; parity tests compare them with the oracle's)
       }
-      if (inb) TOTme[comp] += 1u + (accepted ? 0x10000u : 0u);   // run totals (not in the reference; parity tests compare them with the oracle's)
-      if (adapt[comp] != 0) {
-        int2 cnt = CNTme[comp];
+      if (me.adapting) {
+        int2 cnt = me.cnt;
         cnt.x += accepted ? 1 : 0;      // acceptance_count (mcmc.js:530)
         cnt.y += 1;                     // iterations_since_adaption (mcmc.js:537)
         if ((double)cnt.y >= k.batch_size) {    // batch boundary: the only time batch_count is touched (it stays in HBM)
           // single-wave chains: batch_count and the log scale live in HBM (all lanes of the chain are in lockstep, so they
           // read the old value together before the writer lane stores the new one); multi-wave chains keep per-wave replicas
-          const int32_t bc = (kMulti ? BCme[comp] : a.ch.batch_count[gi]) + 1;
+          const int64_t gi = (int64_t)comp * C + cl;
+          int32_t *const g_bc = kMulti ? nullptr : cold_args()->ch.batch_count;
+          double *const g_pls = kMulti ? nullptr : cold_args()->ch.prop_log_scale;
+          const int32_t bc = (kMulti ? BCme[comp] : g_bc[gi]) + 1;
           const double adj = __builtin_fmin(k.max_adaptation, k.initial_adaptation / __builtin_sqrt((double)bc));
-          double pls = kMulti ? LOGPLSme[comp] : a.ch.prop_log_scale[gi];
+          double pls = kMulti ? LOGPLSme[comp] : g_pls[gi];
           if ((double)cnt.x / k.batch_size > k.target_accept_rate) pls += adj; else pls -= adj;
           cnt = make_int2(0, 0);
           SDme[comp] = exp_v8(pls);
           if constexpr (kMulti) { BCme[comp] = bc; LOGPLSme[comp] = pls; }
-          else if (writer) { a.ch.batch_count[gi] = bc; a.ch.prop_log_scale[gi] = pls; }
+          else if (writer) { g_bc[gi] = bc; g_pls[gi] = pls; }
         }
         CNTme[comp] = cnt;
       }
@@ -448,23 +584,30 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   }
 
   if (writer) {
+    const cold_args_ptr ca = cold_args();
+    double *const o_state = ca->ch.state, *const o_pls = ca->ch.prop_log_scale;
+    int32_t *const o_ac = ca->ch.acceptance_count, *const o_it = ca->ch.iterations_since_adaption, *const o_bc = ca->ch.batch_count;
+    int32_t *const o_acc = ca->ch.accepts, *const o_inb = ca->ch.inbounds;
     for (int p = 0; p < P; ++p) {
-      a.ch.state[p * C + cl] = S(p);
-      a.ch.acceptance_count[p * C + cl] = CNTme[p].x;
-      a.ch.iterations_since_adaption[p * C + cl] = CNTme[p].y;
-      a.ch.accepts[p * C + cl] += (int32_t)(TOTme[p] >> 16);
-      a.ch.inbounds[p * C + cl] += (int32_t)(TOTme[p] & 0xffffu);
-      if constexpr (kMulti) { a.ch.prop_log_scale[p * C + cl] = LOGPLSme[p]; a.ch.batch_count[p * C + cl] = BCme[p]; }
+      o_state[p * C + cl] = S(p);
+      o_ac[p * C + cl] = CNTme[p].x;
+      o_it[p * C + cl] = CNTme[p].y;
+      o_acc[p * C + cl] += (int32_t)(TOTme[p] >> 16);
+      o_inb[p * C + cl] += (int32_t)(TOTme[p] & 0xffffu);
+      if constexpr (kMulti) { o_pls[p * C + cl] = LOGPLSme[p]; o_bc[p * C + cl] = BCme[p]; }
     }
-    if (wide_perm) { for (int k = 0; k < n_named; ++k) a.ch.perm16[(int64_t)k * C + cl] = (uint16_t)pcol.get(k); }
-    else a.ch.perm[cl] = perm;
-    a.ch.rng_n[cl] = rng.consumed();
-    a.ch.lp_curr[cl] = lp_curr;
+    if (wide_perm) { uint16_t *const o_p16 = ca->ch.perm16; for (int k = 0; k < n_named; ++k) o_p16[(int64_t)k * C + cl] = (uint16_t)pcol.get(k); }
+    else ca->ch.perm[cl] = perm;
+    ca->ch.rng_n[cl] = rng.consumed();
+    ca->ch.lp_curr[cl] = lp_curr;
   }
 }
 
-template <class Model, int G>
-__global__ void __launch_bounds__(Model::kMaxThreads) amwg_step_kernel(const StepArgs a) {
+// BT = the workgroup size class the instantiation is compiled for (its register budget): 1024 threads leave 128 VGPRs per lane,
+// 512 leave 256, 256 and fewer 512.  Round 2 compiled everything for 1024 and paid for it with scratch spills inside the slot loop
+// even where the launch used 256- or 512-thread workgroups (cfg2, cfg4).
+template <class Model, int G, int BT>
+__global__ void __launch_bounds__(BT) amwg_step_kernel(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   step_body<Model, G>(a, smem);
 }

@@ -1,0 +1,67 @@
+// amwg_kernels.hip -- the step-kernel instantiations of ONE built-in model family (compiled once per family, -DAMWG_FAMILY=0..3, so the
+// four families build in parallel): amwg_step_kernel<Model, G, BT> for every lane count G and every workgroup size class BT.
+//
+// BT is the register budget the instantiation is compiled for (__launch_bounds__): workgroups of up to 256 threads may use 512
+// VGPRs per lane, 512 threads 256, 1024 threads 128.  A chain on G > 64 lanes is exactly one workgroup of G threads, so those have
+// one class each.  The host (amwg_core.hip, choose_geometry) asks for the kernel of (G, workgroup size) through the lookup below.
+#include <hip/hip_runtime.h>
+
+#include "amwg_kernel.h"
+#include "amwg_models.h"
+#include "amwg_sampler.h"
+
+using namespace amwg;
+
+#if AMWG_FAMILY == 0
+using Family = NormalModel;
+#define AMWG_FAMILY_LOOKUP amwg_kernels_normal
+#elif AMWG_FAMILY == 1
+using Family = BetaBernModel;
+#define AMWG_FAMILY_LOOKUP amwg_kernels_beta_bern
+#elif AMWG_FAMILY == 2
+using Family = HierNormalModel;
+#define AMWG_FAMILY_LOOKUP amwg_kernels_hier_normal
+#elif AMWG_FAMILY == 3
+using Family = PoisGlmModel;
+#define AMWG_FAMILY_LOOKUP amwg_kernels_pois_glm
+#else
+#error "AMWG_FAMILY must be 0..3"
+#endif
+
+namespace {
+
+constexpr int class_of(int block) { return block <= 256 ? 256 : (block <= 512 ? 512 : 1024); }
+
+template <int G>
+step_kernel_t single_wave(int block) {      // G <= 64: any workgroup size up to the family's cap
+  switch (class_of(block)) {
+    case 256: return amwg_step_kernel<Family, G, 256>;
+    case 512: if constexpr (Family::kMaxThreads >= 512) return amwg_step_kernel<Family, G, 512>; else return nullptr;
+    default: if constexpr (Family::kMaxThreads >= 1024) return amwg_step_kernel<Family, G, 1024>; else return nullptr;
+  }
+}
+template <int G>
+step_kernel_t multi_wave(int block) {       // G > 64: one chain = one workgroup of G threads
+  if (block != G) return nullptr;
+  if constexpr (G <= Family::kMaxThreads) return amwg_step_kernel<Family, G, class_of(G)>;
+  else return nullptr;
+}
+
+}  // namespace
+
+step_kernel_t AMWG_FAMILY_LOOKUP(int lanes, int block) {
+  switch (lanes) {
+    case 1: return single_wave<1>(block);
+    case 2: return single_wave<2>(block);
+    case 4: return single_wave<4>(block);
+    case 8: return single_wave<8>(block);
+    case 16: return single_wave<16>(block);
+    case 32: return single_wave<32>(block);
+    case 64: return single_wave<64>(block);
+    case 128: return multi_wave<128>(block);
+    case 256: return multi_wave<256>(block);
+    case 512: return multi_wave<512>(block);
+    case 1024: return multi_wave<1024>(block);
+  }
+  return nullptr;
+}

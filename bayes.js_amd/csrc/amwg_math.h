@@ -17,7 +17,7 @@
 
 #if defined(__HIPCC__)
 #define AMWG_HD __host__ __device__ __forceinline__
-#define AMWG_HD_OUTLINE __host__ __device__ __attribute__((noinline))   // large, rarely executed bodies: one copy per kernel
+#define AMWG_HD_OUTLINE __host__ __device__ inline __attribute__((noinline))   // large, rarely executed bodies: one copy per kernel
 #else
 #define AMWG_HD inline
 #define AMWG_HD_OUTLINE inline

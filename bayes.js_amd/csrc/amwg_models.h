@@ -61,21 +61,31 @@ struct NormalModel {
     double *dst = reinterpret_cast<double *>(smem);
     for (int i = tid; i < d.n_obs; i += nt) dst[i] = d.x[i];
   }
-  __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &) {
+  template <class C>
+  __device__ __forceinline__ static double prior(const StateView &, const ModelConsts &mc, const DataRef &, C &kc) {
     double lp = 0;
-    lp += norm_const_sd(S(0), mc.m0, mc.c0, mc.den0, mc.y0_hi, mc.y0_lo, mc.den0_ok);
-    const double sigma = S(1);
+    lp += norm_const_sd(kc.mu, mc.m0, mc.c0, mc.den0, mc.y0_hi, mc.y0_lo, mc.den0_ok);
+    const double sigma = kc.sigma;
     lp += (sigma < mc.ua || sigma > mc.ub) ? -kInf : mc.lunif;
     return lp;
   }
-  using Cache = NormCache;
-  __device__ __forceinline__ static Cache cache_init() { return norm_cache_init(); }
+  // the chain's two values are mirrored in registers (kept current by on_set): an evaluation does not wait for LDS to hand back what the
+  // stepper has just stored
+  static constexpr bool kTracksState = true;
+  struct Cache { NormCache n; double mu, sigma; bool loaded; };
+  __device__ __forceinline__ static Cache cache_init() { return Cache{norm_cache_init(), 0.0, 0.0, false}; }
+  __device__ __forceinline__ static void on_set(Cache &k, int comp, double v, int, const DataRef &) { if (comp == 0) k.mu = v; else k.sigma = v; }
   template <int GL>
-  __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &mc, const DataRef &d,
-                                               const unsigned char *smem, Cache &k) {
+  __device__ __forceinline__ static void load(Cache &k, const StateView &S, const ModelConsts &, const DataRef &, const unsigned char *, int) {
+    if (!k.loaded) { k.mu = S(0); k.sigma = S(1); k.loaded = true; }
+  }
+  template <int GL>
+  __device__ __forceinline__ static Pass begin(const StateView &, const ModelConsts &mc, const DataRef &d,
+                                               const unsigned char *smem, Cache &kc) {
     Pass ps;
-    ps.mu = S(0);
-    norm_cache_update(k, S(1), mc.neg_half_log_2pi);
+    NormCache &k = kc.n;
+    ps.mu = kc.mu;
+    norm_cache_update(k, kc.sigma, mc.neg_half_log_2pi);
     ps.c = k.c;
     ps.den = k.den;
     ps.y = k.y;
@@ -129,7 +139,8 @@ struct BetaBernModel {
     }
     for (int i = tid; i < d.n_obs; i += nt) smem[i] = d.xb[i];
   }
-  __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &) {
+  template <class C>
+  __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &, C &) {
     const double th = S(0);
     double lp = 0;
     if (th > 1 || th < 0) lp += -kInf;
@@ -275,7 +286,7 @@ struct HierNormalModel {
   static constexpr bool kHasBinary = false;   // real / int parameters only: the BinaryStepper branch is not compiled in
   static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
   static constexpr int kUnroll = 8;
-  struct Pass { double c, den; Reciprocal y; bool fast, lane_const; const double *x; const uint8_t *g; StateView S; };
+  struct Pass { double c, den, th_pass; Reciprocal y; bool fast, lane_const, regs; const double *x; const uint8_t *g; StateView S; };
   __host__ __device__ static size_t lds_bytes(int n_obs, int, int) { return (size_t)n_obs * 8 + (((size_t)n_obs + 15) & ~(size_t)15); }
   __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int) {
     double *dst = reinterpret_cast<double *>(smem);
@@ -285,26 +296,58 @@ struct HierNormalModel {
   // Lane order of the priors (the same a translated closure gets, translate.js): lane 0 adds the terms outside
   // loops -- mu, sigma -- and the `for k` loop over the group means is dealt to the lanes like the data loop.
   static constexpr bool kSplitPrior = true;
-  __device__ __forceinline__ static double prior(const StateView &S, const ModelConsts &mc, const DataRef &d) {
-    const double mu = S(d.G), sigma = S(d.G + 1);
+  // Register mirror of the chain's state (kept current by on_set), usable when the chain's L = min(lanes, 64) lanes inside a wave are at
+  // least as many as the groups and every lane meets one group only (ModelConsts::group_lane_const): lane j of the chain then holds
+  // theta[j] (its prior term, its share of the range check) and theta[g[j]] (the mean of ITS observations), every lane mu and sigma --
+  // an evaluation reads nothing of the state from LDS.  Round 2 read mu, sigma, theta[k], the label and theta[label] back from LDS in
+  // every evaluation: four dependent round trips behind the data passes of the CU's other waves.
+  static constexpr bool kTracksState = true;
+  struct Cache { NormCache n; double th_own, th_pass, mu, sigma; int my_group; bool regs, loaded; };
+  __device__ __forceinline__ static Cache cache_init() { return Cache{norm_cache_init(), 0.0, 0.0, 0.0, 0.0, -1, false, false}; }
+  template <int GL>
+  __device__ __forceinline__ static void load(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
+    if (k.loaded) return;
+    constexpr int L = GL < 64 ? GL : 64;
+    k.loaded = true;
+    k.regs = mc.group_lane_const != 0 && d.G <= L;
+    const int j = sub & (L - 1);
+    k.mu = S(d.G);
+    k.sigma = S(d.G + 1);
+    k.my_group = (k.regs && sub < d.n_obs) ? (int)(smem + (size_t)d.n_obs * 8)[sub] : -1;
+    k.th_own = (k.regs && j < d.G) ? S(j) : 0.0;
+    k.th_pass = k.my_group >= 0 ? S(k.my_group) : 0.0;
+  }
+  __device__ __forceinline__ static void on_set(Cache &k, int comp, double v, int sub, const DataRef &d) {
+    if (comp < d.G) {
+      if (comp == (sub & 63)) k.th_own = v;      // (regs: groups <= L <= 64, so the lane's own index inside the chain is sub mod L = comp only if < L)
+      if (comp == k.my_group) k.th_pass = v;
+    } else if (comp == d.G) k.mu = v;
+    else k.sigma = v;
+  }
+  template <class C>
+  __device__ __forceinline__ static double prior(const StateView &, const ModelConsts &mc, const DataRef &, C &k) {
+    const double mu = k.mu, sigma = k.sigma;
     double lp = 0;
     lp += norm_const_sd(mu, mc.m0, mc.c0, mc.den0, mc.y0_hi, mc.y0_lo, mc.den0_ok);
     lp += (sigma < mc.ua || sigma > mc.ub) ? -kInf : mc.lunif;
     return lp;
   }
-  template <int G>
-  __device__ __forceinline__ static double prior_split(const StateView &S, const ModelConsts &mc, const DataRef &d, int sub, double acc) {
-    const double mu = S(d.G);
-    for (int k = sub; k < d.G; k += G) acc += norm_const_sd(S(k), mu, mc.c1, mc.den1, mc.y1_hi, mc.y1_lo, mc.den1_ok);
+  template <int G, class C>
+  __device__ __forceinline__ static double prior_split(const StateView &S, const ModelConsts &mc, const DataRef &d, int sub, double acc, C &k) {
+    const double mu = k.mu;
+    if (k.regs) {      // groups <= lanes: at most one term per lane, theta[sub] from the mirror
+      if (sub < d.G) acc += norm_const_sd(k.th_own, mu, mc.c1, mc.den1, mc.y1_hi, mc.y1_lo, mc.den1_ok);
+      return acc;
+    }
+    for (int q = sub; q < d.G; q += G) acc += norm_const_sd(S(q), mu, mc.c1, mc.den1, mc.y1_hi, mc.y1_lo, mc.den1_ok);
     return acc;
   }
-  using Cache = NormCache;
-  __device__ __forceinline__ static Cache cache_init() { return norm_cache_init(); }
   template <int GL>
   __device__ __forceinline__ static Pass begin(const StateView &S, const ModelConsts &mc, const DataRef &d,
-                                               const unsigned char *smem, Cache &kc) {
+                                               const unsigned char *smem, Cache &k) {
     Pass ps;
-    norm_cache_update(kc, S(d.G + 1), mc.neg_half_log_2pi);
+    NormCache &kc = k.n;
+    norm_cache_update(kc, k.sigma, mc.neg_half_log_2pi);
     ps.c = kc.c;
     ps.den = kc.den;
     ps.y = kc.y;
@@ -315,7 +358,8 @@ struct HierNormalModel {
       constexpr int L = GL < 64 ? GL : 64;
       const int lane = (int)(threadIdx.x & 63u), sub_in_wave = lane & (L - 1);
       bool mine = true;
-      for (int k = sub_in_wave; k < d.G; k += L) { const double th = S(k); mine = mine && (th == 0 || mid_range(__builtin_fabs(th))); }
+      if (k.regs) { if (sub_in_wave < d.G) { const double th = k.th_own; mine = th == 0 || mid_range(__builtin_fabs(th)); } }
+      else for (int q = sub_in_wave; q < d.G; q += L) { const double th = S(q); mine = mine && (th == 0 || mid_range(__builtin_fabs(th))); }
       if constexpr (L == 1) ok = ok && mine;
       else {
         const uint64_t all = __ballot(mine);
@@ -328,6 +372,8 @@ struct HierNormalModel {
     ps.g = smem + (size_t)d.n_obs * 8;
     ps.S = S;
     ps.lane_const = mc.group_lane_const != 0;
+    ps.regs = k.regs;
+    ps.th_pass = k.th_pass;
     return ps;
   }
   template <bool FAST>
@@ -345,7 +391,7 @@ struct HierNormalModel {
   template <int G>
   __device__ __forceinline__ static double pass_fast(const Pass &ps, int n_obs, int sub, double acc) {
     if (ps.lane_const) {
-      const double m = sub < n_obs ? ps.S(ps.g[sub]) : 0.0;
+      const double m = ps.regs ? ps.th_pass : (sub < n_obs ? ps.S(ps.g[sub]) : 0.0);
       return norm_pass_staged<G, 8, false>(ps.x, nullptr, ps.S, m, ps.c, ps.den, ps.y, n_obs, sub, acc);
     }
     return norm_pass_staged<G, 4, true>(ps.x, ps.g, ps.S, 0.0, ps.c, ps.den, ps.y, n_obs, sub, acc);
@@ -371,9 +417,10 @@ struct PoisGlmModel {
   __device__ static void stage(unsigned char *, const DataRef &, int, int, int) {}
   // closure order: `for k` over the 8 coefficients (dealt to the lanes), then the change point's prior (lane 0), then the data
   static constexpr bool kSplitPrior = true;
-  __device__ __forceinline__ static double prior(const StateView &, const ModelConsts &, const DataRef &) { return 0.0; }
-  template <int G>
-  __device__ __forceinline__ static double prior_split(const StateView &S, const ModelConsts &mc, const DataRef &, int sub, double acc) {
+  template <class C>
+  __device__ __forceinline__ static double prior(const StateView &, const ModelConsts &, const DataRef &, C &) { return 0.0; }
+  template <int G, class C>
+  __device__ __forceinline__ static double prior_split(const StateView &S, const ModelConsts &mc, const DataRef &, int sub, double acc, C &) {
     for (int k = sub; k < 8; k += G) acc += norm_const_sd(S(k), mc.m0, mc.c0, mc.den0, mc.y0_hi, mc.y0_lo, mc.den0_ok);
     if (sub == 0) {
       const double cp = S(8);

@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""tools/isa_audit.py -- what the gfx950 compiler made of the step kernels (no GPU needed).
+
+Compiles bayes.js_amd/csrc/amwg_kernels.hip (once per built-in family) to device assembly (hipcc --cuda-device-only -S, ~30 s; or reads
+existing .s files with --asm) and reports per `amwg_step_kernel<Model, G, BT>` instantiation:
+  * the code object metadata: VGPRs, SGPRs, vgpr/sgpr spill counts, scratch bytes, the workgroup size it was compiled for;
+  * static instruction counts INSIDE LOOPS (between a label and the last backward branch to it): scratch_* (spilled VGPRs / private
+    arrays), v_readlane / v_writelane (how spilled SGPRs travel), s_waitcnt, VALU -- the per-update code of a kernel is all inside
+    the step loop, so anything counted here is paid per update;
+and FAILS (exit 1) if a BENCHED instantiation (--gate, default: the four the bench times) has scratch traffic in a loop, any VGPR
+spill, or more than --max-lane-moves v_readlane/v_writelane in its loops.
+
+    python tools/isa_audit.py                 # compile + audit + gate
+    python tools/isa_audit.py --asm /tmp/core.s --all
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "bayes.js_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function --cuda-device-only -S".split()
+
+# the instantiations bench.py times (model, lanes per chain); any workgroup size of those is gated
+DEFAULT_GATE = ["NormalModel,1,256", "HierNormalModel,64,512", "HierNormalModel,32,1024", "PoisGlmModel,64,256", "BetaBernModel,1,1024"]
+
+
+def compile_asm(family):
+    """device assembly of the step kernels of one built-in family (amwg_kernels.hip -DAMWG_FAMILY=n)"""
+    out = os.path.join(tempfile.gettempdir(), "amwg_kernels_%d.s" % family)
+    subprocess.check_call([HIPCC] + FLAGS + ["-DAMWG_FAMILY=%d" % family, "-o", out, "amwg_kernels.hip"], cwd=CSRC, stderr=subprocess.DEVNULL)
+    return out
+
+
+def demangle(names):
+    p = subprocess.run(["c++filt"] + names, capture_output=True, text=True)
+    return p.stdout.splitlines() if p.returncode == 0 else names
+
+
+def kernel_metadata(txt):
+    m = re.search(r"amdhsa\.kernels:(.*?)amdhsa\.target", txt, re.S)
+    out = {}
+    for k in re.split(r"\n  - ", m.group(1)):
+        name = re.search(r"\.name:\s+(\S+)", k)
+        if not name:
+            continue
+        g = lambda f: int((re.search(r"\.%s:\s+(\d+)" % f, k) or [0, 0])[1])
+        out[name.group(1)] = {"vgpr": g("vgpr_count"), "agpr": g("agpr_count"), "sgpr": g("sgpr_count"), "vgpr_spill": g("vgpr_spill_count"),
+                              "sgpr_spill": g("sgpr_spill_count"), "scratch_bytes": g("private_segment_fixed_size"),
+                              "max_workgroup": g("max_flat_workgroup_size"), "lds_static": g("group_segment_fixed_size")}
+    return out
+
+
+def kernel_bodies(txt):
+    """mangled name -> list of asm lines of the function body"""
+    bodies, cur, name = {}, None, None
+    for line in txt.splitlines():
+        m = re.match(r"^(_Z\w+):\s*(;.*)?$", line)
+        if m and cur is None:
+            name, cur = m.group(1), []
+            continue
+        if cur is not None:
+            if line.startswith(".Lfunc_end") or re.match(r"^\s*\.end_amdhsa_kernel", line):
+                bodies[name] = cur
+                cur = None
+            else:
+                cur.append(line)
+    return bodies
+
+
+def loop_stats(lines):
+    """static counts inside loops: a loop = [label .. last backward branch to that label]"""
+    labels, ins = {}, []
+    for ln in lines:
+        s = ln.split(";")[0].strip()
+        if not s:
+            continue
+        m = re.match(r"^(\.L\w+):", s)
+        if m:
+            labels[m.group(1)] = len(ins)
+            continue
+        if s.startswith("."):
+            continue
+        ins.append(s)
+    in_loop = [0] * (len(ins) + 1)
+    depth_marks = []
+    for i, s in enumerate(ins):
+        m = re.match(r"^s_c?branch\w*\s+(\.L\w+)", s)
+        if m and m.group(1) in labels and labels[m.group(1)] <= i:
+            depth_marks.append((labels[m.group(1)], i))
+    covered = [False] * len(ins)
+    for a, b in depth_marks:
+        for i in range(a, b + 1):
+            covered[i] = True
+    cnt = {"instructions": 0, "scratch": 0, "lane_moves": 0, "waitcnt": 0, "valu": 0, "valu_f64": 0, "ds": 0, "global": 0, "smem": 0}
+    tot = dict(cnt)
+    for i, s in enumerate(ins):
+        op = s.split()[0]
+        for d in ((cnt, tot) if covered[i] else (tot,)):
+            d["instructions"] += 1
+            if op.startswith("scratch_") or op.startswith("buffer_") and "offen" in s and "s[0:3]" in s:
+                d["scratch"] += 1
+            elif op in ("v_readlane_b32", "v_writelane_b32"):
+                d["lane_moves"] += 1
+            elif op == "s_waitcnt":
+                d["waitcnt"] += 1
+            elif op.startswith("v_"):
+                d["valu"] += 1
+                if "f64" in op:
+                    d["valu_f64"] += 1
+            elif op.startswith("ds_"):
+                d["ds"] += 1
+            elif op.startswith("global_") or op.startswith("flat_"):
+                d["global"] += 1
+            elif op.startswith("s_load") or op.startswith("s_buffer_load"):
+                d["smem"] += 1
+    return {"in_loops": cnt, "whole_kernel": tot, "loops": len(depth_marks)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--asm", nargs="*", help="existing device assembly files (else amwg_kernels.hip is compiled for --families)")
+    ap.add_argument("--families", nargs="*", type=int, default=[0, 1, 2, 3], help="0 Normal, 1 BetaBern, 2 HierNormal, 3 PoisGlm")
+    ap.add_argument("--all", action="store_true", help="print every step-kernel instantiation, not only the gated ones")
+    ap.add_argument("--gate", nargs="*", default=DEFAULT_GATE)
+    ap.add_argument("--max-lane-moves", type=int, default=16)
+    ap.add_argument("--json", help="write the table here")
+    args = ap.parse_args()
+    if args.asm:
+        asms = args.asm
+    else:
+        import concurrent.futures
+        with concurrent.futures.ThreadPoolExecutor(4) as ex:
+            asms = list(ex.map(compile_asm, args.families))
+    rows, bad = [], []
+    for asm in asms:
+        txt = open(asm).read()
+        meta, bodies = kernel_metadata(txt), kernel_bodies(txt)
+        names = [n for n in meta if "amwg_step_kernel" in n or "amwg_user_step" in n]
+        for n, d in zip(names, demangle(names)):
+            short = re.sub(r"^void amwg::amwg_step_kernel<amwg::(.*)>\(.*$", r"\1", d).replace(" ", "")
+            st = loop_stats(bodies.get(n, []))
+            row = {"kernel": short, **meta[n], **{"loop_" + k: v for k, v in st["in_loops"].items()}, "total_instructions": st["whole_kernel"]["instructions"]}
+            rows.append(row)
+            gated = any(short.startswith(g + ",") or short == g for g in args.gate)
+            row["gated"] = gated
+            if gated:
+                why = []
+                if row["vgpr_spill"]:
+                    why.append("vgpr_spill_count %d" % row["vgpr_spill"])
+                if row["loop_scratch"]:
+                    why.append("%d scratch instructions inside loops" % row["loop_scratch"])
+                if row["loop_lane_moves"] > args.max_lane_moves:
+                    why.append("%d v_readlane/v_writelane inside loops (> %d)" % (row["loop_lane_moves"], args.max_lane_moves))
+                if why:
+                    bad.append((short, why))
+    rows.sort(key=lambda r: r["kernel"])
+    hdr = "%-34s %5s %5s %6s %6s %7s %6s | %7s %7s %7s %7s %7s" % ("kernel<Model,G,BT>", "vgpr", "sgpr", "vspill", "sspill", "scratch", "maxwg", "l.instr", "l.valu", "l.scr", "l.lane", "l.wait")
+    print(hdr)
+    for r in rows:
+        if args.all or r["gated"]:
+            print("%-34s %5d %5d %6d %6d %7d %6d | %7d %7d %7d %7d %7d%s" % (r["kernel"], r["vgpr"], r["sgpr"], r["vgpr_spill"], r["sgpr_spill"], r["scratch_bytes"], r["max_workgroup"],
+                  r["loop_instructions"], r["loop_valu"], r["loop_scratch"], r["loop_lane_moves"], r["loop_waitcnt"], "  <- gated" if r["gated"] else ""))
+    if args.json:
+        json.dump(rows, open(args.json, "w"), indent=1)
+    if bad:
+        for k, why in bad:
+            print("FAIL %s: %s" % (k, "; ".join(why)))
+        sys.exit(1)
+    print("isa audit ok: %d gated instantiations free of scratch traffic and SGPR-spill lane moves in their loops" % sum(r["gated"] for r in rows))
+
+
+if __name__ == "__main__":
+    main()
