@@ -111,9 +111,9 @@ struct NoCache {};
 template <class M, class = void> struct CacheOf { using type = NoCache; static __device__ __forceinline__ type init() { return type{}; } };
 template <class M> struct CacheOf<M, void_of<typename M::Cache>> { using type = typename M::Cache; static __device__ __forceinline__ type init() { return M::cache_init(); } };
 
-// acc + (the value of lane ^ OFF): the xor butterfly of a chain's partial sums.  Offsets 1, 2 (quad permutes), 4 and 8 (row mirrors) are DPP
-// moves in the VALU -- no trip through the LDS crossbar, whose queue the data passes of the CU's other waves keep full; 16 is a swizzle
-// without an address register; 32 stays a permute.  Every lane still adds the same two numbers in the same order as with __shfl_xor.
+// The value a lane of the xor butterfly adds at offset OFF: that of lane ^ OFF or, for OFF = 4 and 8, of another lane of the same partner
+// group (which holds the same bits at that stage).  Offsets 1, 2 (quad permutes), 4 and 8 (row mirrors) are single DPP moves in the VALU --
+// no trip through the LDS crossbar; 16 and 32 are handled in xor_sum.  Every lane adds the same two numbers as with __shfl_xor.
 template <int OFF>
 __device__ __forceinline__ double xor_partner(double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -122,12 +122,11 @@ __device__ __forceinline__ double xor_partner(double v) {
     lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
   } else if constexpr (OFF == 2) {   // quad_perm [2,3,0,1]
     lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
-  } else if constexpr (OFF == 4) {   // row_half_mirror (i -> 7 - i within 8), then quad_perm [3,2,1,0]: i -> i ^ 4
-    lo = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
-  } else if constexpr (OFF == 8) {   // row_mirror (i -> 15 - i within 16), then row_half_mirror: i -> i ^ 8
-    lo = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true), 0x141, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true), 0x141, 0xF, 0xF, true);
+  } else if constexpr (OFF == 4) {   // row_half_mirror (i -> 7 - i within 8): a lane of the partner quad -- inside the butterfly all four lanes of a
+                                     // quad hold the same sum by now (IEEE addition is commutative), so any of them is "the" partner
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true);
+  } else if constexpr (OFF == 8) {   // row_mirror (i -> 15 - i within 16): a lane of the partner group of eight, likewise
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true);
   } else if constexpr (OFF == 16) {  // ds_swizzle, bit-mask mode: lane' = (lane & 0x1f) ^ 0x10 within each half of the wave
     lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F); hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
   } else {
@@ -168,6 +167,16 @@ __device__ __forceinline__ double butterfly(double acc) {
   else return acc;
 }
 
+#ifndef AMWG_STEPPER_PRIORITY
+#define AMWG_STEPPER_PRIORITY 2
+#endif
+constexpr int kStepperPriority = AMWG_STEPPER_PRIORITY;
+__device__ __forceinline__ void wave_priority(int p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (kStepperPriority > 0) { if (p == 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(kStepperPriority); }
+#endif
+}
+
 // a wave-uniform value the compiler must treat as freshly defined HERE: everything derived from it (loop bounds, block counts, tail masks,
 // base addresses) is then worked out inside the evaluation on the scalar unit -- a few SALU instructions per evaluation, issued beside the
 // other wave's vector work -- instead of being hoisted out of the step loop and carried in scalar registers across all of it
@@ -196,6 +205,12 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
     const double prior = Model::prior(S, a.mc, a.d, cache);
     acc = (sub == 0) ? prior : 0.0;
     if constexpr (Model::kSplitPrior) acc = Model::template prior_split<G>(S, a.mc, a.d, sub, acc, cache);
+    // Issue priority: the stepper around this point is one long dependent chain (a wave alone issues an instruction every ~8 cycles in it),
+    // the data pass below is hundreds of independent instructions.  With equal priorities the SIMD's arbiter favours the OLDER wave, so a
+    // younger wave's stepper starves behind an older wave's pass and the two waves of a SIMD end up in their steppers together, leaving the
+    // fp64 pipe half idle.  A wave therefore runs its stepper at raised priority (set at the top of the step loop) and drops to 0 for the
+    // pass: whoever is in a stepper issues the moment it can, the partner's pass fills every other slot.
+    wave_priority(0);
     if constexpr (Model::kHasFast) {
       if (ps.fast) acc = Model::template pass_fast<G>(ps, a.d.n_obs, sub, acc);   // hand-pipelined (amwg_models.h norm_pass_staged)
       else acc = pass_over_data<Model, false, G, 2>(ps, a.d.n_obs, sub, acc);      // IEEE '/': rare, kept small
@@ -208,6 +223,7 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
       if (ps.has_invalid) acc = acc + (-kInf);   // some x_i outside {0,1}: that term is -inf wherever it sits in the sum
     }
   }
+  wave_priority(kStepperPriority);
   acc = butterfly<1, (G < 64 ? G : 64)>(acc);
   if constexpr (G > 64) {
     constexpr int WV = G / 64;
@@ -357,11 +373,20 @@ __device__ inline cold_args_ptr cold_args() { return nullptr; }
 // round 2 looked them up at the top of the slot, three dependent LDS round trips on the critical path of every update.
 struct SlotPre {
   int comp;
-  CompConst k;
-  double cur, sd;
+  double cur, sd, batch_size;
   int2 cnt;
   bool adapting;
 };
+
+// a value every lane of the chain holds alike; for a chain on a whole wave (G >= 64) it is moved to a scalar register, so that what is
+// derived from it (table addresses, loop counters, branch conditions) runs on the scalar unit beside the vector work
+template <int G>
+__device__ __forceinline__ int chain_uniform(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (G >= 64) return __builtin_amdgcn_readfirstlane(v);
+#endif
+  return v;
+}
 
 template <class Model, int G>
 __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem) {
@@ -451,6 +476,13 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   const bool recording = a.draws != nullptr;
   const int n_steps = a.n_steps;
 
+  // order of the top-level entries of the multidimensional parameter being walked (mcmc.js:244-263): a column of the LDS index table, or
+  // -- a chain on a whole wave and no leading dimension beyond 64 -- one entry per lane of the wave (`ord`), shuffled and read with
+  // v_readlane / selects: no LDS round trip in the shuffle's 31 dependent swaps nor in the per-slot lookup
+  const int lane64 = tid & 63;
+  int ord = lane64;
+  const bool ord_in_regs = G >= 64 && a.pl.max_top <= 64;
+  wave_priority(kStepperPriority);
   for (int step = 0; step < n_steps; ++step) {
     // ---- Sampler.sample: record the state BEFORE the step (mcmc.js:1020-1027)
     if (recording && step == next_rec) {
@@ -477,37 +509,63 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     }
     // ---- every scalar component exactly once; `slot` is uniform across the block
     int np = 0, e = 0, e_top = 0, e_in = 0;   // position inside the current parameter: e = e_top * inner + e_in (no division per slot)
+    // descriptor of the parameter being walked, read from the LDS tables once, when the parameter begins (round 2 re-read it in every
+    // slot: a dependent LDS round trip per update in front of the component lookup)
+    int d_len = 1, d_base = 0, d_multi = 0, d_inner = 1;
     // the component the next slot updates.  Performs the fresh shuffle when a multidimensional parameter begins (mcmc.js:248-252), which
     // consumes uniforms: it must be called in stream order, i.e. after everything the previous slot draws.
     auto next_comp = [&]() -> int {
-      const int p = wide_perm ? pcol.get(np) : (int)perm_get(perm, np);
-      const int len = pl_len[p];
-      int comp = pl_base[p];
-      if (pl_multidim[p]) {
-        const int top = pl_top[p];
-        if (e == 0) {
-          for (int t = 0; t < top; ++t) idx.set(t, t);
-          for (int i = top - 1; i > 0; --i) {
-            const int j = (int)__builtin_floor(rng.next() * (double)(i + 1));
-            const int ti = idx.get(i);
-            idx.set(i, idx.get(j));
-            idx.set(j, ti);
+      if (e == 0) {
+        const int p = chain_uniform<G>(wide_perm ? pcol.get(np) : (int)perm_get(perm, np));
+        d_len = chain_uniform<G>(pl_len[p]);
+        d_base = chain_uniform<G>(pl_base[p]);
+        d_multi = chain_uniform<G>(pl_multidim[p]);
+        if (d_multi) {
+          const int top = chain_uniform<G>(pl_top[p]);
+          d_inner = chain_uniform<G>(pl_inner[p]);
+          if (ord_in_regs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (G >= 64) {
+              ord = lane64;
+              for (int i = top - 1; i > 0; --i) {
+                const int j = __builtin_amdgcn_readfirstlane((int)__builtin_floor(rng.next() * (double)(i + 1)));
+                const int ti = __builtin_amdgcn_readlane(ord, i), tj = __builtin_amdgcn_readlane(ord, j);
+                ord = lane64 == i ? tj : (lane64 == j ? ti : ord);
+              }
+            }
+#endif
+          } else {
+            for (int t = 0; t < top; ++t) idx.set(t, t);
+            for (int i = top - 1; i > 0; --i) {
+              const int j = (int)__builtin_floor(rng.next() * (double)(i + 1));
+              const int ti = idx.get(i);
+              idx.set(i, idx.get(j));
+              idx.set(j, ti);
+            }
           }
         }
-        const int inner = pl_inner[p];
-        comp += idx.get(e_top) * inner + e_in;
-        if (++e_in == inner) { e_in = 0; ++e_top; }
       }
-      if (++e == len) { e = 0; e_top = 0; e_in = 0; ++np; }
+      int comp = d_base;
+      if (d_multi) {
+        int t = 0;
+        if (ord_in_regs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          if constexpr (G >= 64) t = __builtin_amdgcn_readlane(ord, __builtin_amdgcn_readfirstlane(e_top));
+#endif
+        } else t = idx.get(e_top);
+        comp += t * d_inner + e_in;
+        if (++e_in == d_inner) { e_in = 0; ++e_top; }
+      }
+      if (++e == d_len) { e = 0; e_top = 0; e_in = 0; ++np; }
       return comp;
     };
     auto prefetch = [&](int comp) -> SlotPre {
       SlotPre q;
       q.comp = comp;
-      q.k = cc[comp];
       q.cur = Sme[comp];
       q.sd = SDme[comp];
       q.cnt = CNTme[comp];
+      q.batch_size = cc[comp].batch_size;
       q.adapting = adapt[comp] != 0;
       return q;
     };
@@ -516,8 +574,10 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     for (int slot = 0; slot < P_stepped; ++slot) {
       const SlotPre me = nx;
       const int comp = me.comp;
-      const CompConst &k = me.k;
-      if (BinaryOf<Model>::value && k.type == kTypeBinary) {   // compiled in only for models that may have binary parameters
+      // bounds and type: requested now, needed after the proposal is drawn (the adaptation constants only at a batch boundary)
+      const double k_lower = cc[comp].lower, k_upper = cc[comp].upper;
+      const int k_type = cc[comp].type;
+      if (BinaryOf<Model>::value && k_type == kTypeBinary) {   // compiled in only for models that may have binary parameters
         // ---- BinaryStepper.step (mcmc.js:753-767): both states evaluated, 0 chosen with
         // probability exp(z - log(exp(z) + exp(o))) after subtracting the larger log density
         const double old = me.cur;
@@ -538,8 +598,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       // ---- OnedimMetropolisStepper.step (mcmc.js:517-553)
       const double cur = me.cur;
       double prop = rnorm_js(rng, cur, me.sd);
-      if (k.type == kTypeInt) prop = js_round(prop);
-      const bool inb = !(prop < k.lower || prop > k.upper);
+      if (k_type == kTypeInt) prop = js_round(prop);
+      const bool inb = !(prop < k_lower || prop > k_upper);
       // the accept test's uniform (mcmc.js:528) is the next one of the stream whatever log_post returns: drawn now
       double u_accept = 0.0;
       if (inb) { set_state(comp, prop); u_accept = rng.next(); }
@@ -563,7 +623,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         int2 cnt = me.cnt;
         cnt.x += accepted ? 1 : 0;      // acceptance_count (mcmc.js:530)
         cnt.y += 1;                     // iterations_since_adaption (mcmc.js:537)
-        if ((double)cnt.y >= k.batch_size) {    // batch boundary: the only time batch_count is touched (it stays in HBM)
+        if ((double)cnt.y >= me.batch_size) {    // batch boundary: the only time batch_count is touched (it stays in HBM)
+          const CompConst k = cc[comp];
           // single-wave chains: batch_count and the log scale live in HBM (all lanes of the chain are in lockstep, so they
           // read the old value together before the writer lane stores the new one); multi-wave chains keep per-wave replicas
           const int64_t gi = (int64_t)comp * C + cl;

@@ -74,7 +74,7 @@ struct NormalModel {
   static constexpr bool kTracksState = true;
   struct Cache { NormCache n; double mu, sigma; bool loaded; };
   __device__ __forceinline__ static Cache cache_init() { return Cache{norm_cache_init(), 0.0, 0.0, false}; }
-  __device__ __forceinline__ static void on_set(Cache &k, int comp, double v, int, const DataRef &) { if (comp == 0) k.mu = v; else k.sigma = v; }
+  __device__ __forceinline__ static void on_set(Cache &k, int comp, double v, int, const DataRef &) { k.mu = comp == 0 ? v : k.mu; k.sigma = comp == 0 ? k.sigma : v; }
   template <int GL>
   __device__ __forceinline__ static void load(Cache &k, const StateView &S, const ModelConsts &, const DataRef &, const unsigned char *, int) {
     if (!k.loaded) { k.mu = S(0); k.sigma = S(1); k.loaded = true; }
@@ -318,11 +318,12 @@ struct HierNormalModel {
     k.th_pass = k.my_group >= 0 ? S(k.my_group) : 0.0;
   }
   __device__ __forceinline__ static void on_set(Cache &k, int comp, double v, int sub, const DataRef &d) {
-    if (comp < d.G) {
-      if (comp == (sub & 63)) k.th_own = v;      // (regs: groups <= L <= 64, so the lane's own index inside the chain is sub mod L = comp only if < L)
-      if (comp == k.my_group) k.th_pass = v;
-    } else if (comp == d.G) k.mu = v;
-    else k.sigma = v;
+    // selects, not stores under branches: the compiler merges `if (c) k.mu = v; else k.sigma = v;` into ONE store through a selected
+    // address, which pins the whole cache to scratch memory (a VMEM round trip in every evaluation: round 2's 132 B of scratch)
+    k.th_own = (comp == (sub & 63)) ? v : k.th_own;     // (only read when groups <= L <= 64: the lane's own index inside the chain is sub mod L)
+    k.th_pass = (comp == k.my_group) ? v : k.th_pass;
+    k.mu = (comp == d.G) ? v : k.mu;
+    k.sigma = (comp == d.G + 1) ? v : k.sigma;
   }
   template <class C>
   __device__ __forceinline__ static double prior(const StateView &, const ModelConsts &mc, const DataRef &, C &k) {

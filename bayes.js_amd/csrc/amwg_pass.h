@@ -156,7 +156,23 @@ AMWG_HD double norm_pass_staged(const XT *x, const uint8_t *g, const StateView S
   // runs the eight stages on U slots, slots beyond its own count re-read its last valid observation, and only the first cnt terms are
   // added -- in the same order as before (whole rounds first, the remainder observation last).
   const int left = n_full - k;                              // 0 .. U-1, uniform
-  if (left > 0 || rem > 0) {
+  if (left + (rem > 0 ? 1 : 0) <= U / 2 + 1) {
+    // a few terms only (e.g. 10^4 observations on 64 lanes: 19 blocks, then 4 rounds and a quarter): term by term -- (left + 1) x 8
+    // instructions instead of the 8 x U + selects of the masked block below.  The chain of dependent operations this leaves is latency the
+    // SIMD's other wave fills; with few waves per SIMD and longer tails the masked block is the better trade.
+    for (int r = k; r < n_full; ++r) {
+      const int i = r * G + sub;
+      const double t = (double)x[i] - (GATHER ? S(g[i]) : mean);
+      acc = acc + (c - div_by_invariant(t * t, den, y));
+    }
+    if (rem > 0) {
+      int i = n_full * G + sub;
+      i = i < n_obs ? i : n_obs - 1;
+      const double t = (double)x[i] - (GATHER ? S(g[i]) : mean);
+      const double term = c - div_by_invariant(t * t, den, y);
+      acc = sub < rem ? acc + term : acc;
+    }
+  } else if (left > 0 || rem > 0) {
     const int cnt = left + (sub < rem ? 1 : 0);             // this lane's terms: 0 .. U
     NormBlock<U> xt, qt;
     double mt[U];
