@@ -188,12 +188,13 @@ __device__ __forceinline__ int fresh_uniform(int v) {
   return v;
 }
 
-template <class Model, int G>
+template <class Model, int G, int U = 8>
 __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a0, const unsigned char *smem, int sub, CrossWave &xw,
                                            typename CacheOf<Model>::type &cache) {
   // (a copy of the argument block's data descriptor with opaque sizes, see fresh_uniform)
   struct { const ModelConsts &mc; DataRef d; } a{a0.mc, a0.d};
   a.d.n_obs = fresh_uniform(a0.d.n_obs);
+  a.d.G = fresh_uniform(a0.d.G);
   double acc;
   if constexpr (Model::kUser) {
     // translated closure: the generated body returns this lane's partial sum (lane 0 carries every
@@ -212,8 +213,8 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
     // pass: whoever is in a stepper issues the moment it can, the partner's pass fills every other slot.
     wave_priority(0);
     if constexpr (Model::kHasFast) {
-      if (ps.fast) acc = Model::template pass_fast<G>(ps, a.d.n_obs, sub, acc);   // hand-pipelined (amwg_models.h norm_pass_staged)
-      else acc = pass_over_data<Model, false, G, 2>(ps, a.d.n_obs, sub, acc);      // IEEE '/': rare, kept small
+      if (ps.fast) acc = Model::template pass_fast<G, U>(ps, a.d.n_obs, sub, acc);   // hand-pipelined (amwg_models.h norm_pass_staged)
+      else acc = Model::template pass_slow<G>(ps, a.d.n_obs, sub, acc);            // IEEE '/': rare, out of line
     } else if constexpr (Model::kOneLanePass && G == 1) {
       acc = Model::pass_one_lane(ps, a.d.n_obs, acc);
     } else {
@@ -261,15 +262,13 @@ struct CoopStream {
   uint32_t pos;         // uniforms consumed since block b0 (0 .. 2L): the stream position is 2*b0 + pos -- 32-bit bookkeeping per draw
   uint32_t w0, w1, w2, w3;
   int lane_in_chain, base_lane;
+  // one Philox block per lane, OUT OF LINE: ~85 instructions that run once per 2L uniforms but would otherwise be inlined at every one of
+  // the stepper's eight draw sites (a tenth of the kernel's code, all of it on the path the instruction cache has to hold)
+  static __device__ __attribute__((noinline)) Philox4 block(uint64_t b, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    return philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), c2, c3, k0, k1);
+  }
   __device__ __forceinline__ void fill() {
-    const uint64_t b = b0 + (uint64_t)lane_in_chain;
-    uint32_t q0 = k0, q1 = k1;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // the key as an opaque per-lane value: otherwise the compiler precomputes the ten round keys (k + r * W) once and keeps twenty
-    // scalar registers alive across the whole step loop for a function that runs once per 2L uniforms
-    asm volatile("" : "+v"(q0), "+v"(q1));
-#endif
-    const Philox4 w = philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), c2, c3, q0, q1);
+    const Philox4 w = block(b0 + (uint64_t)lane_in_chain, c2, c3, k0, k1);
     w0 = w.w0; w1 = w.w1; w2 = w.w2; w3 = w.w3;
   }
   __device__ __forceinline__ void init(uint64_t seed, uint64_t chain, uint64_t consumed, int tid) {
@@ -319,7 +318,7 @@ __device__ __forceinline__ double rnorm_js(Rng &rng, double mean, double sd) {  
     const double x = u - 0.449871;
     const double y = __builtin_fabs(v) + 0.386595;
     q = x * x + y * (0.19600 * y - 0.25472 * x);
-  } while (q > 0.27597 && (q > 0.27846 || v * v > -4 * log_v8(u) * u * u));
+  } while (q > 0.27597 && (q > 0.27846 || v * v > -4 * log_v8_cold(u) * u * u));
   return (v / u) * sd + mean;
 }
 
@@ -388,8 +387,12 @@ __device__ __forceinline__ int chain_uniform(int v) {
   return v;
 }
 
-template <class Model, int G>
+// BT: the workgroup size class the caller is compiled for (its register budget, see amwg_step_kernel); 1024-thread workgroups leave 128
+// VGPRs per lane, and with four waves per SIMD the staged pass does not need eight observations in flight per lane to keep the pipe busy:
+// it runs four-wide there (same operations in the same order, half the registers).
+template <class Model, int G, int BT = 256>
 __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem) {
+  constexpr int kPassU = BT >= 1024 ? 4 : 8;
   const int tid = threadIdx.x, nt = blockDim.x;
   // G <= 64: nt/G chains per workgroup, each on G lanes of one wave.  G > 64 ("multi"): ONE chain per workgroup on G/64
   // waves; every wave is a full replica of the chain's scalar logic (same Philox stream => same proposals and decisions)
@@ -459,7 +462,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid);
   double lp_curr = a.ch.lp_curr[cl];
   __syncthreads();
-  if (a.init_lp) lp_curr = log_post<Model, G>(S, a, data_lds, sub, xw, cache);  // ctor warm-up call, mcmc.js:961-963
+  if (a.init_lp) lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);  // ctor warm-up call, mcmc.js:961-963
 
   // every store to the state goes through here: the LDS copy (what translated closures, gathers and the final write-back read) and,
   // for models that mirror the state in registers, the mirror
@@ -582,9 +585,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         // probability exp(z - log(exp(z) + exp(o))) after subtracting the larger log density
         const double old = me.cur;
         set_state(comp, 0.0);
-        const double zero_ld = log_post<Model, G>(S, a, data_lds, sub, xw, cache);
+        const double zero_ld = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);
         set_state(comp, 1.0);
-        const double one_ld = log_post<Model, G>(S, a, data_lds, sub, xw, cache);
+        const double one_ld = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);
         const double mx = js_max2(zero_ld, one_ld);
         const double z = zero_ld - mx, o = one_ld - mx;
         const double zero_prob = exp_v8(z - log_v8(exp_v8(z) + exp_v8(o)));
@@ -608,7 +611,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       if (slot + 1 < P_stepped) nx = prefetch(next_comp());
       bool accepted = false;
       if (inb) {
-        const double prop_lp = log_post<Model, G>(S, a, data_lds, sub, xw, cache);
+        const double prop_lp = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);
         // Math.exp(prop - curr) > Math.random() (mcmc.js:527-528).  For a difference >= 0 (incl. +inf) the exponential is >= 1 > u, below
         // -746 it is exactly 0 (never > u): the decision is the reference's without evaluating it; NaN takes the general path (false).
         const double diff = prop_lp - lp_curr;
@@ -635,7 +638,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           double pls = kMulti ? LOGPLSme[comp] : g_pls[gi];
           if ((double)cnt.x / k.batch_size > k.target_accept_rate) pls += adj; else pls -= adj;
           cnt = make_int2(0, 0);
-          SDme[comp] = exp_v8(pls);
+          SDme[comp] = exp_v8_cold(pls);
           if constexpr (kMulti) { BCme[comp] = bc; LOGPLSme[comp] = pls; }
           else if (writer) { g_bc[gi] = bc; g_pls[gi] = pls; }
         }
@@ -670,7 +673,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
 template <class Model, int G, int BT>
 __global__ void __launch_bounds__(BT) amwg_step_kernel(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  step_body<Model, G>(a, smem);
+  step_body<Model, G, BT>(a, smem);
 }
 
 }  // namespace amwg

@@ -33,14 +33,18 @@ struct NormCache {
   bool den_ok;
 };
 __device__ __forceinline__ NormCache norm_cache_init() { return NormCache{__builtin_nan(""), 0.0, 0.0, Reciprocal{0.0, 0.0}, false}; }
+// (out of line and by value: V8's log and an IEEE division, reached once per change of sd -- one update in 34 of the hierarchical model)
+AMWG_HD_OUTLINE NormCache norm_cache_make(double sd, double neg_half_log_2pi) {
+  NormCache k;
+  k.sd = sd;
+  k.c = norm_c(neg_half_log_2pi, sd);
+  k.den = norm_den(sd);
+  k.y = make_reciprocal(k.den);
+  k.den_ok = mid_range(k.den);
+  return k;
+}
 __device__ __forceinline__ void norm_cache_update(NormCache &k, double sd, double neg_half_log_2pi) {
-  if (sd != k.sd) {
-    k.sd = sd;
-    k.c = norm_c(neg_half_log_2pi, sd);
-    k.den = norm_den(sd);
-    k.y = make_reciprocal(k.den);
-    k.den_ok = mid_range(k.den);
-  }
+  if (sd != k.sd) k = norm_cache_make(sd, neg_half_log_2pi);
 }
 
 
@@ -100,12 +104,21 @@ struct NormalModel {
     const double tt = t * t;
     return ps.c - (FAST ? div_by_invariant(tt, ps.den, ps.y) : tt / ps.den);
   }
+  // the term-by-term pass with IEEE division, for evaluations whose values fall outside the range the 4-operation quotient needs: out of
+  // line (scalar arguments, so that nothing travels through the stack), its code and registers are not part of the hot loop
+  template <int G>
+  __device__ inline __attribute__((noinline)) static double pass_slow_impl(const double *x, double mu, double c, double den, int n_obs, int sub, double acc) {
+    for (int i = sub; i < n_obs; i += G) { const double t = x[i] - mu; acc += c - (t * t) / den; }
+    return acc;
+  }
+  template <int G>
+  __device__ __forceinline__ static double pass_slow(const Pass &ps, int n_obs, int sub, double acc) { return pass_slow_impl<G>(ps.x, ps.mu, ps.c, ps.den, n_obs, sub, acc); }
   // the fast pass, hand-pipelined (same operations and order as term<true> summed by pass_over_data)
   static constexpr bool kStagedFast = true;
-  template <int G>
+  template <int G, int U = 8>
   __device__ __forceinline__ static double pass_fast(const Pass &ps, int n_obs, int sub, double acc) {
     if constexpr (G == 1) return norm_pass_uniform<8>(ps.x, ps.mu, ps.c, ps.den, ps.y, n_obs, acc);   // ps.x = the global array
-    else return norm_pass_staged<G, 8, false>(ps.x, nullptr, StateView{nullptr}, ps.mu, ps.c, ps.den, ps.y, n_obs, sub, acc);
+    else return norm_pass_staged<G, U, false>(ps.x, nullptr, StateView{nullptr}, ps.mu, ps.c, ps.den, ps.y, n_obs, sub, acc);
   }
 };
 
@@ -383,19 +396,32 @@ struct HierNormalModel {
     const double tt = t * t;
     return ps.c - (FAST ? div_by_invariant(tt, ps.den, ps.y) : tt / ps.den);
   }
+  template <int G>
+  __device__ inline __attribute__((noinline)) static double pass_slow_impl(const double *x, const uint8_t *g, const StateView S, double c, double den, int n_obs, int sub, double acc) {
+    for (int i = sub; i < n_obs; i += G) { const double t = x[i] - S(g[i]); acc += c - (t * t) / den; }
+    return acc;
+  }
+  template <int G>
+  __device__ __forceinline__ static double pass_slow(const Pass &ps, int n_obs, int sub, double acc) { return pass_slow_impl<G>(ps.x, ps.g, ps.S, ps.c, ps.den, n_obs, sub, acc); }
   // the fast pass, hand-pipelined: group indices two blocks ahead, y and theta[g] one block ahead of the arithmetic
   static constexpr bool kStagedFast = true;
   // When the group labels repeat with the lane stride (g[i] == g[i % G], checked once on the host: ModelConsts::group_lane_const --
   // e.g. the balanced design g_i = i mod 32 on 64 lanes) a lane meets one group only: its mean is read once and the pass is the
   // constant-mean one (no index reads, no gather: 8.1 instead of 9.4 VALU and 1 instead of 2.5 LDS reads per observation -- the
   // gathered pass keeps the LDS pipe of a CU ~95 % busy).  Same operations on the same values in the same order either way.
-  template <int G>
+  template <int G, int U = 8>
   __device__ __forceinline__ static double pass_fast(const Pass &ps, int n_obs, int sub, double acc) {
     if (ps.lane_const) {
       const double m = ps.regs ? ps.th_pass : (sub < n_obs ? ps.S(ps.g[sub]) : 0.0);
-      return norm_pass_staged<G, 8, false>(ps.x, nullptr, ps.S, m, ps.c, ps.den, ps.y, n_obs, sub, acc);
+      return norm_pass_staged<G, U, false>(ps.x, nullptr, ps.S, m, ps.c, ps.den, ps.y, n_obs, sub, acc);
     }
-    return norm_pass_staged<G, 4, true>(ps.x, ps.g, ps.S, 0.0, ps.c, ps.den, ps.y, n_obs, sub, acc);
+    return pass_gathered<G>(ps.x, ps.g, ps.S, ps.c, ps.den, ps.y, n_obs, sub, acc);
+  }
+  // (out of line: a design whose labels do not repeat with the lane stride runs this one instead of the constant-mean pass -- never both)
+  template <int G>
+  __device__ inline __attribute__((noinline)) static double pass_gathered(const double *x, const uint8_t *g, const StateView S, double c, double den, Reciprocal y,
+                                                                         int n_obs, int sub, double acc) {
+    return norm_pass_staged<G, 4, true>(x, g, S, 0.0, c, den, y, n_obs, sub, acc);
   }
 };
 
