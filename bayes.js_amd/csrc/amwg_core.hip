@@ -465,6 +465,10 @@ static int build_layout(amwg_sampler *s, const amwg_param_desc *params, int n_pa
     if (fixed_seen) return fail(AMWG_EINVAL, "parameter %d: stepped parameters must come before the AMWG_FIXED entries", p);
     if (q.type != AMWG_REAL && q.type != AMWG_INT && q.type != AMWG_BINARY)
       return fail(AMWG_EINVAL, "AmwgStepper can't handle parameter %d with type %d", p, q.type);   // mcmc.js:867
+    // the built-in families' kernels are compiled without the BinaryStepper branch (none of them has a binary parameter): a binary
+    // parameter there would silently be stepped by the Metropolis stepper instead of mcmc.js:753-767 -- refuse it
+    if (q.type == AMWG_BINARY && !allow_fixed)
+      return fail(AMWG_EINVAL, "parameter %d: the built-in model families have no binary parameters (BinaryStepper runs for translated closures, amwg_create_user)", p);
     if (n_stepped >= kMaxIndex) return fail(AMWG_EINVAL, "more than %d stepped parameters", kMaxIndex);
     if (q.len < 1 || q.top < 1 || q.len % q.top) return fail(AMWG_EINVAL, "parameter %d: bad dim (len %d, top %d)", p, q.len, q.top);
     if (q.top > kMaxIndex) return fail(AMWG_EINVAL, "parameter %d: leading dimension %d > %d", p, q.top, kMaxIndex);

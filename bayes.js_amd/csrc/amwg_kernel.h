@@ -612,6 +612,11 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       bool accepted = false;
       if (inb) {
         const double prop_lp = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the next slot's prefetched values are "used" HERE: the wait for them lands right behind the pass's own LDS reads (which returned
+        // after them -- no stall), instead of at the top of the next slot behind this slot's closing stores and counter update
+        asm volatile("" : : "v"(nx.cur), "v"(nx.sd), "v"(nx.batch_size), "v"(nx.cnt.x), "v"(nx.cnt.y), "v"((int)nx.adapting));
+#endif
         // Math.exp(prop - curr) > Math.random() (mcmc.js:527-528).  For a difference >= 0 (incl. +inf) the exponential is >= 1 > u, below
         // -746 it is exactly 0 (never > u): the decision is the reference's without evaluating it; NaN takes the general path (false).
         const double diff = prop_lp - lp_curr;

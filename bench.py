@@ -70,7 +70,7 @@ OTHER_WORKLOADS = {
     # the one number the reference publishes (README.md:252): Normal model, 1000 data points, 20 000 draws
     # "~0.5 s" = 8.0e4 param-updates/s on the author's machine -- ONE chain, so this measures single-chain latency
     "readme": ("normal", 1_000, 1, 1_000 * 8 + 8 * 2 + 8, 8, "README.md:252 claim: Normal(mu,sigma), 1000 obs, ONE chain (run with --steps 20000)"),
-    "cfg5": ("pois_glm", 50_000, 8_192, 50_000 * (7 * 8 + 8 + 8) + 8 * 9 + 8, 127, "BASELINE.json configs[4]: Poisson GLM + int change point, 5e4 obs, 8192 chains per GPU (65536 over 8)"),
+    "cfg5": ("pois_glm", 50_000, 8_192, 50_000 * (7 * 8 + 8 + 8) + 8 * 9 + 8, 88, "BASELINE.json configs[4]: Poisson GLM + int change point, 5e4 obs, 8192 chains per GPU (65536 over 8)"),
 }
 
 
@@ -79,8 +79,11 @@ OPS_NOTE = {
     "normal": "8 = sub, mul, 4-operation correctly rounded quotient (amwg_div.h: mul, fma, fma, fma), sub, add; IEEE '/' would be 17",
     "hier_normal": "8 = sub, mul, 4-operation correctly rounded quotient, sub, add (the gather of theta[g_i] is an LDS read, not arithmetic)",
     "beta_bern": "1 = the fp64 add of the term-by-term pass (the observation selects WHICH register is added, on the scalar unit)",
-    "pois_glm": "127 = VALU instructions ISSUED per observation (rocprofv3, profiles/r01g): 7 fma of the linear predictor, V8's exp and log "
-                "(fdlibm, ~50 each incl. their correctly rounded quotients), 4 for the density; an issue count, not a minimal operation count",
+    "pois_glm": "88 = the fp64 operations the expression needs, none of which can go without changing a rounding the reference performs: 14 linear "
+                "predictor (7 mul + 7 add, no contraction), 2 change point (int->double, add), 32 V8 exp (4 reduction k, 5 hi/lo/r/rr, 10 polynomial, 13 "
+                "quotient form incl. the 8-operation r*c/(2-c)), 36 V8 log (3 f/dk/2+f, 8 quotient, 14 polynomials, 11 the selected tail), 4 density + "
+                "accumulate.  ISSUED per observation (rocprofv3, utilisation, not the roofline's unit): ~134 incl. integer/select/address work and the "
+                "second log tail the straight-line form computes",
 }
 
 
@@ -185,50 +188,122 @@ def cpu_baseline_all_cores(spec, single_rate, budget_s=2.0, max_threads=32):
             "sample": "oracle/amwg_oracle.c, %d independent chains on %d threads (of %d usable), %d steps each (%.1f s); ours, not the reference" % (cores, cores, usable, n, dt)}
 
 
-def parity_gate(A, spec, timed_lanes):
-    """next to the speed, the proof that this build reproduces the reference.  The first and the
-    last chain id of the bench job, same seed and data, against the seeded run of the UNMODIFIED reference stored in
-    tests/golden/cfg2_full.json (a committed fixture; nothing here reads /root/reference): with one lane per chain (the
-    reference's summation order) every draw must be bit-identical; with the lane count of the TIMED configuration, if that
-    differs, the accept counts must still be identical.  If the timed configuration is not the one-lane one, the whole job is
-    also timed in reference order for 100 steps."""
+GOLDEN_OF = {"cfg2": "cfg2_full", "cfg3": "cfg3_full", "cfg4": "cfg4_full", "cfg5": "cfg5_full"}
+
+
+def golden_schedule_check(s, gold, locals_and_records, lanes):
+    """Runs the golden case's schedule ON THE GIVEN (full-size) SAMPLER -- device-resident draws -- and compares the listed local chains with
+    the seeded run of the unmodified reference stored in tests/golden/<case>.json: accept counts, in-bounds counts, adaptation state and
+    uniforms consumed always (the reference's decisions); with one lane per chain (the reference's summation order) also every stored
+    draw, the running sums over all kept draws and the final state, bit for bit.  -> dict of booleans."""
+    import torch
+    case = gold["case"]
+    P, C = s.P, s.C
+    seg_draws = []
+    for seg in case["schedule"]:
+        if seg["op"] == "burn":
+            s.burn(seg["n"])
+        elif seg["op"] == "sample":
+            thin = seg.get("thin", 1)
+            rows = -(-seg["n"] // thin)
+            d = torch.empty((rows, P, C), dtype=torch.float64, device="cuda")
+            s.sample_device(seg["n"], thin, d.data_ptr(), d.numel() * 8)
+            s.sync()
+            seg_draws.append(d)
+    info, diag, state = s.info(), s.diag(), s.state()
+    ok = {"accept_counts_identical": True, "uniforms_consumed_identical": True, "adaptation_state_identical": True}
+    if lanes == 1:
+        ok.update({"draws_bit_identical": True, "running_sums_bit_identical": True, "final_state_bit_identical": True})
+    for local, rec in locals_and_records:
+        ok["accept_counts_identical"] &= info["accepts"][:, local].tolist() == rec["accepts"] and info["inbounds"][:, local].tolist() == rec["inbounds"]
+        ok["uniforms_consumed_identical"] &= int(diag["uniforms"][local]) == rec["uniforms"]
+        ok["adaptation_state_identical"] &= (info["batch_count"][:, local].tolist() == rec["batch_count"] and
+                                              info["acceptance_count"][:, local].tolist() == rec["acceptance_count"])
+        if lanes == 1:
+            ok["adaptation_state_identical"] &= info["prop_log_scale"][:, local].tolist() == rec["prop_log_scale"]
+            ok["final_state_bit_identical"] &= state[:, local].tolist() == rec["final_state"]
+            for d, want in zip(seg_draws, rec["samples"]):
+                col = d[:, :, local].cpu().numpy()                      # (rows, P) of ONE chain
+                w = np.array(want["draws"], dtype=np.float64).reshape(-1, P)
+                ok["draws_bit_identical"] &= col.shape[0] == want["kept"] and np.ascontiguousarray(col[: w.shape[0]]).tobytes() == w.tobytes()
+                tot = np.zeros(P)
+                for t in range(col.shape[0]):
+                    tot = tot + col[t]
+                ok["running_sums_bit_identical"] &= tot.tolist() == want["sum"]
+    del seg_draws
+    return {k: bool(v) for k, v in ok.items()}
+
+
+def timed_geometry_parity(A, spec, workload, chains, make_sampler, lanes):
+    """BASELINE.md section 3, item 6 / round-2 review: the bit-for-bit proof taken OUT OF THE FULL-SIZE SAMPLER that is timed -- same chain
+    count, workgroup geometry and lane count as the timed launches.  `make_sampler(chain_offset)` builds it; the golden's chain ids are
+    global, so a chain id beyond this GPU's shard is looked up in the shard that holds it (cfg4: chain 16383 = the last chain of the 8th
+    shard of 2048).  Returns (report, the sampler of shard 0 -- advanced by the golden schedule, reused as the timed one)."""
     import golden_io
-    gold = golden_io.load("cfg2_full")
+    gold = golden_io.load(GOLDEN_OF[workload])
+    first, report, checked = None, None, []
+    by_shard = {}
+    for rec in gold["chains"]:
+        by_shard.setdefault(rec["chain"] // chains, []).append(rec)
+    for shard in sorted(by_shard):
+        smp = make_sampler(shard * chains)
+        r = golden_schedule_check(smp, gold, [(rec["chain"] - shard * chains, rec) for rec in by_shard[shard]], lanes)
+        checked += [rec["chain"] for rec in by_shard[shard]]
+        report = r if report is None else {k: report[k] and r[k] for k in r}
+        if shard == 0:
+            first = smp
+        else:
+            smp.close()
+    sched = gold["case"]["schedule"]
+    report.update({"golden": "tests/golden/%s.json (seeded run of the unmodified reference)" % GOLDEN_OF[workload], "chains_checked": checked,
+                   "schedule": sched, "from_timed_sampler": True, "chains_in_sampler": chains, "lanes_per_chain": lanes,
+                   "reference_order": lanes == 1,
+                   "note": ("one lane per chain: every draw of every chain is the reference's, bit for bit" if lanes == 1 else
+                            "%d lanes per chain: the sum over observations is formed in lane order, so doubles are compared with the oracle in the same "
+                            "order by the test suite; here: every accept decision, adaptation step and uniform count equals the reference's" % lanes)})
+    return report, first
 
-    def run(lanes):
-        ok_acc = ok_state = ok_draws = True
-        for rec in gold["chains"]:
-            s = A.Sampler(spec, chains=1, seed=gold["case"]["seed"], chain_offset=rec["chain"], lanes_per_chain=lanes)
-            draws = None
-            for seg in gold["case"]["schedule"]:
-                if seg["op"] == "burn":
-                    s.burn(seg["n"])
-                else:
-                    draws = s.sample(seg["n"], seg.get("thin", 1))
-            want = np.array(rec["samples"][0]["draws"], dtype=np.float64)
-            ok_draws = ok_draws and np.ascontiguousarray(draws[: want.shape[0], :, 0]).tobytes() == want.tobytes()
-            ok_acc = ok_acc and s.info()["accepts"][:, 0].tolist() == rec["accepts"]
-            ok_state = ok_state and s.state()[:, 0].tolist() == rec["final_state"]
-            s.close()
-        return bool(ok_draws), bool(ok_acc), bool(ok_state)
 
-    ok_draws, ok_acc, ok_state = run(1)
-    out = {"golden": "tests/golden/cfg2_full.json (seeded run of the unmodified reference, chains 0 and 65535, burn 500 + sample 500)",
-           "lanes_per_chain": 1, "draws_bit_identical": ok_draws, "accept_counts_identical": ok_acc, "final_state_bit_identical": ok_state,
-           "timed_lanes_per_chain": timed_lanes, "timed_configuration_is_reference_order": timed_lanes == 1}
-    if timed_lanes != 1:
-        d2, a2, _ = run(timed_lanes)
-        out["timed_lanes_accept_counts_identical"] = a2
-        out["timed_lanes_draws_bit_identical"] = d2
-        s = A.Sampler(spec, chains=CHAINS_PER_GPU, seed=SEED, lanes_per_chain=1, steps_per_launch=100)
-        s.burn(300)
-        s.burn(100)
-        out["reference_order_value"] = CHAINS_PER_GPU * 100 * spec["P"] / (s.launch_info()["kernel_ms"] * 1e-3)
-        s.close()
-        out["note"] = ("reference_order_value = param-updates/s of the same 65536-chain job with one lane per chain, i.e. every chain in the "
-                       "reference's exact summation order (bit-identical draws); the timed configuration splits a chain's sum over %d lanes" % timed_lanes)
-    else:
-        out["note"] = "the timed configuration runs one lane per chain: every draw of every chain is the reference's, bit for bit"
+def measure_other_config(A, name, device):
+    """A short driver-visible measurement of one of the other BASELINE.json configs at its per-GPU size: golden check out of the full-size
+    sampler, then HIP-event time of adapted launches.  -> dict for the bench line's `other_configs`."""
+    fam, n_obs, chains, b_alg, ops_per_obs, label = OTHER_WORKLOADS[name]
+    spec = other_spec(name, A.lib().amwg_exp)
+    P = spec["P"]
+    mk = lambda off: A.Sampler(spec, chains=chains, seed=SEED, chain_offset=off, device=device, steps_per_launch=100)
+    probe = mk(0)
+    lanes = probe.launch_info()["lanes_per_chain"]
+    probe.close()
+    t0 = time.perf_counter()
+    parity, s = timed_geometry_parity(A, spec, name, chains, mk, lanes)
+    # adapted steady state: the golden schedule has already stepped the chains; a little more, then the timed launches
+    per_step = chains * P
+    warm = {"cfg3": 300, "cfg4": 400, "cfg5": 20}[name]
+    timed = {"cfg3": 300, "cfg4": 600, "cfg5": 20}[name]
+    s.burn(warm)
+    s.burn(timed)
+    li = s.launch_info()
+    kernel_s = li["kernel_ms"] * 1e-3
+    value = per_step * timed / kernel_s
+    out = {"workload": label, "value": value, "unit": "param-updates/s", "chains": chains, "n_obs": n_obs, "components": P, "steps_timed": timed,
+           "timing": "HIP events around the %d launches of one burn(%d) call after the golden schedule + %d more steps" % (li["n_launches"], timed, warm),
+           "lanes_per_chain": li["lanes_per_chain"], "block_threads": li["block_threads"], "grid_blocks": li["grid_blocks"], "parity": parity}
+    roof_updates_per_s, kernel, note = value, "amwg_step_kernel<%s,%d>" % ({"beta_bern": "BetaBernModel", "hier_normal": "HierNormalModel", "pois_glm": "PoisGlmModel"}[fam], lanes), None
+    if name == "cfg3":
+        t = A.Sampler(spec, chains=chains, seed=SEED, device=device, lanes_per_chain=1, steps_per_launch=20, exact_division=1)
+        t.burn(40)
+        t.burn(20)
+        roof_updates_per_s = chains * 20 * P / (t.launch_info()["kernel_ms"] * 1e-3)
+        t.close()
+        kernel += " term-by-term pass (exact_division = 1)"
+        note = ("roofline = the term-by-term pass (1 fp64 add per observation), %.3g param-updates/s; `value` is the exact fast-forward of the same two-valued "
+                "sum (bit-identical), which does not stream the data" % roof_updates_per_s)
+    lane_ops = roof_updates_per_s * n_obs * ops_per_obs
+    out["roofline"] = {"bound": "fp64_valu", "achieved": lane_ops, "peak": FP64_VALU_PEAK, "frac": lane_ops / FP64_VALU_PEAK, "unit": "fp64 lane-operations/s",
+                       "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[fam], "kernel": kernel, "note": note,
+                       "effective_hbm_gbps": value * b_alg / 1e9}
+    out["seconds"] = time.perf_counter() - t0
+    s.close()
     return out
 
 
@@ -245,6 +320,7 @@ def main():
                     help="steps fused into one kernel launch; warm-up and timed steps use the same launch size so the "
                          "per-launch time bench.py reports is comparable with rocprofv3's per-kernel average")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short measurements of cfg3 / cfg4 / cfg5 appended to the default line")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K-step region until this much time is on the clock (median reported)")
     ap.add_argument("--single-region", action="store_true", help="time the K-step region once (profiling runs)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "readme"],
@@ -290,8 +366,17 @@ def main():
             args.chains_per_gpu = default_chains
     chains = args.chains_per_gpu
     offset, _ = chain_shard(rank, world, chains * world)
-    s = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=dev_index,
-                  lanes_per_chain=args.lanes, block_threads=args.block, steps_per_launch=args.steps_per_launch)
+    mk = lambda off: A.Sampler(spec, chains=chains, seed=SEED, chain_offset=off, device=dev_index,
+                               lanes_per_chain=args.lanes, block_threads=args.block, steps_per_launch=args.steps_per_launch)
+    parity = None
+    if world == 1 and args.workload in GOLDEN_OF:
+        # the proof that this build reproduces the reference, taken from the sampler that is timed below (its first steps ARE the golden schedule)
+        probe = mk(0)
+        timed_lanes = probe.launch_info()["lanes_per_chain"]
+        probe.close()
+        parity, s = timed_geometry_parity(A, spec, args.workload, chains, mk, timed_lanes)
+    else:
+        s = mk(offset)
     P, K, W, thin = spec["P"], args.steps, args.warmup, max(1, args.thin)
     rows = -(-K // thin)
     draws = torch.empty((rows, P, chains), dtype=torch.float64, device="cuda")
@@ -401,8 +486,15 @@ def main():
             "posterior": {"mean": mean.tolist()[:8], "sd": sd.tolist()[:8], "data_mean": float(np.mean(x)), "data_sd": float(np.std(x, ddof=1)),
                           "note": "moments over the recorded draws of the last region on ALL ranks (all-reduce of per-rank sums for N > 1; after %d warm-up + %d timed steps)" % (W, K * (len(regions) - 1))},
         }
-        if world == 1 and args.workload == "cfg2":
-            out["parity"] = parity_gate(A, spec, li["lanes_per_chain"])
+        if parity is not None:
+            out["parity"] = parity
+        if world == 1 and args.workload == "cfg2" and not args.no_other_configs:
+            out["other_configs"] = {}
+            for name in ("cfg3", "cfg4", "cfg5"):
+                try:
+                    out["other_configs"][name] = measure_other_config(A, name, dev_index)
+                except Exception as e:      # a failure here must not cost the headline line
+                    out["other_configs"][name] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             ref = cpu_baseline_reference(args.workload)
             out["cpu_baseline"] = ref if ref is not None else cpu_baseline_port(spec)

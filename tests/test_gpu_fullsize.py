@@ -112,3 +112,30 @@ def test_cfg5_poisson_glm_runs_and_moves_towards_the_truth():
     info = smp.info()
     assert np.all(info["accepts"] <= info["inbounds"]) and np.all(info["inbounds"] <= 400)
     smp.close()
+
+
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3", "cfg4", "cfg5"])
+def test_chains_taken_out_of_the_timed_full_size_sampler_match_the_reference(workload):
+    """The geometry bench.py times (65 536 chains x 256 workgroups for cfg2, 262 144 for cfg3, 2 048 per GPU on 64 lanes for cfg4, 8 192 for
+    cfg5), not a 3-chain stand-in: the golden schedule is run ON the full-size sampler and the golden's chain ids (first and last of the
+    job; for cfg4 the last one lives in the 8th shard) are read out of it -- bit-identical draws / sums / state with one lane per chain,
+    identical decisions, adaptation state and uniform counts with more (mcmc.js:1020-1027, 517-553)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    if workload == "cfg2":
+        spec, chains = bench.normal_spec(), bench.CHAINS_PER_GPU
+    else:
+        spec, chains = bench.other_spec(workload, A.lib().amwg_exp), bench.OTHER_WORKLOADS[workload][2]
+    mk = lambda off: A.Sampler(spec, chains=chains, seed=bench.SEED, chain_offset=off, steps_per_launch=100)
+    probe = mk(0)
+    lanes = probe.launch_info()["lanes_per_chain"]
+    probe.close()
+    report, s = bench.timed_geometry_parity(A, spec, workload, chains, mk, lanes)
+    s.close()
+    assert report["from_timed_sampler"] and report["chains_in_sampler"] == chains
+    for k, v in report.items():
+        if k.endswith("_identical"):
+            assert v is True, (k, report)
+    if workload in ("cfg2", "cfg3"):
+        assert lanes == 1 and report["draws_bit_identical"] and report["final_state_bit_identical"]

@@ -50,8 +50,9 @@ def test_one_lane_per_chain_is_bit_identical_to_reference(name):
         s.close()
 
 
-@pytest.mark.parametrize("name", ["cfg1_heights", "normal_n1000", "normal_opts", "beta_bern_n2000", "hier_small", "glm_small"])
-@pytest.mark.parametrize("lanes", [2, 4, 8, 16, 32, 64])
+@pytest.mark.parametrize("name,lanes", [(n, l) for n in ["cfg1_heights", "normal_n1000", "normal_opts", "beta_bern_n2000", "hier_small", "glm_small"]
+                                        for l in [2, 4, 8, 16, 32, 64]] +
+                         [("cfg4_full", 64), ("cfg4_full", 32), ("cfg5_full", 64)])      # the full-size cases at the lane counts the bench times
 def test_g_lanes_per_chain_matches_oracle_and_reference_decisions(name, lanes):
     gold = golden_io.load(name)
     case = gold["case"]
@@ -273,3 +274,13 @@ def test_run_totals_survive_launches_longer_than_their_16_bit_launch_counters():
     o.burn(70_000)
     assert info["accepts"][:, 0].tolist() == o.info()["accepts"].tolist() and s.state()[:, 0].tolist() == o.state().tolist()
     s.close()
+
+
+def test_binary_parameter_on_a_built_in_family_is_refused():
+    """The built-in kernels are compiled without the BinaryStepper branch; through the C ABI a binary-typed parameter must be an error, not
+    a silent Metropolis update (mcmc.js:753-767 is what the reference runs for it)."""
+    data = model_spec.make_data("normal", 50, 3)
+    spec = model_spec.build_spec("normal", data)
+    spec["params"][0] = dict(spec["params"][0], type="binary")
+    with pytest.raises(A.AmwgError, match="binary"):
+        A.Sampler(spec, chains=4, seed=1)
