@@ -766,6 +766,21 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   mc.cp_upper = (double)(N - 1);
   mc.lunif_cp = log_v8(1 / (mc.cp_upper - 0.0));
   mc.exact_division = options->exact_division ? 1 : 0;
+  mc.group_local = 0;
+  if (options->group_local) {
+    // group-local evaluation (include/amwg.h, amwg_options::group_local): the hierarchical family on a balanced round-robin design, a chain
+    // on one whole wavefront -- lane j then only ever meets group j mod G, which is what lets one pass evaluate all G proposals of a sweep
+    if (m->model != AMWG_MODEL_HIER_NORMAL) return bail(fail(AMWG_EINVAL, "group_local: only the hierarchical Normal family has a group-local evaluation"));
+    if (m->G < 1 || (m->G & (m->G - 1)) || m->G > 64) return bail(fail(AMWG_EINVAL, "group_local: the number of groups must be a power of two <= 64 (got %d)", m->G));
+    if (N < 64) return bail(fail(AMWG_EINVAL, "group_local: at least 64 observations (one per lane), got %d", N));
+    for (int i = 0; i < N; ++i)
+      if (m->g[i] != i % m->G) return bail(fail(AMWG_EINVAL, "group_local: the group labels must be g[i] = i mod G (observation %d has label %d)", i, m->g[i]));
+    if (n_params != 3 || !params[0].multidim || params[0].len != m->G || params[0].top != m->G)
+      return bail(fail(AMWG_EINVAL, "group_local: parameters must be theta (dim [G]), mu, sigma"));
+    if (options->lanes_per_chain != 0 && options->lanes_per_chain != 64) return bail(fail(AMWG_EINVAL, "group_local runs a chain on one wavefront: lanes_per_chain must be 0 or 64"));
+    s->opt.lanes_per_chain = 64;
+    mc.group_local = 1;
+  }
 
   // ---- data upload
   DataRef &d = s->d;

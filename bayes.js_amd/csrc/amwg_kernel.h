@@ -106,6 +106,10 @@ template <class M> struct BinaryOf<M, void_of<decltype(M::kHasBinary)>> { static
 template <class M, class = void> struct TracksState { static constexpr bool value = false; };
 template <class M> struct TracksState<M, void_of<decltype(M::kTracksState)>> { static constexpr bool value = M::kTracksState; };
 
+// Does the model have a group-local evaluation with a lane-parallel sweep (Model::kGroupSweep; HierNormalModel)?
+template <class M, class = void> struct GroupSweepOf { static constexpr bool value = false; };
+template <class M> struct GroupSweepOf<M, void_of<decltype(M::kGroupSweep)>> { static constexpr bool value = M::kGroupSweep; };
+
 // per-chain values a model keeps from one log_post evaluation to the next (Model::Cache; translated closures have none)
 struct NoCache {};
 template <class M, class = void> struct CacheOf { using type = NoCache; static __device__ __forceinline__ type init() { return type{}; } };
@@ -486,8 +490,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   int ord = lane64;
   const bool ord_in_regs = G >= 64 && a.pl.max_top <= 64;
   wave_priority(kStepperPriority);
-  for (int step = 0; step < n_steps; ++step) {
-    // ---- Sampler.sample: record the state BEFORE the step (mcmc.js:1020-1027)
+  // ---- Sampler.sample: record the state BEFORE the step (mcmc.js:1020-1027)
+  auto record_draws = [&](int step) {
     if (recording && step == next_rec) {
       double *const draws = cold_args()->draws;
       if (writer)
@@ -504,12 +508,184 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       ++row;
       next_rec += cold_args()->thin;
     }
-    // ---- AmwgStepper.step: in-place Durstenfeld shuffle of the named sub-steppers (mcmc.js:887, 228-236)
+  };
+  // ---- AmwgStepper.step: in-place Durstenfeld shuffle of the named sub-steppers (mcmc.js:887, 228-236)
+  auto shuffle_named = [&]() {
     for (int i = n_named - 1; i > 0; --i) {
       const int j = (int)__builtin_floor(rng.next() * (double)(i + 1));
       if (wide_perm) { const int ti = pcol.get(i); pcol.set(i, pcol.get(j)); pcol.set(j, ti); }
       else perm = perm_swap(perm, i, j);
     }
+  };
+  // ---- Roberts-Rosenthal batch adaptation of one component (mcmc.js:536-550); `store`: this lane writes the component's HBM words
+  auto adapt_component = [&](int comp, bool accepted, int2 cnt, double batch_size, bool store) {
+    cnt.x += accepted ? 1 : 0;      // acceptance_count (mcmc.js:530)
+    cnt.y += 1;                     // iterations_since_adaption (mcmc.js:537)
+    if ((double)cnt.y >= batch_size) {    // batch boundary: the only time batch_count is touched (it stays in HBM)
+      const CompConst k = cc[comp];
+      // single-wave chains: batch_count and the log scale live in HBM (all lanes of the chain are in lockstep, so they
+      // read the old value together before the writer lane stores the new one); multi-wave chains keep per-wave replicas
+      const int64_t gi = (int64_t)comp * C + cl;
+      int32_t *const g_bc = kMulti ? nullptr : cold_args()->ch.batch_count;
+      double *const g_pls = kMulti ? nullptr : cold_args()->ch.prop_log_scale;
+      const int32_t bc = (kMulti ? BCme[comp] : g_bc[gi]) + 1;
+      const double adj = __builtin_fmin(k.max_adaptation, k.initial_adaptation / __builtin_sqrt((double)bc));
+      double pls = kMulti ? LOGPLSme[comp] : g_pls[gi];
+      if ((double)cnt.x / k.batch_size > k.target_accept_rate) pls += adj; else pls -= adj;
+      cnt = make_int2(0, 0);
+      SDme[comp] = exp_v8_cold(pls);
+      if constexpr (kMulti) { BCme[comp] = bc; LOGPLSme[comp] = pls; }
+      else if (store) { g_bc[gi] = bc; g_pls[gi] = pls; }
+    }
+    CNTme[comp] = cnt;
+  };
+
+  // ================================================================================================================================
+  // GROUP-LOCAL mode (amwg_options::group_local; HierNormalModel on one wavefront per chain, see amwg_models.h gl_*): the named parameters are
+  // walked in the shuffled order as always, mu and sigma by the ordinary stepper with the group-local evaluation, and the Gn components of
+  // theta in ONE lane-parallel sweep: the stream positions of the Gn proposals are resolved on the scalar unit (which uniform pair survives
+  // rnorm's rejection test is a property of the stream alone), then every lane draws, evaluates and decides the proposal of its own group.
+  // Same uniforms for the same purposes in the same order as the sequential stepper, hence the same decisions (oracle: gl_evaluate).
+  bool group_local = false;
+  if constexpr (GroupSweepOf<Model>::value && G == 64) group_local = a.mc.group_local != 0;
+  if constexpr (GroupSweepOf<Model>::value && G == 64) {
+   if (group_local) {
+    const int Gn = a.d.G, c_l = lane64 & (Gn - 1);          // this lane's group = its component of theta (theta is the first parameter)
+    lp_curr = Model::template gl_refresh<G, kPassU>(cache, S, a.mc, a.d, data_lds, sub);
+    for (int step = 0; step < n_steps; ++step) {
+      record_draws(step);
+      shuffle_named();
+      for (int np = 0; np < n_named; ++np) {
+        const int p = __builtin_amdgcn_readfirstlane((int)perm_get(perm, np));
+        const int base = __builtin_amdgcn_readfirstlane(pl_base[p]);
+        if (__builtin_amdgcn_readfirstlane(pl_multidim[p]) == 0) {
+          // ---- mu or sigma: OnedimMetropolisStepper.step (mcmc.js:517-553) with the group-local evaluation
+          const int comp = base;
+          const double cur = S(comp);
+          const double k_lower = cc[comp].lower, k_upper = cc[comp].upper;
+          const int k_type = cc[comp].type;
+          const int2 cnt = CNTme[comp];
+          const double batch_size = cc[comp].batch_size;
+          const bool adapting = adapt[comp] != 0;
+          double prop = rnorm_js(rng, cur, SDme[comp]);
+          if (k_type == kTypeInt) prop = js_round(prop);
+          const bool inb = !(prop < k_lower || prop > k_upper);
+          bool accepted = false;
+          if (inb) {
+            const double u_accept = rng.next();
+            const double prop_lp = Model::template gl_eval_scalar<G, kPassU>(cache, comp, prop, a.mc, a.d, data_lds, sub);
+            const double diff = prop_lp - lp_curr;
+            if (diff >= 0.0) accepted = true;
+            else if (diff < -746.0) accepted = false;
+            else accepted = exp_v8(diff) > u_accept;
+            if (accepted) { lp_curr = prop_lp; Model::gl_commit_scalar(cache, comp, prop, a.d); Sme[comp] = prop; }
+            if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          if (adapting) adapt_component(comp, accepted, cnt, batch_size, writer);
+          continue;
+        }
+        // ---- theta: fresh shuffle of the order (mcmc.js:248-252), then the sweep
+        const int top = Gn;
+        ord = lane64;
+        for (int i = top - 1; i > 0; --i) {
+          const int j = __builtin_amdgcn_readfirstlane((int)__builtin_floor(rng.next() * (double)(i + 1)));
+          const int ti = __builtin_amdgcn_readlane(ord, i), tj = __builtin_amdgcn_readlane(ord, j);
+          ord = lane64 == i ? tj : (lane64 == j ? ti : ord);
+        }
+        const int comp_l = base + c_l;
+        const double sd_l = SDme[comp_l], lower_l = cc[comp_l].lower, upper_l = cc[comp_l].upper, bs_l = cc[comp_l].batch_size;
+        const int type_l = cc[comp_l].type;
+        const bool adapting_l = adapt[comp_l] != 0;
+        uint64_t inb_assume = ~0ull;       // which components' proposals are assumed to fall inside their bounds (they then draw the accept uniform)
+        int pp = 0, kk = -1;               // per lane: stream position of the accepted (u, v) pair of its component's proposal | its place in the order
+        int k_begin = 0;
+        while (k_begin < top) {
+          // -- the window of the stream: 256 uniforms from block b0 on: A = the CoopStream's own 64 blocks, B = the next 64
+          uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rng.pos);
+          if (p0 >= 128u) { rng.b0 += 64ull; p0 -= 128u; rng.fill(); }
+          rng.pos = p0;
+          const Philox4 wb = CoopStream<G>::block(rng.b0 + 64ull + (uint64_t)lane64, rng.c2, rng.c3, rng.k0, rng.k1);
+          const double ua0 = u53(rng.w0, rng.w1), ua1 = u53(rng.w2, rng.w3), ub0 = u53(wb.w0, wb.w1), ub1 = u53(wb.w2, wb.w3);   // uniforms 2j, 2j+1, 128+2j, 129+2j of the window
+          const double ub0_first = bits_f64(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(f64_bits(ub0) >> 32), 0) << 32) |
+                                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f64_bits(ub0), 0));
+          const double na0 = lane64 == 63 ? ub0_first : __shfl_down(ua0, 1, 64);   // the uniform after this lane's second one
+          const double nb0 = __shfl_down(ub0, 1, 64);                              // (lane 63: beyond the window, masked below)
+          // does rnorm accept the pair (u, v)?  mcmc.js:44-53
+          auto pair_ok = [&](double u, double v_raw) -> bool {
+            const double v = 1.7156 * (v_raw - 0.5);
+            const double x = u - 0.449871;
+            const double y = __builtin_fabs(v) + 0.386595;
+            const double q = x * x + y * (0.19600 * y - 0.25472 * x);
+            return !(q > 0.27597 && (q > 0.27846 || v * v > -4 * log_v8_cold(u) * u * u));
+          };
+          const uint64_t EA = __ballot(pair_ok(ua0, ua1)), OA = __ballot(pair_ok(ua1, na0));
+          const uint64_t EB = __ballot(pair_ok(ub0, ub1)), OB = __ballot(pair_ok(ub1, nb0)) & ~(1ull << 63);
+          // -- scalar resolution: update k of the order takes the first accepted pair at or after the stream position, then (if its proposal is
+          // inside the bounds) one more uniform for the accept test
+          uint32_t p = p0;
+          int k = k_begin;
+          for (; k < top; ++k) {
+            bool found = false;
+            while (p + 2u <= 255u) {
+              const uint64_t m = (p & 128u) ? ((p & 1u) ? OB : EB) : ((p & 1u) ? OA : EA);
+              if ((m >> ((p & 127u) >> 1)) & 1ull) { found = true; break; }
+              p += 2u;
+            }
+            if (!found) break;            // the window ends inside update k's rejected pairs: they are consumed, the search resumes in the next window
+            const int ck = __builtin_amdgcn_readlane(ord, k);
+            pp = lane64 == ck ? (int)p : pp;
+            kk = lane64 == ck ? k : kk;
+            p += ((inb_assume >> ck) & 1ull) ? 3u : 2u;
+          }
+          const int k_end = k;
+          // -- every lane: the proposal of its own group
+          const int pp_l = __shfl(pp, c_l, 64), kk_l = __shfl(kk, c_l, 64);
+          const bool in_round = kk_l >= k_begin && kk_l < k_end;
+          auto window_uniform = [&](uint32_t q) -> double {
+            const int src = (int)((q & 127u) >> 1);
+            const double a0 = __shfl(ua0, src, 64), a1 = __shfl(ua1, src, 64), b0 = __shfl(ub0, src, 64), b1 = __shfl(ub1, src, 64);
+            return (q & 128u) ? ((q & 1u) ? b1 : b0) : ((q & 1u) ? a1 : a0);
+          };
+          const uint32_t q_l = in_round ? (uint32_t)pp_l : 0u;
+          const double u = window_uniform(q_l), v_raw = window_uniform(q_l + 1u), u_accept = window_uniform(q_l + 2u);
+          const double cur = cache.th_pass;
+          double prop = ((1.7156 * (v_raw - 0.5)) / u) * sd_l + cur;       // rnorm_js: (v / u) * sd + mean
+          if (type_l == kTypeInt) prop = js_round(prop);
+          const bool inb = !(prop < lower_l || prop > upper_l);
+          // the resolution assumed which proposals draw an accept uniform: check, and resolve again where it was wrong (each pass fixes at
+          // least the earliest wrong one; with unbounded components there is nothing to fix)
+          const uint64_t lanes_lo = Gn >= 64 ? ~0ull : ((1ull << Gn) - 1ull);
+          const uint64_t round_mask = __ballot(in_round) & lanes_lo, actual = __ballot(inb) & lanes_lo;
+          if (((actual ^ inb_assume) & round_mask) != 0ull) { inb_assume = (inb_assume & ~round_mask) | (actual & round_mask); continue; }
+          const bool eval = in_round && inb;
+          const double delta = Model::template gl_sweep_eval<G, kPassU>(cache, eval, prop, a.mc, a.d, data_lds, sub);
+          // Math.exp(delta) > u (mcmc.js:527-528); >= 0 and < -746 decided without the exponential, NaN takes it and fails
+          bool accepted = false;
+          if (eval) {
+            if (delta >= 0.0) accepted = true;
+            else if (delta < -746.0) accepted = false;
+            else accepted = exp_v8(delta) > u_accept;
+          }
+          Model::gl_sweep_commit(cache, accepted, prop);
+          if (lane64 < Gn && in_round) {         // one lane per component: state, run totals, adaptation
+            if (accepted) Sme[comp_l] = prop;
+            if (inb) TOTme[comp_l] += 1u + (accepted ? 0x10000u : 0u);
+            if (adapting_l) adapt_component(comp_l, accepted, CNTme[comp_l], bs_l, live);
+          }
+          k_begin = k_end;
+          // the stream position after this round; past the CoopStream's own blocks, the window's second half becomes its buffer
+          if (p >= 128u) { rng.b0 += 64ull; rng.w0 = wb.w0; rng.w1 = wb.w1; rng.w2 = wb.w2; rng.w3 = wb.w3; p -= 128u; }
+          rng.pos = p;
+        }
+        lp_curr = Model::template gl_total<G>(cache, sub, Gn, cache.pm, cache.pt, cache.T);
+      }
+    }
+   }
+  }
+  if (!group_local)
+  for (int step = 0; step < n_steps; ++step) {
+    record_draws(step);
+    shuffle_named();
     // ---- every scalar component exactly once; `slot` is uniform across the block
     int np = 0, e = 0, e_top = 0, e_in = 0;   // position inside the current parameter: e = e_top * inner + e_in (no division per slot)
     // descriptor of the parameter being walked, read from the LDS tables once, when the parameter begins (round 2 re-read it in every
@@ -627,28 +803,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         else set_state(comp, cur);
         if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // run totals (not in the reference; parity tests compare them with the oracle's)
       }
-      if (me.adapting) {
-        int2 cnt = me.cnt;
-        cnt.x += accepted ? 1 : 0;      // acceptance_count (mcmc.js:530)
-        cnt.y += 1;                     // iterations_since_adaption (mcmc.js:537)
-        if ((double)cnt.y >= me.batch_size) {    // batch boundary: the only time batch_count is touched (it stays in HBM)
-          const CompConst k = cc[comp];
-          // single-wave chains: batch_count and the log scale live in HBM (all lanes of the chain are in lockstep, so they
-          // read the old value together before the writer lane stores the new one); multi-wave chains keep per-wave replicas
-          const int64_t gi = (int64_t)comp * C + cl;
-          int32_t *const g_bc = kMulti ? nullptr : cold_args()->ch.batch_count;
-          double *const g_pls = kMulti ? nullptr : cold_args()->ch.prop_log_scale;
-          const int32_t bc = (kMulti ? BCme[comp] : g_bc[gi]) + 1;
-          const double adj = __builtin_fmin(k.max_adaptation, k.initial_adaptation / __builtin_sqrt((double)bc));
-          double pls = kMulti ? LOGPLSme[comp] : g_pls[gi];
-          if ((double)cnt.x / k.batch_size > k.target_accept_rate) pls += adj; else pls -= adj;
-          cnt = make_int2(0, 0);
-          SDme[comp] = exp_v8_cold(pls);
-          if constexpr (kMulti) { BCme[comp] = bc; LOGPLSme[comp] = pls; }
-          else if (writer) { g_bc[gi] = bc; g_pls[gi] = pls; }
-        }
-        CNTme[comp] = cnt;
-      }
+      if (me.adapting) adapt_component(comp, accepted, me.cnt, me.batch_size, writer);
     }
   }
 

@@ -33,8 +33,7 @@ struct NormCache {
   bool den_ok;
 };
 __device__ __forceinline__ NormCache norm_cache_init() { return NormCache{__builtin_nan(""), 0.0, 0.0, Reciprocal{0.0, 0.0}, false}; }
-// (out of line and by value: V8's log and an IEEE division, reached once per change of sd -- one update in 34 of the hierarchical model)
-AMWG_HD_OUTLINE NormCache norm_cache_make(double sd, double neg_half_log_2pi) {
+AMWG_HD NormCache norm_cache_make(double sd, double neg_half_log_2pi) {
   NormCache k;
   k.sd = sd;
   k.c = norm_c(neg_half_log_2pi, sd);
@@ -43,8 +42,24 @@ AMWG_HD_OUTLINE NormCache norm_cache_make(double sd, double neg_half_log_2pi) {
   k.den_ok = mid_range(k.den);
   return k;
 }
+// out of line for models whose sd changes rarely (one update in 34 of the hierarchical model): V8's log and an IEEE division, with their
+// code and constants, stay out of the hot loop.  The values come back in registers (two calls: a seven-member struct would travel through
+// the stack).
+struct NormCacheA { double c, den; };
+AMWG_HD_OUTLINE NormCacheA norm_cache_cold_a(double sd, double neg_half_log_2pi) { return NormCacheA{norm_c(neg_half_log_2pi, sd), norm_den(sd)}; }
+AMWG_HD_OUTLINE Reciprocal norm_cache_cold_b(double den) { return make_reciprocal(den); }
+template <bool COLD = false>
 __device__ __forceinline__ void norm_cache_update(NormCache &k, double sd, double neg_half_log_2pi) {
-  if (sd != k.sd) k = norm_cache_make(sd, neg_half_log_2pi);
+  if (sd != k.sd) {
+    if constexpr (COLD) {
+      const NormCacheA a = norm_cache_cold_a(sd, neg_half_log_2pi);
+      k.sd = sd; k.c = a.c; k.den = a.den;
+      k.y = norm_cache_cold_b(a.den);
+      k.den_ok = mid_range(a.den);
+    } else {
+      k = norm_cache_make(sd, neg_half_log_2pi);
+    }
+  }
 }
 
 
@@ -315,8 +330,12 @@ struct HierNormalModel {
   // an evaluation reads nothing of the state from LDS.  Round 2 read mu, sigma, theta[k], the label and theta[label] back from LDS in
   // every evaluation: four dependent round trips behind the data passes of the CU's other waves.
   static constexpr bool kTracksState = true;
-  struct Cache { NormCache n; double th_own, th_pass, mu, sigma; int my_group; bool regs, loaded; };
-  __device__ __forceinline__ static Cache cache_init() { return Cache{norm_cache_init(), 0.0, 0.0, 0.0, 0.0, -1, false, false}; }
+  struct Cache {
+    NormCache n; double th_own, th_pass, mu, sigma; int my_group; bool regs, loaded;
+    // group-local evaluation (gl_* below): committed pieces of log_post_GL, and the tentative ones of the proposal being evaluated
+    double pm, pt, T, pm_t, pt_t, T_t;
+  };
+  __device__ __forceinline__ static Cache cache_init() { return Cache{norm_cache_init(), 0.0, 0.0, 0.0, 0.0, -1, false, false, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; }
   template <int GL>
   __device__ __forceinline__ static void load(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
     if (k.loaded) return;
@@ -361,7 +380,7 @@ struct HierNormalModel {
                                                const unsigned char *smem, Cache &k) {
     Pass ps;
     NormCache &kc = k.n;
-    norm_cache_update(kc, k.sigma, mc.neg_half_log_2pi);
+    norm_cache_update<true>(kc, k.sigma, mc.neg_half_log_2pi);
     ps.c = kc.c;
     ps.den = kc.den;
     ps.y = kc.y;
@@ -390,6 +409,108 @@ struct HierNormalModel {
     ps.th_pass = k.th_pass;
     return ps;
   }
+  // ---------------------------------------------------------------------------------------------------------------------------------
+  // GROUP-LOCAL evaluation (opt-in: amwg_options::group_local; preconditions checked by amwg_create: labels g_i = i mod Gn, Gn a power of
+  // two <= 64, a chain on one whole wavefront).  NOT the reference's operation schedule -- the order it follows is restated, and tested
+  // bit for bit, in oracle/amwg_oracle.c (gl_*):
+  //     T_j  = the data-only partial sum of lane j (0 + term(j) + term(j + 64) + ..., one mean per lane: that of group j mod Gn)
+  //     pt_k = ld.norm(theta_k, mu, tau),  pm = ld.norm(mu, m0, s0) + ld.unif(sigma, a, b)
+  //     log_post_GL = butterfly over the 64 lanes of V_j:  V_0 = (pm + pt_0) + T_0,  V_j = pt_j + T_j (j < Gn),  V_j = T_j (j >= Gn)
+  // Every lane keeps the pieces of ITS group (lanes j and j + Gn, ... hold the same pt).  A proposal for mu needs no pass, one for sigma one
+  // pass; the Gn proposals of a sweep over theta are evaluated TOGETHER in one pass -- every lane with the proposed mean of its own group --
+  // and each is decided on its local difference (pt' - pt) + (L' - L), L = the sum of T over the lanes of the group.  2 passes per step
+  // instead of 34 (mcmc.js:524-526 evaluates the full log_post twice per update).
+  static constexpr bool kGroupSweep = true;
+  __device__ __forceinline__ static double gl_pm(double mu, double sigma, const ModelConsts &mc) {
+    double lp = 0;
+    lp += norm_const_sd(mu, mc.m0, mc.c0, mc.den0, mc.y0_hi, mc.y0_lo, mc.den0_ok);
+    lp += (sigma < mc.ua || sigma > mc.ub) ? -kInf : mc.lunif;
+    return lp;
+  }
+  __device__ __forceinline__ static double gl_pt(double theta, double mu, const ModelConsts &mc) {
+    return norm_const_sd(theta, mu, mc.c1, mc.den1, mc.y1_hi, mc.y1_lo, mc.den1_ok);
+  }
+  __device__ __forceinline__ static double gl_lane_value(int sub, int Gn, double pm, double pt, double T) {
+    return sub == 0 ? (pm + pt) + T : (sub < Gn ? pt + T : T);
+  }
+  template <int G>
+  __device__ __forceinline__ static double gl_total(const Cache &k, int sub, int Gn, double pm, double pt, double T) {
+    return butterfly<1, 64>(gl_lane_value(sub, Gn, pm, pt, T));
+  }
+  // sum of T over the lanes of this lane's group: the butterfly stages whose offset is a multiple of Gn
+  __device__ __forceinline__ static double gl_group_sum(double T, int Gn) {
+    if (Gn <= 1) T = xor_sum<1>(T);
+    if (Gn <= 2) T = xor_sum<2>(T);
+    if (Gn <= 4) T = xor_sum<4>(T);
+    if (Gn <= 8) T = xor_sum<8>(T);
+    if (Gn <= 16) T = xor_sum<16>(T);
+    if (Gn <= 32) T = xor_sum<32>(T);
+    return T;
+  }
+  template <int G>
+  __device__ inline __attribute__((noinline)) static double gl_pass_slow(const double *x, double mean, double c, double den, int n_obs, int sub) {
+    double acc = 0.0;
+    for (int i = sub; i < n_obs; i += G) { const double t = x[i] - mean; acc += c - (t * t) / den; }
+    return acc;
+  }
+  // T of this lane for the given mean of its group, with the sd the NormCache currently holds
+  template <int G, int U>
+  __device__ __forceinline__ static double gl_pass(const Cache &k, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub, double mean) {
+    const double *x = reinterpret_cast<const double *>(smem);
+    const bool mine = mean == 0 || mid_range(__builtin_fabs(mean));
+    const bool ok = !mc.exact_division && mc.data_mid_range && k.n.den_ok && __ballot(mine) == ~0ull;
+    if (ok) return norm_pass_staged<G, U, false>(x, nullptr, StateView{nullptr}, mean, k.n.c, k.n.den, k.n.y, d.n_obs, sub, 0.0);
+    return gl_pass_slow<G>(x, mean, k.n.c, k.n.den, d.n_obs, sub);
+  }
+  // caches and log_post_GL of the state as it stands (launch start; equals the value the previous launch ended with, bit for bit)
+  template <int G, int U>
+  __device__ __forceinline__ static double gl_refresh(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
+    k.loaded = false;
+    load<G>(k, S, mc, d, smem, sub);
+    norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);
+    k.pm = gl_pm(k.mu, k.sigma, mc);
+    k.pt = gl_pt(k.th_pass, k.mu, mc);
+    k.T = gl_pass<G, U>(k, mc, d, smem, sub, k.th_pass);
+    return gl_total<G>(k, sub, d.G, k.pm, k.pt, k.T);
+  }
+  // a proposal v for mu (comp == Gn) or sigma (comp == Gn + 1): log_post_GL of the proposed state, its pieces kept as tentative
+  template <int G, int U>
+  __device__ __forceinline__ static double gl_eval_scalar(Cache &k, int comp, double v, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
+    const bool is_mu = comp == d.G;
+    const double mu = is_mu ? v : k.mu, sigma = is_mu ? k.sigma : v;
+    k.pm_t = gl_pm(mu, sigma, mc);
+    if (is_mu) {
+      k.pt_t = gl_pt(k.th_pass, mu, mc);
+      k.T_t = k.T;
+    } else {
+      k.pt_t = k.pt;
+      norm_cache_update<true>(k.n, sigma, mc.neg_half_log_2pi);
+      k.T_t = gl_pass<G, U>(k, mc, d, smem, sub, k.th_pass);
+    }
+    return gl_total<G>(k, sub, d.G, k.pm_t, k.pt_t, k.T_t);
+  }
+  __device__ __forceinline__ static void gl_commit_scalar(Cache &k, int comp, double v, const DataRef &d) {
+    k.pm = k.pm_t; k.pt = k.pt_t; k.T = k.T_t;
+    k.mu = comp == d.G ? v : k.mu;
+    k.sigma = comp == d.G ? k.sigma : v;
+  }
+  // the sweep over theta: every lane evaluates the proposal of its own group (`eval`: this group's proposal is evaluated in this round,
+  // `prop` its value -- the same on all lanes of the group); -> the local difference the accept test of that proposal uses
+  template <int G, int U>
+  __device__ __forceinline__ static double gl_sweep_eval(Cache &k, bool eval, double prop, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
+    norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);       // (a rejected sigma proposal leaves the cache at the proposed sd)
+    const double mean = eval ? prop : k.th_pass;
+    k.pt_t = eval ? gl_pt(prop, k.mu, mc) : k.pt;
+    k.T_t = gl_pass<G, U>(k, mc, d, smem, sub, mean);
+    return (k.pt_t - k.pt) + (gl_group_sum(k.T_t, d.G) - gl_group_sum(k.T, d.G));
+  }
+  __device__ __forceinline__ static void gl_sweep_commit(Cache &k, bool accepted, double prop) {
+    k.th_pass = accepted ? prop : k.th_pass;
+    k.th_own = accepted ? prop : k.th_own;
+    k.pt = accepted ? k.pt_t : k.pt;
+    k.T = accepted ? k.T_t : k.T;
+  }
+
   template <bool FAST>
   __device__ __forceinline__ static double term(const Pass &ps, int i) {
     const double t = ps.x[i] - ps.S(ps.g[i]);

@@ -63,6 +63,7 @@ struct ModelConsts {
   int32_t data_mid_range;           // every data value is 0 or within 2^-200..2^200 in magnitude
   int32_t exact_division;           // 1 = always use IEEE '/'
   int32_t has_invalid;              // BETA_BERN: some x_i is neither 0 nor 1 => that term is -inf (distributions.js:229)
+  int32_t group_local;              // HIER: group-local evaluation (amwg_options::group_local; preconditions checked by amwg_create)
   int32_t group_lane_const;         // HIER: g[i] == g[i % lanes] for every i -- each lane of a chain only ever meets ONE group (balanced
                                     // round-robin designs such as g_i = i mod 32 with 64 lanes): its mean is read once per evaluation
 };

@@ -112,7 +112,14 @@ typedef struct {
   int32_t steps_per_launch;/* 0 = auto (one launch per burn/sample call up to 65535 steps) */
   int32_t exact_division;  /* 0 = default: result-preserving shortcuts (hoisted-reciprocal division, fast-forward of two-valued sums), bit-identical
                               to the plain schedule and tested against it; 1 = the reference's operation schedule: IEEE '/', term-by-term sums */
-  int32_t reserved[3];
+  int32_t group_local;     /* 0 = default.  1 = GROUP-LOCAL evaluation of the hierarchical family (AMWG_MODEL_HIER_NORMAL with labels g_i = i mod G, G a
+                              power of two <= 64; forces 64 lanes per chain; anything else is AMWG_EINVAL): a proposal for theta_g is decided on the
+                              difference of ITS group's terms only -- and the G proposals of a sweep are evaluated in ONE pass over the data, every lane
+                              with the proposed mean of its own group -- instead of on two full sums (mcmc.js:524-526 evaluates the whole log_post twice
+                              per update).  NOT the reference's operation schedule: the doubles follow the order restated in oracle/amwg_oracle.c (gl_*),
+                              bit for bit; accept decisions, adaptation and uniforms consumed equal the reference's on every golden.  Opt-in, reported
+                              separately by bench.py */
+  int32_t reserved[2];
 } amwg_options;
 
 typedef struct amwg_sampler amwg_sampler;

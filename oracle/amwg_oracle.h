@@ -52,6 +52,9 @@ typedef struct orc_chain orc_chain;
 void orc_set_callback(orc_log_post_fn fn, void *ctx);
 orc_chain *orc_create(const orc_data *d, const orc_param *params, int n_params, const double *init /*P*/,
                       const orc_comp_opt *opts /*P*/, uint64_t seed, uint64_t chain, int lanes);
+/* group-local evaluation of the hierarchical family (see amwg_oracle.c, gl_*): 0 on success, -1 if the model / data / lane count does not
+ * meet its preconditions.  Call right after orc_create (it re-forms lp_curr in the mode's own summation order). */
+int orc_set_group_local(orc_chain *c, int flag);
 void orc_destroy(orc_chain *c);
 int orc_num_components(const orc_chain *c);
 void orc_burn(orc_chain *c, int64_t n);

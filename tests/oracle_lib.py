@@ -82,7 +82,7 @@ class OracleChain:
     """One reference-order chain.  `spec` is a dict from model_spec.build_spec(), or -- for a user closure -- a dict with
     `log_post_fn(state ndarray[P], lanes) -> float` instead of model/data (the oracle steps, the callback evaluates)."""
 
-    def __init__(self, spec, seed, chain, lanes=1):
+    def __init__(self, spec, seed, chain, lanes=1, group_local=False):
         L = lib()
         self.spec = spec
         self._keep = []
@@ -134,6 +134,9 @@ class OracleChain:
         self.n_params = n
         self.h = L.orc_create(C.byref(od), pa, n, _dp(init), oa, seed, chain, lanes)
         assert self.h
+        if group_local:
+            L.orc_set_group_local.argtypes = [C.c_void_p, C.c_int]
+            assert L.orc_set_group_local(self.h, 1) == 0, "group-local evaluation: preconditions not met"
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -20,7 +20,7 @@ def _bench(*extra):
 
 
 def test_default_line_has_the_contract_fields_and_an_honest_roofline():
-    d = _bench("--chains-per-gpu", "4096")
+    d = _bench("--chains-per-gpu", "4096", "--lanes", "1")     # (one lane per chain, as the full-size default picks: reference order)
     for key, want in (("unit", "param-updates/s"), ("n_gpus", 1), ("steps", 5), ("warmup", 2), ("higher_is_better", True), ("scaling", "weak"),
                       ("vs_baseline", None), ("dtype", "f64"), ("data", "synthetic")):
         assert d[key] == want, key

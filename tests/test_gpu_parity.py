@@ -284,3 +284,58 @@ def test_binary_parameter_on_a_built_in_family_is_refused():
     spec["params"][0] = dict(spec["params"][0], type="binary")
     with pytest.raises(A.AmwgError, match="binary"):
         A.Sampler(spec, chains=4, seed=1)
+
+
+def _group_local_case(name):
+    gold = golden_io.load(name)
+    return gold, gold["case"], gold["chains"][0]
+
+
+@pytest.mark.parametrize("name", ["hier_small", "cfg4_full"])
+def test_group_local_sweep_equals_its_oracle_and_takes_the_reference_decisions(name):
+    """amwg_options::group_local (hierarchical family): the lane-parallel sweep over theta -- all G proposals of a step evaluated in one pass,
+    stream positions resolved on the scalar unit -- against its sequential restatement in oracle/amwg_oracle.c (gl_*): every double bit for
+    bit; and against the seeded run of the unmodified reference: every accept decision, adaptation step and uniform count."""
+    gold, case, rec = _group_local_case(name)
+    spec = model_spec.spec_from_golden(gold, rec)
+    s = A.Sampler(spec, chains=5, seed=case["seed"], chain_offset=rec["chain"], group_local=1)
+    assert s.launch_info()["lanes_per_chain"] == 64
+    o = oracle_lib.OracleChain(spec, case["seed"], rec["chain"], lanes=64, group_local=True)
+    gs, os_ = run_schedule(s, case["schedule"]), run_schedule(o, case["schedule"])
+    assert_chain_equals_oracle(s, 0, o, gs, os_)
+    assert s.info()["accepts"][:, 0].tolist() == rec["accepts"]      # the reference's decisions
+    assert s.info()["batch_count"][:, 0].tolist() == rec["batch_count"]
+    assert int(s.diag()["uniforms"][0]) == rec["uniforms"]
+    o3 = oracle_lib.OracleChain(spec, case["seed"], rec["chain"] + 3, lanes=64, group_local=True)
+    assert_chain_equals_oracle(s, 3, o3, gs, run_schedule(o3, case["schedule"]))
+    s.close()
+
+
+def test_group_local_sweep_with_bounded_integer_and_non_adapting_components():
+    """The sweep's resolution of stream positions assumes every proposal falls inside its bounds (and so draws an accept uniform) and
+    repairs the assumption where it was wrong: tight bounds on theta make that the common case here; an int-typed theta, per-component
+    options, launches of 7 steps and a stop / start of the adaptation ride along."""
+    data = model_spec.make_data("hier_normal", 777, 31, G=16)
+    spec = model_spec.build_spec("hier_normal", data)
+    spec["params"][0] = dict(spec["params"][0], lower=3.0, upper=7.5, init=[5.25] * 16)
+    spec["init"] = [5.25] * 16 + list(spec["init"][16:])
+    for i, o in enumerate(spec["comp_opts"]):
+        o.update(batch_size=7 + (i % 3), prop_log_scale=0.8, is_adapting=(i % 5 != 2))
+    sched = [{"op": "burn", "n": 61}, {"op": "stop"}, {"op": "sample", "n": 20, "thin": 2}, {"op": "start"}, {"op": "sample", "n": 45, "thin": 3}]
+    for typ in ("real", "int"):
+        spec["params"][0] = dict(spec["params"][0], type=typ)
+        s = A.Sampler(spec, chains=3, seed=99, chain_offset=7, group_local=1, steps_per_launch=7)
+        o = oracle_lib.OracleChain(spec, 99, 8, lanes=64, group_local=True)
+        gs, os_ = run_schedule(s, sched), run_schedule(o, sched)
+        assert_chain_equals_oracle(s, 1, o, gs, os_)
+        inb = s.info()["inbounds"][:16, 1]
+        assert (inb < 126).any()          # some proposals did fall outside
+        s.close()
+
+
+def test_group_local_preconditions_are_enforced():
+    data = model_spec.make_data("hier_normal", 300, 5, G=6)          # 6 groups: not a power of two
+    with pytest.raises(A.AmwgError, match="power of two"):
+        A.Sampler(model_spec.build_spec("hier_normal", data), chains=2, seed=1, group_local=1)
+    with pytest.raises(A.AmwgError, match="hierarchical"):
+        A.Sampler(model_spec.build_spec("normal", model_spec.make_data("normal", 100, 5)), chains=2, seed=1, group_local=1)

@@ -84,3 +84,24 @@ def test_oracle_kernel_order_same_decisions(name, lanes):
     gold = golden_io.load(name)
     for rec in gold["chains"][:2]:
         check_chain(gold, rec, lanes=lanes)
+
+
+@pytest.mark.parametrize("name,lanes", [("hier_small", 8), ("hier_small", 64), ("cfg4_full", 64), ("cfg4_full", 32)])
+def test_group_local_mode_reproduces_the_reference_decisions(name, lanes):
+    """The opt-in group-local evaluation of the hierarchical family (oracle/amwg_oracle.c gl_*: a theta_g proposal is decided on the local
+    difference of its group's terms) is not the reference's operation schedule, but it must take the reference's DECISIONS: accept counts,
+    adaptation state and uniforms consumed of the seeded reference runs; and its draws must stay within rounding of the reference's."""
+    gold = golden_io.load(name)
+    case = gold["case"]
+    for rec in gold["chains"]:
+        spec = model_spec.spec_from_golden(gold, rec)
+        o = oracle_lib.OracleChain(spec, case["seed"], rec["chain"], lanes=lanes, group_local=True)
+        segs = run_schedule(o, case["schedule"])
+        info = o.info()
+        assert info["accepts"].tolist() == rec["accepts"]
+        assert info["inbounds"].tolist() == rec["inbounds"]
+        assert info["batch_count"].tolist() == rec["batch_count"]
+        assert o.uniforms() == rec["uniforms"]
+        want = np.array(rec["samples"][0]["draws"], dtype=np.float64).reshape(-1, segs[0].shape[1])
+        assert np.allclose(segs[0][: want.shape[0]], want, rtol=1e-9, atol=1e-12)
+        assert np.allclose(o.state(), rec["final_state"], rtol=1e-9, atol=1e-12)
