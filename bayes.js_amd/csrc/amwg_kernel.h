@@ -118,7 +118,7 @@ template <class M> struct CacheOf<M, void_of<typename M::Cache>> { using type = 
 // The value a lane of the xor butterfly adds at offset OFF: that of lane ^ OFF or, for OFF = 4 and 8, of another lane of the same partner
 // group (which holds the same bits at that stage).  Offsets 1, 2 (quad permutes), 4 and 8 (row mirrors) are single DPP moves in the VALU --
 // no trip through the LDS crossbar; 16 and 32 are handled in xor_sum.  Every lane adds the same two numbers as with __shfl_xor.
-template <int OFF>
+template <int OFF, bool EXACT = false>
 __device__ __forceinline__ double xor_partner(double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   int lo = (int)(uint32_t)f64_bits(v), hi = (int)(uint32_t)(f64_bits(v) >> 32);
@@ -129,8 +129,14 @@ __device__ __forceinline__ double xor_partner(double v) {
   } else if constexpr (OFF == 4) {   // row_half_mirror (i -> 7 - i within 8): a lane of the partner quad -- inside the butterfly all four lanes of a
                                      // quad hold the same sum by now (IEEE addition is commutative), so any of them is "the" partner
     lo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true);
+    if constexpr (EXACT) {           // lane ^ 4 itself (a partial butterfly, whose lanes do not hold equal values yet): then quad_perm [3,2,1,0]
+      lo = __builtin_amdgcn_mov_dpp(lo, 0x1B, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x1B, 0xF, 0xF, true);
+    }
   } else if constexpr (OFF == 8) {   // row_mirror (i -> 15 - i within 16): a lane of the partner group of eight, likewise
     lo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true);
+    if constexpr (EXACT) {           // lane ^ 8 itself: then row_half_mirror
+      lo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true);
+    }
   } else if constexpr (OFF == 16) {  // ds_swizzle, bit-mask mode: lane' = (lane & 0x1f) ^ 0x10 within each half of the wave
     lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F); hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
   } else {
@@ -146,7 +152,7 @@ __device__ __forceinline__ double xor_partner(double v) {
 // the lane, and does not matter: IEEE addition is commutative), so the sum of the two results is acc + partner in every lane -- two VALU
 // moves per 32-bit half and no trip through the LDS crossbar (round 2: ds_swizzle and ds_bpermute, i.e. two dependent LDS round trips per
 // evaluation queued behind the data passes of the CU's other waves).
-template <int OFF>
+template <int OFF, bool EXACT = false>
 __device__ __forceinline__ double xor_sum(double acc) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (OFF == 16 || OFF == 32) {
@@ -159,7 +165,7 @@ __device__ __forceinline__ double xor_sum(double acc) {
       return bits_f64(((uint64_t)h[0] << 32) | (uint64_t)l[0]) + bits_f64(((uint64_t)h[1] << 32) | (uint64_t)l[1]);
     }
   } else {
-    return acc + xor_partner<OFF>(acc);
+    return acc + xor_partner<OFF, EXACT>(acc);
   }
 #else
   return acc;
@@ -608,7 +614,11 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           const double ua0 = u53(rng.w0, rng.w1), ua1 = u53(rng.w2, rng.w3), ub0 = u53(wb.w0, wb.w1), ub1 = u53(wb.w2, wb.w3);   // uniforms 2j, 2j+1, 128+2j, 129+2j of the window
           const double ub0_first = bits_f64(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(f64_bits(ub0) >> 32), 0) << 32) |
                                             (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f64_bits(ub0), 0));
-          const double na0 = lane64 == 63 ? ub0_first : __shfl_down(ua0, 1, 64);   // the uniform after this lane's second one
+          // the uniform after this lane's second one = the next lane's first.  The shuffle is done by ALL lanes, before the select: written as
+          // one conditional expression the compiler runs it with lane 63 masked off, and a lane reading from a masked-off lane gets 0
+          double na0 = __shfl_down(ua0, 1, 64);
+          asm volatile("" : "+v"(na0));
+          na0 = lane64 == 63 ? ub0_first : na0;
           const double nb0 = __shfl_down(ub0, 1, 64);                              // (lane 63: beyond the window, masked below)
           // does rnorm accept the pair (u, v)?  mcmc.js:44-53
           auto pair_ok = [&](double u, double v_raw) -> bool {

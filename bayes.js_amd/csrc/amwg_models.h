@@ -439,12 +439,12 @@ struct HierNormalModel {
   }
   // sum of T over the lanes of this lane's group: the butterfly stages whose offset is a multiple of Gn
   __device__ __forceinline__ static double gl_group_sum(double T, int Gn) {
-    if (Gn <= 1) T = xor_sum<1>(T);
-    if (Gn <= 2) T = xor_sum<2>(T);
-    if (Gn <= 4) T = xor_sum<4>(T);
-    if (Gn <= 8) T = xor_sum<8>(T);
-    if (Gn <= 16) T = xor_sum<16>(T);
-    if (Gn <= 32) T = xor_sum<32>(T);
+    if (Gn <= 1) T = xor_sum<1, true>(T);
+    if (Gn <= 2) T = xor_sum<2, true>(T);
+    if (Gn <= 4) T = xor_sum<4, true>(T);
+    if (Gn <= 8) T = xor_sum<8, true>(T);
+    if (Gn <= 16) T = xor_sum<16, true>(T);
+    if (Gn <= 32) T = xor_sum<32, true>(T);
     return T;
   }
   template <int G>
