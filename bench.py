@@ -264,13 +264,13 @@ def timed_geometry_parity(A, spec, workload, chains, make_sampler, lanes):
     return report, first
 
 
-def measure_other_config(A, name, device):
+def measure_other_config(A, name, device, group_local=0):
     """A short driver-visible measurement of one of the other BASELINE.json configs at its per-GPU size: golden check out of the full-size
     sampler, then HIP-event time of adapted launches.  -> dict for the bench line's `other_configs`."""
     fam, n_obs, chains, b_alg, ops_per_obs, label = OTHER_WORKLOADS[name]
     spec = other_spec(name, A.lib().amwg_exp)
     P = spec["P"]
-    mk = lambda off: A.Sampler(spec, chains=chains, seed=SEED, chain_offset=off, device=device, steps_per_launch=100)
+    mk = lambda off: A.Sampler(spec, chains=chains, seed=SEED, chain_offset=off, device=device, steps_per_launch=100, group_local=group_local)
     probe = mk(0)
     lanes = probe.launch_info()["lanes_per_chain"]
     probe.close()
@@ -299,6 +299,15 @@ def measure_other_config(A, name, device):
         note = ("roofline = the term-by-term pass (1 fp64 add per observation), %.3g param-updates/s; `value` is the exact fast-forward of the same two-valued "
                 "sum (bit-identical), which does not stream the data" % roof_updates_per_s)
     lane_ops = roof_updates_per_s * n_obs * ops_per_obs
+    if group_local:
+        # group-local evaluation: a step of the P = G + 2 updates makes TWO passes over the data (the sweep over theta and the sigma update)
+        # instead of P; the fp64 work per update is what those two passes do, not one pass per update
+        lane_ops = roof_updates_per_s * (2.0 / P) * n_obs * ops_per_obs
+        label += " -- GROUP-LOCAL evaluation (amwg_options::group_local, opt-in: not the reference's operation schedule; decisions identical)"
+        out["workload"] = label
+        note = ("group-local: the %d proposals for theta of a step are evaluated in one pass (every lane with the proposed mean of its own group) and decided on "
+                "their local differences, mu needs no pass, sigma one: 2 passes per step instead of %d (mcmc.js:524-526 makes 2 per update).  roofline = "
+                "the arithmetic of those two passes; the rest of a step is the stepper's serial logic" % (P - 2, P))
     out["roofline"] = {"bound": "fp64_valu", "achieved": lane_ops, "peak": FP64_VALU_PEAK, "frac": lane_ops / FP64_VALU_PEAK, "unit": "fp64 lane-operations/s",
                        "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[fam], "kernel": kernel, "note": note,
                        "effective_hbm_gbps": value * b_alg / 1e9}
@@ -320,6 +329,7 @@ def main():
                     help="steps fused into one kernel launch; warm-up and timed steps use the same launch size so the "
                          "per-launch time bench.py reports is comparable with rocprofv3's per-kernel average")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--group-local", action="store_true", help="cfg4 only: the opt-in group-local evaluation (amwg_options::group_local)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short measurements of cfg3 / cfg4 / cfg5 appended to the default line")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K-step region until this much time is on the clock (median reported)")
     ap.add_argument("--single-region", action="store_true", help="time the K-step region once (profiling runs)")
@@ -366,7 +376,7 @@ def main():
             args.chains_per_gpu = default_chains
     chains = args.chains_per_gpu
     offset, _ = chain_shard(rank, world, chains * world)
-    mk = lambda off: A.Sampler(spec, chains=chains, seed=SEED, chain_offset=off, device=dev_index,
+    mk = lambda off: A.Sampler(spec, chains=chains, seed=SEED, chain_offset=off, device=dev_index, group_local=int(args.group_local),
                                lanes_per_chain=args.lanes, block_threads=args.block, steps_per_launch=args.steps_per_launch)
     parity = None
     if world == 1 and args.workload in GOLDEN_OF:
@@ -453,6 +463,9 @@ def main():
                          % (roof_updates / roof_launch_s))
             t.close()
         lane_ops = roof_updates * n_obs * ops_per_obs / roof_launch_s
+        if args.group_local:
+            lane_ops *= 2.0 / P          # two passes per step of P updates (see measure_other_config)
+            label += " -- GROUP-LOCAL evaluation (opt-in; not the reference's operation schedule)"
         out = {
             "metric": "posterior draws/sec (= param-updates/sec)", "value": value, "unit": "param-updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt * 1e3 / K, "higher_is_better": True,
@@ -490,11 +503,14 @@ def main():
             out["parity"] = parity
         if world == 1 and args.workload == "cfg2" and not args.no_other_configs:
             out["other_configs"] = {}
-            for name in ("cfg3", "cfg4", "cfg5"):
+            for name in ("cfg3", "cfg4", "cfg5", "cfg4_group_local"):
                 try:
-                    out["other_configs"][name] = measure_other_config(A, name, dev_index)
+                    out["other_configs"][name] = measure_other_config(A, name.split("_")[0], dev_index, group_local=int(name.endswith("group_local")))
                 except Exception as e:      # a failure here must not cost the headline line
                     out["other_configs"][name] = {"error": repr(e)}
+            o = out["other_configs"]
+            if "value" in o.get("cfg4", {}) and "value" in o.get("cfg4_group_local", {}):
+                o["cfg4_group_local"]["speedup_over_cfg4"] = o["cfg4_group_local"]["value"] / o["cfg4"]["value"]
         if world == 1 and not args.no_cpu_baseline:
             ref = cpu_baseline_reference(args.workload)
             out["cpu_baseline"] = ref if ref is not None else cpu_baseline_port(spec)

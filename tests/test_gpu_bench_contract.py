@@ -33,11 +33,12 @@ def test_default_line_has_the_contract_fields_and_an_honest_roofline():
     assert d["timing"]["regions"] >= 3 and len(d["timing"]["region_ms"]) == min(64, d["timing"]["regions"])      # the first 64 regions are listed
     assert d["parity"]["draws_bit_identical"] and d["parity"]["accept_counts_identical"] and d["parity"]["final_state_bit_identical"]
     assert d["parity"]["from_timed_sampler"] is True and d["parity"]["chains_checked"] == [0, 65535]
-    for name in ("cfg3", "cfg4", "cfg5"):          # the driver's record carries every north-star config
+    for name in ("cfg3", "cfg4", "cfg5", "cfg4_group_local"):          # the driver's record carries every north-star config
         o = d["other_configs"][name]
         assert "error" not in o, o
         assert o["value"] > 0 and 0 < o["roofline"]["frac"] < 1 and o["parity"]["accept_counts_identical"] and o["parity"]["uniforms_consumed_identical"]
     assert d["other_configs"]["cfg3"]["parity"]["draws_bit_identical"] is True
+    assert d["other_configs"]["cfg4_group_local"]["speedup_over_cfg4"] > 3
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "param-updates/s" and c["sample"]
     assert c["kind"] == "reference" or c.get("reference_unavailable") is True
