@@ -45,7 +45,7 @@ class UserModel(C.Structure):
                 ("parallel", C.c_int32), ("max_threads", C.c_int32), ("work_per_eval", C.c_double), ("work_one_lane", C.c_double)]
 
 
-EXPORTS = ["amwg_tuning", "amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_math1", "amwg_math2", "amwg_hypot3", "amwg_log1p", "amwg_expm1", "amwg_two_valued_sum_check", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
+EXPORTS = ["amwg_code_cache_stats", "amwg_tuning", "amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_math1", "amwg_math2", "amwg_hypot3", "amwg_log1p", "amwg_expm1", "amwg_two_valued_sum_check", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
            "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components",
            "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp",
            "amwg_log", "amwg_uniform", "amwg_device_eval"]
@@ -91,6 +91,7 @@ def lib():
         L.amwg_uniform.argtypes = [u64, u64, u64]
         L.amwg_device_eval.argtypes = [i32, i32, i64, pd, pd, pd, pd]
         L.amwg_compile_user.argtypes = [C.c_char_p, i32, i32, C.c_char_p, C.POINTER(C.c_size_t)]
+        L.amwg_code_cache_stats.argtypes = [pi64, pi64, C.c_char_p, C.c_size_t]
         L.amwg_create_user.argtypes = [C.POINTER(UserModel), C.POINTER(ParamDesc), i32, pd, C.POINTER(CompOpt),
                                        C.POINTER(Options), C.POINTER(vp)]
         L.amwg_num_recorded.argtypes = [vp]
@@ -341,6 +342,14 @@ def group_quantiles(samplers, probs):
     out = np.empty((PR, pr.size))
     _check(lib().amwg_group_quantiles(arr, n, _dp(pr), pr.size, _dp(out)))
     return out
+
+
+def code_cache_stats():
+    """(hits, misses, directory) of the on-disk cache of compiled closures in this process."""
+    h, m = C.c_int64(0), C.c_int64(0)
+    buf = C.create_string_buffer(1024)
+    _check(lib().amwg_code_cache_stats(C.byref(h), C.byref(m), buf, 1024))
+    return h.value, m.value, buf.value.decode()
 
 
 def fp64_peak(device=0):

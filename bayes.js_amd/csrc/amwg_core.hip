@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -581,19 +583,91 @@ static std::string user_program(const char *source, int lanes, int block) {
   return p;
 }
 
+// ---- on-disk cache of compiled code objects.  hiprtc takes ~0.6 s per closure and geometry; the reference's own use -- one chain, a
+// script run once (README.md:41-42) -- would pay that at every start.  Key = everything that determines the code object: the program
+// text, the embedded kernel headers, the compile options, the target, the hiprtc version.  Files: <dir>/<128-bit key hash>.hsaco, each
+// carrying the key's length and a second hash, written to a temporary name and renamed (concurrent processes never see a partial file).
+// Directory: $AMWG_CACHE_DIR, else $XDG_CACHE_HOME/amwg, else $HOME/.cache/amwg; AMWG_CACHE_DIR="" (empty) or an unwritable directory
+// disables it silently -- the cache is an optimisation, never a requirement.
+namespace {
+struct CacheKey { uint64_t h1, h2, h3; uint64_t len; };
+CacheKey hash_key(const std::vector<std::string> &parts) {
+  CacheKey k{0xcbf29ce484222325ull, 0x84222325cbf29ce4ull, 0x9e3779b97f4a7c15ull, 0};
+  for (const std::string &p : parts) {
+    for (unsigned char c : p) {
+      k.h1 = (k.h1 ^ c) * 0x100000001b3ull;                                   // FNV-1a
+      k.h2 = (k.h2 + c + (k.h2 << 6) + (k.h2 >> 2)) * 0xff51afd7ed558ccdull;  // an unrelated mix
+      k.h3 = ((k.h3 << 5) | (k.h3 >> 59)) ^ (c * 0xc4ceb9fe1a85ec53ull);
+    }
+    k.h1 = (k.h1 ^ 0xff) * 0x100000001b3ull;                                  // part separator
+    k.len += p.size() + 1;
+  }
+  return k;
+}
+std::string cache_dir() {
+  if (const char *d = getenv("AMWG_CACHE_DIR")) return d;       // (empty string: disabled)
+  if (const char *x = getenv("XDG_CACHE_HOME")) if (*x) return std::string(x) + "/amwg";
+  if (const char *h = getenv("HOME")) if (*h) return std::string(h) + "/.cache/amwg";
+  return "";
+}
+void make_dirs(const std::string &path) {      // mkdir -p
+  for (size_t i = 1; i <= path.size(); ++i)
+    if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), 0755);
+}
+const char kCacheMagic[8] = {'A', 'M', 'W', 'G', 'c', 'o', '0', '1'};
+bool cache_read(const std::string &file, const CacheKey &k, std::vector<char> *code) {
+  FILE *f = fopen(file.c_str(), "rb");
+  if (!f) return false;
+  char magic[8];
+  uint64_t hdr[3] = {0, 0, 0}, n = 0;
+  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kCacheMagic, 8) == 0 && fread(hdr, 8, 3, f) == 3 && fread(&n, 8, 1, f) == 1 &&
+            hdr[0] == k.h2 && hdr[1] == k.h3 && hdr[2] == k.len && n > 0 && n < (1ull << 31);
+  if (ok) { code->resize((size_t)n); ok = fread(code->data(), 1, (size_t)n, f) == (size_t)n; }
+  fclose(f);
+  return ok;
+}
+void cache_write(const std::string &dir, const std::string &file, const CacheKey &k, const std::vector<char> &code) {
+  make_dirs(dir);
+  const std::string tmp = file + ".tmp." + std::to_string((long)getpid());
+  FILE *f = fopen(tmp.c_str(), "wb");
+  if (!f) return;
+  const uint64_t hdr[3] = {k.h2, k.h3, k.len}, n = code.size();
+  const bool ok = fwrite(kCacheMagic, 1, 8, f) == 8 && fwrite(hdr, 8, 3, f) == 3 && fwrite(&n, 8, 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
+  if (fclose(f) != 0 || !ok || rename(tmp.c_str(), file.c_str()) != 0) (void)remove(tmp.c_str());
+}
+int g_cache_hits = 0, g_cache_misses = 0;
+}  // namespace
+
 static int compile_user(const char *source, int lanes, int block, const char *arch, std::vector<char> *code) {
   static const char *names[] = {"amwg_stdint.h", "amwg_types.h", "amwg_math.h", "amwg_div.h", "amwg_ld.h", "amwg_philox.h",
                                 "amwg_kernel.h", "amwg_user.h", "amwg_twoval.h", "amwg_trig.h", "amwg_pass.h"};
   const char *texts[] = {amwg_hdr_stdint, amwg_hdr_types, amwg_hdr_math, amwg_hdr_div, amwg_hdr_ld, amwg_hdr_philox,
                          amwg_hdr_kernel, amwg_hdr_user, amwg_hdr_twoval, amwg_hdr_trig, amwg_hdr_pass};
   const std::string prog_src = user_program(source, lanes, block);
+  const char *const kOpts[] = {"-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-falign-loops=64"};
+  // the on-disk cache (see above)
+  std::string dir = cache_dir(), file;
+  CacheKey key{};
+  if (!dir.empty()) {
+    int rt_major = 0, rt_minor = 0;
+    (void)hiprtcVersion(&rt_major, &rt_minor);
+    std::vector<std::string> parts = {prog_src, arch, "hiprtc " + std::to_string(rt_major) + "." + std::to_string(rt_minor)};
+    for (const char *o : kOpts) parts.push_back(o);
+    for (const char *t : texts) parts.push_back(t);
+    key = hash_key(parts);
+    char name[64];
+    snprintf(name, sizeof name, "/%016llx%016llx.hsaco", (unsigned long long)key.h1, (unsigned long long)key.h2);
+    file = dir + name;
+    if (cache_read(file, key, code)) { ++g_cache_hits; return AMWG_OK; }
+  }
+  ++g_cache_misses;
   hiprtcProgram prog = nullptr;
   hiprtcResult r = hiprtcCreateProgram(&prog, prog_src.c_str(), "amwg_user_model.hip", 11, texts, names);
   if (r != HIPRTC_SUCCESS) return fail(AMWG_EHIP, "hiprtcCreateProgram failed: %s", hiprtcGetErrorString(r));
   const std::string arch_opt = std::string("--offload-arch=") + arch;
   // same floating-point contract as the Makefile: one rounding per operation, no fused contraction
-  const char *opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value"};
-  r = hiprtcCompileProgram(prog, 6, opts);
+  const char *opts[] = {arch_opt.c_str(), kOpts[0], kOpts[1], kOpts[2], kOpts[3], kOpts[4], kOpts[5]};
+  r = hiprtcCompileProgram(prog, 7, opts);
   if (r != HIPRTC_SUCCESS) {
     size_t n = 0;
     hiprtcGetProgramLogSize(prog, &n);
@@ -608,6 +682,7 @@ static int compile_user(const char *source, int lanes, int block, const char *ar
   code->resize(cs);
   hiprtcGetCode(prog, code->data());
   hiprtcDestroyProgram(&prog);
+  if (!file.empty()) cache_write(dir, file, key, *code);
   if (const char *dump = getenv("AMWG_DUMP_CODE_OBJECT")) {   // development aid: inspect the ISA with llvm-objdump
     if (FILE *f = fopen(dump, "wb")) { fwrite(code->data(), 1, code->size(), f); fclose(f); }
   }
@@ -679,6 +754,13 @@ static int autotune_geometry(amwg_sampler *s, int n_cus, size_t max_lds, Prepare
 }
 
 extern "C" {
+
+int amwg_code_cache_stats(int64_t *hits, int64_t *misses, char *dir, size_t dir_capacity) {
+  if (hits) *hits = g_cache_hits;
+  if (misses) *misses = g_cache_misses;
+  if (dir && dir_capacity) snprintf(dir, dir_capacity, "%s", cache_dir().c_str());
+  return AMWG_OK;
+}
 
 int amwg_compile_user(const char *source, int32_t lanes_per_chain, int32_t block_threads, const char *arch, size_t *code_bytes) {
   if (!source || !arch) return fail(AMWG_EINVAL, "amwg_compile_user: null argument");

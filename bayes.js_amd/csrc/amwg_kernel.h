@@ -192,8 +192,10 @@ __device__ __forceinline__ void wave_priority(int p) {
 // other wave's vector work -- instead of being hoisted out of the step loop and carried in scalar registers across all of it
 __device__ __forceinline__ int fresh_uniform(int v) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#if !defined(AMWG_X_NOFRESH)
   v = __builtin_amdgcn_readfirstlane(v);      // (folds away when the value is already in a scalar register)
   asm volatile("" : "+s"(v));
+#endif
 #endif
   return v;
 }

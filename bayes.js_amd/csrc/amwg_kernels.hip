@@ -30,7 +30,11 @@ using Family = PoisGlmModel;
 
 namespace {
 
+#if defined(AMWG_X_BT1024)       // development experiment: every instantiation with the 1024-thread register budget, as in round 2
+constexpr int class_of(int) { return 1024; }
+#else
 constexpr int class_of(int block) { return block <= 256 ? 256 : (block <= 512 ? 512 : 1024); }
+#endif
 
 template <int G>
 step_kernel_t single_wave(int block) {      // G <= 64: any workgroup size up to the family's cap

@@ -206,8 +206,13 @@ AMWG_HD double log_v8(double x) {
 
 // Out-of-line copies for call sites that are rarely reached from inside the step loop (the rejection test of rnorm, a batch boundary, a
 // changed sd): inlined there, their bodies and two dozen polynomial constants would sit in the hot loop's code and scalar registers.
+#if defined(AMWG_X_NOCOLD)
+AMWG_HD double log_v8_cold(double x) { return log_v8(x); }
+AMWG_HD double exp_v8_cold(double x) { return exp_v8(x); }
+#else
 AMWG_HD_OUTLINE double log_v8_cold(double x) { return log_v8(x); }
 AMWG_HD_OUTLINE double exp_v8_cold(double x) { return exp_v8(x); }
+#endif
 
 // ---- pow(x, y): V8's Math.pow (src/base/ieee754.cc pow, the fdlibm e_pow.c algorithm; V8 groups the
 // final quotient differently from fdlibm -- marked below -- and Node's values follow V8).  Used by

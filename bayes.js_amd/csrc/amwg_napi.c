@@ -605,6 +605,22 @@ static napi_value GroupQuantiles(napi_env env, napi_callback_info info) {
   return rc == AMWG_OK ? out : throw_amwg(env, rc);
 }
 
+/* {hits, misses, dir} of the on-disk cache of compiled closures (amwg_code_cache_stats) */
+static napi_value CodeCacheStats(napi_env env, napi_callback_info info) {
+  (void)info;
+  int64_t h = 0, m = 0;
+  char dir[1024];
+  dir[0] = 0;
+  int rc = amwg_code_cache_stats(&h, &m, dir, sizeof dir);
+  if (rc != AMWG_OK) return throw_amwg(env, rc);
+  napi_value o, t;
+  NAPI_OK(napi_create_object(env, &o));
+  napi_create_double(env, (double)h, &t); napi_set_named_property(env, o, "hits", t);
+  napi_create_double(env, (double)m, &t); napi_set_named_property(env, o, "misses", t);
+  napi_create_string_utf8(env, dir, NAPI_AUTO_LENGTH, &t); napi_set_named_property(env, o, "dir", t);
+  return o;
+}
+
 static napi_value LaunchInfo(napi_env env, napi_callback_info info) {
   napi_value a[1];
   if (!get_args(env, info, 1, a)) return NULL;
@@ -679,7 +695,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   static const struct { const char *name; napi_callback fn; } fns[] = {
       {"create", Create}, {"createUser", CreateUser}, {"compileUser", CompileUser}, {"destroy", Destroy}, {"burn", Burn}, {"burnAsync", BurnAsync}, {"sync", Sync},
       {"sample", Sample}, {"sampleAsync", SampleAsync}, {"fetchDraws", FetchDraws}, {"setAdapting", SetAdapting},
-      {"getState", GetState}, {"setState", SetState}, {"convergence", Convergence}, {"quantiles", Quantiles}, {"groupMoments", GroupMoments}, {"groupConvergence", GroupConvergence}, {"groupQuantiles", GroupQuantiles}, {"info", Info}, {"diag", Diag}, {"moments", Moments}, {"launchInfo", LaunchInfo},
+      {"getState", GetState}, {"setState", SetState}, {"convergence", Convergence}, {"quantiles", Quantiles}, {"groupMoments", GroupMoments}, {"groupConvergence", GroupConvergence}, {"groupQuantiles", GroupQuantiles}, {"info", Info}, {"diag", Diag}, {"moments", Moments}, {"launchInfo", LaunchInfo}, {"codeCacheStats", CodeCacheStats},
       {"version", Version}, {"mathExp", MathExp}, {"mathLog", MathLog}, {"uniform", Uniform}};
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

@@ -612,5 +612,8 @@ AmwgStepper.prototype.info = function () {     // keyed by the parameter each en
   return out;
 };
 
-module.exports = { runif, runif_discrete, rnorm, AmwgSampler, complete_params, param_init_fixed, componentOptions, models, ld, native, translate: translator.translate,
+/** {hits, misses, dir} of the on-disk cache of compiled closures in this process ($AMWG_CACHE_DIR | $XDG_CACHE_HOME/amwg | ~/.cache/amwg). */
+function code_cache_stats() { return native().codeCacheStats(); }
+
+module.exports = { code_cache_stats, runif, runif_discrete, rnorm, AmwgSampler, complete_params, param_init_fixed, componentOptions, models, ld, native, translate: translator.translate,
   RealMetropolisStepper, IntMetropolisStepper, MultiRealComponentMetropolisStepper, MultiIntComponentMetropolisStepper, BinaryStepper, BinaryComponentStepper, AmwgStepper };

@@ -111,6 +111,36 @@ def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None):
     return None, None, None
 
 
+def end_to_end_js(chains, n_obs):
+    """SURVEY.md section 8(d) asks for kernel-only AND end-to-end: the same job through the JavaScript host (bench/js_e2e.js: require, constructor incl.
+    translation + hiprtc or the on-disk code-object cache, burn(1000), sample(1000) INCLUDING the copy of every draw to the host and into the
+    arrays sample() returns), plus the reference's own use -- one chain, constructed twice.  None when Node or the addon is missing."""
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if node is None or not os.path.exists(os.path.join(ROOT, "bayes.js_amd", "csrc", "amwg_napi.node")):
+        return None
+    try:
+        p = subprocess.run([node, "--max-old-space-size=8192", os.path.join(ROOT, "bench", "js_e2e.js"), "--chains", str(chains), "--n-obs", str(n_obs)],
+                           capture_output=True, text=True, timeout=300)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+        r = json.loads(line)
+    except (subprocess.SubprocessError, ValueError, IndexError, OSError) as e:
+        return {"error": repr(e)}
+    m = r["many_chains"]
+    out = {"what": "node bench/js_e2e.js: new mcmc.AmwgSampler(README closure, %d obs, {chains: %d}) + burn(%d) + sample(%d) incl. the copy-out of every draw + close()"
+                   % (m["n_obs"], m["chains"], m["burn"], m["sample"]),
+           "updates_per_s": m["updates_per_s"], "updates_per_s_excl_constructor": m["updates_per_s_excl_ctor"], "unit": "param-updates/s",
+           "ctor_ms": m["ctor_ms"], "burn_ms": m["burn_ms"], "sample_ms_incl_copy_out": m["sample_ms"], "total_ms": m["total_ms"], "gb_copied": m["gb_copied"],
+           "lanes_per_chain": (m.get("launch") or [{}])[0].get("lanes_per_chain"), "node": r["node"], "require_ms": r["require_ms"], "code_cache": r.get("code_cache")}
+    if "single_chain_first" in r:
+        a, b = r["single_chain_first"], r["single_chain_again"]
+        out["single_chain"] = {"what": "README.md:18-43 as is: ONE chain, ten heights, burn(1000) + sample(5000); constructed twice in one process",
+                               "first": {"ctor_ms": a["ctor_ms"], "burn_ms": a["burn_ms"], "sample_ms": a["sample_ms"], "total_ms": a["total_ms"], "updates_per_s": a["updates_per_s"]},
+                               "again": {"ctor_ms": b["ctor_ms"], "burn_ms": b["burn_ms"], "sample_ms": b["sample_ms"], "total_ms": b["total_ms"], "updates_per_s": b["updates_per_s"]}}
+    return out
+
+
 def reference_dir():
     """Where the unmodified reference can be loaded from: $AMWG_REF_DIR, /root/reference (build container), or oracle/_ref -- the
     copy `make -C oracle ref` (run by __graft_entry__.build()) leaves beside the oracle; git-ignored, it travels to the GPU box."""
@@ -316,6 +346,77 @@ def measure_other_config(A, name, device, group_local=0):
     return out
 
 
+def main_inproc(args):
+    """`--inproc`: the PRODUCT's own multi-device path, which is what a JavaScript user gets from `options.devices`: ONE process, one sampler
+    per device holding a contiguous shard of the global chain ids, every device driven from this thread with amwg_burn_async /
+    amwg_sample_async + amwg_sync, and the posterior summary of the sharded job formed inside the library (amwg_group_moments: per-device
+    reductions + RCCL all-reduce over the shards' devices).  No torch.distributed.  Weak scaling by default (the workload's chains per GPU on
+    every device); `--strong` keeps the job's TOTAL chain count (cfg4: 16 384, cfg5: 65 536, cfg2: 65 536, cfg3: 262 144) and splits it."""
+    import torch
+    import amwg_ctypes as A
+    N = args.gpus
+    have = torch.cuda.device_count()
+    base = {"metric": "posterior draws/sec (= param-updates/sec)", "unit": "param-updates/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "inproc": True}
+    if have < N:
+        print(json.dumps(dict(base, value=None, ms_per_step=None, config={"workload": args.workload},
+                              note="not measured: --inproc --gpus %d needs %d visible devices, this box has %d" % (N, N, have))), flush=True)
+        return
+    if args.workload == "cfg2":
+        spec, per_gpu, label, n_obs, ops_per_obs = normal_spec(), CHAINS_PER_GPU, "BASELINE.json configs[1]: Normal(mu,sigma) AMWG, 1e4 synthetic obs", N_OBS, 8
+        total_job = CHAINS_PER_GPU
+    else:
+        spec = other_spec(args.workload, A.lib().amwg_exp)
+        _, n_obs, per_gpu, _, ops_per_obs, label = OTHER_WORKLOADS[args.workload]
+        total_job = {"cfg3": 262_144, "cfg4": 16_384, "cfg5": 65_536, "readme": 1}[args.workload]
+    if args.chains_per_gpu != CHAINS_PER_GPU:
+        per_gpu = args.chains_per_gpu
+    total = total_job if args.strong else per_gpu * N
+    P, K, W, thin = spec["P"], args.steps, args.warmup, max(1, args.thin)
+    shards, off = [], 0
+    for r in range(N):
+        cnt = total // N + (1 if r < total % N else 0)
+        shards.append(A.Sampler(spec, chains=cnt, seed=SEED, chain_offset=off, device=r, lanes_per_chain=args.lanes, block_threads=args.block,
+                                steps_per_launch=args.steps_per_launch, group_local=int(args.group_local)))
+        off += cnt
+    for s in shards:
+        s.burn_async(W)
+    for s in shards:
+        s.sync()
+
+    def region():
+        t0 = time.perf_counter()
+        for s in shards:
+            s.sample_async(K, thin)            # draws stay in each device's HBM
+        for s in shards:
+            s.sync()
+        mean, sd = A.group_moments(shards)     # the one exchange of the job: per-device sums, RCCL all-reduce (inside the library)
+        return time.perf_counter() - t0, mean, sd
+    regs = [region()]
+    n_regions = 1 if args.single_region else int(min(400, max(3, np.ceil(args.min_seconds / max(regs[0][0], 1e-6)))))
+    while len(regs) < n_regions:
+        regs.append(region())
+    order = sorted(range(len(regs)), key=lambda i: regs[i][0])
+    dt, mean, sd = regs[order[len(order) // 2]]
+    value = total * K * P / dt
+    kernel_ms = max(s.launch_info()["kernel_ms"] for s in shards)
+    li = shards[0].launch_info()
+    lane_ops = value * n_obs * ops_per_obs * ((2.0 / P) if args.group_local else 1.0)
+    out = dict(base, value=value, ms_per_step=dt * 1e3 / K,
+               config={"workload": label + (" -- GROUP-LOCAL evaluation" if args.group_local else ""), "n_obs": n_obs, "chains_total": total,
+                       "chains_per_gpu": [s.C for s in shards], "components": P, "thin": thin, "lanes_per_chain": li["lanes_per_chain"],
+                       "block_threads": li["block_threads"], "steps_per_launch": args.steps_per_launch,
+                       "path": "one process, one sampler per device (amwg_sample_async x N + amwg_sync), summaries by amwg_group_moments (RCCL all-reduce in the library)"},
+               timing={"regions": len(regs), "reported": "median region (wall clock around sample_async x N + sync x N + group_moments)",
+                       "region_ms": [r[0] * 1e3 for r in regs][:64], "slowest_device_kernel_ms_last_region": kernel_ms},
+               roofline={"bound": "fp64_valu", "achieved": lane_ops, "peak": FP64_VALU_PEAK * N, "frac": lane_ops / (FP64_VALU_PEAK * N),
+                         "unit": "fp64 lane-operations/s", "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[spec["model"]]},
+               posterior={"mean": mean.tolist()[:8], "sd": sd.tolist()[:8], "note": "amwg_group_moments over the recorded draws of all shards (last region)"})
+    print(json.dumps(out), flush=True)
+    for s in shards:
+        s.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -330,6 +431,9 @@ def main():
                          "per-launch time bench.py reports is comparable with rocprofv3's per-kernel average")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--group-local", action="store_true", help="cfg4 only: the opt-in group-local evaluation (amwg_options::group_local)")
+    ap.add_argument("--inproc", action="store_true", help="the product's own multi-device path: one process, one sampler per device, amwg_group_moments (see main_inproc)")
+    ap.add_argument("--strong", action="store_true", help="--inproc only: keep the job's total chain count and split it over the devices")
+    ap.add_argument("--no-js", action="store_true", help="skip the end-to-end run through the JavaScript host (bench/js_e2e.js)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short measurements of cfg3 / cfg4 / cfg5 appended to the default line")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K-step region until this much time is on the clock (median reported)")
     ap.add_argument("--single-region", action="store_true", help="time the K-step region once (profiling runs)")
@@ -337,6 +441,8 @@ def main():
                     help="cfg2 (default) is the bench line; the others measure the remaining BASELINE.json configs")
     args = ap.parse_args()
 
+    if args.inproc:
+        return main_inproc(args)
     import torch
     import amwg_ctypes as A
 
@@ -508,6 +614,8 @@ def main():
                     out["other_configs"][name] = measure_other_config(A, name.split("_")[0], dev_index, group_local=int(name.endswith("group_local")))
                 except Exception as e:      # a failure here must not cost the headline line
                     out["other_configs"][name] = {"error": repr(e)}
+            if not args.no_js:
+                out["end_to_end_js"] = end_to_end_js(chains, n_obs)
             o = out["other_configs"]
             if "value" in o.get("cfg4", {}) and "value" in o.get("cfg4_group_local", {}):
                 o["cfg4_group_local"]["speedup_over_cfg4"] = o["cfg4_group_local"]["value"] / o["cfg4"]["value"]

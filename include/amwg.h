@@ -159,6 +159,12 @@ int amwg_create_user(const amwg_user_model *model, const amwg_param_desc *params
  * arch e.g. "gfx950".  On failure returns AMWG_EINVAL and amwg_last_error() carries the compiler log. */
 int amwg_compile_user(const char *source, int32_t lanes_per_chain, int32_t block_threads, const char *arch, size_t *code_bytes);
 
+/* Compiled closures are kept on disk ($AMWG_CACHE_DIR, else $XDG_CACHE_HOME/amwg, else $HOME/.cache/amwg; AMWG_CACHE_DIR="" disables), keyed by
+ * program text + kernel headers + compile options + target + hiprtc version: a second process constructing the same sampler loads the
+ * code object instead of compiling it (README.md:41-42: a script that is simply run again).  This process's hits / misses so far; `dir`
+ * (may be null) receives the directory in use, empty when the cache is off. */
+int amwg_code_cache_stats(int64_t *hits, int64_t *misses, char *dir, size_t dir_capacity);
+
 /* Replaces sampler.burn(n) (mcmc.js:1035-1039).  amwg_burn blocks until the steps are done;
  * amwg_burn_async only enqueues them on the sampler's stream (pair with amwg_sync), which is how
  * one host thread keeps several GPUs busy. */

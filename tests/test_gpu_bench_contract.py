@@ -50,3 +50,15 @@ def test_other_workloads_report_a_roofline(workload):
     assert d["roofline"]["bound"] == "fp64_valu" and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
     if workload == "cfg3":
         assert "term-by-term" in d["roofline"]["kernel"]
+
+
+def test_inproc_multi_device_path_runs_on_one_gpu_and_declines_more():
+    """`--inproc`: the product's own multi-device path (one process, N samplers, amwg_group_moments) with the bench contract's fields; on a
+    one-GPU box N = 1 is measured and N = 2 says so instead of inventing a number."""
+    d = _bench("--inproc", "--workload", "cfg4", "--strong", "--chains-per-gpu", "512")
+    assert d["inproc"] is True and d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["chains_total"] == 16384
+    assert len(d["posterior"]["mean"]) == 8 and all(abs(m) < 50 for m in d["posterior"]["mean"])
+    import torch
+    if torch.cuda.device_count() < 2:
+        d2 = _bench("--inproc", "--gpus", "2")
+        assert d2["value"] is None and "not measured" in d2["note"]

@@ -188,3 +188,28 @@ def test_fuzzed_closures_equal_v8_on_host(seed):
                     assert all(same(a, b) for a, b in zip(dvl, dv)), (name, lanes, state)
                     assert same(v, got) or (math.isfinite(got) and abs(v - got) <= 1e-9 * max(1.0, abs(got))), (name, lanes, state, v, got)
     assert checked >= 2 * 40 * 26
+
+
+def test_compiled_closures_are_cached_on_disk(tmp_path, monkeypatch):
+    """The second compilation of the same closure + geometry + target is a file read: a fresh process would load the code object instead of
+    spending ~0.6 s in hiprtc (amwg_code_cache_stats counts this process's hits and misses; a changed geometry is a different key)."""
+    monkeypatch.setenv("AMWG_CACHE_DIR", str(tmp_path / "cache"))
+    m = user_host.host_model("readme_normal")
+    L = A.lib()
+    n = C.c_size_t(0)
+    h0, m0, d = A.code_cache_stats()
+    assert d == str(tmp_path / "cache")
+    assert L.amwg_compile_user(m.source.encode(), 4, 256, b"gfx950", C.byref(n)) == 0
+    first = n.value
+    files = list((tmp_path / "cache").glob("*.hsaco"))
+    assert len(files) == 1 and files[0].stat().st_size > first
+    assert L.amwg_compile_user(m.source.encode(), 4, 256, b"gfx950", C.byref(n)) == 0 and n.value == first
+    h1, m1, _ = A.code_cache_stats()
+    assert (h1 - h0, m1 - m0) == (1, 1)
+    assert L.amwg_compile_user(m.source.encode(), 8, 256, b"gfx950", C.byref(n)) == 0            # another geometry: another entry
+    assert len(list((tmp_path / "cache").glob("*.hsaco"))) == 2
+    files[0].write_bytes(files[0].read_bytes()[:100])                                              # a damaged file is ignored and replaced
+    assert L.amwg_compile_user(m.source.encode(), 4, 256, b"gfx950", C.byref(n)) == 0 and n.value == first
+    monkeypatch.setenv("AMWG_CACHE_DIR", "")                                                        # off
+    assert A.code_cache_stats()[2] == ""
+    assert L.amwg_compile_user(m.source.encode(), 4, 256, b"gfx950", C.byref(n)) == 0

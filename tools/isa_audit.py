@@ -24,7 +24,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "bayes.js_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function --cuda-device-only -S".split()
+FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -falign-loops=64 -Wno-unused-function --cuda-device-only -S".split()
 
 # the instantiations bench.py times (model, lanes per chain); any workgroup size of those is gated
 DEFAULT_GATE = ["NormalModel,1,256", "HierNormalModel,64,512", "HierNormalModel,32,1024", "PoisGlmModel,64,256", "BetaBernModel,1,1024"]
