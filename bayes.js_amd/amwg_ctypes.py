@@ -45,10 +45,8 @@ class UserModel(C.Structure):
                 ("parallel", C.c_int32), ("max_threads", C.c_int32), ("work_per_eval", C.c_double), ("work_one_lane", C.c_double)]
 
 
-EXPORTS = ["amwg_code_cache_stats", "amwg_tuning", "amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_math1", "amwg_math2", "amwg_hypot3", "amwg_log1p", "amwg_expm1", "amwg_two_valued_sum_check", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state",
-           "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components",
-           "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp",
-           "amwg_log", "amwg_uniform", "amwg_device_eval"]
+EXPORTS = ["amwg_code_cache_stats", "amwg_tuning", "amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state", "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components", "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp", "amwg_log", "amwg_uniform"]      # include/amwg.h: the product library
+SELFTEST_EXPORTS = ["amwg_math1", "amwg_math2", "amwg_hypot3", "amwg_log1p", "amwg_expm1", "amwg_two_valued_sum_check", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_device_eval"]      # include/amwg_selftest.h: libamwg_selftest.so only
 
 _lib = None
 
@@ -89,7 +87,6 @@ def lib():
         L.amwg_log.argtypes = [dbl]
         L.amwg_uniform.restype = dbl
         L.amwg_uniform.argtypes = [u64, u64, u64]
-        L.amwg_device_eval.argtypes = [i32, i32, i64, pd, pd, pd, pd]
         L.amwg_compile_user.argtypes = [C.c_char_p, i32, i32, C.c_char_p, C.POINTER(C.c_size_t)]
         L.amwg_code_cache_stats.argtypes = [pi64, pi64, C.c_char_p, C.c_size_t]
         L.amwg_create_user.argtypes = [C.POINTER(UserModel), C.POINTER(ParamDesc), i32, pd, C.POINTER(CompOpt),
@@ -97,13 +94,33 @@ def lib():
         L.amwg_num_recorded.argtypes = [vp]
         L.amwg_set_state.argtypes = [vp, pd, C.c_size_t]
         L.amwg_fp64_peak.argtypes = [i32, pd]
-        L.amwg_two_valued_sum_check.argtypes = [i32, pd, i32, i64, pd, pd, pd, pd, pd]
         L.amwg_last_sample_quantiles.argtypes = [vp, pd, i32, pd]
         L.amwg_last_sample_diagnostics.argtypes = [vp, pd, pd]
         pvp = C.POINTER(vp)
         L.amwg_group_moments.argtypes = [pvp, i32, pd, pd]
         L.amwg_group_diagnostics.argtypes = [pvp, i32, pd, pd]
         L.amwg_group_quantiles.argtypes = [pvp, i32, pd, i32, pd]
+        _lib = L
+    return _lib
+
+
+_selftest = None
+
+
+def selftest_lib():
+    """libamwg_selftest.so: the product's sources built with -DAMWG_SELFTEST, which adds the entry points of include/amwg_selftest.h (the
+    arithmetic building blocks one by one).  Test suite only; the product library does not carry them."""
+    global _selftest
+    if _selftest is None:
+        path = os.path.join(os.path.dirname(LIB_PATH), "libamwg_selftest.so")
+        if not os.path.exists(path):
+            raise RuntimeError("libamwg_selftest.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(path)
+        i32, i64, dbl = C.c_int32, C.c_int64, C.c_double
+        pd = C.POINTER(dbl)
+        L.amwg_last_error.restype = C.c_char_p
+        L.amwg_device_eval.argtypes = [i32, i32, i64, pd, pd, pd, pd]
+        L.amwg_two_valued_sum_check.argtypes = [i32, pd, i32, i64, pd, pd, pd, pd, pd]
         L.amwg_pow.restype = dbl
         L.amwg_pow.argtypes = [dbl, dbl]
         L.amwg_math1.restype = dbl
@@ -118,8 +135,8 @@ def lib():
         L.amwg_ld_host.restype = dbl
         L.amwg_ld_host.argtypes = [i32, dbl, dbl, dbl, dbl]
         L.amwg_ld_device.argtypes = [i32, i64, pd, pd]
-        _lib = L
-    return _lib
+        _selftest = L
+    return _selftest
 
 
 class AmwgError(RuntimeError):
@@ -364,6 +381,6 @@ def device_eval(op, a, b=None, c=None, device=0):
     out = np.empty_like(a)
     bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
     cc = np.ascontiguousarray(c, dtype=np.float64) if c is not None else None
-    _check(lib().amwg_device_eval(device, op, a.size, _dp(a), _dp(bb) if bb is not None else None,
+    _check(selftest_lib().amwg_device_eval(device, op, a.size, _dp(a), _dp(bb) if bb is not None else None,
                                   _dp(cc) if cc is not None else None, _dp(out)))
     return out

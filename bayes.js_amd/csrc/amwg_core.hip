@@ -18,7 +18,12 @@
 #include <vector>
 
 #include "../../include/amwg.h"
-#include "amwg_eval.h"
+#if defined(AMWG_SELFTEST)
+#include "../../include/amwg_selftest.h"
+#endif
+#if defined(AMWG_SELFTEST)
+#include "amwg_eval.h"      // device evaluation of the arithmetic building blocks: libamwg_selftest.so only
+#endif
 #include "amwg_kernel.h"
 #include "amwg_models.h"
 #include "amwg_sampler.h"
@@ -371,6 +376,7 @@ const char *amwg_version(void) { return "amwg-mi355x 0.1 (gfx950)"; }
 
 double amwg_exp(double x) { return exp_v8(x); }
 double amwg_log(double x) { return log_v8(x); }
+#if defined(AMWG_SELFTEST)      // include/amwg_selftest.h: the building blocks one by one, for the test suite (libamwg_selftest.so)
 double amwg_pow(double x, double y) { return pow_v8(x, y); }
 double amwg_log1p(double x) { return log1p_v8(x); }
 double amwg_expm1(double x) { return expm1_v8(x); }
@@ -386,6 +392,7 @@ double amwg_math2(int32_t fn, double x, double y) {
 }
 double amwg_hypot3(double x, double y, double z) { return hypot3_v8(x, y, z); }
 double amwg_ld_host(int32_t id, double x, double a, double b, double c) { return ld_by_id(id, x, a, b, c); }
+#endif
 double amwg_uniform(uint64_t seed, uint64_t chain, uint64_t index) {
   ChainStream s;
   s.init(seed, chain, index);
@@ -414,6 +421,7 @@ static std::vector<uint32_t> two_valued_tables(const uint8_t *xb, int N) {
   return tab;
 }
 
+#if defined(AMWG_SELFTEST)
 // tests only: thread j sums the same bit sequence from acc0[j] with addends l1[j], l0[j], once with two_valued_sum and
 // once term by term
 __global__ void two_valued_check_kernel(const uint32_t *tab, int N, int64_t m, const double *acc0, const double *l1, const double *l0,
@@ -427,6 +435,7 @@ __global__ void two_valued_check_kernel(const uint32_t *tab, int N, int64_t m, c
   for (int i = 0; i < N; ++i) acc = acc + (((tab[i >> 5] >> (i & 31)) & 1u) ? l1[j] : l0[j]);
   out_seq[j] = acc;
 }
+#endif
 
 // ---- pieces of construction shared by the built-in and the translated models
 #define TRYB(x) do { int rc_ = (x); if (rc_ != AMWG_OK) return rc_; } while (0)
@@ -434,6 +443,10 @@ __global__ void two_valued_check_kernel(const uint32_t *tab, int N, int64_t m, c
 
 static int check_options(const amwg_options *options, int max_threads) {
   if (options->chains < 1) return fail(AMWG_EINVAL, "amwg_create: chains must be >= 1");
+  // a launch counts its accepted / evaluated proposals in 16-bit fields: longer launches are not silently shortened (launch_info and the
+  // bench's per-launch figures assume the requested size)
+  if (options->steps_per_launch < 0 || options->steps_per_launch > 65535)
+    return fail(AMWG_EINVAL, "steps_per_launch must be 0 (auto: one launch per call, chunked at 65535 steps) or 1..65535, got %d", options->steps_per_launch);
   const int G_opt = options->lanes_per_chain;
   if (G_opt && G_opt != AMWG_LANES_FASTEST && G_opt != AMWG_LANES_AUTOTUNE && (G_opt < 1 || G_opt > 1024 || (G_opt & (G_opt - 1))))
     return fail(AMWG_EINVAL, "lanes_per_chain must be a power of two in 1..1024 (or 0 = auto, AMWG_LANES_FASTEST = -1, AMWG_LANES_AUTOTUNE = -2)");
@@ -725,13 +738,27 @@ static int autotune_geometry(amwg_sampler *s, int n_cus, size_t max_lds, Prepare
     s->opt.lanes_per_chain = G;
     if (choose_geometry(s, n_cus, max_lds) != AMWG_OK || prepare() != AMWG_OK) { if (first_error.empty()) first_error = g_err; continue; }
     TuneCandidate c{s->lanes, s->block, s->grid, s->lds, s->cpb, s->kernel, s->user_module, s->user_fn, 0.f};
+    // One untimed launch first (it evaluates log_post(init), stages the data for the first time and warms the instruction cache); then the
+    // run length is scaled until a launch takes >= 1 ms -- short data loops would otherwise be ranked by launch overhead and noise -- and the
+    // candidate's figure is the FASTEST of three such launches, per step.  The runs continue the chains from one another (a valid lp_curr,
+    // no init evaluation inside a timed launch); the saved state is put back once the candidate is done.
     bool ok = true;
-    for (int rep = 0; rep < 2 && ok; ++rep) {          // the first run also evaluates log_post(init) and warms the caches
-      s->lp_ready = false;
-      ok = launch_steps(s, 3, 1, nullptr) == AMWG_OK && finish_timing(s) == AMWG_OK;
-      c.ms = (float)s->kernel_ms;
-      if (copy_all(true) != hipSuccess) ok = false;
+    s->lp_ready = false;
+    ok = launch_steps(s, 1, 1, nullptr) == AMWG_OK && finish_timing(s) == AMWG_OK;
+    int n_tune = 3, kept = 0;
+    float best = -1.f;
+    for (int rep = 0; rep < 10 && ok && kept < 3; ++rep) {
+      ok = launch_steps(s, n_tune, 1, nullptr) == AMWG_OK && finish_timing(s) == AMWG_OK;
+      if (!ok) break;
+      const float ms = (float)s->kernel_ms;
+      if (ms < 1.0f && n_tune < 192) { n_tune *= 4; continue; }      // too short to rank: a longer run
+      const float per_step = ms / (float)n_tune;
+      if (best < 0 || per_step < best) best = per_step;
+      ++kept;
     }
+    if (copy_all(true) != hipSuccess) ok = false;
+    c.ms = best;
+    ok = ok && best >= 0;
     s->lp_ready = false;
     if (ok) cand.push_back(c);
     else if (c.module) { (void)hipModuleUnload(c.module); }
@@ -1340,6 +1367,7 @@ int amwg_fp64_peak(int32_t device, double *lane_ops_per_s) {
   return AMWG_OK;
 }
 
+#if defined(AMWG_SELFTEST)
 int amwg_two_valued_sum_check(int32_t device, const double *x, int32_t n, int64_t m, const double *acc0, const double *l1, const double *l0,
                               double *out_fast_forward, double *out_term_by_term) {
   if (!x || !acc0 || !l1 || !l0 || !out_fast_forward || !out_term_by_term || n < 0 || m < 0) return fail(AMWG_EINVAL, "amwg_two_valued_sum_check: bad argument");
@@ -1400,5 +1428,7 @@ int amwg_device_eval(int32_t device, int32_t op, int64_t n, const double *a, con
   HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
   return AMWG_OK;
 }
+
+#endif   // AMWG_SELFTEST
 
 }  // extern "C"

@@ -102,6 +102,17 @@ int get_comms(const std::vector<int> &devs, std::vector<ncclComm_t> *out) {
   return AMWG_OK;
 }
 
+// An error return between ncclGroupStart and ncclGroupEnd would leave the process-wide RCCL group open -- and the communicators are cached for
+// the life of the process, so every later collective would misbehave or hang.  The guard closes the group on any exit path.
+struct RcclGroupGuard {
+  Rccl &R;
+  bool open = false;
+  explicit RcclGroupGuard(Rccl &r) : R(r) {}
+  ncclResult_t start() { const ncclResult_t rc = R.GroupStart(); open = rc == ncclSuccess; return rc; }
+  ncclResult_t end() { open = false; return R.GroupEnd(); }
+  ~RcclGroupGuard() { if (open) (void)R.GroupEnd(); }
+};
+
 int open_group(amwg_sampler *const *shards, int n, size_t buf_len, bool need_draws, Group *g) {
   if (!shards || n < 1) return amwg_fail(AMWG_EINVAL, "amwg_group: no samplers");
   const int PR = shards[0]->P + shards[0]->D;
@@ -151,13 +162,16 @@ int all_reduce_sum(Group &g, int count, double *host) {
     HIPG(hipGetLastError());
   }
   // leaders: RCCL all-reduce (one rank per distinct device; in place)
-  NCCLG(R.GroupStart());
-  for (size_t r = 0; r < g.leaders.size(); ++r) {
-    const int i = g.leaders[r];
-    HIPG(hipSetDevice(g.shards[i]->device));
-    NCCLG(R.AllReduce(g.buf[i], g.buf[i], (size_t)count, ncclDouble, ncclSum, g.comms[r], g.shards[i]->stream));
+  {
+    RcclGroupGuard grp(R);
+    NCCLG(grp.start());
+    for (size_t r = 0; r < g.leaders.size(); ++r) {
+      const int i = g.leaders[r];
+      HIPG(hipSetDevice(g.shards[i]->device));
+      NCCLG(R.AllReduce(g.buf[i], g.buf[i], (size_t)count, ncclDouble, ncclSum, g.comms[r], g.shards[i]->stream));
+    }
+    NCCLG(grp.end());
   }
-  NCCLG(R.GroupEnd());
   for (size_t r = 0; r < g.leaders.size(); ++r) {
     const int i = g.leaders[r];
     HIPG(hipSetDevice(g.shards[i]->device));
@@ -400,17 +414,20 @@ int amwg_group_quantiles(amwg_sampler *const *shards, int32_t n, const double *p
     bool any_remote = false;
     for (int i = 1; i < n; ++i) any_remote = any_remote || g.shards[i]->device != root->device;
     if (any_remote) {
-      NCCLG(R.GroupStart());
+      for (int i = 1; i < n; ++i)      // (constraints are checked BEFORE the group is opened)
+        if (g.shards[i]->device != root->device && g.leader_of[i] != i)
+          return amwg_fail(AMWG_EINVAL, "amwg_group_quantiles: two shards share a device other than the first shard's");
+      RcclGroupGuard grp(R);
+      NCCLG(grp.start());
       for (int i = 1; i < n; ++i) {
         amwg_sampler *s = g.shards[i];
         if (s->device == root->device) continue;
-        if (g.leader_of[i] != i) return amwg_fail(AMWG_EINVAL, "amwg_group_quantiles: two shards share a device other than the first shard's");
         HIPG(hipSetDevice(s->device));
         NCCLG(R.Send(vals[i], (size_t)cnt[i], ncclDouble, 0, g.comms[g.rank_of[i]], s->stream));
         HIPG(hipSetDevice(root->device));
         NCCLG(R.Recv(all + off[i], (size_t)cnt[i], ncclDouble, g.rank_of[i], g.comms[0], root->stream));
       }
-      NCCLG(R.GroupEnd());
+      NCCLG(grp.end());
     }
     HIPG(hipSetDevice(root->device));
     HIPG(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, all, sorted, (int)total, 0, 64, root->stream));

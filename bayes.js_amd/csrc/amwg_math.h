@@ -10,6 +10,17 @@
 // pins the host build against 120 000 outputs of Node's Math.exp/Math.log and the device
 // build against the host build.
 //
+// The algorithms restated here are those of FreeBSD msun / Sun fdlibm as V8 carries them (src/base/ieee754.cc), whose files bear:
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//   Developed at SunSoft, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
+// (e_exp.c, e_log.c, e_pow.c, s_log1p.c, s_expm1.c, s_tanh.c, s_atan.c, e_log10.c; for amwg_trig.h also k_rem_pio2.c, e_rem_pio2.c, k_sin.c,
+// k_cos.c, k_tan.c, e_asin.c, e_acos.c, e_atan2.c, e_sinh.c, e_cosh.c, s_asinh.c, e_acosh.c, e_atanh.c, s_cbrt.c, e_log2.c.)
+//
 // GPU shaping: both functions are straight-line on the common path; range/special handling
 // is folded into selects or rare branches so 64 chains with different arguments stay converged.
 #pragma once

@@ -23,6 +23,14 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert getattr(L, name) is not None
     assert b"gfx950" in L.amwg_version()
+    # the building blocks exported one by one live in the test build only, not in the product library
+    T = amwg_ctypes.selftest_lib()
+    hdr = open(os.path.join(ROOT, "include", "amwg_selftest.h")).read()
+    declared_t = set(re.findall(r"\b(amwg_[a-z_0-9]+)\s*\(", hdr))
+    assert declared_t == set(amwg_ctypes.SELFTEST_EXPORTS)
+    for name in declared_t:
+        assert getattr(T, name) is not None
+        assert not hasattr(L, name), name + " leaked into the product library"
 
 
 def test_host_math_bit_exact_vs_v8():
@@ -74,7 +82,7 @@ def test_host_build_of_every_ld_function_and_pow_equals_the_reference():
     """The kernel's own source (csrc/amwg_ld.h, amwg_math.h), compiled for the host: all 22 scalar densities/helpers of
     distributions.js on 13 200 seeded argument sets recorded from the unmodified reference (oracle/gen_ld_golden.js), and
     Math.pow on 60 000 pairs recorded from Node's V8."""
-    L = amwg_ctypes.lib()
+    L = amwg_ctypes.selftest_lib()
     a = np.fromfile(os.path.join(golden_io.GOLDEN, "ld_values.bin"), dtype="<f8").reshape(-1, 6)
     assert a.shape[0] == 13200 and set(a[:, 0].astype(int)) == set(range(22))
     for r in a:
@@ -85,13 +93,13 @@ def test_host_build_of_every_ld_function_and_pow_equals_the_reference():
 
 
 def test_host_build_of_log1p_expm1_equals_v8():
-    L = amwg_ctypes.lib()
+    L = amwg_ctypes.selftest_lib()
     a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_log1p_expm1_pairs.bin"), dtype="<f8").reshape(-1, 3)
     assert sum((not _same(L.amwg_log1p(x), l)) + (not _same(L.amwg_expm1(x), e)) for x, l, e in a) == 0
 
 
 def test_host_build_of_tanh_atan_log10_equals_v8():
-    L = amwg_ctypes.lib()
+    L = amwg_ctypes.selftest_lib()
     a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_math2_pairs.bin"), dtype="<f8").reshape(-1, 4)
     assert sum((not _same(L.amwg_math1(0, x), t)) + (not _same(L.amwg_math1(1, x), at)) + (not _same(L.amwg_math1(2, abs(x)), lg)) for x, t, at, lg in a) == 0
 
@@ -99,7 +107,7 @@ def test_host_build_of_tanh_atan_log10_equals_v8():
 def test_host_build_of_the_trigonometric_hyperbolic_and_root_twins_equals_v8():
     """csrc/amwg_trig.h (sin cos tan asin acos atan2 sinh cosh asinh acosh atanh cbrt log2 hypot) against 24 000 outputs each of this
     Node's V8 (oracle/gen_math3_golden.js), arguments up to 1e300 (Payne-Hanek reduction), subnormals, +-0, NaN, infinities."""
-    L = amwg_ctypes.lib()
+    L = amwg_ctypes.selftest_lib()
     a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_math3_pairs.bin"), dtype="<f8").reshape(-1, 15)
     cols = {"sin": (3, 3, 0), "cos": (4, 4, 0), "tan": (5, 5, 0), "sinh": (8, 6, 0), "cosh": (9, 7, 0), "asinh": (10, 8, 0), "cbrt": (13, 9, 0), "log2": (14, 10, 0),
             "asin": (6, 11, 1), "acos": (7, 12, 1), "atanh": (12, 13, 1), "acosh": (11, 14, 2)}
@@ -116,7 +124,7 @@ def test_host_js_mod_and_toint32_equal_v8():
     """`%` and `x | 0` of translated closures (csrc/amwg_user.h js_mod / js_toint32, host build of the same header the device
     compiles) against 40 000 pairs recorded from V8 (oracle/gen_mod_golden.js): every +-0 / inf / NaN combination, exact
     multiples (sign of a zero result = sign of the dividend), subnormals, exponent gaps of thousands of bits."""
-    L = amwg_ctypes.lib()
+    L = amwg_ctypes.selftest_lib()
     a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_mod_pairs.bin"), dtype="<f8").reshape(-1, 4)
     bad = [(x, y, w, L.amwg_math2(2, x, y)) for x, y, w, _ in a if not _same(L.amwg_math2(2, x, y), w)]
     assert not bad, bad[:5]

@@ -100,7 +100,7 @@ def test_device_ld_functions_and_pow_equal_the_reference_goldens():
     import ctypes as C
     import os
     import golden_io
-    L = A.lib()
+    L = A.selftest_lib()
     a = np.fromfile(os.path.join(golden_io.GOLDEN, "ld_values.bin"), dtype="<f8").reshape(-1, 6)
     rec = np.ascontiguousarray(a[:, :5])
     out = np.empty(a.shape[0])
@@ -121,7 +121,7 @@ def test_two_valued_sum_fast_forward_is_exact_including_ties():
     acc is 2^(z+1) times larger -- for large z a long binade, each of the four tie cases (none / one with even or odd other
     increment / both), starting accumulators of either sign and magnitude."""
     import ctypes as C
-    L = A.lib()
+    L = A.selftest_lib()
     rng = np.random.default_rng(11)
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     for n, p_one in ((100000, 0.3), (5000, 0.5), (4099, 0.02), (777, 0.97), (64, 0.5), (1, 0.5), (0, 0.5)):

@@ -10,10 +10,12 @@ fam, lanes = sys.argv[1], int(sys.argv[2])
 n_obs = int(sys.argv[3]) if len(sys.argv) > 3 else lanes
 chains = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
 spec = model_spec.build_spec(fam, model_spec.make_data(fam, n_obs, 20260925, G=32, exp=A.lib().amwg_exp))
+NS0 = int(os.environ.get("AMWG_STEPS", "200"))
 gl = int(os.environ.get("AMWG_GL", "0"))
-s = A.Sampler(spec, chains=chains, seed=1, lanes_per_chain=lanes, steps_per_launch=200, group_local=gl)
-s.burn(400)          # adapted
-s.burn(200)          # the launch to look at (the last one)
+s = A.Sampler(spec, chains=chains, seed=1, lanes_per_chain=lanes, steps_per_launch=NS0, group_local=gl)
+NS = int(os.environ.get("AMWG_STEPS", "200"))
+s.burn(2 * NS)          # adapted
+s.burn(NS)          # the launch to look at (the last one)
 li = s.launch_info()
-print("%sfamily %s n_obs %d chains %d P %d lanes %d block %d grid %d  kernel_ms %.3f  -> %.3f us per update-round" % ("[group-local] " if gl else "", fam, n_obs, chains, spec["P"], li["lanes_per_chain"], li["block_threads"], li["grid_blocks"], li["kernel_ms"], li["kernel_ms"] * 1e3 / (200 * spec["P"])))
+print("%sfamily %s n_obs %d chains %d P %d lanes %d block %d grid %d  kernel_ms %.3f  -> %.3f us per update-round" % ("[group-local] " if gl else "", fam, n_obs, chains, spec["P"], li["lanes_per_chain"], li["block_threads"], li["grid_blocks"], li["kernel_ms"], li["kernel_ms"] * 1e3 / (NS * spec["P"])))
 s.close()
