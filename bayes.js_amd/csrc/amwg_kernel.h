@@ -110,6 +110,9 @@ template <class M> struct TracksState<M, void_of<decltype(M::kTracksState)>> { s
 template <class M, class = void> struct GroupSweepOf { static constexpr bool value = false; };
 template <class M> struct GroupSweepOf<M, void_of<decltype(M::kGroupSweep)>> { static constexpr bool value = M::kGroupSweep; };
 
+template <class M, class = void> struct OwnPassOf { static constexpr bool value = false; };
+template <class M> struct OwnPassOf<M, void_of<decltype(M::kOwnPass)>> { static constexpr bool value = M::kOwnPass; };
+
 // per-chain values a model keeps from one log_post evaluation to the next (Model::Cache; translated closures have none)
 struct NoCache {};
 template <class M, class = void> struct CacheOf { using type = NoCache; static __device__ __forceinline__ type init() { return type{}; } };
@@ -229,6 +232,8 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
       else acc = Model::template pass_slow<G>(ps, a.d.n_obs, sub, acc);            // IEEE '/': rare, out of line
     } else if constexpr (Model::kOneLanePass && G == 1) {
       acc = Model::pass_one_lane(ps, a.d.n_obs, acc);
+    } else if constexpr (OwnPassOf<Model>::value) {
+      acc = Model::template pass<G>(ps, a.d.n_obs, sub, acc);      // the model's own pipelined pass
     } else {
       acc = pass_over_data<Model, false, G>(ps, a.d.n_obs, sub, acc);
     }
@@ -842,8 +847,13 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
 // BT = the workgroup size class the instantiation is compiled for (its register budget): 1024 threads leave 128 VGPRs per lane,
 // 512 leave 256, 256 and fewer 512.  Round 2 compiled everything for 1024 and paid for it with scratch spills inside the slot loop
 // even where the launch used 256- or 512-thread workgroups (cfg2, cfg4).
+// (Model::kMinWavesPerSimd, optional: the occupancy the register allocation must leave room for -- HIP's second __launch_bounds__ argument
+// counts waves per SIMD)
+template <class M, class = void> struct MinWavesOf { static constexpr int value = 1; };
+template <class M> struct MinWavesOf<M, void_of<decltype(M::kMinWavesPerSimd)>> { static constexpr int value = M::kMinWavesPerSimd; };
+
 template <class Model, int G, int BT>
-__global__ void __launch_bounds__(BT) amwg_step_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(BT, MinWavesOf<Model>::value) amwg_step_kernel(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   step_body<Model, G, BT>(a, smem);
 }

@@ -602,6 +602,52 @@ struct PoisGlmModel {
     const double lam = exp_v8(eta);
     return log_v8(lam) * at(7) - lam - at(8);
   }
+  // The pass over the data with the NEXT observation's nine values (seven columns, the count, lfactorial) requested before the current
+  // one's ~130 instructions start: the compiler's own schedule of the plain loop waits for each value right where it is used, i.e. a
+  // whole L2 round trip per observation with nothing but the SIMD's other wave to cover it (round 2: 31 % of wave cycles in s_waitcnt).
+  // Same terms, added in the same order.
+  static constexpr bool kOwnPass = true;
+#if defined(AMWG_X_GLM_WAVES)
+  static constexpr int kMinWavesPerSimd = AMWG_X_GLM_WAVES;
+#endif
+  struct Row { double v[9]; };
+  __device__ __forceinline__ static void load_row(const Pass &ps, int i, Row &r) {
+    const uint32_t off = (uint32_t)i * 8u;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.v[k] = *reinterpret_cast<const double *>(ps.col[k] + off);
+  }
+  __device__ __forceinline__ static double term_of(const Pass &ps, const Row &r, int i) {
+    double eta = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) eta += r.v[k] * ps.b[k];
+    if ((double)i >= ps.cp) eta += ps.b[7];
+    const double lam = exp_v8(eta);
+    return log_v8(lam) * r.v[7] - lam - r.v[8];
+  }
+  template <int G>
+  __device__ __forceinline__ static double pass(const Pass &ps, int n_obs, int sub, double acc) {
+    const int n_full = n_obs / G, rem = n_obs % G;
+    const int n_mine = n_full + (sub < rem ? 1 : 0);           // this lane's observations: sub, sub + G, ...
+    Row a, b;
+    if (n_mine > 0) load_row(ps, sub, a);
+    int k = 0;
+    for (; k + 1 < n_full; k += 2) {                            // two observations per trip: the register sets swap roles, nothing is copied
+      load_row(ps, (k + 1) * G + sub, b);
+      AMWG_STAGE_FENCE();
+      acc += term_of(ps, a, k * G + sub);
+      AMWG_STAGE_FENCE();
+      { const int nx = k + 2 < n_mine ? k + 2 : k + 1; load_row(ps, nx * G + sub, a); }      // (past the end: re-read the last one, harmless)
+      AMWG_STAGE_FENCE();
+      acc += term_of(ps, b, (k + 1) * G + sub);
+      AMWG_STAGE_FENCE();
+    }
+    for (; k < n_mine; ++k) {                                   // at most one whole round and the remainder observation
+      if (k + 1 < n_mine) load_row(ps, (k + 1) * G + sub, b);
+      acc += term_of(ps, a, k * G + sub);
+      a = b;
+    }
+    return acc;
+  }
 };
 
 }  // namespace amwg

@@ -30,6 +30,7 @@ cpu_baseline = the UNMODIFIED reference (bench/ref_cpu.js: node + $AMWG_REF_DIR 
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -104,7 +105,7 @@ def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None):
             continue
         if p.get("workload", "cfg2") != workload:
             continue
-        if lanes is not None and (", %d>" % lanes) not in p.get("kernel", ""):      # the profile must be of the same kernel instantiation
+        if lanes is not None and not re.search(r",\s*%d(,\s*\d+)?>" % lanes, p.get("kernel", "")):      # the profile must be of the same kernel instantiation (Model, lanes[, workgroup class])
             continue
         if p.get("chains") == chains and p.get("steps_per_launch") == steps_per_launch and p.get("hbm_traffic_bytes_per_launch"):
             return p["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT), p.get("algorithmic_bytes_per_launch")
@@ -433,6 +434,7 @@ def main():
     ap.add_argument("--group-local", action="store_true", help="cfg4 only: the opt-in group-local evaluation (amwg_options::group_local)")
     ap.add_argument("--inproc", action="store_true", help="the product's own multi-device path: one process, one sampler per device, amwg_group_moments (see main_inproc)")
     ap.add_argument("--strong", action="store_true", help="--inproc only: keep the job's total chain count and split it over the devices")
+    ap.add_argument("--no-parity", action="store_true", help="profiling runs only: skip the golden schedule on the timed sampler (its launches record every draw)")
     ap.add_argument("--no-js", action="store_true", help="skip the end-to-end run through the JavaScript host (bench/js_e2e.js)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short measurements of cfg3 / cfg4 / cfg5 appended to the default line")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K-step region until this much time is on the clock (median reported)")
@@ -485,7 +487,7 @@ def main():
     mk = lambda off: A.Sampler(spec, chains=chains, seed=SEED, chain_offset=off, device=dev_index, group_local=int(args.group_local),
                                lanes_per_chain=args.lanes, block_threads=args.block, steps_per_launch=args.steps_per_launch)
     parity = None
-    if world == 1 and args.workload in GOLDEN_OF:
+    if world == 1 and args.workload in GOLDEN_OF and not args.no_parity:
         # the proof that this build reproduces the reference, taken from the sampler that is timed below (its first steps ARE the golden schedule)
         probe = mk(0)
         timed_lanes = probe.launch_info()["lanes_per_chain"]
@@ -554,7 +556,8 @@ def main():
         x = spec["data"]["x"]
         traffic, traffic_src, traffic_alg = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"])
         kname = {"normal": "NormalModel", "beta_bern": "BetaBernModel", "hier_normal": "HierNormalModel", "pois_glm": "PoisGlmModel"}[spec["model"]]
-        kernel = "amwg_step_kernel<%s,%d>" % (kname, li["lanes_per_chain"])
+        bt_class = 256 if li["block_threads"] <= 256 else (512 if li["block_threads"] <= 512 else 1024)
+        kernel = "amwg_step_kernel<%s,%d,%d>" % (kname, li["lanes_per_chain"], bt_class)
         roof_launch_s, roof_updates, roof_note = launch_s, updates_per_launch, None
         if args.workload == "cfg3":
             # the headline value uses the exact fast-forward of the two-valued sum, which does not stream the data at all; the

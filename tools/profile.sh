@@ -4,14 +4,14 @@
 # Outputs under gpurun_out/prof_<tag>/ ; tools/summarize_profile.py <tag> condenses them into profiles/.
 # Counters are collected in their own passes with --kernel-trace only (MI355X_MICROARCH.md: SQ 8 slots, TCC FETCH_SIZE and
 # WRITE_SIZE do not fit one pass, GRBM independent); every pass re-runs the same command.
-TAG=${1:-r02}
+TAG=${1:-r03}
 shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="${@:---steps 500 --warmup 1000}"
-CMD="python $R/bench.py --no-cpu-baseline --single-region $ARGS"
+CMD="python $R/bench.py --no-cpu-baseline --single-region --no-other-configs --no-parity $ARGS"
 echo "$CMD" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace_err.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD > /dev/null 2> $OUT/pmc_fetch_err.log
