@@ -156,4 +156,25 @@ checkAgainstGolden('glm_small', (g, rec) => new mcmc.AmwgSampler(
     s.close();
   }
 }
+// ---- 6. options.group_local (hierarchical family): the opt-in group-local evaluation through the JavaScript host takes the reference's
+// decisions (accept counts, uniforms consumed of the seeded reference run) and stays within rounding of its draws; other families refuse it
+{
+  const g = golden('hier_small'), rec = g.chains[0];
+  const s = new mcmc.AmwgSampler(
+    { theta: { type: 'real', dim: [g.data.G] }, mu: { type: 'real' }, sigma: { type: 'real', lower: 0, init: 1 } },
+    models.hier_normal(), { y: g.data.y, g: g.data.g, G: g.data.G }, { seed: g.case.seed, chain_offset: rec.chain, group_local: true });
+  assert.strictEqual(s.info().launch[0].lanes_per_chain, 64);
+  let smp = null;
+  for (const seg of g.case.schedule) { if (seg.op === 'burn') s.burn(seg.n); else smp = s.sample(seg.n); }
+  const inf = s.info();
+  let acc = []; for (const nm of ['theta', 'mu', 'sigma']) acc = acc.concat(flat(inf.steppers[nm]).map((o) => o.accepts));
+  assert.deepStrictEqual(acc, rec.accepts);
+  assert.strictEqual(s.diagnostics()[0].uniforms[0], rec.uniforms);
+  rec.samples[0].draws.forEach((row, t) => {
+    let got = []; for (const nm of ['theta', 'mu', 'sigma']) got = got.concat(flat(smp[nm][t]));
+    got.forEach((v, j) => assert.ok(Math.abs(v - row[j]) <= 1e-9 * Math.max(1, Math.abs(row[j])), 'group-local draw ' + t + ',' + j));
+  });
+  s.close();
+  assert.throws(() => new mcmc.AmwgSampler({ mu: {}, sigma: { lower: 0 } }, models.normal(), golden('normal_n1000').data.x, { group_local: true }), /hierarchical/);
+}
 console.log('gpu frontend ok');
