@@ -134,6 +134,21 @@ def end_to_end_js(chains, n_obs):
            "updates_per_s": m["updates_per_s"], "updates_per_s_excl_constructor": m["updates_per_s_excl_ctor"], "unit": "param-updates/s",
            "ctor_ms": m["ctor_ms"], "burn_ms": m["burn_ms"], "sample_ms_incl_copy_out": m["sample_ms"], "total_ms": m["total_ms"], "gb_copied": m["gb_copied"],
            "lanes_per_chain": (m.get("launch") or [{}])[0].get("lanes_per_chain"), "node": r["node"], "require_ms": r["require_ms"], "code_cache": r.get("code_cache")}
+    # a closure that has to be translated and compiled: a process with an empty code-object cache, then a second process that finds it on disk
+    try:
+        import tempfile
+        with tempfile.TemporaryDirectory() as cache:
+            env = dict(os.environ, AMWG_CACHE_DIR=cache)
+            runs = []
+            for _ in range(2):
+                q = subprocess.run([node, os.path.join(ROOT, "bench", "js_e2e.js"), "--translated-only", "1"], capture_output=True, text=True, timeout=120, env=env)
+                runs.append(json.loads([ln for ln in q.stdout.splitlines() if ln.startswith("{")][-1]))
+        out["translated_closure"] = {"what": "README model with the priors swapped (not a recognised family): translate.js -> hiprtc; ONE chain, ten heights; two processes sharing one cache directory",
+                                     "first_process": {"ctor_ms": runs[0]["translated"]["ctor_ms"], "code_cache": runs[0]["code_cache"]},
+                                     "second_process": {"ctor_ms": runs[1]["translated"]["ctor_ms"], "code_cache": runs[1]["code_cache"]},
+                                     "burn1000_sample5000_ms": runs[1]["translated"]["burn_sample_ms"]}
+    except (subprocess.SubprocessError, ValueError, IndexError, OSError, KeyError) as e:
+        out["translated_closure"] = {"error": repr(e)}
     if "single_chain_first" in r:
         a, b = r["single_chain_first"], r["single_chain_again"]
         out["single_chain"] = {"what": "README.md:18-43 as is: ONE chain, ten heights, burn(1000) + sample(5000); constructed twice in one process",

@@ -69,6 +69,29 @@ function run(data, chainCount, burn, sample, thinBy) {
 }
 
 const out = { node: process.version, require_ms: t_req };
+if (opt('translated-only', 0)) {
+  // a closure the family recogniser does not know (the README model with its priors written the other way round): translated to HIP and
+  // compiled with hiprtc -- or, in a process that finds it there, loaded from the on-disk code-object cache.  ONE chain, like the reference.
+  const swapped = function (state, data) {
+    var lp = 0;
+    lp += ld.unif(state.sigma, 0, 100);
+    lp += ld.norm(state.mu, 0, 100);
+    for (var i = 0; i < data.length; i++) lp += ld.norm(data[i], state.mu, state.sigma);
+    return lp;
+  };
+  const heights = [183, 192, 182, 183, 177, 185, 188, 188, 182, 185];
+  const t0 = now();
+  const s = new mcmc.AmwgSampler({ sigma: { type: 'real', lower: 0 }, mu: { type: 'real' } }, swapped, heights);
+  const t1 = now();
+  s.burn(1000);
+  const smp = s.sample(5000);
+  const t2 = now();
+  out.translated = { model: s.model, ctor_ms: t1 - t0, burn_sample_ms: t2 - t1, draws: smp.mu.length };
+  s.close();
+  try { out.code_cache = require(path.join(__dirname, '..', 'bayes.js_amd', 'mcmc.js')).code_cache_stats(); } catch (e) { out.code_cache = null; }
+  console.log(JSON.stringify(out));
+  process.exit(0);
+}
 out.many_chains = run(makeData(N), chains, nBurn, nSample, thin);
 if (opt('single', 1)) {
   // the reference's own use (README.md:18-43): ONE chain on the ten heights, 1000 + 5000 steps; twice -- the second construction of the
