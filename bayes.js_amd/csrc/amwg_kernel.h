@@ -277,17 +277,17 @@ struct CoopStream {
   uint32_t k0, k1, c2, c3;
   uint64_t b0;          // first block held by the chain's lanes
   uint32_t pos;         // uniforms consumed since block b0 (0 .. 2L): the stream position is 2*b0 + pos -- 32-bit bookkeeping per draw
-  uint32_t w0, w1, w2, w3;
+  double u0, u1;        // this lane's block as the two uniforms it yields (u53 of the words), converted ONCE per fill: every draw is then a
+                        // cross-lane read of a finished double -- the conversion (2 cvt, ldexp, add, ldexp) used to sit on the dependent chain of
+                        // every one of the stepper's ~4 draws per update
   int lane_in_chain, base_lane;
   // one Philox block per lane, OUT OF LINE: ~85 instructions that run once per 2L uniforms but would otherwise be inlined at every one of
   // the stepper's eight draw sites (a tenth of the kernel's code, all of it on the path the instruction cache has to hold)
   static __device__ __attribute__((noinline)) Philox4 block(uint64_t b, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
     return philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), c2, c3, k0, k1);
   }
-  __device__ __forceinline__ void fill() {
-    const Philox4 w = block(b0 + (uint64_t)lane_in_chain, c2, c3, k0, k1);
-    w0 = w.w0; w1 = w.w1; w2 = w.w2; w3 = w.w3;
-  }
+  __device__ __forceinline__ void set_block(const Philox4 &w) { u0 = u53(w.w0, w.w1); u1 = u53(w.w2, w.w3); }
+  __device__ __forceinline__ void fill() { set_block(block(b0 + (uint64_t)lane_in_chain, c2, c3, k0, k1)); }
   __device__ __forceinline__ void init(uint64_t seed, uint64_t chain, uint64_t consumed, int tid) {
     k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
     c2 = (uint32_t)chain; c3 = (uint32_t)(chain >> 32);
@@ -300,28 +300,23 @@ struct CoopStream {
   __device__ __forceinline__ uint64_t consumed() const { return 2 * b0 + (uint64_t)pos; }
   __device__ __forceinline__ double next() {
     if constexpr (L == 64) {
-      // the chain IS the wave: the stream position is wave-uniform, so the lane that holds the block is named by a scalar and its words
-      // are read with v_readlane -- no trip through the LDS crossbar (round 2: two ds_bpermute per uniform, a dependent LDS round trip
+      // the chain IS the wave: the stream position is wave-uniform, so the lane that holds the block is named by a scalar and its uniform
+      // is read with v_readlane -- no trip through the LDS crossbar (round 2: two ds_bpermute per uniform, a dependent LDS round trip
       // queued behind the data passes of the CU's other waves, on the critical path of every proposal)
       uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
       if (p >= 128u) { b0 += 64ull; p = 0u; fill(); }
-      const bool second = (p & 1u) != 0;
+      const double mine = (p & 1u) ? u1 : u0;
       const int src = (int)(p >> 1);
-      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(second ? w2 : w0), src);
-      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(second ? w3 : w1), src);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(f64_bits(mine) >> 32), src);
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f64_bits(mine), src);
       pos = p + 1u;
-      return u53(hi, lo);
+      return bits_f64(((uint64_t)hi << 32) | (uint64_t)lo);
     } else {
       if (pos >= 2u * (uint32_t)L) { b0 += (uint64_t)L; pos = 0u; fill(); }      // pos only ever reaches 2L exactly
-      const bool second = (pos & 1u) != 0;
-      uint32_t hi = second ? w2 : w0, lo = second ? w3 : w1;
-      if constexpr (L > 1) {
-        const int src = base_lane + (int)(pos >> 1);
-        hi = (uint32_t)__shfl((int)hi, src, 64);
-        lo = (uint32_t)__shfl((int)lo, src, 64);
-      }
+      double mine = (pos & 1u) ? u1 : u0;
+      if constexpr (L > 1) mine = __shfl(mine, base_lane + (int)(pos >> 1), 64);
       ++pos;
-      return u53(hi, lo);
+      return mine;
     }
   }
 };
@@ -618,7 +613,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           if (p0 >= 128u) { rng.b0 += 64ull; p0 -= 128u; rng.fill(); }
           rng.pos = p0;
           const Philox4 wb = CoopStream<G>::block(rng.b0 + 64ull + (uint64_t)lane64, rng.c2, rng.c3, rng.k0, rng.k1);
-          const double ua0 = u53(rng.w0, rng.w1), ua1 = u53(rng.w2, rng.w3), ub0 = u53(wb.w0, wb.w1), ub1 = u53(wb.w2, wb.w3);   // uniforms 2j, 2j+1, 128+2j, 129+2j of the window
+          const double ua0 = rng.u0, ua1 = rng.u1, ub0 = u53(wb.w0, wb.w1), ub1 = u53(wb.w2, wb.w3);   // uniforms 2j, 2j+1, 128+2j, 129+2j of the window
           const double ub0_first = bits_f64(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(f64_bits(ub0) >> 32), 0) << 32) |
                                             (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f64_bits(ub0), 0));
           // the uniform after this lane's second one = the next lane's first.  The shuffle is done by ALL lanes, before the select: written as
@@ -691,7 +686,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           }
           k_begin = k_end;
           // the stream position after this round; past the CoopStream's own blocks, the window's second half becomes its buffer
-          if (p >= 128u) { rng.b0 += 64ull; rng.w0 = wb.w0; rng.w1 = wb.w1; rng.w2 = wb.w2; rng.w3 = wb.w3; p -= 128u; }
+          if (p >= 128u) { rng.b0 += 64ull; rng.u0 = ub0; rng.u1 = ub1; p -= 128u; }
           rng.pos = p;
         }
         lp_curr = Model::template gl_total<G>(cache, sub, Gn, cache.pm, cache.pt, cache.T);
@@ -815,7 +810,17 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         const double diff = prop_lp - lp_curr;
         if (diff >= 0.0) accepted = true;
         else if (diff < -746.0) accepted = false;
-        else accepted = exp_v8(diff) > u_accept;
+        else {
+          // For d < 0:  1 + d <= exp(d) <= 1 + d + d*d/2, and V8's exp is within one ulp (< 2^-53 here) of exp: a uniform below the lower bound
+          // or above the upper one (each taken with a margin of 2^-50, an order of magnitude more than the roundings of the bounds themselves
+          // plus that ulp) decides the comparison exactly as the exponential would -- which is then evaluated for the band in between only
+          // (about a quarter of the proposals at a 44 % acceptance rate); the ~45 instructions of exp are the longest single dependent chain
+          // of an update.  Chains sharing a wavefront diverge here; the exponential runs for those that need it.
+          const double lower = 1.0 + diff;
+          if (u_accept < lower - 0x1p-50) accepted = true;
+          else if (diff > -1.0 && u_accept > (lower + 0.5 * diff * diff) + 0x1p-50) accepted = false;
+          else accepted = exp_v8(diff) > u_accept;
+        }
         if (accepted) lp_curr = prop_lp;
         else set_state(comp, cur);
         if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // run totals (not in the reference; parity tests compare them with the oracle's)

@@ -332,10 +332,14 @@ struct HierNormalModel {
   static constexpr bool kTracksState = true;
   struct Cache {
     NormCache n; double th_own, th_pass, mu, sigma; int my_group; bool regs, loaded;
+    // the prior of (mu, sigma) kept while neither changes (32 of the 34 updates of a step), and the constants of theta's prior held in
+    // VECTOR registers: the stepper keeps more wave-uniform values alive than there are scalar registers, and every use of a spilled one is a
+    // v_readlane plus a wait state -- the priors alone were 0.5 us of the 2.4 us a stepper update takes (measured by cutting them out)
+    double pr_mu, pr_sigma, pr_val, c1, den1, y1h, y1l; int den1_ok;
     // group-local evaluation (gl_* below): committed pieces of log_post_GL, and the tentative ones of the proposal being evaluated
     double pm, pt, T, pm_t, pt_t, T_t;
   };
-  __device__ __forceinline__ static Cache cache_init() { return Cache{norm_cache_init(), 0.0, 0.0, 0.0, 0.0, -1, false, false, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; }
+  __device__ __forceinline__ static Cache cache_init() { return Cache{norm_cache_init(), 0.0, 0.0, 0.0, 0.0, -1, false, false, __builtin_nan(""), __builtin_nan(""), 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; }
   template <int GL>
   __device__ __forceinline__ static void load(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
     if (k.loaded) return;
@@ -348,6 +352,23 @@ struct HierNormalModel {
     k.my_group = (k.regs && sub < d.n_obs) ? (int)(smem + (size_t)d.n_obs * 8)[sub] : -1;
     k.th_own = (k.regs && j < d.G) ? S(j) : 0.0;
     k.th_pass = k.my_group >= 0 ? S(k.my_group) : 0.0;
+    k.c1 = mc.c1; k.den1 = mc.den1; k.y1h = mc.y1_hi; k.y1l = mc.y1_lo; k.den1_ok = mc.den1_ok;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(k.c1), "+v"(k.den1), "+v"(k.y1h), "+v"(k.y1l), "+v"(k.den1_ok));      // (vector registers from here on)
+#endif
+  }
+  // prior(mu, sigma): out of line, its hyper-parameters read through the kernel-argument pointer where they are used -- two updates in 34
+  __device__ inline __attribute__((noinline)) static double prior_mu_sigma_impl(double mu, double sigma, double m0, double c0, double den0, double y0h, double y0l, int den0_ok,
+                                                                                 double ua, double ub, double lunif) {
+    double lp = 0;
+    lp += norm_const_sd(mu, m0, c0, den0, y0h, y0l, den0_ok);
+    lp += (sigma < ua || sigma > ub) ? -kInf : lunif;
+    return lp;
+  }
+  // (the kernel-argument pointer is only valid in the kernel's own body: the fields are fetched here, inlined at the rarely taken call site)
+  __device__ __forceinline__ static double prior_mu_sigma_cold(double mu, double sigma) {
+    const cold_args_ptr ca = cold_args();
+    return prior_mu_sigma_impl(mu, sigma, ca->mc.m0, ca->mc.c0, ca->mc.den0, ca->mc.y0_hi, ca->mc.y0_lo, ca->mc.den0_ok, ca->mc.ua, ca->mc.ub, ca->mc.lunif);
   }
   __device__ __forceinline__ static void on_set(Cache &k, int comp, double v, int sub, const DataRef &d) {
     // selects, not stores under branches: the compiler merges `if (c) k.mu = v; else k.sigma = v;` into ONE store through a selected
@@ -360,16 +381,21 @@ struct HierNormalModel {
   template <class C>
   __device__ __forceinline__ static double prior(const StateView &, const ModelConsts &mc, const DataRef &, C &k) {
     const double mu = k.mu, sigma = k.sigma;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (mu != k.pr_mu || sigma != k.pr_sigma) { k.pr_mu = mu; k.pr_sigma = sigma; k.pr_val = prior_mu_sigma_cold(mu, sigma); }      // (NaN keys never match)
+    return k.pr_val;
+#else
     double lp = 0;
     lp += norm_const_sd(mu, mc.m0, mc.c0, mc.den0, mc.y0_hi, mc.y0_lo, mc.den0_ok);
     lp += (sigma < mc.ua || sigma > mc.ub) ? -kInf : mc.lunif;
     return lp;
+#endif
   }
   template <int G, class C>
   __device__ __forceinline__ static double prior_split(const StateView &S, const ModelConsts &mc, const DataRef &d, int sub, double acc, C &k) {
     const double mu = k.mu;
     if (k.regs) {      // groups <= lanes: at most one term per lane, theta[sub] from the mirror
-      if (sub < d.G) acc += norm_const_sd(k.th_own, mu, mc.c1, mc.den1, mc.y1_hi, mc.y1_lo, mc.den1_ok);
+      if (sub < d.G) acc += norm_const_sd(k.th_own, mu, k.c1, k.den1, k.y1h, k.y1l, k.den1_ok);
       return acc;
     }
     for (int q = sub; q < d.G; q += G) acc += norm_const_sd(S(q), mu, mc.c1, mc.den1, mc.y1_hi, mc.y1_lo, mc.den1_ok);
@@ -391,7 +417,11 @@ struct HierNormalModel {
       constexpr int L = GL < 64 ? GL : 64;
       const int lane = (int)(threadIdx.x & 63u), sub_in_wave = lane & (L - 1);
       bool mine = true;
+#if defined(AMWG_X_CUT_BEGIN)
+      if (k.regs) { }
+#else
       if (k.regs) { if (sub_in_wave < d.G) { const double th = k.th_own; mine = th == 0 || mid_range(__builtin_fabs(th)); } }
+#endif
       else for (int q = sub_in_wave; q < d.G; q += L) { const double th = S(q); mine = mine && (th == 0 || mid_range(__builtin_fabs(th))); }
       if constexpr (L == 1) ok = ok && mine;
       else {
@@ -421,14 +451,9 @@ struct HierNormalModel {
   // and each is decided on its local difference (pt' - pt) + (L' - L), L = the sum of T over the lanes of the group.  2 passes per step
   // instead of 34 (mcmc.js:524-526 evaluates the full log_post twice per update).
   static constexpr bool kGroupSweep = true;
-  __device__ __forceinline__ static double gl_pm(double mu, double sigma, const ModelConsts &mc) {
-    double lp = 0;
-    lp += norm_const_sd(mu, mc.m0, mc.c0, mc.den0, mc.y0_hi, mc.y0_lo, mc.den0_ok);
-    lp += (sigma < mc.ua || sigma > mc.ub) ? -kInf : mc.lunif;
-    return lp;
-  }
-  __device__ __forceinline__ static double gl_pt(double theta, double mu, const ModelConsts &mc) {
-    return norm_const_sd(theta, mu, mc.c1, mc.den1, mc.y1_hi, mc.y1_lo, mc.den1_ok);
+  __device__ __forceinline__ static double gl_pm(double mu, double sigma, const ModelConsts &) { return prior_mu_sigma_cold(mu, sigma); }
+  __device__ __forceinline__ static double gl_pt(const Cache &k, double theta, double mu) {
+    return norm_const_sd(theta, mu, k.c1, k.den1, k.y1h, k.y1l, k.den1_ok);
   }
   __device__ __forceinline__ static double gl_lane_value(int sub, int Gn, double pm, double pt, double T) {
     return sub == 0 ? (pm + pt) + T : (sub < Gn ? pt + T : T);
@@ -469,7 +494,7 @@ struct HierNormalModel {
     load<G>(k, S, mc, d, smem, sub);
     norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);
     k.pm = gl_pm(k.mu, k.sigma, mc);
-    k.pt = gl_pt(k.th_pass, k.mu, mc);
+    k.pt = gl_pt(k, k.th_pass, k.mu);
     k.T = gl_pass<G, U>(k, mc, d, smem, sub, k.th_pass);
     return gl_total<G>(k, sub, d.G, k.pm, k.pt, k.T);
   }
@@ -480,7 +505,7 @@ struct HierNormalModel {
     const double mu = is_mu ? v : k.mu, sigma = is_mu ? k.sigma : v;
     k.pm_t = gl_pm(mu, sigma, mc);
     if (is_mu) {
-      k.pt_t = gl_pt(k.th_pass, mu, mc);
+      k.pt_t = gl_pt(k, k.th_pass, mu);
       k.T_t = k.T;
     } else {
       k.pt_t = k.pt;
@@ -500,7 +525,7 @@ struct HierNormalModel {
   __device__ __forceinline__ static double gl_sweep_eval(Cache &k, bool eval, double prop, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
     norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);       // (a rejected sigma proposal leaves the cache at the proposed sd)
     const double mean = eval ? prop : k.th_pass;
-    k.pt_t = eval ? gl_pt(prop, k.mu, mc) : k.pt;
+    k.pt_t = eval ? gl_pt(k, prop, k.mu) : k.pt;
     k.T_t = gl_pass<G, U>(k, mc, d, smem, sub, mean);
     return (k.pt_t - k.pt) + (gl_group_sum(k.T_t, d.G) - gl_group_sum(k.T, d.G));
   }

@@ -160,7 +160,15 @@ AMWG_HD double norm_pass_staged(const XT *x, const uint8_t *g, const StateView S
     // a few terms only (e.g. 10^4 observations on 64 lanes: 19 blocks, then 4 rounds and a quarter): term by term -- (left + 1) x 8
     // instructions instead of the 8 x U + selects of the masked block below.  The chain of dependent operations this leaves is latency the
     // SIMD's other wave fills; with few waves per SIMD and longer tails the masked block is the better trade.
-    for (int r = k; r < n_full; ++r) {
+    int r = k;
+    for (; r + 1 < n_full; r += 2) {          // two rounds at a time: two independent chains of eight operations, the additions in order
+      const int i0 = r * G + sub, i1 = i0 + G;
+      const double t0 = (double)x[i0] - (GATHER ? S(g[i0]) : mean), t1 = (double)x[i1] - (GATHER ? S(g[i1]) : mean);
+      const double e0 = c - div_by_invariant(t0 * t0, den, y), e1 = c - div_by_invariant(t1 * t1, den, y);
+      acc = acc + e0;
+      acc = acc + e1;
+    }
+    if (r < n_full) {
       const int i = r * G + sub;
       const double t = (double)x[i] - (GATHER ? S(g[i]) : mean);
       acc = acc + (c - div_by_invariant(t * t, den, y));
