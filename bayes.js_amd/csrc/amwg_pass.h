@@ -160,25 +160,28 @@ AMWG_HD double norm_pass_staged(const XT *x, const uint8_t *g, const StateView S
     // a few terms only (e.g. 10^4 observations on 64 lanes: 19 blocks, then 4 rounds and a quarter): term by term -- (left + 1) x 8
     // instructions instead of the 8 x U + selects of the masked block below.  The chain of dependent operations this leaves is latency the
     // SIMD's other wave fills; with few waves per SIMD and longer tails the masked block is the better trade.
-    int r = k;
-    for (; r + 1 < n_full; r += 2) {          // two rounds at a time: two independent chains of eight operations, the additions in order
-      const int i0 = r * G + sub, i1 = i0 + G;
-      const double t0 = (double)x[i0] - (GATHER ? S(g[i0]) : mean), t1 = (double)x[i1] - (GATHER ? S(g[i1]) : mean);
-      const double e0 = c - div_by_invariant(t0 * t0, den, y), e1 = c - div_by_invariant(t1 * t1, den, y);
-      acc = acc + e0;
-      acc = acc + e1;
+    // every value of the tail is requested before the first term is computed: one LDS round trip for the tail, not one per round
+    constexpr int TMAX = U / 2 + 1;
+    double xv[TMAX], mv[TMAX];
+    const int cnt_all = left + (rem > 0 ? 1 : 0);            // uniform: rounds in the tail, the remainder round (if any) last
+    if (cnt_all > 0) {
+#pragma unroll
+    for (int r = 0; r < TMAX; ++r) {
+      int i = (k + (r < cnt_all ? r : 0)) * G + sub;
+      i = i < n_obs ? i : n_obs - 1;                         // (the remainder round of a lane without an observation in it: any valid address)
+      xv[r] = (double)x[i];
+      mv[r] = GATHER ? S(g[i]) : mean;
     }
-    if (r < n_full) {
-      const int i = r * G + sub;
-      const double t = (double)x[i] - (GATHER ? S(g[i]) : mean);
-      acc = acc + (c - div_by_invariant(t * t, den, y));
+    AMWG_STAGE_FENCE();
+#pragma unroll
+    for (int r = 0; r < TMAX; ++r) {
+      if (r < cnt_all) {                                     // uniform
+        const double t = xv[r] - mv[r];
+        const double term = c - div_by_invariant(t * t, den, y);
+        const bool mine = r < left || sub < rem;             // the remainder round belongs to the lanes below rem only
+        acc = mine ? acc + term : acc;
+      }
     }
-    if (rem > 0) {
-      int i = n_full * G + sub;
-      i = i < n_obs ? i : n_obs - 1;
-      const double t = (double)x[i] - (GATHER ? S(g[i]) : mean);
-      const double term = c - div_by_invariant(t * t, den, y);
-      acc = sub < rem ? acc + term : acc;
     }
   } else if (left > 0 || rem > 0) {
     const int cnt = left + (sub < rem ? 1 : 0);             // this lane's terms: 0 .. U
