@@ -214,6 +214,7 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
   if constexpr (Model::kUser) {
     // translated closure: the generated body returns this lane's partial sum (lane 0 carries every
     // term outside the lane-split loops), see bayes.js_amd/translate.js
+    wave_priority(0);      // (the whole evaluation of a translated closure counts as "the data pass" for the issue priority, see below)
     acc = Model::template eval<G, false>(S, a.d, smem, sub, nullptr);
   } else {
     if constexpr (TracksState<Model>::value) Model::template load<G>(cache, S, a.mc, a.d, smem, sub);   // first evaluation: fill the register mirror

@@ -105,3 +105,37 @@ def test_group_local_mode_reproduces_the_reference_decisions(name, lanes):
         want = np.array(rec["samples"][0]["draws"], dtype=np.float64).reshape(-1, segs[0].shape[1])
         assert np.allclose(segs[0][: want.shape[0]], want, rtol=1e-9, atol=1e-12)
         assert np.allclose(o.state(), rec["final_state"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("model,N,G", [("normal", 300, 0), ("beta_bern", 400, 0), ("hier_normal", 200, 4), ("pois_glm", 120, 0)])
+def test_oracle_equals_the_live_reference_on_a_fresh_seed(model, N, G):
+    """Beyond the committed goldens: where Node and the reference are at hand (build container: /root/reference; GPU box: oracle/_ref) the
+    unmodified reference is run on a seed drawn for this test run and the C restatement must reproduce it bit for bit."""
+    import json, os, shutil, subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    node = shutil.which("node")
+    ref = next((d for d in (os.environ.get("AMWG_REF_DIR"), "/root/reference", os.path.join(root, "oracle", "_ref"))
+                if d and os.path.exists(os.path.join(d, "mcmc.js"))), None)
+    if node is None or ref is None:
+        pytest.skip("node or the reference is not available here")
+    seed = int.from_bytes(os.urandom(4), "little") | 1
+    case = {"name": "live", "model": model, "N": N, "data_seed": seed ^ 0x2545F491, "store_data": True, "seed": seed, "chains": [0, 11],
+            "schedule": [{"op": "burn", "n": 80}, {"op": "sample", "n": 40, "thin": 2}]}
+    if G:
+        case["G"] = G
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump(case, f)
+    try:
+        p = subprocess.run([node, os.path.join(root, "oracle", "ref_harness.js"), f.name], capture_output=True, text=True, timeout=300)
+    finally:
+        os.unlink(f.name)
+    assert p.returncode == 0, p.stderr
+    gold = golden_io._untag(json.loads(p.stdout))
+    for rec in gold["chains"]:
+        spec = model_spec.spec_from_golden(gold, rec)
+        o = oracle_lib.OracleChain(spec, seed, rec["chain"], lanes=1)
+        segs = run_schedule(o, case["schedule"])
+        want = np.array(rec["samples"][0]["draws"], dtype=np.float64).reshape(-1, segs[0].shape[1])
+        assert np.ascontiguousarray(segs[0]).tobytes() == want.tobytes(), "seed %d" % seed
+        assert o.info()["accepts"].tolist() == rec["accepts"] and o.uniforms() == rec["uniforms"], "seed %d" % seed
+        assert o.state().tolist() == rec["final_state"]
