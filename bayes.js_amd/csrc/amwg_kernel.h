@@ -26,6 +26,12 @@
 // Reference work avoided without changing any result: the reference evaluates log_post
 // twice per update (mcmc.js:524-526); the current state's value is cached per chain, which
 // is exact because log_post is a pure function of the state.
+//
+// Since round 3: the kernel is instantiated per workgroup size CLASS (amwg_step_kernel<Model, G, BT>: the register budget of the
+// launch it is used for, amwg_kernels.hip); the stepper fetches the next slot's data under the current evaluation, keeps a register
+// mirror of the state for the hand-written families, moves its cross-lane traffic (uniform draws, shuffle order, butterfly) off the
+// LDS crossbar for a chain on a whole wave, and leaves its cold paths out of line (DESIGN.md section 3 has the list and what each was
+// worth); the hierarchical family has an opt-in group-local evaluation with a lane-parallel sweep over theta (second step loop below).
 #pragma once
 #if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>

@@ -70,7 +70,7 @@ struct NormalModel {
   static constexpr bool kUser = false, kHasFast = true, kOneLanePass = false;
   static constexpr int kDerived = 0;
   static constexpr bool kHasBinary = false;   // real / int parameters only: the BinaryStepper branch is not compiled in
-  static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
+  static constexpr int kMaxThreads = 1024;   // workgroup size cap (instantiated per size class 256 / 512 / 1024, amwg_kernels.hip)
   static constexpr int kUnroll = 8;   // independent terms in flight per lane (ILP across the division chains)
   struct Pass { double mu, c, den; Reciprocal y; bool fast; const double *x; };
   // one lane per chain reads the observations through the scalar cache (norm_pass_uniform): no LDS tile
@@ -146,7 +146,7 @@ struct BetaBernModel {
   static constexpr bool kUser = false, kHasFast = false, kOneLanePass = true;
   static constexpr int kDerived = 0;
   static constexpr bool kHasBinary = false;   // real / int parameters only: the BinaryStepper branch is not compiled in
-  static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
+  static constexpr int kMaxThreads = 1024;   // workgroup size cap (instantiated per size class 256 / 512 / 1024, amwg_kernels.hip)
   static constexpr int kUnroll = 8;
   struct Pass { double l1, l0; const uint8_t *x; const uint32_t *bits; bool has_invalid, fast_forward; BitData B; };
   // one lane per chain: the observations as bits plus their prefix popcounts in LDS (two_valued_sum above); the
@@ -312,7 +312,7 @@ struct HierNormalModel {
   static constexpr bool kUser = false, kHasFast = true, kOneLanePass = false;
   static constexpr int kDerived = 0;
   static constexpr bool kHasBinary = false;   // real / int parameters only: the BinaryStepper branch is not compiled in
-  static constexpr int kMaxThreads = 1024;   // workgroup size cap (= __launch_bounds__: 128 VGPRs per lane)
+  static constexpr int kMaxThreads = 1024;   // workgroup size cap (instantiated per size class 256 / 512 / 1024, amwg_kernels.hip)
   static constexpr int kUnroll = 8;
   struct Pass { double c, den, th_pass; Reciprocal y; bool fast, lane_const, regs; const double *x; const uint8_t *g; StateView S; };
   __host__ __device__ static size_t lds_bytes(int n_obs, int, int) { return (size_t)n_obs * 8 + (((size_t)n_obs + 15) & ~(size_t)15); }
@@ -581,7 +581,7 @@ struct PoisGlmModel {
   static constexpr bool kUser = false, kHasFast = false, kOneLanePass = false;
   static constexpr int kDerived = 0;
   static constexpr bool kHasBinary = false;   // real / int parameters only: the BinaryStepper branch is not compiled in
-  static constexpr int kMaxThreads = 256;    // exp+log per observation want > 128 VGPRs (capped at 128 -- 4 waves per SIMD -- the kernel is 30 % slower: measured, round 2); no LDS tile to share anyway
+  static constexpr int kMaxThreads = 256;    // exp+log per observation want > 128 VGPRs (capped at 128 the kernel spills 73 of them; round 3 measured it 1 % faster all the same: VALU-issue bound); no LDS tile to share anyway
   static constexpr int kUnroll = 2;   // exp+log per term: more would spill
   // col[k]: column k of the design matrix, then y and lfactorial(y) -- nine wave-uniform base pointers (scalar registers); an
   // observation is addressed by ONE 32-bit byte offset per lane (global_load ... vOffset, sBase) instead of nine 64-bit adds
