@@ -95,6 +95,12 @@ __global__ void amwg_eval_kernel(int op, int64_t n, const double *a, const doubl
     case 23: r = hypot2_v8(x, y); break;
     case 24: r = js_mod(x, y); break;                // the `%` of translated closures
     case 25: r = (double)js_toint32(x); break;       // `x | 0`
+    case 26: { double lam; r = exp_log_v8(x, lam, exp_log_regs()); } break;          // the fused pair of the Poisson pass: log(exp(x)) ...
+    case 27: { double lam; (void)exp_log_v8(x, lam, exp_log_regs()); r = lam; } break;   // ... and its exp(x)
+    case 28: r = exp_v8_full(x); break;              // the full fdlibm control flow, for comparison
+    case 29: r = log_v8_full(x); break;
+    case 30: r = log_v8_full(exp_v8_full(x)); break;
+    case 31: { double lam; r = exp_log_v8(x, lam, ExpLogLiterals{}); } break;
   }
   out[i] = r;
 }

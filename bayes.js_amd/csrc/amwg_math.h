@@ -163,30 +163,67 @@ AMWG_HD double quot_plain(double a, double b) {
 #endif
 }
 
-AMWG_HD double exp_v8(double x) {
-  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-  const double inv_ln2 = 1.44269504088896338700e+00;
-  const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
-               P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+// The constants of exp / log as a type: ExpLogLiterals are compile-time values (scalar registers or literals once inlined);
+// ExpLogRegs (below) holds the same numbers in per-lane registers for a loop whose scalar registers are better spent on pointers.
+struct ExpLogLiterals {
+  static constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10, inv_ln2 = 1.44269504088896338700e+00;
+  static constexpr double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                          P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  static constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                          Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                          Lg7 = 1.479819860511658591e-01;
+};
+struct ExpLogRegs {
+  double ln2_hi, ln2_lo, inv_ln2, P1, P2, P3, P4, P5, Lg1, Lg2, Lg3, Lg4, Lg5, Lg6, Lg7;
+};
+AMWG_HD ExpLogRegs exp_log_regs() {
+  typedef ExpLogLiterals L;
+  ExpLogRegs k{L::ln2_hi, L::ln2_lo, L::inv_ln2, L::P1, L::P2, L::P3, L::P4, L::P5, L::Lg1, L::Lg2, L::Lg3, L::Lg4, L::Lg5, L::Lg6, L::Lg7};
+#if defined(__HIP_DEVICE_COMPILE__)
+  // "+v": the value now lives in a vector register as far as the compiler can tell (it would otherwise rematerialise the literal into
+  // a scalar pair wherever it is used)
+  asm volatile("" : "+v"(k.ln2_hi), "+v"(k.ln2_lo), "+v"(k.inv_ln2), "+v"(k.P1), "+v"(k.P2), "+v"(k.P3), "+v"(k.P4), "+v"(k.P5));
+  asm volatile("" : "+v"(k.Lg1), "+v"(k.Lg2), "+v"(k.Lg3), "+v"(k.Lg4), "+v"(k.Lg5), "+v"(k.Lg6), "+v"(k.Lg7));
+#endif
+  return k;
+}
+
+// rare arguments of exp: |x| >= ~708 (overflow / underflow / denormal scaling / inf / NaN), |x| < 2^-28, exactly 1.0 (V8 returns Math.E),
+// and the sliver 0x3fd62e42_00000000 <= |x| <= 0x3fd62e42_ffffffff around ln2/2 (0x3fd62e42_fefa39ef), the only place where fdlibm's
+// THREE-way choice of k (0 below 0.5 ln2 by the high word; +-1 up to 1.5 ln2; (int)(x/ln2 +- 0.5) beyond) differs from the last formula
+// applied everywhere: below the sliver x/ln2 < 0.5 - 3e-7, so the formula gives 0; above it and below 1.5 ln2 (high word < 0x3ff0a2b2,
+// i.e. 2e-7 short of it) x/ln2 +- 0.5 lies within (1 + 1e-9, 2 - 3e-7) in magnitude, so it gives +-1 (tests/host/explog_fuzz.cpp walks
+// both edges).
+AMWG_HD bool exp_is_rare(double x) {
   const uint32_t hx = (uint32_t)hi_word(x) & 0x7fffffffu;
-  // rare: |x| >= ~708 (overflow/underflow/denormal scaling/inf/NaN), |x| < 2^-28, or exactly 1.0
-  if (__builtin_expect(hx >= 0x40862000u || hx < 0x3e300000u || x == 1.0, 0)) return exp_v8_full(x);
-  const bool neg = x < 0;
-  const bool big = hx >= 0x3FF0A2B2u;        // |x| >= 1.5 ln2: k from the multiply
-  const bool mid = hx > 0x3fd62e42u;         // |x| >  0.5 ln2: k != 0
-  const int32_t kb = (int32_t)(inv_ln2 * x + (neg ? -0.5 : 0.5));
-  const int32_t k = mid ? (big ? kb : (neg ? -1 : 1)) : 0;
-  const double t = (double)k;
-  // k = +-1: x -+ ln2_hi and +-ln2_lo are exactly t*ln2_hi / t*ln2_lo subtracted/used below;
-  // k = 0: t = +0, so hi = x - 0 = x, lo = +0, r = x - 0 = x -- the unreduced case needs no selects
-  const double hi = x - t * ln2_hi;
-  const double lo = t * ln2_lo;
-  const double r = hi - lo;
+  return hx >= 0x40862000u || hx < 0x3e300000u || x == 1.0 || hx == 0x3fd62e42u;
+}
+
+// x = t ln2 + r (t an integer-valued double with the sign of x, possibly -0); t_hi = t*ln2_hi and lo = t*ln2_lo as fdlibm forms them;
+// y = exp(r) in (0.70, 1.42); exp(x) = y * 2^k.  Not for the arguments exp_is_rare() names.
+struct ExpParts { double t, t_hi, lo, y; int32_t k; };
+template <class K>
+AMWG_HD ExpParts exp_parts(double x, const K &c) {
+  ExpParts e;
+  // (int)(x/ln2 +- 0.5) of fdlibm, sign-symmetric: truncate |x/ln2| + 0.5 and put the sign back (two selects and a compare fewer).
+  // t = -0 for a negative x with k = 0: t_hi = -0, lo = -0, and x - (-0), hi - (-0), (-0) - q (q != 0) are what +0 gives.
+  e.t = __builtin_copysign(__builtin_trunc(__builtin_fabs(c.inv_ln2 * x) + 0.5), x);
+  e.k = (int32_t)e.t;
+  e.t_hi = e.t * c.ln2_hi;
+  const double hi = x - e.t_hi;
+  e.lo = e.t * c.ln2_lo;
+  const double r = hi - e.lo;
   const double rr = r * r;
-  const double c = r - rr * (P1 + rr * (P2 + rr * (P3 + rr * (P4 + rr * P5))));
-  // 2 - c in (1.6, 2.4); r*c is 0 or >= 2^-150 in magnitude (|r| >= ulp(ln2-multiple) of a |x| >= 2^-28)
-  const double y = 1.0 - ((lo - quot_plain(r * c, 2.0 - c)) - hi);
-  return set_hi_word(y, hi_word(y) + (k << 20));
+  const double cc = r - rr * (c.P1 + rr * (c.P2 + rr * (c.P3 + rr * (c.P4 + rr * c.P5))));
+  // 2 - cc in (1.6, 2.4); r*cc is 0 or >= 2^-150 in magnitude (|r| >= ulp(ln2-multiple) of a |x| >= 2^-28)
+  e.y = 1.0 - ((e.lo - quot_plain(r * cc, 2.0 - cc)) - hi);
+  return e;
+}
+
+AMWG_HD double exp_v8(double x) {
+  if (__builtin_expect(exp_is_rare(x), 0)) return exp_v8_full(x);
+  const ExpParts e = exp_parts(x, ExpLogLiterals{});
+  return set_hi_word(e.y, hi_word(e.y) + (e.k << 20));
 }
 
 AMWG_HD double log_v8(double x) {
@@ -224,6 +261,40 @@ AMWG_HD double exp_v8_cold(double x) { return exp_v8(x); }
 AMWG_HD_OUTLINE double log_v8_cold(double x) { return log_v8(x); }
 AMWG_HD_OUTLINE double exp_v8_cold(double x) { return exp_v8(x); }
 #endif
+
+// lam = exp_v8(x) and log_v8(lam) in one go -- the Poisson log-density's  y*log(lambda) - lambda  with lambda = exp(eta)
+// (distributions.js:282-284 under a log link).  log() starts by splitting its argument into 2^k (1 + f) with 1 + f in [sqrt(2)/2, sqrt(2)):
+// for lam = y * 2^k straight out of exp() that split is (k, y) itself whenever y's high word lies in [0x3fe6a09c, 0x3ff6a09c) (fdlibm
+// draws the line at significand high word 0x6a09c), which is everything but two slivers at |r| ~ ln2/2 -- so f = y - 1, dk = t, and the
+// products dk*ln2_hi, dk*ln2_lo are the t_hi, lo exp() already formed (t = -0 where dk = +0: the terms they are added to are non-zero).
+// The tail selection (fdlibm: 0x6147a <= significand high word <= 0x6b851 takes the form with f*f/2) and the |f| < 2^-20 test are
+// restated on tmp = hi(y) - 0x3fe6a09c.  Anything else goes through exp_v8 / log_v8 as they are.  Same bits as log_v8(exp_v8(x)).
+template <class K>
+AMWG_HD double exp_log_v8(double x, double &lam, const K &c) {
+  if (__builtin_expect(exp_is_rare(x), 0)) {
+    lam = exp_v8_cold(x);
+    return log_v8_cold(lam);
+  }
+  const ExpParts e = exp_parts(x, c);
+  const int32_t hy = hi_word(e.y);
+  lam = set_hi_word(e.y, hy + (e.k << 20));
+  constexpr uint32_t base = 0x3fe6a09cu;
+  const uint32_t tmp = (uint32_t)hy - base;
+  // not the plain split, or |f| < 2^-20 (hi(y) in {0x3feffffe, 0x3fefffff, 0x3ff00000})
+  if (__builtin_expect(tmp >= 0x100000u || (tmp - (0x3feffffeu - base)) < 3u, 0)) return log_v8_cold(lam);
+  const double f = e.y - 1.0;
+  const double s = quot_plain(f, 2.0 + f);
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * (c.Lg2 + w * (c.Lg4 + w * c.Lg6));
+  const double t2 = z * (c.Lg1 + w * (c.Lg3 + w * (c.Lg5 + w * c.Lg7)));
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double a = e.t_hi - ((hfsq - (s * (hfsq + R) + e.lo)) - f);
+  const double b = e.t_hi - ((s * (f - R) - e.lo) - f);
+  // form b: significand high word outside [0x6147a, 0x6b851], i.e. hi(y) in [0x3fe6b852, 0x3ff61479]
+  return (tmp - (0x3fe6b852u - base)) <= (0x3ff61479u - 0x3fe6b852u) ? b : a;
+}
 
 // ---- pow(x, y): V8's Math.pow (src/base/ieee754.cc pow, the fdlibm e_pow.c algorithm; V8 groups the
 // final quotient differently from fdlibm -- marked below -- and Node's values follow V8).  Used by

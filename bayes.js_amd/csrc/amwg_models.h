@@ -585,7 +585,9 @@ struct PoisGlmModel {
   static constexpr int kUnroll = 2;   // exp+log per term: more would spill
   // col[k]: column k of the design matrix, then y and lfactorial(y) -- nine wave-uniform base pointers (scalar registers); an
   // observation is addressed by ONE 32-bit byte offset per lane (global_load ... vOffset, sBase) instead of nine 64-bit adds
-  struct Pass { double b[8]; double cp; const char *col[9]; };
+  // icp: the change point as an integer threshold (observation i gets b[7] iff i >= icp, see begin()); K: the constants of exp / log
+  // in vector registers (the scalar ones of this kernel are better spent on the nine base pointers, which must be scalar)
+  struct Pass { double b[8]; double cp; int icp; ExpLogRegs K; const char *col[9]; };
   __host__ __device__ static size_t lds_bytes(int, int, int) { return 0; }
   __device__ static void stage(unsigned char *, const DataRef &, int, int, int) {}
   // closure order: `for k` over the 8 coefficients (dealt to the lanes), then the change point's prior (lane 0), then the data
@@ -610,22 +612,38 @@ struct PoisGlmModel {
 #pragma unroll
     for (int k = 0; k < 8; ++k) ps.b[k] = S(k);
     ps.cp = S(8);
+    // `i >= state.cp` (i = 0, 1, ...; both JavaScript numbers) as an integer comparison: i >= cp <=> i >= ceil(cp); a NaN never
+    // compares (threshold beyond every index: n_obs <= 2^28, amwg_create), anything <= 0 always does
+    ps.icp = !(ps.cp < 536870912.0) ? 536870912 : (ps.cp <= 0.0 ? 0 : (int)__builtin_ceil(ps.cp));
+    ps.K = exp_log_regs();
 #pragma unroll
     for (int k = 0; k < 7; ++k) ps.col[k] = reinterpret_cast<const char *>(d.x + (size_t)k * (size_t)d.n_obs);
     ps.col[7] = reinterpret_cast<const char *>(d.y);
     ps.col[8] = reinterpret_cast<const char *>(d.lfact);
     return ps;
   }
+  struct Row { double v[9]; };
+  __device__ __forceinline__ static void load_row(const Pass &ps, int i, Row &r) {
+    const uint32_t off = (uint32_t)i * 8u;     // n_obs <= 2^28 (amwg_create)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.v[k] = *reinterpret_cast<const double *>(ps.col[k] + off);
+  }
+  // mode (wave-uniform): 0 = i < icp for every lane of the wave, 2 = i >= icp for every lane, 1 = compare
+  __device__ __forceinline__ static double term_of(const Pass &ps, const Row &r, int i, int mode) {
+    double eta = r.v[0] * ps.b[0];
+#pragma unroll
+    for (int k = 1; k < 7; ++k) eta += r.v[k] * ps.b[k];
+    if (mode == 2) eta += ps.b[7];
+    else if (mode == 1) { if (i >= ps.icp) eta += ps.b[7]; }
+    double lam;
+    const double lg = exp_log_v8(eta, lam, ps.K);
+    return lg * r.v[7] - lam - r.v[8];
+  }
   template <bool FAST>
   __device__ __forceinline__ static double term(const Pass &ps, int i) {
-    const uint32_t off = (uint32_t)i * 8u;     // n_obs <= 2^28 (amwg_create)
-    auto at = [&](int k) { return *reinterpret_cast<const double *>(ps.col[k] + off); };
-    double eta = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) eta += at(k) * ps.b[k];
-    if ((double)i >= ps.cp) eta += ps.b[7];
-    const double lam = exp_v8(eta);
-    return log_v8(lam) * at(7) - lam - at(8);
+    Row r;
+    load_row(ps, i, r);
+    return term_of(ps, r, i, 1);
   }
   // The pass over the data with the NEXT observation's nine values (seven columns, the count, lfactorial) requested before the current
   // one's ~130 instructions start: the compiler's own schedule of the plain loop waits for each value right where it is used, i.e. a
@@ -635,40 +653,54 @@ struct PoisGlmModel {
 #if defined(AMWG_X_GLM_WAVES)
   static constexpr int kMinWavesPerSimd = AMWG_X_GLM_WAVES;
 #endif
-  struct Row { double v[9]; };
-  __device__ __forceinline__ static void load_row(const Pass &ps, int i, Row &r) {
-    const uint32_t off = (uint32_t)i * 8u;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) r.v[k] = *reinterpret_cast<const double *>(ps.col[k] + off);
-  }
-  __device__ __forceinline__ static double term_of(const Pass &ps, const Row &r, int i) {
-    double eta = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) eta += r.v[k] * ps.b[k];
-    if ((double)i >= ps.cp) eta += ps.b[7];
-    const double lam = exp_v8(eta);
-    return log_v8(lam) * r.v[7] - lam - r.v[8];
-  }
+  // Round 3, second half: 138 -> ~105 vector instructions per observation, all of them bookkeeping around the 86 fp64 operations the
+  // expression needs:
+  //  * exp and log fused (amwg_math.h exp_log_v8): log's split of its argument, its (double)k and both k*ln2 products are what exp just
+  //    formed; exp's three-way choice of k is one formula;
+  //  * the change point: every lane's FIRST row with i >= cp is known before the loop, so whole rounds (all lanes of the wave on one
+  //    side) are told apart on the scalar unit -- `mode` 0: nobody adds b[7]; 2: everybody does; 1: the one or two rounds in between
+  //    compare (integer compare, see begin());
+  //  * the loop never asks for a row past a lane's last one (the clamp cost a compare, a select and two moves per row): the pipelined
+  //    loop stops two rounds early, the tail is predicated;
+  //  * constants of exp / log in vector registers: three of the nine base pointers had been spilled for them and were read back with
+  //    v_readlane for every row;
+  //  * eta starts at the first product instead of 0 + product (they differ for a product of -0 only, and a sum that is -0 instead of
+  //    +0 in the end has the same exp).
   template <int G>
   __device__ __forceinline__ static double pass(const Pass &ps, int n_obs, int sub, double acc) {
     const int n_full = n_obs / G, rem = n_obs % G;
     const int n_mine = n_full + (sub < rem ? 1 : 0);           // this lane's observations: sub, sub + G, ...
+    // first own round k with k*G + sub >= icp; over the wave: nobody adds before k_some, everybody from k_all on
+    const int first = ps.icp <= sub ? 0 : (ps.icp - sub + (G - 1)) / G;
+    int lo = first, hi = first;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+    }
+    const int k_some = __builtin_amdgcn_readfirstlane(lo), k_all = __builtin_amdgcn_readfirstlane(hi);
+#else
+    const int k_some = lo, k_all = hi;
+#endif
+    auto mode_of = [&](int k) { return k < k_some ? 0 : (k >= k_all ? 2 : 1); };
     Row a, b;
     if (n_mine > 0) load_row(ps, sub, a);
     int k = 0;
-    for (; k + 1 < n_full; k += 2) {                            // two observations per trip: the register sets swap roles, nothing is copied
+    for (; k + 2 < n_full; k += 2) {                            // two observations per trip: the register sets swap roles, nothing is copied
       load_row(ps, (k + 1) * G + sub, b);
       AMWG_STAGE_FENCE();
-      acc += term_of(ps, a, k * G + sub);
+      acc += term_of(ps, a, k * G + sub, mode_of(k));
       AMWG_STAGE_FENCE();
-      { const int nx = k + 2 < n_mine ? k + 2 : k + 1; load_row(ps, nx * G + sub, a); }      // (past the end: re-read the last one, harmless)
+      load_row(ps, (k + 2) * G + sub, a);                       // k + 2 < n_full: every lane has that row
       AMWG_STAGE_FENCE();
-      acc += term_of(ps, b, (k + 1) * G + sub);
+      acc += term_of(ps, b, (k + 1) * G + sub, mode_of(k + 1));
       AMWG_STAGE_FENCE();
     }
-    for (; k < n_mine; ++k) {                                   // at most one whole round and the remainder observation
+    for (; k < n_mine; ++k) {                                   // at most two whole rounds and the remainder observation
       if (k + 1 < n_mine) load_row(ps, (k + 1) * G + sub, b);
-      acc += term_of(ps, a, k * G + sub);
+      acc += term_of(ps, a, k * G + sub, 1);
       a = b;
     }
     return acc;

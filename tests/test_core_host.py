@@ -130,3 +130,17 @@ def test_host_js_mod_and_toint32_equal_v8():
     assert not bad, bad[:5]
     bad = [(x, w, L.amwg_math2(3, x, 0.0)) for x, _, _, w in a if not _same(L.amwg_math2(3, x, 0.0), w)]
     assert not bad, bad[:5]
+
+
+def test_fused_exp_log_host_fuzz(tmp_path):
+    """csrc/amwg_math.h compiled for the host: the straight-line exp_v8 (one formula for k) and the fused exp_log_v8 of the Poisson pass
+    equal the full fdlibm control flow bit for bit on ~12 million arguments: random ones, every high word next to the thresholds the
+    shortcuts replace, and arguments whose exp() lands next to log's significand thresholds (tests/host/explog_fuzz.cpp; it also checks
+    that both sides of each sliver were actually visited)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "explog_fuzz")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(root, "bayes.js_amd", "csrc"),
+                           os.path.join(root, "tests", "host", "explog_fuzz.cpp"), "-o", exe])
+    p = subprocess.run([exe, "600000"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "mismatches=0" in p.stdout, p.stdout[-2000:]

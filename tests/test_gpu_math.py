@@ -20,6 +20,48 @@ def test_device_exp_log_bit_exact_vs_v8():
     assert l.tobytes() == np.ascontiguousarray(a[:, 2]).tobytes()
 
 
+def test_device_full_fdlibm_flow_vs_v8():
+    """exp_v8_full / log_v8_full (every branch of fdlibm, the yardstick of the fused test below) on the device against V8."""
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_math_pairs.bin"), dtype="<f8").reshape(-1, 3)
+    assert A.device_eval(28, a[:, 0]).tobytes() == np.ascontiguousarray(a[:, 1]).tobytes()
+    assert A.device_eval(29, np.abs(a[:, 0])).tobytes() == np.ascontiguousarray(a[:, 2]).tobytes()
+
+
+def _explog_arguments():
+    """as tests/host/explog_fuzz.cpp: the range a log link produces, every high word next to the thresholds of exp's argument reduction,
+    and arguments whose exp() lands next to the significand thresholds of log"""
+    rng = np.random.default_rng(4242)
+    parts = [rng.uniform(-30, 30, 1_000_000), rng.uniform(-745.5, 710, 500_000),
+             np.ldexp(rng.uniform(0.5, 1, 300_000), rng.integers(-60, 11, 300_000)) * rng.choice([-1.0, 1.0], 300_000)]
+    for h in (0x3fd62e42, 0x3ff0a2b2, 0x3e300000, 0x40862000, 0x40862e42, 0x3ff00000, 0x40874910, 0x3fe62e42, 0x3ff62e42):
+        for d in range(-3, 4):
+            lo = rng.integers(0, 2 ** 32, 4000, dtype=np.uint64)
+            lo[:8] = [0, 0xffffffff, 0xfefa39ef, 0xfefa39ee, 0xfefa39f0, 0x3f3bab73, 0x3f3bab72, 0x3f3bab74]
+            u = (np.uint64(h + d) << np.uint64(32)) | lo
+            parts += [u.view(np.float64), -u.view(np.float64)]
+    for h in (0x3ff6a09c, 0x3fe6a09c, 0x3ff6147a, 0x3fe6b851, 0x3ff6b851, 0x3fe6147a, 0x3ff00000, 0x3feffffe, 0x3ff6a09e, 0x3fe6a09e):
+        for d in range(-4, 5):
+            m = ((np.uint64(h + d) << np.uint64(32)) | rng.integers(0, 2 ** 32, 6000, dtype=np.uint64)).view(np.float64)
+            x = rng.integers(-30, 31, 6000) * 0.6931471805599453 + np.log(m)
+            parts += [x, np.nextafter(x, 1e300), np.nextafter(x, -1e300)]
+    parts.append(np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 709.782712893384, 709.7827128933841, -745.1332191019411,
+                           -745.1332191019412, -708.0, 708.0, 1e-300, -1e-300, 5e-324, 0.34657359027997264, -0.34657359027997264,
+                           1.0397207708399179, -1.0397207708399179]))
+    return np.concatenate(parts)
+
+
+def test_device_fused_exp_log_equals_full_flow():
+    """exp_log_v8 (the Poisson pass: lambda = exp(eta) and log(lambda) sharing the argument reduction) and the one-formula k of exp_v8,
+    on the device, against the full fdlibm control flow on the device -- incl. the slivers where the shortcuts do not apply."""
+    x = _explog_arguments()
+    want_e, want_l = A.device_eval(28, x), A.device_eval(30, x)
+    same = lambda p, q: np.array_equal(p.view(np.uint64)[~np.isnan(q)], q.view(np.uint64)[~np.isnan(q)]) and np.array_equal(np.isnan(p), np.isnan(q))
+    assert same(A.device_eval(0, x), want_e)
+    assert same(A.device_eval(27, x), want_e)
+    assert same(A.device_eval(26, x), want_l)
+    assert same(A.device_eval(31, x), want_l)
+
+
 def test_device_sqrt_correctly_rounded():
     k = np.arange(1, 200001, dtype=np.float64)       # batch_count values, mcmc.js:542
     assert A.device_eval(2, k).tobytes() == np.sqrt(k).tobytes()
