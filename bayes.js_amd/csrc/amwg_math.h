@@ -183,7 +183,7 @@ AMWG_HD ExpLogRegs exp_log_regs() {
   // "+v": the value now lives in a vector register as far as the compiler can tell (it would otherwise rematerialise the literal into
   // a scalar pair wherever it is used)
   asm volatile("" : "+v"(k.ln2_hi), "+v"(k.ln2_lo), "+v"(k.inv_ln2), "+v"(k.P1), "+v"(k.P2), "+v"(k.P3), "+v"(k.P4), "+v"(k.P5));
-  asm volatile("" : "+v"(k.Lg1), "+v"(k.Lg2), "+v"(k.Lg3), "+v"(k.Lg4), "+v"(k.Lg5), "+v"(k.Lg6), "+v"(k.Lg7));
+  // (Lg1..Lg7 stay compile-time values: with all fifteen in vector registers the Poisson kernel needs 263 of them, a wave per SIMD less)
 #endif
   return k;
 }
@@ -295,6 +295,124 @@ AMWG_HD double exp_log_v8(double x, double &lam, const K &c) {
   // form b: significand high word outside [0x6147a, 0x6b851], i.e. hi(y) in [0x3fe6b852, 0x3ff61479]
   return (tmp - (0x3fe6b852u - base)) <= (0x3ff61479u - 0x3fe6b852u) ? b : a;
 }
+
+// exp_log_v8 for U arguments at once and without its branches: every step is taken for all U before the next one, so U independent
+// dependent chains sit side by side in ONE basic block (the compiler keeps that order; two calls one after the other are scheduled one
+// after the other).  The values are garbage -- but no trap -- where `rare` comes back set: the caller then goes through exp_v8_cold /
+// log_v8_cold for those lanes.  Same operations as exp_parts + exp_log_v8 (tests/host/explog_fuzz.cpp compares this form too).
+template <int U, class K>
+AMWG_HD void exp_log_v8_open(const double (&x)[U], double (&lam)[U], double (&lg)[U], bool (&rare)[U], const K &c) {
+#define AMWG_EACH for (int u = 0; u < U; ++u)
+  double t[U], t_hi[U], hi[U], lo[U], r[U], rr[U], p[U], cc[U], num[U], den[U], q[U];
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y[U], e[U], res[U];
+#endif
+  uint32_t tmp[U];
+  constexpr uint32_t base = 0x3fe6a09cu;
+#pragma unroll
+  AMWG_EACH t[u] = __builtin_copysign(__builtin_trunc(__builtin_fabs(c.inv_ln2 * x[u]) + 0.5), x[u]);
+#pragma unroll
+  AMWG_EACH t_hi[u] = t[u] * c.ln2_hi;
+#pragma unroll
+  AMWG_EACH hi[u] = x[u] - t_hi[u];
+#pragma unroll
+  AMWG_EACH lo[u] = t[u] * c.ln2_lo;
+#pragma unroll
+  AMWG_EACH r[u] = hi[u] - lo[u];
+#pragma unroll
+  AMWG_EACH rr[u] = r[u] * r[u];
+#pragma unroll
+  AMWG_EACH p[u] = c.P4 + rr[u] * c.P5;
+#pragma unroll
+  AMWG_EACH p[u] = c.P3 + rr[u] * p[u];
+#pragma unroll
+  AMWG_EACH p[u] = c.P2 + rr[u] * p[u];
+#pragma unroll
+  AMWG_EACH p[u] = c.P1 + rr[u] * p[u];
+#pragma unroll
+  AMWG_EACH cc[u] = r[u] - rr[u] * p[u];
+#pragma unroll
+  AMWG_EACH { num[u] = r[u] * cc[u]; den[u] = 2.0 - cc[u]; }
+  // quot_plain(num, den), step by step
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  AMWG_EACH y[u] = __builtin_amdgcn_rcp(den[u]);
+#pragma unroll
+  AMWG_EACH e[u] = __builtin_fma(-den[u], y[u], 1.0);
+#pragma unroll
+  AMWG_EACH y[u] = __builtin_fma(y[u], e[u], y[u]);
+#pragma unroll
+  AMWG_EACH e[u] = __builtin_fma(-den[u], y[u], 1.0);
+#pragma unroll
+  AMWG_EACH y[u] = __builtin_fma(y[u], e[u], y[u]);
+#pragma unroll
+  AMWG_EACH q[u] = num[u] * y[u];
+#pragma unroll
+  AMWG_EACH res[u] = __builtin_fma(-den[u], q[u], num[u]);
+#pragma unroll
+  AMWG_EACH q[u] = __builtin_fma(res[u], y[u], q[u]);
+#else
+  AMWG_EACH q[u] = num[u] / den[u];
+#endif
+  double ey[U], f[U], s[U], z[U], w[U], t1[U], t2[U], R[U], hfsq[U], a[U], b[U];
+#pragma unroll
+  AMWG_EACH ey[u] = 1.0 - ((lo[u] - q[u]) - hi[u]);
+#pragma unroll
+  AMWG_EACH {
+    const int32_t hy = hi_word(ey[u]);
+    lam[u] = set_hi_word(ey[u], hy + ((int32_t)t[u] << 20));
+    tmp[u] = (uint32_t)hy - base;
+    rare[u] = exp_is_rare(x[u]) || tmp[u] >= 0x100000u || (tmp[u] - (0x3feffffeu - base)) < 3u;
+  }
+#pragma unroll
+  AMWG_EACH { f[u] = ey[u] - 1.0; den[u] = 2.0 + f[u]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  AMWG_EACH y[u] = __builtin_amdgcn_rcp(den[u]);
+#pragma unroll
+  AMWG_EACH e[u] = __builtin_fma(-den[u], y[u], 1.0);
+#pragma unroll
+  AMWG_EACH y[u] = __builtin_fma(y[u], e[u], y[u]);
+#pragma unroll
+  AMWG_EACH e[u] = __builtin_fma(-den[u], y[u], 1.0);
+#pragma unroll
+  AMWG_EACH y[u] = __builtin_fma(y[u], e[u], y[u]);
+#pragma unroll
+  AMWG_EACH s[u] = f[u] * y[u];
+#pragma unroll
+  AMWG_EACH res[u] = __builtin_fma(-den[u], s[u], f[u]);
+#pragma unroll
+  AMWG_EACH s[u] = __builtin_fma(res[u], y[u], s[u]);
+#else
+  AMWG_EACH s[u] = f[u] / den[u];
+#endif
+#pragma unroll
+  AMWG_EACH z[u] = s[u] * s[u];
+#pragma unroll
+  AMWG_EACH w[u] = z[u] * z[u];
+#pragma unroll
+  AMWG_EACH { t1[u] = c.Lg4 + w[u] * c.Lg6; t2[u] = c.Lg5 + w[u] * c.Lg7; }
+#pragma unroll
+  AMWG_EACH { t1[u] = c.Lg2 + w[u] * t1[u]; t2[u] = c.Lg3 + w[u] * t2[u]; }
+#pragma unroll
+  AMWG_EACH { t1[u] = w[u] * t1[u]; t2[u] = c.Lg1 + w[u] * t2[u]; }
+#pragma unroll
+  AMWG_EACH { t2[u] = z[u] * t2[u]; hfsq[u] = 0.5 * f[u] * f[u]; }
+#pragma unroll
+  AMWG_EACH R[u] = t2[u] + t1[u];
+#pragma unroll
+  AMWG_EACH { a[u] = s[u] * (hfsq[u] + R[u]); b[u] = s[u] * (f[u] - R[u]); }
+#pragma unroll
+  AMWG_EACH { a[u] = hfsq[u] - (a[u] + lo[u]); b[u] = b[u] - lo[u]; }
+#pragma unroll
+  AMWG_EACH {
+    const double sel = (tmp[u] - (0x3fe6b852u - base)) <= (0x3ff61479u - 0x3fe6b852u) ? b[u] : a[u];
+    lg[u] = t_hi[u] - (sel - f[u]);
+  }
+#undef AMWG_EACH
+}
+
+
 
 // ---- pow(x, y): V8's Math.pow (src/base/ieee754.cc pow, the fdlibm e_pow.c algorithm; V8 groups the
 // final quotient differently from fdlibm -- marked below -- and Node's values follow V8).  Used by

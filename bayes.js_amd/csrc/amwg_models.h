@@ -588,7 +588,9 @@ struct PoisGlmModel {
   // icp: the change point as an integer threshold (observation i gets b[7] iff i >= icp, see begin()); K: the constants of exp / log
   // in vector registers (the scalar ones of this kernel are better spent on the nine base pointers, which must be scalar)
   struct Pass { double b[8]; double cp; int icp; ExpLogRegs K; const char *col[9]; };
-  __host__ __device__ static size_t lds_bytes(int, int, int) { return 0; }
+  // one chain per wave: two tiles of kMaxThreads observations x nine values, shared by the chains of the workgroup (pass_tiled below)
+  static constexpr bool kTilePass = true;
+  __host__ __device__ static size_t lds_bytes(int, int, int lanes) { return lanes == 64 ? (size_t)2 * 9 * kMaxThreads * sizeof(double) : 0; }
   __device__ static void stage(unsigned char *, const DataRef &, int, int, int) {}
   // closure order: `for k` over the 8 coefficients (dealt to the lanes), then the change point's prior (lane 0), then the data
   static constexpr bool kSplitPrior = true;
@@ -625,16 +627,29 @@ struct PoisGlmModel {
   struct Row { double v[9]; };
   __device__ __forceinline__ static void load_row(const Pass &ps, int i, Row &r) {
     const uint32_t off = (uint32_t)i * 8u;     // n_obs <= 2^28 (amwg_create)
+#if defined(AMWG_X_GLM_ONELOAD)     // experiment (wrong results): one load per row instead of nine -- is the pass bound by the memory pipeline?
+    r.v[0] = *reinterpret_cast<const double *>(ps.col[0] + off);
+#pragma unroll
+    for (int k = 1; k < 9; ++k) { r.v[k] = r.v[0]; asm volatile("" : "+v"(r.v[k])); }
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < 9; ++k) r.v[k] = *reinterpret_cast<const double *>(ps.col[k] + off);
   }
   // mode (wave-uniform): 0 = i < icp for every lane of the wave, 2 = i >= icp for every lane, 1 = compare
-  __device__ __forceinline__ static double term_of(const Pass &ps, const Row &r, int i, int mode) {
+  __device__ __forceinline__ static double eta_of(const Pass &ps, const Row &r, int i, int mode) {
     double eta = r.v[0] * ps.b[0];
 #pragma unroll
     for (int k = 1; k < 7; ++k) eta += r.v[k] * ps.b[k];
     if (mode == 2) eta += ps.b[7];
     else if (mode == 1) { if (i >= ps.icp) eta += ps.b[7]; }
+    return eta;
+  }
+  __device__ __forceinline__ static double term_of(const Pass &ps, const Row &r, int i, int mode) {
+    const double eta = eta_of(ps, r, i, mode);
+#if defined(AMWG_X_GLM_NOMATH)      // experiment (wrong results): the loads and the linear predictor only
+    return eta + r.v[7] + r.v[8];
+#endif
     double lam;
     const double lg = exp_log_v8(eta, lam, ps.K);
     return lg * r.v[7] - lam - r.v[8];
@@ -652,6 +667,8 @@ struct PoisGlmModel {
   static constexpr bool kOwnPass = true;
 #if defined(AMWG_X_GLM_WAVES)
   static constexpr int kMinWavesPerSimd = AMWG_X_GLM_WAVES;
+#else
+  static constexpr int kMinWavesPerSimd = 2;      // at most 256 VGPRs: the tiled pass would take 263 and run one wave per SIMD
 #endif
   // Round 3, second half: 138 -> ~105 vector instructions per observation, all of them bookkeeping around the 86 fp64 operations the
   // expression needs:
@@ -686,8 +703,31 @@ struct PoisGlmModel {
 #endif
     auto mode_of = [&](int k) { return k < k_some ? 0 : (k >= k_all ? 2 : 1); };
     Row a, b;
-    if (n_mine > 0) load_row(ps, sub, a);
     int k = 0;
+#if defined(AMWG_X_GLM_PAIR)
+    // two observations side by side in one basic block (their dependent chains interleave), the next two rows requested as soon as the
+    // linear predictors have consumed the current ones
+    if (n_full >= 4) {
+      load_row(ps, sub, a);
+      load_row(ps, G + sub, b);
+      for (; k + 3 < n_full; k += 2) {
+        const double eta_a = eta_of(ps, a, k * G + sub, mode_of(k)), eta_b = eta_of(ps, b, (k + 1) * G + sub, mode_of(k + 1));
+        const double ya = a.v[7], la = a.v[8], yb = b.v[7], lb = b.v[8];
+        AMWG_STAGE_FENCE();
+        load_row(ps, (k + 2) * G + sub, a);
+        load_row(ps, (k + 3) * G + sub, b);
+        AMWG_STAGE_FENCE();
+        acc = pair_finish(ps, eta_a, eta_b, ya, la, yb, lb, acc);
+        AMWG_STAGE_FENCE();
+      }
+    }
+    for (; k < n_mine; ++k) {
+      load_row(ps, k * G + sub, a);
+      acc += term_of(ps, a, k * G + sub, 1);
+    }
+    return acc;
+#endif
+    if (n_mine > 0) load_row(ps, sub, a);
     for (; k + 2 < n_full; k += 2) {                            // two observations per trip: the register sets swap roles, nothing is copied
       load_row(ps, (k + 1) * G + sub, b);
       AMWG_STAGE_FENCE();
@@ -703,6 +743,103 @@ struct PoisGlmModel {
       acc += term_of(ps, a, k * G + sub, 1);
       a = b;
     }
+    return acc;
+  }
+
+  // ---- one chain per wave: the pass as a workgroup operation -----------------------------------------------------------------------
+  // Measured (round 3, same box): with the arithmetic of exp and log REMOVED the per-wave pass above ran only 6 % faster -- it is bound by
+  // the vector memory pipeline, not by the VALU: every chain fetches all nine values of every observation through the CU's L1 (72 B per
+  // observation and chain = 19 TB/s over the chip, about half of what L1 / L2 can deliver at all), although the chains of a workgroup walk
+  // over the SAME observations in the same order.  Here the W = blockDim / 64 chains of a workgroup share the fetch: thread tid requests
+  // observation t*nt + tid of tile t (the loads of tile t + 1 are in flight under the arithmetic of tile t), writes its nine values into
+  // one of two LDS tiles, one barrier, and every wave then reads all nt observations of the tile from LDS (256 B/clk against the L1's
+  // 64 B/clk; the L1 / L2 traffic is divided by W).  A lane still adds ITS observations (sub, sub + 64, ...) in ascending order: the
+  // same partial sums as pass<64>.  A wave whose proposal is out of bounds stages and waits with the others (active = false).
+  // Hazards: tile t is written into buffer t & 1, last read during tile t - 2; a wave can only reach the writes of tile t after the
+  // barrier of tile t - 1, which every wave reaches after its reads of tile t - 2: one barrier per tile is enough, plus one per
+  // evaluation before tile 0 is written.
+  template <int G>
+  __device__ __forceinline__ static double pass_tiled(const Pass &ps, int n_obs, int sub, double acc, bool active, unsigned char *smem) {
+    static_assert(G == 64, "one chain per wave");
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int nt = (int)blockDim.x, tid = (int)threadIdx.x, W = nt >> 6;
+    double *const tiles = reinterpret_cast<double *>(smem);       // [2][9][nt]
+    const int n_tiles = (n_obs + nt - 1) / nt;
+    // first own round k (observation k*64 + sub) with i >= icp; over the wave: nobody adds b[7] before k_some, everybody from k_all on
+    const int first = ps.icp <= sub ? 0 : (ps.icp - sub + 63) / 64;
+    int lo = first, hi = first;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+    }
+    const int k_some = __builtin_amdgcn_readfirstlane(lo), k_all = __builtin_amdgcn_readfirstlane(hi);
+    auto mode_of = [&](int k) { return k < k_some ? 0 : (k >= k_all ? 2 : 1); };
+    Row r;
+    auto fetch = [&](int t) {                                     // (past the end: re-read the last observation, never used)
+      const int i = t * nt + tid;
+      load_row(ps, i < n_obs ? i : n_obs - 1, r);
+    };
+    auto read_round = [&](const double *buf, int j, Row &q) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) q.v[k] = buf[k * nt + j * 64 + sub];
+    };
+    if (n_tiles > 0) fetch(0);
+    // every wave is done reading the previous evaluation's tiles (its last one may sit in the buffer tile 0 is about to be written to)
+    asm volatile("s_barrier" ::: "memory");
+    for (int t = 0; t < n_tiles; ++t) {
+      double *const buf = tiles + (size_t)(t & 1) * 9 * nt;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) buf[k * nt + tid] = r.v[k];
+      if (t + 1 < n_tiles) fetch(t + 1);
+      // (not __syncthreads(): its fence would also wait for the loads just issued)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (!active) continue;
+      const int base = t * nt, k0 = t * W;
+      if (W == 4 && base + nt <= n_obs) {
+        // four whole rounds, two observations side by side through exp / log; the second pair's LDS reads are requested once the first
+        // pair's linear predictors have consumed their rows (same registers), i.e. under the ~180 instructions of its exp / log
+        Row q0, q1;
+        read_round(buf, 0, q0);
+        read_round(buf, 1, q1);
+        const double e0 = eta_of(ps, q0, base + sub, mode_of(k0)), e1 = eta_of(ps, q1, base + 64 + sub, mode_of(k0 + 1));
+        const double y0 = q0.v[7], l0 = q0.v[8], y1 = q1.v[7], l1 = q1.v[8];
+        AMWG_STAGE_FENCE();
+        read_round(buf, 2, q0);
+        read_round(buf, 3, q1);
+        AMWG_STAGE_FENCE();
+        acc = pair_finish(ps, e0, e1, y0, l0, y1, l1, acc);
+        AMWG_STAGE_FENCE();
+        const double e2 = eta_of(ps, q0, base + 128 + sub, mode_of(k0 + 2)), e3 = eta_of(ps, q1, base + 192 + sub, mode_of(k0 + 3));
+        acc = pair_finish(ps, e2, e3, q0.v[7], q0.v[8], q1.v[7], q1.v[8], acc);
+      } else {
+        for (int j = 0; j < W; ++j) {
+          const int r0 = base + j * 64;
+          if (r0 >= n_obs) break;
+          if (r0 + sub < n_obs) {                                 // (a partial round only at the very end of the data)
+            Row q;
+            read_round(buf, j, q);
+            acc += term_of(ps, q, r0 + sub, mode_of(k0 + j));
+          }
+        }
+      }
+    }
+#endif
+    return acc;
+  }
+  // two observations through exp / log side by side (one basic block: the two dependent chains interleave), added in order
+  __device__ __forceinline__ static double pair_finish(const Pass &ps, double eta_a, double eta_b, double ya, double la, double yb, double lb, double acc) {
+    const double eta[2] = {eta_a, eta_b};
+    double lam[2], lg[2];
+    bool rare[2];
+    exp_log_v8_open<2>(eta, lam, lg, rare, ps.K);
+    if (__builtin_expect(rare[0] | rare[1], 0)) {
+      if (rare[0]) { lam[0] = exp_v8_cold(eta[0]); lg[0] = log_v8_cold(lam[0]); }
+      if (rare[1]) { lam[1] = exp_v8_cold(eta[1]); lg[1] = log_v8_cold(lam[1]); }
+    }
+    acc += lg[0] * ya - lam[0] - la;
+    acc += lg[1] * yb - lam[1] - lb;
     return acc;
   }
 };

@@ -21,6 +21,22 @@ static void check(double x) {
   const ExpLogRegs regs = exp_log_regs();
   const double gr = exp_log_v8(x, lam_r, regs);
   ++seen;
+  {   // the two-wide branch-free form: a fresh argument beside the previous one, rare lanes patched as its caller does
+    static double prev = 0.5;
+    const double xs[2] = {x, prev};
+    double lam2[2], lg2[2];
+    bool rare2[2];
+    exp_log_v8_open<2>(xs, lam2, lg2, rare2, regs);
+    for (int u = 0; u < 2; ++u)
+      if (rare2[u]) { lam2[u] = exp_v8(xs[u]); lg2[u] = log_v8(lam2[u]); }
+    const double we1 = exp_v8_full(prev), wl1 = log_v8_full(we1);
+    auto same2 = [](double a, double b) { return memcmp(&a, &b, 8) == 0 || (a != a && b != b); };
+    if (!same2(lam2[0], we) || !same2(lg2[0], wl) || !same2(lam2[1], we1) || !same2(lg2[1], wl1)) {
+      if (bad < 10) printf("MISMATCH (two-wide) x=%a prev=%a\n", x, prev);
+      ++bad;
+    }
+    prev = x;
+  }
   auto same = [](double a, double b) { return memcmp(&a, &b, 8) == 0 || (a != a && b != b); };
   if (!same(ge, we) || !same(lam_l, we) || !same(lam_r, we) || !same(gl, wl) || !same(gr, wl)) {
     if (bad < 10) printf("MISMATCH x=%a exp=%a want=%a | log=%a want=%a\n", x, ge, we, gl, wl);

@@ -15,6 +15,10 @@ PASSES = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "
           ["SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVES", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_SMEM", "GRBM_GUI_ACTIVE"]]
 
 
+if os.environ.get("AMWG_PMC_PASSES"):          # e.g. "TCC_HIT_sum,TCC_MISS_sum;SQ_INSTS_VALU,SQ_WAVE_CYCLES": other counters, raw sums only
+    PASSES = [p.split(",") for p in os.environ["AMWG_PMC_PASSES"].split(";")]
+
+
 def probe(tag, fam, lanes, n_obs, chains, idx):
     out = {}
     geom = None
@@ -62,7 +66,7 @@ def main():
                "wave_cycles_per_update": g("SQ_WAVE_CYCLES") / upd, "busy_cycles": g("SQ_BUSY_CYCLES"), "lds_bank_conflict": g("SQ_LDS_BANK_CONFLICT"),
                "raw": {k: v for k, v in c.items() if not k.startswith("_")}}
         res.append(row)
-        print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in row.items() if k != "raw"}))
+        print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in row.items() if k != "raw" or os.environ.get("AMWG_PMC_PASSES")}))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", tag + "_pmc.json"), "w"), indent=1)
 
