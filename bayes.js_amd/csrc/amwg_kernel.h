@@ -116,11 +116,6 @@ template <class M> struct TracksState<M, void_of<decltype(M::kTracksState)>> { s
 template <class M, class = void> struct GroupSweepOf { static constexpr bool value = false; };
 template <class M> struct GroupSweepOf<M, void_of<decltype(M::kGroupSweep)>> { static constexpr bool value = M::kGroupSweep; };
 
-// Model::kTilePass: with one chain per wave (G == 64) the model's pass is a WORKGROUP operation -- the waves of a workgroup stage the
-// data tile by tile in LDS and every chain reads it from there (Model::pass_tiled) -- so every wave has to come through every
-// evaluation, also the one whose proposal is out of bounds (it takes part in the staging and the barriers with active = false).
-template <class M, class = void> struct TilePassOf { static constexpr bool value = false; };
-template <class M> struct TilePassOf<M, void_of<decltype(M::kTilePass)>> { static constexpr bool value = M::kTilePass; };
 template <class M, class = void> struct OwnPassOf { static constexpr bool value = false; };
 template <class M> struct OwnPassOf<M, void_of<decltype(M::kOwnPass)>> { static constexpr bool value = M::kOwnPass; };
 
@@ -216,7 +211,7 @@ __device__ __forceinline__ int fresh_uniform(int v) {
 
 template <class Model, int G, int U = 8>
 __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a0, const unsigned char *smem, int sub, CrossWave &xw,
-                                           typename CacheOf<Model>::type &cache, bool active = true) {
+                                           typename CacheOf<Model>::type &cache) {
   // (a copy of the argument block's data descriptor with opaque sizes, see fresh_uniform)
   struct { const ModelConsts &mc; DataRef d; } a{a0.mc, a0.d};
   a.d.n_obs = fresh_uniform(a0.d.n_obs);
@@ -244,8 +239,6 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
       else acc = Model::template pass_slow<G>(ps, a.d.n_obs, sub, acc);            // IEEE '/': rare, out of line
     } else if constexpr (Model::kOneLanePass && G == 1) {
       acc = Model::pass_one_lane(ps, a.d.n_obs, acc);
-    } else if constexpr (TilePassOf<Model>::value && G == 64) {
-      acc = Model::template pass_tiled<G>(ps, a.d.n_obs, sub, acc, active, const_cast<unsigned char *>(smem));   // workgroup-shared tiles
     } else if constexpr (OwnPassOf<Model>::value) {
       acc = Model::template pass<G>(ps, a.d.n_obs, sub, acc);      // the model's own pipelined pass
     } else {
@@ -812,9 +805,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       // shuffled), and what the stepper needs of it is requested NOW, under the evaluation below
       if (slot + 1 < P_stepped) nx = prefetch(next_comp());
       bool accepted = false;
-      constexpr bool kEveryWave = TilePassOf<Model>::value && G == 64;      // the evaluation is a workgroup operation (see TilePassOf)
-      if (inb || kEveryWave) {
-        const double prop_lp = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache, inb);
+      if (inb) {
+        const double prop_lp = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);
 #if defined(__HIP_DEVICE_COMPILE__)
         // the next slot's prefetched values are "used" HERE: the wait for them lands right behind the pass's own LDS reads (which returned
         // after them -- no stall), instead of at the top of the next slot behind this slot's closing stores and counter update
@@ -823,8 +815,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         // Math.exp(prop - curr) > Math.random() (mcmc.js:527-528).  For a difference >= 0 (incl. +inf) the exponential is >= 1 > u, below
         // -746 it is exactly 0 (never > u): the decision is the reference's without evaluating it; NaN takes the general path (false).
         const double diff = prop_lp - lp_curr;
-        if (kEveryWave && !inb) accepted = false;      // (nothing was evaluated; with one chain per wave this branch is wave-uniform)
-        else if (diff >= 0.0) accepted = true;
+        if (diff >= 0.0) accepted = true;
         else if (diff < -746.0) accepted = false;
         else {
           // For d < 0:  1 + d <= exp(d) <= 1 + d + d*d/2, and V8's exp is within one ulp (< 2^-53 here) of exp: a uniform below the lower bound
@@ -838,8 +829,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           else accepted = exp_v8(diff) > u_accept;
         }
         if (accepted) lp_curr = prop_lp;
-        else if (!kEveryWave || inb) set_state(comp, cur);
-        if (counter && (!kEveryWave || inb)) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // run totals (not in the reference; parity tests compare them with the oracle's)
+        else set_state(comp, cur);
+        if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // run totals (not in the reference; parity tests compare them with the oracle's)
       }
       if (me.adapting) adapt_component(comp, accepted, me.cnt, me.batch_size, writer);
     }

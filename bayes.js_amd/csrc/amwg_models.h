@@ -588,9 +588,7 @@ struct PoisGlmModel {
   // icp: the change point as an integer threshold (observation i gets b[7] iff i >= icp, see begin()); K: the constants of exp / log
   // in vector registers (the scalar ones of this kernel are better spent on the nine base pointers, which must be scalar)
   struct Pass { double b[8]; double cp; int icp; ExpLogRegs K; const char *col[9]; };
-  // one chain per wave: two tiles of kMaxThreads observations x nine values, shared by the chains of the workgroup (pass_tiled below)
-  static constexpr bool kTilePass = true;
-  __host__ __device__ static size_t lds_bytes(int, int, int lanes) { return lanes == 64 ? (size_t)2 * 9 * kMaxThreads * sizeof(double) : 0; }
+  __host__ __device__ static size_t lds_bytes(int, int, int) { return 0; }
   __device__ static void stage(unsigned char *, const DataRef &, int, int, int) {}
   // closure order: `for k` over the 8 coefficients (dealt to the lanes), then the change point's prior (lane 0), then the data
   static constexpr bool kSplitPrior = true;
@@ -627,12 +625,6 @@ struct PoisGlmModel {
   struct Row { double v[9]; };
   __device__ __forceinline__ static void load_row(const Pass &ps, int i, Row &r) {
     const uint32_t off = (uint32_t)i * 8u;     // n_obs <= 2^28 (amwg_create)
-#if defined(AMWG_X_GLM_ONELOAD)     // experiment (wrong results): one load per row instead of nine -- is the pass bound by the memory pipeline?
-    r.v[0] = *reinterpret_cast<const double *>(ps.col[0] + off);
-#pragma unroll
-    for (int k = 1; k < 9; ++k) { r.v[k] = r.v[0]; asm volatile("" : "+v"(r.v[k])); }
-    return;
-#endif
 #pragma unroll
     for (int k = 0; k < 9; ++k) r.v[k] = *reinterpret_cast<const double *>(ps.col[k] + off);
   }
@@ -668,7 +660,7 @@ struct PoisGlmModel {
 #if defined(AMWG_X_GLM_WAVES)
   static constexpr int kMinWavesPerSimd = AMWG_X_GLM_WAVES;
 #else
-  static constexpr int kMinWavesPerSimd = 2;      // at most 256 VGPRs: the tiled pass would take 263 and run one wave per SIMD
+  static constexpr int kMinWavesPerSimd = 2;      // at most 256 VGPRs
 #endif
   // Round 3, second half: 138 -> ~105 vector instructions per observation, all of them bookkeeping around the 86 fp64 operations the
   // expression needs:
@@ -678,11 +670,17 @@ struct PoisGlmModel {
   //    side) are told apart on the scalar unit -- `mode` 0: nobody adds b[7]; 2: everybody does; 1: the one or two rounds in between
   //    compare (integer compare, see begin());
   //  * the loop never asks for a row past a lane's last one (the clamp cost a compare, a select and two moves per row): the pipelined
-  //    loop stops two rounds early, the tail is predicated;
-  //  * constants of exp / log in vector registers: three of the nine base pointers had been spilled for them and were read back with
+  //    loop stops early, the tail is predicated;
+  //  * constants of exp in vector registers: three of the nine base pointers had been spilled for them and were read back with
   //    v_readlane for every row;
   //  * eta starts at the first product instead of 0 + product (they differ for a product of -0 only, and a sum that is -0 instead of
-  //    +0 in the end has the same exp).
+  //    +0 in the end has the same exp);
+  //  * two observations side by side through exp / log (pair_finish: one basic block, the two dependent chains interleave), the next two
+  //    rows requested as soon as the linear predictors have consumed the current ones (same registers).
+  // What it bought is less than the instruction count says (4.62 -> 5.0e6 updates/s): see DESIGN.md section 4 -- the pass sits on two
+  // ceilings at once, the VALU issue rate (an fp64 instruction every ~4.45 cycles with two waves per SIMD, v_rcp_f64 16) and the vector
+  // memory pipeline (72 B per observation and chain through L1: with exp and log REMOVED it runs only 6 % faster).  A workgroup-shared
+  // LDS tiling of the data (a quarter of the L1 traffic) was built and measured 4 % SLOWER than this loop on the same box, and dropped.
   template <int G>
   __device__ __forceinline__ static double pass(const Pass &ps, int n_obs, int sub, double acc) {
     const int n_full = n_obs / G, rem = n_obs % G;
@@ -704,13 +702,10 @@ struct PoisGlmModel {
     auto mode_of = [&](int k) { return k < k_some ? 0 : (k >= k_all ? 2 : 1); };
     Row a, b;
     int k = 0;
-#if defined(AMWG_X_GLM_PAIR)
-    // two observations side by side in one basic block (their dependent chains interleave), the next two rows requested as soon as the
-    // linear predictors have consumed the current ones
     if (n_full >= 4) {
       load_row(ps, sub, a);
       load_row(ps, G + sub, b);
-      for (; k + 3 < n_full; k += 2) {
+      for (; k + 3 < n_full; k += 2) {                          // rounds k + 2, k + 3 < n_full: every lane has those rows
         const double eta_a = eta_of(ps, a, k * G + sub, mode_of(k)), eta_b = eta_of(ps, b, (k + 1) * G + sub, mode_of(k + 1));
         const double ya = a.v[7], la = a.v[8], yb = b.v[7], lb = b.v[8];
         AMWG_STAGE_FENCE();
@@ -721,111 +716,10 @@ struct PoisGlmModel {
         AMWG_STAGE_FENCE();
       }
     }
-    for (; k < n_mine; ++k) {
+    for (; k < n_mine; ++k) {                                   // the last rounds (two of them were requested above already: re-read)
       load_row(ps, k * G + sub, a);
       acc += term_of(ps, a, k * G + sub, 1);
     }
-    return acc;
-#endif
-    if (n_mine > 0) load_row(ps, sub, a);
-    for (; k + 2 < n_full; k += 2) {                            // two observations per trip: the register sets swap roles, nothing is copied
-      load_row(ps, (k + 1) * G + sub, b);
-      AMWG_STAGE_FENCE();
-      acc += term_of(ps, a, k * G + sub, mode_of(k));
-      AMWG_STAGE_FENCE();
-      load_row(ps, (k + 2) * G + sub, a);                       // k + 2 < n_full: every lane has that row
-      AMWG_STAGE_FENCE();
-      acc += term_of(ps, b, (k + 1) * G + sub, mode_of(k + 1));
-      AMWG_STAGE_FENCE();
-    }
-    for (; k < n_mine; ++k) {                                   // at most two whole rounds and the remainder observation
-      if (k + 1 < n_mine) load_row(ps, (k + 1) * G + sub, b);
-      acc += term_of(ps, a, k * G + sub, 1);
-      a = b;
-    }
-    return acc;
-  }
-
-  // ---- one chain per wave: the pass as a workgroup operation -----------------------------------------------------------------------
-  // Measured (round 3, same box): with the arithmetic of exp and log REMOVED the per-wave pass above ran only 6 % faster -- it is bound by
-  // the vector memory pipeline, not by the VALU: every chain fetches all nine values of every observation through the CU's L1 (72 B per
-  // observation and chain = 19 TB/s over the chip, about half of what L1 / L2 can deliver at all), although the chains of a workgroup walk
-  // over the SAME observations in the same order.  Here the W = blockDim / 64 chains of a workgroup share the fetch: thread tid requests
-  // observation t*nt + tid of tile t (the loads of tile t + 1 are in flight under the arithmetic of tile t), writes its nine values into
-  // one of two LDS tiles, one barrier, and every wave then reads all nt observations of the tile from LDS (256 B/clk against the L1's
-  // 64 B/clk; the L1 / L2 traffic is divided by W).  A lane still adds ITS observations (sub, sub + 64, ...) in ascending order: the
-  // same partial sums as pass<64>.  A wave whose proposal is out of bounds stages and waits with the others (active = false).
-  // Hazards: tile t is written into buffer t & 1, last read during tile t - 2; a wave can only reach the writes of tile t after the
-  // barrier of tile t - 1, which every wave reaches after its reads of tile t - 2: one barrier per tile is enough, plus one per
-  // evaluation before tile 0 is written.
-  template <int G>
-  __device__ __forceinline__ static double pass_tiled(const Pass &ps, int n_obs, int sub, double acc, bool active, unsigned char *smem) {
-    static_assert(G == 64, "one chain per wave");
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int nt = (int)blockDim.x, tid = (int)threadIdx.x, W = nt >> 6;
-    double *const tiles = reinterpret_cast<double *>(smem);       // [2][9][nt]
-    const int n_tiles = (n_obs + nt - 1) / nt;
-    // first own round k (observation k*64 + sub) with i >= icp; over the wave: nobody adds b[7] before k_some, everybody from k_all on
-    const int first = ps.icp <= sub ? 0 : (ps.icp - sub + 63) / 64;
-    int lo = first, hi = first;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const int l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
-      lo = l2 < lo ? l2 : lo;
-      hi = h2 > hi ? h2 : hi;
-    }
-    const int k_some = __builtin_amdgcn_readfirstlane(lo), k_all = __builtin_amdgcn_readfirstlane(hi);
-    auto mode_of = [&](int k) { return k < k_some ? 0 : (k >= k_all ? 2 : 1); };
-    Row r;
-    auto fetch = [&](int t) {                                     // (past the end: re-read the last observation, never used)
-      const int i = t * nt + tid;
-      load_row(ps, i < n_obs ? i : n_obs - 1, r);
-    };
-    auto read_round = [&](const double *buf, int j, Row &q) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) q.v[k] = buf[k * nt + j * 64 + sub];
-    };
-    if (n_tiles > 0) fetch(0);
-    // every wave is done reading the previous evaluation's tiles (its last one may sit in the buffer tile 0 is about to be written to)
-    asm volatile("s_barrier" ::: "memory");
-    for (int t = 0; t < n_tiles; ++t) {
-      double *const buf = tiles + (size_t)(t & 1) * 9 * nt;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) buf[k * nt + tid] = r.v[k];
-      if (t + 1 < n_tiles) fetch(t + 1);
-      // (not __syncthreads(): its fence would also wait for the loads just issued)
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (!active) continue;
-      const int base = t * nt, k0 = t * W;
-      if (W == 4 && base + nt <= n_obs) {
-        // four whole rounds, two observations side by side through exp / log; the second pair's LDS reads are requested once the first
-        // pair's linear predictors have consumed their rows (same registers), i.e. under the ~180 instructions of its exp / log
-        Row q0, q1;
-        read_round(buf, 0, q0);
-        read_round(buf, 1, q1);
-        const double e0 = eta_of(ps, q0, base + sub, mode_of(k0)), e1 = eta_of(ps, q1, base + 64 + sub, mode_of(k0 + 1));
-        const double y0 = q0.v[7], l0 = q0.v[8], y1 = q1.v[7], l1 = q1.v[8];
-        AMWG_STAGE_FENCE();
-        read_round(buf, 2, q0);
-        read_round(buf, 3, q1);
-        AMWG_STAGE_FENCE();
-        acc = pair_finish(ps, e0, e1, y0, l0, y1, l1, acc);
-        AMWG_STAGE_FENCE();
-        const double e2 = eta_of(ps, q0, base + 128 + sub, mode_of(k0 + 2)), e3 = eta_of(ps, q1, base + 192 + sub, mode_of(k0 + 3));
-        acc = pair_finish(ps, e2, e3, q0.v[7], q0.v[8], q1.v[7], q1.v[8], acc);
-      } else {
-        for (int j = 0; j < W; ++j) {
-          const int r0 = base + j * 64;
-          if (r0 >= n_obs) break;
-          if (r0 + sub < n_obs) {                                 // (a partial round only at the very end of the data)
-            Row q;
-            read_round(buf, j, q);
-            acc += term_of(ps, q, r0 + sub, mode_of(k0 + j));
-          }
-        }
-      }
-    }
-#endif
     return acc;
   }
   // two observations through exp / log side by side (one basic block: the two dependent chains interleave), added in order

@@ -71,7 +71,7 @@ OTHER_WORKLOADS = {
     # the one number the reference publishes (README.md:252): Normal model, 1000 data points, 20 000 draws
     # "~0.5 s" = 8.0e4 param-updates/s on the author's machine -- ONE chain, so this measures single-chain latency
     "readme": ("normal", 1_000, 1, 1_000 * 8 + 8 * 2 + 8, 8, "README.md:252 claim: Normal(mu,sigma), 1000 obs, ONE chain (run with --steps 20000)"),
-    "cfg5": ("pois_glm", 50_000, 8_192, 50_000 * (7 * 8 + 8 + 8) + 8 * 9 + 8, 88, "BASELINE.json configs[4]: Poisson GLM + int change point, 5e4 obs, 8192 chains per GPU (65536 over 8)"),
+    "cfg5": ("pois_glm", 50_000, 8_192, 50_000 * (7 * 8 + 8 + 8) + 8 * 9 + 8, 86, "BASELINE.json configs[4]: Poisson GLM + int change point, 5e4 obs, 8192 chains per GPU (65536 over 8)"),
 }
 
 
@@ -80,11 +80,13 @@ OPS_NOTE = {
     "normal": "8 = sub, mul, 4-operation correctly rounded quotient (amwg_div.h: mul, fma, fma, fma), sub, add; IEEE '/' would be 17",
     "hier_normal": "8 = sub, mul, 4-operation correctly rounded quotient, sub, add (the gather of theta[g_i] is an LDS read, not arithmetic)",
     "beta_bern": "1 = the fp64 add of the term-by-term pass (the observation selects WHICH register is added, on the scalar unit)",
-    "pois_glm": "88 = the fp64 operations the expression needs, none of which can go without changing a rounding the reference performs: 14 linear "
-                "predictor (7 mul + 7 add, no contraction), 2 change point (int->double, add), 32 V8 exp (4 reduction k, 5 hi/lo/r/rr, 10 polynomial, 13 "
-                "quotient form incl. the 8-operation r*c/(2-c)), 36 V8 log (3 f/dk/2+f, 8 quotient, 14 polynomials, 11 the selected tail), 4 density + "
-                "accumulate.  ISSUED per observation (rocprofv3, utilisation, not the roofline's unit): ~134 incl. integer/select/address work and the "
-                "second log tail the straight-line form computes",
+    "pois_glm": "86 = the fp64 operations the expression needs once the operations exp and log have in common are formed once: 13 linear "
+                "predictor (7 mul + 6 add, no contraction), 1 change point (add; the comparison is an integer one), 32 V8 exp (3 k: mul, add, trunc; "
+                "4 hi/lo/r; 1 r*r; 10 polynomial; 10 r*c/(2-c) incl. the 8-operation quotient; 3 reassembly; 1 int conversion of k), 36 V8 log of that value (its "
+                "argument split and its two k*ln2 products are exp's own: 2 f and 2+f; 8 quotient; 14 polynomials; 12 both tails and the final sum), "
+                "4 density + accumulate.  ISSUED per observation (disassembly, utilisation, not the roofline's unit): ~105 incl. integer/select/address "
+                "work (138 until round 3's second half).  Practical ceiling of the issue rate: an fp64 instruction every ~4.45 cycles with two waves "
+                "per SIMD and 16.5 for v_rcp_f64 (tools/ubench/valu_rates.hip)",
 }
 
 

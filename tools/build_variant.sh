@@ -7,10 +7,10 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 D=$R/build/$NAME
 mkdir -p $D/bayes.js_amd $D/include
 mkdir -p $D/bayes.js_amd/csrc
-for f in $R/bayes.js_amd/csrc/*.h $R/bayes.js_amd/csrc/*.hip $R/bayes.js_amd/csrc/*.c $R/bayes.js_amd/csrc/*.py $R/bayes.js_amd/csrc/Makefile; do
+for f in $R/bayes.js_amd/csrc/*.h $R/bayes.js_amd/csrc/*.hip $R/bayes.js_amd/csrc/*.c $R/bayes.js_amd/csrc/Makefile; do
   cmp -s $f $D/bayes.js_amd/csrc/$(basename $f) || cp $f $D/bayes.js_amd/csrc/
 done
 cp $R/include/*.h $D/include/
-make -s -j8 -C $D/bayes.js_amd/csrc libamwg.so VOP3_SELECT=${VOP3_SELECT:-1} HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -falign-loops=64 -Wall -Wno-unused-function $*"
+make -s -j8 -C $D/bayes.js_amd/csrc libamwg.so HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -falign-loops=64 -Wall -Wno-unused-function $*"
 cp $D/bayes.js_amd/csrc/libamwg.so $D/libamwg.so
 echo "built $D/libamwg.so"
