@@ -45,7 +45,7 @@ class UserModel(C.Structure):
                 ("parallel", C.c_int32), ("max_threads", C.c_int32), ("work_per_eval", C.c_double), ("work_one_lane", C.c_double)]
 
 
-EXPORTS = ["amwg_code_cache_stats", "amwg_tuning", "amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state", "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components", "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp", "amwg_log", "amwg_uniform"]      # include/amwg.h: the product library
+EXPORTS = ["amwg_code_cache_stats", "amwg_tuning", "amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_fetch_draws_slices", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state", "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components", "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp", "amwg_log", "amwg_uniform"]      # include/amwg.h: the product library
 SELFTEST_EXPORTS = ["amwg_math1", "amwg_math2", "amwg_hypot3", "amwg_log1p", "amwg_expm1", "amwg_two_valued_sum_check", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_device_eval"]      # include/amwg_selftest.h: libamwg_selftest.so only
 
 _lib = None
@@ -66,6 +66,7 @@ def lib():
         L.amwg_burn_async.argtypes = [vp, i64]
         L.amwg_sample_async.argtypes = [vp, i64, i64]
         L.amwg_fetch_draws.argtypes = [vp, pd, C.c_size_t]
+        L.amwg_fetch_draws_slices.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_size_t)]
         L.amwg_sample.argtypes = [vp, i64, i64, pd, C.c_size_t]
         L.amwg_sample_device.argtypes = [vp, i64, i64, vp, C.c_size_t]
         L.amwg_set_adapting.argtypes = [vp, i32]
@@ -261,6 +262,17 @@ class Sampler:
         out = np.empty((self._pending, self.PR, self.C), dtype=np.float64)
         _check(lib().amwg_fetch_draws(self.h, _dp(out), out.nbytes))
         return out
+
+    def fetch_draws_slices(self, slices):
+        """slices: [(base, len), ...] -> one array [kept][len][chains] per slice (amwg_fetch_draws_slices)"""
+        outs = [np.empty((self._pending, ln, self.C), dtype=np.float64) for _, ln in slices]
+        n = len(slices)
+        base = (C.c_int32 * max(n, 1))(*[b for b, _ in slices])
+        ln = (C.c_int32 * max(n, 1))(*[l for _, l in slices])
+        ptrs = (C.POINTER(C.c_double) * max(n, 1))(*[_dp(o) for o in outs])
+        sizes = (C.c_size_t * max(n, 1))(*[o.nbytes for o in outs])
+        _check(lib().amwg_fetch_draws_slices(self.h, n, base, ln, ptrs, sizes))
+        return outs
 
     def sample_device(self, n, thin, dev_ptr, nbytes):
         _check(lib().amwg_sample_device(self.h, n, thin, C.c_void_p(dev_ptr), nbytes))

@@ -270,6 +270,7 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
   a.d = s->d;
   a.ch = s->ch;
   s->n_launches = 0;
+  s->chunk_rows.clear();
   HIP_TRY(hipEventRecord(s->ev0, s->stream));
   int64_t done = 0, row = 0;
   do {
@@ -289,7 +290,17 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
     }
     s->lp_ready = true;
     s->n_launches++;
-    if (d_draws) row += (m > a.step0) ? (m - a.step0 + thin - 1) / thin : 0;
+    if (d_draws) {
+      row += (m > a.step0) ? (m - a.step0 + thin - 1) / thin : 0;
+      const size_t j = s->chunk_rows.size();
+      if (j >= s->chunk_ev.size()) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s->chunk_ev.push_back(e);
+      }
+      HIP_TRY(hipEventRecord(s->chunk_ev[j], s->stream));
+      s->chunk_rows.push_back(row);
+    }
     done += m;
   } while (done < n);
   HIP_TRY(hipEventRecord(s->ev1, s->stream));
@@ -1104,6 +1115,8 @@ int amwg_destroy(amwg_sampler *s) {
   for (void *p : s->dev_allocs) (void)hipFree(p);
   if (s->d_draws) (void)hipFree(s->d_draws);
   if (s->user_module) (void)hipModuleUnload(s->user_module);
+  for (hipEvent_t e : s->chunk_ev) (void)hipEventDestroy(e);
+  if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -1156,18 +1169,48 @@ int amwg_sample_async(amwg_sampler *s, int64_t n, int64_t thin) {
   return amwg_sample_device(s, n, thin, s->d_draws, need);
 }
 
-int amwg_fetch_draws(amwg_sampler *s, double *out, size_t out_bytes) {
+// The rows of a sample call are final launch by launch (launch_steps records an event after each): the rows of launch j leave the
+// device on copy_stream while launches j + 1, ... run on the sampler's stream -- a pageable destination (a JavaScript typed array, a numpy
+// array) makes each copy block THIS thread, not the GPU.  65 536 chains x 1000 draws x 2 components are 1.05 GB: 0.27 s of copying after
+// 0.33 s of kernels when done at the end, hidden behind them this way.
+int amwg_fetch_draws_slices(amwg_sampler *s, int32_t n_slices, const int32_t *base, const int32_t *len, double *const *out, const size_t *out_bytes) {
   if (!s) return fail(AMWG_EINVAL, "amwg_fetch_draws: null sampler");
   if (s->last_draws != s->d_draws) return fail(AMWG_EINVAL, "amwg_fetch_draws: no amwg_sample_async pending");
-  const size_t need = (size_t)s->last_rows * (size_t)(s->P + s->D) * (size_t)s->C * 8;
-  if (need && !out) return fail(AMWG_EINVAL, "amwg_fetch_draws: null output");
-  if (out_bytes < need) return fail(AMWG_ESIZE, "amwg_sample: output needs %zu bytes, got %zu", need, out_bytes);
+  if (n_slices < 0 || (n_slices > 0 && (!base || !len || !out || !out_bytes))) return fail(AMWG_EINVAL, "amwg_fetch_draws_slices: bad argument");
+  const int PR = s->P + s->D;
+  const size_t C = (size_t)s->C;
+  for (int k = 0; k < n_slices; ++k) {
+    if (base[k] < 0 || len[k] < 0 || base[k] + len[k] > PR) return fail(AMWG_EINVAL, "amwg_fetch_draws_slices: slice %d = [%d, %d) outside the %d recorded values", k, base[k], base[k] + len[k], PR);
+    const size_t need = (size_t)s->last_rows * (size_t)len[k] * C * 8;
+    if (need && !out[k]) return fail(AMWG_EINVAL, "amwg_fetch_draws: null output");
+    if (out_bytes[k] < need) return fail(AMWG_ESIZE, "amwg_sample: output needs %zu bytes, got %zu", need, out_bytes[k]);
+  }
   HIP_TRY(hipSetDevice(s->device));
-  int rc = finish_timing(s);
-  if (rc != AMWG_OK) return rc;
-  if (need) HIP_TRY(hipMemcpyAsync(out, s->d_draws, need, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  return AMWG_OK;
+  if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+  int64_t r0 = 0;
+  for (size_t j = 0; j < s->chunk_rows.size(); ++j) {
+    const int64_t r1 = s->chunk_rows[j];
+    if (r1 > r0) {
+      HIP_TRY(hipEventSynchronize(s->chunk_ev[j]));
+      for (int k = 0; k < n_slices; ++k) {
+        if (!len[k]) continue;
+        const size_t width = (size_t)len[k] * C * 8, spitch = (size_t)PR * C * 8;
+        const char *src = reinterpret_cast<const char *>(s->d_draws) + (size_t)r0 * spitch + (size_t)base[k] * C * 8;
+        char *dst = reinterpret_cast<char *>(out[k]) + (size_t)r0 * width;
+        if (len[k] == PR) HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(r1 - r0) * width, hipMemcpyDeviceToHost, s->copy_stream));
+        else HIP_TRY(hipMemcpy2DAsync(dst, width, src, spitch, width, (size_t)(r1 - r0), hipMemcpyDeviceToHost, s->copy_stream));
+      }
+      HIP_TRY(hipStreamSynchronize(s->copy_stream));
+    }
+    r0 = r1;
+  }
+  return finish_timing(s);
+}
+
+int amwg_fetch_draws(amwg_sampler *s, double *out, size_t out_bytes) {
+  if (!s) return fail(AMWG_EINVAL, "amwg_fetch_draws: null sampler");
+  const int32_t base = 0, len = s->P + s->D;
+  return amwg_fetch_draws_slices(s, 1, &base, &len, &out, &out_bytes);
 }
 
 int amwg_sample(amwg_sampler *s, int64_t n, int64_t thin, double *out, size_t out_bytes) {

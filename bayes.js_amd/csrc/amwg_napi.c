@@ -367,6 +367,43 @@ static napi_value FetchDraws(napi_env env, napi_callback_info info) {
   return rc == AMWG_OK ? out : throw_amwg(env, rc);
 }
 
+/* fetchDrawsSplit(handle, rows, bases, lens) -> [Float64Array [rows][lens[k]][chains], ...]: the draws as sampler.sample() returns them, one
+ * array per monitored parameter (mcmc.js:1009-1029), straight from the device into those arrays (amwg_fetch_draws_slices) */
+static napi_value FetchDrawsSplit(napi_env env, napi_callback_info info) {
+  napi_value a[4];
+  if (!get_args(env, info, 4, a)) return NULL;
+  amwg_sampler *s = unwrap(env, a[0]);
+  if (!s) return NULL;
+  const int64_t rows = arg_i64(env, a[1]);
+  uint32_t n = 0, n2 = 0;
+  if (napi_get_array_length(env, a[2], &n) != napi_ok || napi_get_array_length(env, a[3], &n2) != napi_ok || n != n2 || rows < 0) {
+    napi_throw_type_error(env, NULL, "amwg_napi.fetchDrawsSplit: (handle, rows, bases[], lens[]) expected");
+    return NULL;
+  }
+  int32_t *base = (int32_t *)calloc(n ? n : 1, sizeof(int32_t)), *len = (int32_t *)calloc(n ? n : 1, sizeof(int32_t));
+  double **out = (double **)calloc(n ? n : 1, sizeof(double *));
+  size_t *bytes = (size_t *)calloc(n ? n : 1, sizeof(size_t));
+  napi_value result = NULL;
+  int ok = base && len && out && bytes && napi_create_array_with_length(env, n, &result) == napi_ok;
+  const size_t C = (size_t)amwg_num_chains(s);
+  for (uint32_t k = 0; ok && k < n; k++) {
+    napi_value e;
+    napi_get_element(env, a[2], k, &e); base[k] = (int32_t)arg_i64(env, e);
+    napi_get_element(env, a[3], k, &e); len[k] = (int32_t)arg_i64(env, e);
+    if (len[k] < 0) { ok = 0; break; }
+    const size_t cnt = (size_t)rows * (size_t)len[k] * C;
+    napi_value arr = new_f64(env, cnt, &out[k]);
+    if (!arr) { ok = 0; break; }
+    bytes[k] = cnt * 8;
+    napi_set_element(env, result, k, arr);
+  }
+  int rc = AMWG_OK;
+  if (ok) rc = amwg_fetch_draws_slices(s, (int32_t)n, base, len, out, bytes);
+  free(base); free(len); free(out); free(bytes);
+  if (!ok) { napi_throw_error(env, NULL, "amwg_napi: cannot allocate the draws arrays"); return NULL; }
+  return rc == AMWG_OK ? result : throw_amwg(env, rc);
+}
+
 /* sample(handle, n, thin) -> Float64Array [ceil(n/thin)][P][chains] */
 static napi_value Sample(napi_env env, napi_callback_info info) {
   napi_value a[3];
@@ -694,7 +731,7 @@ static napi_value Uniform(napi_env env, napi_callback_info info) {
 static napi_value Init(napi_env env, napi_value exports) {
   static const struct { const char *name; napi_callback fn; } fns[] = {
       {"create", Create}, {"createUser", CreateUser}, {"compileUser", CompileUser}, {"destroy", Destroy}, {"burn", Burn}, {"burnAsync", BurnAsync}, {"sync", Sync},
-      {"sample", Sample}, {"sampleAsync", SampleAsync}, {"fetchDraws", FetchDraws}, {"setAdapting", SetAdapting},
+      {"sample", Sample}, {"sampleAsync", SampleAsync}, {"fetchDraws", FetchDraws}, {"fetchDrawsSplit", FetchDrawsSplit}, {"setAdapting", SetAdapting},
       {"getState", GetState}, {"setState", SetState}, {"convergence", Convergence}, {"quantiles", Quantiles}, {"groupMoments", GroupMoments}, {"groupConvergence", GroupConvergence}, {"groupQuantiles", GroupQuantiles}, {"info", Info}, {"diag", Diag}, {"moments", Moments}, {"launchInfo", LaunchInfo}, {"codeCacheStats", CodeCacheStats},
       {"version", Version}, {"mathExp", MathExp}, {"mathLog", MathLog}, {"uniform", Uniform}};
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

@@ -50,6 +50,11 @@ struct amwg_sampler {
   size_t d_draws_cap = 0;
   const double *last_draws = nullptr;  // device pointer (library- or caller-owned) of the last sample call
   int64_t last_rows = 0;
+  // rows of the last sample call become final launch by launch: an event after each launch and the row count up to it, so that
+  // amwg_fetch_draws* copies the rows of launch j on copy_stream while launches j + 1, ... still run
+  std::vector<hipEvent_t> chunk_ev;
+  std::vector<int64_t> chunk_rows;     // cumulative rows after launch j of the last sample call
+  hipStream_t copy_stream = nullptr;
 };
 
 // shared helper: records an error message for amwg_last_error() and returns `code`

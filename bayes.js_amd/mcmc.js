@@ -289,11 +289,27 @@ AmwgSampler.prototype.sample = function (n_iterations) {
   const N = native(), thin = this.thinning_interval;
   const kept = Math.ceil(n_iterations / thin);
   this._each((sh) => N.sampleAsync(sh.handle, n_iterations, thin));
-  const flat = this._merge(this._each((sh) => N.fetchDraws(sh.handle, kept)), kept * this.PR);   // [kept][P + derived][chains]
   // mcmc.js:1009-1013: by default every key of the state is recorded, parameters first, then derived quantities
   const monitored = this.monitored_params === null ? this.param_names.concat(this.derived) : this.monitored_params;
   const C = this.chains, P = this.PR, out = {};
   const derivedLayout = this.derived.map((name, q) => ({ name, base: this.P + q, len: 1, dim: [1], scalar: true }));
+  if (C > 1 && this._shards.length === 1) {
+    // many chains on one device: every monitored parameter's [kept][len][chains] array is filled straight from the device, launch by
+    // launch while the later launches still run (amwg_fetch_draws_slices) -- no [kept][P][chains] intermediate, no second copy in JavaScript
+    const found = monitored.map((name) => this._layout.find((l) => l.name === name) || derivedLayout.find((l) => l.name === name));
+    const use = found.filter((L) => L);
+    const arrays = N.fetchDrawsSplit(this._shards[0].handle, kept, use.map((L) => L.base), use.map((L) => L.len));
+    let k = 0;
+    monitored.forEach((name, m) => {
+      const L = found[m];
+      if (!L) { out[name] = []; return; }
+      const arr = arrays[k++];
+      Object.defineProperty(arr, 'layout', { value: { kept, len: L.len, chains: C, dim: L.dim }, enumerable: false });
+      out[name] = arr;
+    });
+    return out;
+  }
+  const flat = this._merge(this._each((sh) => N.fetchDraws(sh.handle, kept)), kept * this.PR);   // [kept][P + derived][chains]
   for (const name of monitored) {
     const L = this._layout.find((l) => l.name === name) || derivedLayout.find((l) => l.name === name);
     if (!L) { out[name] = []; continue; }

@@ -136,6 +136,27 @@ def test_sharding_chunking_and_division_mode_do_not_change_results():
     np.testing.assert_allclose(sd, flat.std(axis=1, ddof=1), rtol=1e-10)
 
 
+def test_draws_fetched_by_slices_launch_by_launch_equal_the_whole_array():
+    """amwg_fetch_draws_slices (what sampler.sample() of the JavaScript host is built on): one [kept][len][chains] array per requested
+    range of recorded values, copied launch by launch while later launches run -- equal to the [kept][P][chains] array of amwg_sample
+    on a twin sampler; ranges may overlap, be empty, or cover everything; a range outside the recorded values is refused."""
+    data = model_spec.make_data("hier_normal", 600, 9, G=32)
+    spec = model_spec.build_spec("hier_normal", data)
+    kw = dict(seed=21, chains=96, lanes_per_chain=8, steps_per_launch=7)
+    a, b = A.Sampler(spec, **kw), A.Sampler(spec, **kw)
+    a.burn(30); b.burn(30)
+    whole = a.sample(45, 2)                                   # 23 kept draws over 7 launches
+    b.sample_async(45, 2)
+    P = spec["P"]
+    parts = b.fetch_draws_slices([(0, 1), (1, 1), (2, P - 2), (0, P), (5, 0), (3, 4)])
+    for (base, ln), got in zip([(0, 1), (1, 1), (2, P - 2), (0, P), (5, 0), (3, 4)], parts):
+        assert got.shape == (23, ln, 96)
+        assert got.tobytes() == np.ascontiguousarray(whole[:, base:base + ln, :]).tobytes()
+    assert b.fetch_draws().tobytes() == whole.tobytes()      # and again, in one piece
+    with pytest.raises(A.AmwgError):
+        b.fetch_draws_slices([(P - 1, 2)])
+
+
 def test_edge_cases_empty_data_single_chain_thin_larger_than_n():
     spec = model_spec.build_spec("normal", {"x": np.zeros(0)})
     s = A.Sampler(spec, chains=1, seed=3)
