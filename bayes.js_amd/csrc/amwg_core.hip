@@ -255,7 +255,14 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
   if (rx.push) rx.push(d_draws ? "amwg_sample" : "amwg_burn");
   struct PopOnExit { Roctx &r; ~PopOnExit() { if (r.pop) r.pop(); } } pop_on_exit{rx};
   // a launch counts its accepted / evaluated proposals in 16-bit fields (amwg_kernel.h, TOTme): at most 65535 steps per launch
-  const int64_t chunk = (s->opt.steps_per_launch > 0 && s->opt.steps_per_launch < 65535) ? s->opt.steps_per_launch : 65535;
+  int64_t chunk = (s->opt.steps_per_launch > 0 && s->opt.steps_per_launch < 65535) ? s->opt.steps_per_launch : 65535;
+  if (d_draws && d_draws == s->d_draws && s->opt.steps_per_launch <= 0) {
+    // draws that will be fetched (amwg_sample / amwg_sample_async): launches of ~32 MB of recorded rows each, so that the rows of one launch
+    // leave the device while the next launches run (amwg_fetch_draws_slices); results do not depend on how a call is cut into launches
+    const double per_step = (double)(s->P + s->D) * (double)s->C * 8.0 / (double)thin;
+    const double steps = 33554432.0 / (per_step > 0 ? per_step : 1.0);
+    if (steps < (double)chunk) chunk = steps < 16.0 ? 16 : (int64_t)steps;
+  }
   StepArgs a{};
   a.C = s->C;
   a.seed = s->opt.seed;
