@@ -134,6 +134,18 @@ template <class T> AMWG_HD double ld_bern_inv01(T x, const BernInv &k) { return 
 // ld.pois / ld.binom whose data-only part (lfactorial(x) resp. lchoose(size, x), distributions.js:79-86)
 // was evaluated once per observation on the host by the same formula
 AMWG_HD double ld_pois_pre(double x, double lambda, double lfact_x) { return x < 0 ? -kInf : log_v8(lambda) * x - lambda - lfact_x; }
+// the same under a log link written in place -- ld.pois(y[i], Math.exp(eta)): exp and the log of its value share their argument reduction
+// (amwg_math.h exp_log_v8: same bits as log_v8(exp_v8(eta)))
+AMWG_HD double ld_pois_pre_exp(double x, double eta, double lfact_x) {
+  double lambda;
+  const double lg = exp_log_v8(eta, lambda, ExpLogLiterals{});
+  return x < 0 ? -kInf : lg * x - lambda - lfact_x;
+}
+AMWG_HD double ld_pois_exp(double x, double eta) {
+  double lambda;
+  const double lg = exp_log_v8(eta, lambda, ExpLogLiterals{});
+  return x < 0 ? -kInf : lg * x - lambda - lfactorial_js(x);
+}
 AMWG_HD double ld_binom_pre(double x, double size, double prob, double lchoose_size_x) {
   if (x > size || x < 0) return -kInf;
   if (prob == 0 || prob == 1) return (size * prob) == x ? 0.0 : -kInf;

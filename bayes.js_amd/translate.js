@@ -735,7 +735,9 @@ Translator.prototype.callInner = function (e) {
     if (HEAVY.has(M[0]) && this.loops.length) this.heavyLoop = true;
     if ((f.name === 'floor' || f.name === 'ceil' || f.name === 'round' || f.name === 'trunc' || f.name === 'abs') && args[0].int)
       return f.name === 'abs' ? num('(' + args[0].code + ' < 0 ? -(' + args[0].code + ') : ' + args[0].code + ')', true, undefined, '__builtin_fabs(' + args[0].dcode + ')') : args[0];
-    return num(M[0] + '(' + this.asD(args[0]) + ')', false);
+    const r = num(M[0] + '(' + this.asD(args[0]) + ')', false);
+    if (f.name === 'exp') r.expOf = this.asD(args[0]);      // (ld.pois(x, Math.exp(eta)) fuses the two, see below)
+    return r;
   }
   if (f.ns === 'ld' && (f.name === 'dirichlet' || f.name === 'cat' || f.name === 'bivarnorm')) return this.arrayDensity(f.name, args);
   if (f.ns === 'ld') {
@@ -759,8 +761,10 @@ Translator.prototype.callInner = function (e) {
     if (f.name === 'pois' && args[0].src && this.loops.length) {      // lfactorial(x_i) depends on the data only: once, on the host
       const aux = this.auxArray('lfactorial', [args[0].src.id], (x) => ld_host.lfactorial(x));
       this.heavyLoop = true;
+      if (args[1].expOf) return num('ld_pois_pre_exp(' + a[0] + ', ' + args[1].expOf + ', A' + aux + '[' + args[0].src.off + '])', false);
       return num('ld_pois_pre(' + a[0] + ', ' + a[1] + ', A' + aux + '[' + args[0].src.off + '])', false);
     }
+    if (f.name === 'pois' && args[1].expOf) { if (this.loops.length) this.heavyLoop = true; return num('ld_pois_exp(' + a[0] + ', ' + args[1].expOf + ')', false); }
     if (f.name === 'binom' && args[0].src && args[1].src && args[0].src.off === args[1].src.off && this.loops.length &&
         this.arrays[args[0].src.id].flat.length === this.arrays[args[1].src.id].flat.length) {
       const aux = this.auxArray('lchoose', [args[1].src.id, args[0].src.id], (size, x) => ld_host.lchoose(size, x));
