@@ -464,7 +464,7 @@ static int check_options(const amwg_options *options, int max_threads) {
   // a launch counts its accepted / evaluated proposals in 16-bit fields: longer launches are not silently shortened (launch_info and the
   // bench's per-launch figures assume the requested size)
   if (options->steps_per_launch < 0 || options->steps_per_launch > 65535)
-    return fail(AMWG_EINVAL, "steps_per_launch must be 0 (auto: one launch per call, chunked at 65535 steps) or 1..65535, got %d", options->steps_per_launch);
+    return fail(AMWG_EINVAL, "steps_per_launch must be 0 (auto) or 1..65535, got %d", options->steps_per_launch);
   const int G_opt = options->lanes_per_chain;
   if (G_opt && G_opt != AMWG_LANES_FASTEST && G_opt != AMWG_LANES_AUTOTUNE && (G_opt < 1 || G_opt > 1024 || (G_opt & (G_opt - 1))))
     return fail(AMWG_EINVAL, "lanes_per_chain must be a power of two in 1..1024 (or 0 = auto, AMWG_LANES_FASTEST = -1, AMWG_LANES_AUTOTUNE = -2)");

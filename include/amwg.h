@@ -109,7 +109,8 @@ typedef struct {
                                   one lane per chain whenever it measures within 12 % of the fastest.  The pick may differ between machines,
                                   and with it the summation order (decisions stay the reference's); amwg_tuning reports the timings */
   int32_t block_threads;   /* 0 = auto; else multiple of 64, <= 1024 */
-  int32_t steps_per_launch;/* 0 = auto (one launch per burn/sample call up to 65535 steps) */
+  int32_t steps_per_launch;/* 0 = auto: one launch per burn call (up to 65535 steps); a sample call that will be fetched is cut into launches of ~32 MB
+                            * of recorded rows, so that the rows of one launch are copied out while the next ones run.  Results never depend on it. */
   int32_t exact_division;  /* 0 = default: result-preserving shortcuts (hoisted-reciprocal division, fast-forward of two-valued sums), bit-identical
                               to the plain schedule and tested against it; 1 = the reference's operation schedule: IEEE '/', term-by-term sums */
   int32_t group_local;     /* 0 = default.  1 = GROUP-LOCAL evaluation of the hierarchical family (AMWG_MODEL_HIER_NORMAL with labels g_i = i mod G, G a

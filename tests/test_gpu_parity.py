@@ -155,6 +155,13 @@ def test_draws_fetched_by_slices_launch_by_launch_equal_the_whole_array():
     assert b.fetch_draws().tobytes() == whole.tobytes()      # and again, in one piece
     with pytest.raises(A.AmwgError):
         b.fetch_draws_slices([(P - 1, 2)])
+    # steps_per_launch = 0: a sample call into the library's buffer is cut into launches of ~32 MB of rows by itself (here 512 steps each)
+    spec2 = model_spec.build_spec("normal", model_spec.make_data("normal", 50, 3))
+    auto, one = A.Sampler(spec2, chains=4096, seed=5, lanes_per_chain=1), A.Sampler(spec2, chains=4096, seed=5, lanes_per_chain=1, steps_per_launch=65535)
+    auto.burn(20); one.burn(20)
+    got, want = auto.sample(1200), one.sample(1200)
+    assert auto.launch_info()["n_launches"] == 3 and one.launch_info()["n_launches"] == 1
+    assert got.tobytes() == want.tobytes()
 
 
 def test_edge_cases_empty_data_single_chain_thin_larger_than_n():
