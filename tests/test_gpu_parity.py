@@ -153,6 +153,8 @@ def test_draws_fetched_by_slices_launch_by_launch_equal_the_whole_array():
         assert got.shape == (23, ln, 96)
         assert got.tobytes() == np.ascontiguousarray(whole[:, base:base + ln, :]).tobytes()
     assert b.fetch_draws().tobytes() == whole.tobytes()      # and again, in one piece
+    b.burn(3)                                                 # launches in between do not invalidate the buffer
+    assert b.fetch_draws().tobytes() == whole.tobytes()
     with pytest.raises(A.AmwgError):
         b.fetch_draws_slices([(P - 1, 2)])
     # steps_per_launch = 0: a sample call into the library's buffer is cut into launches of ~32 MB of rows by itself (here 512 steps each)
