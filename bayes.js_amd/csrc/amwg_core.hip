@@ -297,8 +297,12 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
     }
     s->lp_ready = true;
     s->n_launches++;
-    if (d_draws) {
-      row += (m > a.step0) ? (m - a.step0 + thin - 1) / thin : 0;
+    if (d_draws) row += (m > a.step0) ? (m - a.step0 + thin - 1) / thin : 0;
+    // a mark for amwg_fetch_draws*: only for the library's own buffer, and only once >= 8 MB of new rows (or the end of the call) stand
+    // behind it -- a caller who asks for one-step launches gets a handful of events, not one per launch
+    const int64_t marked = s->chunk_rows.empty() ? 0 : s->chunk_rows.back();
+    if (d_draws && d_draws == s->d_draws && row > marked &&
+        (done + m >= n || (double)(row - marked) * (double)(s->P + s->D) * (double)s->C * 8.0 >= 8388608.0)) {
       const size_t j = s->chunk_rows.size();
       if (j >= s->chunk_ev.size()) {
         hipEvent_t e = nullptr;
