@@ -107,6 +107,26 @@ def test_many_chains_auto_geometry_vs_oracle(model, n_obs, G):
     s.close()
 
 
+@pytest.mark.parametrize("n_obs,lanes", [(1, 1), (3, 4), (63, 64), (64, 64), (65, 64), (255, 64), (256, 64), (257, 64), (300, 16), (449, 64), (1023, 256), (130, 128)])
+def test_poisson_pass_edges_vs_oracle(n_obs, lanes):
+    """The Poisson pass (pairs of rounds through the fused exp/log, the change point resolved per round, a predicated tail): fewer
+    observations than lanes, exactly one / two / four rounds, one more and one less, a chain on two and four wavefronts -- chains whose
+    change point wanders over the whole range (the wave-uniform 'nobody / everybody adds' rounds and the comparing ones all occur), bit-equal
+    to the oracle in the same lane order."""
+    data = model_spec.make_data("pois_glm", n_obs, 7 + n_obs, exp=oracle_lib.lib().orc_exp)
+    spec = model_spec.build_spec("pois_glm", data)
+    s = A.Sampler(spec, chains=6, seed=31, chain_offset=5, lanes_per_chain=lanes)
+    assert s.launch_info()["lanes_per_chain"] == lanes
+    sched = [{"op": "burn", "n": 60}, {"op": "sample", "n": 40, "thin": 2}]
+    gs = run_schedule(s, sched)
+    for local in (0, 5):
+        o = oracle_lib.OracleChain(spec, 31, 5 + local, lanes=lanes)
+        assert_chain_equals_oracle(s, local, o, gs, run_schedule(o, sched))
+    cp = gs[0][:, 8, :]
+    assert cp.min() >= 0 and cp.max() <= n_obs - 1
+    s.close()
+
+
 def test_sharding_chunking_and_division_mode_do_not_change_results():
     data = model_spec.make_data("normal", 500, 5)
     spec = model_spec.build_spec("normal", data)
