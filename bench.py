@@ -96,7 +96,7 @@ def other_spec(name, exp):
     return model_spec.build_spec(fam, model_spec.make_data(fam, n_obs, DATA_SEED, G=32, exp=exp))
 
 
-def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None):
+def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None, group_local=False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_summary.json, written by
     tools/profile.sh + tools/summarize_profile.py for this same command); None if no matching profile."""
     import glob
@@ -105,7 +105,7 @@ def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None):
             p = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if p.get("workload", "cfg2") != workload:
+        if p.get("workload", "cfg2") != workload or ("--group-local" in p.get("command", "")) != bool(group_local):
             continue
         if lanes is not None and not re.search(r",\s*%d(,\s*\d+)?>" % lanes, p.get("kernel", "")):      # the profile must be of the same kernel instantiation (Model, lanes[, workgroup class])
             continue
@@ -571,7 +571,7 @@ def main():
         assert dist is not None or np.allclose(pm, mean, rtol=1e-10, atol=0), "library moments differ from the pooled restatement"
         measured_peak = A.fp64_peak(dev_index)      # register-only fma kernel: what the chip sustains under fp64 load
         x = spec["data"]["x"]
-        traffic, traffic_src, traffic_alg = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"])
+        traffic, traffic_src, traffic_alg = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"], args.group_local)
         kname = {"normal": "NormalModel", "beta_bern": "BetaBernModel", "hier_normal": "HierNormalModel", "pois_glm": "PoisGlmModel"}[spec["model"]]
         bt_class = 256 if li["block_threads"] <= 256 else (512 if li["block_threads"] <= 512 else 1024)
         kernel = "amwg_step_kernel<%s,%d,%d>" % (kname, li["lanes_per_chain"], bt_class)
