@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/amwg.h"
+#include "amwg_build_id.h"
 #if defined(AMWG_SELFTEST)
 #include "../../include/amwg_selftest.h"
 #endif
@@ -394,7 +395,8 @@ int amwg_fail(int code, const char *fmt, ...) {
 extern "C" {
 
 const char *amwg_last_error(void) { return g_err.c_str(); }
-const char *amwg_version(void) { return "amwg-mi355x 0.1 (gfx950)"; }
+// which sources this binary was built from (tools/build_id.py: a hash over every source of the library, and one over the device sources + compiler flags)
+const char *amwg_version(void) { return "amwg-mi355x 0.4 (gfx950) build " AMWG_BUILD_ID " kernels " AMWG_KERNEL_ID; }
 
 double amwg_exp(double x) { return exp_v8(x); }
 double amwg_log(double x) { return log_v8(x); }

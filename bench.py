@@ -35,7 +35,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes.js_amd"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes.js_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
 
 import numpy as np  # noqa: E402
 
@@ -46,6 +46,24 @@ DATA_SEED = 20260925
 B_ALG_PER_UPDATE = N_OBS * 8 + 8 * 2 + 8     # 80 024 B: data once + state read + draw write
 HBM_PEAK_GBPS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK = 78.6e12 / 2                 # lane-FMA/s: 256 CU * 4 SIMD * 16 lanes/clk * 2.4 GHz
+FP64_FLOPS_PEAK = 78.6e12                    # the same peak in SURVEY.md section 8(d)'s unit (an FMA = 2 flop)
+# SURVEY.md section 8(d), "Algorithmic flops (secondary)": ld.norm's term as the reference writes it is ~5 fp64 flops per observation INCLUDING
+# one division (sub, mul, div, sub, add).  gfx950 has no fp64 divide instruction: the correctly rounded quotient is 4 issued operations
+# (amwg_div.h: mul + 3 fma; IEEE '/' expands to 11), which is why the issue-based figure counts 8 per observation.  Both are printed.
+SURVEY_FLOPS_PER_OBS = {"normal": 5, "hier_normal": 5}
+
+
+def roofline_units(fam, lane_ops_per_s, ops_per_obs):
+    """frac_issue: issued-operation view (what the VALU has to execute, the roof the kernel runs against); frac_survey_flops: the same run in
+    SURVEY.md section 8(d)'s flop count (a division = one flop) against the 78.6 TFLOP/s datasheet figure (an FMA = two flops)."""
+    out = {"frac_issue": lane_ops_per_s / FP64_VALU_PEAK}
+    f = SURVEY_FLOPS_PER_OBS.get(fam)
+    if f is not None:
+        out["frac_survey_flops"] = lane_ops_per_s / ops_per_obs * f / FP64_FLOPS_PEAK
+        out["survey_flops_note"] = ("SURVEY.md section 8(d) counts ~%d flops per observation incl. ONE division; against 78.6 TFLOP/s (FMA = 2 flops) the same run is frac_survey_flops. "
+                                    "frac (= frac_issue) counts the %d operations the VALU must issue per observation (the division alone is 4: no fp64 divide on gfx950) "
+                                    "against the 3.93e13 lane-operations/s the SIMDs can issue" % (f, ops_per_obs))
+    return out
 
 
 def normal_spec():
@@ -96,11 +114,20 @@ def other_spec(name, exp):
     return model_spec.build_spec(fam, model_spec.make_data(fam, n_obs, DATA_SEED, G=32, exp=exp))
 
 
-def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None, group_local=False):
+def kernel_id_of(version):
+    m = re.search(r"kernels ([0-9a-f]{12})", version or "")
+    return m.group(1) if m else None
+
+
+def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None, group_local=False, kernel_id=None):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_summary.json, written by
-    tools/profile.sh + tools/summarize_profile.py for this same command); None if no matching profile."""
+    tools/profile.sh + tools/summarize_profile.py for this same command).  PMC counters need rocprofv3 around the process, so the figure
+    cannot be taken inside this run; what ties it to the run is the KERNEL ID (tools/build_id.py: a hash of the device sources + compiler
+    flags, carried by amwg_version() and stored with every profile): a profile of other kernel sources is refused.
+    -> (bytes, file, algorithmic bytes of that launch, why-not)"""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+    stale = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), key=os.path.getmtime, reverse=True):
         try:
             p = json.load(open(f))
         except (OSError, ValueError):
@@ -110,8 +137,11 @@ def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None, grou
         if lanes is not None and not re.search(r",\s*%d(,\s*\d+)?>" % lanes, p.get("kernel", "")):      # the profile must be of the same kernel instantiation (Model, lanes[, workgroup class])
             continue
         if p.get("chains") == chains and p.get("steps_per_launch") == steps_per_launch and p.get("hbm_traffic_bytes_per_launch"):
-            return p["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT), p.get("algorithmic_bytes_per_launch")
-    return None, None, None
+            if kernel_id is not None and p.get("kernel_id") != kernel_id:
+                stale = stale or "%s is of kernels %s, this library is kernels %s: refused" % (os.path.relpath(f, ROOT), p.get("kernel_id", "(no id: profiled before round 4)"), kernel_id)
+                continue
+            return p["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT), p.get("algorithmic_bytes_per_launch"), None
+    return None, None, None, stale or "no profile of this workload / geometry under profiles/"
 
 
 def end_to_end_js(chains, n_obs):
@@ -239,6 +269,25 @@ def cpu_baseline_all_cores(spec, single_rate, budget_s=2.0, max_threads=32):
 GOLDEN_OF = {"cfg2": "cfg2_full", "cfg3": "cfg3_full", "cfg4": "cfg4_full", "cfg5": "cfg5_full"}
 
 
+def flip_rate_record():
+    """The decision-parity campaign (tools/flip_rate.py, committed under profiles/): how many chains of a seeded job ever decide differently at 64
+    lanes / group-local than with one lane per chain (the reference's summation order), over 1e9+ decisions."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_flip_rate.json")), key=os.path.getmtime)
+    if not fs:
+        return None
+    try:
+        r = json.load(open(fs[-1]))
+    except (OSError, ValueError):
+        return None
+    return {"source": os.path.relpath(fs[-1], ROOT), "decisions_total": r["decisions_total"], "first_flips_total": r["first_flips_total"],
+            "flips_per_1e9": r["flips_per_1e9"], "upper_95_per_1e9": r["upper_95_per_1e9"], "library_version_of_campaign": r.get("version"),
+            "per_run": [{"workload": q["workload"], "geometry": q["geometry"], "chains": q["chains"], "steps": q["steps"], "decisions": q["decisions"],
+                         "chains_differing": q["chains_differing"], "lp_abs_diff_max": q["lp_abs_diff_max"], "expected_flips_bound": q["expected_flips_bound"]} for q in r["runs"]],
+            "note": "one lane per chain IS the reference's order (bit-identical draws); at more lanes a decision can differ only when the accept uniform falls "
+                    "inside the ~1e-12-relative sliver between the two summation orders' exp(delta): counted here, chain by chain"}
+
+
 def golden_schedule_check(s, gold, locals_and_records, lanes):
     """Runs the golden case's schedule ON THE GIVEN (full-size) SAMPLER -- device-resident draws -- and compares the listed local chains with
     the seeded run of the unmodified reference stored in tests/golden/<case>.json: accept counts, in-bounds counts, adaptation state and
@@ -351,7 +400,7 @@ def measure_other_config(A, name, device, group_local=0):
         # group-local evaluation: a step of the P = G + 2 updates makes TWO passes over the data (the sweep over theta and the sigma update)
         # instead of P; the fp64 work per update is what those two passes do, not one pass per update
         lane_ops = roof_updates_per_s * (2.0 / P) * n_obs * ops_per_obs
-        label += " -- GROUP-LOCAL evaluation (amwg_options::group_local, opt-in: not the reference's operation schedule; decisions identical)"
+        label += " -- GROUP-LOCAL evaluation (amwg_options::group_local, opt-in: not the reference's operation schedule; decisions identical on every golden and over the flip-rate campaign, see parity.flip_rate)"
         out["workload"] = label
         note = ("group-local: the %d proposals for theta of a step are evaluated in one pass (every lane with the proposed mean of its own group) and decided on "
                 "their local differences, mu needs no pass, sigma one: 2 passes per step instead of %d (mcmc.js:524-526 makes 2 per update).  roofline = "
@@ -359,6 +408,7 @@ def measure_other_config(A, name, device, group_local=0):
     out["roofline"] = {"bound": "fp64_valu", "achieved": lane_ops, "peak": FP64_VALU_PEAK, "frac": lane_ops / FP64_VALU_PEAK, "unit": "fp64 lane-operations/s",
                        "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[fam], "kernel": kernel, "note": note,
                        "effective_hbm_gbps": value * b_alg / 1e9}
+    out["roofline"].update(roofline_units(fam, lane_ops, ops_per_obs))
     out["seconds"] = time.perf_counter() - t0
     s.close()
     return out
@@ -440,7 +490,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=1000)
-    ap.add_argument("--thin", type=int, default=10, help="record every thin-th draw inside the timed region")
+    ap.add_argument("--thin", type=int, default=1, help="record every thin-th draw inside the timed region (default 1: SURVEY.md section 8(d) recipe, `sample 1000 (thin 1)`)")
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--block", type=int, default=0)
@@ -571,7 +621,8 @@ def main():
         assert dist is not None or np.allclose(pm, mean, rtol=1e-10, atol=0), "library moments differ from the pooled restatement"
         measured_peak = A.fp64_peak(dev_index)      # register-only fma kernel: what the chip sustains under fp64 load
         x = spec["data"]["x"]
-        traffic, traffic_src, traffic_alg = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"], args.group_local)
+        version = A.lib().amwg_version().decode()
+        traffic, traffic_src, traffic_alg, traffic_why_not = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"], args.group_local, kernel_id_of(version))
         kname = {"normal": "NormalModel", "beta_bern": "BetaBernModel", "hier_normal": "HierNormalModel", "pois_glm": "PoisGlmModel"}[spec["model"]]
         bt_class = 256 if li["block_threads"] <= 256 else (512 if li["block_threads"] <= 512 else 1024)
         kernel = "amwg_step_kernel<%s,%d,%d>" % (kname, li["lanes_per_chain"], bt_class)
@@ -611,7 +662,7 @@ def main():
                          "measured_peak_note": "amwg_fp64_peak: independent v_fma_f64 chains, no memory traffic, same process",
                          "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[spec["model"]],
                          "kernel": kernel, "launch_ms": roof_launch_s * 1e3, "updates_per_launch": roof_updates,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_refused": traffic_why_not if traffic is None else None,
                          "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 --pmc passes",
                          "algorithmic_bytes_per_launch": updates_per_launch * b_alg, "algorithmic_bytes_per_update": b_alg,
                          "traffic_ratio": (traffic / traffic_alg) if (traffic and traffic_alg) else None,
@@ -625,8 +676,16 @@ def main():
             "posterior": {"mean": mean.tolist()[:8], "sd": sd.tolist()[:8], "data_mean": float(np.mean(x)), "data_sd": float(np.std(x, ddof=1)),
                           "note": "moments over the recorded draws of the last region on ALL ranks (all-reduce of per-rank sums for N > 1; after %d warm-up + %d timed steps)" % (W, K * (len(regions) - 1))},
         }
+        out["roofline"].update(roofline_units(spec["model"], lane_ops, ops_per_obs))
+        import build_id
+        out["library"] = {"version": version, "built_from_this_tree": ("build " + build_id.build_id()) in version and ("kernels " + build_id.kernel_id()) in version,
+                          "note": "amwg_version(): a hash over every source of libamwg.so and one over the device sources + compiler flags (tools/build_id.py); "
+                                  "built_from_this_tree compares them with the sources beside this bench.py"}
         if parity is not None:
             out["parity"] = parity
+            fr = flip_rate_record()
+            if fr is not None:
+                out["parity"]["flip_rate"] = fr
         if world == 1 and args.workload == "cfg2" and not args.no_other_configs:
             out["other_configs"] = {}
             for name in ("cfg3", "cfg4", "cfg5", "cfg4_group_local"):

@@ -48,7 +48,7 @@ const CASES = [
   { name: 'glm_small', model: 'pois_glm', N: 500, data_seed: DSEED, store_data: true,
     seed: SEED, chains: [0, 1], schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }] },
   { name: 'cfg5_full', model: 'pois_glm', N: 50000, data_seed: DSEED,
-    seed: SEED, chains: [0], schedule: [{ op: 'burn', n: 30 }, { op: 'sample', n: 30, keep: 10 }] },
+    seed: SEED, chains: [0, 65535], schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 10 }] },
 ];
 
 function checksum(data) { // order-sensitive sum so the Python twin of synth.js can be checked at full N

@@ -1,0 +1,68 @@
+"""How often does a summation order other than the reference's change an accept decision?  (test helper; GPU only)
+
+With one lane per chain the kernel adds the observations' terms in the reference's order and every double is the reference's (the goldens,
+the live-reference test).  With G lanes per chain -- and in the opt-in group-local mode -- log_post differs from the reference's value by a
+few ulps (~1e-12 relative), so `Math.exp(prop - curr) > Math.random()` (mcmc.js:527-528) decides differently only when the uniform falls
+inside that sliver around exp(delta).  A flipped decision changes the chain's state, hence everything after it: a chain whose final state,
+accept / in-bounds counts and uniform count all equal those of the SAME chain id run with one lane per chain had no flipped decision.
+
+compare() runs the same seeded job in two geometries on the device and counts the chains that differ:
+    decisions        in-bounds proposals evaluated (= accept tests performed) by the one-lane run, all chains
+    chains_differing chains for which anything differs at the end
+    first_flips      = chains_differing (every differing chain had at least one flip; after its first flip a chain is a different run, so its
+                       later decisions are not comparisons of the same proposal any more)
+    flips_per_1e9    first_flips / decisions_until_flip * 1e9, where the decisions of a differing chain are counted in full (a lower bound
+                       on the denominator would only raise the rate by chains_differing / chains)
+    lp_abs_diff      |log_post_G - log_post_1| over the agreeing chains at the end of the run (max, mean): the size of the sliver.  Since
+                       |exp(a) - exp(b)| <= |a - b| for a, b <= 0, the probability that one decision flips is at most 2 x (that difference),
+                       which is the analytic expectation the measured count is compared with.
+"""
+import numpy as np
+
+
+def compare(A, spec, chains, steps, seed, alt, ref=None, steps_per_launch=0):
+    ref = dict(ref or {"lanes_per_chain": 1})
+    a = A.Sampler(spec, chains=chains, seed=seed, steps_per_launch=steps_per_launch, **ref)
+    b = A.Sampler(spec, chains=chains, seed=seed, steps_per_launch=steps_per_launch, **alt)
+    la, lb = a.launch_info(), b.launch_info()
+    a.burn_async(steps)
+    b.burn_async(steps)
+    a.sync()
+    b.sync()
+    ia, ib, da, db = a.info(), b.info(), a.diag(), b.diag()
+    sa, sb = a.state(), b.state()
+    same = np.all(ia["accepts"] == ib["accepts"], axis=0) & np.all(ia["inbounds"] == ib["inbounds"], axis=0)
+    same &= da["uniforms"] == db["uniforms"]
+    same &= np.all(sa.view(np.uint64) == sb.view(np.uint64), axis=0)
+    same &= np.all(ia["prop_log_scale"].view(np.uint64) == ib["prop_log_scale"].view(np.uint64), axis=0)
+    decisions = int(ia["inbounds"].sum())
+    differing = int((~same).sum())
+    lpd = np.abs(da["log_post"][same] - db["log_post"][same])
+    lpd = lpd[np.isfinite(lpd)]
+    out = {"chains": chains, "steps": steps, "components": int(spec["P"]), "decisions": decisions, "chains_differing": differing,
+           "first_flips": differing, "flips_per_1e9": (differing / decisions * 1e9) if decisions else None,
+           "upper_95_per_1e9": ((3.0 if differing == 0 else differing + 2.0 * np.sqrt(differing) + 2.0) / decisions * 1e9) if decisions else None,
+           "reference_geometry": {"lanes_per_chain": la["lanes_per_chain"], "block_threads": la["block_threads"]},
+           "geometry": dict({"lanes_per_chain": lb["lanes_per_chain"], "block_threads": lb["block_threads"]}, **{k: v for k, v in alt.items() if k != "lanes_per_chain"}),
+           "lp_abs_diff_max": float(lpd.max()) if lpd.size else None, "lp_abs_diff_mean": float(lpd.mean()) if lpd.size else None,
+           "lp_abs_typical": float(np.median(np.abs(da["log_post"][same]))) if same.any() else None,
+           "expected_flips_bound": (2.0 * float(lpd.mean()) * decisions) if lpd.size else None,
+           "differing_chain_ids": np.nonzero(~same)[0][:16].tolist()}
+    a.close()
+    b.close()
+    return out
+
+
+WORKLOADS = {
+    # name: (family, n_obs, groups)
+    "hier_n640_g8": ("hier_normal", 640, 8),
+    "glm_n500": ("pois_glm", 500, 0),
+    "cfg4_size": ("hier_normal", 10_000, 32),
+    "normal_n1000": ("normal", 1_000, 0),
+}
+
+
+def spec_of(A, name, data_seed=20260925):
+    import model_spec
+    fam, n_obs, G = WORKLOADS[name]
+    return model_spec.build_spec(fam, model_spec.make_data(fam, n_obs, data_seed, G=G or 32, exp=A.lib().amwg_exp))

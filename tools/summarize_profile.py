@@ -61,7 +61,9 @@ units = bench["roofline"].get("updates_per_launch") or (bench["config"]["chains_
 if g("SQ_INSTS_VALU"):
     derived["valu_instructions_per_update_per_wave64"] = g("SQ_INSTS_VALU") / (units * bench["config"]["lanes_per_chain"] / 64.0)
     derived["valu_instructions_per_observation_lane"] = g("SQ_INSTS_VALU") * 64.0 / (units * bench["config"]["n_obs"])
-out = {"tag": tag, "workload": workload, "command": open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "python bench.py --no-cpu-baseline --steps 500 --warmup 1000 (100 steps per launch)",
+_ver = (bench.get("library") or {}).get("version", "")
+_kid = re.search(r"kernels ([0-9a-f]{12})", _ver)
+out = {"tag": tag, "workload": workload, "library_version": _ver, "kernel_id": _kid.group(1) if _kid else None, "command": open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "python bench.py --no-cpu-baseline --steps 500 --warmup 1000 (100 steps per launch)",
        "derived": derived,
        "kernel": step["Name"], "rocprof_calls": int(step["Calls"]), "rocprof_avg_launch_ms": float(step["AverageNs"]) / 1e6,
        "rocprof_min_launch_ms": step["MinNs"] / 1e6, "rocprof_max_launch_ms": step["MaxNs"] / 1e6,
