@@ -687,17 +687,27 @@ struct PoisGlmModel {
     const int n_mine = n_full + (sub < rem ? 1 : 0);           // this lane's observations: sub, sub + G, ...
     // first own round k with k*G + sub >= icp; over the wave: nobody adds before k_some, everybody from k_all on
     const int first = ps.icp <= sub ? 0 : (ps.icp - sub + (G - 1)) / G;
-    int lo = first, hi = first;
+    // Only a chain that IS the wave (G >= 64) can agree on these over the wave: with several chains per wavefront the lanes of a wave hold
+    // different change points AND run this pass under different execution masks (a chain whose proposal fell outside its bounds skips the
+    // evaluation), and a butterfly over a partly masked wave does not reach every lane -- the first active lane's maximum then missed other
+    // chains' later thresholds, which were told "everybody adds b[7] from here on" rounds too early.  (Found in round 4 by running the same
+    // seeded job with one and with 64 lanes per chain, tests/test_gpu_decision_parity.py: one chain in five differed after 1e4 steps; the
+    // goldens' handful of chains never met the case.)  Fewer lanes per chain: every round compares.
+    int k_some = 0, k_all = 0x7fffffff;
 #if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (G >= 64) {
+      int lo = first, hi = first;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const int l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
-      lo = l2 < lo ? l2 : lo;
-      hi = h2 > hi ? h2 : hi;
+      for (int o = 32; o > 0; o >>= 1) {
+        const int l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+      }
+      k_some = __builtin_amdgcn_readfirstlane(lo);
+      k_all = __builtin_amdgcn_readfirstlane(hi);
     }
-    const int k_some = __builtin_amdgcn_readfirstlane(lo), k_all = __builtin_amdgcn_readfirstlane(hi);
 #else
-    const int k_some = lo, k_all = hi;
+    k_some = first; k_all = first;
 #endif
     auto mode_of = [&](int k) { return k < k_some ? 0 : (k >= k_all ? 2 : 1); };
     Row a, b;

@@ -33,3 +33,14 @@ def test_decisions_at_many_lanes_equal_the_one_lane_run(workload, chains, steps,
     assert r["chains_differing"] <= allowed, r
     # the sliver itself: the two orders' log_post agree to ~1e-12 relative
     assert r["lp_abs_diff_max"] <= 1e-10 * max(1.0, r["lp_abs_typical"]), r
+
+
+@pytest.mark.parametrize("workload,chains,steps,lanes", [("glm_n500", 4096, 2_000, 4), ("glm_n500", 4096, 2_000, 16), ("hier_n640_g8", 4096, 3_000, 8), ("normal_n1000", 4096, 3_000, 2)])
+def test_chains_sharing_a_wavefront_decide_like_a_chain_on_a_whole_wavefront(workload, chains, steps, lanes):
+    """Several chains per wavefront (2 .. 32 lanes per chain) run their evaluations under DIFFERENT execution masks -- a chain whose proposal
+    fell outside its bounds skips log_post while its wave-mates evaluate -- which no test with a handful of chains exercises (round 4: the
+    Poisson pass agreed a per-wave shortcut through a butterfly over a partly masked wave and was wrong for one chain in five after 1e4
+    steps, see PoisGlmModel::pass).  Thousands of chains, compared with the same chain ids on whole wavefronts."""
+    r = dp.compare(A, dp.spec_of(A, workload), chains, steps, seed=20260925, alt={"lanes_per_chain": lanes}, ref={"lanes_per_chain": 64})
+    assert r["geometry"]["lanes_per_chain"] == lanes and r["reference_geometry"]["lanes_per_chain"] == 64
+    assert r["chains_differing"] <= math.ceil(BOUND_PER_1E9 * 1e-9 * r["decisions"]), r
