@@ -7,6 +7,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -43,6 +44,7 @@ step_kernel_t amwg_kernels_normal(int lanes, int block);
 step_kernel_t amwg_kernels_beta_bern(int lanes, int block);
 step_kernel_t amwg_kernels_hier_normal(int lanes, int block);
 step_kernel_t amwg_kernels_pois_glm(int lanes, int block);
+step_kernel_t amwg_kernel_hier_gl(int block);      // the group-local kernel of the hierarchical family (amwg_gl.h)
 
 namespace {
 
@@ -123,6 +125,70 @@ int dev_alloc(amwg_sampler *s, T **p, size_t n) {
   return AMWG_OK;
 }
 
+// Group-local evaluation (amwg_gl.h): deals the 64 lanes of a chain's wavefront to the groups and lays the observations out lane-major.
+//   * lanes: every group one lane to begin with (Gn <= 64); then, while lanes are left, the group with the most observations per lane
+//     (ceil(n_k / L_k); ties: the smaller index) has its lane count doubled -- it stops when that group cannot be doubled any more, since
+//     doubling others would not shorten the longest lane;
+//   * placement: blocks in order of decreasing size (ties: group index), so that every block of 2^j lanes starts at a multiple of 2^j;
+//   * observations: lane m of block k takes the group's observations (in index order) number m, m + L_k, m + 2 L_k, ...;
+//   * tile[r * 64 + lane] = the r-th observation of that lane, rows padded with 0 up to the longest lane.
+// Restated in oracle/amwg_oracle.c (gl_layout) -- the order of additions of the group-local mode follows from it.
+struct GlLayoutHost {
+  std::vector<double> tile;
+  GlLane lane[64];
+  int rounds = 0, n_min = 0;
+};
+int gl_layout(const double *y, const int32_t *g, int N, int Gn, GlLayoutHost *out) {
+  if (Gn < 1 || Gn > 64) return fail(AMWG_EINVAL, "group_local: 1 to 64 groups (a chain runs on one wavefront, a lane serves one group), got %d", Gn);
+  std::vector<int> n(Gn, 0), L(Gn, 1), first(Gn, 0);
+  for (int i = 0; i < N; ++i) {
+    if (g[i] < 0 || g[i] >= Gn) return fail(AMWG_EINVAL, "group_local: g[%d] = %d outside 0..%d", i, g[i], Gn - 1);
+    n[g[i]]++;
+  }
+  int total = Gn;
+  for (;;) {
+    int best = 0;
+    long load_best = -1;
+    for (int k = 0; k < Gn; ++k) { const long load = (n[k] + L[k] - 1) / L[k]; if (load > load_best) { load_best = load; best = k; } }
+    if (load_best <= 1 || total + L[best] > 64) break;
+    total += L[best];
+    L[best] *= 2;
+  }
+  std::vector<int> order(Gn);
+  for (int k = 0; k < Gn; ++k) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return L[a] > L[b]; });
+  for (int j = 0; j < 64; ++j) out->lane[j] = GlLane{0, -1, 1, 0, 0};
+  int at = 0;
+  for (int k : order) {
+    first[k] = at;
+    for (int m = 0; m < L[k]; ++m) {
+      GlLane &q = out->lane[at + m];
+      q.grp = (int8_t)k; q.blk = (int8_t)L[k]; q.first = m == 0 ? 1 : 0;
+      q.cnt = (n[k] - m + L[k] - 1) / L[k];
+      if (q.cnt < 0) q.cnt = 0;
+    }
+    at += L[k];
+  }
+  for (int c = 0; c < Gn; ++c) out->lane[c].first_of = (int8_t)first[c];
+  int rounds = 0, n_min = -1;
+  for (int j = 0; j < 64; ++j) {
+    if (out->lane[j].cnt > rounds) rounds = out->lane[j].cnt;
+    if (out->lane[j].cnt > 0 && (n_min < 0 || out->lane[j].cnt < n_min)) n_min = out->lane[j].cnt;
+  }
+  if (rounds < 1) rounds = 1;
+  if (n_min < 0) n_min = 0;
+  out->rounds = rounds;
+  out->n_min = n_min;
+  out->tile.assign((size_t)rounds * 64, 0.0);
+  std::vector<int> seen(Gn, 0);
+  for (int i = 0; i < N; ++i) {
+    const int k = g[i], m = seen[k] % L[k], r = seen[k] / L[k];
+    out->tile[(size_t)r * 64 + first[k] + m] = y[i];
+    seen[k]++;
+  }
+  return AMWG_OK;
+}
+
 // Geometry.  For every lanes-per-chain G take the largest workgroup that still gives every CU a workgroup (more waves
 // share one LDS copy of the data) and price it with a two-term model of one parameter update:
 //     cost(G) = rounds * [ S(G) * max(w_res, 1.8) + (W / G) * max(w_res, 1.15) * (1 + 0.3 / w_res) ]
@@ -156,7 +222,8 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   // cpb: chains per workgroup; 0 = blockDim / G.  A smaller value (one-wavefront workgroups only) is the fallback for models
   // whose per-chain state is so large that 64 / G copies do not fit LDS: the spare lane groups replicate the last chain.
   auto layout = [&](int bt, int G, int cpb = 0) {
-    const size_t data_bytes = s->user ? (size_t)(G == 1 ? s->user_lds_one_lane : s->user_lds) : model_lds_bytes(s->model, s->d.n_obs, s->d.G, G);
+    const size_t data_bytes = s->user ? (size_t)(G == 1 ? s->user_lds_one_lane : s->user_lds)
+                              : (s->mc.group_local ? HierGlModel::gl_lds_bytes(s->d.pad, bt / 64) : model_lds_bytes(s->model, s->d.n_obs, s->d.G, G));
     return G > 64 ? lds_layout(data_bytes, s->P, G / 64, s->pl.max_top, s->n_params, true) : lds_layout(data_bytes, s->P, cpb ? cpb : bt / G, s->pl.max_top, s->n_params);
   };
   const int max_bt = s->user ? s->user_max_threads : model_max_threads(s->model);
@@ -227,7 +294,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   s->grid = (int)((s->C + CPB - 1) / CPB);
   s->lds = (int)layout(bestB, bestG, bestCpb).total;
   if (s->user) return AMWG_OK;    // the kernel is compiled for this geometry afterwards
-  s->kernel = pick_kernel(s->model, s->lanes, s->block);
+  s->kernel = s->mc.group_local ? amwg_kernel_hier_gl(s->block) : pick_kernel(s->model, s->lanes, s->block);
   if (!s->kernel) return fail(AMWG_EINVAL, "no kernel for model %d with %d lanes per chain in workgroups of %d", s->model, s->lanes, s->block);
   return AMWG_OK;
 }
@@ -900,17 +967,15 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   mc.lunif_cp = log_v8(1 / (mc.cp_upper - 0.0));
   mc.exact_division = options->exact_division ? 1 : 0;
   mc.group_local = 0;
+  GlLayoutHost gl;
   if (options->group_local) {
-    // group-local evaluation (include/amwg.h, amwg_options::group_local): the hierarchical family on a balanced round-robin design, a chain
-    // on one whole wavefront -- lane j then only ever meets group j mod G, which is what lets one pass evaluate all G proposals of a sweep
+    // group-local evaluation (include/amwg.h, amwg_options::group_local; amwg_gl.h): the hierarchical family with a chain on one whole
+    // wavefront, every lane serving one group -- which is what lets one pass evaluate all the proposals of a sweep over theta
     if (m->model != AMWG_MODEL_HIER_NORMAL) return bail(fail(AMWG_EINVAL, "group_local: only the hierarchical Normal family has a group-local evaluation"));
-    if (m->G < 1 || (m->G & (m->G - 1)) || m->G > 64) return bail(fail(AMWG_EINVAL, "group_local: the number of groups must be a power of two <= 64 (got %d)", m->G));
-    if (N < 64) return bail(fail(AMWG_EINVAL, "group_local: at least 64 observations (one per lane), got %d", N));
-    for (int i = 0; i < N; ++i)
-      if (m->g[i] != i % m->G) return bail(fail(AMWG_EINVAL, "group_local: the group labels must be g[i] = i mod G (observation %d has label %d)", i, m->g[i]));
     if (n_params != 3 || !params[0].multidim || params[0].len != m->G || params[0].top != m->G)
       return bail(fail(AMWG_EINVAL, "group_local: parameters must be theta (dim [G]), mu, sigma"));
     if (options->lanes_per_chain != 0 && options->lanes_per_chain != 64) return bail(fail(AMWG_EINVAL, "group_local runs a chain on one wavefront: lanes_per_chain must be 0 or 64"));
+    TRYB(gl_layout(m->x, m->g, N, m->G, &gl));
     s->opt.lanes_per_chain = 64;
     mc.group_local = 1;
   }
@@ -935,6 +1000,18 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
       TRYB(dev_alloc(s, &dg, (size_t)N));
       if (N) HIPB(hipMemcpy(dg, gb.data(), (size_t)N, hipMemcpyHostToDevice));
       d.xb = dg;
+      if (mc.group_local) {      // the group-local kernel reads the lane-major tile and the lane table instead (amwg_gl.h)
+        double *dt = nullptr;
+        GlLane *dl = nullptr;
+        TRYB(dev_alloc(s, &dt, gl.tile.size()));
+        TRYB(dev_alloc(s, &dl, (size_t)64));
+        HIPB(hipMemcpy(dt, gl.tile.data(), gl.tile.size() * 8, hipMemcpyHostToDevice));
+        HIPB(hipMemcpy(dl, gl.lane, sizeof gl.lane, hipMemcpyHostToDevice));
+        d.x = dt;
+        d.arr[0] = dl;
+        d.pad = gl.rounds;
+        d.K = gl.n_min;
+      }
     }
   } else if (m->model == AMWG_MODEL_BETA_BERN) {
     std::vector<uint8_t> xb((size_t)N);

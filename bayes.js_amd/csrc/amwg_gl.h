@@ -1,0 +1,312 @@
+// amwg_gl.h -- the GROUP-LOCAL evaluation of the hierarchical Normal family (opt-in: amwg_options::group_local), as its own kernel.
+//
+//     y_i ~ norm(theta[g_i], sigma);  theta_k ~ norm(mu, tau);  mu ~ norm(m0, s0);  sigma ~ unif(a, b)          SURVEY.md section 8(d) cfg4
+//
+// mcmc.js:524-526 evaluates the whole log_post twice per update.  Of this model's Gn + 2 updates per step, Gn touch one group (its
+// observations and one prior term) and one touches no observation at all.  Here a chain lives on one wavefront and
+//   * a proposal for mu re-evaluates the prior terms only, one for sigma makes ONE pass over the data;
+//   * the Gn proposals for theta of a step are evaluated TOGETHER in one pass -- every lane with the proposed mean of the one group it
+//     serves -- and each is decided on its local difference (pt' - pt) + (L' - L).
+// Two passes per step instead of Gn + 2.  NOT the reference's operation schedule: the order of additions it follows is restated, and tested
+// bit for bit, in oracle/amwg_oracle.c (gl_*); its accept decisions equal the reference's unless the accept uniform falls inside the
+// ~1e-12-relative sliver between the two orders' exp(delta) (counted: tests/test_gpu_decision_parity.py, tools/flip_rate.py).
+//
+// Round 4: any labels g_i in [0, Gn), any Gn <= 64 (round 3: g_i = i mod Gn, Gn a power of two).  The host deals the 64 lanes to the groups
+// (gl_layout, amwg_core.hip; restated in the oracle): group k gets an ALIGNED BLOCK of L_k = 2^j lanes -- one lane each to begin with, then the
+// group with the most observations per lane is doubled while lanes are left -- blocks placed in order of decreasing size (ties: group index).
+// Lane m of block k takes the group's observations number m, m + L_k, ... (in index order).  The data is staged LANE-MAJOR in LDS,
+// tile[r * 64 + lane] = the r-th observation of that lane (conflict-free: the 64 lanes read 64 consecutive doubles), rounds beyond a lane's own
+// count are masked.  With that
+//     T_j   = the data-only sum of lane j (0 + term + term + ..., its group's mean)
+//     L_k   = the butterfly of T over the lanes of block k (offsets 1, 2, .. L_k / 2: the block is aligned, partners stay inside)
+//     pt_k  = ld.norm(theta_k, mu, tau),  pm = ld.norm(mu, m0, s0) + ld.unif(sigma, a, b)
+//     log_post_GL = the butterfly over all 64 lanes of V_j:  V_0 = (pm + pt) + T_0;  V_j = pt + T_j on the first lane of a block;  V_j = T_j
+// The sequential semantics of the reference's sweep is kept through the UNIFORM STREAM: which (u, v) pair of the stream survives rnorm's
+// rejection test (mcmc.js:44-53) is a property of the stream alone, so the acceptance flags of the pairs of a 256-uniform window are
+// computed lane-parallel, a scalar loop walks the Gn updates in their shuffled order -- first accepted pair at or after the position (a
+// find-first-set on the flag words), then one accept uniform if the proposal is inside its bounds -- and every lane reads the three uniforms
+// of its group's update from the window (kept in LDS, 2 KB per wavefront).
+//
+// What round 4 changed in the sweep, measured on round 3's profile (141 VALU + 69 SALU per update, 1e7 LDS bank conflicts per launch):
+//   * the per-step Fisher-Yates shuffle of the Gn components (mcmc.js:248-252) consumed a quarter of the non-pass instructions as 31 dependent
+//     rounds of { draw, 2 x v_readlane, selects }.  Its Gn - 1 uniforms are known positions of the stream: every lane fetches and scales ITS one
+//     (j_i = floor(u_i * (i + 1))) at once, and only the 31 transpositions stay sequential -- applied to each lane's POSITION in the order (two
+//     compares + two selects per transposition);
+//   * the window persists across sweeps (a Philox block per lane buys 128 uniforms; round 3 recomputed the second half in every sweep) and
+//     lives in LDS, so a lane's three uniforms are three ds_read_b64 instead of 24 ds_bpermute + selects (the bank conflicts);
+//   * the resolution loop writes update t's stream position into lane t (one v_writelane) instead of comparing and selecting in every lane;
+//   * its own kernel: the ordinary stepper's code, registers and scalar constants are not carried through the sweep.
+#pragma once
+// (included at the end of amwg_models.h: NormCache, norm_const_sd, HierNormalModel::prior_mu_sigma_cold, the staged pass)
+
+namespace amwg {
+
+// one entry per lane of the wavefront (amwg_core.hip gl_layout; d.arr[0])
+struct GlLane {
+  int32_t cnt;      // observations of this lane
+  int8_t grp;       // its group = its component of theta (-1: no group, an idle lane)
+  int8_t blk;       // lanes of its block (a power of two)
+  int8_t first;     // 1 = first lane of its block: holds the group's prior term in log_post_GL and does the component's bookkeeping
+  int8_t first_of;  // lane c (c < Gn): the first lane of component c's block
+};
+
+struct HierGlModel {
+  static constexpr bool kUser = false, kHasFast = false, kOneLanePass = false, kSplitPrior = false;
+  static constexpr int kDerived = 0;
+  static constexpr bool kHasBinary = false;
+  static constexpr int kMaxThreads = 1024;
+  static constexpr int kUnroll = 8;
+  static constexpr bool kGroupLocalKernel = true;
+  // LDS data region of a workgroup: the lane-major tile | the lane table | one 256-uniform window per wavefront
+  static constexpr size_t kTableBytes = 64 * sizeof(GlLane), kWindowBytes = 256 * 8;
+  __host__ __device__ static size_t gl_lds_bytes(int rounds, int waves) { return (size_t)rounds * 64 * 8 + kTableBytes + (size_t)waves * kWindowBytes; }
+  __host__ __device__ static size_t lds_bytes(int, int, int) { return 0; }      // (the group-local kernel sizes its data region with gl_lds_bytes)
+  // DataRef of a group-local sampler: x = the tile [rounds][64], arr[0] = GlLane[64], pad = rounds (the largest lane count), K = the smallest
+  __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int) {
+    double *dst = reinterpret_cast<double *>(smem);
+    const int n = d.pad * 64;
+    for (int i = tid; i < n; i += nt) dst[i] = d.x[i];
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem + (size_t)n * 8);
+    const uint32_t *src = static_cast<const uint32_t *>(d.arr[0]);
+    for (int i = tid; i < (int)(kTableBytes / 4); i += nt) tab[i] = src[i];
+  }
+
+  // ---- the chain's uniform stream as a WINDOW of 256 uniforms: half A = blocks b0 .. b0 + 63 (lane j holds block b0 + j as the two doubles
+  // it yields), half B = the next 64 blocks, computed when a sweep begins or A runs out.  Same stream as CoopStream / ChainStream; the
+  // persisted state is still just the number of uniforms consumed.  Both halves are mirrored in LDS (win[0..127] = A, win[128..255] = B) for
+  // the per-lane reads of a sweep.  E? / O?: bit j = rnorm (mcmc.js:44-53) accepts the pair that starts at the even / odd position 2j / 2j + 1
+  // of that half; the last odd pair of a half ends in the next one: OA bit 63 is valid once B is, OB bit 63 is never set.
+  struct Stream {
+    uint32_t k0, k1, c2, c3;
+    uint64_t b0;
+    uint32_t pos;              // uniforms consumed since block b0 (wave-uniform)
+    double a0, a1, b0v, b1v;
+    uint64_t EA, OA, EB, OB;
+    bool b_valid;
+    double *win;               // LDS
+    int lane;
+    static __device__ __attribute__((noinline)) Philox4 block(uint64_t b, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+      return philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), c2, c3, k0, k1);
+    }
+    // does rnorm accept the pair (u, v)?  mcmc.js:44-53
+    static __device__ __forceinline__ bool pair_ok(double u, double v_raw) {
+      const double v = 1.7156 * (v_raw - 0.5);
+      const double x = u - 0.449871;
+      const double y = __builtin_fabs(v) + 0.386595;
+      const double q = x * x + y * (0.19600 * y - 0.25472 * x);
+      return !(q > 0.27597 && (q > 0.27846 || v * v > -4 * log_v8_cold(u) * u * u));
+    }
+    static __device__ __forceinline__ double from_lane(double v, int src) {      // v of lane `src` (wave-uniform), every lane
+#if defined(__HIP_DEVICE_COMPILE__)
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(f64_bits(v) >> 32), src);
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f64_bits(v), src);
+      return bits_f64(((uint64_t)hi << 32) | (uint64_t)lo);
+#else
+      return v;
+#endif
+    }
+    static __device__ __forceinline__ double next_lane(double v) {                // v of lane + 1 (lane 63: unspecified), all lanes executing
+#if defined(__HIP_DEVICE_COMPILE__)
+      double r = __shfl_down(v, 1, 64);
+      asm volatile("" : "+v"(r));       // (keeps the shuffle out of a later conditional expression: a masked-off source lane reads as 0)
+      return r;
+#else
+      return v;
+#endif
+    }
+    __device__ __forceinline__ void store_a() { win[2 * lane] = a0; win[2 * lane + 1] = a1; }
+    __device__ __forceinline__ void store_b() { win[128 + 2 * lane] = b0v; win[128 + 2 * lane + 1] = b1v; }
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t chain, uint64_t consumed, int tid, double *window) {
+      k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+      c2 = (uint32_t)chain; c3 = (uint32_t)(chain >> 32);
+      lane = tid & 63;
+      win = window;
+      b0 = consumed >> 1;
+      pos = (uint32_t)(consumed & 1u);
+      const Philox4 w = block(b0 + (uint64_t)lane, c2, c3, k0, k1);
+      a0 = u53(w.w0, w.w1); a1 = u53(w.w2, w.w3);
+      store_a();
+      EA = __ballot(pair_ok(a0, a1));
+      const double na = next_lane(a0);
+      OA = __ballot(pair_ok(a1, na)) & ~(1ull << 63);
+      EB = OB = 0ull;
+      b0v = b1v = 0.0;
+      b_valid = false;
+    }
+    // half B: one Philox block per lane, its flags, and the one pair of A that ends in it
+    __device__ __forceinline__ void ensure_b() {
+      if (b_valid) return;
+      const Philox4 w = block(b0 + 64ull + (uint64_t)lane, c2, c3, k0, k1);
+      b0v = u53(w.w0, w.w1); b1v = u53(w.w2, w.w3);
+      store_b();
+      EB = __ballot(pair_ok(b0v, b1v));
+      // odd pairs: lanes 0..62 their own second uniform with the next lane's first; lane 63 does A's last odd pair with B's first uniform
+      const double nb = next_lane(b0v);
+      const double b_first = from_lane(b0v, 0);
+      const double pu = lane == 63 ? a1 : b1v, pv = lane == 63 ? b_first : nb;
+      const uint64_t m = __ballot(pair_ok(pu, pv));
+      OB = m & ~(1ull << 63);
+      OA = (OA & ~(1ull << 63)) | (m & (1ull << 63));
+      b_valid = true;
+    }
+    // A is used up: B becomes A
+    __device__ __forceinline__ void shift() {
+      ensure_b();
+      b0 += 64ull;
+      a0 = b0v; a1 = b1v;
+      EA = EB; OA = OB;
+      store_a();
+      b_valid = false;
+    }
+    __device__ __forceinline__ uint64_t consumed() const { return 2 * b0 + (uint64_t)pos; }
+    __device__ __forceinline__ uint32_t position() {      // < 128 afterwards: at least 128 uniforms of the window lie ahead once B is there
+#if defined(__HIP_DEVICE_COMPILE__)
+      uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+#else
+      uint32_t p = pos;
+#endif
+      while (p >= 128u) { shift(); p -= 128u; }
+      pos = p;
+      return p;
+    }
+    __device__ __forceinline__ double next() {
+      const uint32_t p = position();
+      const double mine = (p & 1u) ? a1 : a0;
+      pos = p + 1u;
+      return from_lane(mine, (int)(p >> 1));
+    }
+    // uniform number q of the window (0 .. 255), per lane
+    __device__ __forceinline__ double at(uint32_t q) const { return win[q & 255u]; }
+  };
+
+  // ---- what every lane keeps of ITS group between evaluations
+  struct Lane {
+    NormCache n;                       // sd-dependent constants of the pass (of the sd last evaluated)
+    double mu, sigma, th;              // th: the mean of this lane's group (0 on an idle lane)
+    double pm, pt, T, Ls;              // committed pieces of log_post_GL: prior(mu, sigma) | prior term of th | this lane's data sum | its block's
+    double pm_t, pt_t, T_t;            // the same of the proposal being evaluated
+    double c1, den1, y1h, y1l;         // constants of theta's prior, in vector registers
+    int den1_ok;
+    int grp, blk, cnt;
+    bool first;
+  };
+  __device__ __forceinline__ static double prior_mu_sigma(double mu, double sigma) { return HierNormalModel::prior_mu_sigma_cold(mu, sigma); }
+  __device__ __forceinline__ static double prior_theta(const Lane &k, double theta, double mu) {
+    return norm_const_sd(theta, mu, k.c1, k.den1, k.y1h, k.y1l, k.den1_ok);
+  }
+  // the value this lane contributes to log_post_GL
+  __device__ __forceinline__ static double lane_value(const Lane &k, int lane, double pm, double pt, double T) {
+    return lane == 0 ? (pm + pt) + T : (k.first ? pt + T : T);
+  }
+  __device__ __forceinline__ static double total(const Lane &k, int lane, double pm, double pt, double T) {
+    return butterfly<1, 64>(lane_value(k, lane, pm, pt, T));
+  }
+  // the sum of T over the lanes of this lane's block: the stages of the butterfly below the block size (the block is aligned: partners are
+  // inside it, and a lane of a smaller block simply keeps its value)
+  __device__ __forceinline__ static double block_sum(double T, int blk) {
+    double s;
+    s = xor_sum<1>(T); T = blk > 1 ? s : T;
+    s = xor_sum<2>(T); T = blk > 2 ? s : T;
+    s = xor_sum<4>(T); T = blk > 4 ? s : T;
+    s = xor_sum<8>(T); T = blk > 8 ? s : T;
+    s = xor_sum<16>(T); T = blk > 16 ? s : T;
+    s = xor_sum<32>(T); T = blk > 32 ? s : T;
+    return T;
+  }
+  // T of this lane for the given mean of its group, with the sd the NormCache holds: the first n_min rounds every lane has (hand-scheduled
+  // pass), then the rounds only some lanes have
+  __device__ inline __attribute__((noinline)) static double pass_slow(const double *tile, double mean, double c, double den, int n_max, int cnt, int lane) {
+    double acc = 0.0;
+    for (int r = 0; r < n_max; ++r) { const double t = tile[r * 64 + lane] - mean; const double term = c - (t * t) / den; acc = r < cnt ? acc + term : acc; }
+    return acc;
+  }
+  // Same operations on the same values in the same order as the plain loop `acc = 0; for r < cnt: acc += c - (x_r - mean)^2 / den`: the
+  // first n_min rounds (every lane that serves a group has them) through the hand-scheduled pass, the rest in masked blocks of U.  An idle
+  // lane computes on the tile's padding and returns 0.
+  template <int U>
+  __device__ __forceinline__ static double pass(const Lane &k, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int lane, double mean) {
+    const double *tile = reinterpret_cast<const double *>(smem);
+    const int n_min = fresh_uniform(d.K), n_max = fresh_uniform(d.pad);
+    const bool mine = mean == 0 || mid_range(__builtin_fabs(mean));
+    const bool ok = !mc.exact_division && mc.data_mid_range && k.n.den_ok && __ballot(mine) == ~0ull;
+    if (!ok) return pass_slow(tile, mean, k.n.c, k.n.den, n_max, k.cnt, lane);
+    double acc = norm_pass_staged<64, U, false>(tile, nullptr, StateView{nullptr}, mean, k.n.c, k.n.den, k.n.y, n_min * 64, lane, 0.0);
+    for (int r0 = n_min; r0 < n_max; r0 += U) {
+      NormBlock<U> xt, qt;
+      double mt[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = r0 + u < n_max ? r0 + u : n_max - 1;      // (rows past the end: any valid address, masked below)
+        xt.v[u] = tile[r * 64 + lane];
+        mt[u] = mean;
+      }
+      AMWG_STAGE_FENCE();
+      norm_block_stages<U, false>(xt, mt, qt, qt, acc, k.n.c, k.n.den, k.n.y);
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc = r0 + u < k.cnt ? acc + qt.v[u] : acc;
+    }
+    return k.cnt > 0 ? acc : 0.0;
+  }
+  // everything from the state as it stands (launch start; equals what the previous launch ended with, bit for bit) -> log_post_GL
+  template <int U>
+  __device__ __forceinline__ static double refresh(Lane &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int lane) {
+    const GlLane *tab = reinterpret_cast<const GlLane *>(smem + (size_t)d.pad * 64 * 8);
+    const GlLane me = tab[lane];
+    k.grp = me.grp; k.blk = me.blk; k.cnt = me.cnt; k.first = me.first != 0;
+    k.mu = S(d.G);
+    k.sigma = S(d.G + 1);
+    k.th = k.grp >= 0 ? S(k.grp) : 0.0;
+    k.c1 = mc.c1; k.den1 = mc.den1; k.y1h = mc.y1_hi; k.y1l = mc.y1_lo; k.den1_ok = mc.den1_ok;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(k.c1), "+v"(k.den1), "+v"(k.y1h), "+v"(k.y1l), "+v"(k.den1_ok));      // (vector registers from here on)
+#endif
+    k.n = norm_cache_init();
+    norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);
+    k.pm = prior_mu_sigma(k.mu, k.sigma);
+    k.pt = k.grp >= 0 ? prior_theta(k, k.th, k.mu) : 0.0;
+    k.T = pass<U>(k, mc, d, smem, lane, k.th);
+    k.Ls = block_sum(k.T, k.blk);
+    k.pm_t = k.pm; k.pt_t = k.pt; k.T_t = k.T;
+    return total(k, lane, k.pm, k.pt, k.T);
+  }
+  // a proposal v for mu (is_mu) or sigma: log_post_GL of the proposed state, its pieces kept as tentative
+  template <int U>
+  __device__ __forceinline__ static double eval_scalar(Lane &k, bool is_mu, double v, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int lane) {
+    const double mu = is_mu ? v : k.mu, sigma = is_mu ? k.sigma : v;
+    k.pm_t = prior_mu_sigma(mu, sigma);
+    if (is_mu) {
+      k.pt_t = k.grp >= 0 ? prior_theta(k, k.th, mu) : 0.0;
+      k.T_t = k.T;
+    } else {
+      k.pt_t = k.pt;
+      norm_cache_update<true>(k.n, sigma, mc.neg_half_log_2pi);
+      k.T_t = pass<U>(k, mc, d, smem, lane, k.th);
+    }
+    return total(k, lane, k.pm_t, k.pt_t, k.T_t);
+  }
+  __device__ __forceinline__ static void commit_scalar(Lane &k, bool is_mu, double v) {
+    k.pm = k.pm_t; k.pt = k.pt_t;
+    if (!is_mu) { k.T = k.T_t; k.Ls = block_sum(k.T_t, k.blk); }      // (wave-uniform branch: every lane of the chain decided alike)
+    k.mu = is_mu ? v : k.mu;
+    k.sigma = is_mu ? k.sigma : v;
+  }
+  // the sweep over theta: every lane evaluates the proposal of its own group (`eval`: that proposal is evaluated in this round, `prop` its
+  // value -- the same on all lanes of the block) -> the local difference its accept test uses; L' is left in Ls_t
+  template <int U>
+  __device__ __forceinline__ static double sweep_eval(Lane &k, bool eval, double prop, double &Ls_t, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int lane) {
+    norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);       // (a rejected sigma proposal leaves the cache at the proposed sd)
+    const double mean = eval ? prop : k.th;
+    k.pt_t = eval ? prior_theta(k, prop, k.mu) : k.pt;
+    k.T_t = pass<U>(k, mc, d, smem, lane, mean);
+    Ls_t = block_sum(k.T_t, k.blk);
+    return (k.pt_t - k.pt) + (Ls_t - k.Ls);
+  }
+  __device__ __forceinline__ static void sweep_commit(Lane &k, bool accepted, double prop, double Ls_t) {
+    k.th = accepted ? prop : k.th;
+    k.pt = accepted ? k.pt_t : k.pt;
+    k.T = accepted ? k.T_t : k.T;
+    k.Ls = accepted ? Ls_t : k.Ls;
+  }
+};
+
+}  // namespace amwg

@@ -112,10 +112,6 @@ template <class M> struct BinaryOf<M, void_of<decltype(M::kHasBinary)>> { static
 template <class M, class = void> struct TracksState { static constexpr bool value = false; };
 template <class M> struct TracksState<M, void_of<decltype(M::kTracksState)>> { static constexpr bool value = M::kTracksState; };
 
-// Does the model have a group-local evaluation with a lane-parallel sweep (Model::kGroupSweep; HierNormalModel)?
-template <class M, class = void> struct GroupSweepOf { static constexpr bool value = false; };
-template <class M> struct GroupSweepOf<M, void_of<decltype(M::kGroupSweep)>> { static constexpr bool value = M::kGroupSweep; };
-
 template <class M, class = void> struct OwnPassOf { static constexpr bool value = false; };
 template <class M> struct OwnPassOf<M, void_of<decltype(M::kOwnPass)>> { static constexpr bool value = M::kOwnPass; };
 
@@ -367,6 +363,13 @@ __device__ __forceinline__ double js_max2(double a, double b) {
   return a > b ? a : b;
 }
 
+// the random stream a step kernel draws from: the cooperative stream of the chain's lanes, or -- group-local kernel -- the model's window stream
+template <class M, int G, bool GL> struct RngOf { using type = CoopStream<G>; };
+template <class M, int G> struct RngOf<M, G, true> { using type = typename M::Stream; };
+// bytes of the data region of a workgroup's LDS
+template <class M, bool GL> struct DataBytesOf { static __device__ __forceinline__ size_t get(const DataRef &d, int lanes, int) { return M::lds_bytes(d.n_obs, d.G, lanes); } };
+template <class M> struct DataBytesOf<M, true> { static __device__ __forceinline__ size_t get(const DataRef &d, int, int threads) { return M::gl_lds_bytes(d.pad, threads / 64); } };
+
 // The kernel's argument block, read on demand.  Arguments taken by value are all loaded into scalar registers in the kernel's entry
 // block and stay there until their last use: the dozen per-chain array pointers needed again only by the write-back after the step loop
 // (and at batch boundaries / recorded steps inside it) alone are ~30 SGPRs held across the whole loop, and round 2's kernels carried ~200
@@ -396,6 +399,23 @@ struct SlotPre {
   bool adapting;
 };
 
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {      // a wave-uniform 64-bit value, in scalar registers
+#if defined(__HIP_DEVICE_COMPILE__)
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+#else
+  return v;
+#endif
+}
+// lane `lane` of v = value (both wave-uniform), the other lanes unchanged: one v_writelane_b32.  The lane select has to travel in M0 (a VOP3
+// instruction of gfx9 reads one scalar register; this compiler has no builtin for the instruction), which is saved and restored around it.
+__device__ __forceinline__ int write_lane(int v, int value, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int keep;
+  asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(v), "=&s"(keep) : "s"(value), "s"(lane));
+#endif
+  return v;
+}
+
 // a value every lane of the chain holds alike; for a chain on a whole wave (G >= 64) it is moved to a scalar register, so that what is
 // derived from it (table addresses, loop counters, branch conditions) runs on the scalar unit beside the vector work
 template <int G>
@@ -409,7 +429,7 @@ __device__ __forceinline__ int chain_uniform(int v) {
 // BT: the workgroup size class the caller is compiled for (its register budget, see amwg_step_kernel); 1024-thread workgroups leave 128
 // VGPRs per lane, and with four waves per SIMD the staged pass does not need eight observations in flight per lane to keep the pipe busy:
 // it runs four-wide there (same operations in the same order, half the registers).
-template <class Model, int G, int BT = 256>
+template <class Model, int G, int BT = 256, bool GL = false>
 __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem) {
   constexpr int kPassU = BT >= 1024 ? 4 : 8;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -429,7 +449,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   const int c_in = c_raw < CPB ? c_raw : CPB - 1, sub = tid % G;
   const int P = a.pl.P;
   const int n_named = a.pl.n_params;
-  const LdsLayout L = lds_layout(Model::lds_bytes(a.d.n_obs, a.d.G, G), P, CPB, a.pl.max_top, n_named, kMulti);
+  const LdsLayout L = lds_layout(DataBytesOf<Model, GL>::get(a.d, G, nt), P, CPB, a.pl.max_top, n_named, kMulti);
 
   const unsigned char *data_lds = smem + L.data;
   double *Sblk = reinterpret_cast<double *>(smem + L.state);
@@ -477,11 +497,12 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   uint64_t perm = wide_perm ? 0ull : a.ch.perm[cl];
   if (wide_perm)
     for (int k = 0; k < n_named; ++k) pcol.set(k, (int)a.ch.perm16[(int64_t)k * C + cl]);
-  CoopStream<G> rng;
-  rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid);
+  typename RngOf<Model, G, GL>::type rng;
+  if constexpr (GL) rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid, reinterpret_cast<double *>(smem + L.data + Model::gl_lds_bytes(a.d.pad, 0)) + (size_t)(tid >> 6) * 256);
+  else rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid);
   double lp_curr = a.ch.lp_curr[cl];
   __syncthreads();
-  if (a.init_lp) lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);  // ctor warm-up call, mcmc.js:961-963
+  if constexpr (!GL) { if (a.init_lp) lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache); }  // ctor warm-up call, mcmc.js:961-963 (the group-local kernel forms it from its pieces below, in every launch)
 
   // every store to the state goes through here: the LDS copy (what translated closures, gathers and the final write-back read) and,
   // for models that mirror the state in registers, the mirror
@@ -556,17 +577,17 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   };
 
   // ================================================================================================================================
-  // GROUP-LOCAL mode (amwg_options::group_local; HierNormalModel on one wavefront per chain, see amwg_models.h gl_*): the named parameters are
-  // walked in the shuffled order as always, mu and sigma by the ordinary stepper with the group-local evaluation, and the Gn components of
-  // theta in ONE lane-parallel sweep: the stream positions of the Gn proposals are resolved on the scalar unit (which uniform pair survives
-  // rnorm's rejection test is a property of the stream alone), then every lane draws, evaluates and decides the proposal of its own group.
-  // Same uniforms for the same purposes in the same order as the sequential stepper, hence the same decisions (oracle: gl_evaluate).
-  bool group_local = false;
-  if constexpr (GroupSweepOf<Model>::value && G == 64) group_local = a.mc.group_local != 0;
-  if constexpr (GroupSweepOf<Model>::value && G == 64) {
-   if (group_local) {
-    const int Gn = a.d.G, c_l = lane64 & (Gn - 1);          // this lane's group = its component of theta (theta is the first parameter)
-    lp_curr = Model::template gl_refresh<G, kPassU>(cache, S, a.mc, a.d, data_lds, sub);
+  // GROUP-LOCAL kernel (GL; amwg_gl.h has the method and its order of additions): the named parameters are walked in the shuffled order
+  // as always, mu and sigma by the ordinary stepper with the group-local evaluation, and the Gn components of theta in ONE lane-parallel
+  // sweep.  Same uniforms for the same purposes in the same order as the sequential stepper (oracle: gl_evaluate).
+  if constexpr (GL) {
+    static_assert(G == 64, "the group-local kernel runs a chain on one whole wavefront");
+    typename Model::Lane gl;
+    const int Gn = a.d.G;
+    lp_curr = Model::template refresh<kPassU>(gl, S, a.mc, a.d, data_lds, lane64);
+    const int comp_l = gl.grp >= 0 ? gl.grp : 0;            // this lane's component of theta (theta is the first parameter); idle lanes: masked
+    const int first_of = (int)reinterpret_cast<const int8_t *>(data_lds + (size_t)a.d.pad * 64 * 8)[lane64 * 8 + 7];      // GlLane::first_of of lane c: the first lane of component c's block
+    uint64_t first_mask = __ballot(gl.first);
     for (int step = 0; step < n_steps; ++step) {
       record_draws(step);
       shuffle_named();
@@ -576,7 +597,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         if (__builtin_amdgcn_readfirstlane(pl_multidim[p]) == 0) {
           // ---- mu or sigma: OnedimMetropolisStepper.step (mcmc.js:517-553) with the group-local evaluation
           const int comp = base;
-          const double cur = S(comp);
+          const bool is_mu = comp == Gn;
+          const double cur = is_mu ? gl.mu : gl.sigma;
           const double k_lower = cc[comp].lower, k_upper = cc[comp].upper;
           const int k_type = cc[comp].type;
           const int2 cnt = CNTme[comp];
@@ -588,96 +610,94 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           bool accepted = false;
           if (inb) {
             const double u_accept = rng.next();
-            const double prop_lp = Model::template gl_eval_scalar<G, kPassU>(cache, comp, prop, a.mc, a.d, data_lds, sub);
+            const double prop_lp = Model::template eval_scalar<kPassU>(gl, is_mu, prop, a.mc, a.d, data_lds, lane64);
             const double diff = prop_lp - lp_curr;
             if (diff >= 0.0) accepted = true;
             else if (diff < -746.0) accepted = false;
             else accepted = exp_v8(diff) > u_accept;
-            if (accepted) { lp_curr = prop_lp; Model::gl_commit_scalar(cache, comp, prop, a.d); Sme[comp] = prop; }
+            if (accepted) { lp_curr = prop_lp; Model::commit_scalar(gl, is_mu, prop); Sme[comp] = prop; }
             if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
           if (adapting) adapt_component(comp, accepted, cnt, batch_size, writer);
           continue;
         }
-        // ---- theta: fresh shuffle of the order (mcmc.js:248-252), then the sweep
+        // ---- theta.  A fresh shuffle of the order (mcmc.js:248-252): the Fisher-Yates loop i = top-1 .. 1 draws one uniform per round, i.e. the
+        // next top - 1 uniforms of the stream -- lane i fetches and scales ITS one, then the transpositions (i, j_i) are applied in sequence to
+        // every lane's POSITION in the order (lane c < top tracks where component c sits).
         const int top = Gn;
-        ord = lane64;
-        for (int i = top - 1; i > 0; --i) {
-          const int j = __builtin_amdgcn_readfirstlane((int)__builtin_floor(rng.next() * (double)(i + 1)));
-          const int ti = __builtin_amdgcn_readlane(ord, i), tj = __builtin_amdgcn_readlane(ord, j);
-          ord = lane64 == i ? tj : (lane64 == j ? ti : ord);
+        uint32_t p_s = rng.position();                          // < 128: once its second half is there the window reaches at least 128 uniforms ahead
+        rng.ensure_b();
+        int jv = 0;
+        {
+          const uint32_t q = p_s + (uint32_t)(top - 1 - lane64);      // round i = lane consumes uniform number (top - 1 - i) of the shuffle
+          const double u = rng.at(lane64 >= 1 && lane64 < top ? q : 0u);
+          jv = (int)__builtin_floor(u * (double)(lane64 + 1));
         }
-        const int comp_l = base + c_l;
+        int posc = lane64;
+        for (int i = top - 1; i > 0; --i) {
+          const int j = __builtin_amdgcn_readlane(jv, i);
+          posc = posc == i ? j : (posc == j ? i : posc);
+        }
+        p_s += (uint32_t)(top - 1);
+        // my component's place in the order, and -- lane t -- the component at place t
+        const int pos_l = __shfl(posc, comp_l, 64);
+        const int ordv = __builtin_amdgcn_ds_permute(posc << 2, lane64);      // lane posc[c] receives c (lanes >= top map onto themselves)
         const double sd_l = SDme[comp_l], lower_l = cc[comp_l].lower, upper_l = cc[comp_l].upper, bs_l = cc[comp_l].batch_size;
         const int type_l = cc[comp_l].type;
         const bool adapting_l = adapt[comp_l] != 0;
-        uint64_t inb_assume = ~0ull;       // which components' proposals are assumed to fall inside their bounds (they then draw the accept uniform)
-        int pp = 0, kk = -1;               // per lane: stream position of the accepted (u, v) pair of its component's proposal | its place in the order
-        int k_begin = 0;
-        while (k_begin < top) {
-          // -- the window of the stream: 256 uniforms from block b0 on: A = the CoopStream's own 64 blocks, B = the next 64
-          uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rng.pos);
-          if (p0 >= 128u) { rng.b0 += 64ull; p0 -= 128u; rng.fill(); }
-          rng.pos = p0;
-          const Philox4 wb = CoopStream<G>::block(rng.b0 + 64ull + (uint64_t)lane64, rng.c2, rng.c3, rng.k0, rng.k1);
-          const double ua0 = rng.u0, ua1 = rng.u1, ub0 = u53(wb.w0, wb.w1), ub1 = u53(wb.w2, wb.w3);   // uniforms 2j, 2j+1, 128+2j, 129+2j of the window
-          const double ub0_first = bits_f64(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(f64_bits(ub0) >> 32), 0) << 32) |
-                                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f64_bits(ub0), 0));
-          // the uniform after this lane's second one = the next lane's first.  The shuffle is done by ALL lanes, before the select: written as
-          // one conditional expression the compiler runs it with lane 63 masked off, and a lane reading from a masked-off lane gets 0
-          double na0 = __shfl_down(ua0, 1, 64);
-          asm volatile("" : "+v"(na0));
-          na0 = lane64 == 63 ? ub0_first : na0;
-          const double nb0 = __shfl_down(ub0, 1, 64);                              // (lane 63: beyond the window, masked below)
-          // does rnorm accept the pair (u, v)?  mcmc.js:44-53
-          auto pair_ok = [&](double u, double v_raw) -> bool {
-            const double v = 1.7156 * (v_raw - 0.5);
-            const double x = u - 0.449871;
-            const double y = __builtin_fabs(v) + 0.386595;
-            const double q = x * x + y * (0.19600 * y - 0.25472 * x);
-            return !(q > 0.27597 && (q > 0.27846 || v * v > -4 * log_v8_cold(u) * u * u));
-          };
-          const uint64_t EA = __ballot(pair_ok(ua0, ua1)), OA = __ballot(pair_ok(ua1, na0));
-          const uint64_t EB = __ballot(pair_ok(ub0, ub1)), OB = __ballot(pair_ok(ub1, nb0)) & ~(1ull << 63);
-          // -- scalar resolution: update k of the order takes the first accepted pair at or after the stream position, then (if its proposal is
-          // inside the bounds) one more uniform for the accept test
-          uint32_t p = p0;
-          int k = k_begin;
-          for (; k < top; ++k) {
+        const bool bounded_any = __ballot(gl.grp >= 0 && (lower_l > -kInf || upper_l < kInf || type_l == kTypeInt)) != 0ull;
+        uint64_t inb_assume = ~0ull;       // (bit = first lane of a component's block) which proposals are assumed to fall inside their bounds: they draw the accept uniform
+        int ppv = 0;                       // lane t: the stream position of the accepted (u, v) pair of update t of the order
+        int t_begin = 0;
+        while (t_begin < top) {
+          rng.ensure_b();
+          // -- scalar resolution: update t of the order takes the first accepted pair at or after the stream position, then (if its proposal is
+          // inside the bounds) one more uniform for the accept test.  A pair must start at or before 253 (its accept uniform is inside the window).
+          // (every input of the loop is handed over as a scalar: the compiler then keeps the loop itself on the scalar unit)
+          const uint64_t EA = uniform_u64(rng.EA), OA = uniform_u64(rng.OA), EB = uniform_u64(rng.EB) & ~(1ull << 63), OB = uniform_u64(rng.OB);
+          const uint64_t assume = uniform_u64(inb_assume);
+          const bool bounded = __builtin_amdgcn_readfirstlane((int)bounded_any) != 0;
+          const int top_s = __builtin_amdgcn_readfirstlane(top);
+          uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p_s);
+          int t = __builtin_amdgcn_readfirstlane(t_begin);
+          for (; t < top_s; ++t) {
             bool found = false;
-            while (p + 2u <= 255u) {
-              const uint64_t m = (p & 128u) ? ((p & 1u) ? OB : EB) : ((p & 1u) ? OA : EA);
-              if ((m >> ((p & 127u) >> 1)) & 1ull) { found = true; break; }
-              p += 2u;
+            while (p < 256u) {
+              const uint32_t par = p & 1u, idx = (p & 127u) >> 1;
+              const uint64_t m = (p & 128u) ? (par ? OB : EB) : (par ? OA : EA);
+              const uint64_t rest = m >> idx;
+              if (rest != 0ull) { p += 2u * (uint32_t)__builtin_ctzll(rest); found = true; break; }
+              if (p & 128u) { p = 254u | par; break; }      // every pair up to the window's last one is rejected (consumed): the search resumes there in the next window
+              p = 128u | par;                               // nothing left in the first half: on to the second
             }
-            if (!found) break;            // the window ends inside update k's rejected pairs: they are consumed, the search resumes in the next window
-            const int ck = __builtin_amdgcn_readlane(ord, k);
-            pp = lane64 == ck ? (int)p : pp;
-            kk = lane64 == ck ? k : kk;
-            p += ((inb_assume >> ck) & 1ull) ? 3u : 2u;
+            if (!found) break;
+            ppv = write_lane(ppv, (int)p, t);
+            uint32_t adv = 3u;
+            if (bounded) {
+              const int ck = __builtin_amdgcn_readlane(ordv, t);
+              const int fl = __builtin_amdgcn_readlane(first_of, ck);
+              adv = ((assume >> fl) & 1ull) ? 3u : 2u;
+            }
+            p += adv;
           }
-          const int k_end = k;
+          const int t_end = t;
           // -- every lane: the proposal of its own group
-          const int pp_l = __shfl(pp, c_l, 64), kk_l = __shfl(kk, c_l, 64);
-          const bool in_round = kk_l >= k_begin && kk_l < k_end;
-          auto window_uniform = [&](uint32_t q) -> double {
-            const int src = (int)((q & 127u) >> 1);
-            const double a0 = __shfl(ua0, src, 64), a1 = __shfl(ua1, src, 64), b0 = __shfl(ub0, src, 64), b1 = __shfl(ub1, src, 64);
-            return (q & 128u) ? ((q & 1u) ? b1 : b0) : ((q & 1u) ? a1 : a0);
-          };
-          const uint32_t q_l = in_round ? (uint32_t)pp_l : 0u;
-          const double u = window_uniform(q_l), v_raw = window_uniform(q_l + 1u), u_accept = window_uniform(q_l + 2u);
-          const double cur = cache.th_pass;
+          const bool in_round = gl.grp >= 0 && pos_l >= t_begin && pos_l < t_end;
+          const uint32_t q_l = in_round ? (uint32_t)__shfl(ppv, pos_l, 64) : 0u;
+          const double u = rng.at(q_l), v_raw = rng.at(q_l + 1u), u_accept = rng.at(q_l + 2u);
+          const double cur = gl.th;
           double prop = ((1.7156 * (v_raw - 0.5)) / u) * sd_l + cur;       // rnorm_js: (v / u) * sd + mean
           if (type_l == kTypeInt) prop = js_round(prop);
           const bool inb = !(prop < lower_l || prop > upper_l);
-          // the resolution assumed which proposals draw an accept uniform: check, and resolve again where it was wrong (each pass fixes at
-          // least the earliest wrong one; with unbounded components there is nothing to fix)
-          const uint64_t lanes_lo = Gn >= 64 ? ~0ull : ((1ull << Gn) - 1ull);
-          const uint64_t round_mask = __ballot(in_round) & lanes_lo, actual = __ballot(inb) & lanes_lo;
-          if (((actual ^ inb_assume) & round_mask) != 0ull) { inb_assume = (inb_assume & ~round_mask) | (actual & round_mask); continue; }
+          if (bounded_any) {
+            // the resolution assumed which proposals draw an accept uniform: check, and resolve again where it was wrong (each pass fixes at
+            // least the earliest wrong one; with unbounded components there is nothing to fix)
+            const uint64_t round_mask = __ballot(in_round) & first_mask, actual = __ballot(inb) & first_mask;
+            if (((actual ^ inb_assume) & round_mask) != 0ull) { inb_assume = (inb_assume & ~round_mask) | (actual & round_mask); continue; }
+          }
           const bool eval = in_round && inb;
-          const double delta = Model::template gl_sweep_eval<G, kPassU>(cache, eval, prop, a.mc, a.d, data_lds, sub);
+          double Ls_t;
+          const double delta = Model::template sweep_eval<kPassU>(gl, eval, prop, Ls_t, a.mc, a.d, data_lds, lane64);
           // Math.exp(delta) > u (mcmc.js:527-528); >= 0 and < -746 decided without the exponential, NaN takes it and fails
           bool accepted = false;
           if (eval) {
@@ -685,23 +705,22 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
             else if (delta < -746.0) accepted = false;
             else accepted = exp_v8(delta) > u_accept;
           }
-          Model::gl_sweep_commit(cache, accepted, prop);
-          if (lane64 < Gn && in_round) {         // one lane per component: state, run totals, adaptation
+          Model::sweep_commit(gl, accepted, prop, Ls_t);
+          if (gl.first && in_round) {            // one lane per component: state, run totals, adaptation
             if (accepted) Sme[comp_l] = prop;
             if (inb) TOTme[comp_l] += 1u + (accepted ? 0x10000u : 0u);
             if (adapting_l) adapt_component(comp_l, accepted, CNTme[comp_l], bs_l, live);
           }
-          k_begin = k_end;
-          // the stream position after this round; past the CoopStream's own blocks, the window's second half becomes its buffer
-          if (p >= 128u) { rng.b0 += 64ull; rng.u0 = ub0; rng.u1 = ub1; p -= 128u; }
+          t_begin = t_end;
+          // the stream position after this round (>= 128: the window moves on when it is next looked at)
+          p_s = p;
           rng.pos = p;
+          if (t_begin < top) p_s = rng.position();
         }
-        lp_curr = Model::template gl_total<G>(cache, sub, Gn, cache.pm, cache.pt, cache.T);
+        lp_curr = Model::total(gl, lane64, gl.pm, gl.pt, gl.T);
       }
     }
-   }
-  }
-  if (!group_local)
+  } else
   for (int step = 0; step < n_steps; ++step) {
     record_draws(step);
     shuffle_named();
@@ -868,6 +887,12 @@ template <class Model, int G, int BT>
 __global__ void __launch_bounds__(BT, MinWavesOf<Model>::value) amwg_step_kernel(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   step_body<Model, G, BT>(a, smem);
+}
+// the group-local kernel of a family that has one (amwg_gl.h): a chain on one whole wavefront
+template <class Model, int BT>
+__global__ void __launch_bounds__(BT, MinWavesOf<Model>::value) amwg_gl_kernel(const StepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  step_body<Model, 64, BT, true>(a, smem);
 }
 
 }  // namespace amwg

@@ -53,6 +53,17 @@ step_kernel_t multi_wave(int block) {       // G > 64: one chain = one workgroup
 
 }  // namespace
 
+#if AMWG_FAMILY == 2
+// the group-local kernel of the hierarchical family (amwg_gl.h): a chain on one wavefront, any workgroup size class
+step_kernel_t amwg_kernel_hier_gl(int block) {
+  switch (class_of(block)) {
+    case 256: return amwg_gl_kernel<HierGlModel, 256>;
+    case 512: return amwg_gl_kernel<HierGlModel, 512>;
+    default: return amwg_gl_kernel<HierGlModel, 1024>;
+  }
+}
+#endif
+
 step_kernel_t AMWG_FAMILY_LOOKUP(int lanes, int block) {
   switch (lanes) {
     case 1: return single_wave<1>(block);

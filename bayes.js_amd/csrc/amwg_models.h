@@ -336,10 +336,8 @@ struct HierNormalModel {
     // VECTOR registers: the stepper keeps more wave-uniform values alive than there are scalar registers, and every use of a spilled one is a
     // v_readlane plus a wait state -- the priors alone were 0.5 us of the 2.4 us a stepper update takes (measured by cutting them out)
     double pr_mu, pr_sigma, pr_val, c1, den1, y1h, y1l; int den1_ok;
-    // group-local evaluation (gl_* below): committed pieces of log_post_GL, and the tentative ones of the proposal being evaluated
-    double pm, pt, T, pm_t, pt_t, T_t;
   };
-  __device__ __forceinline__ static Cache cache_init() { return Cache{norm_cache_init(), 0.0, 0.0, 0.0, 0.0, -1, false, false, __builtin_nan(""), __builtin_nan(""), 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; }
+  __device__ __forceinline__ static Cache cache_init() { return Cache{norm_cache_init(), 0.0, 0.0, 0.0, 0.0, -1, false, false, __builtin_nan(""), __builtin_nan(""), 0.0, 0.0, 0.0, 0.0, 0.0, 0}; }
   template <int GL>
   __device__ __forceinline__ static void load(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
     if (k.loaded) return;
@@ -439,103 +437,6 @@ struct HierNormalModel {
     ps.th_pass = k.th_pass;
     return ps;
   }
-  // ---------------------------------------------------------------------------------------------------------------------------------
-  // GROUP-LOCAL evaluation (opt-in: amwg_options::group_local; preconditions checked by amwg_create: labels g_i = i mod Gn, Gn a power of
-  // two <= 64, a chain on one whole wavefront).  NOT the reference's operation schedule -- the order it follows is restated, and tested
-  // bit for bit, in oracle/amwg_oracle.c (gl_*):
-  //     T_j  = the data-only partial sum of lane j (0 + term(j) + term(j + 64) + ..., one mean per lane: that of group j mod Gn)
-  //     pt_k = ld.norm(theta_k, mu, tau),  pm = ld.norm(mu, m0, s0) + ld.unif(sigma, a, b)
-  //     log_post_GL = butterfly over the 64 lanes of V_j:  V_0 = (pm + pt_0) + T_0,  V_j = pt_j + T_j (j < Gn),  V_j = T_j (j >= Gn)
-  // Every lane keeps the pieces of ITS group (lanes j and j + Gn, ... hold the same pt).  A proposal for mu needs no pass, one for sigma one
-  // pass; the Gn proposals of a sweep over theta are evaluated TOGETHER in one pass -- every lane with the proposed mean of its own group --
-  // and each is decided on its local difference (pt' - pt) + (L' - L), L = the sum of T over the lanes of the group.  2 passes per step
-  // instead of 34 (mcmc.js:524-526 evaluates the full log_post twice per update).
-  static constexpr bool kGroupSweep = true;
-  __device__ __forceinline__ static double gl_pm(double mu, double sigma, const ModelConsts &) { return prior_mu_sigma_cold(mu, sigma); }
-  __device__ __forceinline__ static double gl_pt(const Cache &k, double theta, double mu) {
-    return norm_const_sd(theta, mu, k.c1, k.den1, k.y1h, k.y1l, k.den1_ok);
-  }
-  __device__ __forceinline__ static double gl_lane_value(int sub, int Gn, double pm, double pt, double T) {
-    return sub == 0 ? (pm + pt) + T : (sub < Gn ? pt + T : T);
-  }
-  template <int G>
-  __device__ __forceinline__ static double gl_total(const Cache &k, int sub, int Gn, double pm, double pt, double T) {
-    return butterfly<1, 64>(gl_lane_value(sub, Gn, pm, pt, T));
-  }
-  // sum of T over the lanes of this lane's group: the butterfly stages whose offset is a multiple of Gn
-  __device__ __forceinline__ static double gl_group_sum(double T, int Gn) {
-    if (Gn <= 1) T = xor_sum<1, true>(T);
-    if (Gn <= 2) T = xor_sum<2, true>(T);
-    if (Gn <= 4) T = xor_sum<4, true>(T);
-    if (Gn <= 8) T = xor_sum<8, true>(T);
-    if (Gn <= 16) T = xor_sum<16, true>(T);
-    if (Gn <= 32) T = xor_sum<32, true>(T);
-    return T;
-  }
-  template <int G>
-  __device__ inline __attribute__((noinline)) static double gl_pass_slow(const double *x, double mean, double c, double den, int n_obs, int sub) {
-    double acc = 0.0;
-    for (int i = sub; i < n_obs; i += G) { const double t = x[i] - mean; acc += c - (t * t) / den; }
-    return acc;
-  }
-  // T of this lane for the given mean of its group, with the sd the NormCache currently holds
-  template <int G, int U>
-  __device__ __forceinline__ static double gl_pass(const Cache &k, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub, double mean) {
-    const double *x = reinterpret_cast<const double *>(smem);
-    const bool mine = mean == 0 || mid_range(__builtin_fabs(mean));
-    const bool ok = !mc.exact_division && mc.data_mid_range && k.n.den_ok && __ballot(mine) == ~0ull;
-    if (ok) return norm_pass_staged<G, U, false>(x, nullptr, StateView{nullptr}, mean, k.n.c, k.n.den, k.n.y, d.n_obs, sub, 0.0);
-    return gl_pass_slow<G>(x, mean, k.n.c, k.n.den, d.n_obs, sub);
-  }
-  // caches and log_post_GL of the state as it stands (launch start; equals the value the previous launch ended with, bit for bit)
-  template <int G, int U>
-  __device__ __forceinline__ static double gl_refresh(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
-    k.loaded = false;
-    load<G>(k, S, mc, d, smem, sub);
-    norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);
-    k.pm = gl_pm(k.mu, k.sigma, mc);
-    k.pt = gl_pt(k, k.th_pass, k.mu);
-    k.T = gl_pass<G, U>(k, mc, d, smem, sub, k.th_pass);
-    return gl_total<G>(k, sub, d.G, k.pm, k.pt, k.T);
-  }
-  // a proposal v for mu (comp == Gn) or sigma (comp == Gn + 1): log_post_GL of the proposed state, its pieces kept as tentative
-  template <int G, int U>
-  __device__ __forceinline__ static double gl_eval_scalar(Cache &k, int comp, double v, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
-    const bool is_mu = comp == d.G;
-    const double mu = is_mu ? v : k.mu, sigma = is_mu ? k.sigma : v;
-    k.pm_t = gl_pm(mu, sigma, mc);
-    if (is_mu) {
-      k.pt_t = gl_pt(k, k.th_pass, mu);
-      k.T_t = k.T;
-    } else {
-      k.pt_t = k.pt;
-      norm_cache_update<true>(k.n, sigma, mc.neg_half_log_2pi);
-      k.T_t = gl_pass<G, U>(k, mc, d, smem, sub, k.th_pass);
-    }
-    return gl_total<G>(k, sub, d.G, k.pm_t, k.pt_t, k.T_t);
-  }
-  __device__ __forceinline__ static void gl_commit_scalar(Cache &k, int comp, double v, const DataRef &d) {
-    k.pm = k.pm_t; k.pt = k.pt_t; k.T = k.T_t;
-    k.mu = comp == d.G ? v : k.mu;
-    k.sigma = comp == d.G ? k.sigma : v;
-  }
-  // the sweep over theta: every lane evaluates the proposal of its own group (`eval`: this group's proposal is evaluated in this round,
-  // `prop` its value -- the same on all lanes of the group); -> the local difference the accept test of that proposal uses
-  template <int G, int U>
-  __device__ __forceinline__ static double gl_sweep_eval(Cache &k, bool eval, double prop, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
-    norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);       // (a rejected sigma proposal leaves the cache at the proposed sd)
-    const double mean = eval ? prop : k.th_pass;
-    k.pt_t = eval ? gl_pt(k, prop, k.mu) : k.pt;
-    k.T_t = gl_pass<G, U>(k, mc, d, smem, sub, mean);
-    return (k.pt_t - k.pt) + (gl_group_sum(k.T_t, d.G) - gl_group_sum(k.T, d.G));
-  }
-  __device__ __forceinline__ static void gl_sweep_commit(Cache &k, bool accepted, double prop) {
-    k.th_pass = accepted ? prop : k.th_pass;
-    k.th_own = accepted ? prop : k.th_own;
-    k.pt = accepted ? k.pt_t : k.pt;
-    k.T = accepted ? k.T_t : k.T;
-  }
-
   template <bool FAST>
   __device__ __forceinline__ static double term(const Pass &ps, int i) {
     const double t = ps.x[i] - ps.S(ps.g[i]);
@@ -749,3 +650,5 @@ struct PoisGlmModel {
 };
 
 }  // namespace amwg
+
+#include "amwg_gl.h"      // the group-local kernel of the hierarchical family (HierGlModel)

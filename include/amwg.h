@@ -113,13 +113,15 @@ typedef struct {
                             * of recorded rows, so that the rows of one launch are copied out while the next ones run.  Results never depend on it. */
   int32_t exact_division;  /* 0 = default: result-preserving shortcuts (hoisted-reciprocal division, fast-forward of two-valued sums), bit-identical
                               to the plain schedule and tested against it; 1 = the reference's operation schedule: IEEE '/', term-by-term sums */
-  int32_t group_local;     /* 0 = default.  1 = GROUP-LOCAL evaluation of the hierarchical family (AMWG_MODEL_HIER_NORMAL with labels g_i = i mod G, G a
-                              power of two <= 64; forces 64 lanes per chain; anything else is AMWG_EINVAL): a proposal for theta_g is decided on the
+  int32_t group_local;     /* 0 = default.  1 = GROUP-LOCAL evaluation of the hierarchical family (AMWG_MODEL_HIER_NORMAL, any labels g_i in [0, G), G <= 64
+                              -- since round 4: the library deals the 64 lanes of a chain's wavefront to the groups in aligned power-of-two blocks and
+                              lays the data out lane-major, csrc/amwg_gl.h; forces 64 lanes per chain; anything else is AMWG_EINVAL): a proposal for theta_g is decided on the
                               difference of ITS group's terms only -- and the G proposals of a sweep are evaluated in ONE pass over the data, every lane
                               with the proposed mean of its own group -- instead of on two full sums (mcmc.js:524-526 evaluates the whole log_post twice
                               per update).  NOT the reference's operation schedule: the doubles follow the order restated in oracle/amwg_oracle.c (gl_*),
-                              bit for bit; accept decisions, adaptation and uniforms consumed equal the reference's on every golden.  Opt-in, reported
-                              separately by bench.py */
+                              bit for bit; accept decisions, adaptation and uniforms consumed equal the reference's on every golden and over the
+                              1e10-decision campaign of tools/flip_rate.py (a decision can differ only when the accept uniform falls inside the ~1e-12-relative
+                              sliver between the two summation orders).  Opt-in, reported separately by bench.py */
   int32_t reserved[2];
 } amwg_options;
 

@@ -341,7 +341,7 @@ def _group_local_case(name):
     return gold, gold["case"], gold["chains"][0]
 
 
-@pytest.mark.parametrize("name", ["hier_small", "cfg4_full"])
+@pytest.mark.parametrize("name", ["hier_small", "cfg4_full", "hier_hyper"])      # hier_hyper: 5 groups (not a power of two), 300 observations
 def test_group_local_sweep_equals_its_oracle_and_takes_the_reference_decisions(name):
     """amwg_options::group_local (hierarchical family): the lane-parallel sweep over theta -- all G proposals of a step evaluated in one pass,
     stream positions resolved on the scalar unit -- against its sequential restatement in oracle/amwg_oracle.c (gl_*): every double bit for
@@ -383,9 +383,41 @@ def test_group_local_sweep_with_bounded_integer_and_non_adapting_components():
         s.close()
 
 
+def _shuffled_hier(n_obs, G, seed, sizes=None):
+    """A hierarchical data set whose labels are NOT i mod G: group sizes as given (or random), observations in random order."""
+    rng = np.random.default_rng(seed)
+    if sizes is None:
+        sizes = rng.multinomial(n_obs, rng.dirichlet(np.ones(G) * 2.0))
+    g = np.repeat(np.arange(G), sizes).astype(np.int32)
+    rng.shuffle(g)
+    theta = rng.normal(5.0, 3.0, G)
+    y = theta[g] + rng.normal(0.0, 2.0, g.size)
+    return {"x": y, "g": g, "G": G}
+
+
+@pytest.mark.parametrize("n_obs,G,sizes", [(1000, 5, None), (777, 13, None), (640, 64, None), (300, 2, None), (900, 3, [800, 99, 1]), (40, 4, [0, 25, 15, 0]),
+                                           (2000, 32, None), (130, 64, [3] * 2 + [2] * 62)])
+def test_group_local_any_labels_any_group_count_equals_its_oracle(n_obs, G, sizes):
+    """Round 4: the group-local kernel takes any labels and any G <= 64 -- the host deals the wavefront's lanes to the groups in aligned
+    power-of-two blocks and lays the data out lane-major (amwg_core.hip gl_layout; restated in the oracle).  Ragged designs: groups of
+    very different sizes, empty groups, two groups, 64 groups, fewer observations than lanes; chains 0 and 2 of 3, every double."""
+    data = _shuffled_hier(n_obs, G, 100 + n_obs + G, sizes)
+    spec = model_spec.build_spec("hier_normal", data)
+    s = A.Sampler(spec, chains=3, seed=77, chain_offset=11, group_local=1)
+    assert s.launch_info()["lanes_per_chain"] == 64
+    sched = [{"op": "burn", "n": 130}, {"op": "sample", "n": 60, "thin": 3}]
+    gs = run_schedule(s, sched)
+    for local in (0, 2):
+        o = oracle_lib.OracleChain(spec, 77, 11 + local, lanes=64, group_local=True)
+        assert_chain_equals_oracle(s, local, o, gs, run_schedule(o, sched))
+    s.close()
+
+
 def test_group_local_preconditions_are_enforced():
-    data = model_spec.make_data("hier_normal", 300, 5, G=6)          # 6 groups: not a power of two
-    with pytest.raises(A.AmwgError, match="power of two"):
-        A.Sampler(model_spec.build_spec("hier_normal", data), chains=2, seed=1, group_local=1)
+    data = model_spec.make_data("hier_normal", 300, 5, G=6)
+    data = dict(data, G=65, g=np.arange(300, dtype=np.int32) % 65)      # 65 groups: more than the lanes of a wavefront
+    spec = model_spec.build_spec("hier_normal", data, G=65)
+    with pytest.raises(A.AmwgError, match="1 to 64 groups"):
+        A.Sampler(spec, chains=2, seed=1, group_local=1)
     with pytest.raises(A.AmwgError, match="hierarchical"):
         A.Sampler(model_spec.build_spec("normal", model_spec.make_data("normal", 100, 5)), chains=2, seed=1, group_local=1)

@@ -86,7 +86,7 @@ def test_oracle_kernel_order_same_decisions(name, lanes):
         check_chain(gold, rec, lanes=lanes)
 
 
-@pytest.mark.parametrize("name,lanes", [("hier_small", 8), ("hier_small", 64), ("cfg4_full", 64), ("cfg4_full", 32)])
+@pytest.mark.parametrize("name,lanes", [("hier_small", 64), ("cfg4_full", 64), ("hier_hyper", 64)])      # hier_hyper: 5 groups -- not a power of two
 def test_group_local_mode_reproduces_the_reference_decisions(name, lanes):
     """The opt-in group-local evaluation of the hierarchical family (oracle/amwg_oracle.c gl_*: a theta_g proposal is decided on the local
     difference of its group's terms) is not the reference's operation schedule, but it must take the reference's DECISIONS: accept counts,
@@ -139,3 +139,24 @@ def test_oracle_equals_the_live_reference_on_a_fresh_seed(model, N, G):
         assert np.ascontiguousarray(segs[0]).tobytes() == want.tobytes(), "seed %d" % seed
         assert o.info()["accepts"].tolist() == rec["accepts"] and o.uniforms() == rec["uniforms"], "seed %d" % seed
         assert o.state().tolist() == rec["final_state"]
+
+
+@pytest.mark.parametrize("n_obs,G,seed", [(500, 5, 1), (333, 13, 2), (200, 64, 3), (90, 2, 4)])
+def test_group_local_oracle_on_arbitrary_labels_decides_like_the_ordinary_evaluation(n_obs, G, seed):
+    """Round 4: the group-local mode for any labels / any G <= 64 (lanes dealt to the groups in aligned power-of-two blocks, gl_layout).  On
+    shuffled labels with uneven group sizes the mode must take the decisions of the ordinary evaluation of the same chain (and, the state
+    being a function of the decisions only, produce the same draws bit for bit); its log_post agrees to rounding."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.multinomial(n_obs, rng.dirichlet(np.ones(G) * 2.0))
+    g = np.repeat(np.arange(G), sizes).astype(np.int32)
+    rng.shuffle(g)
+    y = rng.normal(5.0, 3.0, G)[g] + rng.normal(0.0, 2.0, g.size)
+    spec = model_spec.build_spec("hier_normal", {"x": y, "g": g, "G": G})
+    a = oracle_lib.OracleChain(spec, 5, 3, lanes=1)
+    b = oracle_lib.OracleChain(spec, 5, 3, lanes=64, group_local=True)
+    a.burn(150)
+    b.burn(150)
+    da, db = a.sample(50, 1), b.sample(50, 1)
+    assert da.tobytes() == db.tobytes()
+    assert a.info()["accepts"].tolist() == b.info()["accepts"].tolist() and a.uniforms() == b.uniforms()
+    assert abs(a.log_post() - b.log_post()) <= 1e-9 * abs(a.log_post())
