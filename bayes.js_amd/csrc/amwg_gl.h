@@ -90,6 +90,9 @@ struct HierGlModel {
     }
     // does rnorm accept the pair (u, v)?  mcmc.js:44-53
     static __device__ __forceinline__ bool pair_ok(double u, double v_raw) {
+#if defined(AMWG_X_GLCUT) && AMWG_X_GLCUT == 7
+      return u > 0.1;
+#endif
       const double v = 1.7156 * (v_raw - 0.5);
       const double x = u - 0.449871;
       const double y = __builtin_fabs(v) + 0.386595;
@@ -184,13 +187,17 @@ struct HierGlModel {
     NormCache n;                       // sd-dependent constants of the pass (of the sd last evaluated)
     double mu, sigma, th;              // th: the mean of this lane's group (0 on an idle lane)
     double pm, pt, T, Ls;              // committed pieces of log_post_GL: prior(mu, sigma) | prior term of th | this lane's data sum | its block's
-    double pm_t, pt_t, T_t;            // the same of the proposal being evaluated
+    double pa, pb;                     // pm = pa + pb: ld.norm(mu, m0, s0) and ld.unif(sigma, a, b) -- a proposal for one of the two leaves the other term as it is
+    double pm_t, pt_t, T_t, pa_t, pb_t;   // the same of the proposal being evaluated
     double c1, den1, y1h, y1l;         // constants of theta's prior, in vector registers
     int den1_ok;
     int grp, blk, cnt;
     bool first;
   };
-  __device__ __forceinline__ static double prior_mu_sigma(double mu, double sigma) { return HierNormalModel::prior_mu_sigma_cold(mu, sigma); }
+  // the closure's `lp = 0; lp += ld.norm(mu, m0, s0); lp += ld.unif(sigma, a, b)` is (0 + pa) + pb = pa + pb, bit for bit (0 + x = x for every x but -0,
+  // which c0 - q never is).  The hyper-parameters come straight from the kernel's argument block (scalar registers): no call, no load to wait for
+  __device__ __forceinline__ static double prior_mu(double mu, const ModelConsts &mc) { return norm_const_sd(mu, mc.m0, mc.c0, mc.den0, mc.y0_hi, mc.y0_lo, mc.den0_ok); }
+  __device__ __forceinline__ static double prior_sigma(double sigma, const ModelConsts &mc) { return (sigma < mc.ua || sigma > mc.ub) ? -kInf : mc.lunif; }
   __device__ __forceinline__ static double prior_theta(const Lane &k, double theta, double mu) {
     return norm_const_sd(theta, mu, k.c1, k.den1, k.y1h, k.y1l, k.den1_ok);
   }
@@ -231,6 +238,19 @@ struct HierGlModel {
     const bool ok = !mc.exact_division && mc.data_mid_range && k.n.den_ok && __ballot(mine) == ~0ull;
     if (!ok) return pass_slow(tile, mean, k.n.c, k.n.den, n_max, k.cnt, lane);
     double acc = norm_pass_staged<64, U, false>(tile, nullptr, StateView{nullptr}, mean, k.n.c, k.n.den, k.n.y, n_min * 64, lane, 0.0);
+    if (n_max - n_min <= 2) {      // a balanced design: one or two ragged rounds, term by term (a masked block would spend U slots on them)
+      double xv[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) xv[q] = tile[(n_min + q < n_max ? n_min + q : n_max - 1) * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (n_min + q < n_max) {      // uniform
+          const double t = xv[q] - mean;
+          const double term = k.n.c - div_by_invariant(t * t, k.n.den, k.n.y);
+          acc = n_min + q < k.cnt ? acc + term : acc;
+        }
+      }
+    } else
     for (int r0 = n_min; r0 < n_max; r0 += U) {
       NormBlock<U> xt, qt;
       double mt[U];
@@ -262,30 +282,39 @@ struct HierGlModel {
 #endif
     k.n = norm_cache_init();
     norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);
-    k.pm = prior_mu_sigma(k.mu, k.sigma);
+    k.pa = prior_mu(k.mu, mc);
+    k.pb = prior_sigma(k.sigma, mc);
+    k.pm = k.pa + k.pb;
     k.pt = k.grp >= 0 ? prior_theta(k, k.th, k.mu) : 0.0;
     k.T = pass<U>(k, mc, d, smem, lane, k.th);
     k.Ls = block_sum(k.T, k.blk);
-    k.pm_t = k.pm; k.pt_t = k.pt; k.T_t = k.T;
+    k.pm_t = k.pm; k.pt_t = k.pt; k.T_t = k.T; k.pa_t = k.pa; k.pb_t = k.pb;
     return total(k, lane, k.pm, k.pt, k.T);
   }
   // a proposal v for mu (is_mu) or sigma: log_post_GL of the proposed state, its pieces kept as tentative
   template <int U>
   __device__ __forceinline__ static double eval_scalar(Lane &k, bool is_mu, double v, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int lane) {
-    const double mu = is_mu ? v : k.mu, sigma = is_mu ? k.sigma : v;
-    k.pm_t = prior_mu_sigma(mu, sigma);
     if (is_mu) {
-      k.pt_t = k.grp >= 0 ? prior_theta(k, k.th, mu) : 0.0;
+      k.pa_t = prior_mu(v, mc);
+      k.pb_t = k.pb;
+      k.pt_t = k.grp >= 0 ? prior_theta(k, k.th, v) : 0.0;
       k.T_t = k.T;
     } else {
+      k.pa_t = k.pa;
+      k.pb_t = prior_sigma(v, mc);
       k.pt_t = k.pt;
-      norm_cache_update<true>(k.n, sigma, mc.neg_half_log_2pi);
+      norm_cache_update<true>(k.n, v, mc.neg_half_log_2pi);
+#if defined(AMWG_X_GLCUT) && AMWG_X_GLCUT == 5
+      k.T_t = k.T;
+#else
       k.T_t = pass<U>(k, mc, d, smem, lane, k.th);
+#endif
     }
+    k.pm_t = k.pa_t + k.pb_t;
     return total(k, lane, k.pm_t, k.pt_t, k.T_t);
   }
   __device__ __forceinline__ static void commit_scalar(Lane &k, bool is_mu, double v) {
-    k.pm = k.pm_t; k.pt = k.pt_t;
+    k.pm = k.pm_t; k.pt = k.pt_t; k.pa = k.pa_t; k.pb = k.pb_t;
     if (!is_mu) { k.T = k.T_t; k.Ls = block_sum(k.T_t, k.blk); }      // (wave-uniform branch: every lane of the chain decided alike)
     k.mu = is_mu ? v : k.mu;
     k.sigma = is_mu ? k.sigma : v;
@@ -297,7 +326,11 @@ struct HierGlModel {
     norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);       // (a rejected sigma proposal leaves the cache at the proposed sd)
     const double mean = eval ? prop : k.th;
     k.pt_t = eval ? prior_theta(k, prop, k.mu) : k.pt;
+#if defined(AMWG_X_GLCUT) && AMWG_X_GLCUT == 3
+    k.T_t = k.T + mean * 1e-300;
+#else
     k.T_t = pass<U>(k, mc, d, smem, lane, mean);
+#endif
     Ls_t = block_sum(k.T_t, k.blk);
     return (k.pt_t - k.pt) + (Ls_t - k.Ls);
   }

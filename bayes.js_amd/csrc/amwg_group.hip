@@ -22,6 +22,7 @@
 #include <rccl/rccl.h>
 
 #include <cmath>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -41,6 +42,14 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  // one process per device (amwg_comm_*): a communicator from a shared id, and what it says about itself
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   std::string error;
   Rccl() {
     for (const char *name : {"librccl.so.1", "librccl.so"}) {
@@ -56,6 +65,13 @@ struct Rccl {
     GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
     GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    CommCount = reinterpret_cast<decltype(CommCount)>(sym("ncclCommCount"));
+    CommUserRank = reinterpret_cast<decltype(CommUserRank)>(sym("ncclCommUserRank"));
+    CommCuDevice = reinterpret_cast<decltype(CommCuDevice)>(sym("ncclCommCuDevice"));
+    AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
   }
 };
 Rccl &rccl() { static Rccl r; return r; }
@@ -142,6 +158,12 @@ int open_group(amwg_sampler *const *shards, int n, size_t buf_len, bool need_dra
   }
   return AMWG_OK;
 }
+
+// device memory freed on every exit path
+struct DevOwned {
+  void *p = nullptr;
+  ~DevOwned() { if (p) (void)hipFree(p); }
+};
 
 __global__ void add_into_kernel(double *dst, const double *src, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -437,6 +459,214 @@ int amwg_group_quantiles(amwg_sampler *const *shards, int32_t n, const double *p
     HIPG(hipStreamSynchronize(root->stream));
     for (int i = 1; i < n; ++i) { HIPG(hipSetDevice(g.shards[i]->device)); HIPG(hipStreamSynchronize(g.shards[i]->stream)); }
   }
+  return AMWG_OK;
+}
+
+// ---- the gather at sample collection (north_star: "RCCL-over-xGMI gather only at sample collection") -------------------
+// ONE process, one sampler per device: every shard's block of recorded draws [rows][PR][C_i] travels to the device of shard `root`
+// (grouped ncclSend / ncclRecv over the communicator of the shards' devices; shards on the root's own device are copied), where the
+// blocks stand back to back in shard order -- then, if asked, ONE copy to the host.  offsets[i] (optional) = first element of shard i's
+// block.  The Node front-end copies each shard straight to the host instead by default (eight PCIe links in parallel beat funnelling
+// everything through one GPU when the destination is host memory); this is for a caller who wants the job's draws
+// in ONE device buffer, and what bench.py --inproc times as `gather`.
+int amwg_group_gather_draws(amwg_sampler *const *shards, int32_t n, int32_t root_index, double *dst_device, double *dst_host, size_t capacity_bytes, int64_t *offsets) {
+  if (root_index < 0 || root_index >= n) return amwg_fail(AMWG_EINVAL, "amwg_group_gather_draws: root %d outside 0..%d", root_index, n - 1);
+  Group g;
+  int rc = open_group(shards, n, 1, true, &g);
+  if (rc != AMWG_OK) return rc;
+  Rccl &R = rccl();
+  const int PR = g.shards[0]->P + g.shards[0]->D;
+  std::vector<int64_t> cnt(n), off(n);
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) { cnt[i] = g.shards[i]->last_rows * PR * g.shards[i]->C; off[i] = total; total += cnt[i]; if (offsets) offsets[i] = off[i]; }
+  if ((size_t)total * 8 > capacity_bytes) return amwg_fail(AMWG_EINVAL, "amwg_group_gather_draws: %lld bytes needed, %zu given", (long long)total * 8, capacity_bytes);
+  amwg_sampler *root = g.shards[root_index];
+  for (int i = 0; i < n; ++i)      // (constraints are checked BEFORE the RCCL group is opened)
+    if (g.shards[i]->device != root->device && g.leader_of[i] != i)
+      return amwg_fail(AMWG_EINVAL, "amwg_group_gather_draws: two shards share a device other than the root's");
+  DevOwned all;
+  double *dst = dst_device;
+  HIPG(hipSetDevice(root->device));
+  if (!dst) { HIPG(hipMalloc(&all.p, (size_t)(total ? total : 1) * 8)); dst = static_cast<double *>(all.p); }
+  // the shards' own streams have the draws in flight: wait for them where the data is read
+  for (int i = 0; i < n; ++i) {
+    amwg_sampler *s = g.shards[i];
+    if (s->device != root->device) continue;
+    HIPG(hipSetDevice(s->device));
+    HIPG(hipStreamSynchronize(s->stream));
+    HIPG(hipMemcpyAsync(dst + off[i], s->last_draws, (size_t)cnt[i] * 8, hipMemcpyDeviceToDevice, root->stream));
+  }
+  bool any_remote = false;
+  for (int i = 0; i < n; ++i) any_remote = any_remote || g.shards[i]->device != root->device;
+  if (any_remote) {
+    RcclGroupGuard grp(R);
+    NCCLG(grp.start());
+    for (int i = 0; i < n; ++i) {
+      amwg_sampler *s = g.shards[i];
+      if (s->device == root->device) continue;
+      HIPG(hipSetDevice(s->device));
+      NCCLG(R.Send(s->last_draws, (size_t)cnt[i], ncclDouble, g.rank_of[root_index], g.comms[g.rank_of[i]], s->stream));
+      HIPG(hipSetDevice(root->device));
+      NCCLG(R.Recv(dst + off[i], (size_t)cnt[i], ncclDouble, g.rank_of[i], g.comms[g.rank_of[root_index]], root->stream));
+    }
+    NCCLG(grp.end());
+  }
+  for (int i = 0; i < n; ++i) { HIPG(hipSetDevice(g.shards[i]->device)); HIPG(hipStreamSynchronize(g.shards[i]->stream)); }
+  HIPG(hipSetDevice(root->device));
+  HIPG(hipStreamSynchronize(root->stream));
+  if (dst_host) HIPG(hipMemcpy(dst_host, dst, (size_t)total * 8, hipMemcpyDeviceToHost));
+  return AMWG_OK;
+}
+
+// what the communicator of a group of shards says about itself: ranks (ncclCommCount) and the device of every rank
+int amwg_group_comm_info(amwg_sampler *const *shards, int32_t n, int32_t *n_ranks, int32_t *devices, int32_t capacity) {
+  Group g;
+  int rc = open_group(shards, n, 1, false, &g);
+  if (rc != AMWG_OK) return rc;
+  Rccl &R = rccl();
+  int count = 0;
+  NCCLG(R.CommCount(g.comms[0], &count));
+  if (n_ranks) *n_ranks = count;
+  for (size_t r = 0; r < g.comms.size() && devices && (int32_t)r < capacity; ++r) {
+    int dev = -1;
+    NCCLG(R.CommCuDevice(g.comms[r], &dev));
+    devices[r] = dev;
+  }
+  return AMWG_OK;
+}
+
+// ---- one PROCESS per device (torch.distributed.run, MPI, ...): the same two exchanges over a communicator built from a shared id ---------------
+// amwg_comm_unique_id on one rank -> the 128 bytes travel to the others by whatever the host has (a file, a socket, torch's store) ->
+// amwg_comm_create on every rank (collective) -> amwg_comm_gather_draws / amwg_comm_moments (collective) -> amwg_comm_destroy.
+struct amwg_comm {
+  ncclComm_t comm = nullptr;
+  int n_ranks = 0, rank = 0, device = 0;
+};
+
+int amwg_comm_unique_id(char *id, size_t capacity) {
+  Rccl &R = rccl();
+  if (!R.error.empty()) return amwg_fail(AMWG_EHIP, "amwg_comm: RCCL is not available: %s", R.error.c_str());
+  if (!id || capacity < sizeof(ncclUniqueId)) return amwg_fail(AMWG_EINVAL, "amwg_comm_unique_id: the id needs %zu bytes", sizeof(ncclUniqueId));
+  ncclUniqueId u;
+  NCCLG(R.GetUniqueId(&u));
+  memcpy(id, &u, sizeof u);
+  return AMWG_OK;
+}
+
+int amwg_comm_create(const char *id, size_t id_bytes, int32_t n_ranks, int32_t rank, int32_t device, amwg_comm **out) {
+  Rccl &R = rccl();
+  if (!R.error.empty()) return amwg_fail(AMWG_EHIP, "amwg_comm: RCCL is not available: %s", R.error.c_str());
+  if (!id || !out || id_bytes < sizeof(ncclUniqueId) || n_ranks < 1 || rank < 0 || rank >= n_ranks) return amwg_fail(AMWG_EINVAL, "amwg_comm_create: bad argument");
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  HIPG(hipSetDevice(device));
+  amwg_comm *c = new amwg_comm();
+  c->n_ranks = n_ranks; c->rank = rank; c->device = device;
+  const ncclResult_t r = R.CommInitRank(&c->comm, n_ranks, u, rank);
+  if (r != ncclSuccess) { delete c; return amwg_fail(AMWG_EHIP, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, n_ranks, device, R.GetErrorString(r)); }
+  *out = c;
+  return AMWG_OK;
+}
+
+int amwg_comm_info(amwg_comm *c, int32_t *n_ranks, int32_t *rank, int32_t *device) {
+  if (!c) return amwg_fail(AMWG_EINVAL, "amwg_comm_info: null communicator");
+  Rccl &R = rccl();
+  int count = 0, me = -1, dev = -1;
+  NCCLG(R.CommCount(c->comm, &count));      // what RCCL itself reports, not what the caller said
+  NCCLG(R.CommUserRank(c->comm, &me));
+  NCCLG(R.CommCuDevice(c->comm, &dev));
+  if (n_ranks) *n_ranks = count;
+  if (rank) *rank = me;
+  if (device) *device = dev;
+  return AMWG_OK;
+}
+
+int amwg_comm_destroy(amwg_comm *c) {
+  if (!c) return AMWG_OK;
+  Rccl &R = rccl();
+  if (c->comm) (void)R.CommDestroy(c->comm);
+  delete c;
+  return AMWG_OK;
+}
+
+// Collective: the block of recorded draws [rows][PR][C] of this rank's last sample call travels to rank `root`, where the blocks stand
+// back to back in rank order in dst_device (root only; capacity checked there); counts (optional, n_ranks entries, every rank) = the
+// elements each rank contributed.  The blocks may differ in size (uneven shards): the counts are exchanged first (an 8-byte all-gather).
+int amwg_comm_gather_draws(amwg_sampler *s, amwg_comm *c, int32_t root, double *dst_device, size_t capacity_bytes, int64_t *counts) {
+  if (!s || !c) return amwg_fail(AMWG_EINVAL, "amwg_comm_gather_draws: null argument");
+  if (root < 0 || root >= c->n_ranks) return amwg_fail(AMWG_EINVAL, "amwg_comm_gather_draws: root %d outside 0..%d", root, c->n_ranks - 1);
+  if (!s->last_draws || s->last_rows < 1) return amwg_fail(AMWG_EINVAL, "amwg_comm_gather_draws: no sample() call yet");
+  if (s->device != c->device) return amwg_fail(AMWG_EINVAL, "amwg_comm_gather_draws: the sampler is on device %d, the communicator on %d", s->device, c->device);
+  Rccl &R = rccl();
+  HIPG(hipSetDevice(s->device));
+  const int64_t mine = s->last_rows * (int64_t)(s->P + s->D) * s->C;
+  DevOwned cnt_dev;
+  HIPG(hipMalloc(&cnt_dev.p, (size_t)(c->n_ranks + 1) * 8));
+  int64_t *d_all = static_cast<int64_t *>(cnt_dev.p), *d_mine = d_all + c->n_ranks;
+  HIPG(hipMemcpyAsync(d_mine, &mine, 8, hipMemcpyHostToDevice, s->stream));
+  NCCLG(R.AllGather(d_mine, d_all, 1, ncclInt64, c->comm, s->stream));
+  std::vector<int64_t> cnt((size_t)c->n_ranks);
+  HIPG(hipMemcpyAsync(cnt.data(), d_all, (size_t)c->n_ranks * 8, hipMemcpyDeviceToHost, s->stream));
+  HIPG(hipStreamSynchronize(s->stream));
+  if (counts) for (int r = 0; r < c->n_ranks; ++r) counts[r] = cnt[r];
+  if (c->rank == root) {
+    int64_t total = 0;
+    for (int r = 0; r < c->n_ranks; ++r) total += cnt[r];
+    // (a capacity error on the root alone would leave the other ranks inside the collective: the root still takes part, into a scratch buffer)
+    DevOwned scratch;
+    double *dst = dst_device;
+    const bool fits = dst && (size_t)total * 8 <= capacity_bytes;
+    if (!fits) { HIPG(hipMalloc(&scratch.p, (size_t)(total ? total : 1) * 8)); dst = static_cast<double *>(scratch.p); }
+    {
+      RcclGroupGuard grp(R);
+      NCCLG(grp.start());
+      int64_t off = 0;
+      for (int r = 0; r < c->n_ranks; ++r) {
+        if (r != root) NCCLG(R.Recv(dst + off, (size_t)cnt[r], ncclDouble, r, c->comm, s->stream));
+        off += cnt[r];
+      }
+      NCCLG(grp.end());
+    }
+    int64_t off = 0;
+    for (int r = 0; r < root; ++r) off += cnt[r];
+    HIPG(hipMemcpyAsync(dst + off, s->last_draws, (size_t)mine * 8, hipMemcpyDeviceToDevice, s->stream));
+    HIPG(hipStreamSynchronize(s->stream));
+    if (!fits) return amwg_fail(AMWG_EINVAL, "amwg_comm_gather_draws: the root's buffer holds %zu bytes, the job's draws are %lld", capacity_bytes, (long long)total * 8);
+  } else {
+    NCCLG(R.Send(s->last_draws, (size_t)mine, ncclDouble, root, c->comm, s->stream));
+    HIPG(hipStreamSynchronize(s->stream));
+  }
+  return AMWG_OK;
+}
+
+// Collective: mean and sd over the recorded draws of ALL ranks (the twin of amwg_group_moments: two all-reduces of PR + 1 and PR doubles)
+int amwg_comm_moments(amwg_sampler *s, amwg_comm *c, double *mean, double *sd) {
+  if (!s || !c || !mean || !sd) return amwg_fail(AMWG_EINVAL, "amwg_comm_moments: null argument");
+  if (!s->last_draws || s->last_rows < 1) return amwg_fail(AMWG_EINVAL, "amwg_comm_moments: no sample() call yet");
+  Rccl &R = rccl();
+  const int PR = s->P + s->D;
+  HIPG(hipSetDevice(s->device));
+  DevOwned buf, center;
+  HIPG(hipMalloc(&buf.p, (size_t)(PR + 1) * 8));
+  HIPG(hipMalloc(&center.p, (size_t)PR * 8));
+  double *b = static_cast<double *>(buf.p);
+  std::vector<double> h((size_t)PR + 1);
+  hipLaunchKernelGGL(draw_sums_kernel, dim3(PR), dim3(1024), 0, s->stream, s->last_draws, s->last_rows, PR, s->C, (const double *)nullptr, b);
+  HIPG(hipGetLastError());
+  const double cnt = (double)s->last_rows * (double)s->C;
+  HIPG(hipMemcpyAsync(b + PR, &cnt, 8, hipMemcpyHostToDevice, s->stream));
+  NCCLG(R.AllReduce(b, b, (size_t)PR + 1, ncclDouble, ncclSum, c->comm, s->stream));
+  HIPG(hipMemcpyAsync(h.data(), b, (size_t)(PR + 1) * 8, hipMemcpyDeviceToHost, s->stream));
+  HIPG(hipStreamSynchronize(s->stream));
+  const double N = h[PR];
+  for (int p = 0; p < PR; ++p) mean[p] = h[p] / N;
+  HIPG(hipMemcpyAsync(center.p, mean, (size_t)PR * 8, hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(draw_sums_kernel, dim3(PR), dim3(1024), 0, s->stream, s->last_draws, s->last_rows, PR, s->C, (const double *)center.p, b);
+  HIPG(hipGetLastError());
+  NCCLG(R.AllReduce(b, b, (size_t)PR, ncclDouble, ncclSum, c->comm, s->stream));
+  HIPG(hipMemcpyAsync(h.data(), b, (size_t)PR * 8, hipMemcpyDeviceToHost, s->stream));
+  HIPG(hipStreamSynchronize(s->stream));
+  for (int p = 0; p < PR; ++p) sd[p] = N > 1 ? std::sqrt(h[p] / (N - 1)) : 0.0;
   return AMWG_OK;
 }
 

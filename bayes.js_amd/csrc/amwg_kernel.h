@@ -416,6 +416,61 @@ __device__ __forceinline__ int write_lane(int v, int value, int lane) {
   return v;
 }
 
+// The group-local sweep's walk over the uniform stream for components WITHOUT bounds (amwg_gl.h; the general loop is in step_body): update t of
+// the order takes the first pair that rnorm accepts at or after stream position p -- a find-first-set on the flag word of p's half (bit 7) and
+// parity (bit 0); a pair must start at or before 253 (EB arrives with bit 63 cleared, OB never has it) -- leaves that position in lane t of
+// ppv and moves on by 3 (pair + accept uniform).  Stops at `top` updates or when the window is used up (then p = 254 | parity: where the search
+// resumes in the next window; a p of 256 or more stays).  Scalar instructions throughout; M0 carries the lane select and is restored.
+__device__ __forceinline__ void gl_resolve_unbounded(uint64_t EA, uint64_t OA, uint64_t EB, uint64_t OB, uint32_t &p, int &t, int top, int &ppv) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint64_t m, rest;
+  uint32_t tmp, keep_m0;
+  asm volatile(
+      "s_mov_b32 %[km0], m0\n"
+      "1:\n\t"                                   // ---- next update
+      "s_cmp_ge_i32 %[t], %[top]\n\t"
+      "s_cbranch_scc1 9f\n"
+      "2:\n\t"                                   // ---- search from p
+      "s_cmp_ge_u32 %[p], 0x100\n\t"
+      "s_cbranch_scc1 9f\n\t"
+      "s_bitcmp1_b32 %[p], 7\n\t"               // second half?
+      "s_cbranch_scc1 3f\n\t"
+      "s_bitcmp1_b32 %[p], 0\n\t"
+      "s_cselect_b64 %[m], %[OA], %[EA]\n\t"
+      "s_branch 4f\n"
+      "3:\n\t"
+      "s_bitcmp1_b32 %[p], 0\n\t"
+      "s_cselect_b64 %[m], %[OB], %[EB]\n"
+      "4:\n\t"
+      "s_bfe_u32 %[tmp], %[p], 0x60001\n\t"     // (p & 127) >> 1
+      "s_lshr_b64 %[rest], %[m], %[tmp]\n\t"
+      "s_cmp_lg_u64 %[rest], 0\n\t"
+      "s_cbranch_scc1 6f\n\t"
+      "s_and_b32 %[tmp], %[p], 1\n\t"           // nothing left in this half
+      "s_bitcmp1_b32 %[p], 7\n\t"
+      "s_cbranch_scc1 5f\n\t"
+      "s_or_b32 %[p], %[tmp], 0x80\n\t"         // on to the second half
+      "s_branch 2b\n"
+      "5:\n\t"
+      "s_or_b32 %[p], %[tmp], 0xfe\n\t"         // window used up
+      "s_branch 9f\n"
+      "6:\n\t"                                   // ---- found
+      "s_ff1_i32_b64 %[tmp], %[rest]\n\t"
+      "s_lshl_b32 %[tmp], %[tmp], 1\n\t"
+      "s_add_u32 %[p], %[p], %[tmp]\n\t"
+      "s_mov_b32 m0, %[t]\n\t"
+      "v_writelane_b32 %[ppv], %[p], m0\n\t"
+      "s_add_u32 %[p], %[p], 3\n\t"
+      "s_add_u32 %[t], %[t], 1\n\t"
+      "s_branch 1b\n"
+      "9:\n\t"
+      "s_mov_b32 m0, %[km0]"
+      : [p] "+s"(p), [t] "+s"(t), [ppv] "+v"(ppv), [m] "=&s"(m), [rest] "=&s"(rest), [tmp] "=&s"(tmp), [km0] "=&s"(keep_m0)
+      : [EA] "s"(EA), [OA] "s"(OA), [EB] "s"(EB), [OB] "s"(OB), [top] "s"(top)
+      : "scc");
+#endif
+}
+
 // a value every lane of the chain holds alike; for a chain on a whole wave (G >= 64) it is moved to a scalar register, so that what is
 // derived from it (table addresses, loop counters, branch conditions) runs on the scalar unit beside the vector work
 template <int G>
@@ -580,6 +635,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // GROUP-LOCAL kernel (GL; amwg_gl.h has the method and its order of additions): the named parameters are walked in the shuffled order
   // as always, mu and sigma by the ordinary stepper with the group-local evaluation, and the Gn components of theta in ONE lane-parallel
   // sweep.  Same uniforms for the same purposes in the same order as the sequential stepper (oracle: gl_evaluate).
+#ifndef AMWG_X_GLCUT
+#define AMWG_X_GLCUT 0      // development experiments (wrong results): leave one piece of the group-local step out, to price it (tools/dev/gl_cuts.sh)
+#endif
   if constexpr (GL) {
     static_assert(G == 64, "the group-local kernel runs a chain on one whole wavefront");
     typename Model::Lane gl;
@@ -596,6 +654,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         const int base = __builtin_amdgcn_readfirstlane(pl_base[p]);
         if (__builtin_amdgcn_readfirstlane(pl_multidim[p]) == 0) {
           // ---- mu or sigma: OnedimMetropolisStepper.step (mcmc.js:517-553) with the group-local evaluation
+          if (AMWG_X_GLCUT == 6) continue;
           const int comp = base;
           const bool is_mu = comp == Gn;
           const double cur = is_mu ? gl.mu : gl.sigma;
@@ -611,10 +670,17 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           if (inb) {
             const double u_accept = rng.next();
             const double prop_lp = Model::template eval_scalar<kPassU>(gl, is_mu, prop, a.mc, a.d, data_lds, lane64);
+            // Math.exp(diff) > u (mcmc.js:527-528), decided without the exponential where 1 + d <= exp(d) <= 1 + d + d*d/2 (d < 0) already tells (see the
+            // ordinary stepper below): every lane of the wavefront holds the same chain, so skipping it here really skips it
             const double diff = prop_lp - lp_curr;
             if (diff >= 0.0) accepted = true;
             else if (diff < -746.0) accepted = false;
-            else accepted = exp_v8(diff) > u_accept;
+            else {
+              const double lower = 1.0 + diff;
+              if (u_accept < lower - 0x1p-50) accepted = true;
+              else if (diff > -1.0 && u_accept > (lower + 0.5 * diff * diff) + 0x1p-50) accepted = false;
+              else accepted = exp_v8(diff) > u_accept;
+            }
             if (accepted) { lp_curr = prop_lp; Model::commit_scalar(gl, is_mu, prop); Sme[comp] = prop; }
             if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
@@ -624,6 +690,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         // ---- theta.  A fresh shuffle of the order (mcmc.js:248-252): the Fisher-Yates loop i = top-1 .. 1 draws one uniform per round, i.e. the
         // next top - 1 uniforms of the stream -- lane i fetches and scales ITS one, then the transpositions (i, j_i) are applied in sequence to
         // every lane's POSITION in the order (lane c < top tracks where component c sits).
+        if (AMWG_X_GLCUT == 9) continue;
         const int top = Gn;
         uint32_t p_s = rng.position();                          // < 128: once its second half is there the window reaches at least 128 uniforms ahead
         rng.ensure_b();
@@ -634,9 +701,20 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           jv = (int)__builtin_floor(u * (double)(lane64 + 1));
         }
         int posc = lane64;
-        for (int i = top - 1; i > 0; --i) {
-          const int j = __builtin_amdgcn_readlane(jv, i);
-          posc = posc == i ? j : (posc == j ? i : posc);
+        if (AMWG_X_GLCUT != 1) {
+          // (four transpositions per trip, their j's read ahead of the dependent selects: the chain posc -> compare -> select is all that is serial)
+          int i = top - 1;
+          for (; i >= 4; i -= 4) {
+            const int j0 = __builtin_amdgcn_readlane(jv, i), j1 = __builtin_amdgcn_readlane(jv, i - 1), j2 = __builtin_amdgcn_readlane(jv, i - 2), j3 = __builtin_amdgcn_readlane(jv, i - 3);
+            posc = posc == i ? j0 : (posc == j0 ? i : posc);
+            posc = posc == i - 1 ? j1 : (posc == j1 ? i - 1 : posc);
+            posc = posc == i - 2 ? j2 : (posc == j2 ? i - 2 : posc);
+            posc = posc == i - 3 ? j3 : (posc == j3 ? i - 3 : posc);
+          }
+          for (; i > 0; --i) {
+            const int j = __builtin_amdgcn_readlane(jv, i);
+            posc = posc == i ? j : (posc == j ? i : posc);
+          }
         }
         p_s += (uint32_t)(top - 1);
         // my component's place in the order, and -- lane t -- the component at place t
@@ -660,9 +738,15 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           const int top_s = __builtin_amdgcn_readfirstlane(top);
           uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p_s);
           int t = __builtin_amdgcn_readfirstlane(t_begin);
+          if (!bounded && AMWG_X_GLCUT != 2) {
+            // every proposal draws its accept uniform (no bounds): the loop as ~17 scalar instructions + one v_writelane per update.  (The
+            // compiler's version of the general loop below kept its flags in vector registers and branched a dozen times per update: 16 vector +
+            // 30 scalar instructions per update, a sixth of the whole step.)
+            gl_resolve_unbounded(EA, OA, EB, OB, p, t, top_s, ppv);
+          } else
           for (; t < top_s; ++t) {
-            bool found = false;
-            while (p < 256u) {
+            bool found = AMWG_X_GLCUT == 2 && p < 250u;
+            while (AMWG_X_GLCUT != 2 && p < 256u) {
               const uint32_t par = p & 1u, idx = (p & 127u) >> 1;
               const uint64_t m = (p & 128u) ? (par ? OB : EB) : (par ? OA : EA);
               const uint64_t rest = m >> idx;
@@ -672,18 +756,18 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
             }
             if (!found) break;
             ppv = write_lane(ppv, (int)p, t);
-            uint32_t adv = 3u;
-            if (bounded) {
-              const int ck = __builtin_amdgcn_readlane(ordv, t);
-              const int fl = __builtin_amdgcn_readlane(first_of, ck);
-              adv = ((assume >> fl) & 1ull) ? 3u : 2u;
-            }
-            p += adv;
+            const int ck = __builtin_amdgcn_readlane(ordv, t);
+            const int fl = __builtin_amdgcn_readlane(first_of, ck);
+            p += ((assume >> fl) & 1ull) ? 3u : 2u;
           }
           const int t_end = t;
           // -- every lane: the proposal of its own group
           const bool in_round = gl.grp >= 0 && pos_l >= t_begin && pos_l < t_end;
-          const uint32_t q_l = in_round ? (uint32_t)__shfl(ppv, pos_l, 64) : 0u;
+          // (the shuffle is done by ALL lanes, before the select: inside a conditional expression it runs with the other lanes masked off, and a lane
+          // that reads from a masked-off lane gets 0 -- which is what a sweep that needs a second window then read)
+          int q_raw = __shfl(ppv, pos_l, 64);
+          asm volatile("" : "+v"(q_raw));
+          const uint32_t q_l = in_round ? (uint32_t)q_raw : 0u;
           const double u = rng.at(q_l), v_raw = rng.at(q_l + 1u), u_accept = rng.at(q_l + 2u);
           const double cur = gl.th;
           double prop = ((1.7156 * (v_raw - 0.5)) / u) * sd_l + cur;       // rnorm_js: (v / u) * sd + mean
@@ -703,10 +787,10 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           if (eval) {
             if (delta >= 0.0) accepted = true;
             else if (delta < -746.0) accepted = false;
-            else accepted = exp_v8(delta) > u_accept;
+            else accepted = AMWG_X_GLCUT == 4 ? false : exp_v8(delta) > u_accept;
           }
           Model::sweep_commit(gl, accepted, prop, Ls_t);
-          if (gl.first && in_round) {            // one lane per component: state, run totals, adaptation
+          if (AMWG_X_GLCUT != 8 && gl.first && in_round) {            // one lane per component: state, run totals, adaptation
             if (accepted) Sme[comp_l] = prop;
             if (inb) TOTme[comp_l] += 1u + (accepted ? 0x10000u : 0u);
             if (adapting_l) adapt_component(comp_l, accepted, CNTme[comp_l], bs_l, live);

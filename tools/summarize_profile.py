@@ -18,6 +18,8 @@ m = re.match(r"amwg_step_kernel<(\w+),(\d+)(?:,(\d+))?>", bench["roofline"]["ker
 workload = re.search(r"--workload (\w+)", open(os.path.join(src, "command.txt")).read() if os.path.exists(os.path.join(src, "command.txt")) else "")
 workload = workload.group(1) if workload else "cfg2"
 is_bench_kernel = lambda name: ("amwg_step_kernel" in name and re.search(r"%s,\s*%s(,\s*\d+)?>" % (m.group(1), m.group(2)), name) is not None)
+if "--group-local" in (open(os.path.join(src, "command.txt")).read() if os.path.exists(os.path.join(src, "command.txt")) else ""):
+    is_bench_kernel = lambda name: "amwg_gl_kernel" in name      # the group-local evaluation is its own kernel since round 4 (csrc/amwg_gl.h)
 pmc = {}
 meta = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
