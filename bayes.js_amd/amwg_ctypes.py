@@ -45,7 +45,7 @@ class UserModel(C.Structure):
                 ("parallel", C.c_int32), ("max_threads", C.c_int32), ("work_per_eval", C.c_double), ("work_one_lane", C.c_double)]
 
 
-EXPORTS = ["amwg_code_cache_stats", "amwg_tuning", "amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_fetch_draws_slices", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state", "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components", "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp", "amwg_log", "amwg_uniform"]      # include/amwg.h: the product library
+EXPORTS = ["amwg_group_gather_draws", "amwg_group_comm_info", "amwg_comm_unique_id", "amwg_comm_create", "amwg_comm_info", "amwg_comm_gather_draws", "amwg_comm_moments", "amwg_comm_destroy", "amwg_code_cache_stats", "amwg_tuning", "amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_fetch_draws_slices", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state", "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components", "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp", "amwg_log", "amwg_uniform"]      # include/amwg.h: the product library
 SELFTEST_EXPORTS = ["amwg_math1", "amwg_math2", "amwg_hypot3", "amwg_log1p", "amwg_expm1", "amwg_two_valued_sum_check", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_device_eval"]      # include/amwg_selftest.h: libamwg_selftest.so only
 
 _lib = None
@@ -101,6 +101,14 @@ def lib():
         L.amwg_group_moments.argtypes = [pvp, i32, pd, pd]
         L.amwg_group_diagnostics.argtypes = [pvp, i32, pd, pd]
         L.amwg_group_quantiles.argtypes = [pvp, i32, pd, i32, pd]
+        L.amwg_group_gather_draws.argtypes = [pvp, i32, i32, vp, pd, C.c_size_t, pi64]
+        L.amwg_group_comm_info.argtypes = [pvp, i32, pi32, pi32, i32]
+        L.amwg_comm_unique_id.argtypes = [C.c_char_p, C.c_size_t]
+        L.amwg_comm_create.argtypes = [C.c_char_p, C.c_size_t, i32, i32, i32, pvp]
+        L.amwg_comm_info.argtypes = [vp, pi32, pi32, pi32]
+        L.amwg_comm_gather_draws.argtypes = [vp, vp, i32, vp, C.c_size_t, pi64]
+        L.amwg_comm_moments.argtypes = [vp, vp, pd, pd]
+        L.amwg_comm_destroy.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -371,6 +379,64 @@ def group_quantiles(samplers, probs):
     out = np.empty((PR, pr.size))
     _check(lib().amwg_group_quantiles(arr, n, _dp(pr), pr.size, _dp(out)))
     return out
+
+
+def group_gather_draws(samplers, root=0, dst_device=None, to_host=True):
+    """amwg_group_gather_draws: the recorded draws of every shard on the device of shard `root`, blocks back to back in shard order
+    -> (list of per-shard arrays [kept][P + derived][chains_i] if to_host else None, offsets)"""
+    arr, n, PR = _group(samplers)
+    rows = samplers[0]._pending
+    sizes = [rows * PR * s.C for s in samplers]
+    total = sum(sizes)
+    host = np.empty(total, dtype=np.float64) if to_host else None
+    offs = (C.c_int64 * n)()
+    _check(lib().amwg_group_gather_draws(arr, n, root, C.c_void_p(dst_device) if dst_device else None, _dp(host) if to_host else None, total * 8, offs))
+    blocks = None
+    if to_host:
+        blocks = [host[offs[i]:offs[i] + sizes[i]].reshape(rows, PR, samplers[i].C) for i in range(n)]
+    return blocks, list(offs)
+
+
+def group_comm_info(samplers):
+    arr, n, _ = _group(samplers)
+    nr = C.c_int32()
+    devs = (C.c_int32 * max(n, 1))()
+    _check(lib().amwg_group_comm_info(arr, n, C.byref(nr), devs, n))
+    return {"rccl_ranks_seen": nr.value, "devices": [devs[i] for i in range(min(n, nr.value))]}
+
+
+class Comm:
+    """A communicator over the processes of a one-process-per-device job (amwg_comm_*).  `exchange(id_bytes_or_None) -> id_bytes` carries rank 0's
+    128-byte id to every rank (e.g. a torch.distributed broadcast)."""
+
+    def __init__(self, n_ranks, rank, device, exchange):
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _check(lib().amwg_comm_unique_id(buf, 128))
+        ident = exchange(buf.raw if rank == 0 else None)
+        h = C.c_void_p()
+        _check(lib().amwg_comm_create(ident, len(ident), n_ranks, rank, device, C.byref(h)))
+        self.h, self.n_ranks, self.rank = h, n_ranks, rank
+
+    def info(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().amwg_comm_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"rccl_ranks_seen": a.value, "rank": b.value, "device": c.value}
+
+    def gather_draws(self, sampler, root, dst_device_ptr, capacity_bytes):
+        counts = (C.c_int64 * self.n_ranks)()
+        _check(lib().amwg_comm_gather_draws(sampler.h, self.h, root, C.c_void_p(dst_device_ptr) if dst_device_ptr else None, capacity_bytes, counts))
+        return list(counts)
+
+    def moments(self, sampler):
+        m, s = np.empty(sampler.PR), np.empty(sampler.PR)
+        _check(lib().amwg_comm_moments(sampler.h, self.h, _dp(m), _dp(s)))
+        return m, s
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().amwg_comm_destroy(self.h)
+            self.h = None
 
 
 def code_cache_stats():

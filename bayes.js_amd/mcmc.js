@@ -147,8 +147,8 @@ function componentOptions(name, param, options) {
 // ---------------------------------------------------------------------------------------------
 function toF64(a) { return a instanceof Float64Array ? a : Float64Array.from(a); }
 
-function buildModelDesc(recog, data) {
-  const parts = recog.extract(data);
+function buildModelDesc(recog, data, params) {
+  const parts = recog.extract(data, params);
   const family = recog.family;
   const hyper = new Float64Array(8);
   recog.hyper.forEach((v, i) => { hyper[i] = v; });
@@ -191,6 +191,17 @@ function AmwgSampler(params, log_post, data, options) {
   // a recognised family whose parameters are declared in another order than the hand-written kernel lays them out (the reference
   // accepts any order, only the stepper order depends on it, mcmc.js:839): translate the closure like any other
   if (recog && recog.paramNames && recog.paramNames.join() !== this.param_names.join()) recog = null;
+  // the hierarchical family recognised from a closure's source: its loop over the group means must cover exactly the declared components
+  // and every label must name one of them -- anything else is some other model, and is translated
+  if (recog && recog.dimCheck) {
+    let ok = false;
+    try {
+      const parts = recog.extract(data, this.params), p = this.params[recog.dimCheck.name];
+      ok = !!p && p.dim.length === 1 && p.dim[0] === parts.G && parts.x && parts.g && parts.x.length === parts.g.length && parts.G >= 2 &&
+           Array.prototype.every.call(parts.g, (v) => Number.isInteger(v) && v >= 0 && v < parts.G);
+    } catch (e) { ok = false; }
+    if (!ok) recog = null;
+  }
   this.model = recog ? recog.family : 'translated';
 
   // flatten params / init / options in Object.keys order (the stepper order of mcmc.js:839)
@@ -233,7 +244,7 @@ function AmwgSampler(params, log_post, data, options) {
   // the model: a built-in family, or the closure translated to HIP (compiled by the addon with hiprtc)
   let desc = null, user = null;
   this.derived = [];
-  if (recog) desc = buildModelDesc(recog, data);
+  if (recog) desc = buildModelDesc(recog, data, this.params);
   else {
     const tr = translator.translate(log_post, translatedParams, data, { constants: options.constants, helpers: options.helpers,
       lds_budget: options.lds_budget, max_threads: options.max_threads, unroll: options.unroll, state_object: shared ? shared.state : undefined });

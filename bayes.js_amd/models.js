@@ -116,7 +116,7 @@ function parseClosure(src) {
   if (!eat('{')) return null;
   const aliases = {};          // var n = data.x.length  -> aliases.n = {len: ['x']}
   let acc = null;
-  const priors = []; let lik = null;
+  const priors = []; let lik = null, ploop = null;
 
   function path() {            // ID(.ID)*  -> [ids]
     const first = id(); if (!first) return null;
@@ -131,7 +131,19 @@ function parseClosure(src) {
     if (neg) return null;
     const p = path(); if (!p) return null;
     let index = null;
-    if (eat('[')) { index = (i < tk.length && tk[i].t === 'num') ? tk[i++].v : id(); if (index === null || !eat(']')) return null; }
+    if (eat('[')) {
+      if (i < tk.length && tk[i].t === 'num') index = tk[i++].v;
+      else {
+        const q = path(); if (!q) return null;
+        if (q.length === 1 && !peek('[')) index = q[0];                       // S.theta[k]
+        else {                                                                // S.theta[D.g[i]]: a label looked up in the data, by the loop variable
+          if (!D || q[0] !== D || q.length < 2 || !eat('[')) return null;
+          const inner = id(); if (!inner || inner !== loopVar || !eat(']')) return null;
+          index = { k: 'label', field: q.slice(1) };
+        }
+      }
+      if (index === null || !eat(']')) return null;
+    }
     if (p[0] === S && p.length === 2) return { k: 'state', name: p[1], index };
     if (D && p[0] === D && index === loopVar && loopVar) return { k: 'data', field: p.slice(1) };
     return null;
@@ -162,25 +174,40 @@ function parseClosure(src) {
       const lv = id(); if (!lv || !eat('=')) return null;
       if (!(tk[i].t === 'num' && tk[i].v === 0)) return null; i++;
       if (!eat(';') || id() !== lv || !eat('<')) return null;
-      let bound = path(); if (!bound) return null;
-      if (bound.length === 1 && aliases[bound[0]]) bound = aliases[bound[0]];
-      else if (bound[0] === D && bound[bound.length - 1] === 'length') bound = bound.slice(1, -1);
-      else return null;
+      // the bound: D.x.length (or an alias of it) = the loop over the observations; S.theta.length, D.G or a number = a loop over the
+      // components of a parameter (the group means' prior of the hierarchical family), allowed once, before the data loop
+      let bound = null, over_param = null;
+      if (i < tk.length && tk[i].t === 'num') over_param = { k: 'num', v: tk[i++].v };
+      else {
+        bound = path(); if (!bound) return null;
+        if (bound.length === 1 && aliases[bound[0]]) bound = aliases[bound[0]];
+        else if (bound[0] === D && bound[bound.length - 1] === 'length') bound = bound.slice(1, -1);
+        else if (bound[0] === S && bound.length === 3 && bound[2] === 'length') { over_param = { k: 'len', name: bound[1] }; bound = null; }
+        else if (D && bound[0] === D && bound.length >= 2) { over_param = { k: 'field', field: bound.slice(1) }; bound = null; }
+        else return null;
+      }
       if (!eat(';') || id() !== lv || !eat('++') || !eat(')')) return null;
       const braced = eat('{');
       const c = accumulate(lv); if (!c) return null;
       if (braced && !eat('}')) return null;
+      if (over_param) {
+        if (ploop) return null;
+        const a0 = c.args[0];
+        if (!a0 || a0.k !== 'state' || a0.index !== lv) return null;          // the loop variable indexes the parameter: S.theta[k]
+        ploop = { call: c, count: over_param };
+        continue;
+      }
       lik = { call: c, over: bound };
     } else if (eat('return')) {
       if (id() !== acc) return null; eat(';');
     } else {
       const c = accumulate(null); if (!c) return null;
-      if (lik) return null;          // priors must come before the data loop (summation order)
+      if (lik || ploop) return null;          // scalar priors come first, then the loop over a parameter's components, then the data loop (summation order)
       priors.push(c);
     }
   }
   if (!eat('}') || i !== tk.length || !acc || !lik) return null;
-  return { priors, lik };
+  return { priors, lik, ploop };
 }
 
 const isNum = (a) => a && a.k === 'num';
@@ -192,10 +219,36 @@ function recognise(fn) {
   if (fn.amwg) return fn.amwg;
   const ast = parseClosure(Function.prototype.toString.call(fn));
   if (!ast) return null;
-  const { priors, lik } = ast, L = lik.call, field = lik.over;
+  const { priors, lik, ploop } = ast, L = lik.call, field = lik.over;
   const dataArg = L.args[0];
   if (!dataArg || dataArg.k !== 'data' || dataArg.field.join('.') !== field.join('.')) return null;
-  const extract = (d) => { let v = d; for (const f of field) v = v[f]; return { x: v }; };
+  const dig = (d, f) => { let v = d; for (const q of f) v = v[q]; return v; };
+  const extract = (d) => ({ x: dig(d, field) });
+  if (ploop) {
+    // the hierarchical Normal family written out (SURVEY.md section 8(d) cfg4; the order of the terms is the kernel's: the prior of the
+    // location, the prior of the scale, the group means' prior in a loop, the observations):
+    //     lp += ld.norm(S.mu, m0, s0); lp += ld.unif(S.sigma, a, b);
+    //     for (k < G) lp += ld.norm(S.theta[k], S.mu, tau);
+    //     for (i < D.y.length) lp += ld.norm(D.y[i], S.theta[D.g[i]], S.sigma);
+    const Q = ploop.call;
+    if (priors.length !== 2 || L.dist !== 'norm' || L.args.length !== 3 || Q.dist !== 'norm' || Q.args.length !== 3) return null;
+    const [p0, p1] = priors, mean = L.args[1], sd = L.args[2], th = Q.args[0];
+    if (!(p0.dist === 'norm' && p1.dist === 'unif' && p0.args.length === 3 && p1.args.length === 3 && isState(p0.args[0]) && isState(p1.args[0]) &&
+          isNum(p0.args[1]) && isNum(p0.args[2]) && isNum(p1.args[1]) && isNum(p1.args[2]))) return null;
+    if (!(mean && mean.k === 'state' && mean.index && mean.index.k === 'label' && isState(sd) && sd.name === p1.args[0].name)) return null;
+    if (!(th.name === mean.name && isState(Q.args[1]) && Q.args[1].name === p0.args[0].name && isNum(Q.args[2]))) return null;
+    if (ploop.count.k === 'len' && ploop.count.name !== th.name) return null;
+    const gField = mean.index.field, count = ploop.count;
+    return { family: 'hier_normal', hyper: [p0.args[1].v, p0.args[2].v, p1.args[1].v, p1.args[2].v, Q.args[2].v],
+             paramNames: [th.name, p0.args[0].name, p1.args[0].name],
+             // the loop bound is the number of group means the closure adds prior terms for: it must be the parameter's dim (checked by the caller
+             // through G against the declared params; a closure that loops over fewer components is not this family)
+             extract: (d, params) => {
+               const G = count.k === 'num' ? count.v : (count.k === 'field' ? dig(d, count.field) : (params && params[th.name] ? params[th.name].dim[0] : undefined));
+               return { x: dig(d, field), g: dig(d, gField), G };
+             },
+             dimCheck: { name: th.name, count } };
+  }
   if (L.dist === 'norm' && L.args.length === 3 && isState(L.args[1]) && isState(L.args[2]) && priors.length === 2) {
     const [p0, p1] = priors;   // the closure's own order: norm prior on the mean, then unif prior on the sd
     if (p0.dist === 'norm' && p1.dist === 'unif' && isState(p0.args[0]) && isState(p1.args[0]) &&

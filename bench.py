@@ -427,8 +427,8 @@ def main_inproc(args):
     base = {"metric": "posterior draws/sec (= param-updates/sec)", "unit": "param-updates/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "inproc": True}
     if have < N:
-        print(json.dumps(dict(base, value=None, ms_per_step=None, config={"workload": args.workload},
-                              note="not measured: --inproc --gpus %d needs %d visible devices, this box has %d" % (N, N, have))), flush=True)
+        emit(dict(base, value=None, ms_per_step=None, config={"workload": args.workload},
+                  note="not measured: --inproc --gpus %d needs %d visible devices, this box has %d" % (N, N, have)))
         return
     if args.workload == "cfg2":
         spec, per_gpu, label, n_obs, ops_per_obs = normal_spec(), CHAINS_PER_GPU, "BASELINE.json configs[1]: Normal(mu,sigma) AMWG, 1e4 synthetic obs", N_OBS, 8
@@ -458,7 +458,8 @@ def main_inproc(args):
             s.sample_async(K, thin)            # draws stay in each device's HBM
         for s in shards:
             s.sync()
-        mean, sd = A.group_moments(shards)     # the one exchange of the job: per-device sums, RCCL all-reduce (inside the library)
+        A.group_gather_draws(shards, root=0, to_host=False)      # the gather at sample collection: every shard's block to device 0 (amwg_group_gather_draws: grouped ncclSend / ncclRecv)
+        mean, sd = A.group_moments(shards)     # per-device sums, RCCL all-reduce (inside the library)
         return time.perf_counter() - t0, mean, sd
     regs = [region()]
     n_regions = 1 if args.single_region else int(min(400, max(3, np.ceil(args.min_seconds / max(regs[0][0], 1e-6)))))
@@ -469,23 +470,60 @@ def main_inproc(args):
     value = total * K * P / dt
     kernel_ms = max(s.launch_info()["kernel_ms"] for s in shards)
     li = shards[0].launch_info()
+    # how the draws reach the HOST: what the Node front-end does (every device copies its own block: N PCIe links in parallel) against
+    # gather-to-one-device-then-one-copy (north_star's wording); both once, outside the timed regions
+    collection = {}
+    t0 = time.perf_counter()
+    for s in shards:
+        s.fetch_draws()
+    collection["per_device_copy_ms"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    A.group_gather_draws(shards, root=0, to_host=True)
+    collection["gather_then_one_copy_ms"] = (time.perf_counter() - t0) * 1e3
+    collection["bytes"] = sum(s._pending * s.PR * s.C * 8 for s in shards)
+    comm = A.group_comm_info(shards)
     lane_ops = value * n_obs * ops_per_obs * ((2.0 / P) if args.group_local else 1.0)
     out = dict(base, value=value, ms_per_step=dt * 1e3 / K,
                config={"workload": label + (" -- GROUP-LOCAL evaluation" if args.group_local else ""), "n_obs": n_obs, "chains_total": total,
                        "chains_per_gpu": [s.C for s in shards], "components": P, "thin": thin, "lanes_per_chain": li["lanes_per_chain"],
                        "block_threads": li["block_threads"], "steps_per_launch": args.steps_per_launch,
-                       "path": "one process, one sampler per device (amwg_sample_async x N + amwg_sync), summaries by amwg_group_moments (RCCL all-reduce in the library)"},
-               timing={"regions": len(regs), "reported": "median region (wall clock around sample_async x N + sync x N + group_moments)",
+                       "path": "one process, one sampler per device (amwg_sample_async x N + amwg_sync), the recorded draws gathered to device 0 by amwg_group_gather_draws, summaries by amwg_group_moments (RCCL inside the library)",
+                       "rccl_ranks_seen": comm["rccl_ranks_seen"], "devices": comm["devices"], "collection_to_host": collection},
+               timing={"regions": len(regs), "reported": "median region (wall clock around sample_async x N + sync x N + group_gather_draws + group_moments)",
                        "region_ms": [r[0] * 1e3 for r in regs][:64], "slowest_device_kernel_ms_last_region": kernel_ms},
                roofline={"bound": "fp64_valu", "achieved": lane_ops, "peak": FP64_VALU_PEAK * N, "frac": lane_ops / (FP64_VALU_PEAK * N),
                          "unit": "fp64 lane-operations/s", "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[spec["model"]]},
                posterior={"mean": mean.tolist()[:8], "sd": sd.tolist()[:8], "note": "amwg_group_moments over the recorded draws of all shards (last region)"})
-    print(json.dumps(out), flush=True)
+    emit(out)
     for s in shards:
         s.close()
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries loaded into this process write there too -- RCCL prints a five-line version banner
+    through C stdio when a communicator is created, which lands AFTER the line when stdout is a pipe -- so file descriptor 1 is pointed at
+    stderr for the whole run and emit() writes the line to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def main():
+    claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -500,7 +538,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--group-local", action="store_true", help="cfg4 only: the opt-in group-local evaluation (amwg_options::group_local)")
     ap.add_argument("--inproc", action="store_true", help="the product's own multi-device path: one process, one sampler per device, amwg_group_moments (see main_inproc)")
-    ap.add_argument("--strong", action="store_true", help="--inproc only: keep the job's total chain count and split it over the devices")
+    ap.add_argument("--strong", action="store_true", help="keep the job's TOTAL chain count (cfg4: 16 384, cfg5: 65 536, cfg2: 65 536, cfg3: 262 144) and split it over the GPUs; the default for cfg4 / cfg5, which is how BASELINE.json states them")
+    ap.add_argument("--weak", action="store_true", help="the workload's chains per GPU on every GPU (the default for cfg2 / cfg3: 65 536 / 262 144 per GPU)")
+    ap.add_argument("--torch-gather", action="store_true", help="N > 1: gather the draws with torch.distributed instead of the library's own communicator (amwg_comm_*)")
     ap.add_argument("--no-parity", action="store_true", help="profiling runs only: skip the golden schedule on the timed sampler (its launches record every draw)")
     ap.add_argument("--no-js", action="store_true", help="skip the end-to-end run through the JavaScript host (bench/js_e2e.js)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short measurements of cfg3 / cfg4 / cfg5 appended to the default line")
@@ -509,6 +549,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "readme"],
                     help="cfg2 (default) is the bench line; the others measure the remaining BASELINE.json configs")
     args = ap.parse_args()
+    if not args.strong and not args.weak and args.workload in ("cfg4", "cfg5"):
+        args.strong = True      # BASELINE.json: "16 384 chains sharded over 8 MI355X", "65 536 chains over 8 MI355X"
 
     if args.inproc:
         return main_inproc(args)
@@ -528,6 +570,13 @@ def main():
     # N-rank code path on a box with a single GPU (ranks share cuda:0, gather goes through host memory).
     backend = os.environ.get("AMWG_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("AMWG_BENCH_ONE_DEVICE") == "1" else local_rank
+    if os.environ.get("AMWG_BENCH_ONE_DEVICE") != "1" and world > torch.cuda.device_count():
+        if rank == 0:
+            emit({"metric": "posterior draws/sec (= param-updates/sec)", "value": None, "unit": "param-updates/s", "n_gpus": world, "steps": args.steps,
+                  "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+                  "dtype": "f64", "data": "synthetic", "config": {"workload": args.workload},
+                  "note": "not measured: --gpus %d needs %d visible devices, this box has %d" % (world, world, torch.cuda.device_count())})
+        return
     torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
@@ -550,7 +599,13 @@ def main():
         if args.chains_per_gpu == CHAINS_PER_GPU:
             args.chains_per_gpu = default_chains
     chains = args.chains_per_gpu
-    offset, _ = chain_shard(rank, world, chains * world)
+    total_job = {"cfg2": CHAINS_PER_GPU, "cfg3": 262_144, "cfg4": 16_384, "cfg5": 65_536, "readme": 1}[args.workload]
+    if args.strong:      # the job's total chain count, split: rank r gets a contiguous shard (sizes differ by at most one)
+        offset, chains = chain_shard(rank, world, total_job)
+        total_chains_job = total_job
+    else:
+        offset, _ = chain_shard(rank, world, chains * world)
+        total_chains_job = chains * world
     mk = lambda off: A.Sampler(spec, chains=chains, seed=SEED, chain_offset=off, device=dev_index, group_local=int(args.group_local),
                                lanes_per_chain=args.lanes, block_threads=args.block, steps_per_launch=args.steps_per_launch)
     parity = None
@@ -565,7 +620,33 @@ def main():
     P, K, W, thin = spec["P"], args.steps, args.warmup, max(1, args.thin)
     rows = -(-K // thin)
     draws = torch.empty((rows, P, chains), dtype=torch.float64, device="cuda")
-    gathered = [torch.empty(draws.shape, dtype=draws.dtype, device=coll_dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # The gather at sample collection is the LIBRARY's (amwg_comm_*: a communicator over the ranks from a shared id, grouped ncclSend / ncclRecv of
+    # every rank's block to rank 0) -- what a one-process-per-device host of the product calls; torch.distributed only carries the 128-byte id,
+    # the barriers and the max-over-ranks of the timing.  --torch-gather (or a failure to build the communicator, recorded in the line) times
+    # torch's gather of the same blocks instead.
+    comm, comm_error, comm_info = None, None, None
+    if backend == "nccl" and not args.torch_gather:
+        def exchange(ident):
+            if dist is None:
+                return ident
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        try:
+            comm = A.Comm(world, rank, dev_index, exchange)
+            comm_info = comm.info()
+        except Exception as e:      # the headline must not be lost to a communicator that cannot be built (the reason is printed)
+            comm, comm_error = None, repr(e)
+        if dist is not None:      # all ranks or none
+            ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 0 and comm is not None:
+                comm.close()
+                comm, comm_error = None, "another rank could not build the communicator"
+    gather_elems = rows * P * total_chains_job
+    gathered_lib = torch.empty(gather_elems, dtype=torch.float64, device="cuda") if (comm is not None and rank == 0) else None
+    shard_sizes = [chain_shard(r, world, total_chains_job)[1] for r in range(world)] if args.strong else [chains] * world
+    gathered = [torch.empty((rows, P, shard_sizes[r]), dtype=draws.dtype, device=coll_dev) for r in range(world)] if (comm is None and world > 1 and rank == 0) else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -582,8 +663,10 @@ def main():
         t0 = time.perf_counter()
         s.sample_device(K, thin, draws.data_ptr(), draws.numel() * 8)
         s.sync()
-        if dist is not None:
-            gather_draws(dist, draws if coll_dev == "cuda" else draws.cpu(), gathered, rank, equal_sizes=True)
+        if comm is not None:
+            comm.gather_draws(s, 0, gathered_lib.data_ptr() if rank == 0 else 0, gather_elems * 8)
+        elif dist is not None:
+            gather_draws(dist, draws if coll_dev == "cuda" else draws.cpu(), gathered, rank, equal_sizes=len(set(shard_sizes)) == 1)
         barrier()
         dt = time.perf_counter() - t0
         kms = s.launch_info()["kernel_ms"]
@@ -609,8 +692,14 @@ def main():
     from shard import pooled_moments
     pooled = pooled_moments(dist, draws if (dist is None or coll_dev == "cuda") else draws.cpu())
 
+    lib_moments = comm.moments(s) if comm is not None else None      # collective: the library's all-reduce twin of pooled_moments
+    rank_devices = [dev_index]
+    if dist is not None:
+        box = [None] * world
+        dist.all_gather_object(box, {"rank": rank, "device": dev_index, "chains": chains, "rccl": comm_info})
+        rank_devices = box
     if rank == 0:
-        total_chains = chains * world
+        total_chains = total_chains_job
         value = total_chains * K * P / dt
         launches = max(1, li["n_launches"])
         launch_s = kernel_ms * 1e-3 / launches
@@ -619,6 +708,11 @@ def main():
         mean, sd = (s.moments() if dist is None else (pooled[0].cpu().numpy(), pooled[1].cpu().numpy()))
         pm = pooled[0].cpu().numpy()
         assert dist is not None or np.allclose(pm, mean, rtol=1e-10, atol=0), "library moments differ from the pooled restatement"
+        if lib_moments is not None:
+            assert np.allclose(lib_moments[0], pm, rtol=1e-9, atol=1e-300), "amwg_comm_moments differs from the pooled restatement"
+            if gathered_lib is not None:      # rank 0's own block is where its rank says (blocks back to back in rank order)
+                own = gathered_lib[: rows * P * chains].view(rows, P, chains)
+                assert torch.equal(own, draws), "amwg_comm_gather_draws: rank 0's block is not where it belongs"
         measured_peak = A.fp64_peak(dev_index)      # register-only fma kernel: what the chip sustains under fp64 load
         x = spec["data"]["x"]
         version = A.lib().amwg_version().decode()
@@ -646,13 +740,16 @@ def main():
         out = {
             "metric": "posterior draws/sec (= param-updates/sec)", "value": value, "unit": "param-updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt * 1e3 / K, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": (value / 8.0e4) if args.workload == "readme" else None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": (value / 8.0e4) if args.workload == "readme" else None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": label,
                        "n_obs": n_obs, "chains_per_gpu": chains, "chains_total": total_chains, "components": P,
                        "draws_recorded_per_chain": rows, "thin": thin, "lanes_per_chain": li["lanes_per_chain"],
                        "block_threads": li["block_threads"], "grid_blocks": li["grid_blocks"], "lds_bytes": li["lds_bytes"],
                        "steps_per_launch": args.steps_per_launch, "launches_timed": launches,
-                       "gather": ("%s gather of recorded draws to rank 0" % ("rccl" if backend == "nccl" else backend)) if world > 1 else "none (1 GPU)"},
+                       "gather": ("amwg_comm_gather_draws: the library's RCCL communicator over the %d ranks (grouped ncclSend / ncclRecv to rank 0), inside the timed region" % world) if comm is not None
+                                 else (("torch.distributed %s gather of recorded draws to rank 0" % ("rccl" if backend == "nccl" else backend)) if world > 1 else "none (1 GPU, --torch-gather or no communicator)"),
+                       "rccl_ranks_seen": (comm_info or {}).get("rccl_ranks_seen"), "rccl_note": "ncclCommCount of the library's communicator (amwg_comm_info)",
+                       "communicator_error": comm_error, "ranks": rank_devices},
             "timing": {"regions": len(regions), "reported": "median region", "region_ms": [r[0] * 1e3 for r in regions][:64],
                        "first_region_ms": regions[0][0] * 1e3, "min_region_ms": regions[order[0]][0] * 1e3, "max_region_ms": regions[order[-1]][0] * 1e3,
                        "steps_per_region": K, "note": "every region is exactly K steps between barrier + synchronize pairs; chains keep adapting across regions"},
@@ -706,8 +803,10 @@ def main():
             port_rate = (out.get("cpu_baseline_port") or out["cpu_baseline"])["value"]
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(spec, port_rate)
             out["chains_equiv"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        emit(out)
     s.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

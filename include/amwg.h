@@ -240,6 +240,35 @@ int amwg_group_moments(amwg_sampler *const *shards, int32_t n_shards, double *me
 int amwg_group_diagnostics(amwg_sampler *const *shards, int32_t n_shards, double *rhat, double *ess);
 int amwg_group_quantiles(amwg_sampler *const *shards, int32_t n_shards, const double *probs, int32_t n_probs, double *out);
 
+/* The gather at sample collection (BASELINE.json north_star: "chains shard across the GPUs of one node with an RCCL-over-xGMI gather only at
+ * sample collection").  The reference has one chain and nothing to gather: this is where `sampler.sample(n)`'s return
+ * value (mcmc.js:1005-1030) is put together for a job whose chains live on several devices.
+ *   amwg_group_gather_draws -- ONE process, one sampler per device: every shard's block of recorded draws [kept][P + derived][chains_i] of the
+ *     last sample call travels to the device of shard `root_index` (grouped ncclSend / ncclRecv over the shards' communicator; shards on the
+ *     root's own device are copied), where the blocks stand back to back in shard order -- in dst_device (on the root's device; may be null:
+ *     a scratch buffer is used) and, if dst_host is given, in ONE copy to the host.  offsets[i] (optional) = first element of shard i's block.
+ *   amwg_group_comm_info -- what the communicator says about itself: ranks (ncclCommCount) and the device of every rank. */
+int amwg_group_gather_draws(amwg_sampler *const *shards, int32_t n_shards, int32_t root_index, double *dst_device, double *dst_host,
+                            size_t capacity_bytes, int64_t *offsets);
+int amwg_group_comm_info(amwg_sampler *const *shards, int32_t n_shards, int32_t *n_ranks, int32_t *devices, int32_t capacity);
+
+/* The same exchanges for hosts that run ONE PROCESS PER DEVICE (torch.distributed.run, MPI, a process pool of Node workers): a communicator is
+ * built from a shared 128-byte id -- amwg_comm_unique_id on one rank, the bytes travel by whatever the host has, amwg_comm_create on every
+ * rank (collective) -- and then, all collective:
+ *   amwg_comm_gather_draws -- the block [kept][P + derived][chains] of this rank's last sample call travels to rank `root`, where the blocks stand
+ *     back to back in rank order in dst_device (root only).  Blocks may differ in size (uneven shards): the counts are exchanged first;
+ *     counts (optional, one entry per rank, filled on every rank) = the elements each rank contributed.
+ *   amwg_comm_moments -- mean and sd over the recorded draws of all ranks (two all-reduces of a few doubles), on every rank.
+ *   amwg_comm_info -- ranks, own rank and device AS RCCL REPORTS THEM (ncclCommCount / ncclCommUserRank / ncclCommCuDevice). */
+typedef struct amwg_comm amwg_comm;
+#define AMWG_COMM_ID_BYTES 128
+int amwg_comm_unique_id(char *id, size_t capacity);
+int amwg_comm_create(const char *id, size_t id_bytes, int32_t n_ranks, int32_t rank, int32_t device, amwg_comm **out);
+int amwg_comm_info(amwg_comm *c, int32_t *n_ranks, int32_t *rank, int32_t *device);
+int amwg_comm_gather_draws(amwg_sampler *s, amwg_comm *c, int32_t root, double *dst_device, size_t capacity_bytes, int64_t *counts);
+int amwg_comm_moments(amwg_sampler *s, amwg_comm *c, double *mean, double *sd);
+int amwg_comm_destroy(amwg_comm *c);
+
 /* AMWG_LANES_AUTOTUNE: the candidates that were timed at construction -- lanes[i] lanes per chain took ms[i] milliseconds PER STEP (the
  * fastest of several launches long enough to take >= 1 ms, after an untimed warm-up launch).  Returns the number of candidates (0 if the sampler was not autotuned); fills at most `cap` entries. */
 int amwg_tuning(const amwg_sampler *s, int32_t *lanes, double *ms, int32_t cap);

@@ -111,6 +111,21 @@ for (const bad of [function (s, d) { return Math.sin(s.x); },
   function (s, d) { var lp = 0; for (var i = 0; i < d.length; i++) { lp += ld.norm(d[i], s.mu, s.sigma); } lp += ld.norm(s.mu, 0, 100); lp += ld.unif(s.sigma, 0, 100); return lp; },  // priors after the loop: different summation order
   function (s, d) { var lp = 0; lp += ld.norm(s.mu, 0, 100); lp += ld.unif(s.sigma, 0, 100); for (var i = 0; i < d.length; i++) { lp += ld.norm(d[i], s.mu, 2 * s.sigma); } return lp; }])
   assert.strictEqual(models.recognise(bad), null);
+// the hierarchical family written out as a closure (SURVEY.md section 8(d) cfg4) is recognised from its source -- with it `options.group_local`
+// is available to a closure a user wrote, not only to mcmc.models.hier_normal() -- in its three spellings of the loop over the group means
+const hier_src = (bound) => new Function('ld', 'return function (s, d) { let lp = 0; lp += ld.norm(s.mu, 1, 50); lp += ld.unif(s.sigma, 0, 20); ' +
+  'for (let k = 0; k < ' + bound + '; k++) lp += ld.norm(s.theta[k], s.mu, 7); for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], s.sigma); return lp; }')(ld);
+const hdata = { y: [1, 2, 3, 4, 5, 6], g: [0, 1, 2, 0, 1, 2], G: 3 };
+for (const bound of ['d.G', '3', 's.theta.length']) {
+  r = models.recognise(hier_src(bound));
+  assert.deepStrictEqual([r.family, r.hyper, r.paramNames], ['hier_normal', [1, 50, 0, 20, 7], ['theta', 'mu', 'sigma']]);
+  assert.deepStrictEqual(r.extract(hdata, { theta: { dim: [3] } }), { x: hdata.y, g: hdata.g, G: 3 });
+}
+for (const bad of [
+  function (s, d) { let lp = 0; for (let k = 0; k < d.G; k++) lp += ld.norm(s.theta[k], s.mu, 7); lp += ld.norm(s.mu, 1, 50); lp += ld.unif(s.sigma, 0, 20); for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], s.sigma); return lp; },   // another order of the terms
+  function (s, d) { let lp = 0; lp += ld.norm(s.mu, 1, 50); lp += ld.unif(s.sigma, 0, 20); for (let k = 0; k < d.G; k++) lp += ld.norm(s.theta[k], s.mu, s.sigma); for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], s.sigma); return lp; },   // tau is a parameter
+  function (s, d) { let lp = 0; lp += ld.norm(s.mu, 1, 50); lp += ld.unif(s.sigma, 0, 20); for (let k = 0; k < d.G; k++) lp += ld.norm(s.theta[k], s.mu, 7); for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.eta[d.g[i]], s.sigma); return lp; }])      // the means are another parameter
+  assert.strictEqual(models.recognise(bad), null);
 // descriptor closures evaluate like the README closure on the host
 const data10 = [183, 192, 182, 183, 177, 185, 188, 188, 182, 185];
 assert.strictEqual(models.normal()({ mu: 180, sigma: 5 }, data10), readme_normal({ mu: 180, sigma: 5 }, data10));

@@ -177,4 +177,34 @@ checkAgainstGolden('glm_small', (g, rec) => new mcmc.AmwgSampler(
   s.close();
   assert.throws(() => new mcmc.AmwgSampler({ mu: {}, sigma: { lower: 0 } }, models.normal(), golden('normal_n1000').data.x, { group_local: true }), /hierarchical/);
 }
+// ---- 7. the hierarchical family WRITTEN OUT as a closure, on labels that are not i mod G and five groups: recognised from its source
+// (models.recognise), so options.group_local applies to a closure a user wrote; the same bits as the descriptor of the same model, and as
+// the translated closure (options.translate) takes the same decisions
+{
+  const G = 5, N = 333, rnd = (function () { let x = 12345; return () => { x = (x * 1103515245 + 12345) % 2147483648; return x / 2147483648; }; })();
+  const g = [], y = [];
+  for (let i = 0; i < N; i++) { const k = Math.min(G - 1, Math.floor(rnd() * rnd() * G * 1.7)); g.push(k); y.push(3 + k + 2 * (rnd() + rnd() + rnd() - 1.5)); }
+  const closure = function (s, d) {
+    let lp = 0;
+    lp += ld.norm(s.mu, 0, 100);
+    lp += ld.unif(s.sigma, 0, 100);
+    for (let k = 0; k < d.G; k++) lp += ld.norm(s.theta[k], s.mu, 10);
+    for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], s.sigma);
+    return lp;
+  };
+  const params = () => ({ theta: { type: 'real', dim: [G] }, mu: { type: 'real' }, sigma: { type: 'real', lower: 0, init: 1 } });
+  const run = (lp, opts) => {
+    const s = new mcmc.AmwgSampler(params(), lp, { y, g, G }, Object.assign({ seed: 77, chains: 3 }, opts));
+    s.burn(150);
+    const smp = s.sample(40), model = s.model, acc = flat(s.info().steppers.theta).map((o) => o.accepts);
+    s.close();
+    return { smp, model, acc };
+  };
+  const a = run(closure, { group_local: true }), b = run(models.hier_normal(), { group_local: true }), c = run(closure, { translate: true });
+  assert.strictEqual(a.model, 'hier_normal');
+  assert.strictEqual(c.model, 'translated');
+  for (const nm of ['theta', 'mu', 'sigma']) assert.deepStrictEqual(Array.from(a.smp[nm]), Array.from(b.smp[nm]));
+  assert.deepStrictEqual(a.acc, c.acc);
+  for (const nm of ['theta', 'mu', 'sigma']) assert.deepStrictEqual(Array.from(a.smp[nm]), Array.from(c.smp[nm]));      // same decisions => same draws
+}
 console.log('gpu frontend ok');

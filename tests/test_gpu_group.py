@@ -63,3 +63,55 @@ def test_group_calls_reject_mismatched_shards():
         A.group_moments([a, b])
     a.close()
     b.close()
+
+
+def test_gather_at_sample_collection_puts_every_shard_block_on_the_root_device():
+    """amwg_group_gather_draws (north_star's "RCCL gather at sample collection", one process): three shards -- here on one device, so their
+    blocks are copied; on distinct devices they travel by grouped ncclSend / ncclRecv -- stand back to back in shard order on the root's
+    device and arrive on the host in one copy, equal to what each shard returns by itself."""
+    data = model_spec.make_data("normal", 500, 3)
+    spec = model_spec.build_spec("normal", data)
+    counts, off, shards = [300, 300, 201], 0, []
+    for c in counts:
+        shards.append(A.Sampler(spec, chains=c, seed=9, chain_offset=off))
+        off += c
+    for s in shards:
+        s.burn(40)
+        s.sample_async(30, 3)
+    for s in shards:
+        s.sync()
+    blocks, offsets = A.group_gather_draws(shards, root=1)
+    assert offsets == [0, 10 * 2 * 300, 10 * 2 * 600]
+    for s, b in zip(shards, blocks):
+        assert b.tobytes() == s.fetch_draws().tobytes()
+    info = A.group_comm_info(shards)
+    assert info["rccl_ranks_seen"] == 1 and info["devices"] == [0]
+    for s in shards:
+        s.close()
+
+
+def test_one_process_per_device_communicator_with_a_single_rank():
+    """amwg_comm_*: the communicator a one-process-per-device host builds from a shared id (bench.py --gpus N under torch.distributed.run).  A
+    one-GPU box can only run it with one rank: id -> ncclCommInitRank -> what RCCL reports about it -> gather (the rank's own block lands at
+    offset 0 of the root's buffer) -> the all-reduced moments equal the sampler's own."""
+    import torch
+    data = model_spec.make_data("normal", 400, 4)
+    spec = model_spec.build_spec("normal", data)
+    s = A.Sampler(spec, chains=777, seed=5)
+    s.burn(50)
+    s.sample_async(40, 2)
+    s.sync()
+    comm = A.Comm(1, 0, 0, lambda ident: ident)
+    assert comm.info() == {"rccl_ranks_seen": 1, "rank": 0, "device": 0}
+    n = 20 * 2 * 777
+    dst = torch.full((n + 8,), -1.0, dtype=torch.float64, device="cuda")
+    assert comm.gather_draws(s, 0, dst.data_ptr(), n * 8) == [n]
+    torch.cuda.synchronize()
+    assert dst[:n].cpu().numpy().tobytes() == s.fetch_draws().tobytes() and float(dst[n]) == -1.0
+    m, sd = comm.moments(s)
+    m0, sd0 = s.moments()
+    assert np.allclose(m, m0, rtol=1e-12) and np.allclose(sd, sd0, rtol=1e-10)
+    with pytest.raises(A.AmwgError, match="holds"):
+        comm.gather_draws(s, 0, dst.data_ptr(), 16)
+    comm.close()
+    s.close()

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="${@:---steps 500 --warmup 1000}"
+ARGS="${@:---steps 500 --warmup 1000}"   # (cfg4 / cfg5: add --weak to profile the per-GPU shard of the 8-GPU job, 2 048 / 8 192 chains)
 CMD="python $R/bench.py --no-cpu-baseline --single-region --no-other-configs --no-parity $ARGS"
 echo "$CMD" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace_err.log
