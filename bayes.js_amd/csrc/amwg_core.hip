@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -331,6 +332,9 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
     const double steps = 33554432.0 / (per_step > 0 ? per_step : 1.0);
     if (steps < (double)chunk) chunk = steps < 16.0 ? 16 : (int64_t)steps;
   }
+  // the invariants the kernel relies on, enforced where the launch is made (the kernel's own guards -- device_error -- are the backstop)
+  if (s->cpb > 0 && s->block != 64) return fail(AMWG_EINVAL, "internal: %d chains per workgroup of %d threads (replicated chains need one-wavefront workgroups)", s->cpb, s->block);
+  if (chunk > 65535) return fail(AMWG_EINVAL, "internal: launches of %lld steps (at most 65535)", (long long)chunk);
   StepArgs a{};
   a.C = s->C;
   a.seed = s->opt.seed;
@@ -391,6 +395,18 @@ int finish_timing(amwg_sampler *s) {
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
   s->kernel_ms = ms;
+  // what the step kernels had to say (amwg_kernel.h device_error): a launch that refused itself, or a register mirror that no longer
+  // equals the state it mirrors, is an error of this call -- not a successful no-op
+  if (s->ch.error) {
+    int32_t bits = 0;
+    HIP_TRY(hipMemcpy(&bits, s->ch.error, sizeof bits, hipMemcpyDeviceToHost));
+    if (bits) {
+      HIP_TRY(hipMemset(s->ch.error, 0, sizeof bits));
+      return fail(AMWG_EHIP, "the step kernel reported an internal error (bits %d:%s%s%s): the chains' state is not to be trusted", bits,
+                  (bits & 1) ? " replicated chains in a workgroup of more than one wavefront" : "", (bits & 2) ? " more than 65535 steps in one launch" : "",
+                  (bits & 4) ? " the register mirror of the state is out of sync with the state" : "");
+    }
+  }
   return AMWG_OK;
 }
 
@@ -647,6 +663,7 @@ static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int
   if (wide_perm) TRYB(dev_alloc(s, &ch.perm16, (size_t)s->n_params * C));
   TRYB(dev_alloc(s, &ch.rng_n, C));
   TRYB(dev_alloc(s, &ch.lp_curr, C));
+  TRYB(dev_alloc(s, &ch.error, (size_t)1));
   {
     std::vector<double> tmp(PC);
     for (int p = 0; p < P; ++p) for (size_t c = 0; c < C; ++c) tmp[(size_t)p * C + c] = init[p];
@@ -670,6 +687,7 @@ static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int
   HIPB(hipMemset(ch.inbounds, 0, PC * 4));
   HIPB(hipMemset(ch.rng_n, 0, C * 8));
   HIPB(hipMemset(ch.lp_curr, 0, C * 8));
+  HIPB(hipMemset(ch.error, 0, sizeof(int32_t)));
   return AMWG_OK;
 }
 
@@ -714,20 +732,26 @@ std::string cache_dir() {
   if (const char *h = getenv("HOME")) if (*h) return std::string(h) + "/.cache/amwg";
   return "";
 }
-void make_dirs(const std::string &path) {      // mkdir -p
+void make_dirs(const std::string &path) {      // mkdir -p; the cache directory itself is private to the user (code objects are loaded from it)
   for (size_t i = 1; i <= path.size(); ++i)
-    if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), 0755);
+    if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), i == path.size() ? 0700 : 0755);
 }
-const char kCacheMagic[8] = {'A', 'M', 'W', 'G', 'c', 'o', '0', '1'};
+uint64_t payload_sum(const std::vector<char> &code) {      // FNV-1a over the code bytes: a damaged file is recompiled, not handed to the loader
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (unsigned char c : code) h = (h ^ c) * 0x100000001b3ull;
+  return h;
+}
+const char kCacheMagic[8] = {'A', 'M', 'W', 'G', 'c', 'o', '0', '2'};
 bool cache_read(const std::string &file, const CacheKey &k, std::vector<char> *code) {
   FILE *f = fopen(file.c_str(), "rb");
   if (!f) return false;
   char magic[8];
-  uint64_t hdr[3] = {0, 0, 0}, n = 0;
-  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kCacheMagic, 8) == 0 && fread(hdr, 8, 3, f) == 3 && fread(&n, 8, 1, f) == 1 &&
+  uint64_t hdr[4] = {0, 0, 0, 0}, n = 0;
+  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kCacheMagic, 8) == 0 && fread(hdr, 8, 4, f) == 4 && fread(&n, 8, 1, f) == 1 &&
             hdr[0] == k.h2 && hdr[1] == k.h3 && hdr[2] == k.len && n > 0 && n < (1ull << 31);
-  if (ok) { code->resize((size_t)n); ok = fread(code->data(), 1, (size_t)n, f) == (size_t)n; }
+  if (ok) { code->resize((size_t)n); ok = fread(code->data(), 1, (size_t)n, f) == (size_t)n && payload_sum(*code) == hdr[3]; }
   fclose(f);
+  if (!ok) (void)remove(file.c_str());      // stale format, truncated or damaged: gone, the caller compiles
   return ok;
 }
 void cache_write(const std::string &dir, const std::string &file, const CacheKey &k, const std::vector<char> &code) {
@@ -735,14 +759,21 @@ void cache_write(const std::string &dir, const std::string &file, const CacheKey
   const std::string tmp = file + ".tmp." + std::to_string((long)getpid());
   FILE *f = fopen(tmp.c_str(), "wb");
   if (!f) return;
-  const uint64_t hdr[3] = {k.h2, k.h3, k.len}, n = code.size();
-  const bool ok = fwrite(kCacheMagic, 1, 8, f) == 8 && fwrite(hdr, 8, 3, f) == 3 && fwrite(&n, 8, 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
+  const uint64_t hdr[4] = {k.h2, k.h3, k.len, payload_sum(code)}, n = code.size();
+  const bool ok = fwrite(kCacheMagic, 1, 8, f) == 8 && fwrite(hdr, 8, 4, f) == 4 && fwrite(&n, 8, 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
   if (fclose(f) != 0 || !ok || rename(tmp.c_str(), file.c_str()) != 0) (void)remove(tmp.c_str());
 }
-int g_cache_hits = 0, g_cache_misses = 0;
+std::atomic<int> g_cache_hits{0}, g_cache_misses{0};      // (samplers may be created from several threads)
 }  // namespace
 
-static int compile_user(const char *source, int lanes, int block, const char *arch, std::vector<char> *code) {
+static void dump_code_object(const std::vector<char> &code) {      // development aid: inspect the ISA with llvm-objdump
+  if (const char *dump = getenv("AMWG_DUMP_CODE_OBJECT")) {
+    if (FILE *f = fopen(dump, "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
+  }
+}
+
+// use_cache = false: compile even if the on-disk cache has the object (the caller found the cached one unloadable)
+static int compile_user(const char *source, int lanes, int block, const char *arch, std::vector<char> *code, bool use_cache = true) {
   static const char *names[] = {"amwg_stdint.h", "amwg_types.h", "amwg_math.h", "amwg_div.h", "amwg_ld.h", "amwg_philox.h",
                                 "amwg_kernel.h", "amwg_user.h", "amwg_twoval.h", "amwg_trig.h", "amwg_pass.h"};
   const char *texts[] = {amwg_hdr_stdint, amwg_hdr_types, amwg_hdr_math, amwg_hdr_div, amwg_hdr_ld, amwg_hdr_philox,
@@ -762,7 +793,8 @@ static int compile_user(const char *source, int lanes, int block, const char *ar
     char name[64];
     snprintf(name, sizeof name, "/%016llx%016llx.hsaco", (unsigned long long)key.h1, (unsigned long long)key.h2);
     file = dir + name;
-    if (cache_read(file, key, code)) { ++g_cache_hits; return AMWG_OK; }
+    if (use_cache && cache_read(file, key, code)) { ++g_cache_hits; dump_code_object(*code); return AMWG_OK; }
+    if (!use_cache) (void)remove(file.c_str());
   }
   ++g_cache_misses;
   hiprtcProgram prog = nullptr;
@@ -787,9 +819,7 @@ static int compile_user(const char *source, int lanes, int block, const char *ar
   hiprtcGetCode(prog, code->data());
   hiprtcDestroyProgram(&prog);
   if (!file.empty()) cache_write(dir, file, key, *code);
-  if (const char *dump = getenv("AMWG_DUMP_CODE_OBJECT")) {   // development aid: inspect the ISA with llvm-objdump
-    if (FILE *f = fopen(dump, "wb")) { fwrite(code->data(), 1, code->size(), f); fclose(f); }
-  }
+  dump_code_object(*code);
   return AMWG_OK;
 }
 
@@ -1182,7 +1212,19 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
     if (s->user_module) return AMWG_OK;      // (autotune hands back the module it kept)
     hipError_t e = hipModuleLoadData(&s->user_module, it->second.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&s->user_fn, s->user_module, "amwg_user_step");
-    if (e != hipSuccess) return fail(AMWG_EHIP, "loading the compiled log_post failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {
+      // the cache is never a requirement: an object the loader refuses (a planted or half-written file that still passed the checks, another
+      // driver) is dropped and the closure compiled afresh, once
+      (void)hipGetLastError();
+      if (s->user_module) { (void)hipModuleUnload(s->user_module); s->user_module = nullptr; }
+      std::vector<char> fresh;
+      int rc = compile_user(m->source, s->lanes, s->block, prop.gcnArchName, &fresh, false);
+      if (rc != AMWG_OK) return rc;
+      it->second = std::move(fresh);
+      e = hipModuleLoadData(&s->user_module, it->second.data());
+      if (e == hipSuccess) e = hipModuleGetFunction(&s->user_fn, s->user_module, "amwg_user_step");
+      if (e != hipSuccess) return fail(AMWG_EHIP, "loading the compiled log_post failed: %s", hipGetErrorString(e));
+    }
     // workgroups of this kernel use up to the whole 160 KB LDS of a CU; not every runtime needs (or accepts) the opt-in for module functions
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(s->user_fn), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds);
     (void)hipGetLastError();
@@ -1279,7 +1321,7 @@ int amwg_fetch_draws_slices(amwg_sampler *s, int32_t n_slices, const int32_t *ba
   const int PR = s->P + s->D;
   const size_t C = (size_t)s->C;
   for (int k = 0; k < n_slices; ++k) {
-    if (base[k] < 0 || len[k] < 0 || base[k] + len[k] > PR) return fail(AMWG_EINVAL, "amwg_fetch_draws_slices: slice %d = [%d, %d) outside the %d recorded values", k, base[k], base[k] + len[k], PR);
+    if (base[k] < 0 || len[k] < 0 || base[k] > PR || len[k] > PR - base[k]) return fail(AMWG_EINVAL, "amwg_fetch_draws_slices: slice %d = [%d, %d) outside the %d recorded values", k, base[k], base[k] + len[k], PR);
     const size_t need = (size_t)s->last_rows * (size_t)len[k] * C * 8;
     if (need && !out[k]) return fail(AMWG_EINVAL, "amwg_fetch_draws: null output");
     if (out_bytes[k] < need) return fail(AMWG_ESIZE, "amwg_sample: output needs %zu bytes, got %zu", need, out_bytes[k]);
@@ -1310,7 +1352,7 @@ int amwg_fetch_draws_slices(amwg_sampler *s, int32_t n_slices, const int32_t *ba
     }
     r0 = r1;
   }
-  return marks ? finish_timing(s) : AMWG_OK;
+  return finish_timing(s);      // (kernel_ms / launch_info of the LATEST call on the stream, whichever path was taken)
 }
 
 int amwg_fetch_draws(amwg_sampler *s, double *out, size_t out_bytes) {

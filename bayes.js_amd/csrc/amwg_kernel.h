@@ -481,6 +481,19 @@ __device__ __forceinline__ int chain_uniform(int v) {
   return v;
 }
 
+// Device-side invariants.  The host keeps them (choose_geometry pairs cpb with one-wavefront workgroups, launch_steps cuts calls into launches
+// of at most 65 535 steps); a launch that breaks one -- a future geometry or launch change -- must not look like a successful no-op: the
+// kernel leaves a bit in ChainArrays::error, which the host reads after every call (finish_timing) and reports as AMWG_EHIP.
+constexpr int kErrReplicasNeedOneWave = 1, kErrLaunchTooLong = 2, kErrMirrorOutOfSync = 4;
+__device__ __forceinline__ void device_error(const StepArgs &a, int code) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (threadIdx.x == 0) (void)atomicOr(a.ch.error, code);
+#endif
+}
+// a model that mirrors the state in registers (kTracksState) says whether the mirror still equals the LDS copy (Model::mirror_ok)
+template <class M, class = void> struct MirrorCheckOf { static constexpr bool value = false; };
+template <class M> struct MirrorCheckOf<M, void_of<decltype(M::kMirrorCheck)>> { static constexpr bool value = M::kMirrorCheck; };
+
 // BT: the workgroup size class the caller is compiled for (its register budget, see amwg_step_kernel); 1024-thread workgroups leave 128
 // VGPRs per lane, and with four waves per SIMD the staged pass does not need eight observations in flight per lane to keep the pipe busy:
 // it runs four-wide there (same operations in the same order, half the registers).
@@ -497,8 +510,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // replicate the workgroup's last chain -- same chain id, hence the same stream, decisions and stores: redundant, never different.
   // (Replicas are only sound in lockstep, i.e. inside ONE wavefront: the host pairs cpb with 64-thread workgroups, and a launch that
   // does not is refused here rather than left to race.)
-  if (!kMulti && a.cpb > 0 && nt != 64) return;
-  if (a.n_steps > 65535) return;      // run totals of a launch are 16-bit fields (TOTme); the host chunks launches accordingly
+  if (!kMulti && a.cpb > 0 && nt != 64) { device_error(a, kErrReplicasNeedOneWave); return; }
+  if (a.n_steps > 65535) { device_error(a, kErrLaunchTooLong); return; }      // run totals of a launch are 16-bit fields (TOTme); the host chunks launches accordingly
   const int CPB = kMulti ? G / 64 : ((a.cpb > 0 && a.cpb < nt / G) ? a.cpb : nt / G);
   const int c_raw = kMulti ? tid / 64 : tid / G;
   const int c_in = c_raw < CPB ? c_raw : CPB - 1, sub = tid % G;
@@ -939,6 +952,11 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     }
   }
 
+  // the register mirror of the state (kTracksState models) is a second copy that every store must keep current (set_state -> on_set): once per
+  // launch it is compared with the LDS copy, bit for bit -- a store that bypassed set_state would otherwise go unnoticed until a parity test
+  if constexpr (!GL && MirrorCheckOf<Model>::value) {
+    if (!Model::template mirror_ok<G>(cache, S, a.d, sub)) (void)atomicOr(cold_args()->ch.error, kErrMirrorOutOfSync);
+  }
   if (writer) {
     const cold_args_ptr ca = cold_args();
     double *const o_state = ca->ch.state, *const o_pls = ca->ch.prop_log_scale;

@@ -94,6 +94,11 @@ struct NormalModel {
   struct Cache { NormCache n; double mu, sigma; bool loaded; };
   __device__ __forceinline__ static Cache cache_init() { return Cache{norm_cache_init(), 0.0, 0.0, false}; }
   __device__ __forceinline__ static void on_set(Cache &k, int comp, double v, int, const DataRef &) { k.mu = comp == 0 ? v : k.mu; k.sigma = comp == 0 ? k.sigma : v; }
+  static constexpr bool kMirrorCheck = true;
+  template <int GL>
+  __device__ __forceinline__ static bool mirror_ok(const Cache &k, const StateView &S, const DataRef &, int) {
+    return !k.loaded || (f64_bits(k.mu) == f64_bits(S(0)) && f64_bits(k.sigma) == f64_bits(S(1)));
+  }
   template <int GL>
   __device__ __forceinline__ static void load(Cache &k, const StateView &S, const ModelConsts &, const DataRef &, const unsigned char *, int) {
     if (!k.loaded) { k.mu = S(0); k.sigma = S(1); k.loaded = true; }
@@ -375,6 +380,19 @@ struct HierNormalModel {
     k.th_pass = (comp == k.my_group) ? v : k.th_pass;
     k.mu = (comp == d.G) ? v : k.mu;
     k.sigma = (comp == d.G + 1) ? v : k.sigma;
+  }
+  static constexpr bool kMirrorCheck = true;
+  template <int GL>
+  __device__ __forceinline__ static bool mirror_ok(const Cache &k, const StateView &S, const DataRef &d, int sub) {
+    if (!k.loaded) return true;
+    constexpr int L = GL < 64 ? GL : 64;
+    const int j = sub & (L - 1);
+    bool ok = f64_bits(k.mu) == f64_bits(S(d.G)) && f64_bits(k.sigma) == f64_bits(S(d.G + 1));
+    if (k.regs) {
+      if (j < d.G) ok = ok && f64_bits(k.th_own) == f64_bits(S(j));
+      if (k.my_group >= 0) ok = ok && f64_bits(k.th_pass) == f64_bits(S(k.my_group));
+    }
+    return ok;
   }
   template <class C>
   __device__ __forceinline__ static double prior(const StateView &, const ModelConsts &mc, const DataRef &, C &k) {

@@ -91,6 +91,8 @@ struct ChainArrays {
   uint16_t *perm16;         // [n_params][C] the same order as 16-bit entries when n_params > kPackedNamed (else null)
   uint64_t *rng_n;          // [C] uniforms consumed
   double *lp_curr;          // [C] log_post(state)
+  int32_t *error;           // one word: bits set by a step kernel that refused its launch or found its own bookkeeping inconsistent (amwg_kernel.h
+                            // device_error); the host reads it after every call and turns it into an error -- never a silent no-op
 };
 
 struct StepArgs {

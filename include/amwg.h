@@ -186,7 +186,9 @@ int amwg_sample_async(amwg_sampler *s, int64_t n, int64_t thin);
 int amwg_fetch_draws(amwg_sampler *s, double *out_draws, size_t out_bytes);
 /* The same, delivered the way sampler.sample() returns it (mcmc.js:1009-1029: one array per monitored parameter): slice k receives the
  * recorded values base[k] .. base[k] + len[k] - 1 of every kept draw, laid out [draw][len[k]][chain], into out[k] (capacity out_bytes[k]).
- * Both forms copy the rows of each launch as soon as that launch has finished, while the later launches of the call still run. */
+ * Both forms copy the rows of each launch as soon as that launch has finished, while the later launches of the call still run.  The output
+ * buffers must be writable and must not be touched by another thread during the call: their pages are made resident ahead of the copy by
+ * rewriting one byte per page with its own value. */
 int amwg_fetch_draws_slices(amwg_sampler *s, int32_t n_slices, const int32_t *base, const int32_t *len, double *const *out, const size_t *out_bytes);
 
 /* Same, but the destination is DEVICE memory owned by the caller (e.g. a buffer that is then
