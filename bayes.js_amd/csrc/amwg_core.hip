@@ -198,6 +198,9 @@ int gl_layout(const double *y, const int32_t *g, int N, int Gn, GlLayoutHost *ou
 // such batches; the floors are the occupancies below which each part is latency- rather than issue-bound.  The cheapest
 // G wins, ties go to the smaller G.  The choice depends only on the model, the data size and the chain count, so a
 // given sampler configuration always gets the same G (the lane count fixes the summation order, hence the draws).
+bool hier_rows_wanted(const amwg_sampler *s, int G);
+bool hier_rows_fit(const amwg_sampler *s, int bt, size_t max_lds);
+
 double model_work(const amwg_sampler *s, int G) {
   const double N = (double)s->d.n_obs;
   switch (s->model) {
@@ -210,12 +213,26 @@ double model_work(const amwg_sampler *s, int G) {
       int lg = 0;
       for (int g = G; g > 1; g >>= 1) ++lg;
       const bool periodic = ((s->hier_periodic_mask >> lg) & 1u) != 0;
-      return (periodic ? 8.6 : 12.0) * N + 12.0 * s->d.G;
+      double w = (periodic ? 8.6 : 12.0) * N + 12.0 * s->d.G;
+      // lane-local re-evaluation (row layout): of the G + 2 updates of a step only two make the full pass, the others re-form the sums of
+      // the lanes of one group (~0.3 of a pass in time: a dependent chain on one lane)
+      if (hier_rows_wanted(s, G) && hier_rows_fit(s, 256, (size_t)160 * 1024)) w *= (2.0 + 0.35 * s->d.G) / (2.0 + s->d.G);
+      return w;
     }
     case AMWG_MODEL_POIS_GLM: return 90.0 * N;
   }
   if (G == 1 && s->user_work_one_lane > 0) return s->user_work_one_lane;   // translated closure with a two-valued sum: fast-forwarded
   return s->user_work > 0 ? s->user_work : 1e6;   // translated closure: the translator's estimate
+}
+
+// the hierarchical family's row layout (amwg_models.h: lane-local re-evaluation): a chain on one wavefront, labels that repeat with the lane
+// stride, not switched off -- and the tile, the label bytes and the per-wavefront term rows must fit beside the stepper state
+bool hier_rows_wanted(const amwg_sampler *s, int G) {
+  return !s->user && s->model == AMWG_MODEL_HIER_NORMAL && !s->mc.group_local && !s->opt.full_evaluation && G == 64 && ((s->hier_periodic_mask >> 6) & 1u) && s->d.G <= 64 && s->d.n_obs >= 64;
+}
+bool hier_rows_fit(const amwg_sampler *s, int bt, size_t max_lds) {
+  const size_t data = HierNormalModel::rows_lds_bytes(HierNormalModel::row_pitch(s->d.n_obs), bt / 64, s->d.G);
+  return lds_layout(data, s->P, bt / 64, s->pl.max_top, s->n_params).total <= max_lds;
 }
 
 int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
@@ -224,7 +241,9 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   // whose per-chain state is so large that 64 / G copies do not fit LDS: the spare lane groups replicate the last chain.
   auto layout = [&](int bt, int G, int cpb = 0) {
     const size_t data_bytes = s->user ? (size_t)(G == 1 ? s->user_lds_one_lane : s->user_lds)
-                              : (s->mc.group_local ? HierGlModel::gl_lds_bytes(s->d.pad, bt / 64) : model_lds_bytes(s->model, s->d.n_obs, s->d.G, G));
+                              : (s->mc.group_local ? HierGlModel::gl_lds_bytes(s->d.pad, bt / 64)
+                                 : ((hier_rows_wanted(s, G) && hier_rows_fit(s, bt, max_lds)) ? HierNormalModel::rows_lds_bytes(HierNormalModel::row_pitch(s->d.n_obs), bt / 64, s->d.G)
+                                    : model_lds_bytes(s->model, s->d.n_obs, s->d.G, G)));
     return G > 64 ? lds_layout(data_bytes, s->P, G / 64, s->pl.max_top, s->n_params, true) : lds_layout(data_bytes, s->P, cpb ? cpb : bt / G, s->pl.max_top, s->n_params);
   };
   const int max_bt = s->user ? s->user_max_threads : model_max_threads(s->model);
@@ -1103,6 +1122,8 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
       int lg = 0;
       for (int g = s->lanes; g > 1; g >>= 1) ++lg;
       s->mc.group_lane_const = (int32_t)((s->hier_periodic_mask >> lg) & 1u);
+      if (!s->mc.group_local)      // (the group-local kernel has its own use of DataRef::pad)
+        s->d.pad = (hier_rows_wanted(s, s->lanes) && hier_rows_fit(s, s->block, max_lds)) ? HierNormalModel::row_pitch(s->d.n_obs) : 0;
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(s->kernel), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds);
     return e == hipSuccess ? AMWG_OK : fail(AMWG_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));

@@ -112,6 +112,10 @@ template <class M> struct BinaryOf<M, void_of<decltype(M::kHasBinary)>> { static
 template <class M, class = void> struct TracksState { static constexpr bool value = false; };
 template <class M> struct TracksState<M, void_of<decltype(M::kTracksState)>> { static constexpr bool value = M::kTracksState; };
 
+// Does the model keep per-lane sums across evaluations (Model::kLaneReuse; HierNormalModel's row layout)?
+template <class M, class = void> struct LaneReuseOf { static constexpr bool value = false; };
+template <class M> struct LaneReuseOf<M, void_of<decltype(M::kLaneReuse)>> { static constexpr bool value = M::kLaneReuse; };
+
 template <class M, class = void> struct OwnPassOf { static constexpr bool value = false; };
 template <class M> struct OwnPassOf<M, void_of<decltype(M::kOwnPass)>> { static constexpr bool value = M::kOwnPass; };
 
@@ -230,7 +234,13 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
     // fp64 pipe half idle.  A wave therefore runs its stepper at raised priority (set at the top of the step loop) and drops to 0 for the
     // pass: whoever is in a stepper issues the moment it can, the partner's pass fills every other slot.
     wave_priority(0);
-    if constexpr (Model::kHasFast) {
+    bool summed = false;
+    if constexpr (LaneReuseOf<Model>::value && G == 64) {
+      // row layout: the lanes whose sum cannot have changed keep it, the others are re-formed (amwg_models.h lane_sum_rows)
+      if (ps.rows) { acc = Model::template lane_sum_rows<U>(cache, ps, acc, a.d.n_obs, a.d.G, sub, smem, a0.d.pad, (int)(threadIdx.x >> 6)); summed = true; }
+    }
+    if (summed) {
+    } else if constexpr (Model::kHasFast) {
       if (ps.fast) acc = Model::template pass_fast<G, U>(ps, a.d.n_obs, sub, acc);   // hand-pipelined (amwg_models.h norm_pass_staged)
       else acc = Model::template pass_slow<G>(ps, a.d.n_obs, sub, acc);            // IEEE '/': rare, out of line
     } else if constexpr (Model::kOneLanePass && G == 1) {
@@ -367,7 +377,14 @@ __device__ __forceinline__ double js_max2(double a, double b) {
 template <class M, int G, bool GL> struct RngOf { using type = CoopStream<G>; };
 template <class M, int G> struct RngOf<M, G, true> { using type = typename M::Stream; };
 // bytes of the data region of a workgroup's LDS
-template <class M, bool GL> struct DataBytesOf { static __device__ __forceinline__ size_t get(const DataRef &d, int lanes, int) { return M::lds_bytes(d.n_obs, d.G, lanes); } };
+template <class M, class = void> struct DynamicLdsOf { static constexpr bool value = false; };
+template <class M> struct DynamicLdsOf<M, void_of<decltype(M::kDynamicLds)>> { static constexpr bool value = M::kDynamicLds; };
+template <class M, bool GL> struct DataBytesOf {
+  static __device__ __forceinline__ size_t get(const DataRef &d, int lanes, int threads) {
+    if constexpr (DynamicLdsOf<M>::value) return M::lds_bytes_of(d, lanes, threads);      // (a layout the host chose for this launch geometry, DataRef::pad)
+    else return M::lds_bytes(d.n_obs, d.G, lanes);
+  }
+};
 template <class M> struct DataBytesOf<M, true> { static __device__ __forceinline__ size_t get(const DataRef &d, int, int threads) { return M::gl_lds_bytes(d.pad, threads / 64); } };
 
 // The kernel's argument block, read on demand.  Arguments taken by value are all loaded into scalar registers in the kernel's entry

@@ -319,10 +319,29 @@ struct HierNormalModel {
   static constexpr bool kHasBinary = false;   // real / int parameters only: the BinaryStepper branch is not compiled in
   static constexpr int kMaxThreads = 1024;   // workgroup size cap (instantiated per size class 256 / 512 / 1024, amwg_kernels.hip)
   static constexpr int kUnroll = 8;
-  struct Pass { double c, den, th_pass; Reciprocal y; bool fast, lane_const, regs; const double *x; const uint8_t *g; StateView S; };
+  struct Pass { double c, den, th_pass; Reciprocal y; bool fast, lane_const, regs, rows; const double *x; const uint8_t *g; StateView S; };
   __host__ __device__ static size_t lds_bytes(int n_obs, int, int) { return (size_t)n_obs * 8 + (((size_t)n_obs + 15) & ~(size_t)15); }
+  // ROW LAYOUT (DataRef::pad = row pitch Rp > 0; chosen by the host for a chain on one wavefront whose labels repeat with the lane stride, i.e.
+  // a lane that meets ONE group): the observations of lane j -- j, j + 64, ... -- stand side by side, row j of a [64][Rp] tile, Rp odd (lane
+  // stride 8 Rp bytes: the 32 lanes of a half-wave land in 32 different bank pairs, and the U observations of a block are one base address
+  // with immediate offsets).  What it buys is the lane-local re-evaluation below: any lane can read any other lane's observations side by side.
+  // LDS: tile | the first 64 labels | per wavefront kMaxLocal rows of terms.
+  static constexpr int kMaxLocal = 4;      // lanes whose sums are re-formed cooperatively; more stale lanes: the ordinary pass
+  __host__ __device__ static int row_pitch(int n_obs) { return ((n_obs + 63) / 64) | 1; }
+  __host__ __device__ static int local_rows(int groups) { const int per_group = groups > 0 ? 64 / groups : 1; const int r = per_group < 2 ? 2 : per_group; return r > kMaxLocal ? kMaxLocal : r; }      // term rows per wavefront: the lanes of one group (in pairs)
+  __host__ __device__ static int term_pitch(int pitch) { return (pitch + 16 + 1) & ~1; }      // a row of terms: 16 spare slots (the adder reads ahead), 16-byte aligned
+  __host__ __device__ static size_t rows_lds_bytes(int pitch, int waves, int groups) { return (size_t)64 * pitch * 8 + 64 + (size_t)waves * local_rows(groups) * term_pitch(pitch) * 8; }
+  static constexpr bool kDynamicLds = true;
+  __host__ __device__ static size_t lds_bytes_of(const DataRef &d, int lanes, int threads) { return d.pad > 0 ? rows_lds_bytes(d.pad, threads / 64, d.G) : lds_bytes(d.n_obs, d.G, lanes); }
   __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int) {
     double *dst = reinterpret_cast<double *>(smem);
+    if (d.pad > 0) {
+      const int Rp = d.pad;
+      for (int i = tid; i < d.n_obs; i += nt) dst[(i & 63) * Rp + (i >> 6)] = d.x[i];
+      uint8_t *gd = smem + (size_t)64 * Rp * 8;
+      for (int i = tid; i < 64; i += nt) gd[i] = i < d.n_obs ? d.xb[i] : 0;
+      return;
+    }
     uint8_t *gd = smem + (size_t)d.n_obs * 8;
     for (int i = tid; i < d.n_obs; i += nt) { dst[i] = d.x[i]; gd[i] = d.xb[i]; }
   }
@@ -341,8 +360,15 @@ struct HierNormalModel {
     // VECTOR registers: the stepper keeps more wave-uniform values alive than there are scalar registers, and every use of a spilled one is a
     // v_readlane plus a wait state -- the priors alone were 0.5 us of the 2.4 us a stepper update takes (measured by cutting them out)
     double pr_mu, pr_sigma, pr_val, c1, den1, y1h, y1l; int den1_ok;
+    // lane-local re-evaluation (row layout): the last two sums this lane formed, each with what it was formed FROM -- the value the
+    // sum starts with (the lane's prior terms), the mean of its observations and the sd: together they determine the sum, bit for bit
+    double a_start, a_mean, a_sd, a_T, b_start, b_mean, b_sd, b_T;
+    bool a_recent;
   };
-  __device__ __forceinline__ static Cache cache_init() { return Cache{norm_cache_init(), 0.0, 0.0, 0.0, 0.0, -1, false, false, __builtin_nan(""), __builtin_nan(""), 0.0, 0.0, 0.0, 0.0, 0.0, 0}; }
+  __device__ __forceinline__ static Cache cache_init() {
+    const double nan = __builtin_nan("");
+    return Cache{norm_cache_init(), 0.0, 0.0, 0.0, 0.0, -1, false, false, nan, nan, 0.0, 0.0, 0.0, 0.0, 0.0, 0, nan, nan, nan, 0.0, nan, nan, nan, 0.0, false};
+  }
   template <int GL>
   __device__ __forceinline__ static void load(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
     if (k.loaded) return;
@@ -352,7 +378,7 @@ struct HierNormalModel {
     const int j = sub & (L - 1);
     k.mu = S(d.G);
     k.sigma = S(d.G + 1);
-    k.my_group = (k.regs && sub < d.n_obs) ? (int)(smem + (size_t)d.n_obs * 8)[sub] : -1;
+    k.my_group = (k.regs && sub < d.n_obs) ? (int)(smem + (d.pad > 0 ? (size_t)64 * d.pad * 8 : (size_t)d.n_obs * 8))[sub] : -1;
     k.th_own = (k.regs && j < d.G) ? S(j) : 0.0;
     k.th_pass = k.my_group >= 0 ? S(k.my_group) : 0.0;
     k.c1 = mc.c1; k.den1 = mc.den1; k.y1h = mc.y1_hi; k.y1l = mc.y1_lo; k.den1_ok = mc.den1_ok;
@@ -452,9 +478,133 @@ struct HierNormalModel {
     ps.S = S;
     ps.lane_const = mc.group_lane_const != 0;
     ps.regs = k.regs;
+    ps.rows = d.pad > 0;
     ps.th_pass = k.th_pass;
     return ps;
   }
+  // ---------------------------------------------------------------------------------------------------------------------------------
+  // LANE-LOCAL RE-EVALUATION (row layout, a chain on one whole wavefront).  mcmc.js:524-526 evaluates the whole log_post for every update.
+  // In the 64-lane order log_post is the butterfly of 64 per-lane sums, and the sum of lane j is a pure function of three numbers: the value
+  // it starts from (the lane's prior terms), the mean of its observations (its ONE group's theta) and sd.  An update of theta_g changes those
+  // for the lanes of group g only (two of 64 in cfg4), so every other lane's sum is -- bit for bit -- the one it formed last time.  Each lane
+  // keeps its last two sums with what they were formed from (two: the committed state and the proposal under evaluation; the less recently
+  // used one is replaced), and only the lanes whose three numbers match neither are re-formed: all 64 lanes compute the terms of such a
+  // lane's observations side by side (read from its row of the tile), leave them in LDS, and the lane itself adds them up IN ORDER --
+  //     sum = start; for r = 0, 1, ...: sum += term_r            the same additions of the same values in the same order as the ordinary pass
+  // -- ~160 dependent additions on one lane (latency the SIMD's other wave fills) instead of ~1 270 instructions on all 64.  mu and sigma change
+  // every lane's numbers: then, and whenever more than kMaxLocal lanes are stale, the ordinary pass runs.  Results are IDENTICAL to evaluating
+  // everything (tests: every 64-lane comparison with the oracle runs through this; options.full_evaluation = 1 switches it off, and the two are
+  // compared chain by chain), so -- like the cached log_post of the current state -- it is not an approximation but work not done twice.
+  static constexpr bool kLaneReuse = true;
+  template <int U>
+  __device__ __forceinline__ static double rows_full(const Pass &ps, const double *row, int n_obs, int sub, double acc) {
+    const int n_full = n_obs >> 6, rem = n_obs & 63;
+    const double last = row[sub < rem ? n_full : 0];      // (the remainder round's observation, requested before the pass)
+    if (ps.fast) {
+      acc = norm_pass_staged<1, U, false>(row, nullptr, StateView{nullptr}, ps.th_pass, ps.c, ps.den, ps.y, n_full, 0, acc);
+      const double t = last - ps.th_pass;
+      const double term = ps.c - div_by_invariant(t * t, ps.den, ps.y);
+      return sub < rem ? acc + term : acc;
+    }
+    for (int r = 0; r < n_full; ++r) { const double t = row[r] - ps.th_pass; acc += ps.c - (t * t) / ps.den; }
+    const double t = last - ps.th_pass;
+    const double term = ps.c - (t * t) / ps.den;
+    return sub < rem ? acc + term : acc;
+  }
+  template <int U>
+  __device__ __forceinline__ static double lane_sum_rows(Cache &k, const Pass &ps, double start, int n_obs, int groups, int sub, const unsigned char *smem, int pitch, int wave) {
+    const double *tile = reinterpret_cast<const double *>(smem);
+    const int rows = local_rows(groups);
+    const int spitch = term_pitch(pitch);
+    double *scratch = const_cast<double *>(tile) + (size_t)64 * pitch + 8 + (size_t)wave * rows * spitch;      // (+ 8 doubles: the 64 label bytes)
+    const double mean = ps.th_pass, sd = k.n.sd;
+    const bool hitA = f64_bits(start) == f64_bits(k.a_start) && f64_bits(mean) == f64_bits(k.a_mean) && f64_bits(sd) == f64_bits(k.a_sd);
+    const bool hitB = f64_bits(start) == f64_bits(k.b_start) && f64_bits(mean) == f64_bits(k.b_mean) && f64_bits(sd) == f64_bits(k.b_sd);
+    const bool miss = !(hitA || hitB);
+    const uint64_t missing = __ballot(miss);
+    double T = hitA ? k.a_T : k.b_T;
+    if (missing != 0ull) {
+      double Tn;
+      if (!ps.fast || __popcll(missing) > rows) {
+        Tn = rows_full<U>(ps, tile + (size_t)sub * pitch, n_obs, sub, start);
+      } else {
+        const int n_full = n_obs >> 6, rem = n_obs & 63;
+        // -- the terms of the stale lanes' observations, side by side: two lanes (= the two lanes of a group in cfg4) per trip, two rounds of
+        // 64 observations each in flight -- four LDS reads requested before the first subtraction
+        uint64_t m = missing;
+        int q = 0, my_slot = 0;
+        while (m != 0ull) {      // (scalar loop over the stale lanes: at most kMaxLocal)
+          const int o0 = __builtin_ctzll(m);
+          m &= m - 1ull;
+          const bool two = m != 0ull;
+          const int o1 = two ? __builtin_ctzll(m) : o0;
+          if (two) m &= m - 1ull;
+          const double mean0 = lane_double(mean, o0), mean1 = lane_double(mean, o1);
+          const int n0 = n_full + (o0 < rem ? 1 : 0), n1 = two ? n_full + (o1 < rem ? 1 : 0) : 0;
+          const int n_hi = n0 > n1 ? n0 : n1;
+          const double *row0 = tile + (size_t)o0 * pitch, *row1 = tile + (size_t)o1 * pitch;
+          double *out0 = scratch + (size_t)q * spitch, *out1 = scratch + (size_t)(q + 1) * spitch;
+          for (int r = sub; r < n_hi; r += 128) {
+            const int ra = r, rb = r + 64;
+            const int ca = ra < pitch ? ra : 0, cb = rb < pitch ? rb : 0;      // (reads past a row's end: any valid address, not stored)
+            const double x0a = row0[ca], x1a = row1[ca], x0b = row0[cb], x1b = row1[cb];
+            AMWG_STAGE_FENCE();
+            const double t0a = x0a - mean0, t1a = x1a - mean1, t0b = x0b - mean0, t1b = x1b - mean1;
+            const double e0a = ps.c - div_by_invariant(t0a * t0a, ps.den, ps.y), e1a = ps.c - div_by_invariant(t1a * t1a, ps.den, ps.y);
+            const double e0b = ps.c - div_by_invariant(t0b * t0b, ps.den, ps.y), e1b = ps.c - div_by_invariant(t1b * t1b, ps.den, ps.y);
+            if (ra < n0) out0[ra] = e0a;
+            if (ra < n1) out1[ra] = e1a;
+            if (rb < n0) out0[rb] = e0b;
+            if (rb < n1) out1[rb] = e1b;
+          }
+          my_slot = sub == o0 ? q : (two && sub == o1 ? q + 1 : my_slot);
+          q += 2;
+        }
+        AMWG_STAGE_FENCE();
+        Tn = start;
+        if (miss) {      // the stale lanes add their terms up, in order: sixteen per trip, the second eight requested before the first eight are added
+          const double *mine = scratch + (size_t)my_slot * spitch;
+          const int n_me = n_full + (sub < rem ? 1 : 0);
+          int r = 0;
+          if (n_me >= 16) {
+            double va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) va[u] = mine[u];
+            for (; r + 16 <= n_me; r += 16) {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) vb[u] = mine[r + 8 + u];
+              AMWG_STAGE_FENCE();
+#pragma unroll
+              for (int u = 0; u < 8; ++u) Tn = Tn + va[u];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) va[u] = mine[r + 16 + u];      // (a row has 16 spare slots behind its last term: read, never added)
+              AMWG_STAGE_FENCE();
+#pragma unroll
+              for (int u = 0; u < 8; ++u) Tn = Tn + vb[u];
+            }
+          }
+          for (; r < n_me; ++r) Tn = Tn + mine[r];
+        }
+      }
+      if (miss) {
+        T = Tn;
+        if (k.a_recent) { k.b_start = start; k.b_mean = mean; k.b_sd = sd; k.b_T = Tn; k.a_recent = false; }
+        else { k.a_start = start; k.a_mean = mean; k.a_sd = sd; k.a_T = Tn; k.a_recent = true; }
+      }
+    }
+    if (!miss) k.a_recent = hitA;
+    return T;
+  }
+  __device__ __forceinline__ static double lane_double(double v, int src) {      // v of lane `src` (wave-uniform)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(f64_bits(v) >> 32), src);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f64_bits(v), src);
+    return bits_f64(((uint64_t)hi << 32) | (uint64_t)lo);
+#else
+    return v;
+#endif
+  }
+
   template <bool FAST>
   __device__ __forceinline__ static double term(const Pass &ps, int i) {
     const double t = ps.x[i] - ps.S(ps.g[i]);

@@ -395,6 +395,19 @@ def measure_other_config(A, name, device, group_local=0):
         kernel += " term-by-term pass (exact_division = 1)"
         note = ("roofline = the term-by-term pass (1 fp64 add per observation), %.3g param-updates/s; `value` is the exact fast-forward of the same two-valued "
                 "sum (bit-identical), which does not stream the data" % roof_updates_per_s)
+    if name == "cfg4" and not group_local:
+        # by default only the lanes whose sum an update can have changed are re-formed (csrc/amwg_models.h lane_sum_rows: bit-identical to evaluating
+        # everything, like the cached log_post of the current state), so `value` no longer streams the data once per update: the roofline figure is
+        # the kernel that does (options.full_evaluation = 1), measured on the side
+        t = A.Sampler(spec, chains=chains, seed=SEED, device=device, steps_per_launch=100, full_evaluation=1)
+        t.burn(200)
+        t.burn(300)
+        roof_updates_per_s = chains * 300 * P / (t.launch_info()["kernel_ms"] * 1e-3)
+        t.close()
+        kernel += " with options.full_evaluation = 1"
+        out["full_evaluation_value"] = roof_updates_per_s
+        note = ("roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s; `value` re-forms only the per-lane sums an update can "
+                "have changed (two of 64 lanes for an update of one group mean; mu and sigma: all) -- the same bits, %.2fx" % (roof_updates_per_s, value / roof_updates_per_s))
     lane_ops = roof_updates_per_s * n_obs * ops_per_obs
     if group_local:
         # group-local evaluation: a step of the P = G + 2 updates makes TWO passes over the data (the sweep over theta and the sigma update)
@@ -732,6 +745,16 @@ def main():
             roof_note = ("roofline = the term-by-term pass (scalar jump-table kernel, 1 fp64 add per observation), %.3g param-updates/s; `value` is the exact "
                          "fast-forward of the same sum (bit-identical, ~log2(N) binade steps instead of N additions), which has no meaningful roofline"
                          % (roof_updates / roof_launch_s))
+            t.close()
+        if args.workload == "cfg4" and not args.group_local:
+            t = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=dev_index, lanes_per_chain=args.lanes, block_threads=args.block, steps_per_launch=args.steps_per_launch, full_evaluation=1)
+            t.burn(2 * args.steps_per_launch)
+            t.burn(3 * args.steps_per_launch)
+            roof_launch_s, roof_updates = t.launch_info()["kernel_ms"] * 1e-3, chains * 3 * args.steps_per_launch * P
+            tl = t.launch_info()
+            kernel = "amwg_step_kernel<HierNormalModel,%d,%d> with options.full_evaluation = 1" % (tl["lanes_per_chain"], 256 if tl["block_threads"] <= 256 else (512 if tl["block_threads"] <= 512 else 1024))
+            roof_note = ("roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s; `value` re-forms only the per-lane sums an update "
+                         "can have changed (csrc/amwg_models.h lane_sum_rows: bit-identical)" % (roof_updates / roof_launch_s))
             t.close()
         lane_ops = roof_updates * n_obs * ops_per_obs / roof_launch_s
         if args.group_local:

@@ -421,3 +421,40 @@ def test_group_local_preconditions_are_enforced():
         A.Sampler(spec, chains=2, seed=1, group_local=1)
     with pytest.raises(A.AmwgError, match="hierarchical"):
         A.Sampler(model_spec.build_spec("normal", model_spec.make_data("normal", 100, 5)), chains=2, seed=1, group_local=1)
+
+
+@pytest.mark.parametrize("n_obs,G,chains", [(10_000, 32, 300), (1_000, 8, 130), (640, 64, 70), (257, 2, 65)])
+def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains):
+    """Hierarchical family on a wavefront per chain (labels that repeat with the lane stride): by default only the lanes whose sum an update
+    can have changed are re-formed (amwg_models.h lane_sum_rows); options.full_evaluation = 1 makes every evaluation pass over all the data.
+    The two must agree in EVERY bit of every chain -- draws, counters, proposal scales, log_post, uniforms -- over a schedule with short launches,
+    a stop / start of the adaptation, thinning, and states overwritten from the host in between (every cached sum is then stale)."""
+    data = model_spec.make_data("hier_normal", n_obs, 77, G=G)
+    spec = model_spec.build_spec("hier_normal", data)
+    mk = lambda full: A.Sampler(spec, chains=chains, seed=4, chain_offset=9, lanes_per_chain=64, steps_per_launch=7, full_evaluation=full)
+    a, b = mk(0), mk(1)
+    assert a.launch_info()["lds_bytes"] != b.launch_info()["lds_bytes"]      # the row layout (tile + term rows) is in use on one side only
+    rng = np.random.default_rng(3)
+    outs = []
+    for s in (a, b):
+        seq = [s.sample(40, 1)]
+        s.burn(33)
+        s.set_adapting(False)
+        seq.append(s.sample(25, 4))
+        s.set_adapting(True)
+        st = s.state()
+        st[:, ::3] = np.random.default_rng(11).normal(5.0, 2.0, st[:, ::3].shape)
+        st[-1] = np.abs(st[-1]) + 0.5                                          # sigma stays inside its bounds
+        s.set_state(st)
+        s.burn(50)
+        seq.append(s.sample(30, 2))
+        outs.append((seq, s.info(), s.diag(), s.state()))
+    (sa, ia, da, sta), (sb, ib, db, stb) = outs
+    for x, y in zip(sa, sb):
+        assert x.tobytes() == y.tobytes()
+    for k in ia:
+        assert ia[k].tobytes() == ib[k].tobytes(), k
+    assert da["uniforms"].tobytes() == db["uniforms"].tobytes() and da["log_post"].tobytes() == db["log_post"].tobytes()
+    assert sta.tobytes() == stb.tobytes()
+    a.close()
+    b.close()
