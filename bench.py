@@ -553,6 +553,7 @@ def main():
     ap.add_argument("--inproc", action="store_true", help="the product's own multi-device path: one process, one sampler per device, amwg_group_moments (see main_inproc)")
     ap.add_argument("--strong", action="store_true", help="keep the job's TOTAL chain count (cfg4: 16 384, cfg5: 65 536, cfg2: 65 536, cfg3: 262 144) and split it over the GPUs; the default for cfg4 / cfg5, which is how BASELINE.json states them")
     ap.add_argument("--weak", action="store_true", help="the workload's chains per GPU on every GPU (the default for cfg2 / cfg3: 65 536 / 262 144 per GPU)")
+    ap.add_argument("--full-evaluation", action="store_true", help="cfg4: options.full_evaluation = 1 for the timed sampler too (every evaluation passes over all the data; profiling the roofline kernel)")
     ap.add_argument("--torch-gather", action="store_true", help="N > 1: gather the draws with torch.distributed instead of the library's own communicator (amwg_comm_*)")
     ap.add_argument("--no-parity", action="store_true", help="profiling runs only: skip the golden schedule on the timed sampler (its launches record every draw)")
     ap.add_argument("--no-js", action="store_true", help="skip the end-to-end run through the JavaScript host (bench/js_e2e.js)")
@@ -619,7 +620,7 @@ def main():
     else:
         offset, _ = chain_shard(rank, world, chains * world)
         total_chains_job = chains * world
-    mk = lambda off: A.Sampler(spec, chains=chains, seed=SEED, chain_offset=off, device=dev_index, group_local=int(args.group_local),
+    mk = lambda off: A.Sampler(spec, chains=chains, seed=SEED, chain_offset=off, device=dev_index, group_local=int(args.group_local), full_evaluation=int(args.full_evaluation),
                                lanes_per_chain=args.lanes, block_threads=args.block, steps_per_launch=args.steps_per_launch)
     parity = None
     if world == 1 and args.workload in GOLDEN_OF and not args.no_parity:
@@ -746,7 +747,7 @@ def main():
                          "fast-forward of the same sum (bit-identical, ~log2(N) binade steps instead of N additions), which has no meaningful roofline"
                          % (roof_updates / roof_launch_s))
             t.close()
-        if args.workload == "cfg4" and not args.group_local:
+        if args.workload == "cfg4" and not args.group_local and not args.full_evaluation:
             t = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=dev_index, lanes_per_chain=args.lanes, block_threads=args.block, steps_per_launch=args.steps_per_launch, full_evaluation=1)
             t.burn(2 * args.steps_per_launch)
             t.burn(3 * args.steps_per_launch)

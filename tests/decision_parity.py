@@ -20,17 +20,20 @@ compare() runs the same seeded job in two geometries on the device and counts th
 import numpy as np
 
 
-def compare(A, spec, chains, steps, seed, alt, ref=None, steps_per_launch=0):
+def run_one(A, spec, chains, steps, seed, kw, steps_per_launch=0):
+    """-> what compare() looks at, of one geometry (kept by tools/flip_rate.py to compare several geometries with ONE reference run)"""
+    s = A.Sampler(spec, chains=chains, seed=seed, steps_per_launch=steps_per_launch, **kw)
+    li = s.launch_info()
+    s.burn(steps)
+    out = (li, s.info(), s.diag(), s.state())
+    s.close()
+    return out
+
+
+def compare(A, spec, chains, steps, seed, alt, ref=None, steps_per_launch=0, ref_run=None):
     ref = dict(ref or {"lanes_per_chain": 1})
-    a = A.Sampler(spec, chains=chains, seed=seed, steps_per_launch=steps_per_launch, **ref)
-    b = A.Sampler(spec, chains=chains, seed=seed, steps_per_launch=steps_per_launch, **alt)
-    la, lb = a.launch_info(), b.launch_info()
-    a.burn_async(steps)
-    b.burn_async(steps)
-    a.sync()
-    b.sync()
-    ia, ib, da, db = a.info(), b.info(), a.diag(), b.diag()
-    sa, sb = a.state(), b.state()
+    la, ia, da, sa = ref_run if ref_run is not None else run_one(A, spec, chains, steps, seed, ref, steps_per_launch)
+    lb, ib, db, sb = run_one(A, spec, chains, steps, seed, alt, steps_per_launch)
     same = np.all(ia["accepts"] == ib["accepts"], axis=0) & np.all(ia["inbounds"] == ib["inbounds"], axis=0)
     same &= da["uniforms"] == db["uniforms"]
     same &= np.all(sa.view(np.uint64) == sb.view(np.uint64), axis=0)
@@ -48,8 +51,6 @@ def compare(A, spec, chains, steps, seed, alt, ref=None, steps_per_launch=0):
            "lp_abs_typical": float(np.median(np.abs(da["log_post"][same]))) if same.any() else None,
            "expected_flips_bound": (2.0 * float(lpd.mean()) * decisions) if lpd.size else None,
            "differing_chain_ids": np.nonzero(~same)[0][:16].tolist()}
-    a.close()
-    b.close()
     return out
 
 

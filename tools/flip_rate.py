@@ -33,9 +33,14 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="multiplies the step counts")
     args = ap.parse_args()
     runs = []
+    ref_runs = {}      # the one-lane reference run of a (workload, chains, steps) is made once
     for wl, chains, steps, alt in CAMPAIGN:
         t0 = time.perf_counter()
-        r = dp.compare(A, dp.spec_of(A, wl), chains, max(10, int(steps * args.scale)), seed=20260925, alt=alt)
+        n = max(10, int(steps * args.scale))
+        spec = dp.spec_of(A, wl)
+        if (wl, chains, n) not in ref_runs:
+            ref_runs = {(wl, chains, n): dp.run_one(A, spec, chains, n, 20260925, {"lanes_per_chain": 1})}
+        r = dp.compare(A, spec, chains, n, seed=20260925, alt=alt, ref_run=ref_runs[(wl, chains, n)])
         r["workload"] = wl
         r["seconds"] = time.perf_counter() - t0
         runs.append(r)
