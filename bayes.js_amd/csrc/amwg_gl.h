@@ -77,6 +77,7 @@ struct HierGlModel {
   // the per-lane reads of a sweep.  E? / O?: bit j = rnorm (mcmc.js:44-53) accepts the pair that starts at the even / odd position 2j / 2j + 1
   // of that half; the last odd pair of a half ends in the next one: OA bit 63 is valid once B is, OB bit 63 is never set.
   struct Stream {
+    static constexpr int kLanesPerChain = 64;
     uint32_t k0, k1, c2, c3;
     uint64_t b0;
     uint32_t pos;              // uniforms consumed since block b0 (wave-uniform)

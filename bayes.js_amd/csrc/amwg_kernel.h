@@ -287,6 +287,7 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
 template <int G>
 struct CoopStream {
   static constexpr int L = G < 64 ? G : 64;
+  static constexpr int kLanesPerChain = G;
   uint32_t k0, k1, c2, c3;
   uint64_t b0;          // first block held by the chain's lanes
   uint32_t pos;         // uniforms consumed since block b0 (0 .. 2L): the stream position is 2*b0 + pos -- 32-bit bookkeeping per draw
@@ -334,16 +335,31 @@ struct CoopStream {
   }
 };
 
+// A condition every lane of the chain decides alike.  For a chain on a whole wave (G >= 64) saying so -- through the ballot, which is a scalar -- turns
+// the branch into a scalar one: no exec-mask save / restore, no per-lane merges of the values defined under it.  (The compiler cannot know that the
+// 64 lanes hold the same chain: every `if` on a value computed in vector registers otherwise compiles to the divergent form.)
+template <int G>
+__device__ __forceinline__ bool chain_true(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (G >= 64) return __ballot(c) != 0ull;
+#endif
+  return c;
+}
+
 template <class Rng>
 __device__ __forceinline__ double rnorm_js(Rng &rng, double mean, double sd) {  // mcmc.js:43-54
+  constexpr int GU = Rng::kLanesPerChain;      // (a chain on a whole wave: the loop and its inner test are scalar branches, see chain_true)
   double u, v, q;
+  bool again;
   do {
     u = rng.next();
     v = 1.7156 * (rng.next() - 0.5);
     const double x = u - 0.449871;
     const double y = __builtin_fabs(v) + 0.386595;
     q = x * x + y * (0.19600 * y - 0.25472 * x);
-  } while (q > 0.27597 && (q > 0.27846 || v * v > -4 * log_v8_cold(u) * u * u));
+    again = false;
+    if (chain_true<GU>(q > 0.27597)) again = chain_true<GU>(q > 0.27846) || chain_true<GU>(v * v > -4 * log_v8_cold(u) * u * u);
+  } while (again);
   return (v / u) * sd + mean;
 }
 
@@ -642,7 +658,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   auto adapt_component = [&](int comp, bool accepted, int2 cnt, double batch_size, bool store) {
     cnt.x += accepted ? 1 : 0;      // acceptance_count (mcmc.js:530)
     cnt.y += 1;                     // iterations_since_adaption (mcmc.js:537)
-    if ((double)cnt.y >= batch_size) {    // batch boundary: the only time batch_count is touched (it stays in HBM)
+    if (chain_true<GL ? 1 : G>((double)cnt.y >= batch_size)) {    // batch boundary: the only time batch_count is touched (it stays in HBM); (the group-local sweep calls this per lane)
       const CompConst k = cc[comp];
       // single-wave chains: batch_count and the log scale live in HBM (all lanes of the chain are in lockstep, so they
       // read the old value together before the writer lane stores the new one); multi-wave chains keep per-wave replicas
@@ -929,8 +945,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       // ---- OnedimMetropolisStepper.step (mcmc.js:517-553)
       const double cur = me.cur;
       double prop = rnorm_js(rng, cur, me.sd);
-      if (k_type == kTypeInt) prop = js_round(prop);
-      const bool inb = !(prop < k_lower || prop > k_upper);
+      if (chain_true<G>(k_type == kTypeInt)) prop = js_round(prop);
+      const bool inb = chain_true<G>(!(prop < k_lower || prop > k_upper));
       // the accept test's uniform (mcmc.js:528) is the next one of the stream whatever log_post returns: drawn now
       double u_accept = 0.0;
       if (inb) { set_state(comp, prop); u_accept = rng.next(); }
@@ -948,8 +964,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         // Math.exp(prop - curr) > Math.random() (mcmc.js:527-528).  For a difference >= 0 (incl. +inf) the exponential is >= 1 > u, below
         // -746 it is exactly 0 (never > u): the decision is the reference's without evaluating it; NaN takes the general path (false).
         const double diff = prop_lp - lp_curr;
-        if (diff >= 0.0) accepted = true;
-        else if (diff < -746.0) accepted = false;
+        if (chain_true<G>(diff >= 0.0)) accepted = true;
+        else if (chain_true<G>(diff < -746.0)) accepted = false;
         else {
           // For d < 0:  1 + d <= exp(d) <= 1 + d + d*d/2, and V8's exp is within one ulp (< 2^-53 here) of exp: a uniform below the lower bound
           // or above the upper one (each taken with a margin of 2^-50, an order of magnitude more than the roundings of the bounds themselves
@@ -957,15 +973,16 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           // (about a quarter of the proposals at a 44 % acceptance rate); the ~45 instructions of exp are the longest single dependent chain
           // of an update.  Chains sharing a wavefront diverge here; the exponential runs for those that need it.
           const double lower = 1.0 + diff;
-          if (u_accept < lower - 0x1p-50) accepted = true;
-          else if (diff > -1.0 && u_accept > (lower + 0.5 * diff * diff) + 0x1p-50) accepted = false;
-          else accepted = exp_v8(diff) > u_accept;
+          if (chain_true<G>(u_accept < lower - 0x1p-50)) accepted = true;
+          else if (chain_true<G>(diff > -1.0 && u_accept > (lower + 0.5 * diff * diff) + 0x1p-50)) accepted = false;
+          else accepted = chain_true<G>(exp_v8(diff) > u_accept);
         }
+        accepted = chain_true<G>(accepted);
         if (accepted) lp_curr = prop_lp;
         else set_state(comp, cur);
         if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // run totals (not in the reference; parity tests compare them with the oracle's)
       }
-      if (me.adapting) adapt_component(comp, accepted, me.cnt, me.batch_size, writer);
+      if (chain_true<G>(me.adapting)) adapt_component(comp, accepted, me.cnt, me.batch_size, writer);
     }
   }
 

@@ -747,7 +747,7 @@ def main():
                          "fast-forward of the same sum (bit-identical, ~log2(N) binade steps instead of N additions), which has no meaningful roofline"
                          % (roof_updates / roof_launch_s))
             t.close()
-        if args.workload == "cfg4" and not args.group_local and not args.full_evaluation:
+        if args.workload == "cfg4" and not args.group_local and not args.full_evaluation and not args.single_region:      # (profiling runs -- --single-region -- keep to ONE kernel)
             t = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=dev_index, lanes_per_chain=args.lanes, block_threads=args.block, steps_per_launch=args.steps_per_launch, full_evaluation=1)
             t.burn(2 * args.steps_per_launch)
             t.burn(3 * args.steps_per_launch)
