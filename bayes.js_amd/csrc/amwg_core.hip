@@ -37,7 +37,7 @@ using namespace amwg;
 // together with the very same step kernel source the built-in models are compiled from.
 extern "C" {
 extern const char amwg_hdr_stdint[], amwg_hdr_types[], amwg_hdr_math[], amwg_hdr_div[], amwg_hdr_ld[], amwg_hdr_philox[],
-    amwg_hdr_kernel[], amwg_hdr_user[], amwg_hdr_twoval[], amwg_hdr_trig[], amwg_hdr_pass[];
+    amwg_hdr_kernel[], amwg_hdr_user[], amwg_hdr_twoval[], amwg_hdr_kval[], amwg_hdr_trig[], amwg_hdr_pass[];
 }
 
 // the step kernels of the built-in families, one translation unit each (amwg_kernels.hip): kernel for (lanes per chain, workgroup size)
@@ -794,9 +794,9 @@ static void dump_code_object(const std::vector<char> &code) {      // developmen
 // use_cache = false: compile even if the on-disk cache has the object (the caller found the cached one unloadable)
 static int compile_user(const char *source, int lanes, int block, const char *arch, std::vector<char> *code, bool use_cache = true) {
   static const char *names[] = {"amwg_stdint.h", "amwg_types.h", "amwg_math.h", "amwg_div.h", "amwg_ld.h", "amwg_philox.h",
-                                "amwg_kernel.h", "amwg_user.h", "amwg_twoval.h", "amwg_trig.h", "amwg_pass.h"};
+                                "amwg_kernel.h", "amwg_user.h", "amwg_twoval.h", "amwg_kval.h", "amwg_trig.h", "amwg_pass.h"};
   const char *texts[] = {amwg_hdr_stdint, amwg_hdr_types, amwg_hdr_math, amwg_hdr_div, amwg_hdr_ld, amwg_hdr_philox,
-                         amwg_hdr_kernel, amwg_hdr_user, amwg_hdr_twoval, amwg_hdr_trig, amwg_hdr_pass};
+                         amwg_hdr_kernel, amwg_hdr_user, amwg_hdr_twoval, amwg_hdr_kval, amwg_hdr_trig, amwg_hdr_pass};
   const std::string prog_src = user_program(source, lanes, block);
   const char *const kOpts[] = {"-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-falign-loops=64"};
   // the on-disk cache (see above)
@@ -817,7 +817,7 @@ static int compile_user(const char *source, int lanes, int block, const char *ar
   }
   ++g_cache_misses;
   hiprtcProgram prog = nullptr;
-  hiprtcResult r = hiprtcCreateProgram(&prog, prog_src.c_str(), "amwg_user_model.hip", 11, texts, names);
+  hiprtcResult r = hiprtcCreateProgram(&prog, prog_src.c_str(), "amwg_user_model.hip", 12, texts, names);
   if (r != HIPRTC_SUCCESS) return fail(AMWG_EHIP, "hiprtcCreateProgram failed: %s", hiprtcGetErrorString(r));
   const std::string arch_opt = std::string("--offload-arch=") + arch;
   // same floating-point contract as the Makefile: one rounding per operation, no fused contraction

@@ -13,5 +13,6 @@ AMWG_TEXT(amwg_hdr_philox, "amwg_philox.h");
 AMWG_TEXT(amwg_hdr_kernel, "amwg_kernel.h");
 AMWG_TEXT(amwg_hdr_user, "amwg_user.h");
 AMWG_TEXT(amwg_hdr_twoval, "amwg_twoval.h");
+AMWG_TEXT(amwg_hdr_kval, "amwg_kval.h");
 AMWG_TEXT(amwg_hdr_trig, "amwg_trig.h");
 AMWG_TEXT(amwg_hdr_pass, "amwg_pass.h");

@@ -5,6 +5,7 @@
 #include "amwg_ld.h"
 #include "amwg_pass.h"
 #include "amwg_twoval.h"
+#include "amwg_kval.h"
 #include "amwg_types.h"
 
 namespace amwg {
@@ -159,6 +160,15 @@ AMWG_HD double bern_loop_one_lane(double acc, const BernInv &k, const int32_t *t
   const uint32_t *t = reinterpret_cast<const uint32_t *>(tab);
   const BitData B{t, t + W, t + 2 * W, t + 3 * W, t + 4 * W, t + 5 * W, n};
   return two_valued_sum(acc, k.l1, k.l0, B);
+}
+
+// `for (i = 0; i < n; i++) lp += ld.pois(y[i], rate)` (or ld.binom with loop-invariant size / prob) over a data array with K <= 16 distinct
+// values, one lane per chain: c[k] = the term of the k-th distinct value (computed by the generated code with the same function the
+// term-by-term loop calls), the tables of amwg_kval.h for that array (built by the translator) and the exact fast-forward
+template <int K>
+AMWG_HD double kval_loop_one_lane(double acc, const double (&c)[K], const int32_t *tab, const uint8_t *idx, int n) {
+  const KValData B{reinterpret_cast<const uint32_t *>(tab), idx, n};
+  return k_valued_sum<K>(acc, c, B);
 }
 
 // JavaScript operators that differ from C++

@@ -844,6 +844,33 @@ Translator.prototype.twoValuedTables = function (id) {
   return out;
 };
 
+// The data-only tables of csrc/amwg_kval.h for an array with at most 16 distinct values (a count column, ...): per distinct value its
+// occurrence mask and prefix counts, back to back as 32-bit words, plus the value INDEX of every observation as its own (byte) array.
+// -> {tab, idx, first: [index of the first occurrence of every distinct value], K} or null when the array has too many distinct values
+Translator.prototype.kValuedTables = function (id) {
+  const key = '#aux:kval:' + id;
+  if (this.kvalCache && this.kvalCache[key]) return this.kvalCache[key];
+  const x = this.arrays[id].flat, N = x.length, W = Math.floor(N / 32) + 2;
+  const slot = new Map(), first = [];
+  for (let i = 0; i < N; i++) {
+    if (!slot.has(x[i])) { if (first.length === 16) return null; slot.set(x[i], first.length); first.push(i); }
+  }
+  const K = first.length;
+  if (K < 1 || N < 64) return null;
+  const tab = new Uint32Array(2 * K * W), idx = new Array(N);
+  for (let i = 0; i < N; i++) { const k = slot.get(x[i]); idx[i] = k; tab[2 * k * W + (i >> 5)] |= (1 << (i & 31)) >>> 0; }
+  const popc = (v) => { v = v - ((v >>> 1) & 0x55555555); v = (v & 0x33333333) + ((v >>> 2) & 0x33333333); return (((v + (v >>> 4)) & 0x0f0f0f0f) * 0x01010101) >>> 24; };
+  for (let k = 0; k < K; k++) for (let w = 1; w < W; w++) tab[(2 * k + 1) * W + w] = tab[(2 * k + 1) * W + w - 1] + popc(tab[2 * k * W + w - 1]);
+  const signed = new Array(2 * K * W);
+  for (let k = 0; k < 2 * K * W; k++) signed[k] = tab[k] | 0;
+  const t = this.registerArray(key + ':tab', signed);
+  if (this.arrays[t].type === 1) { this.arrays[t].type = 2; this.arrays[t].ctype = 'int32_t'; this.arrays[t].esize = 4; this.arrays[t].is01 = false; }   // always i32
+  const j = this.registerArray(key + ':idx', idx);
+  if (this.arrays[j].type !== 1) return null;      // (value indices 0 .. 15 are stored as bytes)
+  this.kvalCache = this.kvalCache || {};
+  return (this.kvalCache[key] = { tab: t, idx: j, first, K });
+};
+
 // a named temporary for a value that is used twice (keeps the evaluation single, as in JS)
 Translator.prototype.temp = function (code) {
   if (/^[\w.]+$/.test(code) || /^S\(\d+\)$/.test(code)) return code;
@@ -1263,6 +1290,35 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
         out.push(indent + '}');
         return;
       }
+      // `for (i = 0; i < y.length; i++) lp += ld.pois(y[i], rate)` / `ld.binom(y[i], size, prob)` with loop-invariant rate / size / prob over a
+      // whole array of at most 16 distinct values: the term is a function of y[i] alone, so with one lane per chain the sequential sum has
+      // K distinct addends and is fast-forwarded exactly (csrc/amwg_kval.h); with G > 1 lanes the ordinary split loop runs
+      // (any density whose only per-observation argument is y[i] qualifies; ld.pois arrives with lfactorial(y[i]) precomputed as a second array)
+      let mk = null;
+      if (simple && pend.length === 0 && !this.opts.no_fast_forward) {
+        const m1 = /^(ld_pois_pre)\(((?:\(double\))?)A(\d+)\[v_(\w+)\], (.+), A(\d+)\[v_\4\]\)$/.exec(term.code);
+        const m2 = m1 ? null : /^(ld_\w+)\(((?:\(double\))?)A(\d+)\[v_(\w+)\], (.+)\)$/.exec(term.code);
+        const m = m1 || m2;
+        if (m && m[4] === canon.name && m[5].indexOf('v_' + canon.name) < 0 && !/A\d+\[/.test(m[5]))
+          mk = { fn: m[1], cast: m[2], arr: Number(m[3]), rest: m[5], aux: m1 ? Number(m1[6]) : -1 };
+      }
+      if (mk && startV.cst === 0 && !canon.le && boundV.cst === this.arrays[mk.arr].flat.length && this.arrays[mk.arr].type !== 0) {      // (a small-integer array: stored as u8 / i32)
+        const kv = this.kValuedTables(mk.arr);
+        if (kv) {
+          s.fastForwardOneLane = true;
+          this.oneLaneWork = 1;
+          out.push(indent + '{');
+          for (const ln of L.preamble) out.push(indent + '  ' + ln);
+          out.push(indent + '  if constexpr (G == 1) {');
+          out.push(indent + '    const double c_[' + kv.K + '] = {' + kv.first.map((i0) => mk.fn + '(' + mk.cast + 'A' + mk.arr + '[' + i0 + '], ' + mk.rest + (mk.aux >= 0 ? ', A' + mk.aux + '[' + i0 + ']' : '') + ')').join(', ') + '};');
+          out.push(indent + '    ' + acc + ' = kval_loop_one_lane<' + kv.K + '>(' + acc + ', c_, A' + kv.tab + ', A' + kv.idx + ', ' + boundV.cst + ');');
+          out.push(indent + '  } else {');
+          for (const ln of head.concat(loop)) out.push(indent + '  ' + ln);
+          out.push(indent + '  }');
+          out.push(indent + '}');
+          return;
+        }
+      }
       // `for (i = 0; i < x.length; i++) lp += ld.norm(x[i], mean, sd)` over a whole f64 data array, mean and sd loop-invariant: the
       // hand-scheduled pass the built-in Normal family runs (csrc/amwg_pass.h via norm_data_loop, amwg_user.h) -- staged LDS reads
       // with G lanes, scalar loads with one lane per chain; same operations in the same order as the generic loop below
@@ -1610,7 +1666,7 @@ Translator.prototype.run = function () {
   // two plans: G > 1 lanes per chain (arrays in order of first use), and ONE lane per chain, where a fast-forwarded loop reads
   // its bit tables instead of the observations (tables first)
   const PG = makePlan(all), plan = PG.plan, off = PG.bytes;
-  const isTab = (j) => this.arrays[j].key.indexOf('#aux:twoval:') === 0;
+  const isTab = (j) => this.arrays[j].key.indexOf('#aux:twoval:') === 0 || this.arrays[j].key.indexOf('#aux:kval:') === 0;
   const P1 = this.oneLaneWork ? makePlan(all.filter(isTab).concat(all.filter((j) => !isTab(j)))) : PG;
   const D = this.derived.length;
   const maxThreads = this.opts.max_threads || (this.heavyLoop ? 256 : 1024);

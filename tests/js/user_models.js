@@ -673,6 +673,34 @@ CASES.records_logistic = {
 
 // ---- categorical columns kept as strings in the data (treatment arm, site, a model switch): the translator stores them as integer
 // codes and only ever compares them (=== / !==) -- with literals (one that never occurs among them), with each other, through an alias
+// constant-rate count likelihoods over small-integer data: the term is a function of y[i] alone, so with one lane per chain the sequential sum has as many
+// distinct addends as the data has distinct values and is fast-forwarded exactly (csrc/amwg_kval.h; distributions.js:240-248, 282-284)
+CASES.pois_const_rate = {
+  params: () => ({ lambda: { lower: 0, init: 2 }, off: { init: 0 } }),
+  data: (seed) => {
+    const r = lcg(seed), y = [];
+    for (let i = 0; i < 20000; i++) { let k = 0, p = Math.exp(-3.2), f = p, u = r(); while (u > f && k < 12) { k++; p *= 3.2 / k; f += p; } y.push(k); }
+    return { y };
+  },
+  log_post: function (s, d) {
+    var lp = ld.gamma(s.lambda, 2, 0.5) + ld.norm(s.off, 0, 1);
+    for (var i = 0; i < d.y.length; i++) lp += ld.pois(d.y[i], s.lambda);
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+CASES.binom_const_size = {
+  params: () => ({ p: { lower: 0, upper: 1 } }),
+  data: (seed) => { const r = lcg(seed), y = []; for (let i = 0; i < 6000; i++) { let k = 0; for (let t = 0; t < 7; t++) if (r() < 0.37) k++; y.push(k); } return { y, size: 7 }; },
+  log_post: function (s, d) {
+    var lp = ld.beta(s.p, 1.5, 2.5);
+    var n = d.size;
+    for (var i = 0; i < d.y.length; i++) lp += ld.binom(d.y[i], n, s.p);
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+
 CASES.categorical_arms = {
   params: () => ({ mu: {}, d_low: {}, d_high: {}, sigma: { lower: 0, init: 1 } }),
   data: (seed) => {

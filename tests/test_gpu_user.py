@@ -42,7 +42,7 @@ def spec_for(name):
 
 @pytest.mark.parametrize("name,lanes", [("readme_normal", 1), ("readme_normal", 4), ("norm_post_derived", 8), ("complex_model", 2),
                                         ("hier_binomial", 2), ("hier_normal_closure", 16), ("pois_glm_closure", 4), ("pois_glm_closure", 64),
-                                        ("spike_slab", 4), ("survival_mix", 2), ("discrete_mix", 1), ("multi_bern", 1), ("multivar_poisson", 1), ("mixture_arrays", 2), ("many_named", 4), ("readme_bern", 1), ("readme_bern", 4), ("semantics_probe", 1), ("logistic_softplus", 4), ("modern_js", 1), ("live_out_temp", 4), ("circular_wrapped_cauchy", 8), ("structured_helpers", 4), ("records_logistic", 4), ("categorical_arms", 2),
+                                        ("spike_slab", 4), ("survival_mix", 2), ("discrete_mix", 1), ("multi_bern", 1), ("multivar_poisson", 1), ("mixture_arrays", 2), ("many_named", 4), ("readme_bern", 1), ("readme_bern", 4), ("semantics_probe", 1), ("logistic_softplus", 4), ("modern_js", 1), ("live_out_temp", 4), ("circular_wrapped_cauchy", 8), ("structured_helpers", 4), ("records_logistic", 4), ("categorical_arms", 2), ("pois_const_rate", 1), ("pois_const_rate", 4), ("binom_const_size", 1), ("binom_const_size", 8),      # K-valued fast-forward with one lane; the split loop otherwise
                                         ("wide_regression", 1), ("wide_regression", 4), ("long_dim", 1), ("long_dim", 4)])     # > 16 named parameters, > 16 data arrays, dim [300]
 def test_device_lane_sum_equals_host_emulation(name, lanes):
     spec, m, gold = spec_for(name)

@@ -21,7 +21,7 @@ import user_host
 pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
 
 NAMES = ["readme_normal", "readme_bern", "norm_post_derived", "complex_model", "hier_binomial", "multi_bern", "multivar_poisson",
-         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js", "live_out_temp", "circular_wrapped_cauchy", "structured_helpers", "records_logistic", "categorical_arms", "wide_regression", "long_dim", "undefined_reads", "readme_normal_swapped"] + ["cfgfuzz_%d" % k for k in range(16)]
+         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js", "live_out_temp", "circular_wrapped_cauchy", "structured_helpers", "records_logistic", "categorical_arms", "pois_const_rate", "binom_const_size", "wide_regression", "long_dim", "undefined_reads", "readme_normal_swapped"] + ["cfgfuzz_%d" % k for k in range(16)]
 BIG_SHAPES = ("wide_regression", "long_dim")     # 20 named parameters + 19 data arrays; dim [300]: short runs, fewer recorded states
 
 
@@ -150,6 +150,31 @@ def test_two_valued_sum_host_fuzz(tmp_path):
                            os.path.join(root, "tests", "host", "twoval_fuzz.cpp"), "-o", exe])
     p = subprocess.run([exe, "200000"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "mismatches=0" in p.stdout, p.stdout[-2000:]
+
+
+def test_k_valued_sum_host_fuzz(tmp_path):
+    """csrc/amwg_kval.h compiled for the host (K = 1, 2, 3, 5, 8, 16 distinct addends): ~100 000 random / adversarial (data, acc0, addends)
+    cases -- trailing-zero significands (ties in reachable binades: summed term by term there), exact multiples of one another, either sign
+    of acc0, non-finite and positive addends -- against the plain fp64 loop, bit for bit."""
+    import os
+    import subprocess
+    exe = str(tmp_path / "kval_fuzz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(root, "bayes.js_amd", "csrc"),
+                           os.path.join(root, "tests", "host", "kval_fuzz.cpp"), "-o", exe])
+    p = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "mismatches=0" in p.stdout, p.stdout[-2000:]
+
+
+def test_constant_rate_count_loops_are_fast_forwarded_with_one_lane():
+    """`lp += ld.pois(y[i], rate)` / `ld.binom(y[i], size, prob)` with loop-invariant parameters over small-integer data: the generated code
+    evaluates the term once per distinct value and hands the loop to k_valued_sum when a chain has one lane (the reference's order); the
+    lane-split loop stays for G > 1.  (That the result equals the reference's closure bit for bit is test_translated_closure_equals_reference_on_host.)"""
+    for name, K in (("pois_const_rate", 12), ("binom_const_size", 8)):
+        m = user_host.host_model(name)
+        assert "kval_loop_one_lane<%d>" % K in m.source and "if constexpr (G == 1)" in m.source
+        assert any(k.startswith("#aux:kval:") for k in m.meta["array_keys"])
+        assert 0 < m.meta["work_one_lane"] < 0.05 * m.meta["work_per_eval"]
 
 
 def test_division_by_invariant_host_fuzz(tmp_path):
