@@ -10,10 +10,11 @@
 // before the significand would reach 2^53; the one addition that leaves the binade is a real fp64 add.  ~log2(N) binades instead of N
 // additions, the same bits as the sequential loop.
 //
-// Ties: |c_k| exactly half-way between two multiples of u -- possible in ONE binade per addend, the one where u is twice the lowest set
-// bit of c_k, i.e. within the first ~2^(t+2) terms for an addend with t trailing zero bits -- round by the parity of acc, which with more
-// than two addends depends on the ORDER of the others, not on their counts (amwg_twoval.h has closed forms for two).  Such a binade is
-// summed term by term; every other binade is fast-forwarded.  Exact for any data; only as fast as the data allows.
+// Ties: |c_k| exactly half-way between two multiples of u -- in the one binade per addend where u is twice the lowest set bit of c_k; an
+// addend with s significand bits below u ties with probability 2^-s, so the binades right above the addends' own meet one often and a high
+// binade now and then -- round by the parity of acc, which with more than two addends depends on the ORDER of the others, not on their
+// counts (amwg_twoval.h has closed forms for two).  A binade with one tying addend is walked 32 observations at a time with bit tricks on
+// the occurrence masks (below); one with several, term by term; every other binade is fast-forwarded.  Exact for any data.
 #pragma once
 #include "amwg_twoval.h"
 
@@ -21,9 +22,10 @@ namespace amwg {
 
 constexpr int kMaxKValues = 16;
 
-// Data-only tables (translate.js kValuedTables; tests/host/kval_fuzz.cpp builds them the same way), W = n / 32 + 2 words per array:
-//   tab: for value k = 0 .. K-1:  mask_k[W] (bit i & 31 of word i >> 5: observation i has value k), then pre_k[W] (occurrences among
-//        the observations [0, 32 w));   idx: the value index of every observation, one byte each
+// Data-only tables (translate.js kValuedTables; tests/host/kval_fuzz.cpp builds them the same way), W = n / 32 + 2 blocks of 32 observations:
+//   tab: for block w:  pre[K] (occurrences of every value among the observations [0, 32 w)), then mask[K] (bit j of mask[k]: observation
+//        32 w + j has value k) -- the 2 K words of a block side by side: one evaluation of the bisection reads ONE block (a cache line or two; with
+//        one array per value it read 2 K lines, and the loop was memory bound);   idx: the value index of every observation, one byte each
 struct KValData {
   const uint32_t *tab;
   const uint8_t *idx;
@@ -46,10 +48,10 @@ AMWG_HD_SHARED double k_valued_sum(double acc, const double (&c)[K], const KValD
     return v;
   };
   auto step = [&](int obs) { acc = acc + addend(obs); };
+  (void)W;
   auto count_before = [&](int k, int m) -> uint32_t {
-    const uint32_t *mask = B.tab + (size_t)(2 * k) * W, *pre = mask + W;
-    const int w = m >> 5;
-    return pre[w] + (uint32_t)__builtin_popcount(mask[w] & low_mask(m & 31));
+    const uint32_t *blk = B.tab + (size_t)(m >> 5) * (2 * K);
+    return blk[k] + (uint32_t)__builtin_popcount(blk[K + k] & low_mask(m & 31));
   };
   const uint64_t kMant = 0x000fffffffffffffull, kHidden = 0x0010000000000000ull, kSat = ~0ull;
   int ek[K];
@@ -69,29 +71,83 @@ AMWG_HD_SHARED double k_valued_sum(double acc, const double (&c)[K], const KValD
     for (; i < N; ++i) step(i);
     return acc;
   }
+  // Shape of the loop (it matters on the device, where the 64 lanes of a wavefront are 64 different chains): every trip of the outer loop
+  // first lets each lane add term by term for as long as IT has to -- cheap trips, lanes wait for the slowest -- and then makes ONE
+  // bisection for all lanes together.  (Written as one loop with the term-by-term cases as `continue`, the lanes drifted apart and every
+  // trip paid a full bisection because SOME lane needed one: ten times the loads and instructions of a single chain.)
   while (i < N) {
-    const uint64_t ab = f64_bits(-acc);
-    const int e = (int)(ab >> 52);                  // includes the sign bit of -acc: > 0x7ff when acc > 0
-    if (!(e >= emax + 1 && e < 0x7ff)) { step(i); ++i; continue; }   // acc not yet negative / not yet 2x the largest addend / inf / NaN
-    uint64_t A = (ab & kMant) | kHidden;            // |acc| = A * 2^(e - 1075)
-    uint64_t d[K];
-    bool tie = false, any = false;
+    uint64_t A = 0, d[K];
+    int e = 0;
+    bool ready = false, any = false;
+    while (i < N) {
+      const uint64_t ab = f64_bits(-acc);
+      e = (int)(ab >> 52);                          // includes the sign bit of -acc: > 0x7ff when acc > 0
+      if (!(e >= emax + 1 && e < 0x7ff)) { step(i); ++i; continue; }   // acc not yet negative / not yet 2x the largest addend / inf / NaN
+      A = (ab & kMant) | kHidden;                   // |acc| = A * 2^(e - 1075)
+      int n_tie = 0, t_tie = 0;
+      any = false;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int s = e - ek[k];                      // >= 1
-      if (s >= 54) d[k] = 0;
-      else {
-        const uint64_t r = mk[k] & ((1ull << s) - 1ull), h = 1ull << (s - 1);
-        tie = tie || r == h;
-        d[k] = (mk[k] >> s) + (r > h ? 1u : 0u);
+      for (int k = 0; k < K; ++k) {
+        const int s = e - ek[k];                    // >= 1
+        if (s >= 54) d[k] = 0;
+        else {
+          const uint64_t r = mk[k] & ((1ull << s) - 1ull), h = 1ull << (s - 1);
+          if (r == h) { ++n_tie; t_tie = k; }
+          d[k] = (mk[k] >> s) + (r > h ? 1u : 0u);  // (a tying addend: d = its floor q)
+        }
+        any = any || d[k] != 0;
       }
-      any = any || d[k] != 0;
+      if (n_tie != 0) {
+        // A half-way addend in this binade: RN(A + q + 1/2) goes to the even neighbour -- up iff A + q is odd, and the result is even -- so its
+        // rounding depends on the ORDER of the other addends (each flips the parity of A iff its d is odd), not on their counts.  With ONE
+        // tying addend t the binade is still walked 32 observations at a time on the occurrence masks: with Z = the observations whose
+        // addend has an odd d and X = the exclusive prefix XOR of Z, the parity in front of an occurrence of t is X there XOR X at the
+        // previous occurrence (the parity is 0 right after one), or the incoming parity XOR X before the first; a fill-forward of X over
+        // the occurrences of t gives all 32 at once.  (A lane of a wavefront that met such a binade term by term held the other 63 up for
+        // thousands of additions: the longest of 64 such runs, not the average, was what an evaluation cost.)  Two or more tying addends,
+        // and the block in which the binade is left: term by term.
+        if (n_tie == 1) {
+          const int t = t_tie;
+          bool moved = false;
+          while (i < N) {
+            const int w = i >> 5;
+            const uint32_t *blk = B.tab + (size_t)w * (2 * K);
+            const uint32_t keep = ~low_mask(i & 31);
+            uint32_t Tm = 0, Z = 0;
+            uint64_t add = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const uint32_t m = blk[K + k] & keep;
+              add += (uint64_t)__builtin_popcount(m) * d[k];
+              if (k == t) Tm = m; else Z |= (d[k] & 1ull) ? m : 0u;
+            }
+            uint32_t x = Z;                          // inclusive prefix XOR towards later observations
+            x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16;
+            const uint32_t X = x << 1;               // exclusive: bit j = parity of the odd addends among the block's observations before j
+            uint32_t v = X & Tm, m = Tm;             // fill-forward: v = X at the last occurrence of t at or before each position (where m says there is one)
+            v |= (v << 1) & ~m; m |= m << 1;
+            v |= (v << 2) & ~m; m |= m << 2;
+            v |= (v << 4) & ~m; m |= m << 4;
+            v |= (v << 8) & ~m; m |= m << 8;
+            v |= (v << 16) & ~m; m |= m << 16;
+            const uint32_t prev_val = v << 1, prev_cov = m << 1;      // ... strictly before each position
+            const uint32_t QB = (d[t] & 1ull) ? ~0u : 0u, PIN = (A & 1ull) ? ~0u : 0u;
+            const uint32_t up = Tm & ((prev_cov & (X ^ prev_val ^ QB)) | (~prev_cov & (X ^ PIN ^ QB)));
+            const uint64_t A_new = A + add + (uint64_t)__builtin_popcount(up);
+            if (A_new >= (1ull << 53)) break;        // the binade is left inside this block
+            A = A_new;
+            i = (w + 1) * 32 < N ? (w + 1) * 32 : N;
+            moved = true;
+          }
+          if (moved) acc = -bits_f64(((uint64_t)e << 52) | (A & kMant));
+        }
+        while (i < N && (int)(f64_bits(-acc) >> 52) == e) { step(i); ++i; }
+        continue;
+      }
+      ready = true;
+      break;
     }
-    if (tie) {      // a half-way addend in this binade: its rounding depends on the order of the others -- term by term until the binade is left
-      do { step(i); ++i; } while (i < N && (int)(f64_bits(-acc) >> 52) == e);
-      continue;
-    }
-    if (!any) break;                                // every addend is below half an ulp of acc: nothing changes any more
+    if (!ready || !any) break;                      // the data is used up | every addend is below half an ulp of acc: nothing changes any more
     const uint64_t limit = (1ull << 53) - A;        // the significand may grow by strictly less than this
     uint32_t base[K];
 #pragma unroll
@@ -105,10 +161,12 @@ AMWG_HD_SHARED double k_valued_sum(double acc, const double (&c)[K], const KValD
     auto growth = [&](int m) -> uint64_t {          // growth of the significand over the observations [i, m); kSat when it certainly reaches `limit`
       uint64_t T = 0;
       bool sat = false;
+      uint32_t cnt[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) cnt[k] = count_before(k, m);      // (the 2 K words of block m >> 5: requested together, no branch in between)
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        if (d[k] == 0) continue;
-        const uint64_t t = scaled(count_before(k, m) - base[k], d[k]);
+        const uint64_t t = scaled(cnt[k] - base[k], d[k]);
         sat = sat || t >= limit;
         T += t < limit ? t : 0;                     // (each kept term < 2^52, K <= 16: no overflow)
       }

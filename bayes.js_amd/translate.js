@@ -858,9 +858,10 @@ Translator.prototype.kValuedTables = function (id) {
   const K = first.length;
   if (K < 1 || N < 64) return null;
   const tab = new Uint32Array(2 * K * W), idx = new Array(N);
-  for (let i = 0; i < N; i++) { const k = slot.get(x[i]); idx[i] = k; tab[2 * k * W + (i >> 5)] |= (1 << (i & 31)) >>> 0; }
+  // per block of 32 observations: pre[K] then mask[K], side by side (csrc/amwg_kval.h)
+  for (let i = 0; i < N; i++) { const k = slot.get(x[i]); idx[i] = k; tab[(i >> 5) * 2 * K + K + k] |= (1 << (i & 31)) >>> 0; }
   const popc = (v) => { v = v - ((v >>> 1) & 0x55555555); v = (v & 0x33333333) + ((v >>> 2) & 0x33333333); return (((v + (v >>> 4)) & 0x0f0f0f0f) * 0x01010101) >>> 24; };
-  for (let k = 0; k < K; k++) for (let w = 1; w < W; w++) tab[(2 * k + 1) * W + w] = tab[(2 * k + 1) * W + w - 1] + popc(tab[2 * k * W + w - 1]);
+  for (let w = 1; w < W; w++) for (let k = 0; k < K; k++) tab[w * 2 * K + k] = tab[(w - 1) * 2 * K + k] + popc(tab[(w - 1) * 2 * K + K + k]);
   const signed = new Array(2 * K * W);
   for (let k = 0; k < 2 * K * W; k++) signed[k] = tab[k] | 0;
   const t = this.registerArray(key + ':tab', signed);

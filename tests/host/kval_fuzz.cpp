@@ -20,11 +20,9 @@ static Tables tables(const std::vector<uint8_t> &v, int K) {      // same recipe
   Tables t;
   t.tab.assign((size_t)2 * K * W, 0u);
   t.idx = v;
-  for (int i = 0; i < N; ++i) t.tab[(size_t)(2 * v[i]) * W + ((size_t)i >> 5)] |= 1u << (i & 31);
-  for (int k = 0; k < K; ++k) {
-    uint32_t *mask = t.tab.data() + (size_t)(2 * k) * W, *pre = mask + W;
-    for (size_t w = 1; w < W; ++w) pre[w] = pre[w - 1] + (uint32_t)__builtin_popcount(mask[w - 1]);
-  }
+  for (int i = 0; i < N; ++i) t.tab[((size_t)i >> 5) * (2 * K) + K + v[i]] |= 1u << (i & 31);
+  for (size_t w = 1; w < W; ++w)
+    for (int k = 0; k < K; ++k) t.tab[w * (2 * K) + k] = t.tab[(w - 1) * (2 * K) + k] + (uint32_t)__builtin_popcount(t.tab[(w - 1) * (2 * K) + K + k]);
   return t;
 }
 

@@ -679,7 +679,7 @@ CASES.pois_const_rate = {
   params: () => ({ lambda: { lower: 0, init: 2 }, off: { init: 0 } }),
   data: (seed) => {
     const r = lcg(seed), y = [];
-    for (let i = 0; i < 20000; i++) { let k = 0, p = Math.exp(-3.2), f = p, u = r(); while (u > f && k < 12) { k++; p *= 3.2 / k; f += p; } y.push(k); }
+    for (let i = 0; i < 100000; i++) { let k = 0, p = Math.exp(-3.2), f = p, u = r(); while (u > f && k < 12) { k++; p *= 3.2 / k; f += p; } y.push(k); }
     return { y };
   },
   log_post: function (s, d) {

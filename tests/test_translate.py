@@ -170,9 +170,11 @@ def test_constant_rate_count_loops_are_fast_forwarded_with_one_lane():
     """`lp += ld.pois(y[i], rate)` / `ld.binom(y[i], size, prob)` with loop-invariant parameters over small-integer data: the generated code
     evaluates the term once per distinct value and hands the loop to k_valued_sum when a chain has one lane (the reference's order); the
     lane-split loop stays for G > 1.  (That the result equals the reference's closure bit for bit is test_translated_closure_equals_reference_on_host.)"""
-    for name, K in (("pois_const_rate", 12), ("binom_const_size", 8)):
+    import re
+    for name, K in (("pois_const_rate", 13), ("binom_const_size", 8)):      # counts 0 .. 12; successes 0 .. 7
         m = user_host.host_model(name)
-        assert "kval_loop_one_lane<%d>" % K in m.source and "if constexpr (G == 1)" in m.source
+        found = re.search(r"kval_loop_one_lane<(\d+)>", m.source)
+        assert found and int(found.group(1)) == K and "if constexpr (G == 1)" in m.source
         assert any(k.startswith("#aux:kval:") for k in m.meta["array_keys"])
         assert 0 < m.meta["work_one_lane"] < 0.05 * m.meta["work_per_eval"]
 

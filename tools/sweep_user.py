@@ -17,6 +17,8 @@ LAYOUT = {  # completed params of the bench closures
     "bench_bern": ([("real", 1, 0.0, 1.0, 0.5)]),
     "bench_hier": ([("real", 32, -inf, inf, 0.5), ("real", 1, -inf, inf, 0.5), ("real", 1, 0.0, inf, 1.0)]),
     "bench_glm": ([("real", 8, -inf, inf, 0.0), ("int", 1, 0.0, 49999.0, 25000.0)]),
+    "pois_const_rate": ([("real", 1, 0.0, inf, 2.0), ("real", 1, -inf, inf, 0.0)]),      # N = 1e5 counts, constant rate: K-valued fast-forward with one lane per chain
+    "binom_const_size": ([("real", 1, 0.0, 1.0, 0.5)]),
 }[name]
 params, init = [], []
 for ty, ln, lo, hi, iv in LAYOUT:
