@@ -625,6 +625,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // v_readlane / selects: no LDS round trip in the shuffle's 31 dependent swaps nor in the per-slot lookup
   const int lane64 = tid & 63;
   int ord = lane64;
+  (void)ord;      // (the group-local kernel keeps its own order)
   const bool ord_in_regs = G >= 64 && a.pl.max_top <= 64;
   wave_priority(kStepperPriority);
   // ---- Sampler.sample: record the state BEFORE the step (mcmc.js:1020-1027)

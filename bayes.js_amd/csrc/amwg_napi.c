@@ -604,6 +604,36 @@ static napi_value GroupMoments(napi_env env, napi_callback_info info) {
   return o;
 }
 
+/* groupGatherDraws([handles], root, rows) -> {draws: Float64Array, offsets: [first element of every shard's block]}: the recorded draws of all shards, gathered
+ * to the device of shard `root` inside the library (grouped ncclSend / ncclRecv; amwg_group_gather_draws) and copied to the host in ONE copy --
+ * north_star's "RCCL gather at sample collection"; sampler.sample() uses it when options.gather is set */
+static napi_value GroupGatherDraws(napi_env env, napi_callback_info info) {
+  napi_value a[3];
+  if (!get_args(env, info, 3, a)) return NULL;
+  uint32_t n = 0;
+  amwg_sampler **g = unwrap_group(env, a[0], &n);
+  if (!g) return NULL;
+  const int32_t root = (int32_t)arg_i64(env, a[1]);
+  const int64_t rows = arg_i64(env, a[2]);
+  size_t total = 0;
+  for (uint32_t i = 0; i < n; i++) total += (size_t)rows * (size_t)amwg_num_recorded(g[i]) * (size_t)amwg_num_chains(g[i]);
+  double *data = NULL;
+  napi_value out = new_f64(env, total, &data);
+  int64_t *offs = (int64_t *)calloc(n ? n : 1, sizeof(int64_t));
+  if (!out || !offs) { free(g); free(offs); napi_throw_error(env, NULL, "amwg_napi: cannot allocate the draws array"); return NULL; }
+  int rc = amwg_group_gather_draws(g, (int32_t)n, root, NULL, data, total * 8, offs);
+  free(g);
+  if (rc != AMWG_OK) { free(offs); return throw_amwg(env, rc); }
+  napi_value o, arr;
+  NAPI_OK(napi_create_object(env, &o));
+  NAPI_OK(napi_create_array_with_length(env, n, &arr));
+  for (uint32_t i = 0; i < n; i++) { napi_value v; NAPI_OK(napi_create_double(env, (double)offs[i], &v)); NAPI_OK(napi_set_element(env, arr, i, v)); }
+  free(offs);
+  napi_set_named_property(env, o, "draws", out);
+  napi_set_named_property(env, o, "offsets", arr);
+  return o;
+}
+
 /* groupConvergence([handles]) -> {rhat, ess} over the chains of all shards */
 static napi_value GroupConvergence(napi_env env, napi_callback_info info) {
   napi_value a[1];
@@ -733,7 +763,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   static const struct { const char *name; napi_callback fn; } fns[] = {
       {"create", Create}, {"createUser", CreateUser}, {"compileUser", CompileUser}, {"destroy", Destroy}, {"burn", Burn}, {"burnAsync", BurnAsync}, {"sync", Sync},
       {"sample", Sample}, {"sampleAsync", SampleAsync}, {"fetchDraws", FetchDraws}, {"fetchDrawsSplit", FetchDrawsSplit}, {"setAdapting", SetAdapting},
-      {"getState", GetState}, {"setState", SetState}, {"convergence", Convergence}, {"quantiles", Quantiles}, {"groupMoments", GroupMoments}, {"groupConvergence", GroupConvergence}, {"groupQuantiles", GroupQuantiles}, {"info", Info}, {"diag", Diag}, {"moments", Moments}, {"launchInfo", LaunchInfo}, {"codeCacheStats", CodeCacheStats},
+      {"getState", GetState}, {"setState", SetState}, {"convergence", Convergence}, {"quantiles", Quantiles}, {"groupMoments", GroupMoments}, {"groupGatherDraws", GroupGatherDraws}, {"groupConvergence", GroupConvergence}, {"groupQuantiles", GroupQuantiles}, {"info", Info}, {"diag", Diag}, {"moments", Moments}, {"launchInfo", LaunchInfo}, {"codeCacheStats", CodeCacheStats},
       {"version", Version}, {"mathExp", MathExp}, {"mathLog", MathLog}, {"uniform", Uniform}};
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

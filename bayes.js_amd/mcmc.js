@@ -320,7 +320,15 @@ AmwgSampler.prototype.sample = function (n_iterations) {
     });
     return out;
   }
-  const flat = this._merge(this._each((sh) => N.fetchDraws(sh.handle, kept)), kept * this.PR);   // [kept][P + derived][chains]
+  // several shards: each device copies its own block to the host (N PCIe links in parallel: the default), or -- options.gather -- the blocks are
+  // first gathered to the device of shard options.gather_root (default 0) by RCCL inside the library and leave in ONE copy (north_star's wording)
+  let blocks;
+  if (this._shards.length > 1 && this.options && this.options.gather) {
+    this._each((sh) => N.sync(sh.handle));
+    const g = N.groupGatherDraws(this._shards.map((sh) => sh.handle), this.options.gather_root || 0, kept);
+    blocks = this._shards.map((sh, k) => g.draws.subarray(g.offsets[k], g.offsets[k] + kept * this.PR * sh.count));
+  } else blocks = this._each((sh) => N.fetchDraws(sh.handle, kept));
+  const flat = this._merge(blocks, kept * this.PR);   // [kept][P + derived][chains]
   for (const name of monitored) {
     const L = this._layout.find((l) => l.name === name) || derivedLayout.find((l) => l.name === name);
     if (!L) { out[name] = []; continue; }

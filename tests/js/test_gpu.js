@@ -116,6 +116,15 @@ checkAgainstGolden('glm_small', (g, rec) => new mcmc.AmwgSampler(
   assert.deepStrictEqual(Array.from(s1.sigma), Array.from(s2.sigma));
   assert.deepStrictEqual(Array.from(one.state.mu), Array.from(two.state.mu));
   assert.deepStrictEqual(Array.from(one.info().steppers.sigma.prop_log_scale), Array.from(two.info().steppers.sigma.prop_log_scale));
+  // options.gather: the shards' draws are gathered to one device inside the library (amwg_group_gather_draws) and leave it in ONE copy -- same arrays
+  {
+    const three = mk({ devices: [0, 0, 0], gather: true, gather_root: 1 });
+    three.burn(60); three.thin(4);
+    const s3 = three.sample(30);
+    assert.deepStrictEqual(Array.from(s3.mu), Array.from(s1.mu));
+    assert.deepStrictEqual(Array.from(s3.sigma), Array.from(s1.sigma));
+    three.close();
+  }
   // summaries of the sharded sampler (per-shard reductions + RCCL all-reduce, amwg_group_*) == those of the single shard
   {
     const close = (a, b, tol) => Math.abs(a - b) <= tol * Math.max(1, Math.abs(b));
