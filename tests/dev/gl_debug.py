@@ -2,7 +2,7 @@
 """development aid (GPU box): group-local sampler vs the oracle's group-local mode and vs the one-lane run, several group counts; prints which
 per-component counters differ."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (under tests/: it uses the oracle, which only the test tree may)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes.js_amd"), os.path.join(ROOT, "tests")]
 import numpy as np
 import amwg_ctypes as A, model_spec, oracle_lib
