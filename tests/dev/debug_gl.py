@@ -1,6 +1,6 @@
 """Development aid (GPU box): step the group-local GPU sampler and its oracle side by side, print the first step at which they part."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (under tests/dev: it uses the oracle, which only the test tree may)
 sys.path[:0] = [os.path.join(ROOT, "bayes.js_amd"), os.path.join(ROOT, "tests")]
 import numpy as np
 import amwg_ctypes as A, model_spec, oracle_lib, golden_io
