@@ -101,6 +101,9 @@ __global__ void amwg_eval_kernel(int op, int64_t n, const double *a, const doubl
     case 29: r = log_v8_full(x); break;
     case 30: r = log_v8_full(exp_v8_full(x)); break;
     case 31: { double lam; r = exp_log_v8(x, lam, ExpLogLiterals{}); } break;
+    case 32: r = log1p_exp_v8(x); break;                      // softplus in one straight line ...
+    case 33: r = log1p_exp_v8(x, exp_log_regs()); break;
+    case 34: r = log1p_v8(exp_v8_full(x)); break;             // ... and the full fdlibm control flow it replaces
   }
   out[i] = r;
 }

@@ -622,6 +622,50 @@ AMWG_HD double log1p_v8(double x) {
   R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
   if (k == 0) return f - (hfsq - s * (hfsq + R)); else return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
 }
+// softplus(x) = log1p_v8(exp_v8(x)) -- the log-likelihood of a logistic regression written `y*eta - Math.log1p(Math.exp(eta))` -- as ONE
+// straight line for a 64-lane SIMD: fdlibm's log1p has four data-dependent branches (x < sqrt(2)-1: no reduction; the correction term c
+// of u = 1 + x by the exponent of u; which half of [sqrt(2)/2, sqrt(2)) the significand lands in; |f| < 2^-20) and two IEEE divisions, and a
+// wavefront whose lanes are different observations takes every side of every branch.  Here the branches are selects, both quotients
+// are quot_plain (their operands need no exponent juggling: 2 + f in (1.7, 2.42); u in [1.41, 2^53) and c zero or >= 2^-54 in
+// magnitude), and what is left -- exp's rare arguments, exp(x) < 2^-29 (log1p's small-argument forms) or >= 2^53 (its large-argument form),
+// |f| < 2^-20 -- leaves through one rarely taken branch to the full functions.  For exp(x) >= sqrt(2)-1 the exponent k of the reduced
+// argument is >= 1 (u >= sqrt(2): its significand's high word is >= 0x6a09e, so k is raised), which is why only TWO result forms remain:
+// k == 0 exactly when no reduction was made.  Same bits as log1p_v8(exp_v8(x)) (tests/host/explog_fuzz.cpp, tests/test_gpu_math.py).
+#if defined(AMWG_X_NOCOLD)
+AMWG_HD double log1p_exp_cold(double x) { return log1p_v8(exp_v8(x)); }
+#else
+AMWG_HD_OUTLINE double log1p_exp_cold(double x) { return log1p_v8(exp_v8(x)); }
+#endif
+template <class K>
+AMWG_HD double log1p_exp_v8(double x, const K &c) {
+  // exp(-20) = 2.06e-9 > 2^-29 = 1.86e-9 and exp(36) = 4.3e15 < 2^53 = 9.0e15 with room to spare for exp's last-place error; a NaN fails the first test
+  if (__builtin_expect(!(x >= -20.0 && x <= 36.0) || exp_is_rare(x), 0)) return log1p_exp_cold(x);
+  const ExpParts e = exp_parts(x, c);
+  const double v = set_hi_word(e.y, hi_word(e.y) + (e.k << 20));      // exp(x), in (2^-29, 2^53)
+  const bool small = hi_word(v) < 0x3FDA827A;                            // below sqrt(2) - 1: f = v, k = 0
+  const double u = 1.0 + v;
+  const int32_t hu0 = hi_word(u);
+  const int32_t ke = (hu0 >> 20) - 1023;                                 // >= 0 (u > 1)
+  const double cn = (ke > 0) ? 1.0 - (u - v) : v - (u - 1.0);            // the rounding error of u = 1 + v
+  const double cq = quot_plain(cn, u);
+  const int32_t mant = hu0 & 0x000fffff;
+  const bool up = mant >= 0x6a09e;
+  const double un = set_hi_word(u, mant | (up ? 0x3fe00000 : 0x3ff00000));
+  // |f| < 2^-20 after the reduction (fdlibm's `hu == 0`: significand high word 0, or within 3 of the next power of two)
+  if (__builtin_expect(!small && (up ? mant > 0xffffc : mant == 0), 0)) return log1p_exp_cold(x);
+  const double f = small ? v : un - 1.0;
+  const double dk = (double)(ke + (up ? 1 : 0));
+  const double hfsq = 0.5 * f * f;
+  const double s = quot_plain(f, 2.0 + f);
+  const double z = s * s;
+  const double R = z * (c.Lg1 + z * (c.Lg2 + z * (c.Lg3 + z * (c.Lg4 + z * (c.Lg5 + z * (c.Lg6 + z * c.Lg7))))));   // (log1p's Lp1..Lp7 are log's Lg1..Lg7)
+  const double sr = s * (hfsq + R);
+  const double r0 = f - (hfsq - sr);
+  const double rk = dk * c.ln2_hi - ((hfsq - (sr + (dk * c.ln2_lo + cq))) - f);
+  return small ? r0 : rk;
+}
+AMWG_HD double log1p_exp_v8(double x) { return log1p_exp_v8(x, ExpLogLiterals{}); }
+
 AMWG_HD double expm1_v8(double x) {
   const double one = 1.0, huge = 1.0e+300, tiny = 1.0e-300, o_threshold = 7.09782712893383973096e+02,
     ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00,

@@ -83,7 +83,7 @@ const MATH_FUNS = {
   sinh: ['sinh_v8', 1, Math.sinh], cosh: ['cosh_v8', 1, Math.cosh], asinh: ['asinh_v8', 1, Math.asinh], acosh: ['acosh_v8', 1, Math.acosh], atanh: ['atanh_v8', 1, Math.atanh],
   cbrt: ['cbrt_v8', 1, Math.cbrt], log2: ['log2_v8', 1, Math.log2], clz32: ['js_clz32', 1, Math.clz32], fround: ['js_fround', 1, Math.fround],
 };
-const HEAVY = new Set(['log_v8', 'exp_v8', 'pow_v8', 'log1p_v8', 'expm1_v8', 'tanh_v8', 'atan_v8', 'log10_v8', 'sin_v8', 'cos_v8', 'tan_v8', 'asin_v8', 'acos_v8', 'sinh_v8', 'cosh_v8', 'asinh_v8', 'acosh_v8', 'atanh_v8', 'cbrt_v8', 'log2_v8', 'atan2_v8', 'hypot', 'ld_norm', 'ld_beta', 'ld_pois', 'ld_bern', 'ld_gamma', 'ld_invgamma', 'ld_lnorm', 'ld_t',
+const HEAVY = new Set(['log_v8', 'exp_v8', 'pow_v8', 'log1p_v8', 'log1p_exp_v8', 'expm1_v8', 'tanh_v8', 'atan_v8', 'log10_v8', 'sin_v8', 'cos_v8', 'tan_v8', 'asin_v8', 'acos_v8', 'sinh_v8', 'cosh_v8', 'asinh_v8', 'acosh_v8', 'atanh_v8', 'cbrt_v8', 'log2_v8', 'atan2_v8', 'hypot', 'ld_norm', 'ld_beta', 'ld_pois', 'ld_bern', 'ld_gamma', 'ld_invgamma', 'ld_lnorm', 'ld_t',
   'ld_weibull', 'ld_logis', 'ld_binom', 'ld_nbinom', 'ld_hyper', 'ld_cauchy', 'ld_pareto', 'ld_exp', 'ld_laplace', 'ld_unif', 'lgamma_js', 'lfactorial_js', 'lchoose_js', 'lbeta_js']);
 
 const ld_host = require('./ld.js');
@@ -653,7 +653,7 @@ Translator.prototype.cond = function (e) {
 Translator.prototype.call = function (e) {
   const v = this.callInner(e);
   if (v.t !== 'num' || v.cst !== undefined || v.int || !this.loops.length || this.noHoist || this.pending.length) return v;
-  if (!/^(exp_v8|log_v8|pow_v8|log1p_v8|expm1_v8|tanh_v8|atan_v8|log10_v8|__builtin_sqrt|ld_\w+|lgamma_js|lfactorial_js|lchoose_js|lbeta_js|h_\w+)\(/.test(v.code)) return v;
+  if (!/^(exp_v8|log_v8|pow_v8|log1p_v8|log1p_exp_v8|expm1_v8|tanh_v8|atan_v8|log10_v8|__builtin_sqrt|ld_\w+|lgamma_js|lfactorial_js|lchoose_js|lbeta_js|h_\w+)\(/.test(v.code)) return v;
   if (/NORMCALL|_inv\(|_inv01\(|_pre\(/.test(v.code)) return v;            // already specialised for the loop
   const k = this.hoist(e, 'double', '', v.code, '');
   return k ? num(k, false) : v;
@@ -735,6 +735,9 @@ Translator.prototype.callInner = function (e) {
     if (HEAVY.has(M[0]) && this.loops.length) this.heavyLoop = true;
     if ((f.name === 'floor' || f.name === 'ceil' || f.name === 'round' || f.name === 'trunc' || f.name === 'abs') && args[0].int)
       return f.name === 'abs' ? num('(' + args[0].code + ' < 0 ? -(' + args[0].code + ') : ' + args[0].code + ')', true, undefined, '__builtin_fabs(' + args[0].dcode + ')') : args[0];
+    // Math.log1p(Math.exp(eta)) -- softplus, the logistic log-likelihood -- is ONE straight-line function on the device (csrc/amwg_math.h
+    // log1p_exp_v8: the branches of fdlibm's log1p as selects; same bits as log1p_v8(exp_v8(eta)))
+    if (f.name === 'log1p' && args[0].expOf !== undefined) return num('log1p_exp_v8(' + args[0].expOf + ')', false);
     const r = num(M[0] + '(' + this.asD(args[0]) + ')', false);
     if (f.name === 'exp') r.expOf = this.asD(args[0]);      // (ld.pois(x, Math.exp(eta)) fuses the two, see below)
     return r;

@@ -646,11 +646,26 @@ def main():
             box = [ident]
             dist.broadcast_object_list(box, src=0)
             return box[0]
-        try:
-            comm = A.Comm(world, rank, dev_index, exchange)
-            comm_info = comm.info()
-        except Exception as e:      # the headline must not be lost to a communicator that cannot be built (the reason is printed)
-            comm, comm_error = None, repr(e)
+        # the headline must not be lost to a communicator that cannot be built -- or whose construction never returns (ncclCommInitRank is
+        # collective and blocking: it runs on a helper thread with a deadline; the reason is printed either way)
+        import threading
+        made = {}
+
+        def make():
+            try:
+                made["comm"] = A.Comm(world, rank, dev_index, exchange)
+                made["info"] = made["comm"].info()
+            except Exception as e:
+                made["error"] = repr(e)
+        th = threading.Thread(target=make, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("AMWG_BENCH_COMM_DEADLINE_S", "180")))
+        if th.is_alive():
+            comm_error = "amwg_comm_create did not return within its deadline"
+        elif "error" in made:
+            comm_error = made["error"]
+        else:
+            comm, comm_info = made["comm"], made["info"]
         if dist is not None:      # all ranks or none
             ok = torch.tensor([1 if comm is not None else 0], device="cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)

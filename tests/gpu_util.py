@@ -21,6 +21,31 @@ def run_schedule(s, schedule):
     return segs
 
 
+def run_schedule_many(samplers, schedule):
+    """The same schedule on several samplers AT ONCE (each has its own stream: the launches of one-chain samplers overlap on the device)
+    -> one list of draw arrays per sampler."""
+    segs, thin = [[] for _ in samplers], 1
+    for seg in schedule:
+        if seg["op"] == "burn":
+            for s in samplers:
+                s.burn_async(seg["n"])
+            for s in samplers:
+                s.sync()
+        elif seg["op"] == "stop":
+            for s in samplers:
+                s.set_adapting(False)
+        elif seg["op"] == "start":
+            for s in samplers:
+                s.set_adapting(True)
+        elif seg["op"] == "sample":
+            thin = seg.get("thin", thin)
+            for s in samplers:
+                s.sample_async(seg["n"], thin)
+            for k, s in enumerate(samplers):
+                segs[k].append(s.fetch_draws())
+    return segs
+
+
 def assert_chain_equals_oracle(gpu, local, orc, gpu_segs, orc_segs):
     """Bit-exact comparison of local chain `local` of a GPU sampler with an oracle chain run in the same order."""
     for g, o in zip(gpu_segs, orc_segs):

@@ -701,6 +701,46 @@ CASES.binom_const_size = {
   schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
 };
 
+// logistic regression at N = 10^4 in its two usual spellings: `y*eta - Math.log1p(Math.exp(eta))` (softplus: ONE straight-line device
+// function, csrc/amwg_math.h log1p_exp_v8) and `ld.bern(y, 1 / (1 + Math.exp(-eta)))` (distributions.js:228-230)
+const logit_data = (seed) => {
+  const r = lcg(seed), x1 = [], x2 = [], x3 = [], y = [];
+  for (let i = 0; i < 10000; i++) {
+    const a = r() * 4 - 2, b = r() * 2 - 1, c = (r() + r() + r() - 1.5) * 2;
+    x1.push(a); x2.push(b); x3.push(c);
+    y.push(r() < 1 / (1 + Math.exp(-(-0.4 + 1.3 * a - 0.8 * b + 0.5 * c))) ? 1 : 0);
+  }
+  return { x1, x2, x3, y };
+};
+CASES.logit_n10k = {
+  params: () => ({ b: { dim: [4], init: 0 } }),
+  data: logit_data,
+  log_post: function (s, d) {
+    var lp = 0;
+    for (var j = 0; j < 4; j++) lp += ld.norm(s.b[j], 0, 10);
+    for (var i = 0; i < d.y.length; i++) {
+      var eta = s.b[0] + s.b[1] * d.x1[i] + s.b[2] * d.x2[i] + s.b[3] * d.x3[i];
+      lp += d.y[i] * eta - Math.log1p(Math.exp(eta));
+    }
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+CASES.logit_bern_n10k = {
+  params: () => ({ b: { dim: [4], init: 0 } }),
+  data: logit_data,
+  log_post: function (s, d) {
+    var lp = 0;
+    for (var j = 0; j < 4; j++) lp += ld.norm(s.b[j], 0, 10);
+    for (var i = 0; i < d.y.length; i++) {
+      var eta = s.b[0] + s.b[1] * d.x1[i] + s.b[2] * d.x2[i] + s.b[3] * d.x3[i];
+      lp += ld.bern(d.y[i], 1 / (1 + Math.exp(-eta)));
+    }
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }], chains: [0, 1],
+};
+
 CASES.categorical_arms = {
   params: () => ({ mu: {}, d_low: {}, d_high: {}, sigma: { lower: 0, init: 1 } }),
   data: (seed) => {

@@ -144,3 +144,17 @@ def test_fused_exp_log_host_fuzz(tmp_path):
                            os.path.join(root, "tests", "host", "explog_fuzz.cpp"), "-o", exe])
     p = subprocess.run([exe, "600000"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "mismatches=0" in p.stdout, p.stdout[-2000:]
+
+
+def test_fused_softplus_host_fuzz(tmp_path):
+    """csrc/amwg_math.h compiled for the host: log1p_exp_v8 (Math.log1p(Math.exp(eta)) of a logistic likelihood as one straight line of selects)
+    equals log1p_v8(exp_v8_full(x)) -- fdlibm's full control flow -- bit for bit on ~12 million arguments, and Node's own
+    Math.log1p(Math.exp(x)) on the 100 000 pairs of tests/golden/v8_softplus_pairs.bin (tests/host/softplus_fuzz.cpp; it also checks that every
+    form of log1p was visited)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "softplus_fuzz")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(root, "bayes.js_amd", "csrc"),
+                           os.path.join(root, "tests", "host", "softplus_fuzz.cpp"), "-o", exe])
+    p = subprocess.run([exe, "600000", os.path.join(root, "tests", "golden", "v8_softplus_pairs.bin")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "mismatches=0" in p.stdout and "v8_mismatches=0" in p.stdout, p.stdout[-2000:]

@@ -242,3 +242,34 @@ def test_device_js_mod_and_toint32_equal_v8():
         got = A.device_eval(op, x, y)
         ok = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
         assert ok.all(), (op, x[~ok][:5], y[~ok][:5], got[~ok][:5], want[~ok][:5])
+
+
+def test_device_fused_softplus_equals_full_flow():
+    """log1p_exp_v8 (Math.log1p(Math.exp(eta)) of a logistic likelihood as one straight line: fdlibm's branches as selects, both quotients
+    without the exponent juggling of the general division) on the device against log1p_v8(exp_v8_full(x)) on the device, and that against V8
+    on the host's golden pairs -- incl. arguments whose exp() lands next to every threshold the selects replace (tests/host/softplus_fuzz.cpp)."""
+    rng = np.random.default_rng(777)
+    parts = [rng.uniform(-8, 8, 1_000_000), rng.uniform(-22, 38, 1_000_000), rng.uniform(-745.5, 710, 200_000),
+             np.ldexp(rng.uniform(0.5, 1, 300_000), rng.integers(-60, 7, 300_000)) * rng.choice([-1.0, 1.0], 300_000)]
+    for h in (0x3FDA827A, 0x3e200000, 0x43400000, 0x3ff00000, 0x3fe00000, 0x40000000):
+        for d in range(-3, 4):
+            v = ((np.uint64(h + d) << np.uint64(32)) | rng.integers(0, 2 ** 32, 20000, dtype=np.uint64)).view(np.float64)
+            x = np.log(v)
+            parts += [x, np.nextafter(x, 1e300), np.nextafter(x, -1e300)]
+    for h in (0x3ff6a09e, 0x3ff00000, 0x3ffffffd, 0x3ff00004, 0x3ff80000):      # 1 + exp(x) = m 2^k, m next to sqrt(2), 1 and 2
+        for d in range(-3, 4):
+            m = ((np.uint64(h + d) << np.uint64(32)) | rng.integers(0, 2 ** 32, 40000, dtype=np.uint64)).view(np.float64)
+            t = np.ldexp(m, rng.integers(0, 53, 40000)) - 1.0
+            x = np.log(t[t > 0])
+            parts += [x, np.nextafter(x, 1e300), np.nextafter(x, -1e300)]
+    parts.append(np.array([-20.0, 36.0, np.nextafter(-20.0, -1e300), np.nextafter(36.0, 1e300), -20.10126823623841, 36.7368005696771, 30.0, 0.0, -0.0, 1.0, -1.0,
+                           np.inf, -np.inf, np.nan, 709.782712893384, -745.1332191019411, 1e-300, 5e-324, 0.34657359027997264, -0.8813735870195429]))
+    x = np.concatenate(parts)
+    want = A.device_eval(34, x)
+    same = lambda p, q: np.array_equal(p.view(np.uint64)[~np.isnan(q)], q.view(np.uint64)[~np.isnan(q)]) and np.array_equal(np.isnan(p), np.isnan(q))
+    assert same(A.device_eval(32, x), want)
+    assert same(A.device_eval(33, x), want)
+    # the yardstick itself against Node (Math.log1p(Math.exp(x)) of tests/golden/v8_softplus_pairs.bin, oracle/gen_math_pairs.js)
+    a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_softplus_pairs.bin"), dtype="<f8").reshape(-1, 2)
+    assert A.device_eval(34, a[:, 0]).tobytes() == np.ascontiguousarray(a[:, 1]).tobytes()
+    assert A.device_eval(32, a[:, 0]).tobytes() == np.ascontiguousarray(a[:, 1]).tobytes()

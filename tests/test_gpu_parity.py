@@ -12,7 +12,7 @@ import amwg_ctypes as A
 import golden_io
 import model_spec
 import oracle_lib
-from gpu_util import assert_chain_equals_oracle, run_schedule
+from gpu_util import assert_chain_equals_oracle, run_schedule, run_schedule_many
 
 pytestmark = pytest.mark.gpu
 
@@ -24,10 +24,10 @@ GOLDEN_CASES = ["cfg1_heights", "normal_n1000", "cfg2_full", "normal_opts", "bet
 def test_one_lane_per_chain_is_bit_identical_to_reference(name):
     gold = golden_io.load(name)
     case = gold["case"]
-    for rec in gold["chains"]:
-        spec = model_spec.spec_from_golden(gold, rec)
-        s = A.Sampler(spec, chains=3, seed=case["seed"], chain_offset=rec["chain"], lanes_per_chain=1)
-        segs = run_schedule(s, case["schedule"])
+    # (the golden's chains run side by side, each on its own stream: a one-chain sampler at N = 5e4 is a single wavefront for half a minute)
+    samplers = [A.Sampler(model_spec.spec_from_golden(gold, rec), chains=3, seed=case["seed"], chain_offset=rec["chain"], lanes_per_chain=1) for rec in gold["chains"]]
+    all_segs = run_schedule_many(samplers, case["schedule"])
+    for rec, s, segs in zip(gold["chains"], samplers, all_segs):
         for got, want in zip(segs, rec["samples"]):
             assert got.shape[0] == want["kept"]
             w = np.array(want["draws"], dtype=np.float64).reshape(-1, got.shape[1])

@@ -42,7 +42,7 @@ def spec_for(name):
 
 @pytest.mark.parametrize("name,lanes", [("readme_normal", 1), ("readme_normal", 4), ("norm_post_derived", 8), ("complex_model", 2),
                                         ("hier_binomial", 2), ("hier_normal_closure", 16), ("pois_glm_closure", 4), ("pois_glm_closure", 64),
-                                        ("spike_slab", 4), ("survival_mix", 2), ("discrete_mix", 1), ("multi_bern", 1), ("multivar_poisson", 1), ("mixture_arrays", 2), ("many_named", 4), ("readme_bern", 1), ("readme_bern", 4), ("semantics_probe", 1), ("logistic_softplus", 4), ("modern_js", 1), ("live_out_temp", 4), ("circular_wrapped_cauchy", 8), ("structured_helpers", 4), ("records_logistic", 4), ("categorical_arms", 2), ("pois_const_rate", 1), ("pois_const_rate", 4), ("binom_const_size", 1), ("binom_const_size", 8),      # K-valued fast-forward with one lane; the split loop otherwise
+                                        ("spike_slab", 4), ("survival_mix", 2), ("discrete_mix", 1), ("multi_bern", 1), ("multivar_poisson", 1), ("mixture_arrays", 2), ("many_named", 4), ("readme_bern", 1), ("readme_bern", 4), ("semantics_probe", 1), ("logistic_softplus", 4), ("modern_js", 1), ("live_out_temp", 4), ("circular_wrapped_cauchy", 8), ("structured_helpers", 4), ("records_logistic", 4), ("categorical_arms", 2), ("pois_const_rate", 1), ("pois_const_rate", 4), ("binom_const_size", 1), ("binom_const_size", 8), ("logit_n10k", 1), ("logit_n10k", 64), ("logit_bern_n10k", 16),     # K-valued fast-forward with one lane; the split loop otherwise
                                         ("wide_regression", 1), ("wide_regression", 4), ("long_dim", 1), ("long_dim", 4)])     # > 16 named parameters, > 16 data arrays, dim [300]
 def test_device_lane_sum_equals_host_emulation(name, lanes):
     spec, m, gold = spec_for(name)
@@ -120,30 +120,28 @@ def test_translated_closure_equals_hand_written_family_at_any_lane_count(name, b
 def test_translated_closures_reproduce_the_reference_at_full_baseline_sizes(closure, golden):
     """BASELINE.json configs[1..4] at their full data sizes, written as plain closures and TRANSLATED: one lane per chain
     reproduces the seeded runs of the unmodified reference (first and last chain id of each config) bit for bit."""
+    from gpu_util import run_schedule_many
     gold = golden_io.load(golden)
     src, arrays, meta = user_host.translated(closure)
+    samplers = []
     for rec in gold["chains"]:
-        params, init, opts = [], [], []
+        params, init = [], []
         for p in rec["params_completed"]:
             ln = int(np.prod(p["dim"]))
             params.append({"type": p["type"], "len": ln, "top": p["dim"][0], "multidim": 0 if p["dim"] == [1] else 1, "lower": p["lower"], "upper": p["upper"]})
             init += p["init"]
         spec = {"user": user_host.user_spec_part(src, arrays, meta), "params": params, "P": len(init), "init": init, "comp_opts": rec["comp_opts"]}
-        s = A.Sampler(spec, chains=2, seed=gold["case"]["seed"], chain_offset=rec["chain"], lanes_per_chain=1)
-        k = 0
-        for seg in gold["case"]["schedule"]:
-            if seg["op"] == "burn":
-                s.burn(seg["n"])
-            else:
-                got = s.sample(seg["n"], seg.get("thin", 1))
-                want = rec["samples"][k]
-                k += 1
-                w = np.array(want["draws"], dtype=np.float64)
-                assert np.ascontiguousarray(got[: w.shape[0], :, 0]).tobytes() == w.tobytes()
-                tot = np.zeros(got.shape[1])
-                for t in range(got.shape[0]):
-                    tot = tot + got[t, :, 0]
-                assert tot.tolist() == want["sum"]
+        samplers.append(A.Sampler(spec, chains=2, seed=gold["case"]["seed"], chain_offset=rec["chain"], lanes_per_chain=1))
+    # (the golden's chains side by side, each sampler on its own stream: one wavefront each for half a minute at N = 5e4)
+    all_segs = run_schedule_many(samplers, gold["case"]["schedule"])
+    for rec, s, segs in zip(gold["chains"], samplers, all_segs):
+        for got, want in zip(segs, rec["samples"]):
+            w = np.array(want["draws"], dtype=np.float64)
+            assert np.ascontiguousarray(got[: w.shape[0], :, 0]).tobytes() == w.tobytes()
+            tot = np.zeros(got.shape[1])
+            for t in range(got.shape[0]):
+                tot = tot + got[t, :, 0]
+            assert tot.tolist() == want["sum"]
         assert s.state()[:, 0].tolist() == rec["final_state"]
         assert s.info()["accepts"][:, 0].tolist() == rec["accepts"]
         assert int(s.diag()["uniforms"][0]) == rec["uniforms"]

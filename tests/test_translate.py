@@ -21,7 +21,7 @@ import user_host
 pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
 
 NAMES = ["readme_normal", "readme_bern", "norm_post_derived", "complex_model", "hier_binomial", "multi_bern", "multivar_poisson",
-         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js", "live_out_temp", "circular_wrapped_cauchy", "structured_helpers", "records_logistic", "categorical_arms", "pois_const_rate", "binom_const_size", "wide_regression", "long_dim", "undefined_reads", "readme_normal_swapped"] + ["cfgfuzz_%d" % k for k in range(16)]
+         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js", "live_out_temp", "circular_wrapped_cauchy", "structured_helpers", "records_logistic", "categorical_arms", "pois_const_rate", "binom_const_size", "logit_n10k", "logit_bern_n10k", "wide_regression", "long_dim", "undefined_reads", "readme_normal_swapped"] + ["cfgfuzz_%d" % k for k in range(16)]
 BIG_SHAPES = ("wide_regression", "long_dim")     # 20 named parameters + 19 data arrays; dim [300]: short runs, fewer recorded states
 
 
