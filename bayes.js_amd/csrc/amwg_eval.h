@@ -104,6 +104,7 @@ __global__ void amwg_eval_kernel(int op, int64_t n, const double *a, const doubl
     case 32: r = log1p_exp_v8(x); break;                      // softplus in one straight line ...
     case 33: r = log1p_exp_v8(x, exp_log_regs()); break;
     case 34: r = log1p_v8(exp_v8_full(x)); break;             // ... and the full fdlibm control flow it replaces
+    case 35: { bool rare = false; r = log1p_exp_v8_open(rare, x); if (rare) r = log1p_exp_cold(x); } break;   // the branch-free form of unrolled loops
   }
   out[i] = r;
 }

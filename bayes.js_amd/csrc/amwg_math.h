@@ -665,6 +665,34 @@ AMWG_HD double log1p_exp_v8(double x, const K &c) {
   return small ? r0 : rk;
 }
 AMWG_HD double log1p_exp_v8(double x) { return log1p_exp_v8(x, ExpLogLiterals{}); }
+// The same without its two branches, for an unrolled loop: `rare` is SET (never cleared) where the argument needs the full functions and the
+// value returned is then garbage (no trap); the caller evaluates its U terms back to back -- U independent dependency chains in one basic
+// block --, tests `rare` ONCE and re-forms the terms of such a lane with log1p_exp_cold (translate.js emits exactly that).
+AMWG_HD double log1p_exp_v8_open(bool &rare, double x) {
+  const ExpLogLiterals c{};
+  const ExpParts e = exp_parts(x, c);
+  const double v = set_hi_word(e.y, hi_word(e.y) + (e.k << 20));
+  const bool small = hi_word(v) < 0x3FDA827A;
+  const double u = 1.0 + v;
+  const int32_t hu0 = hi_word(u);
+  const int32_t ke = (hu0 >> 20) - 1023;
+  const double cn = (ke > 0) ? 1.0 - (u - v) : v - (u - 1.0);
+  const double cq = quot_plain(cn, u);
+  const int32_t mant = hu0 & 0x000fffff;
+  const bool up = mant >= 0x6a09e;
+  const double un = set_hi_word(u, mant | (up ? 0x3fe00000 : 0x3ff00000));
+  rare = rare || !(x >= -20.0 && x <= 36.0) || exp_is_rare(x) || (!small && (up ? mant > 0xffffc : mant == 0));
+  const double f = small ? v : un - 1.0;
+  const double dk = (double)(ke + (up ? 1 : 0));
+  const double hfsq = 0.5 * f * f;
+  const double s = quot_plain(f, 2.0 + f);
+  const double z = s * s;
+  const double R = z * (c.Lg1 + z * (c.Lg2 + z * (c.Lg3 + z * (c.Lg4 + z * (c.Lg5 + z * (c.Lg6 + z * c.Lg7))))));
+  const double sr = s * (hfsq + R);
+  const double r0 = f - (hfsq - sr);
+  const double rk = dk * c.ln2_hi - ((hfsq - (sr + (dk * c.ln2_lo + cq))) - f);
+  return small ? r0 : rk;
+}
 
 AMWG_HD double expm1_v8(double x) {
   const double one = 1.0, huge = 1.0e+300, tiny = 1.0e-300, o_threshold = 7.09782712893383973096e+02,

@@ -1271,6 +1271,20 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
       loop.push('  for (; it_ + ' + U + ' <= n_; it_ += ' + U + ') {');
       loop.push('    double tb_[' + U + '];');
       loop.push('#pragma unroll');
+      // a softplus in the term (csrc/amwg_math.h log1p_exp_v8): the U terms are formed by its branch-free form, one after the other in a single basic
+      // block, and a lane that met an argument it does not cover (flagged, a handful per million) forms its U terms again through the full functions
+      const termText = this.asD(term), softplus = /\blog1p_exp_v8\(/.test(bodyText + termText) && !this.opts.no_open_softplus;
+      if (softplus) {
+        const open = (t) => t.replace(/\blog1p_exp_v8\(/g, 'log1p_exp_v8_open(rr_, '), cold = (t) => t.replace(/\blog1p_exp_v8\(/g, 'log1p_exp_cold(');
+        loop.pop();
+        loop.push('    bool rr_ = false;');
+        loop.push('#pragma unroll');
+        loop.push('    for (int u_ = 0; u_ < ' + U + '; ++u_) { const int ' + iv + ' = i0_ + (it_ + u_) * G; ' + open(bodyText) + ' tb_[u_] = ' + open(termText) + '; }');
+        loop.push('    if (rr_) {');
+        loop.push('#pragma unroll');
+        loop.push('      for (int u_ = 0; u_ < ' + U + '; ++u_) { const int ' + iv + ' = i0_ + (it_ + u_) * G; ' + cold(bodyText) + ' tb_[u_] = ' + cold(termText) + '; }');
+        loop.push('    }');
+      } else
       loop.push('    for (int u_ = 0; u_ < ' + U + '; ++u_) { const int ' + iv + ' = i0_ + (it_ + u_) * G; ' + bodyText + ' tb_[u_] = ' + this.asD(term) + '; }');
       loop.push('#pragma unroll');
       loop.push('    for (int u_ = 0; u_ < ' + U + '; ++u_) ' + acc + ' += tb_[u_];');
@@ -1673,7 +1687,11 @@ Translator.prototype.run = function () {
   const isTab = (j) => this.arrays[j].key.indexOf('#aux:twoval:') === 0 || this.arrays[j].key.indexOf('#aux:kval:') === 0;
   const P1 = this.oneLaneWork ? makePlan(all.filter(isTab).concat(all.filter((j) => !isTab(j)))) : PG;
   const D = this.derived.length;
-  const maxThreads = this.opts.max_threads || (this.heavyLoop ? 256 : 1024);
+  // Workgroup limit.  Loops with exp / log / ld.* calls need ~140 vector registers per lane: 256-thread workgroups (one wavefront per SIMD each),
+  // several of them per CU -- unless the staged data leaves room for only ONE workgroup per CU (more than ~half of the 160 KB): then
+  // 512 threads, so that every SIMD still holds two wavefronts (a lone one cannot hide its own fp64 latency: logit_n10k, 88 KB staged,
+  // 1.52e7 -> 2.01e7 updates/s).  Plain arithmetic loops: up to 1024.
+  const maxThreads = this.opts.max_threads || (this.heavyLoop ? (off > 73728 ? 512 : 256) : 1024);
   const src = [];
   src.push('// generated by bayes.js_amd/translate.js from the user\'s log_post closure');
   src.push('namespace amwg {');

@@ -13,12 +13,24 @@
 
 using namespace amwg;
 
-static long bad = 0, seen = 0, n_small = 0, n_up = 0, n_down = 0, n_cold = 0, n_k0 = 0;
+static long n_open_clean = 0, bad = 0, seen = 0, n_small = 0, n_up = 0, n_down = 0, n_cold = 0, n_k0 = 0;
 static void check(double x) {
   const double want = log1p_v8(exp_v8_full(x));
   const double got = log1p_exp_v8(x), got_r = log1p_exp_v8(x, exp_log_regs());
   ++seen;
   auto same = [](double a, double b) { return memcmp(&a, &b, 8) == 0 || (a != a && b != b); };
+  {   // the branch-free form as translate.js uses it: four arguments back to back, one flag, flagged lanes through the full functions
+    static double prev[3] = {0.5, -3.0, 7.0};
+    const double xs[4] = {x, prev[0], prev[1], prev[2]};
+    double t[4];
+    bool rare = false;
+    for (int u = 0; u < 4; ++u) t[u] = log1p_exp_v8_open(rare, xs[u]);
+    if (rare) for (int u = 0; u < 4; ++u) t[u] = log1p_exp_cold(xs[u]);
+    else ++n_open_clean;
+    for (int u = 0; u < 4; ++u)
+      if (!same(t[u], log1p_v8(exp_v8_full(xs[u])))) { if (bad < 10) printf("MISMATCH (open) x=%a\n", xs[u]); ++bad; }
+    prev[2] = prev[1]; prev[1] = prev[0]; prev[0] = x;
+  }
   if (!same(got, want) || !same(got_r, want)) {
     if (bad < 10) printf("MISMATCH x=%a got=%a want=%a\n", x, got, want);
     ++bad;
@@ -91,6 +103,8 @@ int main(int argc, char **argv) {
     printf("v8_pairs=%ld v8_mismatches=%ld\n", v8_pairs, v8_bad);
     if (v8_pairs < 1000 || v8_bad) return 3;
   }
+  printf("open_form_unflagged_quads=%ld\n", n_open_clean);
+  if (n_open_clean < 1000) { printf("coverage too thin (open form)\n"); return 2; }
   printf("arguments=%ld no_reduction=%ld reduced_low_half=%ld (k = 0 before: %ld) reduced_high_half=%ld cold=%ld mismatches=%ld\n", seen, n_small, n_down, n_k0, n_up, n_cold, bad);
   if (n_small < 1000 || n_down < 1000 || n_up < 1000 || n_cold < 1000 || n_k0 < 1000) { printf("coverage too thin\n"); return 2; }
   return bad ? 1 : 0;

@@ -12,7 +12,8 @@ const want = process.argv.slice(3);
 for (const name of (want.length ? want : um.names)) {
   const m = um.build(name);
   const params = mcmc.complete_params(m.params, mcmc.param_init_fixed);
-  const tr = mcmc.translate(m.log_post, params, m.data, { helpers: m.helpers, constants: m.constants });
+  // ($AMWG_TRANSLATE_OPTS: extra translator options as JSON -- development A/B runs, e.g. {"no_open_softplus":true,"max_threads":256})
+  const tr = mcmc.translate(m.log_post, params, m.data, Object.assign({ helpers: m.helpers, constants: m.constants }, JSON.parse(process.env.AMWG_TRANSLATE_OPTS || '{}')));
   fs.writeFileSync(path.join(out, name + '.hip'), tr.source);
   let bytes = 4;
   for (const a of tr.arrays) bytes += 8 + a.length * 8;

@@ -269,6 +269,7 @@ def test_device_fused_softplus_equals_full_flow():
     same = lambda p, q: np.array_equal(p.view(np.uint64)[~np.isnan(q)], q.view(np.uint64)[~np.isnan(q)]) and np.array_equal(np.isnan(p), np.isnan(q))
     assert same(A.device_eval(32, x), want)
     assert same(A.device_eval(33, x), want)
+    assert same(A.device_eval(35, x), want)      # the branch-free form + its flag
     # the yardstick itself against Node (Math.log1p(Math.exp(x)) of tests/golden/v8_softplus_pairs.bin, oracle/gen_math_pairs.js)
     a = np.fromfile(os.path.join(golden_io.GOLDEN, "v8_softplus_pairs.bin"), dtype="<f8").reshape(-1, 2)
     assert A.device_eval(34, a[:, 0]).tobytes() == np.ascontiguousarray(a[:, 1]).tobytes()

@@ -1,20 +1,18 @@
 #!/bin/bash
-# (GPU box) A/B of the fused softplus: translated logistic closures with log1p_exp_v8 vs the two calls it replaces
+# (GPU box) A/B of the fused softplus and of the 512-thread workgroups of closures with large staged data:
+#   final   what the translator emits now             noopen  log1p_exp_v8 with its two branches per term
+#   bt256   final, workgroups of at most 256 threads  unfused the two calls log1p_v8(exp_v8(eta)) (round 3), 256 threads
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/softplus
+run() { echo "== $1 [$2]"; AMWG_TRANSLATE_OPTS="$3" python tools/sweep_user.py $1 $4 $5 0x0 2>&1 | grep -v "^W2\|^E2"; }
 for n in logit_n10k; do
-  for mode in fused unfused; do
-    if [ $mode = unfused ]; then export SWEEP_UNFUSE=1; else unset SWEEP_UNFUSE; fi
-    echo "== $n $mode"
-    python tools/sweep_user.py $n 8192 20 0x0 64x256 16x256 1x256
-  done
+  run $n final '{}' 8192 20
+  run $n noopen '{"no_open_softplus":true}' 8192 20
+  run $n bt256 '{"max_threads":256}' 8192 20
+  SWEEP_UNFUSE=1 run $n unfused '{"no_open_softplus":true,"max_threads":256}' 8192 20
+  run $n final '{}' 65536 10
 done
-unset SWEEP_UNFUSE
-echo "== logit_bern_n10k"; python tools/sweep_user.py logit_bern_n10k 8192 20 0x0 64x256
-for n in logistic_softplus records_logistic; do
-  for mode in fused unfused; do
-    if [ $mode = unfused ]; then export SWEEP_UNFUSE=1; else unset SWEEP_UNFUSE; fi
-    echo "== $n $mode"; python tools/sweep_user.py $n 65536 200 0x0
-  done
-done
+run logit_bern_n10k final '{}' 8192 20
+run logit_bern_n10k bt256 '{"max_threads":256}' 8192 20
+run pois_const_rate final '{}' 65536 20
+run pois_const_rate final '{}' 131072 20

@@ -11,11 +11,8 @@ name, chains = sys.argv[1], int(sys.argv[2])
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 combos = [tuple(map(int, c.split("x"))) for c in sys.argv[4:]] or [(0, 0)]
 src, arrays, meta = user_host.translated(name)
-if os.environ.get("SWEEP_MAXT"):      # experiment: another workgroup limit than the translator's
-    src = src.replace("kMaxThreads = %d;" % meta["max_threads"], "kMaxThreads = %s;" % os.environ["SWEEP_MAXT"])
-    meta["max_threads"] = int(os.environ["SWEEP_MAXT"])
-if os.environ.get("SWEEP_UNFUSE"):      # A/B: the softplus of a logistic likelihood as two calls (what the translator emitted before log1p_exp_v8)
-    import re
+if os.environ.get("SWEEP_UNFUSE"):      # A/B: the softplus of a logistic likelihood as two calls (what the translator emitted before log1p_exp_v8; translate with
+    import re                           # AMWG_TRANSLATE_OPTS='{"no_open_softplus":true}' so that the call is the plain one)
     src = re.sub(r"log1p_exp_v8\((v_\w+)\)", r"log1p_v8(exp_v8(\1))", src)
 inf = float("inf")
 LAYOUT = {  # completed params of the bench closures
