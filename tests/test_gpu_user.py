@@ -149,6 +149,21 @@ def test_translated_closures_reproduce_the_reference_at_full_baseline_sizes(clos
         s.close()
 
 
+@pytest.mark.parametrize("name,chains,steps,lanes", [("logit_n10k", 2048, 1_500, 16), ("logit_bern_n10k", 1024, 1_000, 64), ("logistic_softplus", 8192, 10_000, 4)])
+def test_translated_logistic_decisions_at_many_lanes_equal_the_one_lane_run(name, chains, steps, lanes):
+    """Translated closures, decision parity counted as for the built-in families (tests/decision_parity.py): the same seeded job with one lane per
+    chain (the reference's summation order) and lane-split -- where the fused softplus runs in its branch-free form, four terms per flag test, several
+    chains to a wavefront -- chain against chain on the device; at most 50 first flips per 1e9 decisions."""
+    import math
+    import decision_parity as dp
+    spec, m, gold = spec_for(name)
+    r = dp.compare(A, spec, chains, steps, seed=gold["case"]["seed"], alt={"lanes_per_chain": lanes})
+    assert r["reference_geometry"]["lanes_per_chain"] == 1 and r["geometry"]["lanes_per_chain"] == lanes
+    assert r["decisions"] > 0.8 * chains * steps * r["components"]
+    assert r["chains_differing"] <= math.ceil(50.0 * 1e-9 * r["decisions"]), r
+    assert r["lp_abs_diff_max"] <= 1e-10 * max(1.0, r["lp_abs_typical"]), r
+
+
 def test_translated_normal_samples_the_analytic_posterior():
     """Normal model with flat-ish priors: posterior mean of mu ~ data mean, E[sigma^2] ~ s^2 (n-1)/(n-3)."""
     spec, m, gold = spec_for("norm_post_derived")
