@@ -46,6 +46,7 @@ step_kernel_t amwg_kernels_beta_bern(int lanes, int block);
 step_kernel_t amwg_kernels_hier_normal(int lanes, int block);
 step_kernel_t amwg_kernels_pois_glm(int lanes, int block);
 step_kernel_t amwg_kernel_hier_gl(int block);      // the group-local kernel of the hierarchical family (amwg_gl.h)
+step_kernel_t amwg_kernel_hier_sweep(int block);   // the hierarchical family's kernel with the sweep prefetch (row layout, 64 lanes per chain)
 
 namespace {
 
@@ -314,7 +315,8 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   s->grid = (int)((s->C + CPB - 1) / CPB);
   s->lds = (int)layout(bestB, bestG, bestCpb).total;
   if (s->user) return AMWG_OK;    // the kernel is compiled for this geometry afterwards
-  s->kernel = s->mc.group_local ? amwg_kernel_hier_gl(s->block) : pick_kernel(s->model, s->lanes, s->block);
+  s->kernel = s->mc.group_local ? amwg_kernel_hier_gl(s->block)
+              : ((hier_rows_wanted(s, s->lanes) && hier_rows_fit(s, s->block, max_lds)) ? amwg_kernel_hier_sweep(s->block) : pick_kernel(s->model, s->lanes, s->block));
   if (!s->kernel) return fail(AMWG_EINVAL, "no kernel for model %d with %d lanes per chain in workgroups of %d", s->model, s->lanes, s->block);
   return AMWG_OK;
 }
@@ -1549,6 +1551,25 @@ int amwg_launch_info(const amwg_sampler *s, int32_t *lanes, int32_t *block, int3
   if (n_launches) *n_launches = s->n_launches;
   if (kernel_ms) *kernel_ms = s->kernel_ms;
   return AMWG_OK;
+}
+
+const char *amwg_kernel_name(const amwg_sampler *s) {
+  if (!s) { (void)fail(AMWG_EINVAL, "amwg_kernel_name: null sampler"); return ""; }
+  amwg_sampler *m = const_cast<amwg_sampler *>(s);
+  if (m->kernel_name.empty()) {
+    const int cls = s->block <= 256 ? 256 : (s->block <= 512 ? 512 : 1024);
+    char buf[96];
+    if (s->user) snprintf(buf, sizeof buf, "amwg_user_step");
+    else if (s->mc.group_local) snprintf(buf, sizeof buf, "amwg_gl_kernel<HierGlModel,%d>", cls);
+    else if (s->model == AMWG_MODEL_HIER_NORMAL && s->d.pad > 0) snprintf(buf, sizeof buf, "amwg_sweep_kernel<HierNormalModel,%d>", cls);
+    else {
+      static const char *const fam[] = {"NormalModel", "BetaBernModel", "HierNormalModel", "PoisGlmModel"};
+      const int f = s->model == AMWG_MODEL_NORMAL ? 0 : (s->model == AMWG_MODEL_BETA_BERN ? 1 : (s->model == AMWG_MODEL_HIER_NORMAL ? 2 : 3));
+      snprintf(buf, sizeof buf, "amwg_step_kernel<%s,%d,%d>", fam[f], s->lanes, s->lanes > 64 ? (s->lanes <= 256 ? 256 : (s->lanes <= 512 ? 512 : 1024)) : cls);
+    }
+    m->kernel_name = buf;
+  }
+  return m->kernel_name.c_str();
 }
 
 int amwg_fp64_peak(int32_t device, double *lane_ops_per_s) {

@@ -514,6 +514,17 @@ __device__ __forceinline__ int chain_uniform(int v) {
   return v;
 }
 
+// the double lane `src` (wave-uniform) holds in v
+__device__ __forceinline__ double lane_value(double v, int src) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(f64_bits(v) >> 32), src);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f64_bits(v), src);
+  return bits_f64(((uint64_t)hi << 32) | (uint64_t)lo);
+#else
+  return v;
+#endif
+}
+
 // Device-side invariants.  The host keeps them (choose_geometry pairs cpb with one-wavefront workgroups, launch_steps cuts calls into launches
 // of at most 65 535 steps); a launch that breaks one -- a future geometry or launch change -- must not look like a successful no-op: the
 // kernel leaves a bit in ChainArrays::error, which the host reads after every call (finish_timing) and reports as AMWG_EHIP.
@@ -530,7 +541,7 @@ template <class M> struct MirrorCheckOf<M, void_of<decltype(M::kMirrorCheck)>> {
 // BT: the workgroup size class the caller is compiled for (its register budget, see amwg_step_kernel); 1024-thread workgroups leave 128
 // VGPRs per lane, and with four waves per SIMD the staged pass does not need eight observations in flight per lane to keep the pipe busy:
 // it runs four-wide there (same operations in the same order, half the registers).
-template <class Model, int G, int BT = 256, bool GL = false>
+template <class Model, int G, int BT = 256, bool GL = false, bool SW = false>
 __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem) {
   constexpr int kPassU = BT >= 1024 ? 4 : 8;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -627,6 +638,11 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   int ord = lane64;
   (void)ord;      // (the group-local kernel keeps its own order)
   const bool ord_in_regs = G >= 64 && a.pl.max_top <= 64;
+  // sweep prefetch (below): a model with the lane-local re-evaluation in its row layout, a chain on one whole wavefront, the order in registers
+  // (SW: its own kernel, amwg_sweep_kernel below -- the host launches it when the row layout is in use; the ordinary kernel, which is also the
+  // full-evaluation one, does not carry the extra registers: with the sweep compiled into it, it ran a third slower)
+  constexpr bool kSweep = SW && !GL && LaneReuseOf<Model>::value && G == 64 && !BinaryOf<Model>::value;
+  const bool sweep_rt = kSweep && ord_in_regs && a.d.pad > 0;
   wave_priority(kStepperPriority);
   // ---- Sampler.sample: record the state BEFORE the step (mcmc.js:1020-1027)
   auto record_draws = [&](int step) {
@@ -656,10 +672,11 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     }
   };
   // ---- Roberts-Rosenthal batch adaptation of one component (mcmc.js:536-550); `store`: this lane writes the component's HBM words
-  auto adapt_component = [&](int comp, bool accepted, int2 cnt, double batch_size, bool store) {
+  auto adapt_component = [&](int comp, bool accepted, int2 cnt, double batch_size, bool store, bool per_lane = false) {
     cnt.x += accepted ? 1 : 0;      // acceptance_count (mcmc.js:530)
     cnt.y += 1;                     // iterations_since_adaption (mcmc.js:537)
-    if (chain_true<GL ? 1 : G>((double)cnt.y >= batch_size)) {    // batch boundary: the only time batch_count is touched (it stays in HBM); (the group-local sweep calls this per lane)
+    const bool boundary = (double)cnt.y >= batch_size;
+    if (per_lane ? boundary : chain_true<GL ? 1 : G>(boundary)) {    // batch boundary: the only time batch_count is touched (it stays in HBM); (the group-local sweep calls this per lane)
       const CompConst k = cc[comp];
       // single-wave chains: batch_count and the log scale live in HBM (all lanes of the chain are in lockstep, so they
       // read the old value together before the writer lane stores the new one); multi-wave chains keep per-wave replicas
@@ -676,6 +693,25 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       else if (store) { g_bc[gi] = bc; g_pls[gi] = pls; }
     }
     CNTme[comp] = cnt;
+  };
+
+  // Math.exp(prop - curr) > Math.random() (mcmc.js:527-528), for a chain whose lanes all hold the same difference and uniform.  For a difference
+  // >= 0 (incl. +inf) the exponential is >= 1 > u, below -746 it is exactly 0 (never > u): the decision is the reference's without evaluating it; NaN
+  // takes the general path (false).  For d < 0:  1 + d <= exp(d) <= 1 + d + d*d/2, and V8's exp is within one ulp (< 2^-53 here) of exp: a uniform below
+  // the lower bound or above the upper one (each taken with a margin of 2^-50, an order of magnitude more than the roundings of the bounds themselves
+  // plus that ulp) decides the comparison exactly as the exponential would -- which is then evaluated for the band in between only (about a quarter of
+  // the proposals at a 44 % acceptance rate).
+  auto accept_sweep = [&](double diff, double u_accept) -> bool {
+    bool accepted = false;
+    if (chain_true<G>(diff >= 0.0)) accepted = true;
+    else if (chain_true<G>(diff < -746.0)) accepted = false;
+    else {
+      const double lower = 1.0 + diff;
+      if (chain_true<G>(u_accept < lower - 0x1p-50)) accepted = true;
+      else if (chain_true<G>(diff > -1.0 && u_accept > (lower + 0.5 * diff * diff) + 0x1p-50)) accepted = false;
+      else accepted = chain_true<G>(exp_v8(diff) > u_accept);
+    }
+    return chain_true<G>(accepted);
   };
 
   // ================================================================================================================================
@@ -857,6 +893,13 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     shuffle_named();
     // ---- every scalar component exactly once; `slot` is uniform across the block
     int np = 0, e = 0, e_top = 0, e_in = 0;   // position inside the current parameter: e = e_top * inner + e_in (no division per slot)
+    // Sweep prefetch (models with the lane-local re-evaluation, Model::prefetch_rows): when the walk reaches the vector parameter whose entries are
+    // the lanes' group means, the proposals and accept uniforms of ALL its updates are drawn at once -- the same uniforms for the same purposes in
+    // the same order: nothing an update draws depends on an earlier decision -- and kept one per lane (lane c: component c); the model forms
+    // every lane's proposed sum in one pass, and the updates then run as always, taking their proposal and uniform from the lanes.
+    double sw_prop = 0.0, sw_u = 0.0;
+    int sw_left = 0;          // updates of the sweep still to come (0: the stepper draws as it goes)
+    bool sw_pending = false;  // the parameter whose first slot comes next is such a sweep: drawn at the top of that slot
     // descriptor of the parameter being walked, read from the LDS tables once, when the parameter begins (round 2 re-read it in every
     // slot: a dependent LDS round trip per update in front of the component lookup)
     int d_len = 1, d_base = 0, d_multi = 0, d_inner = 1;
@@ -891,6 +934,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
               idx.set(j, ti);
             }
           }
+          if constexpr (kSweep) sw_pending = sweep_rt && d_base == 0 && d_inner == 1 && d_len == chain_uniform<G>(a.d.G) && d_len > 1;
         }
       }
       int comp = d_base;
@@ -920,6 +964,52 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     SlotPre nx{};
     if (P_stepped > 0) nx = prefetch(next_comp());
     for (int slot = 0; slot < P_stepped; ++slot) {
+      if constexpr (kSweep) {
+        if (sw_pending) {      // (wave-uniform) the first slot of the sweep: draw everything its updates draw, in their order
+          sw_pending = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+          uint64_t sw_inb = 0ull;      // bit c: the proposal of component c is inside its bounds (it drew an accept uniform and is evaluated)
+          for (int t = 0; t < d_len; ++t) {
+            const int c = __builtin_amdgcn_readlane(ord, t);
+            double prop_c = rnorm_js(rng, Sme[c], SDme[c]);
+            if (chain_true<G>(cc[c].type == kTypeInt)) prop_c = js_round(prop_c);
+            double u_c = 0.0;
+            if (chain_true<G>(!(prop_c < cc[c].lower || prop_c > cc[c].upper))) { u_c = rng.next(); sw_inb |= 1ull << c; }
+            sw_prop = lane64 == c ? prop_c : sw_prop;
+            sw_u = lane64 == c ? u_c : sw_u;
+          }
+          const auto rows = Model::template prefetch_rows<kPassU>(cache, S, a.mc, a.d, data_lds, sub, sw_prop, a.d.pad);
+          if (rows.ok && slot + d_len <= P_stepped) {
+            // every lane holds its committed sum and its sum under its component's proposal: an update is the butterfly of the 64 sums with the
+            // proposed ones in the lanes of ITS component -- the value the whole evaluation returns for that state, bit for bit --, the accept test,
+            // and on acceptance the new sums, value and state; counters and adaptation afterwards, every component in its own lane
+            double T_cur = rows.T_cur;
+            uint64_t acc_mask = 0ull;
+            const uint64_t inb_s = uniform_u64(sw_inb);
+            for (int t = 0; t < d_len; ++t) {
+              const int c = __builtin_amdgcn_readlane(ord, t);
+              if (!((inb_s >> c) & 1ull)) continue;
+              const double prop_c = lane_value(sw_prop, c), u_c = lane_value(sw_u, c);
+              const double Tv = rows.comp == c ? rows.T_new : T_cur;
+              const double prop_lp = butterfly<1, 64>(Tv);
+              if (accept_sweep(prop_lp - lp_curr, u_c)) { lp_curr = prop_lp; T_cur = Tv; set_state(c, prop_c); acc_mask |= 1ull << c; }
+            }
+            if (lane64 < d_len) {
+              const bool inb_l = ((inb_s >> lane64) & 1ull) != 0ull, acc_l = ((acc_mask >> lane64) & 1ull) != 0ull;
+              if (inb_l) TOTme[lane64] += 1u + (acc_l ? 0x10000u : 0u);
+              if (adapt[lane64] != 0) adapt_component(lane64, acc_l, CNTme[lane64], cc[lane64].batch_size, live, true);
+            }
+            Model::sweep_done(cache, rows, rows.comp >= 0 && ((acc_mask >> (rows.comp & 63)) & 1ull) != 0ull);
+            // the walk moves past the parameter: its first component was handed out when the previous slot looked ahead
+            e = 0; e_top = 0; e_in = 0; ++np;
+            slot += d_len - 1;
+            if (slot + 1 < P_stepped) nx = prefetch(next_comp());
+            continue;
+          }
+#endif
+          sw_left = d_len;      // update by update (the sums that could be prepared are in the lanes' caches)
+        }
+      }
       const SlotPre me = nx;
       const int comp = me.comp;
       // bounds and type: requested now, needed after the proposal is drawn (the adaptation constants only at a batch boundary)
@@ -945,12 +1035,18 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       }
       // ---- OnedimMetropolisStepper.step (mcmc.js:517-553)
       const double cur = me.cur;
-      double prop = rnorm_js(rng, cur, me.sd);
-      if (chain_true<G>(k_type == kTypeInt)) prop = js_round(prop);
+      const bool in_sweep = kSweep && sw_left > 0;      // (this update's proposal and uniform were drawn when the sweep began)
+      double prop;
+      if (in_sweep) prop = lane_value(sw_prop, comp);
+      else {
+        prop = rnorm_js(rng, cur, me.sd);
+        if (chain_true<G>(k_type == kTypeInt)) prop = js_round(prop);
+      }
       const bool inb = chain_true<G>(!(prop < k_lower || prop > k_upper));
       // the accept test's uniform (mcmc.js:528) is the next one of the stream whatever log_post returns: drawn now
       double u_accept = 0.0;
-      if (inb) { set_state(comp, prop); u_accept = rng.next(); }
+      if (inb) { set_state(comp, prop); u_accept = in_sweep ? lane_value(sw_u, comp) : rng.next(); }
+      if (in_sweep) --sw_left;
       // everything this slot draws is drawn: the next slot's component is known (and, if a multidimensional parameter begins there,
       // shuffled), and what the stepper needs of it is requested NOW, under the evaluation below
       if (slot + 1 < P_stepped) nx = prefetch(next_comp());
@@ -1024,6 +1120,13 @@ template <class Model, int G, int BT>
 __global__ void __launch_bounds__(BT, MinWavesOf<Model>::value) amwg_step_kernel(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   step_body<Model, G, BT>(a, smem);
+}
+// the kernel of a family with the lane-local re-evaluation (Model::kLaneReuse) in its row layout, a chain on one whole wavefront: the ordinary stepper
+// plus the sweep prefetch (step_body: kSweep)
+template <class Model, int BT>
+__global__ void __launch_bounds__(BT, MinWavesOf<Model>::value) amwg_sweep_kernel(const StepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  step_body<Model, 64, BT, false, true>(a, smem);
 }
 // the group-local kernel of a family that has one (amwg_gl.h): a chain on one whole wavefront
 template <class Model, int BT>

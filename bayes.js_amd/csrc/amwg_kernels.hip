@@ -64,6 +64,17 @@ step_kernel_t amwg_kernel_hier_gl(int block) {
 }
 #endif
 
+#if AMWG_FAMILY == 2
+// the sweep kernel of the hierarchical family (row layout, 64 lanes per chain: amwg_kernel.h kSweep)
+step_kernel_t amwg_kernel_hier_sweep(int block) {
+  switch (class_of(block)) {
+    case 256: return amwg_sweep_kernel<HierNormalModel, 256>;
+    case 512: return amwg_sweep_kernel<HierNormalModel, 512>;
+    default: return amwg_sweep_kernel<HierNormalModel, 1024>;
+  }
+}
+#endif
+
 step_kernel_t AMWG_FAMILY_LOOKUP(int lanes, int block) {
   switch (lanes) {
     case 1: return single_wave<1>(block);

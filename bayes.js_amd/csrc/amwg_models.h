@@ -595,6 +595,69 @@ struct HierNormalModel {
     if (!miss) k.a_recent = hitA;
     return T;
   }
+  // SWEEP PREFETCH.  The updates of theta's components within one step draw their proposals from the chain's stream one after the other, and
+  // nothing they draw depends on what was accepted before (a proposal is rnorm(theta_c, sd_c): the component's OWN value and scale, which only its
+  // own update changes; the accept uniform follows it in the stream whatever log_post returns).  The stepper therefore draws the proposals of the
+  // whole sweep when it begins (same uniforms for the same purposes in the same order), and hands them over here -- lane c holds the proposal of
+  // theta_c --: every lane forms, in ONE ordinary pass over its own row, the sum it will be asked for when ITS group's update comes (its start
+  // value with the proposed theta in its prior term, the proposed mean, the current sd), and leaves it in the cache entry that does not hold the
+  // committed state's sum.  The 32 updates then find every lane's sum in the cache: a step makes three passes (mu, sigma, this one) instead of
+  // two passes and 32 re-formations of ~160 dependent additions each.  Nothing is approximated: an entry is only ever used when its three
+  // numbers match bit for bit, and whatever is not found is formed as before.
+  // -> what the stepper's sweep needs: ok (wave-uniform: everything below holds and the sums are there), this lane's committed sum T_cur and its sum under
+  // the proposal T_new, comp = the ONE component this lane's sum depends on (its group's mean; for the lanes that hold a term of theta's prior the
+  // same component: checked) or -1.  !ok: nothing was stored that a later evaluation could not use; the stepper goes on update by update.
+  struct SweepRows { bool ok; double T_cur, T_new; int comp; bool new_in_b; };
+  template <int U>
+  __device__ __forceinline__ static SweepRows prefetch_rows(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub, double prop_own, int pitch) {
+    SweepRows out{false, 0.0, 0.0, -1, false};
+#if defined(__HIP_DEVICE_COMPILE__)
+    load<64>(k, S, mc, d, smem, sub);
+    if (!k.regs) return out;      // (wave-uniform)
+    Pass ps = begin<64>(S, mc, d, smem, k);
+    const double sd = k.n.sd;
+    const double own = sub < d.G ? prop_own : k.th_own;
+    double mean = 0.0;
+    {
+      const int src = (k.my_group >= 0 ? k.my_group : sub) << 2;
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(f64_bits(prop_own) >> 32)), lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)f64_bits(prop_own));
+      mean = k.my_group >= 0 ? bits_f64(((uint64_t)hi << 32) | (uint64_t)lo) : 0.0;
+    }
+    // the passes below are the fast one: every proposed mean inside the range amwg_div.h needs (a lane checks the component it holds), like begin() checks
+    // the current ones; and a lane that holds a term of theta's prior must have that same component as its group (its sum then depends on ONE component)
+    const bool mine_ok = !(sub < d.G) || own == 0 || mid_range(__builtin_fabs(own));
+    const bool one_comp = !(sub < d.G && k.my_group >= 0 && k.my_group != sub);
+    if (!ps.fast || __ballot(mine_ok && one_comp) != ~0ull) return out;
+    // this lane's start value as log_post forms it (kernel: prior on lane 0, then the lane's term of theta's prior), now and under the proposal
+    const double pr = prior(S, mc, d, k);
+    Cache k2 = k;
+    k2.th_own = own;
+    const double start_new = prior_split<64>(S, mc, d, sub, (sub == 0) ? pr : 0.0, k2);
+    const double start_cur = prior_split<64>(S, mc, d, sub, (sub == 0) ? pr : 0.0, k);
+    const double *row = reinterpret_cast<const double *>(smem) + (size_t)sub * pitch;
+    // the committed state's sum: in the cache (the usual case), else formed now -- by all lanes, into entry a (the first sweep of a launch)
+    bool curA = f64_bits(start_cur) == f64_bits(k.a_start) && f64_bits(k.th_pass) == f64_bits(k.a_mean) && f64_bits(sd) == f64_bits(k.a_sd);
+    const bool curB = f64_bits(start_cur) == f64_bits(k.b_start) && f64_bits(k.th_pass) == f64_bits(k.b_mean) && f64_bits(sd) == f64_bits(k.b_sd);
+    if (__ballot(!(curA || curB)) != 0ull) {
+      const double Tc = rows_full<U>(ps, row, d.n_obs, sub, start_cur);
+      if (!(curA || curB)) { k.a_start = start_cur; k.a_mean = k.th_pass; k.a_sd = sd; k.a_T = Tc; curA = true; }
+    }
+    out.T_cur = curA ? k.a_T : k.b_T;
+    ps.th_pass = mean;
+    const double Tn = rows_full<U>(ps, row, d.n_obs, sub, start_new);
+    const bool intoB = curA;
+    k.b_start = intoB ? start_new : k.b_start; k.b_mean = intoB ? mean : k.b_mean; k.b_sd = intoB ? sd : k.b_sd; k.b_T = intoB ? Tn : k.b_T;
+    k.a_start = intoB ? k.a_start : start_new; k.a_mean = intoB ? k.a_mean : mean; k.a_sd = intoB ? k.a_sd : sd; k.a_T = intoB ? k.a_T : Tn;
+    k.a_recent = intoB;      // (the committed one counts as recently used: a miss replaces the other)
+    out.ok = true;
+    out.T_new = Tn;
+    out.comp = k.my_group >= 0 ? k.my_group : (sub < d.G ? sub : -1);
+    out.new_in_b = intoB;
+#endif
+    return out;
+  }
+  // after the sweep: the entry that now holds the committed state's sum is the recently used one (the lane's component accepted: the proposal's)
+  __device__ __forceinline__ static void sweep_done(Cache &k, const SweepRows &r, bool accepted_mine) { k.a_recent = r.new_in_b != accepted_mine; }
   __device__ __forceinline__ static double lane_double(double v, int src) {      // v of lane `src` (wave-uniform)
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(f64_bits(v) >> 32), src);

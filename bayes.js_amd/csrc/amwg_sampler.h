@@ -32,6 +32,7 @@ struct amwg_sampler {
   // geometry
   int lanes = 0, block = 0, grid = 0, lds = 0, cpb = 0;   // cpb: chains per workgroup if fewer than block / lanes (StepArgs::cpb)
   step_kernel_t kernel = nullptr;
+  std::string kernel_name;          // amwg_kernel_name(): filled on first request
   uint32_t hier_periodic_mask = 0;   // HIER: bit j set = the group labels repeat with a lane stride of 2^j (g[i] == g[i mod 2^j])
   bool lp_ready = false;
   std::vector<std::pair<int, float>> tuned;   // AMWG_LANES_AUTOTUNE: (lanes per chain, ms of the timing run) of every candidate

@@ -119,7 +119,16 @@ def kernel_id_of(version):
     return m.group(1) if m else None
 
 
-def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None, group_local=False, kernel_id=None):
+def kernel_base_name(name):
+    """'void amwg::amwg_sweep_kernel<amwg::HierNormalModel, 512>(amwg::StepArgs)' (rocprofv3) and 'amwg_sweep_kernel<HierNormalModel,512> with ...'
+    (this file) -> 'amwg_sweep_kernel<HierNormalModel,512>'"""
+    n = (name or "").replace("amwg::", "").replace(" ", "")
+    n = n[4:] if n.startswith("void") else n
+    m = re.match(r"[\w]+(<[^>]*>)?", n)
+    return m.group(0) if m else n
+
+
+def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None, group_local=False, kernel_id=None, kernel=None):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_summary.json, written by
     tools/profile.sh + tools/summarize_profile.py for this same command).  PMC counters need rocprofv3 around the process, so the figure
     cannot be taken inside this run; what ties it to the run is the KERNEL ID (tools/build_id.py: a hash of the device sources + compiler
@@ -134,7 +143,13 @@ def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None, grou
             continue
         if p.get("workload", "cfg2") != workload or ("--group-local" in p.get("command", "")) != bool(group_local):
             continue
-        if lanes is not None and not re.search(r",\s*%d(,\s*\d+)?>" % lanes, p.get("kernel", "")):      # the profile must be of the same kernel instantiation (Model, lanes[, workgroup class])
+        # the profile must be of the same kernel instantiation: the kernel the roofline figure is about, by name (cfg4: the full-evaluation step kernel, not
+        # the sweep kernel that produces `value`); a name without its workgroup class (cfg3's side measurement) is matched on Model and lanes
+        want, have = kernel_base_name(kernel), kernel_base_name(p.get("kernel", ""))
+        if kernel is not None and re.search(r",\d+,\d+>$|^amwg_(sweep|gl)_kernel|^amwg_user_step", want):
+            if want != have:
+                continue
+        elif lanes is not None and not re.search(r",\s*%d(,\s*\d+)?>" % lanes, p.get("kernel", "")):
             continue
         if p.get("chains") == chains and p.get("steps_per_launch") == steps_per_launch and p.get("hbm_traffic_bytes_per_launch"):
             if kernel_id is not None and p.get("kernel_id") != kernel_id:
@@ -745,10 +760,9 @@ def main():
         measured_peak = A.fp64_peak(dev_index)      # register-only fma kernel: what the chip sustains under fp64 load
         x = spec["data"]["x"]
         version = A.lib().amwg_version().decode()
-        traffic, traffic_src, traffic_alg, traffic_why_not = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"], args.group_local, kernel_id_of(version))
         kname = {"normal": "NormalModel", "beta_bern": "BetaBernModel", "hier_normal": "HierNormalModel", "pois_glm": "PoisGlmModel"}[spec["model"]]
         bt_class = 256 if li["block_threads"] <= 256 else (512 if li["block_threads"] <= 512 else 1024)
-        kernel = "amwg_step_kernel<%s,%d,%d>" % (kname, li["lanes_per_chain"], bt_class)
+        kernel = li.get("kernel") or "amwg_step_kernel<%s,%d,%d>" % (kname, li["lanes_per_chain"], bt_class)      # (amwg_kernel_name: what a profiler lists)
         roof_launch_s, roof_updates, roof_note = launch_s, updates_per_launch, None
         if args.workload == "cfg3":
             # the headline value uses the exact fast-forward of the two-valued sum, which does not stream the data at all; the
@@ -768,10 +782,11 @@ def main():
             t.burn(3 * args.steps_per_launch)
             roof_launch_s, roof_updates = t.launch_info()["kernel_ms"] * 1e-3, chains * 3 * args.steps_per_launch * P
             tl = t.launch_info()
-            kernel = "amwg_step_kernel<HierNormalModel,%d,%d> with options.full_evaluation = 1" % (tl["lanes_per_chain"], 256 if tl["block_threads"] <= 256 else (512 if tl["block_threads"] <= 512 else 1024))
+            kernel = "%s with options.full_evaluation = 1" % tl["kernel"]
             roof_note = ("roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s; `value` re-forms only the per-lane sums an update "
                          "can have changed (csrc/amwg_models.h lane_sum_rows: bit-identical)" % (roof_updates / roof_launch_s))
             t.close()
+        traffic, traffic_src, traffic_alg, traffic_why_not = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"], args.group_local, kernel_id_of(version), kernel)
         lane_ops = roof_updates * n_obs * ops_per_obs / roof_launch_s
         if args.group_local:
             lane_ops *= 2.0 / P          # two passes per step of P updates (see measure_other_config)

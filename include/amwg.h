@@ -286,6 +286,11 @@ int64_t amwg_num_chains(const amwg_sampler *s);
 /* Launch geometry actually used and HIP-event time of the step kernels of the last burn/sample call. */
 int amwg_launch_info(const amwg_sampler *s, int32_t *lanes_per_chain, int32_t *block_threads, int32_t *grid_blocks,
                      int32_t *lds_bytes, int32_t *n_launches, double *kernel_ms);
+/* Name of the step kernel this sampler launches, as a profiler lists it (without the amwg:: qualifiers): "amwg_step_kernel<HierNormalModel,64,512>",
+ * "amwg_sweep_kernel<HierNormalModel,512>" (the hierarchical family's row layout: lane-local re-evaluation + sweep prefetch),
+ * "amwg_gl_kernel<HierGlModel,512>" (options.group_local), "amwg_user_step" (a translated closure).  The last number is the workgroup size
+ * class the kernel was compiled for (256 / 512 / 1024).  Valid until the sampler is destroyed. */
+const char *amwg_kernel_name(const amwg_sampler *s);
 int amwg_destroy(amwg_sampler *s);
 const char *amwg_last_error(void);
 const char *amwg_version(void);

@@ -33,7 +33,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -falign-loops=64 -Wno-unused-function --cuda-device-only -S".split()
 
 # the instantiations bench.py times (model, lanes per chain); any workgroup size of those is gated
-DEFAULT_GATE = ["NormalModel,1,256", "HierNormalModel,64,512", "HierNormalModel,32,1024", "PoisGlmModel,64,256", "BetaBernModel,1,1024", "HierGlModel,512"]
+DEFAULT_GATE = ["NormalModel,1,256", "HierNormalModel,64,512", "HierNormalModel,sweep,512", "HierNormalModel,32,1024", "PoisGlmModel,64,256", "BetaBernModel,1,1024", "HierGlModel,512"]
 
 
 def compile_asm(family):
@@ -147,9 +147,11 @@ def main():
     for asm in asms:
         txt = open(asm).read()
         meta, bodies = kernel_metadata(txt), kernel_bodies(txt)
-        names = [n for n in meta if "amwg_step_kernel" in n or "amwg_user_step" in n or "amwg_gl_kernel" in n]
+        names = [n for n in meta if "amwg_step_kernel" in n or "amwg_user_step" in n or "amwg_gl_kernel" in n or "amwg_sweep_kernel" in n]
         for n, d in zip(names, demangle(names)):
-            short = re.sub(r"^void amwg::amwg_(?:step|gl)_kernel<amwg::(.*)>\(.*$", r"\1", d).replace(" ", "")
+            short = re.sub(r"^void amwg::amwg_(?:step|gl|sweep)_kernel<amwg::(.*)>\(.*$", r"\1", d).replace(" ", "")
+            if "amwg_sweep_kernel" in d:
+                short = short.replace("HierNormalModel,", "HierNormalModel,sweep,")
             st = loop_stats(bodies.get(n, []))
             row = {"kernel": short, **meta[n], **{"loop_" + k: v for k, v in st["in_loops"].items()}, "total_instructions": st["whole_kernel"]["instructions"]}
             rows.append(row)

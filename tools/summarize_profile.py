@@ -14,12 +14,14 @@ shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, tag +
 bench = json.load(open(os.path.join(src, "bench_under_trace.json")))
 # the kernel the bench line is about (the parity gate of bench.py also launches one-lane kernels: not those)
 import re
-m = re.match(r"amwg_step_kernel<(\w+),(\d+)(?:,(\d+))?>", bench["roofline"]["kernel"])
+m = re.match(r"amwg_step_kernel<(\w+),(\d+)(?:,(\d+))?>", bench["roofline"]["kernel"]) or re.match(r"amwg_(sweep|gl)_kernel<(\w+),(\d+)>", bench["roofline"]["kernel"])
 workload = re.search(r"--workload (\w+)", open(os.path.join(src, "command.txt")).read() if os.path.exists(os.path.join(src, "command.txt")) else "")
 workload = workload.group(1) if workload else "cfg2"
 is_bench_kernel = lambda name: ("amwg_step_kernel" in name and re.search(r"%s,\s*%s(,\s*\d+)?>" % (m.group(1), m.group(2)), name) is not None)
 if "--group-local" in (open(os.path.join(src, "command.txt")).read() if os.path.exists(os.path.join(src, "command.txt")) else ""):
     is_bench_kernel = lambda name: "amwg_gl_kernel" in name      # the group-local evaluation is its own kernel since round 4 (csrc/amwg_gl.h)
+elif bench["roofline"]["kernel"].startswith("amwg_sweep_kernel"):
+    is_bench_kernel = lambda name: "amwg_sweep_kernel" in name   # the hierarchical family's row layout (lane-local re-evaluation + sweep prefetch)
 pmc = {}
 meta = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
