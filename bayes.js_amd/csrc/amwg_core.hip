@@ -248,7 +248,9 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     return G > 64 ? lds_layout(data_bytes, s->P, G / 64, s->pl.max_top, s->n_params, true) : lds_layout(data_bytes, s->P, cpb ? cpb : bt / G, s->pl.max_top, s->n_params);
   };
   const int max_bt = s->user ? s->user_max_threads : model_max_threads(s->model);
-  auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds; };
+  // (the hierarchical family's sweep kernel -- row layout, 64 lanes per chain -- keeps the window stream and the sweep's per-lane values in registers:
+  // compiled for at most 512 threads, where a lane has 256 of them; with the 128 of a 1024-thread workgroup it ran from scratch memory, five times slower)
+  auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds && !(bt > 512 && hier_rows_wanted(s, G) && hier_rows_fit(s, 512, max_lds)); };
   if (s->user && !s->user_parallel && o.lanes_per_chain > 1)
     return fail(AMWG_EINVAL, "this closure has no loop that can be split over lanes: lanes_per_chain must be 1 (or 0 = auto), got %d", o.lanes_per_chain);
   const int bts[5] = {1024, 512, 256, 128, 64};
@@ -423,9 +425,10 @@ int finish_timing(amwg_sampler *s) {
     HIP_TRY(hipMemcpy(&bits, s->ch.error, sizeof bits, hipMemcpyDeviceToHost));
     if (bits) {
       HIP_TRY(hipMemset(s->ch.error, 0, sizeof bits));
-      return fail(AMWG_EHIP, "the step kernel reported an internal error (bits %d:%s%s%s): the chains' state is not to be trusted", bits,
+      return fail(AMWG_EHIP, "the step kernel reported an internal error (bits %d:%s%s%s%s): the chains' state is not to be trusted", bits,
                   (bits & 1) ? " replicated chains in a workgroup of more than one wavefront" : "", (bits & 2) ? " more than 65535 steps in one launch" : "",
-                  (bits & 4) ? " the register mirror of the state is out of sync with the state" : "");
+                  (bits & 4) ? " the register mirror of the state is out of sync with the state" : "",
+                  (bits & 8) ? " the sweep kernel was launched for a parameter vector of more than 64 entries" : "");
     }
   }
   return AMWG_OK;

@@ -390,8 +390,9 @@ __device__ __forceinline__ double js_max2(double a, double b) {
 }
 
 // the random stream a step kernel draws from: the cooperative stream of the chain's lanes, or -- group-local kernel -- the model's window stream
-template <class M, int G, bool GL> struct RngOf { using type = CoopStream<G>; };
-template <class M, int G> struct RngOf<M, G, true> { using type = typename M::Stream; };
+template <class M, int G, bool GL, bool SW = false> struct RngOf { using type = CoopStream<G>; };
+template <class M, int G> struct RngOf<M, G, true, false> { using type = typename M::Stream; };
+template <class M, int G> struct RngOf<M, G, false, true> { using type = typename M::SweepStream; };      // the sweep kernel (kSweep): the window stream as well
 // bytes of the data region of a workgroup's LDS
 template <class M, class = void> struct DynamicLdsOf { static constexpr bool value = false; };
 template <class M> struct DynamicLdsOf<M, void_of<decltype(M::kDynamicLds)>> { static constexpr bool value = M::kDynamicLds; };
@@ -528,7 +529,7 @@ __device__ __forceinline__ double lane_value(double v, int src) {
 // Device-side invariants.  The host keeps them (choose_geometry pairs cpb with one-wavefront workgroups, launch_steps cuts calls into launches
 // of at most 65 535 steps); a launch that breaks one -- a future geometry or launch change -- must not look like a successful no-op: the
 // kernel leaves a bit in ChainArrays::error, which the host reads after every call (finish_timing) and reports as AMWG_EHIP.
-constexpr int kErrReplicasNeedOneWave = 1, kErrLaunchTooLong = 2, kErrMirrorOutOfSync = 4;
+constexpr int kErrReplicasNeedOneWave = 1, kErrLaunchTooLong = 2, kErrMirrorOutOfSync = 4, kErrSweepNeedsOrderInRegisters = 8;
 __device__ __forceinline__ void device_error(const StepArgs &a, int code) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (threadIdx.x == 0) (void)atomicOr(a.ch.error, code);
@@ -543,7 +544,7 @@ template <class M> struct MirrorCheckOf<M, void_of<decltype(M::kMirrorCheck)>> {
 // it runs four-wide there (same operations in the same order, half the registers).
 template <class Model, int G, int BT = 256, bool GL = false, bool SW = false>
 __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem) {
-  constexpr int kPassU = BT >= 1024 ? 4 : 8;
+  constexpr int kPassU = (BT >= 1024 || SW) ? 4 : 8;      // (the sweep kernel keeps the window stream and the per-lane values of a sweep alive across its passes: four-wide as well -- eight-wide spilled 14 registers)
   const int tid = threadIdx.x, nt = blockDim.x;
   // G <= 64: nt/G chains per workgroup, each on G lanes of one wave.  G > 64 ("multi"): ONE chain per workgroup on G/64
   // waves; every wave is a full replica of the chain's scalar logic (same Philox stream => same proposals and decisions)
@@ -609,8 +610,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   uint64_t perm = wide_perm ? 0ull : a.ch.perm[cl];
   if (wide_perm)
     for (int k = 0; k < n_named; ++k) pcol.set(k, (int)a.ch.perm16[(int64_t)k * C + cl]);
-  typename RngOf<Model, G, GL>::type rng;
+  typename RngOf<Model, G, GL, SW>::type rng;
   if constexpr (GL) rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid, reinterpret_cast<double *>(smem + L.data + Model::gl_lds_bytes(a.d.pad, 0)) + (size_t)(tid >> 6) * 256);
+  else if constexpr (SW) rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid, reinterpret_cast<double *>(smem + L.data + Model::rows_window_offset(a.d.pad, nt / 64, a.d.G)) + (size_t)(tid >> 6) * 256);
   else rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid);
   double lp_curr = a.ch.lp_curr[cl];
   __syncthreads();
@@ -637,7 +639,10 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   const int lane64 = tid & 63;
   int ord = lane64;
   (void)ord;      // (the group-local kernel keeps its own order)
-  const bool ord_in_regs = G >= 64 && a.pl.max_top <= 64;
+  // (the sweep kernel is only launched for a parameter vector of at most 64 entries -- hier_rows_wanted, amwg_core.hip --: the order is always in
+  // registers there, and the LDS-table walk is not compiled in; a launch that breaks this is refused like the other device-side invariants)
+  if (SW && a.pl.max_top > 64) { device_error(a, kErrSweepNeedsOrderInRegisters); return; }
+  const bool ord_in_regs = SW ? true : (G >= 64 && a.pl.max_top <= 64);
   // sweep prefetch (below): a model with the lane-local re-evaluation in its row layout, a chain on one whole wavefront, the order in registers
   // (SW: its own kernel, amwg_sweep_kernel below -- the host launches it when the row layout is in use; the ordinary kernel, which is also the
   // full-evaluation one, does not carry the extra registers: with the sweep compiled into it, it ran a third slower)
@@ -898,6 +903,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     // the same order: nothing an update draws depends on an earlier decision -- and kept one per lane (lane c: component c); the model forms
     // every lane's proposed sum in one pass, and the updates then run as always, taking their proposal and uniform from the lanes.
     double sw_prop = 0.0, sw_u = 0.0;
+    int ord_pos = lane64;     // lane c: the place of entry c in the shuffled order (the inverse of `ord`; sweep kernel only)
     int sw_left = 0;          // updates of the sweep still to come (0: the stepper draws as it goes)
     bool sw_pending = false;  // the parameter whose first slot comes next is such a sweep: drawn at the top of that slot
     // descriptor of the parameter being walked, read from the LDS tables once, when the parameter begins (round 2 re-read it in every
@@ -916,7 +922,30 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           d_inner = chain_uniform<G>(pl_inner[p]);
           if (ord_in_regs) {
 #if defined(__HIP_DEVICE_COMPILE__)
-            if constexpr (G >= 64) {
+            if constexpr (kSweep) {
+              // the window stream: round i = top-1 .. 1 of the Fisher-Yates loop draws uniform number top-1-i of the next top-1 -- lane i fetches
+              // and scales ITS one, then the transpositions (i, j_i) are applied in sequence to every lane's POSITION (lane c tracks where entry c
+              // sits); four per trip, their j's read ahead of the dependent selects (as in the group-local kernel)
+              const uint32_t p0 = rng.position();
+              rng.ensure_b();
+              const double uf = rng.at(lane64 >= 1 && lane64 < top ? p0 + (uint32_t)(top - 1 - lane64) : 0u);
+              const int jv = (int)__builtin_floor(uf * (double)(lane64 + 1));
+              int posc = lane64, i = top - 1;
+              for (; i >= 4; i -= 4) {
+                const int j0 = __builtin_amdgcn_readlane(jv, i), j1 = __builtin_amdgcn_readlane(jv, i - 1), j2 = __builtin_amdgcn_readlane(jv, i - 2), j3 = __builtin_amdgcn_readlane(jv, i - 3);
+                posc = posc == i ? j0 : (posc == j0 ? i : posc);
+                posc = posc == i - 1 ? j1 : (posc == j1 ? i - 1 : posc);
+                posc = posc == i - 2 ? j2 : (posc == j2 ? i - 2 : posc);
+                posc = posc == i - 3 ? j3 : (posc == j3 ? i - 3 : posc);
+              }
+              for (; i > 0; --i) {
+                const int j = __builtin_amdgcn_readlane(jv, i);
+                posc = posc == i ? j : (posc == j ? i : posc);
+              }
+              rng.pos = p0 + (uint32_t)(top - 1);
+              ord_pos = posc;
+              ord = __builtin_amdgcn_ds_permute(posc << 2, lane64);      // lane posc[c] receives c (lanes >= top map onto themselves)
+            } else if constexpr (G >= 64) {
               ord = lane64;
               for (int i = top - 1; i > 0; --i) {
                 const int j = __builtin_amdgcn_readfirstlane((int)__builtin_floor(rng.next() * (double)(i + 1)));
@@ -968,16 +997,43 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         if (sw_pending) {      // (wave-uniform) the first slot of the sweep: draw everything its updates draw, in their order
           sw_pending = false;
 #if defined(__HIP_DEVICE_COMPILE__)
-          uint64_t sw_inb = 0ull;      // bit c: the proposal of component c is inside its bounds (it drew an accept uniform and is evaluated)
-          for (int t = 0; t < d_len; ++t) {
-            const int c = __builtin_amdgcn_readlane(ord, t);
-            double prop_c = rnorm_js(rng, Sme[c], SDme[c]);
-            if (chain_true<G>(cc[c].type == kTypeInt)) prop_c = js_round(prop_c);
-            double u_c = 0.0;
-            if (chain_true<G>(!(prop_c < cc[c].lower || prop_c > cc[c].upper))) { u_c = rng.next(); sw_inb |= 1ull << c; }
-            sw_prop = lane64 == c ? prop_c : sw_prop;
-            sw_u = lane64 == c ? u_c : sw_u;
+          // Every lane draws the proposal of ITS component (sweep_comp: the one its sum depends on).  Which (u, v) pair of the stream survives rnorm's
+          // rejection test (mcmc.js:44-53) is a property of the stream alone: the window stream holds those flags for 256 uniforms, a scalar loop walks
+          // the updates in their shuffled order -- first accepted pair at or after the position, then the accept uniform (as in the group-local kernel,
+          // gl_resolve_unbounded) -- and a lane reads the three uniforms of its component's update from the window.  Components with bounds or of integer
+          // type may draw no accept uniform: such a parameter is walked update by update, as always.
+          const int comp_l = Model::sweep_comp(data_lds, a.d, sub), cidx = comp_l >= 0 ? comp_l : 0;
+          const double sd_l = SDme[cidx], cur_l = Sme[cidx];
+          const double lower_l = cc[cidx].lower, upper_l = cc[cidx].upper;
+          const int type_l = cc[cidx].type;
+          if (__ballot(comp_l >= 0 && (lower_l > -kInf || upper_l < kInf || type_l == kTypeInt)) == 0ull) {
+          {
+            const int top = d_len;
+            const int pos_l = __shfl(ord_pos, cidx, 64);
+            uint32_t p_s = rng.position();
+            int ppv = 0, t_begin = 0;
+            while (t_begin < top) {
+              rng.ensure_b();
+              const uint64_t EA = uniform_u64(rng.EA), OA = uniform_u64(rng.OA), EB = uniform_u64(rng.EB) & ~(1ull << 63), OB = uniform_u64(rng.OB);
+              uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)p_s);
+              int t = __builtin_amdgcn_readfirstlane(t_begin);
+              gl_resolve_unbounded(EA, OA, EB, OB, pw, t, __builtin_amdgcn_readfirstlane(top), ppv);
+              const int t_end = t;
+              const bool in_round = comp_l >= 0 && pos_l >= t_begin && pos_l < t_end;
+              int q_raw = __shfl(ppv, pos_l, 64);      // (by all lanes, outside the select: a masked-off source lane reads as 0)
+              asm volatile("" : "+v"(q_raw));
+              const uint32_t q_l = in_round ? (uint32_t)q_raw : 0u;
+              const double u = rng.at(q_l), v_raw = rng.at(q_l + 1u), ua = rng.at(q_l + 2u);
+              const double prop_l = ((1.7156 * (v_raw - 0.5)) / u) * sd_l + cur_l;       // rnorm_js: (v / u) * sd + mean
+              sw_prop = in_round ? prop_l : sw_prop;
+              sw_u = in_round ? ua : sw_u;
+              t_begin = t_end;
+              p_s = pw;
+              rng.pos = pw;
+              if (t_begin < top) p_s = rng.position();
+            }
           }
+          const uint64_t sw_inb = d_len >= 64 ? ~0ull : ((1ull << d_len) - 1ull);      // (no bounds: every proposal is evaluated)
           const auto rows = Model::template prefetch_rows<kPassU>(cache, S, a.mc, a.d, data_lds, sub, sw_prop, a.d.pad);
           if (rows.ok && slot + d_len <= P_stepped) {
             // every lane holds its committed sum and its sum under its component's proposal: an update is the butterfly of the 64 sums with the
@@ -1006,8 +1062,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
             if (slot + 1 < P_stepped) nx = prefetch(next_comp());
             continue;
           }
+          sw_left = d_len;      // drawn, but the sums could not be prepared: update by update, proposals and uniforms taken from the lanes
+          }
 #endif
-          sw_left = d_len;      // update by update (the sums that could be prepared are in the lanes' caches)
         }
       }
       const SlotPre me = nx;

@@ -11,6 +11,7 @@
 #include "amwg_pass.h"
 #include "amwg_twoval.h"
 #include "amwg_types.h"
+#include "amwg_window.h"
 
 namespace amwg {
 
@@ -330,7 +331,14 @@ struct HierNormalModel {
   __host__ __device__ static int row_pitch(int n_obs) { return ((n_obs + 63) / 64) | 1; }
   __host__ __device__ static int local_rows(int groups) { const int per_group = groups > 0 ? 64 / groups : 1; const int r = per_group < 2 ? 2 : per_group; return r > kMaxLocal ? kMaxLocal : r; }      // term rows per wavefront: the lanes of one group (in pairs)
   __host__ __device__ static int term_pitch(int pitch) { return (pitch + 16 + 1) & ~1; }      // a row of terms: 16 spare slots (the adder reads ahead), 16-byte aligned
-  __host__ __device__ static size_t rows_lds_bytes(int pitch, int waves, int groups) { return (size_t)64 * pitch * 8 + 64 + (size_t)waves * local_rows(groups) * term_pitch(pitch) * 8; }
+  // (+ one 256-uniform window per wavefront: the sweep kernel's stream, amwg_window.h)
+  __host__ __device__ static size_t rows_window_offset(int pitch, int waves, int groups) { return (size_t)64 * pitch * 8 + 64 + (size_t)waves * local_rows(groups) * term_pitch(pitch) * 8; }
+  __host__ __device__ static size_t rows_lds_bytes(int pitch, int waves, int groups) { return rows_window_offset(pitch, waves, groups) + (size_t)waves * 256 * 8; }
+  using SweepStream = WindowStream;
+  // the one component lane `sub` of a chain on a whole wavefront stands for in a sweep over theta: the component whose prior term it holds, else its group's
+  __device__ __forceinline__ static int sweep_comp(const unsigned char *smem, const DataRef &d, int sub) {
+    return sub < d.G ? sub : (sub < d.n_obs ? (int)(smem + (size_t)64 * d.pad * 8)[sub] : -1);
+  }
   static constexpr bool kDynamicLds = true;
   __host__ __device__ static size_t lds_bytes_of(const DataRef &d, int lanes, int threads) { return d.pad > 0 ? rows_lds_bytes(d.pad, threads / 64, d.G) : lds_bytes(d.n_obs, d.G, lanes); }
   __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int) {

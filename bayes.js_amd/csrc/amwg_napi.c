@@ -704,6 +704,8 @@ static napi_value LaunchInfo(napi_env env, napi_callback_info info) {
   for (int i = 0; i < 5; i++) { napi_create_int32(env, v[i], &t); napi_set_named_property(env, o, names[i], t); }
   napi_create_double(env, ms, &t);
   napi_set_named_property(env, o, "kernel_ms", t);
+  napi_create_string_utf8(env, amwg_kernel_name(s), NAPI_AUTO_LENGTH, &t);      /* the step kernel, as a profiler lists it */
+  napi_set_named_property(env, o, "kernel", t);
   /* lanes_per_chain: -2 (AMWG_LANES_AUTOTUNE): what was timed at construction, [{lanes_per_chain, ms}, ...] */
   int32_t tl[16];
   double tm[16];
