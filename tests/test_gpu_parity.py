@@ -423,17 +423,37 @@ def test_group_local_preconditions_are_enforced():
         A.Sampler(model_spec.build_spec("normal", model_spec.make_data("normal", 100, 5)), chains=2, seed=1, group_local=1)
 
 
-@pytest.mark.parametrize("n_obs,G,chains", [(10_000, 32, 300), (1_000, 8, 130), (640, 64, 70), (257, 2, 65)])
-def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains):
+@pytest.mark.parametrize("n_obs,G,chains,theta", [(10_000, 32, 300, None), (1_000, 8, 130, None), (640, 64, 70, None), (257, 2, 65, None),
+                                                  (2_000, 32, 130, "bounded"), (1_000, 16, 70, "int"), (1_500, 8, 70, "shifted"), (900, 16, 66, "tiny")])
+def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains, theta):
     """Hierarchical family on a wavefront per chain (labels that repeat with the lane stride): by default only the lanes whose sum an update
     can have changed are re-formed (amwg_models.h lane_sum_rows); options.full_evaluation = 1 makes every evaluation pass over all the data.
     The two must agree in EVERY bit of every chain -- draws, counters, proposal scales, log_post, uniforms -- over a schedule with short launches,
     a stop / start of the adaptation, thinning, and states overwritten from the host in between (every cached sum is then stale)."""
     data = model_spec.make_data("hier_normal", n_obs, 77, G=G)
     spec = model_spec.build_spec("hier_normal", data)
-    mk = lambda full: A.Sampler(spec, chains=chains, seed=4, chain_offset=9, lanes_per_chain=64, steps_per_launch=7, full_evaluation=full)
+    # theta with bounds some proposals fall outside of, or of integer type: the sweep kernel then walks the parameter update by update (an update
+    # that draws no accept uniform cannot be drawn ahead by the lane-parallel resolution), still re-forming only the lanes an update changes
+    if theta == "bounded":
+        spec["params"][0] = dict(spec["params"][0], lower=-0.5, upper=6.5)
+    elif theta == "int":
+        spec["params"][0] = dict(spec["params"][0], type="int", lower=-3.0, upper=8.0, init=[float(round(v)) for v in spec["params"][0]["init"]])
+        spec["init"] = [v for p in spec["params"] for v in p["init"]]
+    # labels shifted against the lanes (lane j holds a term of theta_j's prior but the observations of another group: its sum depends on TWO components),
+    # or an observation outside the range the 4-operation quotient needs (IEEE division everywhere, no fast pass): the sweep is drawn ahead, its sums cannot be prepared, and the updates take their proposals from the lanes
+    kw = {}
+    if theta == "shifted":
+        data = dict(data, g=((np.arange(n_obs) + 3) % G).astype(np.int32))
+        spec = model_spec.build_spec("hier_normal", data)
+    elif theta == "tiny":
+        x = np.array(data["x"], dtype=np.float64)
+        x[5] = 1e-250
+        data = dict(data, x=x)
+        spec = model_spec.build_spec("hier_normal", data)
+    mk = lambda full: A.Sampler(spec, chains=chains, seed=4, chain_offset=9, lanes_per_chain=64, steps_per_launch=7, full_evaluation=full, **kw)
     a, b = mk(0), mk(1)
     assert a.launch_info()["lds_bytes"] != b.launch_info()["lds_bytes"]      # the row layout (tile + term rows) is in use on one side only
+    assert a.launch_info()["kernel"].startswith("amwg_sweep_kernel<HierNormalModel") and b.launch_info()["kernel"].startswith("amwg_step_kernel<HierNormalModel,64")
     rng = np.random.default_rng(3)
     outs = []
     for s in (a, b):
@@ -445,6 +465,10 @@ def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains):
         st = s.state()
         st[:, ::3] = np.random.default_rng(11).normal(5.0, 2.0, st[:, ::3].shape)
         st[-1] = np.abs(st[-1]) + 0.5                                          # sigma stays inside its bounds
+        if theta == "bounded":
+            st[:G] = np.clip(st[:G], -0.5, 6.5)
+        elif theta == "int":
+            st[:G] = np.clip(np.round(st[:G]), -3.0, 8.0)
         s.set_state(st)
         s.burn(50)
         seq.append(s.sample(30, 2))
