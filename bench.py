@@ -421,8 +421,11 @@ def measure_other_config(A, name, device, group_local=0):
         t.close()
         kernel += " with options.full_evaluation = 1"
         out["full_evaluation_value"] = roof_updates_per_s
-        note = ("roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s; `value` re-forms only the per-lane sums an update can "
-                "have changed (two of 64 lanes for an update of one group mean; mu and sigma: all) -- the same bits, %.2fx" % (roof_updates_per_s, value / roof_updates_per_s))
+        out["value_kernel"] = li.get("kernel")
+        note = ("roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s; `value` (%s) keeps the per-lane sums an update cannot "
+                "have changed and forms the proposed sums of a whole sweep over theta in one pass, its proposals drawn ahead in stream order (csrc/amwg_models.h "
+                "lane_sum_rows / prefetch_rows): three passes over the data per step instead of 34, every update still the whole log_post, the same bits -- %.2fx"
+                % (roof_updates_per_s, li.get("kernel"), value / roof_updates_per_s))
     lane_ops = roof_updates_per_s * n_obs * ops_per_obs
     if group_local:
         # group-local evaluation: a step of the P = G + 2 updates makes TWO passes over the data (the sweep over theta and the sigma update)
@@ -519,8 +522,12 @@ def main_inproc(args):
                        "rccl_ranks_seen": comm["rccl_ranks_seen"], "devices": comm["devices"], "collection_to_host": collection},
                timing={"regions": len(regs), "reported": "median region (wall clock around sample_async x N + sync x N + group_gather_draws + group_moments)",
                        "region_ms": [r[0] * 1e3 for r in regs][:64], "slowest_device_kernel_ms_last_region": kernel_ms},
-               roofline={"bound": "fp64_valu", "achieved": lane_ops, "peak": FP64_VALU_PEAK * N, "frac": lane_ops / (FP64_VALU_PEAK * N),
-                         "unit": "fp64 lane-operations/s", "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[spec["model"]]},
+               roofline=({"bound": "fp64_valu", "achieved": lane_ops, "peak": FP64_VALU_PEAK * N, "frac": lane_ops / (FP64_VALU_PEAK * N),
+                          "unit": "fp64 lane-operations/s", "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[spec["model"]], "kernel": li.get("kernel")}
+                         if not str(li.get("kernel", "")).startswith("amwg_sweep_kernel") else
+                         {"bound": "fp64_valu", "achieved": None, "peak": FP64_VALU_PEAK * N, "frac": None, "unit": "fp64 lane-operations/s", "kernel": li.get("kernel"),
+                          "note": "the sweep kernel makes three passes over the data per step of %d updates, not one per update: `value` x observations x operations is not its "
+                                  "arithmetic; the roofline figure of this workload is the full-evaluation kernel's (python bench.py --workload cfg4: roofline.frac)" % P}),
                posterior={"mean": mean.tolist()[:8], "sd": sd.tolist()[:8], "note": "amwg_group_moments over the recorded draws of all shards (last region)"})
     emit(out)
     for s in shards:
@@ -783,8 +790,9 @@ def main():
             roof_launch_s, roof_updates = t.launch_info()["kernel_ms"] * 1e-3, chains * 3 * args.steps_per_launch * P
             tl = t.launch_info()
             kernel = "%s with options.full_evaluation = 1" % tl["kernel"]
-            roof_note = ("roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s; `value` re-forms only the per-lane sums an update "
-                         "can have changed (csrc/amwg_models.h lane_sum_rows: bit-identical)" % (roof_updates / roof_launch_s))
+            roof_note = ("roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s; `value` (%s) keeps the per-lane sums an update "
+                         "cannot have changed and forms the proposed sums of a whole sweep over theta in one pass (csrc/amwg_models.h lane_sum_rows / prefetch_rows: bit-identical, "
+                         "three passes over the data per step instead of 34)" % (roof_updates / roof_launch_s, li.get("kernel")))
             t.close()
         traffic, traffic_src, traffic_alg, traffic_why_not = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"], args.group_local, kernel_id_of(version), kernel)
         lane_ops = roof_updates * n_obs * ops_per_obs / roof_launch_s

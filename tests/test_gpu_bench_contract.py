@@ -38,7 +38,10 @@ def test_default_line_has_the_contract_fields_and_an_honest_roofline():
         assert "error" not in o, o
         assert o["value"] > 0 and 0 < o["roofline"]["frac"] < 1 and o["parity"]["accept_counts_identical"] and o["parity"]["uniforms_consumed_identical"]
     assert d["other_configs"]["cfg3"]["parity"]["draws_bit_identical"] is True
-    assert d["other_configs"]["cfg4_group_local"]["speedup_over_cfg4"] > 3
+    # (cfg4's default is the sweep kernel since round 4 -- the reference's schedule with three passes per step: the opt-in group-local evaluation is
+    # less than 2x ahead of it, and > 5x ahead of the kernel that evaluates everything, which stays the roofline figure)
+    assert d["other_configs"]["cfg4_group_local"]["speedup_over_cfg4"] > 1.3
+    assert d["other_configs"]["cfg4"]["value"] > 2.5 * d["other_configs"]["cfg4"]["full_evaluation_value"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "param-updates/s" and c["sample"]
     assert c["kind"] == "reference" or c.get("reference_unavailable") is True
