@@ -123,8 +123,10 @@ typedef struct {
                               1e10-decision campaign of tools/flip_rate.py (a decision can differ only when the accept uniform falls inside the ~1e-12-relative
                               sliver between the two summation orders).  Opt-in, reported separately by bench.py */
   int32_t full_evaluation; /* 0 = default: the hierarchical family on a wavefront per chain keeps the per-lane sums of log_post that an update cannot have changed
-                              (an update of theta_g changes the sums of the lanes that hold group g only; csrc/amwg_models.h lane_sum_rows) -- the same values,
-                              bit for bit, as evaluating everything, like the cached log_post of the current state.  1 = every evaluation makes its full pass
+                              (an update of theta_g changes the sums of the lanes that hold group g only; csrc/amwg_models.h lane_sum_rows), and draws the
+                              proposals of a whole sweep over theta ahead -- in stream order: nothing an update draws depends on an earlier decision -- so that
+                              ONE pass forms every lane's proposed sum (prefetch_rows; amwg_sweep_kernel) -- the same values, bit for bit, as evaluating
+                              everything, like the cached log_post of the current state.  1 = every evaluation makes its full pass
                               over the data (what bench.py's roofline figure of cfg4 is measured with) */
   int32_t reserved[1];
 } amwg_options;
