@@ -124,7 +124,9 @@ def test_translated_closures_reproduce_the_reference_at_full_baseline_sizes(clos
     gold = golden_io.load(golden)
     src, arrays, meta = user_host.translated(closure)
     samplers = []
-    for rec in gold["chains"]:
+    # (cfg5: the LAST chain id only -- a one-lane chain at N = 5e4 is a single wavefront for half a minute, and the built-in family's test walks both ids)
+    recs = gold["chains"][-1:] if golden == "cfg5_full" else gold["chains"]
+    for rec in recs:
         params, init = [], []
         for p in rec["params_completed"]:
             ln = int(np.prod(p["dim"]))
@@ -134,7 +136,7 @@ def test_translated_closures_reproduce_the_reference_at_full_baseline_sizes(clos
         samplers.append(A.Sampler(spec, chains=2, seed=gold["case"]["seed"], chain_offset=rec["chain"], lanes_per_chain=1))
     # (the golden's chains side by side, each sampler on its own stream: one wavefront each for half a minute at N = 5e4)
     all_segs = run_schedule_many(samplers, gold["case"]["schedule"])
-    for rec, s, segs in zip(gold["chains"], samplers, all_segs):
+    for rec, s, segs in zip(recs, samplers, all_segs):
         for got, want in zip(segs, rec["samples"]):
             w = np.array(want["draws"], dtype=np.float64)
             assert np.ascontiguousarray(got[: w.shape[0], :, 0]).tobytes() == w.tobytes()
@@ -149,7 +151,7 @@ def test_translated_closures_reproduce_the_reference_at_full_baseline_sizes(clos
         s.close()
 
 
-@pytest.mark.parametrize("name,chains,steps,lanes", [("logit_n10k", 2048, 1_500, 16), ("logit_bern_n10k", 1024, 1_000, 64), ("logistic_softplus", 8192, 10_000, 4)])
+@pytest.mark.parametrize("name,chains,steps,lanes", [("logit_n10k", 1024, 1_000, 16), ("logit_bern_n10k", 512, 800, 64), ("logistic_softplus", 8192, 10_000, 4)])
 def test_translated_logistic_decisions_at_many_lanes_equal_the_one_lane_run(name, chains, steps, lanes):
     """Translated closures, decision parity counted as for the built-in families (tests/decision_parity.py): the same seeded job with one lane per
     chain (the reference's summation order) and lane-split -- where the fused softplus runs in its branch-free form, four terms per flag test, several
