@@ -179,6 +179,21 @@ def test_constant_rate_count_loops_are_fast_forwarded_with_one_lane():
         assert 0 < m.meta["work_one_lane"] < 0.05 * m.meta["work_per_eval"]
 
 
+def test_logistic_likelihoods_get_the_fused_softplus_and_wide_workgroups():
+    """`y*eta - Math.log1p(Math.exp(eta))`: the generated code calls ONE device function for the softplus (csrc/amwg_math.h log1p_exp_v8), in the unrolled
+    lane-split loop its branch-free form with one flag per block of terms and a re-evaluation through the full functions under that flag; a closure
+    whose staged data leaves room for one workgroup per CU may use 512-thread workgroups (two wavefronts per SIMD), smaller ones keep 256.  (That the
+    values equal the reference's bit for bit is test_translated_closure_equals_reference_on_host; the function itself: test_core_host.py, test_gpu_math.py.)"""
+    m = user_host.host_model("logit_n10k")
+    assert "log1p_exp_v8_open(rr_, v_eta)" in m.source and "if (rr_)" in m.source and "log1p_exp_cold(v_eta)" in m.source
+    assert "log1p_v8(exp_v8(" not in m.source
+    assert m.meta["max_threads"] == 512 and m.meta["lds_bytes"] > 73728
+    b = user_host.host_model("logit_bern_n10k")
+    assert "log1p_exp_v8" not in b.source and "ld_bern(" in b.source and b.meta["max_threads"] == 512
+    small = user_host.host_model("records_logistic")
+    assert "log1p_exp_v8" in small.source and small.meta["max_threads"] == 256
+
+
 def test_division_by_invariant_host_fuzz(tmp_path):
     """csrc/amwg_div.h compiled for the host: 8 million quotients (divisor 2^-200..2^200, numerator 2^-600..2^600 or 0, all-ones and
     power-of-two significands among them) equal IEEE division bit for bit."""
