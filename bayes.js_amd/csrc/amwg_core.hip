@@ -227,9 +227,11 @@ double model_work(const amwg_sampler *s, int G) {
 }
 
 // the hierarchical family's row layout (amwg_models.h: lane-local re-evaluation): a chain on one wavefront, labels that repeat with the lane
-// stride, not switched off -- and the tile, the label bytes and the per-wavefront term rows must fit beside the stepper state
+// stride, not switched off -- and the tile, the label bytes and the per-wavefront term rows must fit beside the stepper state.  The sweep kernel that
+// goes with it is compiled for workgroups of at most 512 threads: a caller who ASKS for more (options.block_threads = 1024) gets the kernel that
+// evaluates everything, as before round 4, instead of a "no launch geometry fits" that names the wrong cause
 bool hier_rows_wanted(const amwg_sampler *s, int G) {
-  return !s->user && s->model == AMWG_MODEL_HIER_NORMAL && !s->mc.group_local && !s->opt.full_evaluation && G == 64 && ((s->hier_periodic_mask >> 6) & 1u) && s->d.G <= 64 && s->d.n_obs >= 64;
+  return !(s->opt.block_threads > 512) && !s->user && s->model == AMWG_MODEL_HIER_NORMAL && !s->mc.group_local && !s->opt.full_evaluation && G == 64 && ((s->hier_periodic_mask >> 6) & 1u) && s->d.G <= 64 && s->d.n_obs >= 64;
 }
 bool hier_rows_fit(const amwg_sampler *s, int bt, size_t max_lds) {
   const size_t data = HierNormalModel::rows_lds_bytes(HierNormalModel::row_pitch(s->d.n_obs), bt / 64, s->d.G);

@@ -452,7 +452,6 @@ def main_inproc(args):
     reductions + RCCL all-reduce over the shards' devices).  No torch.distributed.  Weak scaling by default (the workload's chains per GPU on
     every device); `--strong` keeps the job's TOTAL chain count (cfg4: 16 384, cfg5: 65 536, cfg2: 65 536, cfg3: 262 144) and splits it."""
     import torch
-    import amwg_ctypes as A
     N = args.gpus
     have = torch.cuda.device_count()
     base = {"metric": "posterior draws/sec (= param-updates/sec)", "unit": "param-updates/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -461,6 +460,7 @@ def main_inproc(args):
         emit(dict(base, value=None, ms_per_step=None, config={"workload": args.workload},
                   note="not measured: --inproc --gpus %d needs %d visible devices, this box has %d" % (N, N, have)))
         return
+    import amwg_ctypes as A
     if args.workload == "cfg2":
         spec, per_gpu, label, n_obs, ops_per_obs = normal_spec(), CHAINS_PER_GPU, "BASELINE.json configs[1]: Normal(mu,sigma) AMWG, 1e4 synthetic obs", N_OBS, 8
         total_job = CHAINS_PER_GPU
@@ -548,8 +548,101 @@ def claim_stdout():
         os.dup2(2, 1)
 
 
-def emit(obj):
-    line = (json.dumps(obj) + "\n").encode()
+DETAIL_FILE = os.path.join(ROOT, "bench_detail.json")
+LINE_LIMIT = 4096      # bytes of the stdout line (round-4 review: a 19 KB line was not parsed by the driver; tests assert < 8192)
+
+
+def _num(x, sig=7):
+    """floats of the stdout line at 7 significant digits (the detail file keeps every bit)"""
+    if isinstance(x, float) and x == x and abs(x) != float("inf"):
+        return float("%.*g" % (sig, x))
+    return x
+
+
+def _pick(d, *keys):
+    return {k: _num(d[k]) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line of stdout: the contract's fields and nothing that grows with the run.  Everything else `out` holds (region lists, notes, flip-rate runs,
+    the JavaScript end-to-end figures, the other configs' parity reports) goes to the detail file and to stderr."""
+    line = {k: _num(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = out.get("config") or {}
+    line["config"] = _pick(cfg, "workload", "n_obs", "chains_per_gpu", "chains_total", "components", "lanes_per_chain", "block_threads", "steps_per_launch", "thin", "rccl_ranks_seen")
+    if isinstance(line["config"].get("chains_per_gpu"), list) and len(line["config"]["chains_per_gpu"]) > 8:
+        line["config"]["chains_per_gpu"] = line["config"]["chains_per_gpu"][:8]
+    for k in ("inproc", "note", "kernel_only_value", "chains_equiv"):
+        if out.get(k) is not None:
+            line[k] = _num(out[k])
+    r = out.get("roofline")
+    if r:
+        line["roofline"] = _pick(r, "bound", "achieved", "peak", "unit", "frac", "frac_of_measured_peak", "kernel", "launch_ms", "traffic", "traffic_ratio")
+        line["roofline"].setdefault("traffic", None)
+        if r.get("traffic") is None and r.get("traffic_refused"):
+            line["roofline"]["traffic_refused"] = str(r["traffic_refused"])[:120]
+        if r.get("effective_hbm"):
+            line["roofline"]["effective_hbm"] = _pick(r["effective_hbm"], "achieved", "peak", "unit", "frac", "lds_resident")
+    c = out.get("cpu_baseline")
+    if c:
+        line["cpu_baseline"] = _pick(c, "value", "unit", "cores", "kind", "reference_unavailable")
+        line["cpu_baseline"]["sample"] = str(c.get("sample", ""))[:160]
+    p = out.get("parity")
+    if p:
+        line["parity"] = _pick(p, "accept_counts_identical", "uniforms_consumed_identical", "adaptation_state_identical", "draws_bit_identical", "final_state_bit_identical", "lanes_per_chain", "reference_order")
+        fr = p.get("flip_rate")
+        if fr:
+            line["parity"]["flip_rate"] = _pick(fr, "flips_per_1e9", "upper_95_per_1e9", "decisions_total", "first_flips_total", "refused")
+    oc = out.get("other_configs")
+    if oc:
+        line["other_configs"] = {}
+        for name, o in oc.items():
+            if "error" in o:
+                line["other_configs"][name] = {"error": str(o["error"])[:100]}
+                continue
+            q = _pick(o, "value", "chains", "lanes_per_chain", "reference_order_value", "full_evaluation_value")
+            rr = o.get("roofline") or {}
+            q.update(_pick(rr, "frac"))
+            if rr.get("kernel"):
+                q["kernel"] = kernel_base_name(rr["kernel"])
+            pp = o.get("parity") or {}
+            q["parity_ok"] = bool(pp) and all(v for k, v in pp.items() if k.endswith("_identical"))
+            line["other_configs"][name] = q
+    e = out.get("end_to_end_js")
+    if isinstance(e, dict) and "updates_per_s" in e:
+        line["end_to_end_js"] = _pick(e, "updates_per_s", "total_ms")
+        sc = (e.get("single_chain") or {}).get("again")
+        if sc:
+            line["end_to_end_js"]["single_chain_warm_ms"] = _num(sc.get("total_ms"))
+    lib = out.get("library")
+    if lib:
+        line["library"] = {"kernels": kernel_id_of(lib.get("version")), "built_from_this_tree": lib.get("built_from_this_tree")}
+    if detail_path:
+        line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT) else detail_path
+    text = json.dumps(line, separators=(",", ":"))
+    # a line over the limit sheds its optional parts, least important first, rather than going out unparseable
+    for drop in ("end_to_end_js", "library", "kernel_only_value", "chains_equiv", "other_configs", "parity"):
+        if len(text) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        line["dropped_for_size"] = line.get("dropped_for_size", []) + [drop]
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= LINE_LIMIT, "bench line is %d bytes" % len(text)
+    return text
+
+
+def emit(obj, detail_path=None):
+    """stdout: compact_line(obj), ONE line <= 4 KB.  The whole record: `detail_path` (default bench_detail.json beside this file) and stderr."""
+    detail_path = detail_path or os.environ.get("AMWG_BENCH_DETAIL") or DETAIL_FILE
+    full = json.dumps(obj, indent=1)
+    try:
+        with open(detail_path, "w") as f:
+            f.write(full + "\n")
+    except OSError as e:
+        sys.stderr.write("bench.py: cannot write %s: %r\n" % (detail_path, e))
+        detail_path = None
+    sys.stderr.write("".join("| " + ln + "\n" for ln in full.splitlines()))      # (prefixed: no line of stderr can be taken for the JSON line)
+    sys.stderr.flush()
+    line = (compact_line(obj, detail_path) + "\n").encode()
     if _REAL_STDOUT is None:
         sys.stdout.write(line.decode())
         sys.stdout.flush()
@@ -598,7 +691,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+            # `python bench.py --gpus N` without torch.distributed.run: never leave without a line.  With N devices visible this is the PRODUCT's own
+            # multi-device path (one process, one sampler per device, amwg_group_gather_draws: main_inproc); otherwise the "not measured" line, rc 0.
+            sys.stderr.write("bench.py: --gpus %d without torch.distributed.run (WORLD_SIZE unset): the one-process multi-device path (--inproc)\n" % args.gpus)
+            return main_inproc(args)
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")

@@ -108,7 +108,8 @@ typedef struct {
                                   steps on the device (the chain state is saved and restored, tuning leaves no trace) and the fastest is kept --
                                   one lane per chain whenever it measures within 12 % of the fastest.  The pick may differ between machines,
                                   and with it the summation order (decisions stay the reference's); amwg_tuning reports the timings */
-  int32_t block_threads;   /* 0 = auto; else multiple of 64, <= 1024 */
+  int32_t block_threads;   /* 0 = auto; else multiple of 64, <= 1024.  (Hierarchical family at 64 lanes per chain: its sweep kernel runs in workgroups of
+                              at most 512 threads; asking for more selects the kernel that evaluates everything, as full_evaluation = 1 does.) */
   int32_t steps_per_launch;/* 0 = auto: one launch per burn call (up to 65535 steps); a sample call that will be fetched is cut into launches of ~32 MB
                             * of recorded rows, so that the rows of one launch are copied out while the next ones run.  Results never depend on it. */
   int32_t exact_division;  /* 0 = default: result-preserving shortcuts (hoisted-reciprocal division, fast-forward of two-valued sums), bit-identical

@@ -37,3 +37,70 @@ def test_traffic_comes_from_a_profile_of_the_same_kernel_and_kernel_sources(tmp_
     assert t is None and "refused" in why and "abc" in why and "other" in why
     t, src, alg, why = bench.measured_traffic(4096, 100, "cfg4", 64, False, "abc", "amwg_sweep_kernel<HierNormalModel,512>")
     assert t is None and "no profile" in why
+
+
+def _fat_record():
+    """a record at least as large as the one the round-4 driver could not parse (profiles/r04_bench_default.json, 19 KB on one line), made larger"""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")))
+    d["timing"]["region_ms"] = [1.2345678901234] * 400
+    d["parity"]["flip_rate"]["per_run"] = d["parity"]["flip_rate"]["per_run"] * 8
+    d["roofline"]["note"] = "x" * 5000
+    return d
+
+
+def test_the_stdout_line_stays_under_4_kb_whatever_the_record_holds(tmp_path):
+    """Round-4 review: BENCH_r04.json had parsed = null because the line had grown to 19 KB.  stdout carries compact_line(record) <= 4 KB -- the
+    contract's fields, the roofline and cpu_baseline objects, three parity booleans, value + frac of the other configs -- and the rest goes to the side file."""
+    import bench
+    d = _fat_record()
+    assert len(json.dumps(d)) > 19000
+    text = bench.compact_line(d, str(tmp_path / "bench_detail.json"))
+    assert "\n" not in text and len(text) <= bench.LINE_LIMIT == 4096 and len(text) < 8192
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in line and (line[k] == d[k] or abs(line[k] - d[k]) <= 1e-6 * abs(d[k])), k
+    assert line["config"]["workload"] == d["config"]["workload"] and line["config"]["chains_per_gpu"] == 65536 and "rccl_ranks_seen" in line["config"]
+    r = line["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel")) <= set(r) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+    assert r["effective_hbm"]["frac"] > 1 and r["effective_hbm"]["lds_resident"] is True
+    c = line["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "param-updates/s" and 0 < len(c["sample"]) <= 160
+    assert line["parity"]["accept_counts_identical"] and line["parity"]["draws_bit_identical"] and line["parity"]["final_state_bit_identical"]
+    assert set(line["other_configs"]) == {"cfg3", "cfg4", "cfg5", "cfg4_group_local"}
+    assert all(o["value"] > 0 and 0 < o["frac"] < 1 and o["parity_ok"] for o in line["other_configs"].values())
+    assert "dropped_for_size" not in line
+
+
+def test_a_line_that_would_still_be_too_long_sheds_optional_parts_not_the_contract(tmp_path):
+    import bench
+    d = _fat_record()
+    d["other_configs"] = {"cfg%d" % i: dict(d["other_configs"]["cfg4"]) for i in range(60)}
+    text = bench.compact_line(d, None)
+    line = json.loads(text)
+    assert len(text) <= 4096 and "other_configs" in line["dropped_for_size"] and line["value"] > 0 and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+
+
+def test_emit_writes_one_line_to_stdout_the_record_to_the_side_file_and_nothing_json_like_to_stderr(tmp_path):
+    import subprocess
+    side = tmp_path / "bench_detail.json"
+    code = ("import json, sys; sys.path.insert(0, %r); import bench; d = json.load(open(%r)); bench.claim_stdout(); print('a library banner'); bench.emit(d)"
+            % (ROOT, os.path.join(ROOT, "profiles", "r04_bench_default.json")))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, AMWG_BENCH_DETAIL=str(side)), timeout=120)
+    assert p.returncode == 0, p.stderr[-1000:]
+    assert p.stdout.count("\n") == 1 and len(p.stdout) <= 4097 and json.loads(p.stdout)["value"] > 0
+    assert "a library banner" in p.stderr and not any(ln.startswith("{") for ln in p.stderr.splitlines())
+    assert json.load(open(side))["timing"]["regions"] >= 3
+
+
+def test_gpus_n_without_a_launcher_prints_the_not_measured_line_on_a_box_without_n_devices(tmp_path):
+    """Round-4 review: `python3 bench.py --gpus 8` outside torch.distributed.run was a SystemExit.  Here (no GPU): rc 0, one line, value null."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["AMWG_BENCH_DETAIL"] = str(tmp_path / "d.json")
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-1000:]
+    line = json.loads(p.stdout)
+    assert p.stdout.count("\n") == 1 and line["value"] is None and line["n_gpus"] == 2 and line["steps"] == 20 and "not measured" in line["note"]

@@ -1,6 +1,6 @@
 #!/bin/bash
-# development aid (GPU box): runs a command under rocprofv3 PMC passes and prints the per-kernel means of a few counters
-#   tools/dev/pmc_cmd.sh <tag> <command ...>
+# GPU box: runs a command under rocprofv3 PMC passes and prints the per-kernel means of a few counters
+#   tools/pmc_cmd.sh <tag> <command ...>
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_$TAG

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""tools/dev/user_isa.py NAME [LANES ...] -- what the gfx950 compiler makes of a TRANSLATED closure's step kernel (no GPU needed).
+"""tools/user_isa.py NAME [LANES ...] -- what the gfx950 compiler makes of a TRANSLATED closure's step kernel (no GPU needed).
 Translates tests/js/user_models.js:NAME, writes the program csrc/amwg_core.hip would hand to hiprtc, compiles it with hipcc -S and lists
 the innermost loops by VALU count (the likelihood loop's unrolled body is the largest)."""
 import os, re, subprocess, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "bayes.js_amd")]
 import isa_audit
 import user_host
