@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -762,6 +763,16 @@ void make_dirs(const std::string &path) {      // mkdir -p; the cache directory 
   for (size_t i = 1; i <= path.size(); ++i)
     if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), i == path.size() ? 0700 : 0755);
 }
+// Code objects are LOADED from this directory: it is used only while it belongs to this user and nobody else can write to it.  An existing
+// directory with group / other write bits is tightened to 0700 when it is ours (a leftover 0755 from before round 4 included); one that
+// belongs to somebody else, or is not a directory (a symlink is not followed), switches the cache off.  The payload sum in a file's header
+// guards against damage, not against a planted file -- this check, O_NOFOLLOW and the owner test in cache_read are what guard against that.
+bool cache_dir_trusted(const std::string &dir) {
+  struct stat st;
+  if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid()) return false;
+  if ((st.st_mode & (S_IWGRP | S_IWOTH)) != 0 && chmod(dir.c_str(), 0700) != 0) return false;
+  return true;
+}
 uint64_t payload_sum(const std::vector<char> &code) {      // FNV-1a over the code bytes: a damaged file is recompiled, not handed to the loader
   uint64_t h = 0xcbf29ce484222325ull;
   for (unsigned char c : code) h = (h ^ c) * 0x100000001b3ull;
@@ -769,8 +780,12 @@ uint64_t payload_sum(const std::vector<char> &code) {      // FNV-1a over the co
 }
 const char kCacheMagic[8] = {'A', 'M', 'W', 'G', 'c', 'o', '0', '2'};
 bool cache_read(const std::string &file, const CacheKey &k, std::vector<char> *code) {
-  FILE *f = fopen(file.c_str(), "rb");
-  if (!f) return false;
+  const int fd = open(file.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+  if (fd < 0) return false;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH)) != 0) { close(fd); return false; }      // not ours: not loaded (and not removed)
+  FILE *f = fdopen(fd, "rb");
+  if (!f) { close(fd); return false; }
   char magic[8];
   uint64_t hdr[4] = {0, 0, 0, 0}, n = 0;
   bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kCacheMagic, 8) == 0 && fread(hdr, 8, 4, f) == 4 && fread(&n, 8, 1, f) == 1 &&
@@ -782,9 +797,12 @@ bool cache_read(const std::string &file, const CacheKey &k, std::vector<char> *c
 }
 void cache_write(const std::string &dir, const std::string &file, const CacheKey &k, const std::vector<char> &code) {
   make_dirs(dir);
+  if (!cache_dir_trusted(dir)) return;
   const std::string tmp = file + ".tmp." + std::to_string((long)getpid());
-  FILE *f = fopen(tmp.c_str(), "wb");
-  if (!f) return;
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+  if (fd < 0) return;
+  FILE *f = fdopen(fd, "wb");
+  if (!f) { close(fd); (void)remove(tmp.c_str()); return; }
   const uint64_t hdr[4] = {k.h2, k.h3, k.len, payload_sum(code)}, n = code.size();
   const bool ok = fwrite(kCacheMagic, 1, 8, f) == 8 && fwrite(hdr, 8, 4, f) == 4 && fwrite(&n, 8, 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
   if (fclose(f) != 0 || !ok || rename(tmp.c_str(), file.c_str()) != 0) (void)remove(tmp.c_str());
@@ -819,7 +837,7 @@ static int compile_user(const char *source, int lanes, int block, const char *ar
     char name[64];
     snprintf(name, sizeof name, "/%016llx%016llx.hsaco", (unsigned long long)key.h1, (unsigned long long)key.h2);
     file = dir + name;
-    if (use_cache && cache_read(file, key, code)) { ++g_cache_hits; dump_code_object(*code); return AMWG_OK; }
+    if (use_cache && cache_dir_trusted(dir) && cache_read(file, key, code)) { ++g_cache_hits; dump_code_object(*code); return AMWG_OK; }
     if (!use_cache) (void)remove(file.c_str());
   }
   ++g_cache_misses;

@@ -22,6 +22,7 @@
 #include <rccl/rccl.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -479,8 +480,14 @@ int amwg_group_gather_draws(amwg_sampler *const *shards, int32_t n, int32_t root
   std::vector<int64_t> cnt(n), off(n);
   int64_t total = 0;
   for (int i = 0; i < n; ++i) { cnt[i] = g.shards[i]->last_rows * PR * g.shards[i]->C; off[i] = total; total += cnt[i]; if (offsets) offsets[i] = off[i]; }
-  if ((size_t)total * 8 > capacity_bytes) return amwg_fail(AMWG_EINVAL, "amwg_group_gather_draws: %lld bytes needed, %zu given", (long long)total * 8, capacity_bytes);
+  if ((size_t)total * 8 > capacity_bytes) return amwg_fail(AMWG_ESIZE, "amwg_group_gather_draws: %lld bytes needed, %zu given", (long long)total * 8, capacity_bytes);
   amwg_sampler *root = g.shards[root_index];
+  // the shards' own streams have the draws in flight: wait for them, and hear what their step kernels had to say (amwg_sync reads the device
+  // error word: a launch that refused itself must not be gathered as if it had produced draws) -- a caller need not have called amwg_sync
+  for (int i = 0; i < n; ++i) {
+    rc = amwg_sync(g.shards[i]);
+    if (rc != AMWG_OK) return rc;
+  }
   for (int i = 0; i < n; ++i)      // (constraints are checked BEFORE the RCCL group is opened)
     if (g.shards[i]->device != root->device && g.leader_of[i] != i)
       return amwg_fail(AMWG_EINVAL, "amwg_group_gather_draws: two shards share a device other than the root's");
@@ -488,12 +495,10 @@ int amwg_group_gather_draws(amwg_sampler *const *shards, int32_t n, int32_t root
   double *dst = dst_device;
   HIPG(hipSetDevice(root->device));
   if (!dst) { HIPG(hipMalloc(&all.p, (size_t)(total ? total : 1) * 8)); dst = static_cast<double *>(all.p); }
-  // the shards' own streams have the draws in flight: wait for them where the data is read
   for (int i = 0; i < n; ++i) {
     amwg_sampler *s = g.shards[i];
     if (s->device != root->device) continue;
     HIPG(hipSetDevice(s->device));
-    HIPG(hipStreamSynchronize(s->stream));
     HIPG(hipMemcpyAsync(dst + off[i], s->last_draws, (size_t)cnt[i] * 8, hipMemcpyDeviceToDevice, root->stream));
   }
   bool any_remote = false;
@@ -593,21 +598,30 @@ int amwg_comm_destroy(amwg_comm *c) {
 // back to back in rank order in dst_device (root only; capacity checked there); counts (optional, n_ranks entries, every rank) = the
 // elements each rank contributed.  The blocks may differ in size (uneven shards): the counts are exchanged first (an 8-byte all-gather).
 int amwg_comm_gather_draws(amwg_sampler *s, amwg_comm *c, int32_t root, double *dst_device, size_t capacity_bytes, int64_t *counts) {
-  if (!s || !c) return amwg_fail(AMWG_EINVAL, "amwg_comm_gather_draws: null argument");
-  if (root < 0 || root >= c->n_ranks) return amwg_fail(AMWG_EINVAL, "amwg_comm_gather_draws: root %d outside 0..%d", root, c->n_ranks - 1);
-  if (!s->last_draws || s->last_rows < 1) return amwg_fail(AMWG_EINVAL, "amwg_comm_gather_draws: no sample() call yet");
-  if (s->device != c->device) return amwg_fail(AMWG_EINVAL, "amwg_comm_gather_draws: the sampler is on device %d, the communicator on %d", s->device, c->device);
+  if (!s || !c) return amwg_fail(AMWG_EINVAL, "amwg_comm_gather_draws: null argument");      // (nothing to take part in a collective WITH)
+  // Conditions only THIS rank can see are not returned before the collective -- the other ranks would sit in it for good -- but travel with it:
+  // a rank that cannot contribute all-gathers a count of -1, and every rank then returns an error without any send or receive posted.
+  char why[200] = "";
+  if (root < 0 || root >= c->n_ranks) snprintf(why, sizeof why, "root %d outside 0..%d", root, c->n_ranks - 1);
+  else if (!s->last_draws || s->last_rows < 1) snprintf(why, sizeof why, "no sample() call yet");
+  else if (s->device != c->device) snprintf(why, sizeof why, "the sampler is on device %d, the communicator on %d", s->device, c->device);
+  else if (amwg_sync(s) != AMWG_OK) snprintf(why, sizeof why, "%.190s", amwg_last_error());      // (incl. the step kernels' device error word)
+  const bool bad = why[0] != 0;
   Rccl &R = rccl();
-  HIPG(hipSetDevice(s->device));
-  const int64_t mine = s->last_rows * (int64_t)(s->P + s->D) * s->C;
+  HIPG(hipSetDevice(c->device));
+  hipStream_t st = (s->device == c->device) ? s->stream : nullptr;
+  const int64_t mine = bad ? -1 : s->last_rows * (int64_t)(s->P + s->D) * s->C;
   DevOwned cnt_dev;
   HIPG(hipMalloc(&cnt_dev.p, (size_t)(c->n_ranks + 1) * 8));
   int64_t *d_all = static_cast<int64_t *>(cnt_dev.p), *d_mine = d_all + c->n_ranks;
-  HIPG(hipMemcpyAsync(d_mine, &mine, 8, hipMemcpyHostToDevice, s->stream));
-  NCCLG(R.AllGather(d_mine, d_all, 1, ncclInt64, c->comm, s->stream));
+  HIPG(hipMemcpyAsync(d_mine, &mine, 8, hipMemcpyHostToDevice, st));
+  NCCLG(R.AllGather(d_mine, d_all, 1, ncclInt64, c->comm, st));
   std::vector<int64_t> cnt((size_t)c->n_ranks);
-  HIPG(hipMemcpyAsync(cnt.data(), d_all, (size_t)c->n_ranks * 8, hipMemcpyDeviceToHost, s->stream));
-  HIPG(hipStreamSynchronize(s->stream));
+  HIPG(hipMemcpyAsync(cnt.data(), d_all, (size_t)c->n_ranks * 8, hipMemcpyDeviceToHost, st));
+  HIPG(hipStreamSynchronize(st));
+  if (bad) return amwg_fail(AMWG_EINVAL, "amwg_comm_gather_draws: %s (every rank was told; nothing was exchanged)", why);
+  for (int r = 0; r < c->n_ranks; ++r)
+    if (cnt[r] < 0) return amwg_fail(AMWG_EINVAL, "amwg_comm_gather_draws: rank %d could not contribute (its own call says why); nothing was exchanged", r);
   if (counts) for (int r = 0; r < c->n_ranks; ++r) counts[r] = cnt[r];
   if (c->rank == root) {
     int64_t total = 0;
@@ -631,7 +645,7 @@ int amwg_comm_gather_draws(amwg_sampler *s, amwg_comm *c, int32_t root, double *
     for (int r = 0; r < root; ++r) off += cnt[r];
     HIPG(hipMemcpyAsync(dst + off, s->last_draws, (size_t)mine * 8, hipMemcpyDeviceToDevice, s->stream));
     HIPG(hipStreamSynchronize(s->stream));
-    if (!fits) return amwg_fail(AMWG_EINVAL, "amwg_comm_gather_draws: the root's buffer holds %zu bytes, the job's draws are %lld", capacity_bytes, (long long)total * 8);
+    if (!fits) return amwg_fail(AMWG_ESIZE, "amwg_comm_gather_draws: the root's buffer holds %zu bytes, the job's draws are %lld", capacity_bytes, (long long)total * 8);
   } else {
     NCCLG(R.Send(s->last_draws, (size_t)mine, ncclDouble, root, c->comm, s->stream));
     HIPG(hipStreamSynchronize(s->stream));
@@ -641,23 +655,36 @@ int amwg_comm_gather_draws(amwg_sampler *s, amwg_comm *c, int32_t root, double *
 
 // Collective: mean and sd over the recorded draws of ALL ranks (the twin of amwg_group_moments: two all-reduces of PR + 1 and PR doubles)
 int amwg_comm_moments(amwg_sampler *s, amwg_comm *c, double *mean, double *sd) {
-  if (!s || !c || !mean || !sd) return amwg_fail(AMWG_EINVAL, "amwg_comm_moments: null argument");
-  if (!s->last_draws || s->last_rows < 1) return amwg_fail(AMWG_EINVAL, "amwg_comm_moments: no sample() call yet");
+  if (!s || !c) return amwg_fail(AMWG_EINVAL, "amwg_comm_moments: null argument");
+  // (as in amwg_comm_gather_draws: what only this rank can see travels WITH the first all-reduce -- a rank that cannot contribute adds a count of
+  // -inf, so that every rank sees a total that is not a count and returns an error, instead of the others waiting in the collective for good)
+  char why[200] = "";
+  if (!mean || !sd) snprintf(why, sizeof why, "null output");
+  else if (!s->last_draws || s->last_rows < 1) snprintf(why, sizeof why, "no sample() call yet");
+  else if (s->device != c->device) snprintf(why, sizeof why, "the sampler is on device %d, the communicator on %d", s->device, c->device);
+  else if (amwg_sync(s) != AMWG_OK) snprintf(why, sizeof why, "%.190s", amwg_last_error());
+  const bool bad = why[0] != 0;
   Rccl &R = rccl();
-  const int PR = s->P + s->D;
-  HIPG(hipSetDevice(s->device));
+  const int PR = s->P + s->D;      // (equal on every rank: one model)
+  HIPG(hipSetDevice(c->device));
+  hipStream_t st = (s->device == c->device) ? s->stream : nullptr;
   DevOwned buf, center;
   HIPG(hipMalloc(&buf.p, (size_t)(PR + 1) * 8));
   HIPG(hipMalloc(&center.p, (size_t)PR * 8));
   double *b = static_cast<double *>(buf.p);
   std::vector<double> h((size_t)PR + 1);
-  hipLaunchKernelGGL(draw_sums_kernel, dim3(PR), dim3(1024), 0, s->stream, s->last_draws, s->last_rows, PR, s->C, (const double *)nullptr, b);
-  HIPG(hipGetLastError());
-  const double cnt = (double)s->last_rows * (double)s->C;
-  HIPG(hipMemcpyAsync(b + PR, &cnt, 8, hipMemcpyHostToDevice, s->stream));
-  NCCLG(R.AllReduce(b, b, (size_t)PR + 1, ncclDouble, ncclSum, c->comm, s->stream));
-  HIPG(hipMemcpyAsync(h.data(), b, (size_t)(PR + 1) * 8, hipMemcpyDeviceToHost, s->stream));
-  HIPG(hipStreamSynchronize(s->stream));
+  if (bad) HIPG(hipMemsetAsync(b, 0, (size_t)PR * 8, st));
+  else {
+    hipLaunchKernelGGL(draw_sums_kernel, dim3(PR), dim3(1024), 0, st, s->last_draws, s->last_rows, PR, s->C, (const double *)nullptr, b);
+    HIPG(hipGetLastError());
+  }
+  const double cnt = bad ? -HUGE_VAL : (double)s->last_rows * (double)s->C;
+  HIPG(hipMemcpyAsync(b + PR, &cnt, 8, hipMemcpyHostToDevice, st));
+  NCCLG(R.AllReduce(b, b, (size_t)PR + 1, ncclDouble, ncclSum, c->comm, st));
+  HIPG(hipMemcpyAsync(h.data(), b, (size_t)(PR + 1) * 8, hipMemcpyDeviceToHost, st));
+  HIPG(hipStreamSynchronize(st));
+  if (bad) return amwg_fail(AMWG_EINVAL, "amwg_comm_moments: %s (every rank was told)", why);
+  if (!(h[PR] > 0)) return amwg_fail(AMWG_EINVAL, "amwg_comm_moments: another rank could not contribute (its own call says why)");
   const double N = h[PR];
   for (int p = 0; p < PR; ++p) mean[p] = h[p] / N;
   HIPG(hipMemcpyAsync(center.p, mean, (size_t)PR * 8, hipMemcpyHostToDevice, s->stream));

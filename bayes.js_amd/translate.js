@@ -1683,8 +1683,10 @@ Translator.prototype.run = function () {
   const all = this.arrays.map((a, j) => j);
   // two plans: G > 1 lanes per chain (arrays in order of first use), and ONE lane per chain, where a fast-forwarded loop reads
   // its bit tables instead of the observations (tables first)
-  const PG = makePlan(all), plan = PG.plan, off = PG.bytes;
+  // (the tables are read by the one-lane fast-forward alone -- `if constexpr (G == 1)` in the generated loops --: the G > 1 plan neither stages them
+  // nor counts their bytes, which also feed the workgroup limit below)
   const isTab = (j) => this.arrays[j].key.indexOf('#aux:twoval:') === 0 || this.arrays[j].key.indexOf('#aux:kval:') === 0;
+  const PG = makePlan(all.filter((j) => !isTab(j))), plan = PG.plan, off = PG.bytes;
   const P1 = this.oneLaneWork ? makePlan(all.filter(isTab).concat(all.filter((j) => !isTab(j)))) : PG;
   const D = this.derived.length;
   // Workgroup limit.  Loops with exp / log / ld.* calls need ~140 vector registers per lane: 256-thread workgroups (one wavefront per SIMD each),

@@ -177,6 +177,14 @@ def test_constant_rate_count_loops_are_fast_forwarded_with_one_lane():
         assert found and int(found.group(1)) == K and "if constexpr (G == 1)" in m.source
         assert any(k.startswith("#aux:kval:") for k in m.meta["array_keys"])
         assert 0 < m.meta["work_one_lane"] < 0.05 * m.meta["work_per_eval"]
+        # the tables are the one-lane plan's alone: the G > 1 plan stages the observations (one byte each) and the lfactorial column ld.pois reads,
+        # not the K x N / 4 + N bytes of tables it never reads -- whose bytes would also feed the 73 728-byte rule of the workgroup limit
+        n = len(m.arrays[0])
+        assert m.meta["lds_bytes"] <= (n + 15 & ~15) + (8 * n + 15 & ~15)
+        stage = m.source[m.source.index("static void stage("):m.source.index("template <int G, bool DERIVE>")]
+        many = stage[stage.index("} else {"):]
+        tabs = [j for j, k in enumerate(m.meta["array_keys"]) if k.startswith("#aux:")]
+        assert tabs and not any("user_arr<%d>" % j in many for j in tabs) and all("user_arr<%d>" % j in stage for j in tabs)
 
 
 def test_logistic_likelihoods_get_the_fused_softplus_and_wide_workgroups():
