@@ -183,8 +183,8 @@ def test_constant_rate_count_loops_are_fast_forwarded_with_one_lane():
         assert m.meta["lds_bytes"] <= (n + 15 & ~15) + (8 * n + 15 & ~15)
         stage = m.source[m.source.index("static void stage("):m.source.index("template <int G, bool DERIVE>")]
         many = stage[stage.index("} else {"):]
-        tabs = [j for j, k in enumerate(m.meta["array_keys"]) if k.startswith("#aux:")]
-        assert tabs and not any("user_arr<%d>" % j in many for j in tabs) and all("user_arr<%d>" % j in stage for j in tabs)
+        tabs = [j for j, k in enumerate(m.meta["array_keys"]) if k.startswith("#aux:kval:")]
+        assert len(tabs) == 2 and not any("user_arr<%d>" % j in many for j in tabs) and any("user_arr<%d>" % j in stage for j in tabs)
 
 
 def test_logistic_likelihoods_get_the_fused_softplus_and_wide_workgroups():
