@@ -66,6 +66,20 @@ def roofline_units(fam, lane_ops_per_s, ops_per_obs):
     return out
 
 
+HIER_SWEEP_PASSES = 3      # amwg_sweep_kernel: one pass for the whole sweep over theta, one for mu, one for sigma (csrc/amwg_models.h prefetch_rows)
+
+
+def sweep_lane_ops(updates_per_s, P, n_obs, ops_per_obs):
+    """fp64 lane-operations/s of the hierarchical family's sweep kernel: a Sampler.step of P updates makes HIER_SWEEP_PASSES passes over the data (not P),
+    each n_obs x ops_per_obs; the stepper's own arithmetic (proposals, butterflies, accept tests) is not counted as algorithmic work."""
+    return updates_per_s / P * HIER_SWEEP_PASSES * n_obs * ops_per_obs
+
+
+SWEEP_NOTE = ("roofline of the kernel that produces `value` (%s): a step of %d updates = 3 passes over the data (the sweep over theta, mu, sigma) x %d observations x 8 fp64 "
+              "operations; everything else the kernel issues (32 butterflies + accept tests, the window stream, proposals) is overhead against this roof.  The kernel that "
+              "passes over all the data in EVERY update (options.full_evaluation = 1) runs at %.3g param-updates/s, %.3f of the same roof in its own unit (one pass per update)")
+
+
 def normal_spec():
     import synth
     data = synth.normal(N_OBS, DATA_SEED)
@@ -284,17 +298,21 @@ def cpu_baseline_all_cores(spec, single_rate, budget_s=2.0, max_threads=32):
 GOLDEN_OF = {"cfg2": "cfg2_full", "cfg3": "cfg3_full", "cfg4": "cfg4_full", "cfg5": "cfg5_full"}
 
 
-def flip_rate_record():
+def flip_rate_record(kernel_id=None):
     """The decision-parity campaign (tools/flip_rate.py, committed under profiles/): how many chains of a seeded job ever decide differently at 64
-    lanes / group-local than with one lane per chain (the reference's summation order), over 1e9+ decisions."""
+    lanes / group-local than with one lane per chain (the reference's summation order), over 1e9+ decisions.  Like roofline.traffic, the figure is
+    REFUSED when the campaign ran other kernels than the library that is being timed (kernel id of amwg_version())."""
     import glob
-    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_flip_rate.json")), key=os.path.getmtime)
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_flip_rate.json")))      # (by name: rNN sorts by round; checkouts do not keep mtimes)
     if not fs:
         return None
     try:
         r = json.load(open(fs[-1]))
     except (OSError, ValueError):
         return None
+    if kernel_id is not None and kernel_id_of(r.get("version")) != kernel_id:
+        return {"source": os.path.relpath(fs[-1], ROOT), "refused": "the campaign ran kernels %s, this library is kernels %s: re-run tools/flip_rate.py" % (kernel_id_of(r.get("version")), kernel_id),
+                "library_version_of_campaign": r.get("version")}
     return {"source": os.path.relpath(fs[-1], ROOT), "decisions_total": r["decisions_total"], "first_flips_total": r["first_flips_total"],
             "flips_per_1e9": r["flips_per_1e9"], "upper_95_per_1e9": r["upper_95_per_1e9"], "library_version_of_campaign": r.get("version"),
             "per_run": [{"workload": q["workload"], "geometry": q["geometry"], "chains": q["chains"], "steps": q["steps"], "decisions": q["decisions"],
@@ -419,14 +437,18 @@ def measure_other_config(A, name, device, group_local=0):
         t.burn(300)
         roof_updates_per_s = chains * 300 * P / (t.launch_info()["kernel_ms"] * 1e-3)
         t.close()
-        kernel += " with options.full_evaluation = 1"
         out["full_evaluation_value"] = roof_updates_per_s
+        out["full_evaluation_frac"] = roof_updates_per_s * n_obs * ops_per_obs / FP64_VALU_PEAK
         out["value_kernel"] = li.get("kernel")
-        note = ("roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s; `value` (%s) keeps the per-lane sums an update cannot "
-                "have changed and forms the proposed sums of a whole sweep over theta in one pass, its proposals drawn ahead in stream order (csrc/amwg_models.h "
-                "lane_sum_rows / prefetch_rows): three passes over the data per step instead of 34, every update still the whole log_post, the same bits -- %.2fx"
-                % (roof_updates_per_s, li.get("kernel"), value / roof_updates_per_s))
-    lane_ops = roof_updates_per_s * n_obs * ops_per_obs
+        if str(li.get("kernel", "")).startswith("amwg_sweep_kernel"):
+            # `value` and `frac` describe the SAME kernel (round-4 review): the sweep kernel against the arithmetic of its three passes
+            kernel = li["kernel"]
+            note = SWEEP_NOTE % (kernel, P, n_obs, roof_updates_per_s, out["full_evaluation_frac"])
+            roof_updates_per_s = None
+        else:
+            kernel += " with options.full_evaluation = 1"
+            note = "roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s" % roof_updates_per_s
+    lane_ops = sweep_lane_ops(value, P, n_obs, ops_per_obs) if roof_updates_per_s is None else roof_updates_per_s * n_obs * ops_per_obs
     if group_local:
         # group-local evaluation: a step of the P = G + 2 updates makes TWO passes over the data (the sweep over theta and the sigma update)
         # instead of P; the fp64 work per update is what those two passes do, not one pass per update
@@ -440,9 +462,36 @@ def measure_other_config(A, name, device, group_local=0):
                        "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[fam], "kernel": kernel, "note": note,
                        "effective_hbm_gbps": value * b_alg / 1e9}
     out["roofline"].update(roofline_units(fam, lane_ops, ops_per_obs))
+    if lanes > 1 and not group_local:
+        out["reference_order"] = reference_order_price(A, name, spec, device)
+        if "value" in out["reference_order"]:
+            out["reference_order_value"] = out["reference_order"]["value"]
     out["seconds"] = time.perf_counter() - t0
     s.close()
     return out
+
+
+# What strict identity costs (round-4 review, item 7; mcmc.js:527-528): north_star asks for bit-identical accept counts.  With ONE lane per chain the
+# sum over observations is the reference's `lp += term`, so every draw and every decision is the reference's; the default geometry of cfg4 / cfg5
+# (a chain on a whole wavefront) decides 3 of 3.7e10 decisions differently (parity.flip_rate).  The same config forced to lanes_per_chain = 1, with the
+# chain count raised to the whole 8-GPU job so that the one-lane launch has lanes to fill the chip with (stated), is timed here.
+REFERENCE_ORDER_RUN = {"cfg4": (16_384, 20, 40), "cfg5": (65_536, 2, 3)}      # chains, warm-up steps, timed steps
+
+
+def reference_order_price(A, name, spec, device):
+    chains, warm, timed = REFERENCE_ORDER_RUN[name]
+    try:
+        t = A.Sampler(spec, chains=chains, seed=SEED, device=device, lanes_per_chain=1, steps_per_launch=timed)
+        t.burn(warm)
+        t.burn(timed)
+        li = t.launch_info()
+        t.close()
+    except Exception as e:
+        return {"error": repr(e)}
+    return {"value": chains * timed * spec["P"] / (li["kernel_ms"] * 1e-3), "unit": "param-updates/s", "lanes_per_chain": 1, "chains": chains, "block_threads": li["block_threads"],
+            "grid_blocks": li["grid_blocks"], "kernel": li.get("kernel"), "steps_timed": timed,
+            "note": "options.lanes_per_chain = 1: the reference's summation order, every draw and accept count bit-identical to mcmc.js; %d chains (the whole 8-GPU job on this one "
+                    "GPU: a one-lane launch needs that many to occupy the chip), HIP events around %d steps after %d" % (chains, timed, warm)}
 
 
 def main_inproc(args):
@@ -513,7 +562,8 @@ def main_inproc(args):
     collection["gather_then_one_copy_ms"] = (time.perf_counter() - t0) * 1e3
     collection["bytes"] = sum(s._pending * s.PR * s.C * 8 for s in shards)
     comm = A.group_comm_info(shards)
-    lane_ops = value * n_obs * ops_per_obs * ((2.0 / P) if args.group_local else 1.0)
+    sweep = str(li.get("kernel", "")).startswith("amwg_sweep_kernel")
+    lane_ops = sweep_lane_ops(value, P, n_obs, ops_per_obs) if sweep else value * n_obs * ops_per_obs * ((2.0 / P) if args.group_local else 1.0)
     out = dict(base, value=value, ms_per_step=dt * 1e3 / K,
                config={"workload": label + (" -- GROUP-LOCAL evaluation" if args.group_local else ""), "n_obs": n_obs, "chains_total": total,
                        "chains_per_gpu": [s.C for s in shards], "components": P, "thin": thin, "lanes_per_chain": li["lanes_per_chain"],
@@ -522,12 +572,9 @@ def main_inproc(args):
                        "rccl_ranks_seen": comm["rccl_ranks_seen"], "devices": comm["devices"], "collection_to_host": collection},
                timing={"regions": len(regs), "reported": "median region (wall clock around sample_async x N + sync x N + group_gather_draws + group_moments)",
                        "region_ms": [r[0] * 1e3 for r in regs][:64], "slowest_device_kernel_ms_last_region": kernel_ms},
-               roofline=({"bound": "fp64_valu", "achieved": lane_ops, "peak": FP64_VALU_PEAK * N, "frac": lane_ops / (FP64_VALU_PEAK * N),
-                          "unit": "fp64 lane-operations/s", "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[spec["model"]], "kernel": li.get("kernel")}
-                         if not str(li.get("kernel", "")).startswith("amwg_sweep_kernel") else
-                         {"bound": "fp64_valu", "achieved": None, "peak": FP64_VALU_PEAK * N, "frac": None, "unit": "fp64 lane-operations/s", "kernel": li.get("kernel"),
-                          "note": "the sweep kernel makes three passes over the data per step of %d updates, not one per update: `value` x observations x operations is not its "
-                                  "arithmetic; the roofline figure of this workload is the full-evaluation kernel's (python bench.py --workload cfg4: roofline.frac)" % P}),
+               roofline={"bound": "fp64_valu", "achieved": lane_ops, "peak": FP64_VALU_PEAK * N, "frac": lane_ops / (FP64_VALU_PEAK * N),
+                         "unit": "fp64 lane-operations/s", "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[spec["model"]], "kernel": li.get("kernel"),
+                         "note": ("the sweep kernel: three passes over the data per step of %d updates" % P) if sweep else None},
                posterior={"mean": mean.tolist()[:8], "sd": sd.tolist()[:8], "note": "amwg_group_moments over the recorded draws of all shards (last region)"})
     emit(out)
     for s in shards:
@@ -866,7 +913,7 @@ def main():
         kname = {"normal": "NormalModel", "beta_bern": "BetaBernModel", "hier_normal": "HierNormalModel", "pois_glm": "PoisGlmModel"}[spec["model"]]
         bt_class = 256 if li["block_threads"] <= 256 else (512 if li["block_threads"] <= 512 else 1024)
         kernel = li.get("kernel") or "amwg_step_kernel<%s,%d,%d>" % (kname, li["lanes_per_chain"], bt_class)      # (amwg_kernel_name: what a profiler lists)
-        roof_launch_s, roof_updates, roof_note = launch_s, updates_per_launch, None
+        roof_launch_s, roof_updates, roof_note, full_eval = launch_s, updates_per_launch, None, None
         if args.workload == "cfg3":
             # the headline value uses the exact fast-forward of the two-valued sum, which does not stream the data at all; the
             # roofline figure is the TERM-BY-TERM pass (exact_division = 1: one fp64 add per observation), measured on the side
@@ -883,15 +930,19 @@ def main():
             t = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=dev_index, lanes_per_chain=args.lanes, block_threads=args.block, steps_per_launch=args.steps_per_launch, full_evaluation=1)
             t.burn(2 * args.steps_per_launch)
             t.burn(3 * args.steps_per_launch)
-            roof_launch_s, roof_updates = t.launch_info()["kernel_ms"] * 1e-3, chains * 3 * args.steps_per_launch * P
-            tl = t.launch_info()
-            kernel = "%s with options.full_evaluation = 1" % tl["kernel"]
-            roof_note = ("roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s; `value` (%s) keeps the per-lane sums an update "
-                         "cannot have changed and forms the proposed sums of a whole sweep over theta in one pass (csrc/amwg_models.h lane_sum_rows / prefetch_rows: bit-identical, "
-                         "three passes over the data per step instead of 34)" % (roof_updates / roof_launch_s, li.get("kernel")))
+            full_launch_s, full_updates = t.launch_info()["kernel_ms"] * 1e-3, chains * 3 * args.steps_per_launch * P
+            full_eval = {"value": full_updates / full_launch_s, "frac": full_updates / full_launch_s * n_obs * ops_per_obs / FP64_VALU_PEAK, "kernel": t.launch_info()["kernel"]}
+            if not str(li.get("kernel", "")).startswith("amwg_sweep_kernel"):
+                roof_launch_s, roof_updates, kernel = full_launch_s, full_updates, "%s with options.full_evaluation = 1" % full_eval["kernel"]
+                roof_note = "roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s" % full_eval["value"]
             t.close()
         traffic, traffic_src, traffic_alg, traffic_why_not = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"], args.group_local, kernel_id_of(version), kernel)
         lane_ops = roof_updates * n_obs * ops_per_obs / roof_launch_s
+        if str(kernel).startswith("amwg_sweep_kernel"):
+            # `value` and `frac` describe the same kernel: the sweep kernel against the arithmetic of its three passes per step
+            lane_ops = sweep_lane_ops(roof_updates / roof_launch_s, P, n_obs, ops_per_obs)
+            fe = full_eval or {"value": float("nan"), "frac": float("nan")}
+            roof_note = SWEEP_NOTE % (kernel, P, n_obs, fe["value"], fe["frac"])
         if args.group_local:
             lane_ops *= 2.0 / P          # two passes per step of P updates (see measure_other_config)
             label += " -- GROUP-LOCAL evaluation (opt-in; not the reference's operation schedule)"
@@ -927,7 +978,7 @@ def main():
                                                    "The data vector is staged once per launch into LDS (L2/MALL for cfg5) and re-read from there, so this is an "
                                                    "EFFECTIVE rate that exceeds the HBM peak by design; it is not the roof this kernel runs against"},
                          "note": roof_note},
-            "kernel_only_value": chains * K * P / (kernel_ms * 1e-3),
+            "kernel_only_value": chains * K * P / (kernel_ms * 1e-3), "full_evaluation": full_eval,
             "posterior": {"mean": mean.tolist()[:8], "sd": sd.tolist()[:8], "data_mean": float(np.mean(x)), "data_sd": float(np.std(x, ddof=1)),
                           "note": "moments over the recorded draws of the last region on ALL ranks (all-reduce of per-rank sums for N > 1; after %d warm-up + %d timed steps)" % (W, K * (len(regions) - 1))},
         }
@@ -938,7 +989,7 @@ def main():
                                   "built_from_this_tree compares them with the sources beside this bench.py"}
         if parity is not None:
             out["parity"] = parity
-            fr = flip_rate_record()
+            fr = flip_rate_record(kernel_id_of(version))
             if fr is not None:
                 out["parity"]["flip_rate"] = fr
         if world == 1 and args.workload == "cfg2" and not args.no_other_configs:

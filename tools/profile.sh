@@ -13,7 +13,9 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="${@:---steps 500 --warmup 1000}"   # (cfg4 / cfg5: add --weak to profile the per-GPU shard of the 8-GPU job, 2 048 / 8 192 chains)
 CMD="python $R/bench.py --no-cpu-baseline --single-region --no-other-configs --no-parity $ARGS"
 echo "$CMD" > $OUT/command.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace_err.log
+# (bench.py's stdout is the <= 4 KB line; the whole record -- what tools/summarize_profile.py reads -- is the detail file)
+AMWG_BENCH_DETAIL=$OUT/bench_under_trace.json rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/bench_line.json 2> $OUT/trace_err.log
+export AMWG_BENCH_DETAIL=/dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD > /dev/null 2> $OUT/pmc_fetch_err.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $CMD > /dev/null 2> $OUT/pmc_write_err.log
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o pmc -- $CMD > /dev/null 2> $OUT/pmc_sq_err.log

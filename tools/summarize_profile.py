@@ -58,6 +58,17 @@ if g("SQ_WAVE_CYCLES") and g("SQ_ACTIVE_INST_VALU"):
     derived["valu_active_share_of_wave_cycles"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES")
     derived["wait_inst_any_share_of_wave_cycles"] = (g("SQ_WAIT_INST_ANY") or 0) / g("SQ_WAVE_CYCLES")
     derived["wait_any_share_of_wave_cycles"] = (g("SQ_WAIT_ANY") or 0) / g("SQ_WAVE_CYCLES")
+# How busy the vector pipe is, from counts alone (round-4 review): a wave64 VALU instruction occupies its SIMD's 16-lane pipe for 4 cycles (fp64 runs at full
+# rate on this chip); a transcendental (v_rcp_f64 ...) for ~16.5 (tools/ubench/valu_rates.hip), i.e. 12.5 more.  SIMD-cycles = 1024 SIMDs x launch time x the
+# effective clock.  TRANS_PER_UNIT: transcendental instructions per observation (static count in the kernel's pass; PoisGlm: the two v_rcp_f64 of exp and log).
+TRANS_PER_OBS = {"cfg5": 2.0, "cfg2": 0.0, "cfg4": 0.0, "cfg3": 0.0}
+if g("SQ_INSTS_VALU") and derived.get("effective_clock_ghz"):
+    simd_cycles = 1024.0 * launch_s * derived["effective_clock_ghz"] * 1e9
+    n_obs_lane_iterations = (bench["roofline"].get("updates_per_launch") or 0) * bench["config"]["n_obs"] / 64.0      # per-wave passes over an observation
+    trans = TRANS_PER_OBS.get(workload, 0.0) * n_obs_lane_iterations
+    derived["valu_pipe_busy"] = (g("SQ_INSTS_VALU") * 4.0 + trans * 12.5) / simd_cycles
+    derived["valu_pipe_busy_without_transcendentals"] = g("SQ_INSTS_VALU") * 4.0 / simd_cycles
+    derived["valu_pipe_busy_note"] = "(SQ_INSTS_VALU x 4 cycles + %g transcendental instructions x 12.5 extra cycles) / (1024 SIMDs x launch time x effective clock)" % trans
 if g("SQ_BUSY_CYCLES") and g("SQ_ACTIVE_INST_VALU"):
     # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; SQ_BUSY_CYCLES counts cycles per SE/XCC: report the raw ratio only
     derived["active_inst_valu_per_busy_cycle"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_BUSY_CYCLES")
