@@ -42,7 +42,8 @@ class Options(C.Structure):
 class UserModel(C.Structure):
     _fields_ = [("source", C.c_char_p), ("n_arrays", C.c_int32), ("arrays", C.POINTER(C.POINTER(C.c_double))),
                 ("array_len", C.POINTER(C.c_int64)), ("array_type", C.POINTER(C.c_int32)), ("n_derived", C.c_int32), ("lds_bytes", C.c_int32), ("lds_bytes_one_lane", C.c_int32),
-                ("parallel", C.c_int32), ("max_threads", C.c_int32), ("work_per_eval", C.c_double), ("work_one_lane", C.c_double)]
+                ("parallel", C.c_int32), ("max_threads", C.c_int32), ("work_per_eval", C.c_double), ("work_one_lane", C.c_double),
+                ("rows_n_obs", C.c_int32), ("rows_groups", C.c_int32), ("rows_sweep", C.c_int32)]
 
 
 EXPORTS = ["amwg_kernel_name", "amwg_group_gather_draws", "amwg_group_comm_info", "amwg_comm_unique_id", "amwg_comm_create", "amwg_comm_info", "amwg_comm_gather_draws", "amwg_comm_moments", "amwg_comm_destroy", "amwg_code_cache_stats", "amwg_tuning", "amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_fetch_draws_slices", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state", "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components", "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp", "amwg_log", "amwg_uniform"]      # include/amwg.h: the product library
@@ -211,6 +212,7 @@ class Sampler:
             um.parallel, um.max_threads = int(user.get("parallel", 0)), int(user.get("max_threads", 0))
             um.work_per_eval = float(user.get("work_per_eval", 0.0))
             um.work_one_lane = float(user.get("work_one_lane", 0.0))
+            um.rows_n_obs, um.rows_groups, um.rows_sweep = int(user.get("rows_n_obs", 0)), int(user.get("rows_groups", 0)), int(user.get("rows_sweep", 0))
         n = len(spec["params"])
         pa = (ParamDesc * n)()
         TYPE = {"real": 0, "int": 1, "binary": 2}

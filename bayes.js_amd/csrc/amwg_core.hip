@@ -38,7 +38,7 @@ using namespace amwg;
 // together with the very same step kernel source the built-in models are compiled from.
 extern "C" {
 extern const char amwg_hdr_stdint[], amwg_hdr_types[], amwg_hdr_math[], amwg_hdr_div[], amwg_hdr_ld[], amwg_hdr_philox[],
-    amwg_hdr_kernel[], amwg_hdr_user[], amwg_hdr_twoval[], amwg_hdr_kval[], amwg_hdr_trig[], amwg_hdr_pass[];
+    amwg_hdr_kernel[], amwg_hdr_user[], amwg_hdr_twoval[], amwg_hdr_kval[], amwg_hdr_trig[], amwg_hdr_pass[], amwg_hdr_rows[], amwg_hdr_window[];
 }
 
 // the step kernels of the built-in families, one translation unit each (amwg_kernels.hip): kernel for (lanes per chain, workgroup size)
@@ -202,6 +202,8 @@ int gl_layout(const double *y, const int32_t *g, int N, int Gn, GlLayoutHost *ou
 // given sampler configuration always gets the same G (the lane count fixes the summation order, hence the draws).
 bool hier_rows_wanted(const amwg_sampler *s, int G);
 bool hier_rows_fit(const amwg_sampler *s, int bt, size_t max_lds);
+bool user_rows_wanted(const amwg_sampler *s, int G);
+bool user_rows_fit(const amwg_sampler *s, int bt, size_t max_lds);
 
 double model_work(const amwg_sampler *s, int G) {
   const double N = (double)s->d.n_obs;
@@ -224,7 +226,10 @@ double model_work(const amwg_sampler *s, int G) {
     case AMWG_MODEL_POIS_GLM: return 90.0 * N;
   }
   if (G == 1 && s->user_work_one_lane > 0) return s->user_work_one_lane;   // translated closure with a two-valued sum: fast-forwarded
-  return s->user_work > 0 ? s->user_work : 1e6;   // translated closure: the translator's estimate
+  double w = s->user_work > 0 ? s->user_work : 1e6;   // translated closure: the translator's estimate
+  // row plan (lane-local re-evaluation, like the hierarchical family's): of the groups + 2 updates of a step only a few make the full pass
+  if (user_rows_wanted(s, G) && user_rows_fit(s, 256, (size_t)160 * 1024)) w *= (2.0 + 0.35 * s->user_rows_groups) / (2.0 + s->user_rows_groups);
+  return w;
 }
 
 // the hierarchical family's row layout (amwg_models.h: lane-local re-evaluation): a chain on one wavefront, labels that repeat with the lane
@@ -233,6 +238,19 @@ double model_work(const amwg_sampler *s, int G) {
 // evaluates everything, as before round 4, instead of a "no launch geometry fits" that names the wrong cause
 bool hier_rows_wanted(const amwg_sampler *s, int G) {
   return !(s->opt.block_threads > 512) && !s->user && s->model == AMWG_MODEL_HIER_NORMAL && !s->mc.group_local && !s->opt.full_evaluation && G == 64 && ((s->hier_periodic_mask >> 6) & 1u) && s->d.G <= 64 && s->d.n_obs >= 64;
+}
+// a translated closure with a row plan (amwg_rows.h; translate.js): the same layout, LDS bytes by the same formula (UserRows<M> has HierNormalModel's)
+bool user_rows_wanted(const amwg_sampler *s, int G) {
+  return s->user && s->user_rows_n >= 64 && s->user_rows_groups >= 1 && s->user_rows_groups <= 64 && !s->opt.full_evaluation && !(s->opt.block_threads > 512) && G == 64;
+}
+size_t user_rows_bytes(const amwg_sampler *s, int bt) { return HierNormalModel::rows_lds_bytes(HierNormalModel::row_pitch(s->user_rows_n), bt / 64, s->user_rows_groups); }
+bool user_rows_fit(const amwg_sampler *s, int bt, size_t max_lds) {
+  return bt <= 512 && lds_layout(user_rows_bytes(s, bt), s->P, bt / 64, s->pl.max_top, s->n_params).total <= max_lds;
+}
+// ... and the sweep prefetch with it, when the translator proved that a lane's sum depends on one entry of the swept vector (rows_sweep), the
+// model has no binary parameter (BinaryStepper draws differently) and the order of every parameter vector fits the lanes of a wavefront
+bool user_sweep_wanted(const amwg_sampler *s, int G, int bt, size_t max_lds) {
+  return user_rows_wanted(s, G) && user_rows_fit(s, bt, max_lds) && s->user_rows_sweep && !s->user_has_binary && s->pl.max_top <= 64;
 }
 bool hier_rows_fit(const amwg_sampler *s, int bt, size_t max_lds) {
   const size_t data = HierNormalModel::rows_lds_bytes(HierNormalModel::row_pitch(s->d.n_obs), bt / 64, s->d.G);
@@ -244,7 +262,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   // cpb: chains per workgroup; 0 = blockDim / G.  A smaller value (one-wavefront workgroups only) is the fallback for models
   // whose per-chain state is so large that 64 / G copies do not fit LDS: the spare lane groups replicate the last chain.
   auto layout = [&](int bt, int G, int cpb = 0) {
-    const size_t data_bytes = s->user ? (size_t)(G == 1 ? s->user_lds_one_lane : s->user_lds)
+    const size_t data_bytes = s->user ? ((user_rows_wanted(s, G) && user_rows_fit(s, bt, max_lds)) ? user_rows_bytes(s, bt) : (size_t)(G == 1 ? s->user_lds_one_lane : s->user_lds))
                               : (s->mc.group_local ? HierGlModel::gl_lds_bytes(s->d.pad, bt / 64)
                                  : ((hier_rows_wanted(s, G) && hier_rows_fit(s, bt, max_lds)) ? HierNormalModel::rows_lds_bytes(HierNormalModel::row_pitch(s->d.n_obs), bt / 64, s->d.G)
                                     : model_lds_bytes(s->model, s->d.n_obs, s->d.G, G)));
@@ -253,7 +271,8 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const int max_bt = s->user ? s->user_max_threads : model_max_threads(s->model);
   // (the hierarchical family's sweep kernel -- row layout, 64 lanes per chain -- keeps the window stream and the sweep's per-lane values in registers:
   // compiled for at most 512 threads, where a lane has 256 of them; with the 128 of a 1024-thread workgroup it ran from scratch memory, five times slower)
-  auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds && !(bt > 512 && hier_rows_wanted(s, G) && hier_rows_fit(s, 512, max_lds)); };
+  auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds && !(bt > 512 && hier_rows_wanted(s, G) && hier_rows_fit(s, 512, max_lds)) &&
+                                          !(bt > 512 && user_rows_wanted(s, G) && user_rows_fit(s, 512, max_lds)); };
   if (s->user && !s->user_parallel && o.lanes_per_chain > 1)
     return fail(AMWG_EINVAL, "this closure has no loop that can be split over lanes: lanes_per_chain must be 1 (or 0 = auto), got %d", o.lanes_per_chain);
   const int bts[5] = {1024, 512, 256, 128, 64};
@@ -319,7 +338,12 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const int CPB = bestG > 64 ? 1 : (bestCpb ? bestCpb : bestB / bestG);
   s->grid = (int)((s->C + CPB - 1) / CPB);
   s->lds = (int)layout(bestB, bestG, bestCpb).total;
-  if (s->user) return AMWG_OK;    // the kernel is compiled for this geometry afterwards
+  if (s->user) {    // the kernel is compiled for this geometry afterwards
+    const bool rows = user_rows_wanted(s, s->lanes) && user_rows_fit(s, s->block, max_lds);
+    s->d.pad = rows ? HierNormalModel::row_pitch(s->user_rows_n) : 0;
+    s->user_sweep = rows && user_sweep_wanted(s, s->lanes, s->block, max_lds);
+    return AMWG_OK;
+  }
   s->kernel = s->mc.group_local ? amwg_kernel_hier_gl(s->block)
               : ((hier_rows_wanted(s, s->lanes) && hier_rows_fit(s, s->block, max_lds)) ? amwg_kernel_hier_sweep(s->block) : pick_kernel(s->model, s->lanes, s->block));
   if (!s->kernel) return fail(AMWG_EINVAL, "no kernel for model %d with %d lanes per chain in workgroups of %d", s->model, s->lanes, s->block);
@@ -722,12 +746,17 @@ static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int
 static std::string user_program(const char *source, int lanes, int block) {
   std::string p = "#include \"amwg_kernel.h\"\n#include \"amwg_user.h\"\n";
   p += source;
-  char tail[512];
+  char tail[1200];
+  // amwg_user_step: the step kernel for this geometry.  amwg_user_sweep: for a closure with a row plan (amwg_rows.h: UserModel::kLaneReuse) on a whole
+  // wavefront per chain, the same stepper with the sweep prefetch (amwg_sweep_kernel's twin); an empty kernel otherwise -- the host never launches it then.
   snprintf(tail, sizeof tail,
            "\nextern \"C\" __global__ void __launch_bounds__(%d) amwg_user_step(const amwg::StepArgs a) {\n"
            "  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n"
-           "  amwg::step_body<amwg::UserModel, %d>(a, smem);\n}\n",
-           block, lanes);
+           "  amwg::step_body<amwg::UserModel, %d>(a, smem);\n}\n"
+           "extern \"C\" __global__ void __launch_bounds__(%d) amwg_user_sweep(const amwg::StepArgs a) {\n"
+           "  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n"
+           "  if constexpr (amwg::LaneReuseOf<amwg::UserModel>::value && %d == 64 && %d <= 512) amwg::step_body<amwg::UserModel, 64, 512, false, true>(a, smem);\n}\n",
+           block, lanes, block, lanes, block);
   p += tail;
   return p;
 }
@@ -819,9 +848,10 @@ static void dump_code_object(const std::vector<char> &code) {      // developmen
 // use_cache = false: compile even if the on-disk cache has the object (the caller found the cached one unloadable)
 static int compile_user(const char *source, int lanes, int block, const char *arch, std::vector<char> *code, bool use_cache = true) {
   static const char *names[] = {"amwg_stdint.h", "amwg_types.h", "amwg_math.h", "amwg_div.h", "amwg_ld.h", "amwg_philox.h",
-                                "amwg_kernel.h", "amwg_user.h", "amwg_twoval.h", "amwg_kval.h", "amwg_trig.h", "amwg_pass.h"};
+                                "amwg_kernel.h", "amwg_user.h", "amwg_twoval.h", "amwg_kval.h", "amwg_trig.h", "amwg_pass.h", "amwg_rows.h", "amwg_window.h"};
   const char *texts[] = {amwg_hdr_stdint, amwg_hdr_types, amwg_hdr_math, amwg_hdr_div, amwg_hdr_ld, amwg_hdr_philox,
-                         amwg_hdr_kernel, amwg_hdr_user, amwg_hdr_twoval, amwg_hdr_kval, amwg_hdr_trig, amwg_hdr_pass};
+                         amwg_hdr_kernel, amwg_hdr_user, amwg_hdr_twoval, amwg_hdr_kval, amwg_hdr_trig, amwg_hdr_pass, amwg_hdr_rows, amwg_hdr_window};
+  constexpr int kHeaders = (int)(sizeof(texts) / sizeof(texts[0]));
   const std::string prog_src = user_program(source, lanes, block);
   const char *const kOpts[] = {"-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-falign-loops=64"};
   // the on-disk cache (see above)
@@ -842,7 +872,7 @@ static int compile_user(const char *source, int lanes, int block, const char *ar
   }
   ++g_cache_misses;
   hiprtcProgram prog = nullptr;
-  hiprtcResult r = hiprtcCreateProgram(&prog, prog_src.c_str(), "amwg_user_model.hip", 12, texts, names);
+  hiprtcResult r = hiprtcCreateProgram(&prog, prog_src.c_str(), "amwg_user_model.hip", kHeaders, texts, names);
   if (r != HIPRTC_SUCCESS) return fail(AMWG_EHIP, "hiprtcCreateProgram failed: %s", hiprtcGetErrorString(r));
   const std::string arch_opt = std::string("--offload-arch=") + arch;
   // same floating-point contract as the Makefile: one rounding per operation, no fused contraction
@@ -871,7 +901,7 @@ static int compile_user(const char *source, int lanes, int block, const char *ar
 // hiprtc compile + load, plus whatever depends on the lane count), run for a few steps on the real chain state -- which is saved
 // before and restored after, so tuning leaves no trace in the chains -- and timed with HIP events.  The fastest wins, except that one
 // lane per chain (the reference's summation order) is kept whenever it MEASURES within 12 % of the fastest.
-struct TuneCandidate { int lanes, block, grid, lds, cpb; step_kernel_t kernel; hipModule_t module; hipFunction_t fn; float ms; };
+struct TuneCandidate { int lanes, block, grid, lds, cpb; step_kernel_t kernel; hipModule_t module; hipFunction_t fn; float ms; int pad; bool sweep; };
 
 template <class Prepare>
 static int autotune_geometry(amwg_sampler *s, int n_cus, size_t max_lds, Prepare prepare) {
@@ -902,7 +932,7 @@ static int autotune_geometry(amwg_sampler *s, int n_cus, size_t max_lds, Prepare
   for (int G = 1; G <= 1024; G <<= 1) {
     s->opt.lanes_per_chain = G;
     if (choose_geometry(s, n_cus, max_lds) != AMWG_OK || prepare() != AMWG_OK) { if (first_error.empty()) first_error = g_err; continue; }
-    TuneCandidate c{s->lanes, s->block, s->grid, s->lds, s->cpb, s->kernel, s->user_module, s->user_fn, 0.f};
+    TuneCandidate c{s->lanes, s->block, s->grid, s->lds, s->cpb, s->kernel, s->user_module, s->user_fn, 0.f, s->d.pad, s->user_sweep};
     // One untimed launch first (it evaluates log_post(init), stages the data for the first time and warms the instruction cache); then the
     // run length is scaled until a launch takes >= 1 ms -- short data loops would otherwise be ranked by launch overhead and noise -- and the
     // candidate's figure is the FASTEST of three such launches, per step.  The runs continue the chains from one another (a valid lp_curr,
@@ -938,6 +968,7 @@ static int autotune_geometry(amwg_sampler *s, int n_cus, size_t max_lds, Prepare
   for (size_t i = 0; i < cand.size(); ++i) if (i != best && cand[i].module) (void)hipModuleUnload(cand[i].module);
   const TuneCandidate &c = cand[best];
   s->lanes = c.lanes; s->block = c.block; s->grid = c.grid; s->lds = c.lds; s->cpb = c.cpb; s->kernel = c.kernel; s->user_module = c.module; s->user_fn = c.fn;
+  s->d.pad = c.pad; s->user_sweep = c.sweep;      // (the row layout and the sweep kernel go with the geometry)
   s->tuned.clear();
   for (auto &q : cand) s->tuned.push_back({q.lanes, q.ms});
   s->n_launches = 0;
@@ -1185,10 +1216,15 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
   s->user_max_threads = max_threads;
   s->user_work = m->work_per_eval;
   s->user_work_one_lane = m->work_one_lane;
+  if (m->rows_n_obs < 0 || m->rows_groups < 0) return fail(AMWG_EINVAL, "amwg_create_user: negative row plan");
+  s->user_rows_n = m->rows_n_obs;
+  s->user_rows_groups = m->rows_groups;
+  s->user_rows_sweep = m->rows_sweep ? 1 : 0;
   s->C = options->chains;
   s->device = options->device;
   auto bail = [&](int rc) { amwg_destroy(s); return rc; };
   TRYB(build_layout(s, params, n_params, true));
+  for (int p = 0; p < n_params; ++p) s->user_has_binary = s->user_has_binary || params[p].type == AMWG_BINARY;
   hipDeviceProp_t prop;
   TRYB(open_device(s, &prop));
 
@@ -1257,7 +1293,7 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
     }
     if (s->user_module) return AMWG_OK;      // (autotune hands back the module it kept)
     hipError_t e = hipModuleLoadData(&s->user_module, it->second.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&s->user_fn, s->user_module, "amwg_user_step");
+    if (e == hipSuccess) e = hipModuleGetFunction(&s->user_fn, s->user_module, s->user_sweep ? "amwg_user_sweep" : "amwg_user_step");
     if (e != hipSuccess) {
       // the cache is never a requirement: an object the loader refuses (a planted or half-written file that still passed the checks, another
       // driver) is dropped and the closure compiled afresh, once
@@ -1268,7 +1304,7 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
       if (rc != AMWG_OK) return rc;
       it->second = std::move(fresh);
       e = hipModuleLoadData(&s->user_module, it->second.data());
-      if (e == hipSuccess) e = hipModuleGetFunction(&s->user_fn, s->user_module, "amwg_user_step");
+      if (e == hipSuccess) e = hipModuleGetFunction(&s->user_fn, s->user_module, s->user_sweep ? "amwg_user_sweep" : "amwg_user_step");
       if (e != hipSuccess) return fail(AMWG_EHIP, "loading the compiled log_post failed: %s", hipGetErrorString(e));
     }
     // workgroups of this kernel use up to the whole 160 KB LDS of a CU; not every runtime needs (or accepts) the opt-in for module functions
@@ -1582,7 +1618,7 @@ const char *amwg_kernel_name(const amwg_sampler *s) {
   if (m->kernel_name.empty()) {
     const int cls = s->block <= 256 ? 256 : (s->block <= 512 ? 512 : 1024);
     char buf[96];
-    if (s->user) snprintf(buf, sizeof buf, "amwg_user_step");
+    if (s->user) snprintf(buf, sizeof buf, "%s", s->user_sweep ? "amwg_user_sweep" : "amwg_user_step");
     else if (s->mc.group_local) snprintf(buf, sizeof buf, "amwg_gl_kernel<HierGlModel,%d>", cls);
     else if (s->model == AMWG_MODEL_HIER_NORMAL && s->d.pad > 0) snprintf(buf, sizeof buf, "amwg_sweep_kernel<HierNormalModel,%d>", cls);
     else {

@@ -221,7 +221,12 @@ __device__ __forceinline__ double log_post(const StateView &S, const StepArgs &a
     // translated closure: the generated body returns this lane's partial sum (lane 0 carries every
     // term outside the lane-split loops), see bayes.js_amd/translate.js
     wave_priority(0);      // (the whole evaluation of a translated closure counts as "the data pass" for the issue priority, see below)
-    acc = Model::template eval<G, false>(S, a.d, smem, sub, nullptr);
+    bool summed = false;
+    if constexpr (LaneReuseOf<Model>::value && G == 64) {
+      // a closure that ends in a likelihood loop with group means, in the row layout (amwg_rows.h): the lanes whose three numbers did not change keep their sums
+      if (a0.d.pad > 0) { acc = Model::template rows_eval<U>(cache, S, a.d, smem, sub, a0.d.pad, (int)(threadIdx.x >> 6)); summed = true; }
+    }
+    if (!summed) acc = Model::template eval<G, false>(S, a.d, smem, sub, nullptr);
   } else {
     if constexpr (TracksState<Model>::value) Model::template load<G>(cache, S, a.mc, a.d, smem, sub);   // first evaluation: fill the register mirror
     const typename Model::Pass ps = Model::template begin<G>(S, a.mc, a.d, smem, cache);
@@ -612,7 +617,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     for (int k = 0; k < n_named; ++k) pcol.set(k, (int)a.ch.perm16[(int64_t)k * C + cl]);
   typename RngOf<Model, G, GL, SW>::type rng;
   if constexpr (GL) rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid, reinterpret_cast<double *>(smem + L.data + Model::gl_lds_bytes(a.d.pad, 0)) + (size_t)(tid >> 6) * 256);
-  else if constexpr (SW) rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid, reinterpret_cast<double *>(smem + L.data + Model::rows_window_offset(a.d.pad, nt / 64, a.d.G)) + (size_t)(tid >> 6) * 256);
+  else if constexpr (SW) rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid, reinterpret_cast<double *>(smem + L.data + Model::window_offset(a.d, nt / 64)) + (size_t)(tid >> 6) * 256);
   else rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid);
   double lp_curr = a.ch.lp_curr[cl];
   __syncthreads();
@@ -905,6 +910,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     double sw_prop = 0.0, sw_u = 0.0;
     int ord_pos = lane64;     // lane c: the place of entry c in the shuffled order (the inverse of `ord`; sweep kernel only)
     int sw_left = 0;          // updates of the sweep still to come (0: the stepper draws as it goes)
+    int sb = 0;               // the swept vector's place in the state: its entry c is component sb + c (the built-in family: 0)
+    if constexpr (kSweep) sb = Model::sweep_base(a.d);
     bool sw_pending = false;  // the parameter whose first slot comes next is such a sweep: drawn at the top of that slot
     // descriptor of the parameter being walked, read from the LDS tables once, when the parameter begins (round 2 re-read it in every
     // slot: a dependent LDS round trip per update in front of the component lookup)
@@ -963,7 +970,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
               idx.set(j, ti);
             }
           }
-          if constexpr (kSweep) sw_pending = sweep_rt && d_base == 0 && d_inner == 1 && d_len == chain_uniform<G>(a.d.G) && d_len > 1;
+          if constexpr (kSweep) sw_pending = sweep_rt && d_base == Model::sweep_base(a.d) && d_inner == 1 && d_len == chain_uniform<G>(Model::sweep_len(a.d)) && d_len > 1;
         }
       }
       int comp = d_base;
@@ -1000,16 +1007,20 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           // Every lane draws the proposal of ITS component (sweep_comp: the one its sum depends on).  Which (u, v) pair of the stream survives rnorm's
           // rejection test (mcmc.js:44-53) is a property of the stream alone: the window stream holds those flags for 256 uniforms, a scalar loop walks
           // the updates in their shuffled order -- first accepted pair at or after the position, then the accept uniform (as in the group-local kernel,
-          // gl_resolve_unbounded) -- and a lane reads the three uniforms of its component's update from the window.  Components with bounds or of integer
-          // type may draw no accept uniform: such a parameter is walked update by update, as always.
-          const int comp_l = Model::sweep_comp(data_lds, a.d, sub), cidx = comp_l >= 0 ? comp_l : 0;
+          // gl_resolve_unbounded) -- and a lane reads the three uniforms of its component's update from the window.  An integer component rounds its
+          // proposal (mcmc.js:597), which draws nothing.  A component with BOUNDS draws no accept uniform when its proposal falls outside (mcmc.js:520-522):
+          // the walk assumes every proposal inside, the lanes check their own, and where the assumption was wrong the round is walked again with it
+          // corrected (the earliest wrong one is final after each pass, as in the group-local kernel) -- round 4 walked such a parameter update by update.
+          const int comp_l = Model::sweep_comp(data_lds, a.d, sub), cl = comp_l >= 0 ? comp_l : 0, cidx = sb + cl;
           const double sd_l = SDme[cidx], cur_l = Sme[cidx];
           const double lower_l = cc[cidx].lower, upper_l = cc[cidx].upper;
           const int type_l = cc[cidx].type;
-          if (__ballot(comp_l >= 0 && (lower_l > -kInf || upper_l < kInf || type_l == kTypeInt)) == 0ull) {
+          const bool bounded_any = __ballot(comp_l >= 0 && (lower_l > -kInf || upper_l < kInf)) != 0ull;
+          uint64_t inb_assume = ~0ull;      // bit c: the proposal of entry c is taken to fall inside its bounds (it draws the accept uniform)
+          {
           {
             const int top = d_len;
-            const int pos_l = __shfl(ord_pos, cidx, 64);
+            const int pos_l = __shfl(ord_pos, cl, 64);
             uint32_t p_s = rng.position();
             int ppv = 0, t_begin = 0;
             while (t_begin < top) {
@@ -1017,14 +1028,39 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
               const uint64_t EA = uniform_u64(rng.EA), OA = uniform_u64(rng.OA), EB = uniform_u64(rng.EB) & ~(1ull << 63), OB = uniform_u64(rng.OB);
               uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)p_s);
               int t = __builtin_amdgcn_readfirstlane(t_begin);
-              gl_resolve_unbounded(EA, OA, EB, OB, pw, t, __builtin_amdgcn_readfirstlane(top), ppv);
+              const int top_s = __builtin_amdgcn_readfirstlane(top);
+              if (!bounded_any) gl_resolve_unbounded(EA, OA, EB, OB, pw, t, top_s, ppv);
+              else {
+                const uint64_t assume = uniform_u64(inb_assume);
+                for (; t < top_s; ++t) {
+                  bool found = false;
+                  while (pw < 256u) {
+                    const uint32_t par = pw & 1u, ix = (pw & 127u) >> 1;
+                    const uint64_t m = (pw & 128u) ? (par ? OB : EB) : (par ? OA : EA);
+                    const uint64_t rest = m >> ix;
+                    if (rest != 0ull) { pw += 2u * (uint32_t)__builtin_ctzll(rest); found = true; break; }
+                    if (pw & 128u) { pw = 254u | par; break; }      // every pair up to the window's last one is rejected (consumed): the search resumes there in the next window
+                    pw = 128u | par;                               // nothing left in the first half: on to the second
+                  }
+                  if (!found) break;
+                  ppv = write_lane(ppv, (int)pw, t);
+                  const int ck = __builtin_amdgcn_readlane(ord, t);
+                  pw += ((assume >> ck) & 1ull) ? 3u : 2u;
+                }
+              }
               const int t_end = t;
               const bool in_round = comp_l >= 0 && pos_l >= t_begin && pos_l < t_end;
               int q_raw = __shfl(ppv, pos_l, 64);      // (by all lanes, outside the select: a masked-off source lane reads as 0)
               asm volatile("" : "+v"(q_raw));
               const uint32_t q_l = in_round ? (uint32_t)q_raw : 0u;
               const double u = rng.at(q_l), v_raw = rng.at(q_l + 1u), ua = rng.at(q_l + 2u);
-              const double prop_l = ((1.7156 * (v_raw - 0.5)) / u) * sd_l + cur_l;       // rnorm_js: (v / u) * sd + mean
+              double prop_l = ((1.7156 * (v_raw - 0.5)) / u) * sd_l + cur_l;       // rnorm_js: (v / u) * sd + mean
+              if (type_l == kTypeInt) prop_l = js_round(prop_l);
+              if (bounded_any) {
+                const bool inb_me = !(prop_l < lower_l || prop_l > upper_l);
+                const uint64_t round_mask = __ballot(in_round && lane64 < top), actual = __ballot(inb_me);      // (lane c < top: entry c)
+                if (((actual ^ inb_assume) & round_mask) != 0ull) { inb_assume = (inb_assume & ~round_mask) | (actual & round_mask); continue; }
+              }
               sw_prop = in_round ? prop_l : sw_prop;
               sw_u = in_round ? ua : sw_u;
               t_begin = t_end;
@@ -1033,8 +1069,11 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
               if (t_begin < top) p_s = rng.position();
             }
           }
-          const uint64_t sw_inb = d_len >= 64 ? ~0ull : ((1ull << d_len) - 1ull);      // (no bounds: every proposal is evaluated)
-          const auto rows = Model::template prefetch_rows<kPassU>(cache, S, a.mc, a.d, data_lds, sub, sw_prop, a.d.pad);
+          const uint64_t sw_inb = (d_len >= 64 ? ~0ull : ((1ull << d_len) - 1ull)) & inb_assume;      // (a proposal outside its bounds is not evaluated)
+          // (the sums are prepared for proposals INSIDE their bounds; an entry whose proposal fell outside keeps its value: its lanes' sums are not used)
+          const bool inb_mine = ((inb_assume >> cl) & 1ull) != 0ull;
+          const double sw_eval = (bounded_any && !inb_mine) ? cur_l : sw_prop;
+          const auto rows = Model::template prefetch_rows<kPassU>(cache, S, a.mc, a.d, data_lds, sub, sw_eval, a.d.pad);
           if (rows.ok && slot + d_len <= P_stepped) {
             // every lane holds its committed sum and its sum under its component's proposal: an update is the butterfly of the 64 sums with the
             // proposed ones in the lanes of ITS component -- the value the whole evaluation returns for that state, bit for bit --, the accept test,
@@ -1048,12 +1087,12 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
               const double prop_c = lane_value(sw_prop, c), u_c = lane_value(sw_u, c);
               const double Tv = rows.comp == c ? rows.T_new : T_cur;
               const double prop_lp = butterfly<1, 64>(Tv);
-              if (accept_sweep(prop_lp - lp_curr, u_c)) { lp_curr = prop_lp; T_cur = Tv; set_state(c, prop_c); acc_mask |= 1ull << c; }
+              if (accept_sweep(prop_lp - lp_curr, u_c)) { lp_curr = prop_lp; T_cur = Tv; set_state(sb + c, prop_c); acc_mask |= 1ull << c; }
             }
             if (lane64 < d_len) {
               const bool inb_l = ((inb_s >> lane64) & 1ull) != 0ull, acc_l = ((acc_mask >> lane64) & 1ull) != 0ull;
-              if (inb_l) TOTme[lane64] += 1u + (acc_l ? 0x10000u : 0u);
-              if (adapt[lane64] != 0) adapt_component(lane64, acc_l, CNTme[lane64], cc[lane64].batch_size, live, true);
+              if (inb_l) TOTme[sb + lane64] += 1u + (acc_l ? 0x10000u : 0u);
+              if (adapt[sb + lane64] != 0) adapt_component(sb + lane64, acc_l, CNTme[sb + lane64], cc[sb + lane64].batch_size, live, true);
             }
             Model::sweep_done(cache, rows, rows.comp >= 0 && ((acc_mask >> (rows.comp & 63)) & 1ull) != 0ull);
             // the walk moves past the parameter: its first component was handed out when the previous slot looked ahead
@@ -1094,7 +1133,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       const double cur = me.cur;
       const bool in_sweep = kSweep && sw_left > 0;      // (this update's proposal and uniform were drawn when the sweep began)
       double prop;
-      if (in_sweep) prop = lane_value(sw_prop, comp);
+      if (in_sweep) prop = lane_value(sw_prop, comp - sb);
       else {
         prop = rnorm_js(rng, cur, me.sd);
         if (chain_true<G>(k_type == kTypeInt)) prop = js_round(prop);
@@ -1102,7 +1141,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       const bool inb = chain_true<G>(!(prop < k_lower || prop > k_upper));
       // the accept test's uniform (mcmc.js:528) is the next one of the stream whatever log_post returns: drawn now
       double u_accept = 0.0;
-      if (inb) { set_state(comp, prop); u_accept = in_sweep ? lane_value(sw_u, comp) : rng.next(); }
+      if (inb) { set_state(comp, prop); u_accept = in_sweep ? lane_value(sw_u, comp - sb) : rng.next(); }
       if (in_sweep) --sw_left;
       // everything this slot draws is drawn: the next slot's component is known (and, if a multidimensional parameter begins there,
       // shuffled), and what the stepper needs of it is requested NOW, under the evaluation below

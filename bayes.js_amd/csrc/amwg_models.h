@@ -335,6 +335,10 @@ struct HierNormalModel {
   __host__ __device__ static size_t rows_window_offset(int pitch, int waves, int groups) { return (size_t)64 * pitch * 8 + 64 + (size_t)waves * local_rows(groups) * term_pitch(pitch) * 8; }
   __host__ __device__ static size_t rows_lds_bytes(int pitch, int waves, int groups) { return rows_window_offset(pitch, waves, groups) + (size_t)waves * 256 * 8; }
   using SweepStream = WindowStream;
+  __device__ __forceinline__ static size_t window_offset(const DataRef &d, int waves) { return rows_window_offset(d.pad, waves, d.G); }
+  // which parameter vector the sweep prefetch is for (amwg_kernel.h kSweep): theta, the first parameter, one entry per group
+  __device__ __forceinline__ static int sweep_base(const DataRef &) { return 0; }
+  __device__ __forceinline__ static int sweep_len(const DataRef &d) { return d.G; }
   // the one component lane `sub` of a chain on a whole wavefront stands for in a sweep over theta: the component whose prior term it holds, else its group's
   __device__ __forceinline__ static int sweep_comp(const unsigned char *smem, const DataRef &d, int sub) {
     return sub < d.G ? sub : (sub < d.n_obs ? (int)(smem + (size_t)64 * d.pad * 8)[sub] : -1);

@@ -268,6 +268,9 @@ static napi_value CreateUser(napi_env env, napi_callback_info info) {
   um.max_threads = (int32_t)prop_i64(env, a[0], "max_threads", 0);
   um.work_per_eval = prop_double(env, a[0], "work_per_eval", 0.0);
   um.work_one_lane = prop_double(env, a[0], "work_one_lane", 0.0);
+  um.rows_n_obs = (int32_t)prop_double(env, a[0], "rows_n_obs", 0.0);      /* row plan (csrc/amwg_rows.h), 0 = none */
+  um.rows_groups = (int32_t)prop_double(env, a[0], "rows_groups", 0.0);
+  um.rows_sweep = (int32_t)prop_double(env, a[0], "rows_sweep", 0.0);
   amwg_param_desc *pd; amwg_comp_opt *co; uint32_t n_params; const double *init; amwg_options op;
   if (!parse_common(env, a, &pd, &co, &n_params, &init, &op)) { free(src); free(arrs); free(lens); free(types); return NULL; }
   amwg_sampler *s = NULL;

@@ -16,3 +16,5 @@ AMWG_TEXT(amwg_hdr_twoval, "amwg_twoval.h");
 AMWG_TEXT(amwg_hdr_kval, "amwg_kval.h");
 AMWG_TEXT(amwg_hdr_trig, "amwg_trig.h");
 AMWG_TEXT(amwg_hdr_pass, "amwg_pass.h");
+AMWG_TEXT(amwg_hdr_rows, "amwg_rows.h");
+AMWG_TEXT(amwg_hdr_window, "amwg_window.h");

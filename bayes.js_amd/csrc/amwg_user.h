@@ -237,3 +237,5 @@ AMWG_HD double js_clz32(double a) { const uint32_t u = (uint32_t)js_toint32(a); 
 AMWG_HD double js_fround(double a) { return (double)(float)a; }
 
 }  // namespace amwg
+
+#include "amwg_rows.h"      // lane-local re-evaluation + sweep prefetch for closures with a row plan (device only)

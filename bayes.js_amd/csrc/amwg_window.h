@@ -2,7 +2,9 @@
 // sweep draw their proposals side by side (the group-local kernel, amwg_gl.h; the sweep prefetch of the hierarchical family's row layout,
 // amwg_kernel.h kSweep).  Same stream as CoopStream / ChainStream (amwg_philox.h).
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
+#endif
 
 #include "amwg_math.h"
 #include "amwg_philox.h"

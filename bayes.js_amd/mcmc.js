@@ -251,7 +251,7 @@ function AmwgSampler(params, log_post, data, options) {
     this.derived = tr.derived;
     this.translation = tr;
     user = { source: tr.source, arrays: tr.arrays, array_types: tr.array_types, n_derived: tr.derived.length, lds_bytes: tr.lds_bytes, lds_bytes_one_lane: tr.lds_bytes_one_lane, parallel: tr.parallel,
-             max_threads: tr.max_threads, work_per_eval: tr.work_per_eval, work_one_lane: tr.work_one_lane };
+             max_threads: tr.max_threads, work_per_eval: tr.work_per_eval, work_one_lane: tr.work_one_lane, rows_n_obs: tr.rows_n_obs, rows_groups: tr.rows_groups, rows_sweep: tr.rows_sweep };
   }
   this.PR = this.P + this.derived.length;   // values per recorded draw
 

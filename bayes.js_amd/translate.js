@@ -1253,6 +1253,7 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
     for (const st of body.slice(0, -1)) walk(st, (x) => { if ((x.k === 'Assign' || x.k === 'Update') && x.target.k === 'Id' && this.accSet.has(x.target.name)) accElsewhere = true; });
     const single = split && isInt && boundV.int && endsInAcc && !accElsewhere && !containsKind(s.body, 'Return') &&
                    !containsKind(s.body, 'Continue') && !containsKind(s.body, 'Break');
+    if (this.loopInfo) this.loopInfo.push({ name: canon.name, single: !!single, start: startV.cst, bound: boundV.cst, le: !!canon.le });
     if (single) {
       const pre = [];
       const heavyBefore = this.heavyLoop;
@@ -1366,10 +1367,18 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
         for (let i = 0; i < n && mid; i++) { const v = Math.abs(arr.flat[i]); mid = v === 0 || (v >= Math.pow(2, -200) && v <= Math.pow(2, 200)); }
         for (let i = 0; i < n; i++) ng = Math.max(ng, gl[i] + 1);
         for (let j = 0; j <= 10; j++) { const Gj = 1 << j; let per = n > 0; for (let i = Gj; i < n && per; i++) per = gl[i] === gl[i % Gj]; if (per) mask |= 1 << j; }
+        // ROW PLAN candidate (csrc/amwg_rows.h): this loop at the top level of the closure, adding to the closure's one accumulator, f64 observations,
+        // labels that repeat with a stride of 64, an sd that is an expression of the state alone.  run() decides (it must be the LAST statement).
+        const sdLine = L.preamble.length === 1 && /^const NormInv (k\d+) = norm_inv\((.+)\);(?: KFASTCHECK\(\1\))?$/.exec(L.preamble[0].trim());
+        const rowCand = !this.isHelper && !this.opts.no_row_plan && !this.linear && this.acc && loopAcc === this.acc && indent === '    ' && !this.condDepth &&
+                        arr.ctype === 'double' && n >= 64 && ng >= 1 && ng <= 64 && ((mask >> 6) & 1) && sdLine && sdLine[1] === mg[6] &&
+                        !/\b(v_\w+|A\d+|t\d+|k\d+|tb_|it_|sub|dq_\w+)\b/.test(sdLine[2]);
+        if (rowCand) out.push(indent + '//@ROWS y=A' + mg[1] + ' labels=A' + mg[4] + ' base=' + (mg[3] || '0') + ' ng=' + ng + ' n=' + n + ' mid=' + (mid ? 1 : 0) + ' acc=' + loopAcc + ' sd=' + sdLine[2]);
         out.push(indent + '{');
         for (const ln of renderNorm(L.preamble.map((q) => '  ' + q), 'inv')) out.push(indent + ln);
         out.push(indent + '  ' + acc + ' = norm_data_loop_gather<G, ((' + mask + 'u >> __builtin_ctz((unsigned)G)) & 1u) != 0u>(A' + mg[1] + ', A' + mg[4] + ', S, ' + (mg[3] || '0') + ', ' + ng + ', ' + n + ', ' + mg[6] + ', ' + (mid ? 'true' : 'false') + ', sub, ' + acc + ');');
         out.push(indent + '}');
+        if (rowCand) out.push(indent + '//@ROWS_END');
         this.otherSplitLoops = (this.otherSplitLoops || 0) + 1;      // (one lane per chain gains nothing here: the data stays in LDS)
         return;
       }
@@ -1631,6 +1640,7 @@ Translator.prototype.functionBody = function (numericParams, allowSplit) {
     this.oneLaneWork = 0;
     this.uniformNormLoops = 0;
     this.otherSplitLoops = 0;
+    this.loopInfo = [];      // every canonical loop of this round: {name, single, start, bound, le} (the row plan's proof reads it)
     lines = [];
     for (const st of stmts) this.stmt(st, lines, '    ', { inLoop: false, split: false });
     if (!last || last.k !== 'Return') this.fail('log_post must end with a return statement');
@@ -1694,10 +1704,18 @@ Translator.prototype.run = function () {
   // 512 threads, so that every SIMD still holds two wavefronts (a lone one cannot hide its own fp64 latency: logit_n10k, 88 KB staged,
   // 1.52e7 -> 2.01e7 updates/s).  Plain arithmetic loops: up to 1024.
   const maxThreads = this.opts.max_threads || (this.heavyLoop ? (off > 73728 ? 512 : 256) : 1024);
+  const rows = this.rowPlan(body);
   const src = [];
   src.push('// generated by bayes.js_amd/translate.js from the user\'s log_post closure');
   src.push('namespace amwg {');
   for (const h of this.helperSources) src.push(h);
+  if (rows) {
+    src.push('struct UserModel');
+    src.push('#if defined(__HIPCC__) || defined(__HIPCC_RTC__)');
+    src.push('    : UserRows<UserModel>      // row plan (csrc/amwg_rows.h): the closure ends in a likelihood loop with group means');
+    src.push('#endif');
+    src.push('{');
+  } else
   src.push('struct UserModel {');
   src.push('  static constexpr bool kUser = true, kHasFast = false, kOneLanePass = false;');
   src.push('  static constexpr bool kHasBinary = ' + (this.hasBinary ? 'true' : 'false') + ';   // BinaryStepper branch of the step kernel');
@@ -1707,6 +1725,7 @@ Translator.prototype.run = function () {
   const copies = (pl) => this.arrays.map((a, j) => pl[j].lds ? '{ ' + a.ctype + ' *dst = reinterpret_cast<' + a.ctype + ' *>(smem + ' + pl[j].off + '); const ' + a.ctype + ' *src = static_cast<const ' + a.ctype + ' *>(user_arr<' + j + '>(d)); for (int i = tid; i < ' + a.flat.length + '; i += nt) dst[i] = src[i]; }' : '').filter((x) => x);
   src.push('  __host__ __device__ static size_t lds_bytes(int, int, int lanes) { return lanes == 1 ? ' + P1.bytes + ' : ' + off + '; }');
   src.push('  __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int lanes) {');
+  if (rows) src.push('    if (d.pad > 0) { stage_rows(smem, d, tid, nt); return; }      // row layout: the observations of the final loop one row per lane, the other arrays from global memory');
   if (P1 === PG) for (const c of copies(plan)) src.push('    ' + c);
   else {
     src.push('    if (lanes == 1) {');
@@ -1716,6 +1735,23 @@ Translator.prototype.run = function () {
     src.push('    }');
   }
   src.push('  }');
+  if (rows) {
+    src.push('  // ---- row plan: `' + rows.acc + '` ends in  for (i < ' + rows.n + ') ' + rows.acc + ' += ld.norm(A' + rows.y + '[i], state[' + rows.base + ' + A' + rows.labels + '[i]], ' + rows.sd + ')');
+    src.push('  static constexpr int kRowN = ' + rows.n + ', kRowBase = ' + rows.base + ', kRowGroups = ' + rows.K + ', kRowY = ' + rows.y + ', kRowLabels = ' + rows.labels + ';');
+    src.push('  static constexpr bool kRowDataMid = ' + (rows.mid ? 'true' : 'false') + ';');
+    src.push('  // kRowSweep: a lane\'s accumulator at that loop reads the swept vector only as its OWN entry (entry k in a lane-split loop over all K entries, lane k) and');
+    src.push('  // lane k < K has label k: ' + rows.sweepWhy);
+    src.push('  static constexpr bool kRowSweep = ' + (rows.sweep ? 'true' : 'false') + ';');
+    src.push('  __device__ __forceinline__ static double row_sd(const StateView &S, const DataRef &d) { (void)S; (void)d; return ' + rows.sd + '; }');
+    src.push('  // the closure up to that loop: what this lane\'s accumulator holds when the loop begins (data arrays read from global memory)');
+    src.push('  template <int G>');
+    src.push('  __device__ static double head(const StateView &S, const DataRef &d, const unsigned char *smem, int sub) {');
+    this.arrays.forEach((a, j) => { src.push('    const ' + a.ctype + ' *A' + j + ' = static_cast<const ' + a.ctype + ' *>(user_arr<' + j + '>(d));'); });
+    src.push('    (void)smem; (void)sub; (void)d;');
+    for (const ln of rows.head) src.push(ln);
+    src.push('    return v_' + rows.acc + ';');
+    src.push('  }');
+  }
   src.push('#endif');
   src.push('  template <int G, bool DERIVE>');
   src.push('  AMWG_HD static double eval(const StateView &S, const DataRef &d, const unsigned char *smem, int sub, double *dv) {');
@@ -1749,7 +1785,66 @@ Translator.prototype.run = function () {
     // the reference's own summation order, which the host library prefers when it is priced within 12 % of the cheapest geometry)
     work_one_lane: (this.oneLaneWork || (this.uniformNormLoops > 0 && !this.otherSplitLoops)) ? this.workEstimate(true) : 0,
     P: this.P,
+    // row plan (csrc/amwg_rows.h; include/amwg.h amwg_user_model::rows_*): 0 / 0 / 0 = none
+    rows_n_obs: rows ? rows.n : 0,
+    rows_groups: rows ? rows.K : 0,
+    rows_sweep: rows && rows.sweep ? 1 : 0,
   };
+};
+
+// The ROW PLAN of a closure (csrc/amwg_rows.h): its LAST statement before `return acc` is the gathered normal loop forLoop() marked with //@ROWS, over all
+// observations, with labels that repeat with a stride of 64.  Everything before is the `head` -- it must not return early or write derived quantities.
+// -> {y, labels, base, K (entries of the swept vector), n, mid, acc, sd, head: [lines], sweep, sweepWhy} or null
+Translator.prototype.rowPlan = function (body) {
+  if (this.derived.length || this.isHelper || this.opts.no_row_plan) return null;
+  let iB = -1, iE = -1;
+  body.forEach((ln, i) => { const t = ln.trim(); if (t.indexOf('//@ROWS ') === 0) iB = i; else if (t === '//@ROWS_END') iE = i; });
+  if (iB < 0 || iE < iB) return null;
+  const m = /^\/\/@ROWS y=A(\d+) labels=A(\d+) base=(\d+) ng=(\d+) n=(\d+) mid=([01]) acc=(\w+) sd=(.+)$/.exec(body[iB].trim());
+  if (!m) return null;
+  const tail = body.slice(iE + 1).map((ln) => ln.trim()).filter((t) => t && t.indexOf('//') !== 0);
+  if (!(tail.length === 2 && /^if constexpr \(DERIVE\) \{ \(void\)dv; \}$/.test(tail[0]) && tail[1] === 'return v_' + m[7] + ';')) return null;
+  const head = body.slice(0, iB);
+  if (head.some((ln) => /\breturn\b|\bdv\[|\bdq_/.test(ln))) return null;
+  const base = Number(m[3]), ng = Number(m[4]);
+  // the swept vector: the parameter whose entries the labels select
+  let K = 0, vec = null;
+  for (const nm of Object.keys(this.layout)) { const L = this.layout[nm]; if (L.base === base && L.dim.length === 1 && !L.scalar) { K = L.len; vec = nm; } }
+  if (!vec || ng > K || K > 64) return null;
+  const plan = { y: Number(m[1]), labels: Number(m[2]), base, K, n: Number(m[5]), mid: m[6] === '1', acc: m[7], sd: m[8], head, sweep: false, sweepWhy: '' };
+  // ---- may the proposals of a whole sweep over the vector be evaluated at once?  (a) lane k < K has label k;
+  const gl = this.arrays[plan.labels].flat;
+  let why = '';
+  for (let l = 0; l < Math.min(K, 64, plan.n) && !why; l++) if (gl[l] !== l) why = 'no: observation ' + l + ' has label ' + gl[l];
+  // (b) every read of the state in the head (and in helpers) is a scalar outside the vector, an entry of ANOTHER parameter vector, or `vec[k]` with k the
+  // counter of lane-split loops over exactly 0 .. K-1 (lane k then reads entry k and no other)
+  const texts = head.concat(this.helperSources || []);
+  const bases = Object.keys(this.layout).map((nm) => this.layout[nm]);
+  for (const ln of texts) {
+    let at = 0;
+    while (!why && (at = ln.indexOf('S(', at)) >= 0) {
+      if (at > 0 && /[\w.]/.test(ln[at - 1])) { at += 2; continue; }      // (another identifier that ends in S)
+      let depth = 1, j = at + 2;
+      while (j < ln.length && depth > 0) { if (ln[j] === '(') depth++; else if (ln[j] === ')') depth--; j++; }
+      const arg = ln.slice(at + 2, j - 1).trim();
+      at = j;
+      let mm;
+      if (/^\d+$/.test(arg)) { const c = Number(arg); if (c >= base && c < base + K) why = 'no: the head reads entry ' + (c - base) + ' of ' + vec + ' by a constant index'; continue; }
+      if ((mm = /^(?:(\d+) \+ )?v_(\w+)$/.exec(arg))) {
+        const b = mm[1] ? Number(mm[1]) : 0;
+        const other = bases.find((L) => L.base === b && !L.scalar);
+        if (b !== base) { if (!other || (b < base + K && b + other.len > base)) why = 'no: the head reads the state at ' + arg; continue; }
+        const loops = (this.loopInfo || []).filter((q) => q.name === mm[2]);
+        if (!loops.length || !loops.every((q) => q.single && q.start === 0 && q.bound === K && !q.le)) why = 'no: ' + vec + '[' + mm[2] + '] is read outside a lane-split loop over 0 .. ' + (K - 1);
+        continue;
+      }
+      why = 'no: the head reads the state at S(' + arg + ')';
+    }
+    if (why) break;
+  }
+  plan.sweep = !why && !this.hasBinary;
+  plan.sweepWhy = why || (this.hasBinary ? 'no: the model has binary parameters' : 'proved');
+  return plan;
 };
 
 // Rough instruction count of one evaluation (steers only the lanes-per-chain choice of the host library): operators 1,

@@ -159,6 +159,12 @@ typedef struct {
   int32_t max_threads;           /* workgroup-size cap the translator suggests (0 = 1024) */
   double work_per_eval;          /* rough instruction count of one log_post evaluation (0 = unknown); only steers lanes_per_chain */
   double work_one_lane;          /* the same with ONE lane per chain, when the generated code then fast-forwards a two-valued sum (0 = no) */
+  /* Row plan (csrc/amwg_rows.h): the closure ENDS in `lp += ld.norm(y[i], state.theta[g[i]], sd)` over all rows_n_obs observations, labels that repeat
+   * with a stride of 64 and rows_groups <= 64 group means.  With 64 lanes per chain the library then lays the observations out in rows (one per lane)
+   * and re-forms only the per-lane sums an update can have changed -- the same bits as evaluating everything (amwg_options::full_evaluation = 1
+   * switches it off).  rows_sweep: the translator PROVED that a lane's sum depends on one entry of theta only, which allows the proposals of a whole
+   * sweep over theta to be evaluated in one pass (UserModel::kRowSweep in the source says the same).  0 / 0 / 0 = no row plan. */
+  int32_t rows_n_obs, rows_groups, rows_sweep;
 } amwg_user_model;
 
 /* Replaces `new mcmc.AmwgSampler(params, log_post, data, options)` for an arbitrary (translated) closure. */

@@ -45,6 +45,12 @@ const CASES = [
     seed: SEED, chains: [0, 1], schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 50 }] },
   { name: 'cfg4_full', model: 'hier_normal', N: 10000, G: 32, data_seed: DSEED,
     seed: SEED, chains: [0, 16383], schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 10 }] },
+  // configs[3] at full size with a BOUNDED and with an INTEGER theta (mcmc.js:520-522: a proposal outside draws no accept uniform; mcmc.js:597: rounded proposals):
+  // what the sweep kernel's walk over the stream has to get right when not every update draws three uniforms
+  { name: 'cfg4_theta_bounded', model: 'hier_normal', N: 10000, G: 32, data_seed: DSEED, param_overrides: { theta: { lower: 2.5, upper: 7.5, init: 5 } },
+    seed: SEED, chains: [0, 16383], schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 10 }] },
+  { name: 'cfg4_theta_int', model: 'hier_normal', N: 10000, G: 32, data_seed: DSEED, param_overrides: { theta: { type: 'int', init: 5 } },
+    seed: SEED, chains: [0, 16383], schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 10 }] },
   { name: 'glm_small', model: 'pois_glm', N: 500, data_seed: DSEED, store_data: true,
     seed: SEED, chains: [0, 1], schedule: [{ op: 'burn', n: 150 }, { op: 'sample', n: 150, keep: 50 }] },
   { name: 'cfg5_full', model: 'pois_glm', N: 50000, data_seed: DSEED,

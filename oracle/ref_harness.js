@@ -48,6 +48,8 @@ function runChain(c, data, chain, model) {
   try {
     const m = model || (c.hyper ? makeModels(ld, { [c.model]: c.hyper }) : models)[c.model];
     const params = m.params(data);
+    // (a case may change a parameter's description -- type, bounds, init -- before the reference completes it: c.param_overrides = {name: {...}})
+    for (const nm of Object.keys(c.param_overrides || {})) Object.assign(params[nm], c.param_overrides[nm]);
     const sampler = new mcmc.AmwgSampler(params, m.log_post, data, c.options);
     const names = Object.keys(params);
     const comps = flattenSteppers(sampler.steppers[0]);

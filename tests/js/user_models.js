@@ -190,6 +190,28 @@ CASES.hier_normal_closure = {
   },
   schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 50 }], chains: [0, 1],
 };
+// ---- closures with a ROW PLAN (csrc/amwg_rows.h) whose swept vector is NOT the first parameter, has bounds / is of integer type, and whose head
+// has a hyper-parameter the hand-written family does not know: lane-local re-evaluation and the sweep prefetch against seeded runs of the reference
+CASES.hier_rows_bounded = {
+  params: (d) => ({ mu: { type: 'real' }, tau: { type: 'real', lower: 0, upper: 50, init: 5 }, theta: { type: 'real', dim: [d.G], lower: 2, upper: 8, init: 5 }, sigma: { type: 'real', lower: 0, init: 1 } }),
+  data: () => synth.hier(640, 8, 20260925),
+  log_post: function (s, d) {
+    let lp = 0;
+    lp += ld.norm(s.mu, 0, 100);
+    lp += ld.unif(s.tau, 0, 50);
+    lp += ld.unif(s.sigma, 0, 100);
+    for (let k = 0; k < d.G; k++) lp += ld.norm(s.theta[k], s.mu, s.tau);
+    for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], s.sigma);
+    return lp;
+  },
+  schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 50 }], chains: [0, 1],
+};
+CASES.hier_rows_int = {
+  params: (d) => ({ theta: { type: 'int', dim: [d.G], init: 5 }, mu: { type: 'real' }, sigma: { type: 'real', lower: 0, init: 1 } }),
+  data: () => synth.hier(640, 8, 20260925),
+  log_post: CASES.hier_normal_closure.log_post,
+  schedule: [{ op: 'burn', n: 200 }, { op: 'sample', n: 200, keep: 50 }], chains: [0, 1],
+};
 CASES.pois_glm_closure = {
   params: (d) => ({ beta: { type: 'real', dim: [8], init: 0 }, cp: { type: 'int', lower: 0, upper: d.y.length - 1 } }),
   data: () => synth.glm(500, 20260925),

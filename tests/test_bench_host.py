@@ -104,3 +104,29 @@ def test_gpus_n_without_a_launcher_prints_the_not_measured_line_on_a_box_without
     assert p.returncode == 0, p.stderr[-1000:]
     line = json.loads(p.stdout)
     assert p.stdout.count("\n") == 1 and line["value"] is None and line["n_gpus"] == 2 and line["steps"] == 20 and "not measured" in line["note"]
+
+
+def test_flip_rate_of_a_campaign_run_with_other_kernels_is_refused(tmp_path, monkeypatch):
+    """parity.flip_rate quotes the committed campaign only when it ran the kernels that are being timed (round-4 review: two kept bench lines quoted
+    a campaign of earlier kernels); the newest campaign by ROUND NAME is the one looked at."""
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    rec = {"version": "amwg-mi355x 0.4 (gfx950) build aaaaaaaaaaaa kernels 111111111111", "runs": [], "decisions_total": 10 ** 10, "first_flips_total": 1,
+           "flips_per_1e9": 0.1, "upper_95_per_1e9": 0.5}
+    (prof / "r04_flip_rate.json").write_text(json.dumps(dict(rec, version=rec["version"].replace("111111111111", "000000000000"))))
+    (prof / "r05_flip_rate.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    ok = bench.flip_rate_record("111111111111")
+    assert ok["source"].endswith("r05_flip_rate.json") and ok["flips_per_1e9"] == 0.1 and "refused" not in ok
+    no = bench.flip_rate_record("222222222222")
+    assert "refused" in no and "111111111111" in no["refused"] and "222222222222" in no["refused"] and "flips_per_1e9" not in no
+    line = json.loads(bench.compact_line({"metric": "m", "value": 1.0, "parity": {"accept_counts_identical": True, "flip_rate": no}}))
+    assert "refused" in line["parity"]["flip_rate"]
+
+
+def test_sweep_kernel_roofline_counts_three_passes_per_step():
+    import bench
+    # 1.6e9 updates/s of the 34-component model over 1e4 observations: 4.7e7 steps/s x 3 passes x 1e4 x 8 operations
+    ops = bench.sweep_lane_ops(1.6e9, 34, 10_000, 8)
+    assert abs(ops - 1.6e9 / 34 * 3 * 10_000 * 8) < 1 and 0.25 < ops / bench.FP64_VALU_PEAK < 0.35

@@ -17,7 +17,8 @@ from gpu_util import assert_chain_equals_oracle, run_schedule, run_schedule_many
 pytestmark = pytest.mark.gpu
 
 GOLDEN_CASES = ["cfg1_heights", "normal_n1000", "cfg2_full", "normal_opts", "beta_bern_n2000", "cfg3_full", "hier_small",
-                "cfg4_full", "glm_small", "cfg5_full", "normal_hyper", "beta_bern_hyper", "beta_bern_hyper2", "hier_hyper", "glm_hyper"]
+                "cfg4_full", "glm_small", "cfg5_full", "normal_hyper", "beta_bern_hyper", "beta_bern_hyper2", "hier_hyper", "glm_hyper",
+         "cfg4_theta_bounded", "cfg4_theta_int"]      # (configs[3] with a bounded / an integer theta: updates that draw no accept uniform, rounded proposals)
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
@@ -52,7 +53,8 @@ def test_one_lane_per_chain_is_bit_identical_to_reference(name):
 
 @pytest.mark.parametrize("name,lanes", [(n, l) for n in ["cfg1_heights", "normal_n1000", "normal_opts", "beta_bern_n2000", "hier_small", "glm_small"]
                                         for l in [2, 4, 8, 16, 32, 64]] +
-                         [("cfg4_full", 64), ("cfg4_full", 32), ("cfg5_full", 64)])      # the full-size cases at the lane counts the bench times
+                         [("cfg4_full", 64), ("cfg4_full", 32), ("cfg5_full", 64),      # the full-size cases at the lane counts the bench times
+                          ("cfg4_theta_bounded", 64), ("cfg4_theta_int", 64)])           # ... the sweep kernel straight against reference goldens with a bounded / integer theta
 def test_g_lanes_per_chain_matches_oracle_and_reference_decisions(name, lanes):
     gold = golden_io.load(name)
     case = gold["case"]
@@ -63,7 +65,10 @@ def test_g_lanes_per_chain_matches_oracle_and_reference_decisions(name, lanes):
     gs, os_ = run_schedule(s, case["schedule"]), run_schedule(o, case["schedule"])
     assert_chain_equals_oracle(s, 0, o, gs, os_)
     assert s.info()["accepts"][:, 0].tolist() == rec["accepts"]      # the reference's decisions
+    assert s.info()["inbounds"][:, 0].tolist() == rec["inbounds"]
     assert int(s.diag()["uniforms"][0]) == rec["uniforms"]
+    if name.startswith("cfg4_theta"):
+        assert s.launch_info()["kernel"].startswith("amwg_sweep_kernel")
     s.close()
 
 

@@ -42,6 +42,7 @@ def spec_for(name):
 
 @pytest.mark.parametrize("name,lanes", [("readme_normal", 1), ("readme_normal", 4), ("norm_post_derived", 8), ("complex_model", 2),
                                         ("hier_binomial", 2), ("hier_normal_closure", 16), ("pois_glm_closure", 4), ("pois_glm_closure", 64),
+                                        ("hier_normal_closure", 64), ("hier_rows_bounded", 64), ("hier_rows_int", 64), ("hier_rows_bounded", 8),      # 64 lanes: the row plan (csrc/amwg_rows.h), swept / bounded / integer
                                         ("spike_slab", 4), ("survival_mix", 2), ("discrete_mix", 1), ("multi_bern", 1), ("multivar_poisson", 1), ("mixture_arrays", 2), ("many_named", 4), ("readme_bern", 1), ("readme_bern", 4), ("semantics_probe", 1), ("logistic_softplus", 4), ("modern_js", 1), ("live_out_temp", 4), ("circular_wrapped_cauchy", 8), ("structured_helpers", 4), ("records_logistic", 4), ("categorical_arms", 2), ("pois_const_rate", 1), ("pois_const_rate", 4), ("binom_const_size", 1), ("binom_const_size", 8), ("logit_n10k", 1), ("logit_n10k", 64), ("logit_bern_n10k", 16),     # K-valued fast-forward with one lane; the split loop otherwise
                                         ("wide_regression", 1), ("wide_regression", 4), ("long_dim", 1), ("long_dim", 4)])     # > 16 named parameters, > 16 data arrays, dim [300]
 def test_device_lane_sum_equals_host_emulation(name, lanes):
@@ -96,7 +97,7 @@ def test_g_lane_trajectories_equal_oracle_stepper_with_same_lane_order(name, lan
 
 
 @pytest.mark.parametrize("name,builtin", [("hier_normal_closure", "hier_small"), ("pois_glm_closure", "glm_small")])
-@pytest.mark.parametrize("lanes", [1, 4, 16])
+@pytest.mark.parametrize("lanes", [1, 4, 16, 64])
 def test_translated_closure_equals_hand_written_family_at_any_lane_count(name, builtin, lanes):
     """Two independent implementations of the same model -- the hand-written functor of csrc/amwg_models.h and the text
     translate.js generates from the closure -- use the same lane order and give the same bits."""
@@ -114,6 +115,71 @@ def test_translated_closure_equals_hand_written_family_at_any_lane_count(name, b
     assert a.diag()["log_post"].tobytes() == b.diag()["log_post"].tobytes()
     assert a.info()["accepts"].tolist() == b.info()["accepts"].tolist()
     a.close(); b.close()
+
+
+def _golden_spec(gold, rec, src, arrays, meta):
+    params, init = [], []
+    for p in rec["params_completed"]:
+        ln = int(np.prod(p["dim"]))
+        params.append({"type": p["type"], "len": ln, "top": p["dim"][0], "multidim": 0 if p["dim"] == [1] else 1, "lower": p["lower"], "upper": p["upper"]})
+        init += p["init"]
+    return {"user": user_host.user_spec_part(src, arrays, meta), "params": params, "P": len(init), "init": init, "comp_opts": rec["comp_opts"]}
+
+
+@pytest.mark.parametrize("name,kernel", [("hier_normal_closure", "amwg_user_sweep"), ("hier_rows_bounded", "amwg_user_sweep"), ("hier_rows_int", "amwg_user_sweep")])
+def test_row_plan_of_a_translated_closure_reproduces_the_reference_and_the_full_evaluation(name, kernel):
+    """csrc/amwg_rows.h on the device, 64 lanes per chain: a closure that ends in the likelihood loop of a model with group means keeps the per-lane sums an
+    update cannot have changed and evaluates the proposals of a whole sweep over theta in one pass -- for a swept vector that is not the first parameter, has
+    bounds (a proposal outside draws no accept uniform) or is of integer type as well.  Checked against (1) the seeded run of the UNMODIFIED reference
+    (tests/golden/user_<name>.json): accept counts, in-bounds counts, adaptation state and uniforms consumed of the golden's chains; (2) the same sampler with
+    options.full_evaluation = 1 (every update evaluates the whole closure): every draw, the final state and the cached log_post bit for bit, 96 chains."""
+    from gpu_util import run_schedule
+    gold = golden_io.load("user_" + name)
+    m = user_host.host_model(name)
+    assert m.meta["rows_n_obs"] > 0
+    for rec in gold["chains"]:
+        spec = _golden_spec(gold, rec, m.source, m.arrays, m.meta)
+        s = A.Sampler(spec, chains=3, seed=gold["case"]["seed"], chain_offset=rec["chain"], lanes_per_chain=64)
+        assert s.launch_info()["kernel"] == kernel and s.launch_info()["lanes_per_chain"] == 64
+        run_schedule(s, gold["case"]["schedule"])
+        info = s.info()
+        assert info["accepts"][:, 0].tolist() == rec["accepts"] and info["inbounds"][:, 0].tolist() == rec["inbounds"]
+        assert info["batch_count"][:, 0].tolist() == rec["batch_count"] and int(s.diag()["uniforms"][0]) == rec["uniforms"]
+        assert np.allclose(s.state()[:, 0], rec["final_state"], rtol=1e-9, atol=1e-12)      # (64-lane order: the doubles are those of that order, the decisions the reference's)
+        s.close()
+    spec = _golden_spec(gold, gold["chains"][0], m.source, m.arrays, m.meta)
+    sched = [{"op": "burn", "n": 130}, {"op": "sample", "n": 60, "thin": 2}, {"op": "burn", "n": 7}]
+    kw = dict(chains=96, seed=77, chain_offset=5, lanes_per_chain=64)
+    a, b = A.Sampler(spec, **kw), A.Sampler(spec, full_evaluation=1, **kw)
+    assert a.launch_info()["kernel"] == kernel and b.launch_info()["kernel"] == "amwg_user_step"
+    da, db = run_schedule(a, sched), run_schedule(b, sched)
+    assert da[0].tobytes() == db[0].tobytes()
+    assert a.state().tobytes() == b.state().tobytes() and a.diag()["log_post"].tobytes() == b.diag()["log_post"].tobytes()
+    assert a.info()["accepts"].tolist() == b.info()["accepts"].tolist() and a.diag()["uniforms"].tolist() == b.diag()["uniforms"].tolist()
+    a.close(); b.close()
+
+
+def test_translated_hierarchical_closure_at_full_size_runs_the_sweep_kernel_and_equals_the_hand_written_family():
+    """BASELINE.json configs[3] written as a plain closure, 64 lanes per chain, 2 048 chains: the translated closure runs amwg_user_sweep (row plan + sweep
+    prefetch) and gives the same bits as the hand-written family's sweep kernel -- two implementations of the same 64-lane order -- and the decisions of the
+    seeded reference run (cfg4_full: chain ids 0 and 16383)."""
+    import model_spec
+    from gpu_util import run_schedule
+    gold = golden_io.load("cfg4_full")
+    src, arrays, meta = user_host.translated("bench_hier")
+    assert (meta["rows_n_obs"], meta["rows_groups"], meta["rows_sweep"]) == (10000, 32, 1)
+    for rec in gold["chains"]:
+        spec = _golden_spec(gold, rec, src, arrays, meta)
+        bspec = model_spec.spec_from_golden(gold, rec)
+        kw = dict(chains=4, seed=gold["case"]["seed"], chain_offset=rec["chain"], lanes_per_chain=64)
+        a, b = A.Sampler(spec, **kw), A.Sampler(bspec, **kw)
+        assert a.launch_info()["kernel"] == "amwg_user_sweep" and b.launch_info()["kernel"].startswith("amwg_sweep_kernel")
+        da, db = run_schedule(a, gold["case"]["schedule"]), run_schedule(b, gold["case"]["schedule"])
+        assert all(x.tobytes() == y.tobytes() for x, y in zip(da, db))
+        assert a.state().tobytes() == b.state().tobytes() and a.diag()["log_post"].tobytes() == b.diag()["log_post"].tobytes()
+        info = a.info()
+        assert info["accepts"][:, 0].tolist() == rec["accepts"] and info["inbounds"][:, 0].tolist() == rec["inbounds"] and int(a.diag()["uniforms"][0]) == rec["uniforms"]
+        a.close(); b.close()
 
 
 @pytest.mark.parametrize("closure,golden", [("bench_normal", "cfg2_full"), ("bench_bern", "cfg3_full"), ("bench_hier", "cfg4_full"), ("bench_glm", "cfg5_full")])

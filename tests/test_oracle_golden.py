@@ -15,7 +15,8 @@ import model_spec
 import oracle_lib
 
 CASES = ["cfg1_heights", "normal_n1000", "cfg2_full", "normal_opts", "beta_bern_n2000", "cfg3_full", "hier_small",
-         "cfg4_full", "glm_small", "cfg5_full", "normal_hyper", "beta_bern_hyper", "beta_bern_hyper2", "hier_hyper", "glm_hyper"]
+         "cfg4_full", "glm_small", "cfg5_full", "normal_hyper", "beta_bern_hyper", "beta_bern_hyper2", "hier_hyper", "glm_hyper",
+         "cfg4_theta_bounded", "cfg4_theta_int"]      # (configs[3] with a bounded / an integer theta: updates that draw no accept uniform, rounded proposals)
 
 
 def run_schedule(chain, schedule):

@@ -9,6 +9,7 @@ the BASELINE cfg4/cfg5 closures, and models covering the rest of distributions.j
 """
 import ctypes as C
 import math
+import os
 import shutil
 
 import numpy as np
@@ -21,7 +22,7 @@ import user_host
 pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
 
 NAMES = ["readme_normal", "readme_bern", "norm_post_derived", "complex_model", "hier_binomial", "multi_bern", "multivar_poisson",
-         "hier_normal_closure", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js", "live_out_temp", "circular_wrapped_cauchy", "structured_helpers", "records_logistic", "categorical_arms", "pois_const_rate", "binom_const_size", "logit_n10k", "logit_bern_n10k", "wide_regression", "long_dim", "undefined_reads", "readme_normal_swapped"] + ["cfgfuzz_%d" % k for k in range(16)]
+         "hier_normal_closure", "hier_rows_bounded", "hier_rows_int", "pois_glm_closure", "spike_slab", "survival_mix", "discrete_mix", "mixture_arrays", "many_named", "semantics_probe", "logistic_softplus", "modern_js", "live_out_temp", "circular_wrapped_cauchy", "structured_helpers", "records_logistic", "categorical_arms", "pois_const_rate", "binom_const_size", "logit_n10k", "logit_bern_n10k", "wide_regression", "long_dim", "undefined_reads", "readme_normal_swapped"] + ["cfgfuzz_%d" % k for k in range(16)]
 BIG_SHAPES = ("wide_regression", "long_dim")     # 20 named parameters + 19 data arrays; dim [300]: short runs, fewer recorded states
 
 
@@ -263,3 +264,54 @@ def test_compiled_closures_are_cached_on_disk(tmp_path, monkeypatch):
     monkeypatch.setenv("AMWG_CACHE_DIR", "")                                                        # off
     assert A.code_cache_stats()[2] == ""
     assert L.amwg_compile_user(m.source.encode(), 4, 256, b"gfx950", C.byref(n)) == 0
+
+
+def test_row_plan_is_found_proved_and_refused_where_it_must_be():
+    """csrc/amwg_rows.h: a closure that ENDS in `lp += ld.norm(y[i], theta[g[i]], sd)` over all observations gets a row plan (head + the loop's three numbers);
+    the sweep prefetch additionally needs the translator's proof that a lane's head reads theta only as its own entry.  Closures that do not end in such a
+    loop, or whose head returns early / reads theta[const], get no plan / no sweep."""
+    m = user_host.host_model("hier_normal_closure")
+    assert (m.meta["rows_n_obs"], m.meta["rows_groups"], m.meta["rows_sweep"]) == (640, 8, 1)
+    assert "kRowBase = 0, kRowGroups = 8" in m.source and "kRowSweep = true" in m.source and ": UserRows<UserModel>" in m.source
+    head = m.source[m.source.index("static double head("):m.source.index("template <int G, bool DERIVE>")]
+    assert "norm_data_loop_gather" not in head and "ld_norm_fast(S(v_k), S(8), k0" in head and "return v_lp;" in head
+    b = user_host.host_model("hier_rows_bounded")      # theta is the THIRD parameter (state offset 2), the head has a hyper-parameter of its own
+    assert (b.meta["rows_n_obs"], b.meta["rows_groups"], b.meta["rows_sweep"]) == (640, 8, 1) and "kRowBase = 2" in b.source and "return S(10);" in b.source
+    assert user_host.host_model("hier_rows_int").meta["rows_sweep"] == 1
+    for name in ("readme_normal", "pois_glm_closure", "hier_binomial", "logit_n10k"):      # no gathered normal loop at the end
+        q = user_host.host_model(name)
+        assert q.meta["rows_n_obs"] == 0 and "UserRows" not in q.source
+
+
+def test_row_plan_proof_refuses_heads_that_read_other_entries(tmp_path):
+    """the same likelihood with heads the proof must refuse: theta[0] read by a constant index (lane 0's sum then depends on TWO entries when its group is
+    not 0 ... and on entry 0 for every lane's start), an early return, labels that do not start 0, 1, 2, ..."""
+    import json
+    import subprocess
+    js = r"""
+const t = require(process.argv[2]); const synth = require(process.argv[3]);
+global.ld = require(process.argv[4]);
+const d = synth.hier(640, 8, 20260925);
+const P = { theta: { type: 'real', dim: [8], lower: -Infinity, upper: Infinity, init: [0.5,0.5,0.5,0.5,0.5,0.5,0.5,0.5] }, mu: { type: 'real', dim: [1], lower: -Infinity, upper: Infinity, init: 0.5 }, sigma: { type: 'real', dim: [1], lower: 0, upper: Infinity, init: 1 } };
+const lik = 'for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], s.sigma); return lp; }';
+const out = {};
+const run = (k, src, data) => { const r = t.translate(src, P, data || d, {}); out[k] = [r.rows_n_obs, r.rows_groups, r.rows_sweep, /kRowSweep = (true|false)/.exec(r.source) ? RegExp.$1 : null]; };
+run('plain', 'function (s, d) { let lp = 0; for (let k = 0; k < 8; k++) lp += ld.norm(s.theta[k], s.mu, 10); ' + lik);
+run('const_index', 'function (s, d) { let lp = 0; lp += ld.norm(s.theta[0], s.mu, 10); ' + lik);
+run('early_return', 'function (s, d) { let lp = 0; if (s.sigma > 50) return -Infinity; ' + lik);
+run('partial_loop', 'function (s, d) { let lp = 0; for (let k = 0; k < 4; k++) lp += ld.norm(s.theta[k], s.mu, 10); ' + lik);
+run('shifted_labels', 'function (s, d) { let lp = 0; for (let k = 0; k < 8; k++) lp += ld.norm(s.theta[k], s.mu, 10); ' + lik, Object.assign({}, d, { g: d.g.map((v) => (v + 1) % 8) }));
+run('not_last', 'function (s, d) { let lp = 0; for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], s.sigma); lp += ld.norm(s.mu, 0, 100); return lp; }');
+run('sd_local', 'function (s, d) { let lp = 0; const sd = Math.sqrt(s.sigma); for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], sd); return lp; }');
+console.log(JSON.stringify(out));
+"""
+    f = tmp_path / "probe.js"
+    f.write_text(js)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(["node", str(f), os.path.join(root, "bayes.js_amd", "translate.js"), os.path.join(root, "oracle", "synth.js"), os.path.join(root, "bayes.js_amd", "ld.js")],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["plain"] == [640, 8, 1, "true"]
+    assert out["const_index"] == [640, 8, 0, "false"] and out["partial_loop"] == [640, 8, 0, "false"] and out["shifted_labels"] == [640, 8, 0, "false"]      # lane reuse yes, sweep no
+    assert out["early_return"][:3] == [0, 0, 0] and out["not_last"][:3] == [0, 0, 0] and out["sd_local"][:3] == [0, 0, 0]

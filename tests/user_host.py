@@ -72,7 +72,8 @@ def user_spec_part(source, arrays, meta):
     """The `user` entry of an amwg_ctypes.Sampler spec."""
     return {"source": source, "arrays": arrays, "array_types": meta["array_types"], "n_derived": len(meta["derived"]),
             "lds_bytes": meta["lds_bytes"], "lds_bytes_one_lane": meta.get("lds_bytes_one_lane", meta["lds_bytes"]), "parallel": meta["parallel"], "max_threads": meta["max_threads"],
-            "work_per_eval": meta.get("work_per_eval", 0.0), "work_one_lane": meta.get("work_one_lane", 0.0)}
+            "work_per_eval": meta.get("work_per_eval", 0.0), "work_one_lane": meta.get("work_one_lane", 0.0),
+            "rows_n_obs": meta.get("rows_n_obs", 0), "rows_groups": meta.get("rows_groups", 0), "rows_sweep": meta.get("rows_sweep", 0)}
 
 
 def read_arrays(path):
