@@ -237,11 +237,11 @@ double model_work(const amwg_sampler *s, int G) {
 // goes with it is compiled for workgroups of at most 512 threads: a caller who ASKS for more (options.block_threads = 1024) gets the kernel that
 // evaluates everything, as before round 4, instead of a "no launch geometry fits" that names the wrong cause
 bool hier_rows_wanted(const amwg_sampler *s, int G) {
-  return !(s->opt.block_threads > 512) && !s->user && s->model == AMWG_MODEL_HIER_NORMAL && !s->mc.group_local && !s->opt.full_evaluation && G == 64 && ((s->hier_periodic_mask >> 6) & 1u) && s->d.G <= 64 && s->d.n_obs >= 64;
+  return !(s->opt.block_threads > 512) && !s->user && s->model == AMWG_MODEL_HIER_NORMAL && !s->mc.group_local && s->opt.full_evaluation != 1 && G == 64 && ((s->hier_periodic_mask >> 6) & 1u) && s->d.G <= 64 && s->d.n_obs >= 64;
 }
 // a translated closure with a row plan (amwg_rows.h; translate.js): the same layout, LDS bytes by the same formula (UserRows<M> has HierNormalModel's)
 bool user_rows_wanted(const amwg_sampler *s, int G) {
-  return s->user && s->user_rows_n >= 64 && s->user_rows_groups >= 1 && s->user_rows_groups <= 64 && !s->opt.full_evaluation && !(s->opt.block_threads > 512) && G == 64;
+  return s->user && s->user_rows_n >= 64 && s->user_rows_groups >= 1 && s->user_rows_groups <= 64 && s->opt.full_evaluation != 1 && !(s->opt.block_threads > 512) && G == 64;
 }
 size_t user_rows_bytes(const amwg_sampler *s, int bt) { return HierNormalModel::rows_lds_bytes(HierNormalModel::row_pitch(s->user_rows_n), bt / 64, s->user_rows_groups); }
 bool user_rows_fit(const amwg_sampler *s, int bt, size_t max_lds) {
@@ -395,6 +395,7 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
   a.is_adapting = s->d_adapt;
   a.pl = s->pl;
   a.cpb = s->cpb;
+  a.sweep_update_by_update = s->opt.full_evaluation == 2 ? 1 : 0;
   a.mc = s->mc;
   a.d = s->d;
   a.ch = s->ch;
@@ -615,6 +616,8 @@ static int check_options(const amwg_options *options, int max_threads) {
     return fail(AMWG_EINVAL, "block_threads must be a multiple of 64 in 64..1024");
   if (options->block_threads > max_threads)
     return fail(AMWG_EINVAL, "block_threads %d exceeds this model's workgroup limit %d", options->block_threads, max_threads);
+  if (options->full_evaluation < 0 || options->full_evaluation > 2)
+    return fail(AMWG_EINVAL, "full_evaluation must be 0 (default), 1 (every evaluation passes over all the data) or 2 (sweeps decided update by update), got %d", options->full_evaluation);
   return AMWG_OK;
 }
 

@@ -1081,6 +1081,45 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
             double T_cur = rows.T_cur;
             uint64_t acc_mask = 0ull;
             const uint64_t inb_s = uniform_u64(sw_inb);
+            // ALL the sweep's accept tests at once, lane c deciding entry c.  The test of an update is exp(prop_lp - lp_curr) > u with both values butterflies of
+            // the 64 per-lane sums, which differ in the lanes of ITS entry only: as real numbers their difference is D_c = sum over those lanes of
+            // (T_new - T_cur) whatever was accepted before (an entry is updated once per sweep, and nothing else reaches its lanes' sums).  The rounded
+            // butterflies are each within 6 x 2^-53 x M of the real sums (pairwise summation over 6 levels; M = sum over the lanes of max(|T_cur|, |T_new|), a
+            // bound on every vector of sums the sweep can pass through), D_c as computed here within 28 x 2^-53 x M of the real difference: the stepper's
+            // difference lies within eps = 2^-46 M of D_c, its exponential within a factor 1 +- eta (eta = 1.0625 eps + 2^-49: V8's exp is within an ulp of
+            // exp) of exp(D_c).  A uniform outside that sliver decides the test exactly as the update-by-update evaluation would -- the same argument as the
+            // 1 + d <= exp(d) bounds of accept_sweep; if ANY entry's uniform falls inside (some 1e-8 of the sweeps at cfg4) the sweep is walked update by
+            // update as before.  Afterwards the committed sums, the state and ONE butterfly give what the last accepted update would have left: the same bits.
+            bool decided = false;
+            {
+              const int top = d_len;
+              const bool regular = !a.sweep_update_by_update && (top & (top - 1)) == 0 && __ballot(rows.comp != (lane64 & (top - 1))) == 0ull;      // entry c in lanes c, c + top, ... (labels i mod top)
+              if (regular) {
+                double dsum = rows.T_new - rows.T_cur;
+                if (top <= 32) dsum = xor_sum<32>(dsum);
+                if (top <= 16) dsum = xor_sum<16>(dsum);
+                if (top <= 8) dsum = xor_sum<8, true>(dsum);
+                if (top <= 4) dsum = xor_sum<4, true>(dsum);
+                if (top <= 2) dsum = xor_sum<2>(dsum);
+                const double M = butterfly<1, 64>(__builtin_fmax(__builtin_fabs(rows.T_cur), __builtin_fabs(rows.T_new)));
+                const double eta = (M * 0x1p-46 + __builtin_fabs(dsum) * 0x1p-51) * 1.0625 + 0x1p-49;
+                const double ex = exp_v8(dsum);
+                const bool valid = lane64 < top && ((inb_s >> lane64) & 1ull) != 0ull;
+                const bool sure_acc = ex * (1.0 - eta) > sw_u, sure_rej = ex * (1.0 + eta) < sw_u;
+                const bool unsure = valid && !(eta < 0x1p-20 && (sure_acc || sure_rej));      // (a NaN or an infinity anywhere in the sums ends up here)
+                if (__ballot(unsure) == 0ull) {
+                  decided = true;
+                  acc_mask = __ballot(valid && sure_acc);
+                  if (acc_mask != 0ull) {
+                    const bool mine = ((acc_mask >> (rows.comp & 63)) & 1ull) != 0ull;
+                    lp_curr = butterfly<1, 64>(mine ? rows.T_new : rows.T_cur);
+                    if (lane64 < top && ((acc_mask >> lane64) & 1ull) != 0ull) Sme[sb + lane64] = sw_prop;
+                    if constexpr (TracksState<Model>::value) Model::sweep_commit_all(cache, rows, acc_mask, sw_prop, sub, a.d);
+                  }
+                }
+              }
+            }
+            if (!decided)
             for (int t = 0; t < d_len; ++t) {
               const int c = __builtin_amdgcn_readlane(ord, t);
               if (!((inb_s >> c) & 1ull)) continue;

@@ -619,10 +619,10 @@ struct HierNormalModel {
   // -> what the stepper's sweep needs: ok (wave-uniform: everything below holds and the sums are there), this lane's committed sum T_cur and its sum under
   // the proposal T_new, comp = the ONE component this lane's sum depends on (its group's mean; for the lanes that hold a term of theta's prior the
   // same component: checked) or -1.  !ok: nothing was stored that a later evaluation could not use; the stepper goes on update by update.
-  struct SweepRows { bool ok; double T_cur, T_new; int comp; bool new_in_b; };
+  struct SweepRows { bool ok; double T_cur, T_new; int comp; bool new_in_b; double mean_new; };
   template <int U>
   __device__ __forceinline__ static SweepRows prefetch_rows(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub, double prop_own, int pitch) {
-    SweepRows out{false, 0.0, 0.0, -1, false};
+    SweepRows out{false, 0.0, 0.0, -1, false, 0.0};
 #if defined(__HIP_DEVICE_COMPILE__)
     load<64>(k, S, mc, d, smem, sub);
     if (!k.regs) return out;      // (wave-uniform)
@@ -665,8 +665,16 @@ struct HierNormalModel {
     out.T_new = Tn;
     out.comp = k.my_group >= 0 ? k.my_group : (sub < d.G ? sub : -1);
     out.new_in_b = intoB;
+    out.mean_new = mean;
 #endif
     return out;
+  }
+  // the accepted entries of a sweep decided all at once (amwg_kernel.h): what on_set does for one store, for every accepted entry -- bit c of acc_mask: entry c
+  __device__ __forceinline__ static void sweep_commit_all(Cache &k, const SweepRows &r, uint64_t acc_mask, double prop_own, int sub, const DataRef &d) {
+    const bool own = sub < d.G && ((acc_mask >> (sub & 63)) & 1ull) != 0ull;
+    k.th_own = own ? prop_own : k.th_own;
+    const bool grp = k.my_group >= 0 && ((acc_mask >> (k.my_group & 63)) & 1ull) != 0ull;
+    k.th_pass = grp ? r.mean_new : k.th_pass;
   }
   // after the sweep: the entry that now holds the committed state's sum is the recently used one (the lane's component accepted: the proposal's)
   __device__ __forceinline__ static void sweep_done(Cache &k, const SweepRows &r, bool accepted_mine) { k.a_recent = r.new_in_b != accepted_mine; }

@@ -105,6 +105,7 @@ struct StepArgs {
   const CompConst *cc;      // [P]
   const uint8_t *is_adapting;  // [P]
   int32_t init_lp;          // 1 = first launch: compute lp_curr = log_post(init) (the ctor's warm-up call, mcmc.js:961-963)
+  int32_t sweep_update_by_update;   // amwg_options::full_evaluation == 2: the sweep kernel decides a sweep's accept tests one after the other (verification switch)
   int32_t cpb;              // chains per workgroup when the per-chain state of blockDim / lanes chains does not fit LDS (0 = all of them);
                             // the lane groups beyond cpb then replicate the workgroup's last chain (same stream, same stores)
   ParamLayout pl;

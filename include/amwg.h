@@ -127,8 +127,12 @@ typedef struct {
                               (an update of theta_g changes the sums of the lanes that hold group g only; csrc/amwg_models.h lane_sum_rows), and draws the
                               proposals of a whole sweep over theta ahead -- in stream order: nothing an update draws depends on an earlier decision -- so that
                               ONE pass forms every lane's proposed sum (prefetch_rows; amwg_sweep_kernel) -- the same values, bit for bit, as evaluating
-                              everything, like the cached log_post of the current state.  1 = every evaluation makes its full pass
-                              over the data (what bench.py's roofline figure of cfg4 is measured with) */
+                              everything, like the cached log_post of the current state; a translated closure with a row plan (amwg_user_model::rows_*)
+                              does the same.  The accept tests of such a sweep are decided all at once, each from the difference of its entry's lanes' sums
+                              with a rigorous bound on what the butterflies' roundings can add (csrc/amwg_kernel.h: a uniform inside that sliver, ~1e-8 of
+                              the sweeps, sends the sweep down the update-by-update path).  1 = every evaluation makes its full pass over the data.
+                              2 = as 0, but every sweep takes the update-by-update path (a butterfly of the 64 sums per update): a verification switch --
+                              0, 1 and 2 give the same bits */
   int32_t reserved[1];
 } amwg_options;
 

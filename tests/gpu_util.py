@@ -46,6 +46,16 @@ def run_schedule_many(samplers, schedule):
     return segs
 
 
+def run_schedules_concurrently(jobs, max_threads=48):
+    """jobs: [(sampler, schedule)] with DIFFERENT schedules -> [list of draw arrays per job].  One host thread per sampler (ctypes releases the GIL; every
+    sampler has its own stream): a one-lane chain at N = 5e4 is a single wavefront for a minute, and a dozen of those fit the chip side by side."""
+    import concurrent.futures
+    if not jobs:
+        return []
+    with concurrent.futures.ThreadPoolExecutor(min(max_threads, len(jobs))) as ex:
+        return list(ex.map(lambda j: run_schedule(j[0], j[1]), jobs))
+
+
 def assert_chain_equals_oracle(gpu, local, orc, gpu_segs, orc_segs):
     """Bit-exact comparison of local chain `local` of a GPU sampler with an oracle chain run in the same order."""
     for g, o in zip(gpu_segs, orc_segs):

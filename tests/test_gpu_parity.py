@@ -21,14 +21,34 @@ GOLDEN_CASES = ["cfg1_heights", "normal_n1000", "cfg2_full", "normal_opts", "bet
          "cfg4_theta_bounded", "cfg4_theta_int"]      # (configs[3] with a bounded / an integer theta: updates that draw no accept uniform, rounded proposals)
 
 
+@pytest.fixture(scope="module")
+def one_lane_runs(request):
+    """Every selected golden case's chains with ONE lane per chain, all run SIDE BY SIDE (one host thread and one stream per sampler): a one-lane chain of
+    cfg5 is a single wavefront for over a minute, and run one case after the other these tests were a third of the suite's time (round-4 review).
+    -> {case: [(chain record, sampler, draw segments)]}"""
+    from gpu_util import run_schedules_concurrently
+    names = sorted({it.callspec.params["name"] for it in request.session.items
+                    if getattr(it, "originalname", "") == "test_one_lane_per_chain_is_bit_identical_to_reference" and hasattr(it, "callspec")})
+    jobs, meta = [], []
+    for name in names:
+        gold = golden_io.load(name)
+        case = gold["case"]
+        for rec in gold["chains"]:
+            s = A.Sampler(model_spec.spec_from_golden(gold, rec), chains=3, seed=case["seed"], chain_offset=rec["chain"], lanes_per_chain=1)
+            jobs.append((s, case["schedule"]))
+            meta.append((name, rec, s))
+    segs = run_schedules_concurrently(jobs)
+    out = {}
+    for (name, rec, s), sg in zip(meta, segs):
+        out.setdefault(name, []).append((rec, s, sg))
+    yield out
+    for name, rec, s in meta:
+        s.close()
+
+
 @pytest.mark.parametrize("name", GOLDEN_CASES)
-def test_one_lane_per_chain_is_bit_identical_to_reference(name):
-    gold = golden_io.load(name)
-    case = gold["case"]
-    # (the golden's chains run side by side, each on its own stream: a one-chain sampler at N = 5e4 is a single wavefront for half a minute)
-    samplers = [A.Sampler(model_spec.spec_from_golden(gold, rec), chains=3, seed=case["seed"], chain_offset=rec["chain"], lanes_per_chain=1) for rec in gold["chains"]]
-    all_segs = run_schedule_many(samplers, case["schedule"])
-    for rec, s, segs in zip(gold["chains"], samplers, all_segs):
+def test_one_lane_per_chain_is_bit_identical_to_reference(name, one_lane_runs):
+    for rec, s, segs in one_lane_runs[name]:
         for got, want in zip(segs, rec["samples"]):
             assert got.shape[0] == want["kept"]
             w = np.array(want["draws"], dtype=np.float64).reshape(-1, got.shape[1])
@@ -48,7 +68,6 @@ def test_one_lane_per_chain_is_bit_identical_to_reference(name):
         assert int(d["uniforms"][0]) == rec["uniforms"]
         assert d["named_order"][0].tolist() == rec["named_order"]
         assert float(d["log_post"][0]) == rec["log_post"]
-        s.close()
 
 
 @pytest.mark.parametrize("name,lanes", [(n, l) for n in ["cfg1_heights", "normal_n1000", "normal_opts", "beta_bern_n2000", "hier_small", "glm_small"]
@@ -456,12 +475,15 @@ def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains, th
         data = dict(data, x=x)
         spec = model_spec.build_spec("hier_normal", data)
     mk = lambda full: A.Sampler(spec, chains=chains, seed=4, chain_offset=9, lanes_per_chain=64, steps_per_launch=7, full_evaluation=full, **kw)
-    a, b = mk(0), mk(1)
+    # (2: the row layout and the sweep prefetch like 0, but every sweep's accept tests decided update by update instead of all at once from the entries' local
+    # differences with their rounding bound -- the path a sweep takes when a uniform falls inside that bound, some 1e-8 of the sweeps otherwise)
+    a, b, c2 = mk(0), mk(1), mk(2)
     assert a.launch_info()["lds_bytes"] != b.launch_info()["lds_bytes"]      # the row layout (tile + term rows) is in use on one side only
+    assert c2.launch_info()["kernel"] == a.launch_info()["kernel"]
     assert a.launch_info()["kernel"].startswith("amwg_sweep_kernel<HierNormalModel") and b.launch_info()["kernel"].startswith("amwg_step_kernel<HierNormalModel,64")
     rng = np.random.default_rng(3)
     outs = []
-    for s in (a, b):
+    for s in (a, b, c2):
         seq = [s.sample(40, 1)]
         s.burn(33)
         s.set_adapting(False)
@@ -478,12 +500,14 @@ def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains, th
         s.burn(50)
         seq.append(s.sample(30, 2))
         outs.append((seq, s.info(), s.diag(), s.state()))
-    (sa, ia, da, sta), (sb, ib, db, stb) = outs
-    for x, y in zip(sa, sb):
-        assert x.tobytes() == y.tobytes()
-    for k in ia:
-        assert ia[k].tobytes() == ib[k].tobytes(), k
-    assert da["uniforms"].tobytes() == db["uniforms"].tobytes() and da["log_post"].tobytes() == db["log_post"].tobytes()
-    assert sta.tobytes() == stb.tobytes()
+    (sa, ia, da, sta) = outs[0]
+    for (sb, ib, db, stb) in outs[1:]:
+        for x, y in zip(sa, sb):
+            assert x.tobytes() == y.tobytes()
+        for k in ia:
+            assert ia[k].tobytes() == ib[k].tobytes(), k
+        assert da["uniforms"].tobytes() == db["uniforms"].tobytes() and da["log_post"].tobytes() == db["log_post"].tobytes()
+        assert sta.tobytes() == stb.tobytes()
     a.close()
     b.close()
+    c2.close()

@@ -150,13 +150,17 @@ def test_row_plan_of_a_translated_closure_reproduces_the_reference_and_the_full_
     spec = _golden_spec(gold, gold["chains"][0], m.source, m.arrays, m.meta)
     sched = [{"op": "burn", "n": 130}, {"op": "sample", "n": 60, "thin": 2}, {"op": "burn", "n": 7}]
     kw = dict(chains=96, seed=77, chain_offset=5, lanes_per_chain=64)
-    a, b = A.Sampler(spec, **kw), A.Sampler(spec, full_evaluation=1, **kw)
-    assert a.launch_info()["kernel"] == kernel and b.launch_info()["kernel"] == "amwg_user_step"
-    da, db = run_schedule(a, sched), run_schedule(b, sched)
-    assert da[0].tobytes() == db[0].tobytes()
-    assert a.state().tobytes() == b.state().tobytes() and a.diag()["log_post"].tobytes() == b.diag()["log_post"].tobytes()
-    assert a.info()["accepts"].tolist() == b.info()["accepts"].tolist() and a.diag()["uniforms"].tolist() == b.diag()["uniforms"].tolist()
-    a.close(); b.close()
+    # (full_evaluation = 2: the row plan with every sweep's accept tests decided update by update -- the path a sweep takes when a uniform falls inside the
+    # rounding bound of the all-at-once decision, csrc/amwg_kernel.h)
+    a, b, c2 = A.Sampler(spec, **kw), A.Sampler(spec, full_evaluation=1, **kw), A.Sampler(spec, full_evaluation=2, **kw)
+    assert a.launch_info()["kernel"] == kernel and b.launch_info()["kernel"] == "amwg_user_step" and c2.launch_info()["kernel"] == kernel
+    da = run_schedule(a, sched)
+    for o in (b, c2):
+        do = run_schedule(o, sched)
+        assert da[0].tobytes() == do[0].tobytes()
+        assert a.state().tobytes() == o.state().tobytes() and a.diag()["log_post"].tobytes() == o.diag()["log_post"].tobytes()
+        assert a.info()["accepts"].tolist() == o.info()["accepts"].tolist() and a.diag()["uniforms"].tolist() == o.diag()["uniforms"].tolist()
+    a.close(); b.close(); c2.close()
 
 
 def test_translated_hierarchical_closure_at_full_size_runs_the_sweep_kernel_and_equals_the_hand_written_family():
@@ -182,27 +186,41 @@ def test_translated_hierarchical_closure_at_full_size_runs_the_sweep_kernel_and_
         a.close(); b.close()
 
 
-@pytest.mark.parametrize("closure,golden", [("bench_normal", "cfg2_full"), ("bench_bern", "cfg3_full"), ("bench_hier", "cfg4_full"), ("bench_glm", "cfg5_full")])
-def test_translated_closures_reproduce_the_reference_at_full_baseline_sizes(closure, golden):
+FULL_SIZE = [("bench_normal", "cfg2_full"), ("bench_bern", "cfg3_full"), ("bench_hier", "cfg4_full"), ("bench_glm", "cfg5_full")]
+
+
+@pytest.fixture(scope="module")
+def full_size_runs(request):
+    """the selected full-size closures, one lane per chain, every chain of every closure side by side (a one-lane chain at N = 5e4 is one wavefront for
+    most of a minute: run one after the other these were 60 s of the suite) -> {closure: [(chain record, sampler, draw segments)]}"""
+    from gpu_util import run_schedules_concurrently
+    want = {it.callspec.params["closure"] for it in request.session.items
+            if getattr(it, "originalname", "") == "test_translated_closures_reproduce_the_reference_at_full_baseline_sizes" and hasattr(it, "callspec")}
+    jobs, meta = [], []
+    for closure, golden in FULL_SIZE:
+        if closure not in want:
+            continue
+        gold = golden_io.load(golden)
+        src, arrays, m = user_host.translated(closure)
+        # (cfg5: the LAST chain id only -- the built-in family's test walks both ids)
+        for rec in (gold["chains"][-1:] if golden == "cfg5_full" else gold["chains"]):
+            s = A.Sampler(_golden_spec(gold, rec, src, arrays, m), chains=2, seed=gold["case"]["seed"], chain_offset=rec["chain"], lanes_per_chain=1)
+            jobs.append((s, gold["case"]["schedule"]))
+            meta.append((closure, rec, s))
+    segs = run_schedules_concurrently(jobs)
+    out = {}
+    for (closure, rec, s), sg in zip(meta, segs):
+        out.setdefault(closure, []).append((rec, s, sg))
+    yield out
+    for closure, rec, s in meta:
+        s.close()
+
+
+@pytest.mark.parametrize("closure,golden", FULL_SIZE)
+def test_translated_closures_reproduce_the_reference_at_full_baseline_sizes(closure, golden, full_size_runs):
     """BASELINE.json configs[1..4] at their full data sizes, written as plain closures and TRANSLATED: one lane per chain
     reproduces the seeded runs of the unmodified reference (first and last chain id of each config) bit for bit."""
-    from gpu_util import run_schedule_many
-    gold = golden_io.load(golden)
-    src, arrays, meta = user_host.translated(closure)
-    samplers = []
-    # (cfg5: the LAST chain id only -- a one-lane chain at N = 5e4 is a single wavefront for half a minute, and the built-in family's test walks both ids)
-    recs = gold["chains"][-1:] if golden == "cfg5_full" else gold["chains"]
-    for rec in recs:
-        params, init = [], []
-        for p in rec["params_completed"]:
-            ln = int(np.prod(p["dim"]))
-            params.append({"type": p["type"], "len": ln, "top": p["dim"][0], "multidim": 0 if p["dim"] == [1] else 1, "lower": p["lower"], "upper": p["upper"]})
-            init += p["init"]
-        spec = {"user": user_host.user_spec_part(src, arrays, meta), "params": params, "P": len(init), "init": init, "comp_opts": rec["comp_opts"]}
-        samplers.append(A.Sampler(spec, chains=2, seed=gold["case"]["seed"], chain_offset=rec["chain"], lanes_per_chain=1))
-    # (the golden's chains side by side, each sampler on its own stream: one wavefront each for half a minute at N = 5e4)
-    all_segs = run_schedule_many(samplers, gold["case"]["schedule"])
-    for rec, s, segs in zip(recs, samplers, all_segs):
+    for rec, s, segs in full_size_runs[closure]:
         for got, want in zip(segs, rec["samples"]):
             w = np.array(want["draws"], dtype=np.float64)
             assert np.ascontiguousarray(got[: w.shape[0], :, 0]).tobytes() == w.tobytes()
@@ -214,7 +232,6 @@ def test_translated_closures_reproduce_the_reference_at_full_baseline_sizes(clos
         assert s.info()["accepts"][:, 0].tolist() == rec["accepts"]
         assert int(s.diag()["uniforms"][0]) == rec["uniforms"]
         assert float(s.diag()["log_post"][0]) == rec["log_post"]
-        s.close()
 
 
 @pytest.mark.parametrize("name,chains,steps,lanes", [("logit_n10k", 1024, 1_000, 16), ("logit_bern_n10k", 512, 800, 64), ("logistic_softplus", 8192, 10_000, 4)])
