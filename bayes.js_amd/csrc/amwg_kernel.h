@@ -116,6 +116,9 @@ template <class M> struct TracksState<M, void_of<decltype(M::kTracksState)>> { s
 template <class M, class = void> struct LaneReuseOf { static constexpr bool value = false; };
 template <class M> struct LaneReuseOf<M, void_of<decltype(M::kLaneReuse)>> { static constexpr bool value = M::kLaneReuse; };
 
+template <class M, class = void> struct EarlyRejectOf { static constexpr bool value = false; };
+template <class M> struct EarlyRejectOf<M, void_of<decltype(M::kEarlyReject)>> { static constexpr bool value = M::kEarlyReject; };
+
 template <class M, class = void> struct OwnPassOf { static constexpr bool value = false; };
 template <class M> struct OwnPassOf<M, void_of<decltype(M::kOwnPass)>> { static constexpr bool value = M::kOwnPass; };
 
@@ -1186,6 +1189,16 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       // shuffled), and what the stepper needs of it is requested NOW, under the evaluation below
       if (slot + 1 < P_stepped) nx = prefetch(next_comp());
       bool accepted = false;
+      // (sweep kernel, models that can tell: a proposal that moves only the lanes' start values and is REJECTED for certain -- a bound on what the
+      // evaluation could return says so -- is not evaluated: Model::surely_rejected)
+      bool pre_rejected = false;
+      if constexpr (kSweep && EarlyRejectOf<Model>::value) {
+        if (inb && !in_sweep && !a.sweep_update_by_update) pre_rejected = chain_true<G>(Model::surely_rejected(cache, S, a.mc, a.d, sub, comp, cur, u_accept));
+      }
+      if (pre_rejected) {
+        set_state(comp, cur);
+        if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // an evaluated proposal, not accepted
+      } else
       if (inb) {
         const double prop_lp = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);
 #if defined(__HIP_DEVICE_COMPILE__)

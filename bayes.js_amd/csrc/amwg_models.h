@@ -669,6 +669,56 @@ struct HierNormalModel {
 #endif
     return out;
   }
+  // EARLY REJECTION of an update that moves nothing but the lanes' START values -- mu: the prior terms of theta and of mu itself (sweep kernel, amwg_kernel.h).
+  // Such a proposal leaves every lane's mean and sd alone: lane l's new sum is  start'_l + term_0 + term_1 + ...  over the SAME terms as its committed sum
+  // start_l + term_0 + ..., so as real numbers log_post(proposal) - log_post(current) = D = sum over the lanes of (start'_l - start_l), without a pass over the
+  // data.  What the stepper would compute differs from D by the roundings of the two sequential sums of every lane and of the two butterflies:
+  //     a sequential sum s_i = fl(s_(i-1) + t_i) of n terms is within  n 2^-53 max|s_i|  of the real one, and with t_i = c - q_i, q_i >= 0, every partial
+  //     sum lies between combinations of start, i c and the q's:  max|s_i| <= 2|start| + 2 n |c| + |T|   (T: the lane's final sum);
+  //     a butterfly of 64 values is within 6 x 2^-53 x (sum of their magnitudes) of the real sum.
+  // With eps the sum of those bounds and eta = 1.0625 eps + 2^-49 (V8's exp is within an ulp of exp), exp(D) (1 + eta) < u proves that the stepper's own
+  // test exp(prop_lp - lp_curr) > u fails: the update is REJECTED, and a rejected update leaves nothing behind but its counters -- the pass (a third of a
+  // step's arithmetic, more than half of mu's proposals) is not made.  Anything else -- acceptance, a uniform inside the sliver, sums not in the cache,
+  // non-finite values -- takes the ordinary evaluation.  (options.full_evaluation = 2 switches this off together with the all-at-once sweep decisions.)
+  static constexpr bool kEarlyReject = true;
+  // (out of line: two butterflies and an exponential that run once per step; inlined they cost the step loop a spilled register)
+  __device__ inline __attribute__((noinline)) static bool rejection_is_certain(double start_cur, double start_new, double T, double n_l, double c_abs, double u) {
+    const double dl = start_new - start_cur;
+    const double D = butterfly<1, 64>(dl);
+    const double span = 2.0 * (__builtin_fabs(start_cur) + __builtin_fabs(start_new)) + 4.0 * n_l * c_abs + 2.0 * __builtin_fabs(T) + __builtin_fabs(dl);      // both sums' max|s_i|
+    const double leaf = __builtin_fabs(T) + __builtin_fabs(dl);                                                   // a bound on both butterflies' inputs (per lane)
+    const double e_l = ((n_l + 2.0) * span + 12.0 * (leaf + (n_l + 2.0) * span * 0x1p-50)) * 0x1p-53;
+    const double eps = butterfly<1, 64>(e_l) * 1.0625 + __builtin_fabs(D) * 0x1p-51;
+    const double eta = eps * 1.0625 + 0x1p-49;
+    const double ex = exp_v8(D);
+    return eta < 0x1p-20 && ex * (1.0 + eta) < u;      // (NaN anywhere: false)
+  }
+  __device__ __forceinline__ static double start_value(const Cache &k, double mu, double pr, int sub, const DataRef &d) {      // prior_split for the register mirror, mu given
+    double acc = (sub == 0) ? pr : 0.0;
+    if (sub < d.G) acc += norm_const_sd(k.th_own, mu, k.c1, k.den1, k.y1h, k.y1l, k.den1_ok);
+    return acc;
+  }
+  __device__ __forceinline__ static bool surely_rejected(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, int sub, int comp, double old_value, double u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (comp != d.G || !k.loaded || !k.regs || d.pad <= 0) return false;      // (wave-uniform: mu, the register mirror in use, the row layout)
+    norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);               // (what the next evaluation needs in any case)
+    const double sd = k.n.sd;
+    const bool pr_cached = f64_bits(k.pr_mu) == f64_bits(old_value) && f64_bits(k.pr_sigma) == f64_bits(k.sigma);
+    const double pr_old = pr_cached ? k.pr_val : prior_mu_sigma_cold(old_value, k.sigma);
+    const double start_cur = start_value(k, old_value, pr_old, sub, d);
+    const double pr_new = prior(S, mc, d, k);      // (k.mu is the proposal: the stepper has stored it; this fills the cache for the evaluation that follows a "no")
+    const double start_new = start_value(k, k.mu, pr_new, sub, d);
+    const bool hitA = f64_bits(start_cur) == f64_bits(k.a_start) && f64_bits(k.th_pass) == f64_bits(k.a_mean) && f64_bits(sd) == f64_bits(k.a_sd);
+    const bool hitB = f64_bits(start_cur) == f64_bits(k.b_start) && f64_bits(k.th_pass) == f64_bits(k.b_mean) && f64_bits(sd) == f64_bits(k.b_sd);
+    if (__ballot(!(hitA || hitB)) != 0ull) return false;      // the committed sums are not all in the cache
+    const double n_l = (double)((d.n_obs >> 6) + (sub < (d.n_obs & 63) ? 1 : 0));
+    const bool sure = rejection_is_certain(start_cur, start_new, hitA ? k.a_T : k.b_T, n_l, __builtin_fabs(k.n.c), u);
+    if (sure) { k.pr_mu = old_value; k.pr_val = pr_old; }        // the stepper puts the old mu back: so is its prior
+    return sure;
+#else
+    return false;
+#endif
+  }
   // the accepted entries of a sweep decided all at once (amwg_kernel.h): what on_set does for one store, for every accepted entry -- bit c of acc_mask: entry c
   __device__ __forceinline__ static void sweep_commit_all(Cache &k, const SweepRows &r, uint64_t acc_mask, double prop_own, int sub, const DataRef &d) {
     const bool own = sub < d.G && ((acc_mask >> (sub & 63)) & 1ull) != 0ull;

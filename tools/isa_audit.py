@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--families", nargs="*", type=int, default=[0, 1, 2, 3], help="0 Normal, 1 BetaBern, 2 HierNormal, 3 PoisGlm")
     ap.add_argument("--all", action="store_true", help="print every step-kernel instantiation, not only the gated ones")
     ap.add_argument("--gate", nargs="*", default=DEFAULT_GATE)
-    ap.add_argument("--max-lane-moves", type=int, default=600)
+    ap.add_argument("--max-lane-moves", type=int, default=720)      # (round 5: the sweep kernel carries three step loops -- all-at-once decisions, update by update, ordinary -- 683 static)
     ap.add_argument("--json", help="write the table here")
     args = ap.parse_args()
     if args.asm:
