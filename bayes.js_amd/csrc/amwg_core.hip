@@ -396,6 +396,8 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
   a.pl = s->pl;
   a.cpb = s->cpb;
   a.sweep_update_by_update = s->opt.full_evaluation == 2 ? 1 : 0;
+  a.certified = (s->opt.full_evaluation == 0 && !s->opt.exact_division) ? 1 : 0;
+  a.bound_scale = std::ldexp(1.0, s->opt.test_bound_shift);
   a.mc = s->mc;
   a.d = s->d;
   a.ch = s->ch;
@@ -616,6 +618,7 @@ static int check_options(const amwg_options *options, int max_threads) {
     return fail(AMWG_EINVAL, "block_threads must be a multiple of 64 in 64..1024");
   if (options->block_threads > max_threads)
     return fail(AMWG_EINVAL, "block_threads %d exceeds this model's workgroup limit %d", options->block_threads, max_threads);
+  if (options->test_bound_shift < 0 || options->test_bound_shift > 40) return fail(AMWG_EINVAL, "test_bound_shift must be 0..40, got %d", options->test_bound_shift);
   if (options->full_evaluation < 0 || options->full_evaluation > 2)
     return fail(AMWG_EINVAL, "full_evaluation must be 0 (default), 1 (every evaluation passes over all the data) or 2 (sweeps decided update by update), got %d", options->full_evaluation);
   return AMWG_OK;

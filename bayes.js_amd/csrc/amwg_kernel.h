@@ -116,6 +116,10 @@ template <class M> struct TracksState<M, void_of<decltype(M::kTracksState)>> { s
 template <class M, class = void> struct LaneReuseOf { static constexpr bool value = false; };
 template <class M> struct LaneReuseOf<M, void_of<decltype(M::kLaneReuse)>> { static constexpr bool value = M::kLaneReuse; };
 
+// Does the model offer a cheaper value of log_post with a bound on its distance from the expression's (Model::kCertified, log_post_approx)?
+template <class M, class = void> struct CertifiedOf { static constexpr bool value = false; };
+template <class M> struct CertifiedOf<M, void_of<decltype(M::kCertified)>> { static constexpr bool value = M::kCertified; };
+
 template <class M, class = void> struct EarlyRejectOf { static constexpr bool value = false; };
 template <class M> struct EarlyRejectOf<M, void_of<decltype(M::kEarlyReject)>> { static constexpr bool value = M::kEarlyReject; };
 
@@ -625,6 +629,20 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   double lp_curr = a.ch.lp_curr[cl];
   __syncthreads();
   if constexpr (!GL) { if (a.init_lp) lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache); }  // ctor warm-up call, mcmc.js:961-963 (the group-local kernel forms it from its pieces below, in every launch)
+  // CERTIFIED DECISIONS (models with Model::log_post_approx; one lane per chain).  The accept test Math.exp(prop_lp - lp_curr) > u (mcmc.js:527-528) needs the
+  // two values only as far as they decide the comparison.  The model hands back a cheaper value of log_post together with a bound on its distance from what
+  // the reference's expression gives (the Normal family: prior + n c - sum (x - mu)^2 / den, two operations per observation instead of eight); the
+  // stepper keeps such a pair (lpA, epsA) for the current state as well, and
+  //     exp(dA) (1 - eta) > u  proves the expression's own test true,   exp(dA) (1 + eta) < u  proves it false      (dA = difference of the cheap values, eta
+  //     = 1.0625 (their bounds + the subtraction's rounding) + 2^-49: V8's exp is within an ulp of exp) --
+  // the same argument as the 1 + d <= exp(d) bounds below.  A uniform inside the sliver (~1e-7 of the updates at cfg2) gets the expression itself, for
+  // both states if need be; and whatever is stored, returned or compared -- lp_curr at the end of every launch, the ctor's value -- is the expression's.
+  // Every decision, hence every draw, is the one the term-by-term evaluation makes (tests: the reference goldens, bit for bit, and the same sampler with
+  // options.full_evaluation = 1, which evaluates the expression in every update).
+  constexpr bool kCert = CertifiedOf<Model>::value && G == 1 && !GL && !SW;
+  double lpA = lp_curr, epsA = 0.0;      // the cheap value of log_post(current state) and its bound (0: lp_curr itself)
+  bool lp_exact = true;                  // lp_curr is the expression's value of the current state
+  (void)lpA; (void)epsA; (void)lp_exact;
 
   // every store to the state goes through here: the LDS copy (what translated closures, gathers and the final write-back read) and,
   // for models that mirror the state in registers, the mirror
@@ -1105,11 +1123,11 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
                 if (top <= 4) dsum = xor_sum<4, true>(dsum);
                 if (top <= 2) dsum = xor_sum<2>(dsum);
                 const double M = butterfly<1, 64>(__builtin_fmax(__builtin_fabs(rows.T_cur), __builtin_fabs(rows.T_new)));
-                const double eta = (M * 0x1p-46 + __builtin_fabs(dsum) * 0x1p-51) * 1.0625 + 0x1p-49;
+                const double eta = ((M * 0x1p-46 + __builtin_fabs(dsum) * 0x1p-51) * 1.0625 + 0x1p-49) * a.bound_scale;
                 const double ex = exp_v8(dsum);
                 const bool valid = lane64 < top && ((inb_s >> lane64) & 1ull) != 0ull;
                 const bool sure_acc = ex * (1.0 - eta) > sw_u, sure_rej = ex * (1.0 + eta) < sw_u;
-                const bool unsure = valid && !(eta < 0x1p-20 && (sure_acc || sure_rej));      // (a NaN or an infinity anywhere in the sums ends up here)
+                const bool unsure = valid && !(eta < 0x1p-7 && (sure_acc || sure_rej));      // (a NaN or an infinity anywhere in the sums ends up here)
                 if (__ballot(unsure) == 0ull) {
                   decided = true;
                   acc_mask = __ballot(valid && sure_acc);
@@ -1193,13 +1211,32 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       // evaluation could return says so -- is not evaluated: Model::surely_rejected)
       bool pre_rejected = false;
       if constexpr (kSweep && EarlyRejectOf<Model>::value) {
-        if (inb && !in_sweep && !a.sweep_update_by_update) pre_rejected = chain_true<G>(Model::surely_rejected(cache, S, a.mc, a.d, sub, comp, cur, u_accept));
+        if (inb && !in_sweep && !a.sweep_update_by_update) pre_rejected = chain_true<G>(Model::surely_rejected(cache, S, a.mc, a.d, sub, comp, cur, u_accept, a.bound_scale));
       }
-      if (pre_rejected) {
+      bool certified = false;
+      if constexpr (kCert) {
+        if (inb && a.certified) {
+          wave_priority(0);
+          const typename Model::Approx r = Model::template log_post_approx<G>(cache, S, a.mc, a.d, data_lds, sub);
+          wave_priority(kStepperPriority);
+          const double dA = r.value - lpA;
+          const double eta = ((r.eps + epsA + __builtin_fabs(dA) * 0x1p-51) * 1.0625 + 0x1p-49) * a.bound_scale;
+          const double ex = exp_v8(dA);
+          const bool ok = eta < 0x1p-7;      // (false for a NaN; exp(eps) <= 1 + 1.0625 eps holds far beyond)
+          if (ok && ex * (1.0 - eta) > u_accept) { certified = true; accepted = true; lpA = r.value; epsA = r.eps; lp_exact = false; }
+          else if (ok && ex * (1.0 + eta) < u_accept) { certified = true; set_state(comp, cur); }
+          if (certified && counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      if (certified) {
+      } else if (pre_rejected) {
         set_state(comp, cur);
         if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // an evaluated proposal, not accepted
       } else
       if (inb) {
+        if constexpr (kCert) {      // the cheap values could not decide: the expression, for the current state first if a cheap value has been standing in for it
+          if (!lp_exact) { set_state(comp, cur); lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache); set_state(comp, prop); lp_exact = true; }
+        }
         const double prop_lp = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);
 #if defined(__HIP_DEVICE_COMPILE__)
         // the next slot's prefetched values are "used" HERE: the wait for them lands right behind the pass's own LDS reads (which returned
@@ -1225,6 +1262,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         accepted = chain_true<G>(accepted);
         if (accepted) lp_curr = prop_lp;
         else set_state(comp, cur);
+        if constexpr (kCert) { lpA = lp_curr; epsA = 0.0; }
         if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // run totals (not in the reference; parity tests compare them with the oracle's)
       }
       if (chain_true<G>(me.adapting)) adapt_component(comp, accepted, me.cnt, me.batch_size, writer);
@@ -1233,6 +1271,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
 
   // the register mirror of the state (kTracksState models) is a second copy that every store must keep current (set_state -> on_set): once per
   // launch it is compared with the LDS copy, bit for bit -- a store that bypassed set_state would otherwise go unnoticed until a parity test
+  if constexpr (kCert) {      // what leaves the launch is the expression's value of the final state
+    if (!lp_exact) lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);
+  }
   if constexpr (!GL && MirrorCheckOf<Model>::value) {
     if (!Model::template mirror_ok<G>(cache, S, a.d, sub)) (void)atomicOr(cold_args()->ch.error, kErrMirrorOutOfSync);
   }

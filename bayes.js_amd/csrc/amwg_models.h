@@ -141,6 +141,29 @@ struct NormalModel {
     if constexpr (G == 1) return norm_pass_uniform<8>(ps.x, ps.mu, ps.c, ps.den, ps.y, n_obs, acc);   // ps.x = the global array
     else return norm_pass_staged<G, U, false>(ps.x, nullptr, StateView{nullptr}, ps.mu, ps.c, ps.den, ps.y, n_obs, sub, acc);
   }
+  // CERTIFIED DECISIONS (one lane per chain; amwg_kernel.h).  log_post of the state the stepper has just stored, as  prior + n c - S2 / den  with
+  // S2 = sum (x_i - mu)^2 (amwg_pass.h norm_sq_pass_uniform: two operations per observation), together with a bound eps on how far BOTH this value and
+  // the one the reference's expression gives -- prior + term_0 + term_1 + ... in order, term_i = c - RN((x_i - mu)^2 / den) (log_post above) -- can
+  // lie from each other.  With u = 2^-53, Q = S2 / den, mag = |prior| + n |c| + Q:
+  //     term by term:  n correctly rounded quotients (u Q), n subtractions (u (n |c| + Q)), n + 1 additions whose partial sums stay below mag (n u mag)
+  //     here:          eight partial sums of n / 8 non-negative terms each ((n / 8 + 3) u S2), the squares taken exactly inside the fma where the other path
+  //                    rounds them (u S2), 1 / den correctly rounded and one product (2 u Q), n c and two additions (3 u mag)
+  // i.e. |difference| <= (1.125 n + 16) u mag; eps = (2 n + 64) u (|prior| + n |c| + 2 Q) 1.25 leaves a factor of two.  A non-finite value anywhere
+  // makes eps non-finite, which the stepper reads as "evaluate the expression".
+  static constexpr bool kCertified = true;
+  struct Approx { double value, eps; };
+  template <int G>
+  __device__ __forceinline__ static Approx log_post_approx(Cache &kc, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
+    static_assert(G == 1, "the certified pass of the Normal family is the one-lane one");
+    load<G>(kc, S, mc, d, smem, sub);
+    norm_cache_update(kc.n, kc.sigma, mc.neg_half_log_2pi);
+    const double P = prior(S, mc, d, kc);
+    const double S2 = norm_sq_pass_uniform<8>(d.x, kc.mu, d.n_obs);
+    const double n = (double)d.n_obs;
+    const double Q = S2 * kc.n.y.hi, nc = n * kc.n.c;
+    const double mag = __builtin_fabs(P) + __builtin_fabs(nc) + 2.0 * Q;
+    return Approx{(P + nc) - Q, (2.0 * n + 64.0) * 0x1p-53 * mag * 1.25};
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -682,23 +705,23 @@ struct HierNormalModel {
   // non-finite values -- takes the ordinary evaluation.  (options.full_evaluation = 2 switches this off together with the all-at-once sweep decisions.)
   static constexpr bool kEarlyReject = true;
   // (out of line: two butterflies and an exponential that run once per step; inlined they cost the step loop a spilled register)
-  __device__ inline __attribute__((noinline)) static bool rejection_is_certain(double start_cur, double start_new, double T, double n_l, double c_abs, double u) {
+  __device__ inline __attribute__((noinline)) static bool rejection_is_certain(double start_cur, double start_new, double T, double n_l, double c_abs, double u, double bound_scale) {
     const double dl = start_new - start_cur;
     const double D = butterfly<1, 64>(dl);
     const double span = 2.0 * (__builtin_fabs(start_cur) + __builtin_fabs(start_new)) + 4.0 * n_l * c_abs + 2.0 * __builtin_fabs(T) + __builtin_fabs(dl);      // both sums' max|s_i|
     const double leaf = __builtin_fabs(T) + __builtin_fabs(dl);                                                   // a bound on both butterflies' inputs (per lane)
     const double e_l = ((n_l + 2.0) * span + 12.0 * (leaf + (n_l + 2.0) * span * 0x1p-50)) * 0x1p-53;
     const double eps = butterfly<1, 64>(e_l) * 1.0625 + __builtin_fabs(D) * 0x1p-51;
-    const double eta = eps * 1.0625 + 0x1p-49;
+    const double eta = (eps * 1.0625 + 0x1p-49) * bound_scale;
     const double ex = exp_v8(D);
-    return eta < 0x1p-20 && ex * (1.0 + eta) < u;      // (NaN anywhere: false)
+    return eta < 0x1p-7 && ex * (1.0 + eta) < u;      // (NaN anywhere: false)
   }
   __device__ __forceinline__ static double start_value(const Cache &k, double mu, double pr, int sub, const DataRef &d) {      // prior_split for the register mirror, mu given
     double acc = (sub == 0) ? pr : 0.0;
     if (sub < d.G) acc += norm_const_sd(k.th_own, mu, k.c1, k.den1, k.y1h, k.y1l, k.den1_ok);
     return acc;
   }
-  __device__ __forceinline__ static bool surely_rejected(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, int sub, int comp, double old_value, double u) {
+  __device__ __forceinline__ static bool surely_rejected(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, int sub, int comp, double old_value, double u, double bound_scale) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (comp != d.G || !k.loaded || !k.regs || d.pad <= 0) return false;      // (wave-uniform: mu, the register mirror in use, the row layout)
     norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);               // (what the next evaluation needs in any case)
@@ -712,7 +735,7 @@ struct HierNormalModel {
     const bool hitB = f64_bits(start_cur) == f64_bits(k.b_start) && f64_bits(k.th_pass) == f64_bits(k.b_mean) && f64_bits(sd) == f64_bits(k.b_sd);
     if (__ballot(!(hitA || hitB)) != 0ull) return false;      // the committed sums are not all in the cache
     const double n_l = (double)((d.n_obs >> 6) + (sub < (d.n_obs & 63) ? 1 : 0));
-    const bool sure = rejection_is_certain(start_cur, start_new, hitA ? k.a_T : k.b_T, n_l, __builtin_fabs(k.n.c), u);
+    const bool sure = rejection_is_certain(start_cur, start_new, hitA ? k.a_T : k.b_T, n_l, __builtin_fabs(k.n.c), u, bound_scale);
     if (sure) { k.pr_mu = old_value; k.pr_val = pr_old; }        // the stepper puts the old mu back: so is its prior
     return sure;
 #else

@@ -284,4 +284,67 @@ AMWG_HD double norm_pass_uniform(const double *x_global, double mean, double c, 
   return acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The CERTIFIED pass, one lane per chain: S2 = sum_i (x_i - mean)^2 over all observations -- two fp64 operations per observation (sub, fma)
+// instead of the eight of the reference's term c - (x - mean)^2 / den.  As real numbers  sum_i [c - (x_i - mean)^2 / den] = n c - S2 / den:
+// the stepper's accept test needs log_post only to within what decides exp(difference) > u, and both this sum and the term-by-term one are
+// within a computable bound of that real number (amwg_models.h NormalModel::log_post_approx; amwg_kernel.h "certified decisions").  The order
+// of the additions is free here (eight interleaved partial sums: no dependent chain), the observations arrive through the scalar path as in
+// norm_pass_uniform.
+template <int U>
+AMWG_HD double norm_sq_pass_uniform(const double *x_global, double mean, int n_obs) {
+  constexpr int CH = 2 * U;
+  double acc[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) acc[u] = 0.0;
+  const int n_chunks = n_obs / CH;
+  int k = 0;
+  if (n_chunks > 0) {
+    amwg_uniform_f64_ptr px = (amwg_uniform_f64_ptr)(uintptr_t)x_global;
+    NormBlock<CH> sa, sb;                         // the two chunks in flight (wave-uniform: scalar registers)
+    auto load_chunk = [&](int ch, NormBlock<CH> &dst) {
+      ch = ch < n_chunks ? ch : n_chunks - 1;     // prefetches past the end re-read the last chunk (keeps the loop one basic block)
+#pragma unroll
+      for (int u = 0; u < CH; ++u) dst.v[u] = px[ch * CH + u];
+    };
+    auto compute = [&](const NormBlock<CH> &src) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const double t = src.v[u] - mean; acc[u] = __builtin_fma(t, t, acc[u]); }
+      AMWG_STAGE_FENCE();
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const double t = src.v[U + u] - mean; acc[u] = __builtin_fma(t, t, acc[u]); }
+      AMWG_STAGE_FENCE();
+    };
+    load_chunk(0, sb);
+    AMWG_WAIT_LDS_LE(0); AMWG_STAGE_FENCE();
+    load_chunk(1, sa);
+    AMWG_STAGE_FENCE();
+    compute(sb);
+    int ch = 1;
+    for (; ch + 1 < n_chunks; ch += 2) {          // chunk ch is on its way into sa
+      AMWG_WAIT_LDS_LE(0); AMWG_STAGE_FENCE();
+      load_chunk(ch + 1, sb);
+      AMWG_STAGE_FENCE();
+      compute(sa);
+      AMWG_WAIT_LDS_LE(0); AMWG_STAGE_FENCE();
+      load_chunk(ch + 2, sa);
+      AMWG_STAGE_FENCE();
+      compute(sb);
+    }
+    if (ch < n_chunks) {                          // one chunk left, on its way into sa
+      AMWG_WAIT_LDS_LE(0); AMWG_STAGE_FENCE();
+      compute(sa);
+    }
+    k = n_chunks * CH;
+  }
+  for (; k < n_obs; ++k) {                        // ragged tail
+    const double t = x_global[k] - mean;
+    acc[0] = __builtin_fma(t, t, acc[0]);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) s += acc[u];
+  return s;
+}
+
 }  // namespace amwg

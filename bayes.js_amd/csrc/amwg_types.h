@@ -105,6 +105,9 @@ struct StepArgs {
   const CompConst *cc;      // [P]
   const uint8_t *is_adapting;  // [P]
   int32_t init_lp;          // 1 = first launch: compute lp_curr = log_post(init) (the ctor's warm-up call, mcmc.js:961-963)
+  int32_t certified;                // 1 = accept tests may be decided from a model's cheaper value of log_post with its bound (amwg_kernel.h "certified decisions"):
+                                    // amwg_options::full_evaluation == 0 and not exact_division
+  double bound_scale;               // 2^amwg_options::test_bound_shift (1 in production): multiplies the bounds of the certified decisions
   int32_t sweep_update_by_update;   // amwg_options::full_evaluation == 2: the sweep kernel decides a sweep's accept tests one after the other (verification switch)
   int32_t cpb;              // chains per workgroup when the per-chain state of blockDim / lanes chains does not fit LDS (0 = all of them);
                             // the lane groups beyond cpb then replicate the workgroup's last chain (same stream, same stores)

@@ -108,6 +108,11 @@ OTHER_WORKLOADS = {
 
 
 # what the fp64 lane-operations per observation of each family are (the roofline's unit of arithmetic)
+CERTIFIED_OPS_PER_OBS = 2      # the certified pass of the Normal family with one lane per chain: sub, fma (sum of (x - mu)^2; csrc/amwg_pass.h norm_sq_pass_uniform)
+CERTIFIED_NOTE = ("2 = sub, fma: by default the accept test of the Normal family (one lane per chain) is decided from prior + n c - sum (x - mu)^2 / den with a rigorous bound on its "
+                  "distance from the reference's term-by-term expression (csrc/amwg_kernel.h 'certified decisions'); every update still passes over all the observations; the "
+                  "expression itself (8 operations per observation) is evaluated when a uniform falls inside the bound (~1e-7 of the updates) and once per launch and chain. "
+                  "Every draw is bit-identical to the reference's (parity block).  `full_evaluation` beside this: the kernel that evaluates the expression in every update")
 OPS_NOTE = {
     "normal": "8 = sub, mul, 4-operation correctly rounded quotient (amwg_div.h: mul, fma, fma, fma), sub, add; IEEE '/' would be 17",
     "hier_normal": "8 = sub, mul, 4-operation correctly rounded quotient, sub, add (the gather of theta[g_i] is an LDS read, not arithmetic)",
@@ -621,6 +626,8 @@ def compact_line(out, detail_path=None):
     for k in ("inproc", "note", "kernel_only_value", "chains_equiv"):
         if out.get(k) is not None:
             line[k] = _num(out[k])
+    if isinstance(out.get("full_evaluation"), dict):      # the kernel that evaluates the reference's expression in every update, beside the default
+        line["full_evaluation"] = _pick(out["full_evaluation"], "value", "frac")
     r = out.get("roofline")
     if r:
         line["roofline"] = _pick(r, "bound", "achieved", "peak", "unit", "frac", "frac_of_measured_peak", "kernel", "launch_ms", "traffic", "traffic_ratio")
@@ -936,6 +943,20 @@ def main():
                 roof_launch_s, roof_updates, kernel = full_launch_s, full_updates, "%s with options.full_evaluation = 1" % full_eval["kernel"]
                 roof_note = "roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s" % full_eval["value"]
             t.close()
+        certified = spec["model"] == "normal" and li["lanes_per_chain"] == 1 and not args.full_evaluation
+        ops_note = OPS_NOTE[spec["model"]]
+        if certified:
+            # `value` and `frac` describe the same kernel: the certified pass issues 2 fp64 operations per observation; the expression kernel is measured beside it
+            if not args.single_region:
+                t = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=dev_index, lanes_per_chain=1, block_threads=args.block, steps_per_launch=args.steps_per_launch, full_evaluation=1)
+                t.burn(2 * args.steps_per_launch)
+                t.burn(2 * args.steps_per_launch)
+                fl = t.launch_info()
+                fv = chains * 2 * args.steps_per_launch * P / (fl["kernel_ms"] * 1e-3)
+                full_eval = {"value": fv, "frac": fv * n_obs * ops_per_obs / FP64_VALU_PEAK, "kernel": fl["kernel"], "lane_ops_per_obs": ops_per_obs,
+                             "note": "options.full_evaluation = 1: the reference's expression, term by term, in every update (rounds 1-4's kernel)"}
+                t.close()
+            ops_per_obs, ops_note = CERTIFIED_OPS_PER_OBS, CERTIFIED_NOTE
         traffic, traffic_src, traffic_alg, traffic_why_not = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"], args.group_local, kernel_id_of(version), kernel)
         lane_ops = roof_updates * n_obs * ops_per_obs / roof_launch_s
         if str(kernel).startswith("amwg_sweep_kernel"):
@@ -966,8 +987,8 @@ def main():
                          "peak_note": "78.6 TFLOP/s fp64 vector (MI355X_MICROARCH.md) = 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 3.93e13 lane-FMA/s",
                          "measured_peak": measured_peak, "frac_of_measured_peak": lane_ops / measured_peak,
                          "measured_peak_note": "amwg_fp64_peak: independent v_fma_f64 chains, no memory traffic, same process",
-                         "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[spec["model"]],
-                         "kernel": kernel, "launch_ms": roof_launch_s * 1e3, "updates_per_launch": roof_updates,
+                         "lane_ops_per_obs": ops_per_obs, "lane_ops_note": ops_note,
+                         "kernel": kernel + (" (certified decisions)" if certified else ""), "launch_ms": roof_launch_s * 1e3, "updates_per_launch": roof_updates,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_refused": traffic_why_not if traffic is None else None,
                          "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 --pmc passes",
                          "algorithmic_bytes_per_launch": updates_per_launch * b_alg, "algorithmic_bytes_per_update": b_alg,
@@ -982,7 +1003,9 @@ def main():
             "posterior": {"mean": mean.tolist()[:8], "sd": sd.tolist()[:8], "data_mean": float(np.mean(x)), "data_sd": float(np.std(x, ddof=1)),
                           "note": "moments over the recorded draws of the last region on ALL ranks (all-reduce of per-rank sums for N > 1; after %d warm-up + %d timed steps)" % (W, K * (len(regions) - 1))},
         }
-        out["roofline"].update(roofline_units(spec["model"], lane_ops, ops_per_obs))
+        out["roofline"].update(roofline_units(spec["model"], lane_ops, ops_per_obs) if not certified else
+                               {"frac_issue": lane_ops / FP64_VALU_PEAK, "frac_survey_flops": (roof_updates / roof_launch_s) * n_obs * 3 / FP64_FLOPS_PEAK,
+                                "survey_flops_note": "the certified pass is a sub and an fma per observation = 3 flops (an FMA = 2) against 78.6 TFLOP/s"})
         import build_id
         out["library"] = {"version": version, "built_from_this_tree": ("build " + build_id.build_id()) in version and ("kernels " + build_id.kernel_id()) in version,
                           "note": "amwg_version(): a hash over every source of libamwg.so and one over the device sources + compiler flags (tools/build_id.py); "

@@ -133,7 +133,9 @@ typedef struct {
                               the sweeps, sends the sweep down the update-by-update path).  1 = every evaluation makes its full pass over the data.
                               2 = as 0, but every sweep takes the update-by-update path (a butterfly of the 64 sums per update): a verification switch --
                               0, 1 and 2 give the same bits */
-  int32_t reserved[1];
+  int32_t test_bound_shift; /* TEST HOOK, 0 in production: the rounding bounds of the certified decisions (csrc/amwg_kernel.h: accept tests decided from a cheaper value
+                               of log_post, from the local differences of a sweep, early rejections) are multiplied by 2^shift, 0..40.  A wider bound sends more
+                               updates down the path that evaluates the reference's expression; the results must not change by a bit (tests run 0 against 14 and 40) */
 } amwg_options;
 
 typedef struct amwg_sampler amwg_sampler;

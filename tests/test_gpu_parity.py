@@ -474,16 +474,18 @@ def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains, th
         x[5] = 1e-250
         data = dict(data, x=x)
         spec = model_spec.build_spec("hier_normal", data)
-    mk = lambda full: A.Sampler(spec, chains=chains, seed=4, chain_offset=9, lanes_per_chain=64, steps_per_launch=7, full_evaluation=full, **kw)
+    mk = lambda full, shift=0: A.Sampler(spec, chains=chains, seed=4, chain_offset=9, lanes_per_chain=64, steps_per_launch=7, full_evaluation=full, test_bound_shift=shift, **kw)
     # (2: the row layout and the sweep prefetch like 0, but every sweep's accept tests decided update by update instead of all at once from the entries' local
     # differences with their rounding bound -- the path a sweep takes when a uniform falls inside that bound, some 1e-8 of the sweeps otherwise)
-    a, b, c2 = mk(0), mk(1), mk(2)
+    # (test_bound_shift = 12: the rounding bounds of the all-at-once sweep decisions and of mu's early rejection made 4096 times wider -- a good share of the
+    # sweeps then meets a uniform inside the bound and is walked update by update, mixed with sweeps that are not)
+    a, b, c2, c3 = mk(0), mk(1), mk(2), mk(0, 12)
     assert a.launch_info()["lds_bytes"] != b.launch_info()["lds_bytes"]      # the row layout (tile + term rows) is in use on one side only
-    assert c2.launch_info()["kernel"] == a.launch_info()["kernel"]
+    assert c2.launch_info()["kernel"] == a.launch_info()["kernel"] == c3.launch_info()["kernel"]
     assert a.launch_info()["kernel"].startswith("amwg_sweep_kernel<HierNormalModel") and b.launch_info()["kernel"].startswith("amwg_step_kernel<HierNormalModel,64")
     rng = np.random.default_rng(3)
     outs = []
-    for s in (a, b, c2):
+    for s in (a, b, c2, c3):
         seq = [s.sample(40, 1)]
         s.burn(33)
         s.set_adapting(False)
@@ -511,3 +513,45 @@ def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains, th
     a.close()
     b.close()
     c2.close()
+    c3.close()
+
+
+@pytest.mark.parametrize("n_obs,chains,steps,hyper", [(1000, 4096, 400, None), (777, 1024, 300, None), (17, 512, 300, None), (1000, 16384, 600, [0.0, 100.0, 0.0, 1.0])])
+def test_certified_decisions_equal_the_expression_in_every_update(n_obs, chains, steps, hyper):
+    """Normal family, one lane per chain (the reference's order): by default the accept test is decided from  prior + n c - sum (x - mu)^2 / den  and a bound on
+    its distance from the reference's term-by-term expression (csrc/amwg_kernel.h "certified decisions"); options.full_evaluation = 1 evaluates the expression
+    in every update.  The two must agree in EVERY bit of every chain -- draws, counters, proposal scales, uniforms, and the cached log_post, which is the
+    expression's on both sides -- over short launches (a launch ends by evaluating the expression), a stop / start of the adaptation and a state overwritten
+    from the host.  test_bound_shift widens the bound 2^14- and 2^40-fold: updates then fall back to the expression often / always.  The last case (data
+    45 sd wide against a sigma pinned below 1: |log_post| ~ 1e6) has a bound so wide by itself that tens of its 2e7 decisions fall inside it."""
+    data = model_spec.make_data("normal", n_obs, 31)
+    if hyper is not None:
+        data = dict(data, x=3.0 + 22.5 * (np.array(data["x"], dtype=np.float64) - 3.0))
+    spec = model_spec.build_spec("normal", data, hyper=hyper)
+    if hyper is not None:
+        spec["params"][1] = dict(spec["params"][1], upper=1.0)
+    mk = lambda full, shift=0: A.Sampler(spec, chains=chains, seed=8, chain_offset=3, lanes_per_chain=1, steps_per_launch=13, full_evaluation=full, test_bound_shift=shift)
+    variants = [mk(0), mk(1), mk(0, 14), mk(0, 40)] if hyper is None else [mk(0), mk(1)]
+    outs = []
+    for s in variants:
+        assert s.launch_info()["lanes_per_chain"] == 1
+        seq = [s.sample(steps // 4, 3)]
+        s.burn(steps // 2)
+        s.set_adapting(False)
+        seq.append(s.sample(steps // 8, 1))
+        s.set_adapting(True)
+        st = s.state()
+        st[0, ::3] += 0.25
+        s.set_state(st)
+        s.burn(steps // 8)
+        seq.append(s.sample(20, 2))
+        outs.append((seq, s.info(), s.diag(), s.state()))
+        s.close()
+    (sa, ia, da, sta) = outs[0]
+    for (sb, ib, db, stb) in outs[1:]:
+        for x, y in zip(sa, sb):
+            assert x.tobytes() == y.tobytes()
+        for k in ia:
+            assert ia[k].tobytes() == ib[k].tobytes(), k
+        assert da["uniforms"].tobytes() == db["uniforms"].tobytes() and da["log_post"].tobytes() == db["log_post"].tobytes()
+        assert sta.tobytes() == stb.tobytes()

@@ -152,15 +152,15 @@ def test_row_plan_of_a_translated_closure_reproduces_the_reference_and_the_full_
     kw = dict(chains=96, seed=77, chain_offset=5, lanes_per_chain=64)
     # (full_evaluation = 2: the row plan with every sweep's accept tests decided update by update -- the path a sweep takes when a uniform falls inside the
     # rounding bound of the all-at-once decision, csrc/amwg_kernel.h)
-    a, b, c2 = A.Sampler(spec, **kw), A.Sampler(spec, full_evaluation=1, **kw), A.Sampler(spec, full_evaluation=2, **kw)
+    a, b, c2, c3 = A.Sampler(spec, **kw), A.Sampler(spec, full_evaluation=1, **kw), A.Sampler(spec, full_evaluation=2, **kw), A.Sampler(spec, test_bound_shift=12, **kw)
     assert a.launch_info()["kernel"] == kernel and b.launch_info()["kernel"] == "amwg_user_step" and c2.launch_info()["kernel"] == kernel
     da = run_schedule(a, sched)
-    for o in (b, c2):
+    for o in (b, c2, c3):
         do = run_schedule(o, sched)
         assert da[0].tobytes() == do[0].tobytes()
         assert a.state().tobytes() == o.state().tobytes() and a.diag()["log_post"].tobytes() == o.diag()["log_post"].tobytes()
         assert a.info()["accepts"].tolist() == o.info()["accepts"].tolist() and a.diag()["uniforms"].tolist() == o.diag()["uniforms"].tolist()
-    a.close(); b.close(); c2.close()
+    a.close(); b.close(); c2.close(); c3.close()
 
 
 def test_translated_hierarchical_closure_at_full_size_runs_the_sweep_kernel_and_equals_the_hand_written_family():
