@@ -208,7 +208,8 @@ bool user_rows_fit(const amwg_sampler *s, int bt, size_t max_lds);
 double model_work(const amwg_sampler *s, int G) {
   const double N = (double)s->d.n_obs;
   switch (s->model) {
-    case AMWG_MODEL_NORMAL: return 9.0 * N;
+    // (one lane per chain: accept tests are decided from the certified pass -- two operations per observation -- unless the caller asked for the expression in every update)
+    case AMWG_MODEL_NORMAL: return (G == 1 && s->opt.full_evaluation == 0 && !s->opt.exact_division) ? 2.6 * N : 9.0 * N;
     case AMWG_MODEL_BETA_BERN:   // one lane: exact fast-forward over ~log2(N) binades (or the scalar jump-table pass, one add per observation)
       return G == 1 ? (s->mc.exact_division ? 1.8 * N : 400.0 * (1.0 + std::log2(N + 2.0))) : 6.0 * N;
     case AMWG_MODEL_HIER_NORMAL: {

@@ -1215,17 +1215,21 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       }
       bool certified = false;
       if constexpr (kCert) {
-        if (inb && a.certified) {
+        // (the model's pass is the WAVEFRONT's: with a lane per chain the 64 chains of a wave are evaluated together, every lane taking part whether its own
+        // proposal needs a value or not -- control flow is uniform here: the slot loop is, and the lanes have come back together from their rnorm loops)
+        if (a.certified && __ballot(inb) != 0ull) {
           wave_priority(0);
-          const typename Model::Approx r = Model::template log_post_approx<G>(cache, S, a.mc, a.d, data_lds, sub);
+          const typename Model::Approx r = Model::template log_post_approx<G, BT>(cache, S, a.mc, a.d, data_lds, sub);
           wave_priority(kStepperPriority);
-          const double dA = r.value - lpA;
-          const double eta = ((r.eps + epsA + __builtin_fabs(dA) * 0x1p-51) * 1.0625 + 0x1p-49) * a.bound_scale;
-          const double ex = exp_v8(dA);
-          const bool ok = eta < 0x1p-7;      // (false for a NaN; exp(eps) <= 1 + 1.0625 eps holds far beyond)
-          if (ok && ex * (1.0 - eta) > u_accept) { certified = true; accepted = true; lpA = r.value; epsA = r.eps; lp_exact = false; }
-          else if (ok && ex * (1.0 + eta) < u_accept) { certified = true; set_state(comp, cur); }
-          if (certified && counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (inb) {
+            const double dA = r.value - lpA;
+            const double eta = ((r.eps + epsA + __builtin_fabs(dA) * 0x1p-51) * 1.0625 + 0x1p-49) * a.bound_scale;
+            const double ex = exp_v8(dA);
+            const bool ok = eta < 0x1p-7;      // (false for a NaN; exp(eps) <= 1 + 1.0625 eps holds far beyond)
+            if (ok && ex * (1.0 - eta) > u_accept) { certified = true; accepted = true; lpA = r.value; epsA = r.eps; lp_exact = false; }
+            else if (ok && ex * (1.0 + eta) < u_accept) { certified = true; set_state(comp, cur); }
+            if (certified && counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
       }
       if (certified) {

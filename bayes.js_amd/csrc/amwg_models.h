@@ -65,6 +65,96 @@ __device__ __forceinline__ void norm_cache_update(NormCache &k, double sd, doubl
 
 
 // ---------------------------------------------------------------------------------------------
+// The certified pass of the Normal family, one lane per chain, for the 64 chains of a wavefront AT ONCE:  S2_c = sum_i (x_i - mu_c)^2.
+// Lane l enters with its chain's mean and leaves with its chain's sum.  With a lane per chain every chain needs every observation: read one at a time
+// and broadcast (scalar loads, norm_sq_pass_uniform) the pass waits for its loads -- two operations per observation are not enough work to cover a scalar
+// cache round trip with one wavefront per SIMD (measured: 0.37 of the issue rate).  Here the ROLES are swapped for the length of the pass: a lane holds
+// OBSERVATIONS (lane l: x_l, x_(l+64), ...: coalesced reads of the LDS tile, each value used for all 64 chains), the means are broadcast (v_readlane, eight
+// chains' worth at a time), every lane keeps 64 partial sums -- one per chain -- and a transposing butterfly (v_permlane32_swap / v_permlane16_swap /
+// DPP: 63 exchange-and-add steps) leaves chain c's total in lane c.  Same count of fp64 operations, no load on the critical path.  The order of the
+// additions is whatever this schedule gives: the value is used with its rounding bound only (NormalModel::log_post_approx).
+template <int B>
+__device__ __forceinline__ double norm_sq_pass_wave(const double *x, double mu, int n_obs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int lane = (int)(threadIdx.x & 63u);
+  double a[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) a[c] = 0.0;
+  const int mu_lo = (int)(uint32_t)f64_bits(mu), mu_hi = (int)(uint32_t)(f64_bits(mu) >> 32);
+  auto mean_of = [&](int c) { return bits_f64(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mu_hi, c) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mu_lo, c)); };
+  int base = 0;
+  for (; base + 64 * B <= n_obs; base += 64 * B) {
+    double xv[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) xv[b] = x[base + b * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < 64; g += 8) {      // eight chains' means in scalar registers, then this lane's B observations against each: the eight running sums interleave
+      double m[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = mean_of(g + j);
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const double t = xv[b] - m[j]; a[g + j] = __builtin_fma(t, t, a[g + j]); }
+      }
+    }
+  }
+  for (; base < n_obs; base += 64) {       // the rest, 64 observations a round; the last round masked
+    const int i = base + lane;
+    const bool has = i < n_obs;
+    const double xv = x[has ? i : base];
+#pragma unroll
+    for (int g = 0; g < 64; g += 8) {
+      double m[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = mean_of(g + j);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const double t = has ? xv - m[j] : 0.0; a[g + j] = __builtin_fma(t, t, a[g + j]); }
+    }
+  }
+  // transposing butterfly: after the step with offset o a lane holds the chains that agree with it in that bit, a[j] <- kept + received
+  auto swap_add = [&](double A, double Bv, int off) {      // A: what the lanes with the bit CLEAR keep, Bv: what the lanes with the bit SET keep
+    const uint32_t al = (uint32_t)f64_bits(A), ah = (uint32_t)(f64_bits(A) >> 32), bl = (uint32_t)f64_bits(Bv), bh = (uint32_t)(f64_bits(Bv) >> 32);
+    if (off == 32) {
+      const auto l = __builtin_amdgcn_permlane32_swap(al, bl, false, false), h = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+      return bits_f64(((uint64_t)h[0] << 32) | (uint64_t)l[0]) + bits_f64(((uint64_t)h[1] << 32) | (uint64_t)l[1]);
+    } else {
+      const auto l = __builtin_amdgcn_permlane16_swap(al, bl, false, false), h = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+      return bits_f64(((uint64_t)h[0] << 32) | (uint64_t)l[0]) + bits_f64(((uint64_t)h[1] << 32) | (uint64_t)l[1]);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < 32; ++j) a[j] = swap_add(a[j], a[j + 32], 32);      // the upper 32 lanes' a[j] <-> the lower 32 lanes' a[j + 32]: every lane then adds its two registers
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = swap_add(a[j], a[j + 16], 16);      // likewise between the odd and the even rows of 16 lanes
+  {
+    const bool up = (lane & 8) != 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const double send = up ? a[j] : a[j + 8], keep = up ? a[j + 8] : a[j]; a[j] = keep + xor_partner<8, true>(send); }
+  }
+  {
+    const bool up = (lane & 4) != 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const double send = up ? a[j] : a[j + 4], keep = up ? a[j + 4] : a[j]; a[j] = keep + xor_partner<4, true>(send); }
+  }
+  {
+    const bool up = (lane & 2) != 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const double send = up ? a[j] : a[j + 2], keep = up ? a[j + 2] : a[j]; a[j] = keep + xor_partner<2>(send); }
+  }
+  {
+    const bool up = (lane & 1) != 0;
+    const double send = up ? a[0] : a[1], keep = up ? a[1] : a[0];
+    a[0] = keep + xor_partner<1>(send);
+  }
+  return a[0];
+#else
+  (void)x; (void)mu; (void)n_obs;
+  return 0.0;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // x_i ~ norm(mu, sigma); mu ~ norm(m0,s0); sigma ~ unif(a,b)              README.md:22-36
 struct NormalModel {
   static constexpr bool kSplitPrior = false;
@@ -74,10 +164,12 @@ struct NormalModel {
   static constexpr int kMaxThreads = 1024;   // workgroup size cap (instantiated per size class 256 / 512 / 1024, amwg_kernels.hip)
   static constexpr int kUnroll = 8;   // independent terms in flight per lane (ILP across the division chains)
   struct Pass { double mu, c, den; Reciprocal y; bool fast; const double *x; };
-  // one lane per chain reads the observations through the scalar cache (norm_pass_uniform): no LDS tile
-  __host__ __device__ static size_t lds_bytes(int n_obs, int, int lanes) { return lanes == 1 ? 0 : (size_t)n_obs * 8; }
+  // one lane per chain: the EXPRESSION's pass reads the observations through the scalar cache (norm_pass_uniform); the certified pass (norm_sq_pass_wave) reads
+  // a tile in LDS when the data fits beside the stepper state of a full workgroup (else the array in global memory)
+  static constexpr size_t kOneLaneTileLimit = 96 * 1024;
+  __host__ __device__ static size_t lds_bytes(int n_obs, int, int lanes) { return lanes == 1 ? ((size_t)n_obs * 8 <= kOneLaneTileLimit ? (size_t)n_obs * 8 : 0) : (size_t)n_obs * 8; }
   __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int lanes) {
-    if (lanes == 1) return;
+    if (lanes == 1 && lds_bytes(d.n_obs, 0, 1) == 0) return;
     double *dst = reinterpret_cast<double *>(smem);
     for (int i = tid; i < d.n_obs; i += nt) dst[i] = d.x[i];
   }
@@ -152,13 +244,17 @@ struct NormalModel {
   // makes eps non-finite, which the stepper reads as "evaluate the expression".
   static constexpr bool kCertified = true;
   struct Approx { double value, eps; };
-  template <int G>
+  template <int G, int BT>
   __device__ __forceinline__ static Approx log_post_approx(Cache &kc, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
     static_assert(G == 1, "the certified pass of the Normal family is the one-lane one");
     load<G>(kc, S, mc, d, smem, sub);
     norm_cache_update(kc.n, kc.sigma, mc.neg_half_log_2pi);
     const double P = prior(S, mc, d, kc);
-    const double S2 = norm_sq_pass_uniform<8>(d.x, kc.mu, d.n_obs);
+    // (every lane of the wavefront takes part: the caller has made sure of that.  The wavefront's pass keeps 64 partial sums per lane: workgroups of up to 256
+    // threads, whose lanes have 512 registers; the larger classes read the observations one at a time through the scalar path)
+    double S2;
+    if constexpr (BT <= 256) S2 = norm_sq_pass_wave<8>(lds_bytes(d.n_obs, 0, 1) ? reinterpret_cast<const double *>(smem) : d.x, kc.mu, d.n_obs);
+    else S2 = norm_sq_pass_uniform<8>(d.x, kc.mu, d.n_obs);
     const double n = (double)d.n_obs;
     const double Q = S2 * kc.n.y.hi, nc = n * kc.n.c;
     const double mag = __builtin_fabs(P) + __builtin_fabs(nc) + 2.0 * Q;
