@@ -224,7 +224,7 @@ double model_work(const amwg_sampler *s, int G) {
       if (hier_rows_wanted(s, G) && hier_rows_fit(s, 256, (size_t)160 * 1024)) w *= (2.0 + 0.35 * s->d.G) / (2.0 + s->d.G);
       return w;
     }
-    case AMWG_MODEL_POIS_GLM: return 90.0 * N;
+    case AMWG_MODEL_POIS_GLM: return (G == 16 && s->opt.full_evaluation == 0 && !s->opt.exact_division) ? 36.0 * N : 90.0 * N;      // (16 lanes per chain: the certified pass, four chains sharing every row they read)
   }
   if (G == 1 && s->user_work_one_lane > 0) return s->user_work_one_lane;   // translated closure with a two-valued sum: fast-forwarded
   double w = s->user_work > 0 ? s->user_work : 1e6;   // translated closure: the translator's estimate
@@ -1163,6 +1163,10 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
       HIPB(hipMemcpy(dlf, lf.data(), (size_t)N * 8, hipMemcpyHostToDevice));
     }
     d.x = dX; d.y = dy; d.lfact = dlf;
+    // what the bounds of the certified pass are made of (PoisGlmModel::log_post_approx)
+    for (int k = 0; k < 7; ++k) { double mx = 0; for (int i = 0; i < N; ++i) { const double v = std::fabs(m->x[(size_t)i * 7 + k]); mx = (v > mx || v != v) ? v : mx; } mc.glm_xmax[k] = mx; }
+    mc.glm_sum_y = 0; mc.glm_sum_lf = 0;
+    for (int i = 0; i < N; ++i) { mc.glm_sum_y += std::fabs(m->y[i]); mc.glm_sum_lf += std::fabs(lf[i]); }
   }
   mc.data_mid_range = mid ? 1 : 0;
 

@@ -118,7 +118,9 @@ template <class M> struct LaneReuseOf<M, void_of<decltype(M::kLaneReuse)>> { sta
 
 // Does the model offer a cheaper value of log_post with a bound on its distance from the expression's (Model::kCertified, log_post_approx)?
 template <class M, class = void> struct CertifiedOf { static constexpr bool value = false; };
-template <class M> struct CertifiedOf<M, void_of<decltype(M::kCertified)>> { static constexpr bool value = M::kCertified; };
+template <class M> struct CertifiedOf<M, void_of<decltype(M::kCertified)>> { static constexpr bool value = M::kCertified; static constexpr int lanes = M::kCertifiedLanes; };
+template <class M, int G, class = void> struct CertifiedAt { static constexpr bool value = false; };
+template <class M, int G> struct CertifiedAt<M, G, void_of<decltype(M::kCertified)>> { static constexpr bool value = M::kCertified && M::kCertifiedLanes == G; };
 
 template <class M, class = void> struct EarlyRejectOf { static constexpr bool value = false; };
 template <class M> struct EarlyRejectOf<M, void_of<decltype(M::kEarlyReject)>> { static constexpr bool value = M::kEarlyReject; };
@@ -639,7 +641,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // both states if need be; and whatever is stored, returned or compared -- lp_curr at the end of every launch, the ctor's value -- is the expression's.
   // Every decision, hence every draw, is the one the term-by-term evaluation makes (tests: the reference goldens, bit for bit, and the same sampler with
   // options.full_evaluation = 1, which evaluates the expression in every update).
-  constexpr bool kCert = CertifiedOf<Model>::value && G == 1 && !GL && !SW;
+  constexpr bool kCert = CertifiedAt<Model, G>::value && !GL && !SW;      // (one lane per chain: the Normal family; a wavefront per chain: the Poisson family)
   double lpA = lp_curr, epsA = 0.0;      // the cheap value of log_post(current state) and its bound (0: lp_curr itself)
   bool lp_exact = true;                  // lp_curr is the expression's value of the current state
   (void)lpA; (void)epsA; (void)lp_exact;
@@ -1226,8 +1228,8 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
             const double eta = ((r.eps + epsA + __builtin_fabs(dA) * 0x1p-51) * 1.0625 + 0x1p-49) * a.bound_scale;
             const double ex = exp_v8(dA);
             const bool ok = eta < 0x1p-7;      // (false for a NaN; exp(eps) <= 1 + 1.0625 eps holds far beyond)
-            if (ok && ex * (1.0 - eta) > u_accept) { certified = true; accepted = true; lpA = r.value; epsA = r.eps; lp_exact = false; }
-            else if (ok && ex * (1.0 + eta) < u_accept) { certified = true; set_state(comp, cur); }
+            if (chain_true<G>(ok && ex * (1.0 - eta) > u_accept)) { certified = true; accepted = true; lpA = r.value; epsA = r.eps; lp_exact = false; }
+            else if (chain_true<G>(ok && ex * (1.0 + eta) < u_accept)) { certified = true; set_state(comp, cur); }
             if (certified && counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }

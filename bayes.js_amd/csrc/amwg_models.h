@@ -243,6 +243,7 @@ struct NormalModel {
   // i.e. |difference| <= (1.125 n + 16) u mag; eps = (2 n + 64) u (|prior| + n |c| + 2 Q) 1.25 leaves a factor of two.  A non-finite value anywhere
   // makes eps non-finite, which the stepper reads as "evaluate the expression".
   static constexpr bool kCertified = true;
+  static constexpr int kCertifiedLanes = 1;
   struct Approx { double value, eps; };
   template <int G, int BT>
   __device__ __forceinline__ static Approx log_post_approx(Cache &kc, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
@@ -1052,6 +1053,113 @@ struct PoisGlmModel {
       acc += term_of(ps, a, k * G + sub, 1);
     }
     return acc;
+  }
+  // CERTIFIED DECISIONS (16 lanes per chain: four chains to a wavefront; amwg_kernel.h).  The reference's term is  log(lambda) y - lambda - lfactorial(y)  with
+  // lambda = exp(eta) -- it takes the LOGARITHM of the exponential it has just formed (ld.pois(y, Math.exp(eta)), distributions.js:282-284), which V8 returns to
+  // within an ulp of eta but not as eta: 36 of the term's 86 operations.  As real numbers log_post = prior + sum eta_i y_i - sum e^eta_i - sum lfactorial(y_i); the
+  // pass below forms exactly that -- eta by one product and six fmas, e^eta by exp_bounded (19 operations, no reciprocal), two running sums; the third sum is a
+  // constant of the data -- ~32 operations per observation, and hands it to the stepper with a bound eps on how far it and the expression's value (log_post
+  // above, in the chain's lane order) can be apart.
+  //   And it is the WAVEFRONT's pass: the expression's pass re-reads the 72 bytes of every observation for every chain (3.6 MB per evaluation through L1 / L2:
+  //   19 TB/s over the chip, the ceiling that kept this kernel at 0.55 of its arithmetic roof for three rounds -- with exp and log removed it ran 6 % faster).
+  //   Here the 64 lanes of a wavefront share out the OBSERVATIONS whichever chain they belong to, the four chains' coefficients travel in scalar registers, and
+  //   a row, once in registers, is evaluated for all four chains: a quarter of the memory traffic, and the kernel is bound by its arithmetic.  Four partial
+  //   results per lane and one butterfly over the wavefront per chain leave each chain's total in its own lanes.
+  // With u = 2^-53, H >= max_i |eta_i| (sum_k |b_k| max_i |x_ik| + |b_7|, from the column maxima the host keeps), Y = sum y_i, F = sum lfactorial(y_i), L = sum lambda_i:
+  //   log(exp_v8(eta)) vs eta: 2 u (1 + H) 1.01 per unit of y; exp_v8 vs e^eta: 2 u L; the term's three roundings: 4 u (H Y + L + F); eta's 13 roundings against
+  //   the 7 here: 22 u H (Y + L) 1.05; exp_bounded: 2^-46 L = 128 u L; the per-lane sums of n_l terms and the butterflies, on both sides: 2 (n_l + 8) u W; the final
+  //   combination 4 u W -- W = |prior| + (1 + H) Y + L + F bounds every sum of magnitudes above, n_l = n / 16 + 1 (the expression's lanes hold the longer sums).
+  //   eps = u W (2 n_l + 23 H + 200) 1.25.
+  // H > 690 (an eta could leave the range in which exp and log are ordinary), a negative count (F = +inf) or any non-finite value make eps non-finite: the
+  // stepper then evaluates the expression.
+  static constexpr bool kCertified = true;
+  static constexpr int kCertifiedLanes = 16;
+  struct Approx { double value, eps; };
+  template <int G, int BT>
+  __device__ __forceinline__ static Approx log_post_approx(Cache &kc, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
+    static_assert(G == 16, "the certified pass of the Poisson family runs four chains to a wavefront");
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int CW = 64 / G;
+    const int lane = (int)(threadIdx.x & 63u);
+    const Pass ps = begin<G>(S, mc, d, smem, kc);      // this lane's chain: b[0..7], icp, the column pointers
+    const double start = prior_split<G>(S, mc, d, sub, (sub == 0) ? prior(S, mc, d, kc) : 0.0, kc);
+    // (what the bound needs of this lane's own chain, taken before the pass: its coefficients need not stay in registers through it)
+    double H = __builtin_fabs(ps.b[7]);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) H += __builtin_fabs(ps.b[q]) * mc.glm_xmax[q];
+    const double P = butterfly<1, G>(start), Pabs = butterfly<1, G>(__builtin_fabs(start));
+    const ExpTaylorRegs E = exp_taylor_regs();
+    // the four chains' coefficients and thresholds, wave-uniform (v_readlane from the first lane of each chain: scalar registers for the whole pass)
+    double bc[CW][8];
+    int icp[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint64_t v = f64_bits(ps.b[k]);
+        bc[c][k] = bits_f64(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), c * G) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, c * G));
+      }
+      icp[c] = __builtin_amdgcn_readlane(ps.icp, c * G);
+    }
+    double s1[CW], ls[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) { s1[c] = 0.0; ls[c] = 0.0; }
+    auto load8 = [&](int i, double (&v)[8]) {
+      const uint32_t off = (uint32_t)i * 8u;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const double *>(ps.col[k] + off);      // seven columns and the count (col[7])
+    };
+    auto row = [&](const double (&v)[8], int i) {
+      double eta[CW];
+#pragma unroll
+      for (int c = 0; c < CW; ++c) eta[c] = v[0] * bc[c][0];
+#pragma unroll
+      for (int k = 1; k < 7; ++k) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) eta[c] = __builtin_fma(v[k], bc[c][k], eta[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < CW; ++c) eta[c] = i >= icp[c] ? eta[c] + bc[c][7] : eta[c];
+      double lam[CW];
+#pragma unroll
+      for (int c = 0; c < CW; ++c) lam[c] = exp_bounded(eta[c], E);
+#pragma unroll
+      for (int c = 0; c < CW; ++c) { s1[c] = __builtin_fma(eta[c], v[7], s1[c]); ls[c] += lam[c]; }
+    };
+    const int n_obs = d.n_obs, n_full = n_obs >> 6, rem = n_obs & 63;
+    double a[8], nx[8];
+    int k = 0;
+    if (n_full >= 2) {
+      load8(lane, a);
+      for (; k + 1 < n_full; ++k) {                              // round k + 1 < n_full: every lane has that row
+        load8((k + 1) * 64 + lane, nx);
+        AMWG_STAGE_FENCE();
+        row(a, k * 64 + lane);
+        AMWG_STAGE_FENCE();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = nx[q];
+      }
+    }
+    for (; k < n_full + (lane < rem ? 1 : 0); ++k) {
+      load8(k * 64 + lane, a);
+      row(a, k * 64 + lane);
+    }
+    // every chain's totals over the wavefront; a lane keeps its own chain's
+    const int mine = lane / G;
+    double tot = 0.0, L = 0.0;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const double t = butterfly<1, 64>(s1[c] - ls[c]), l = butterfly<1, 64>(ls[c]);
+      tot = mine == c ? t : tot;
+      L = mine == c ? l : L;
+    }
+    const double n_l = (double)(n_obs / G + 1);
+    const double W = Pabs + (1.0 + H) * mc.glm_sum_y + L + mc.glm_sum_lf;
+    const double eps = (H <= 690.0) ? W * (2.0 * n_l + 23.0 * H + 200.0) * 1.25 * 0x1p-53 : __builtin_inf();
+    return Approx{(P + tot) - mc.glm_sum_lf, eps};
+#else
+    return Approx{0.0, __builtin_inf()};
+#endif
   }
   // two observations through exp / log side by side (one basic block: the two dependent chains interleave), added in order
   __device__ __forceinline__ static double pair_finish(const Pass &ps, double eta_a, double eta_b, double ya, double la, double yb, double lb, double acc) {

@@ -64,6 +64,9 @@ struct ModelConsts {
   int32_t exact_division;           // 1 = always use IEEE '/'
   int32_t has_invalid;              // BETA_BERN: some x_i is neither 0 nor 1 => that term is -inf (distributions.js:229)
   int32_t group_local;              // HIER: group-local evaluation (amwg_options::group_local; preconditions checked by amwg_create)
+  // POIS_GLM, for the bounds of the certified pass (amwg_models.h PoisGlmModel::log_post_approx): max_i |X[i][k]| per column, sum of the counts, sum of
+  // lfactorial(y_i) (+inf if some count is negative: such data always takes the expression)
+  double glm_xmax[7], glm_sum_y, glm_sum_lf;
   int32_t group_lane_const;         // HIER: g[i] == g[i % lanes] for every i -- each lane of a chain only ever meets ONE group (balanced
                                     // round-robin designs such as g_i = i mod 32 with 64 lanes): its mean is read once per evaluation
 };

@@ -89,6 +89,24 @@ int main(int argc, char **argv) {
   const double sp[] = {0.0, -0.0, 1.0, -1.0, INFINITY, -INFINITY, NAN, 709.782712893384, 709.7827128933841, -745.1332191019411, -745.1332191019412,
                        -708.0, 708.0, 1e-300, -1e-300, 5e-324, 0.34657359027997264, -0.34657359027997264, 1.0397207708399179, -1.0397207708399179};
   for (double x : sp) check(x);
+  // 5. exp_bounded (the certified pass of the Poisson family): NOT V8's exp -- its relative distance from exp, measured against long double, must stay
+  // below the 2^-46 its users add to their bounds (kExpBoundedRel); literal and register-struct constants give the same bits
+  {
+    long double worst = 0;
+    const ExpTaylorRegs tr = exp_taylor_regs();
+    std::uniform_real_distribution<double> V(-700.0, 700.0), S(-2.0, 2.0);
+    auto one = [&](double x) {
+      const double g = exp_bounded(x, ExpTaylorLiterals{}), g2 = exp_bounded(x, tr);
+      const long double w = expl((long double)x);
+      const long double rel = fabsl(((long double)g - w) / w);
+      if (rel > worst) worst = rel;
+      if (memcmp(&g, &g2, 8) != 0) { if (bad < 10) printf("MISMATCH (exp_bounded literals vs registers) x=%a\n", x); ++bad; }
+    };
+    for (long c = 0; c < cases; ++c) { one(V(rng)); one(S(rng)); one((double)((long)(rng() % 2001) - 1000) * 0.6931471805599453 * 0.5 + S(rng) * 1e-9); }
+    for (double x : {0.0, -0.0, 700.0, -700.0, 0.34657359027997264, -0.34657359027997264, 1e-300, -1e-300}) one(x);
+    printf("exp_bounded_worst_rel=%.3Le (2^-46 = %.3e)\n", worst, 0x1p-46);
+    if (!(worst < 0x1p-48L)) { printf("exp_bounded is not within a quarter of its stated bound\n"); ++bad; }
+  }
   printf("arguments=%ld fused_common=%ld (form a: %ld) other_split=%ld mismatches=%ld\n", seen, fused_common, form_a, fused_other, bad);
   if (fused_other < 1000 || form_a < 1000) { printf("coverage too thin\n"); return 2; }
   return bad ? 1 : 0;

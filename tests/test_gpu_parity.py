@@ -72,7 +72,7 @@ def test_one_lane_per_chain_is_bit_identical_to_reference(name, one_lane_runs):
 
 @pytest.mark.parametrize("name,lanes", [(n, l) for n in ["cfg1_heights", "normal_n1000", "normal_opts", "beta_bern_n2000", "hier_small", "glm_small"]
                                         for l in [2, 4, 8, 16, 32, 64]] +
-                         [("cfg4_full", 64), ("cfg4_full", 32), ("cfg5_full", 64),      # the full-size cases at the lane counts the bench times
+                         [("cfg4_full", 64), ("cfg4_full", 32), ("cfg5_full", 64), ("cfg5_full", 16),      # the full-size cases at the lane counts the bench times
                           ("cfg4_theta_bounded", 64), ("cfg4_theta_int", 64)])           # ... the sweep kernel straight against reference goldens with a bounded / integer theta
 def test_g_lanes_per_chain_matches_oracle_and_reference_decisions(name, lanes):
     gold = golden_io.load(name)
@@ -514,6 +514,37 @@ def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains, th
     b.close()
     c2.close()
     c3.close()
+
+
+@pytest.mark.parametrize("n_obs,chains,steps", [(500, 1024, 300), (3000, 512, 120), (449, 260, 200), (61, 256, 200)])
+def test_certified_decisions_of_the_poisson_family_equal_the_expression_in_every_update(n_obs, chains, steps):
+    """Poisson GLM + integer change point, 16 lanes per chain (four chains to a wavefront): by default the accept test is decided from  prior + sum eta y - sum
+    e^eta - sum lfactorial(y)  -- no logarithm of the exponential, the four chains of a wavefront sharing every row they read -- and a bound on its distance
+    from the reference's expression (csrc/amwg_models.h PoisGlmModel::log_post_approx); options.full_evaluation = 1 evaluates the expression in every update.
+    Every bit of every chain must agree: draws, counters, proposal scales, uniforms, the cached log_post; with the bound widened 2^14- and 2^40-fold as well
+    (updates fall back to the expression often / always).  Chain counts that leave a wavefront partly filled, fewer observations than lanes."""
+    data = model_spec.make_data("pois_glm", n_obs, 123, exp=oracle_lib.lib().orc_exp)
+    spec = model_spec.build_spec("pois_glm", data)
+    mk = lambda full, shift=0: A.Sampler(spec, chains=chains, seed=21, chain_offset=2, lanes_per_chain=16, steps_per_launch=9, full_evaluation=full, test_bound_shift=shift)
+    outs = []
+    for s in (mk(0), mk(1), mk(0, 14), mk(0, 40)):
+        assert s.launch_info()["lanes_per_chain"] == 16
+        seq = [s.sample(steps // 3, 2)]
+        s.burn(steps // 3)
+        s.set_adapting(False)
+        seq.append(s.sample(steps // 6, 1))
+        s.set_adapting(True)
+        s.burn(steps // 6)
+        outs.append((seq, s.info(), s.diag(), s.state()))
+        s.close()
+    (sa, ia, da, sta) = outs[0]
+    for (sb, ib, db, stb) in outs[1:]:
+        for x, y in zip(sa, sb):
+            assert x.tobytes() == y.tobytes()
+        for k in ia:
+            assert ia[k].tobytes() == ib[k].tobytes(), k
+        assert da["uniforms"].tobytes() == db["uniforms"].tobytes() and da["log_post"].tobytes() == db["log_post"].tobytes()
+        assert sta.tobytes() == stb.tobytes()
 
 
 @pytest.mark.parametrize("n_obs,chains,steps,hyper", [(1000, 4096, 400, None), (777, 1024, 300, None), (17, 512, 300, None), (1000, 16384, 600, [0.0, 100.0, 0.0, 1.0])])
