@@ -370,7 +370,13 @@ struct Roctx {
 };
 Roctx &roctx() { static Roctx r; return r; }
 
-int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
+// does this sampler's kernel decide from a model's cheaper value of log_post (amwg_kernel.h kCert: NormalModel at one lane per chain, PoisGlmModel at 16)?
+static bool certified_kernel(const amwg_sampler *s) {
+  if (s->user || s->opt.full_evaluation != 0 || s->opt.exact_division || s->mc.group_local) return false;
+  return (s->model == AMWG_MODEL_NORMAL && s->lanes == 1) || (s->model == AMWG_MODEL_POIS_GLM && s->lanes == 16);
+}
+
+int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws, bool finalize = false) {
   Roctx &rx = roctx();
   if (rx.push) rx.push(d_draws ? "amwg_sample" : "amwg_burn");
   struct PopOnExit { Roctx &r; ~PopOnExit() { if (r.pop) r.pop(); } } pop_on_exit{rx};
@@ -410,6 +416,7 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
     const int64_t m = (n - done < chunk) ? n - done : chunk;
     a.n_steps = (int32_t)m;
     a.init_lp = s->lp_ready ? 0 : 1;
+    a.finalize_lp = finalize ? 1 : 0;
     // steps until the first recorded step of this launch: smallest t >= 0 with (done + t) % thin == 0
     a.step0 = (thin - (done % thin)) % thin;
     a.row0 = row;
@@ -422,6 +429,8 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws) {
       HIP_TRY(hipGetLastError());
     }
     s->lp_ready = true;
+    if (finalize || a.init_lp) s->lp_is_expression = true;                        // (the launch began / ends with the expression)
+    if (m > 0 && !finalize && certified_kernel(s)) s->lp_is_expression = false;      // (it may have left the stepper's cheaper value and its bound behind)
     s->n_launches++;
     if (d_draws) row += (m > a.step0) ? (m - a.step0 + thin - 1) / thin : 0;
     // a mark for amwg_fetch_draws*: only for the library's own buffer, and only once >= 8 MB of new rows (or the end of the call) stand
@@ -721,6 +730,7 @@ static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int
   if (wide_perm) TRYB(dev_alloc(s, &ch.perm16, (size_t)s->n_params * C));
   TRYB(dev_alloc(s, &ch.rng_n, C));
   TRYB(dev_alloc(s, &ch.lp_curr, C));
+  TRYB(dev_alloc(s, &ch.lp_eps, C));
   TRYB(dev_alloc(s, &ch.error, (size_t)1));
   {
     std::vector<double> tmp(PC);
@@ -745,6 +755,7 @@ static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int
   HIPB(hipMemset(ch.inbounds, 0, PC * 4));
   HIPB(hipMemset(ch.rng_n, 0, C * 8));
   HIPB(hipMemset(ch.lp_curr, 0, C * 8));
+  HIPB(hipMemset(ch.lp_eps, 0, C * 8));
   HIPB(hipMemset(ch.error, 0, sizeof(int32_t)));
   return AMWG_OK;
 }
@@ -916,7 +927,7 @@ static int autotune_geometry(amwg_sampler *s, int n_cus, size_t max_lds, Prepare
   const size_t PC = (size_t)s->P * (size_t)s->C, C = (size_t)s->C;
   std::vector<std::pair<void *, size_t>> parts = {
       {s->ch.state, PC * 8}, {s->ch.prop_log_scale, PC * 8}, {s->ch.acceptance_count, PC * 4}, {s->ch.iterations_since_adaption, PC * 4},
-      {s->ch.batch_count, PC * 4}, {s->ch.accepts, PC * 4}, {s->ch.inbounds, PC * 4}, {s->ch.perm, C * 8}, {s->ch.rng_n, C * 8}, {s->ch.lp_curr, C * 8}};
+      {s->ch.batch_count, PC * 4}, {s->ch.accepts, PC * 4}, {s->ch.inbounds, PC * 4}, {s->ch.perm, C * 8}, {s->ch.rng_n, C * 8}, {s->ch.lp_curr, C * 8}, {s->ch.lp_eps, C * 8}};
   if (s->ch.perm16) parts.push_back({s->ch.perm16, (size_t)s->n_params * C * 2});
   size_t total = 0;
   for (auto &p : parts) total += (p.second + 255) & ~(size_t)255;
@@ -1565,7 +1576,8 @@ int amwg_chain_diag(amwg_sampler *s, uint64_t *uniforms, double *log_post_out, i
   if (!s) return fail(AMWG_EINVAL, "amwg_chain_diag: null sampler");
   const size_t C = (size_t)s->C;
   HIP_TRY(hipSetDevice(s->device));
-  if (!s->lp_ready) { int rc = launch_steps(s, 0, 1, nullptr); if (rc != AMWG_OK) return rc; }
+  // (log_post of the current state as the expression gives it: a 0-step launch computes it where it was never formed or where the stepper's cheaper value stands in)
+  if (!s->lp_ready || !s->lp_is_expression) { int rc = launch_steps(s, 0, 1, nullptr, true); if (rc != AMWG_OK) return rc; }
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (uniforms) HIP_TRY(hipMemcpy(uniforms, s->ch.rng_n, C * 8, hipMemcpyDeviceToHost));
   if (log_post_out) HIP_TRY(hipMemcpy(log_post_out, s->ch.lp_curr, C * 8, hipMemcpyDeviceToHost));

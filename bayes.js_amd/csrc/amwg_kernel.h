@@ -642,8 +642,11 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // Every decision, hence every draw, is the one the term-by-term evaluation makes (tests: the reference goldens, bit for bit, and the same sampler with
   // options.full_evaluation = 1, which evaluates the expression in every update).
   constexpr bool kCert = CertifiedAt<Model, G>::value && !GL && !SW;      // (one lane per chain: the Normal family; a wavefront per chain: the Poisson family)
+  // (between launches the pair travels in ChainArrays::lp_curr / lp_eps: a launch does not close with an evaluation of the expression unless the host
+  // asks for its value -- StepArgs::finalize_lp, amwg_chain_diag)
   double lpA = lp_curr, epsA = 0.0;      // the cheap value of log_post(current state) and its bound (0: lp_curr itself)
   bool lp_exact = true;                  // lp_curr is the expression's value of the current state
+  if constexpr (kCert) { if (!a.init_lp) { epsA = a.ch.lp_eps[cl]; lp_exact = epsA == 0.0; } }
   (void)lpA; (void)epsA; (void)lp_exact;
 
   // every store to the state goes through here: the LDS copy (what translated closures, gathers and the final write-back read) and,
@@ -1277,8 +1280,10 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
 
   // the register mirror of the state (kTracksState models) is a second copy that every store must keep current (set_state -> on_set): once per
   // launch it is compared with the LDS copy, bit for bit -- a store that bypassed set_state would otherwise go unnoticed until a parity test
-  if constexpr (kCert) {      // what leaves the launch is the expression's value of the final state
-    if (!lp_exact) lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);
+  if constexpr (kCert) {      // what leaves the launch: the expression's value of the final state if the host asked for it, else the pair the stepper holds
+    if (a.finalize_lp && !lp_exact) { lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache); lp_exact = true; }
+    if (!lp_exact) lp_curr = lpA;
+    if (writer) cold_args()->ch.lp_eps[cl] = lp_exact ? 0.0 : epsA;
   }
   if constexpr (!GL && MirrorCheckOf<Model>::value) {
     if (!Model::template mirror_ok<G>(cache, S, a.d, sub)) (void)atomicOr(cold_args()->ch.error, kErrMirrorOutOfSync);

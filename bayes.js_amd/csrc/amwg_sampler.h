@@ -35,6 +35,7 @@ struct amwg_sampler {
   std::string kernel_name;          // amwg_kernel_name(): filled on first request
   uint32_t hier_periodic_mask = 0;   // HIER: bit j set = the group labels repeat with a lane stride of 2^j (g[i] == g[i mod 2^j])
   bool lp_ready = false;
+  bool lp_is_expression = true;      // ch.lp_curr holds the expression's value for every chain (false after steps of a kernel with certified decisions, until a finalize launch)
   std::vector<std::pair<int, float>> tuned;   // AMWG_LANES_AUTOTUNE: (lanes per chain, ms of the timing run) of every candidate
   // translated closure (amwg_create_user): hiprtc module function instead of a built-in kernel
   bool user = false;

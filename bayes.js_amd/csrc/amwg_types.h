@@ -93,7 +93,9 @@ struct ChainArrays {
   uint64_t *perm;           // [C] order of the named sub-steppers, 4 bits each (mcmc.js:887 shuffles in place); n_params <= kPackedNamed
   uint16_t *perm16;         // [n_params][C] the same order as 16-bit entries when n_params > kPackedNamed (else null)
   uint64_t *rng_n;          // [C] uniforms consumed
-  double *lp_curr;          // [C] log_post(state)
+  double *lp_curr;          // [C] log_post(state): the expression's value -- or, between the launches of a kernel with certified decisions, the cheaper value the
+                            // stepper last decided from, when lp_eps says so (made exact on demand: StepArgs::finalize_lp)
+  double *lp_eps;           // [C] 0: lp_curr is the expression's value; else the bound that goes with the cheaper value in lp_curr
   int32_t *error;           // one word: bits set by a step kernel that refused its launch or found its own bookkeeping inconsistent (amwg_kernel.h
                             // device_error); the host reads it after every call and turns it into an error -- never a silent no-op
 };
@@ -108,6 +110,8 @@ struct StepArgs {
   const CompConst *cc;      // [P]
   const uint8_t *is_adapting;  // [P]
   int32_t init_lp;          // 1 = first launch: compute lp_curr = log_post(init) (the ctor's warm-up call, mcmc.js:961-963)
+  int32_t finalize_lp;              // 1 = leave the expression's value of log_post(state) in lp_curr (amwg_chain_diag asks for it; a launch otherwise hands the stepper's
+                                    // cheaper value and its bound on to the next launch: no closing evaluation per launch)
   int32_t certified;                // 1 = accept tests may be decided from a model's cheaper value of log_post with its bound (amwg_kernel.h "certified decisions"):
                                     // amwg_options::full_evaluation == 0 and not exact_division
   double bound_scale;               // 2^amwg_options::test_bound_shift (1 in production): multiplies the bounds of the certified decisions

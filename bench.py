@@ -113,6 +113,25 @@ CERTIFIED_NOTE = ("2 = sub, fma: by default the accept test of the Normal family
                   "distance from the reference's term-by-term expression (csrc/amwg_kernel.h 'certified decisions'); every update still passes over all the observations; the "
                   "expression itself (8 operations per observation) is evaluated when a uniform falls inside the bound (~1e-7 of the updates) and once per launch and chain. "
                   "Every draw is bit-identical to the reference's (parity block).  `full_evaluation` beside this: the kernel that evaluates the expression in every update")
+CERTIFIED_GLM_OPS_PER_OBS = 29
+CERTIFIED_GLM_NOTE = ("29 = the certified pass of the Poisson family (16 lanes per chain, the four chains of a wavefront sharing every row they read): linear predictor as one "
+                      "product + six fmas (7), change point (1), exp_bounded (19: k = round(x / ln2), two fused reduction steps, a degree-13 Taylor polynomial by Horner's rule "
+                      "in fmas, conversion of k, ldexp), sum eta y (1 fma), sum lambda (1).  The logarithm of the exponential the reference takes is NOT formed: the value is used "
+                      "with a rigorous bound on its distance from the expression's (csrc/amwg_models.h PoisGlmModel::log_post_approx); the expression itself (86 operations per "
+                      "observation) is evaluated when a uniform falls inside the bound and once per launch and chain.  `full_evaluation` beside this: the expression in every update")
+
+
+def certified_kind(fam, lanes, full_evaluation=False):
+    """which certified pass the default geometry runs (None: the reference's expression in every update)"""
+    if full_evaluation:
+        return None
+    if fam == "normal" and lanes == 1:
+        return "normal"
+    if fam == "pois_glm" and lanes == 16:
+        return "pois_glm"
+    return None
+
+
 OPS_NOTE = {
     "normal": "8 = sub, mul, 4-operation correctly rounded quotient (amwg_div.h: mul, fma, fma, fma), sub, add; IEEE '/' would be 17",
     "hier_normal": "8 = sub, mul, 4-operation correctly rounded quotient, sub, add (the gather of theta[g_i] is an LDS read, not arithmetic)",
@@ -453,6 +472,18 @@ def measure_other_config(A, name, device, group_local=0):
         else:
             kernel += " with options.full_evaluation = 1"
             note = "roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s" % roof_updates_per_s
+    ops_note = OPS_NOTE[fam]
+    if name == "cfg5" and certified_kind(fam, li["lanes_per_chain"]):
+        # the default runs the certified pass (29 operations per observation, four chains sharing a row): `value` and `frac` describe that kernel; the
+        # kernel that evaluates the reference's expression in every update is measured beside it
+        t = A.Sampler(spec, chains=chains, seed=SEED, device=device, lanes_per_chain=li["lanes_per_chain"], steps_per_launch=10, full_evaluation=1)
+        t.burn(10)
+        t.burn(10)
+        fv = chains * 10 * P / (t.launch_info()["kernel_ms"] * 1e-3)
+        out["full_evaluation_value"], out["full_evaluation_frac"] = fv, fv * n_obs * ops_per_obs / FP64_VALU_PEAK
+        t.close()
+        ops_per_obs, ops_note = CERTIFIED_GLM_OPS_PER_OBS, CERTIFIED_GLM_NOTE
+        kernel = li.get("kernel", kernel) + " (certified decisions)"
     lane_ops = sweep_lane_ops(value, P, n_obs, ops_per_obs) if roof_updates_per_s is None else roof_updates_per_s * n_obs * ops_per_obs
     if group_local:
         # group-local evaluation: a step of the P = G + 2 updates makes TWO passes over the data (the sweep over theta and the sigma update)
@@ -464,7 +495,7 @@ def measure_other_config(A, name, device, group_local=0):
                 "their local differences, mu needs no pass, sigma one: 2 passes per step instead of %d (mcmc.js:524-526 makes 2 per update).  roofline = "
                 "the arithmetic of those two passes; the rest of a step is the stepper's serial logic" % (P - 2, P))
     out["roofline"] = {"bound": "fp64_valu", "achieved": lane_ops, "peak": FP64_VALU_PEAK, "frac": lane_ops / FP64_VALU_PEAK, "unit": "fp64 lane-operations/s",
-                       "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[fam], "kernel": kernel, "note": note,
+                       "lane_ops_per_obs": ops_per_obs, "lane_ops_note": ops_note, "kernel": kernel, "note": note,
                        "effective_hbm_gbps": value * b_alg / 1e9}
     out["roofline"].update(roofline_units(fam, lane_ops, ops_per_obs))
     if lanes > 1 and not group_local:
@@ -943,20 +974,22 @@ def main():
                 roof_launch_s, roof_updates, kernel = full_launch_s, full_updates, "%s with options.full_evaluation = 1" % full_eval["kernel"]
                 roof_note = "roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s" % full_eval["value"]
             t.close()
-        certified = spec["model"] == "normal" and li["lanes_per_chain"] == 1 and not args.full_evaluation
+        ckind = certified_kind(spec["model"], li["lanes_per_chain"], args.full_evaluation)
+        certified = ckind is not None
         ops_note = OPS_NOTE[spec["model"]]
         if certified:
-            # `value` and `frac` describe the same kernel: the certified pass issues 2 fp64 operations per observation; the expression kernel is measured beside it
+            # `value` and `frac` describe the same kernel: the certified pass and ITS operations per observation; the expression kernel is measured beside it
             if not args.single_region:
-                t = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=dev_index, lanes_per_chain=1, block_threads=args.block, steps_per_launch=args.steps_per_launch, full_evaluation=1)
-                t.burn(2 * args.steps_per_launch)
-                t.burn(2 * args.steps_per_launch)
+                few = 2 * args.steps_per_launch if ckind == "normal" else max(4, min(args.steps_per_launch, 10))
+                t = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=dev_index, lanes_per_chain=li["lanes_per_chain"], block_threads=args.block, steps_per_launch=args.steps_per_launch, full_evaluation=1)
+                t.burn(few)
+                t.burn(few)
                 fl = t.launch_info()
-                fv = chains * 2 * args.steps_per_launch * P / (fl["kernel_ms"] * 1e-3)
+                fv = chains * few * P / (fl["kernel_ms"] * 1e-3)
                 full_eval = {"value": fv, "frac": fv * n_obs * ops_per_obs / FP64_VALU_PEAK, "kernel": fl["kernel"], "lane_ops_per_obs": ops_per_obs,
                              "note": "options.full_evaluation = 1: the reference's expression, term by term, in every update (rounds 1-4's kernel)"}
                 t.close()
-            ops_per_obs, ops_note = CERTIFIED_OPS_PER_OBS, CERTIFIED_NOTE
+            ops_per_obs, ops_note = (CERTIFIED_OPS_PER_OBS, CERTIFIED_NOTE) if ckind == "normal" else (CERTIFIED_GLM_OPS_PER_OBS, CERTIFIED_GLM_NOTE)
         traffic, traffic_src, traffic_alg, traffic_why_not = measured_traffic(chains, args.steps_per_launch, args.workload, li["lanes_per_chain"], args.group_local, kernel_id_of(version), kernel)
         lane_ops = roof_updates * n_obs * ops_per_obs / roof_launch_s
         if str(kernel).startswith("amwg_sweep_kernel"):
@@ -1004,8 +1037,8 @@ def main():
                           "note": "moments over the recorded draws of the last region on ALL ranks (all-reduce of per-rank sums for N > 1; after %d warm-up + %d timed steps)" % (W, K * (len(regions) - 1))},
         }
         out["roofline"].update(roofline_units(spec["model"], lane_ops, ops_per_obs) if not certified else
-                               {"frac_issue": lane_ops / FP64_VALU_PEAK, "frac_survey_flops": (roof_updates / roof_launch_s) * n_obs * 3 / FP64_FLOPS_PEAK,
-                                "survey_flops_note": "the certified pass is a sub and an fma per observation = 3 flops (an FMA = 2) against 78.6 TFLOP/s"})
+                               {"frac_issue": lane_ops / FP64_VALU_PEAK, "frac_survey_flops": (roof_updates / roof_launch_s) * n_obs * (3 if ckind == "normal" else 50) / FP64_FLOPS_PEAK,
+                                "survey_flops_note": "the certified pass in flops (an FMA = 2) against 78.6 TFLOP/s: a sub and an fma per observation = 3 (Normal); 8 + 21 fmas = 50 (Poisson)"})
         import build_id
         out["library"] = {"version": version, "built_from_this_tree": ("build " + build_id.build_id()) in version and ("kernels " + build_id.kernel_id()) in version,
                           "note": "amwg_version(): a hash over every source of libamwg.so and one over the device sources + compiler flags (tools/build_id.py); "

@@ -39,7 +39,12 @@ def test_default_line_has_the_contract_fields_and_an_honest_roofline():
     assert abs(d["value"] - full["value"]) < 1e-6 * full["value"]
     r = d["roofline"]
     assert r["bound"] == "fp64_valu" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
-    assert "traffic" in r and r["kernel"].startswith("amwg_step_kernel<NormalModel,1")
+    assert "traffic" in r and r["kernel"].startswith("amwg_step_kernel<NormalModel,1") and "certified" in r["kernel"]
+    # the default decides from the certified pass (2 operations per observation); the kernel that evaluates the reference's expression in every update is
+    # measured beside it and is slower
+    assert full["roofline"]["lane_ops_per_obs"] == 2 and 0 < d["full_evaluation"]["frac"] < 1 and d["full_evaluation"]["value"] < d["value"]
+    c5 = full["other_configs"]["cfg5"]
+    assert c5["lanes_per_chain"] == 16 and c5["roofline"]["lane_ops_per_obs"] == 29 and c5["full_evaluation_value"] < c5["value"]
     assert r["effective_hbm"]["lds_resident"] is True and r["effective_hbm"]["unit"] == "GB/s"
     assert d["parity"]["draws_bit_identical"] and d["parity"]["accept_counts_identical"] and d["parity"]["final_state_bit_identical"]
     assert d["detail"].endswith("bench_detail.json")
@@ -65,7 +70,7 @@ def test_default_line_has_the_contract_fields_and_an_honest_roofline():
     assert ("refused" in fr) != ("flips_per_1e9" in fr)      # a campaign of other kernels is refused, not quoted
     # (cfg4's default is the sweep kernel since round 4 -- the reference's schedule with three passes per step: the opt-in group-local evaluation is
     # less than 2x ahead of it, and > 5x ahead of the kernel that evaluates everything)
-    assert full["other_configs"]["cfg4_group_local"]["speedup_over_cfg4"] > 1.3
+    assert full["other_configs"]["cfg4_group_local"]["speedup_over_cfg4"] > 1.05      # (round 5: the default's sweeps are decided all at once -- 1.23x left)
     assert full["other_configs"]["cfg4"]["value"] > 2.5 * full["other_configs"]["cfg4"]["full_evaluation_value"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "param-updates/s" and c["sample"]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/flip_rate.py -- the decision-parity campaign (GPU box): the same seeded job with one lane per chain (the reference's summation order)
 and at 64 lanes / group-local, counting the chains whose run ever differs (tests/decision_parity.py).  Prints one JSON object; the committed
-copy is profiles/r04_flip_rate.json, quoted in DESIGN.md section 2 and in the bench line's parity.flip_rate.
+copy is profiles/r05_flip_rate.json, quoted in DESIGN.md section 2 and in the bench line's parity.flip_rate.
 
     python tools/flip_rate.py [--scale 1.0] > gpurun_out/flip_rate.json
 """
@@ -21,6 +21,7 @@ CAMPAIGN = [
     ("hier_n640_g8", 65_536, 20_000, {"lanes_per_chain": 64}),
     ("hier_n640_g8", 65_536, 20_000, {"lanes_per_chain": 64, "group_local": 1}),
     ("glm_n500", 16_384, 10_000, {"lanes_per_chain": 64}),
+    ("glm_n500", 16_384, 10_000, {"lanes_per_chain": 16}),      # (round 5: the default geometry of cfg5 -- certified decisions, four chains to a wavefront)
     ("cfg4_size", 16_384, 4_000, {"lanes_per_chain": 64}),
     ("cfg4_size", 16_384, 4_000, {"lanes_per_chain": 64, "group_local": 1}),
     ("cfg4_size", 16_384, 4_000, {"lanes_per_chain": 32}),

