@@ -11,6 +11,7 @@ for f in $R/bayes.js_amd/csrc/*.h $R/bayes.js_amd/csrc/*.hip $R/bayes.js_amd/csr
   cmp -s $f $D/bayes.js_amd/csrc/$(basename $f) || cp $f $D/bayes.js_amd/csrc/
 done
 cp $R/include/*.h $D/include/
+mkdir -p $D/tools && cp $R/tools/build_id.py $D/tools/
 make -s -j8 -C $D/bayes.js_amd/csrc libamwg.so HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -falign-loops=64 -Wall -Wno-unused-function $*"
 cp $D/bayes.js_amd/csrc/libamwg.so $D/libamwg.so
 echo "built $D/libamwg.so"
