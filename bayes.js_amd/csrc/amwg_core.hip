@@ -373,7 +373,8 @@ Roctx &roctx() { static Roctx r; return r; }
 // does this sampler's kernel decide from a model's cheaper value of log_post (amwg_kernel.h kCert: NormalModel at one lane per chain, PoisGlmModel at 16)?
 static bool certified_kernel(const amwg_sampler *s) {
   if (s->user || s->opt.full_evaluation != 0 || s->opt.exact_division || s->mc.group_local) return false;
-  return (s->model == AMWG_MODEL_NORMAL && s->lanes == 1) || (s->model == AMWG_MODEL_POIS_GLM && s->lanes == 16);
+  return (s->model == AMWG_MODEL_NORMAL && s->lanes == 1) || (s->model == AMWG_MODEL_POIS_GLM && s->lanes == 16) ||
+         (s->model == AMWG_MODEL_HIER_NORMAL && s->lanes == 64 && s->d.pad > 0);      // (the sweep kernel: the row layout is in use)
 }
 
 int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws, bool finalize = false) {

@@ -122,8 +122,9 @@ template <class M> struct CertifiedOf<M, void_of<decltype(M::kCertified)>> { sta
 template <class M, int G, class = void> struct CertifiedAt { static constexpr bool value = false; };
 template <class M, int G> struct CertifiedAt<M, G, void_of<decltype(M::kCertified)>> { static constexpr bool value = M::kCertified && M::kCertifiedLanes == G; };
 
-template <class M, class = void> struct EarlyRejectOf { static constexpr bool value = false; };
-template <class M> struct EarlyRejectOf<M, void_of<decltype(M::kEarlyReject)>> { static constexpr bool value = M::kEarlyReject; };
+// ... only in its row layout, i.e. in the sweep kernel (Model::kCertifiedNeedsRows)?
+template <class M, class = void> struct CertNeedsRows { static constexpr bool value = false; };
+template <class M> struct CertNeedsRows<M, void_of<decltype(M::kCertifiedNeedsRows)>> { static constexpr bool value = M::kCertifiedNeedsRows; };
 
 template <class M, class = void> struct OwnPassOf { static constexpr bool value = false; };
 template <class M> struct OwnPassOf<M, void_of<decltype(M::kOwnPass)>> { static constexpr bool value = M::kOwnPass; };
@@ -558,7 +559,9 @@ template <class M> struct MirrorCheckOf<M, void_of<decltype(M::kMirrorCheck)>> {
 // it runs four-wide there (same operations in the same order, half the registers).
 template <class Model, int G, int BT = 256, bool GL = false, bool SW = false>
 __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem) {
-  constexpr int kPassU = (BT >= 1024 || SW) ? 4 : 8;      // (the sweep kernel keeps the window stream and the per-lane values of a sweep alive across its passes: four-wide as well -- eight-wide spilled 14 registers)
+  // (round 5: in the sweep kernel the expression's passes are the rare path -- certified decisions, amwg_models.h HierNormalModel::sweep_approx --: two-wide, what
+  // counts is the registers they leave to everything else)
+  constexpr int kPassU = SW ? (CertNeedsRows<Model>::value ? 2 : 4) : (BT >= 1024 ? 4 : 8);      // (the sweep kernel keeps the window stream and the per-lane values of a sweep alive across its passes: four-wide as well -- eight-wide spilled 14 registers)
   const int tid = threadIdx.x, nt = blockDim.x;
   // G <= 64: nt/G chains per workgroup, each on G lanes of one wave.  G > 64 ("multi"): ONE chain per workgroup on G/64
   // waves; every wave is a full replica of the chain's scalar logic (same Philox stream => same proposals and decisions)
@@ -641,7 +644,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // both states if need be; and whatever is stored, returned or compared -- lp_curr at the end of every launch, the ctor's value -- is the expression's.
   // Every decision, hence every draw, is the one the term-by-term evaluation makes (tests: the reference goldens, bit for bit, and the same sampler with
   // options.full_evaluation = 1, which evaluates the expression in every update).
-  constexpr bool kCert = CertifiedAt<Model, G>::value && !GL && !SW;      // (one lane per chain: the Normal family; a wavefront per chain: the Poisson family)
+  constexpr bool kCert = CertifiedAt<Model, G>::value && !GL && (SW == CertNeedsRows<Model>::value);      // (one lane per chain: the Normal family; 16 lanes: the Poisson family; the sweep kernel: the hierarchical family)
   // (between launches the pair travels in ChainArrays::lp_curr / lp_eps: a launch does not close with an evaluation of the expression unless the host
   // asks for its value -- StepArgs::finalize_lp, amwg_chain_diag)
   double lpA = lp_curr, epsA = 0.0;      // the cheap value of log_post(current state) and its bound (0: lp_curr itself)
@@ -737,7 +740,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // the lower bound or above the upper one (each taken with a margin of 2^-50, an order of magnitude more than the roundings of the bounds themselves
   // plus that ulp) decides the comparison exactly as the exponential would -- which is then evaluated for the band in between only (about a quarter of
   // the proposals at a 44 % acceptance rate).
-  auto accept_sweep = [&](double diff, double u_accept) -> bool {
+  [[maybe_unused]] auto accept_sweep = [&](double diff, double u_accept) -> bool {
     bool accepted = false;
     if (chain_true<G>(diff >= 0.0)) accepted = true;
     else if (chain_true<G>(diff < -746.0)) accepted = false;
@@ -755,7 +758,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // as always, mu and sigma by the ordinary stepper with the group-local evaluation, and the Gn components of theta in ONE lane-parallel
   // sweep.  Same uniforms for the same purposes in the same order as the sequential stepper (oracle: gl_evaluate).
 #ifndef AMWG_X_GLCUT
-#define AMWG_X_GLCUT 0      // development experiments (wrong results): leave one piece of the group-local step out, to price it (tools/dev/gl_cuts.sh)
+#define AMWG_X_GLCUT 0      // development experiments (wrong results): leave one piece of the group-local step out, to price it (a build with -DAMWG_X_GLCUT=n: tools/build_variant.sh)
 #endif
   if constexpr (GL) {
     static_assert(G == 64, "the group-local kernel runs a chain on one whole wavefront");
@@ -935,6 +938,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     // every lane's proposed sum in one pass, and the updates then run as always, taking their proposal and uniform from the lanes.
     double sw_prop = 0.0, sw_u = 0.0;
     int ord_pos = lane64;     // lane c: the place of entry c in the shuffled order (the inverse of `ord`; sweep kernel only)
+    (void)ord_pos;
     int sw_left = 0;          // updates of the sweep still to come (0: the stepper draws as it goes)
     int sb = 0;               // the swept vector's place in the state: its entry c is component sb + c (the built-in family: 0)
     if constexpr (kSweep) sb = Model::sweep_base(a.d);
@@ -1099,6 +1103,56 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           // (the sums are prepared for proposals INSIDE their bounds; an entry whose proposal fell outside keeps its value: its lanes' sums are not used)
           const bool inb_mine = ((inb_assume >> cl) & 1ull) != 0ull;
           const double sw_eval = (bounded_any && !inb_mine) ? cur_l : sw_prop;
+          // CERTIFIED SWEEP (models with Model::sweep_approx: the hierarchical family).  Every lane's sum under its entry's proposal as  start' + n_l c - S2' / den
+          // with S2' the sum of squares of its row about the proposed mean -- two operations per observation, where the prefetch below forms the
+          // expression's sum in eight --, the sweep's accept tests from the entries' local differences of THOSE values with the bound that goes with them
+          // (Model::difference_bound).  If every test is decided, the accepted entries' values, the state and one butterfly are all that is left to do, and the
+          // stepper carries on with the cheap value of log_post and its bound; else the sweep takes the path below (the expression's sums) as if this had not run.
+          bool sweep_certified = false;
+          if constexpr (kCert) {
+            const int top = d_len;
+            if (a.certified && slot + d_len <= P_stepped && (top & (top - 1)) == 0) {
+              const auto sa = Model::sweep_approx(cache, S, a.mc, a.d, data_lds, sub, sw_eval);      // {ok, comp, cur, neu (values), mag, mean_new, s2_new}
+              const bool regular = sa.ok && __ballot(sa.comp != (lane64 & (top - 1))) == 0ull;
+              if (regular) {
+                double dsum = sa.neu - sa.cur;
+                if (top <= 32) dsum = xor_sum<32>(dsum);
+                if (top <= 16) dsum = xor_sum<16>(dsum);
+                if (top <= 8) dsum = xor_sum<8, true>(dsum);
+                if (top <= 4) dsum = xor_sum<4, true>(dsum);
+                if (top <= 2) dsum = xor_sum<2>(dsum);
+                const double M = butterfly<1, 64>(sa.mag);
+                const double eta = ((Model::difference_bound(M, a.d) + __builtin_fabs(dsum) * 0x1p-51) * 1.0625 + 0x1p-49) * a.bound_scale;
+                const double ex = exp_v8(dsum);
+                const uint64_t inb_s = uniform_u64(sw_inb);
+                const bool valid = lane64 < top && ((inb_s >> lane64) & 1ull) != 0ull;
+                const bool sure_acc = ex * (1.0 - eta) > sw_u, sure_rej = ex * (1.0 + eta) < sw_u;
+                const bool unsure = valid && !(eta < 0x1p-7 && (sure_acc || sure_rej));
+                if (__ballot(unsure) == 0ull) {
+                  sweep_certified = true;
+                  const uint64_t acc_mask = __ballot(valid && sure_acc);
+                  const bool mine = ((acc_mask >> (sa.comp & 63)) & 1ull) != 0ull;
+                  if (lane64 < top && ((acc_mask >> lane64) & 1ull) != 0ull) Sme[sb + lane64] = sw_prop;
+                  Model::sweep_approx_commit(cache, sa, acc_mask, mine, sw_prop, sub, a.d);
+                  // the cheap value of log_post of the state the sweep leaves, and its bound: what the following updates are decided against
+                  lpA = butterfly<1, 64>(mine ? sa.neu : sa.cur);
+                  epsA = Model::value_bound(M, a.d);
+                  lp_exact = false;
+                  if (lane64 < top) {
+                    const bool inb_l = ((inb_s >> lane64) & 1ull) != 0ull, acc_l = ((acc_mask >> lane64) & 1ull) != 0ull;
+                    if (inb_l) TOTme[sb + lane64] += 1u + (acc_l ? 0x10000u : 0u);
+                    if (adapt[sb + lane64] != 0) adapt_component(sb + lane64, acc_l, CNTme[sb + lane64], cc[sb + lane64].batch_size, live, true);
+                  }
+                  e = 0; e_top = 0; e_in = 0; ++np;
+                  slot += d_len - 1;
+                  if (slot + 1 < P_stepped) nx = prefetch(next_comp());
+                }
+              }
+            }
+            // (the path below compares the expression's values: lp_curr must be one)
+            if (!sweep_certified && !lp_exact) { lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache); lp_exact = true; lpA = lp_curr; epsA = 0.0; }
+          }
+          if (sweep_certified) continue;
           const auto rows = Model::template prefetch_rows<kPassU>(cache, S, a.mc, a.d, data_lds, sub, sw_eval, a.d.pad);
           if (rows.ok && slot + d_len <= P_stepped) {
             // every lane holds its committed sum and its sum under its component's proposal: an update is the butterfly of the 64 sums with the
@@ -1160,6 +1214,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
               if (adapt[sb + lane64] != 0) adapt_component(sb + lane64, acc_l, CNTme[sb + lane64], cc[sb + lane64].batch_size, live, true);
             }
             Model::sweep_done(cache, rows, rows.comp >= 0 && ((acc_mask >> (rows.comp & 63)) & 1ull) != 0ull);
+            if constexpr (kCert) { lpA = lp_curr; epsA = 0.0; }
             // the walk moves past the parameter: its first component was handed out when the previous slot looked ahead
             e = 0; e_top = 0; e_in = 0; ++np;
             slot += d_len - 1;
@@ -1212,12 +1267,6 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       // shuffled), and what the stepper needs of it is requested NOW, under the evaluation below
       if (slot + 1 < P_stepped) nx = prefetch(next_comp());
       bool accepted = false;
-      // (sweep kernel, models that can tell: a proposal that moves only the lanes' start values and is REJECTED for certain -- a bound on what the
-      // evaluation could return says so -- is not evaluated: Model::surely_rejected)
-      bool pre_rejected = false;
-      if constexpr (kSweep && EarlyRejectOf<Model>::value) {
-        if (inb && !in_sweep && !a.sweep_update_by_update) pre_rejected = chain_true<G>(Model::surely_rejected(cache, S, a.mc, a.d, sub, comp, cur, u_accept, a.bound_scale));
-      }
       bool certified = false;
       if constexpr (kCert) {
         // (the model's pass is the WAVEFRONT's: with a lane per chain the 64 chains of a wave are evaluated together, every lane taking part whether its own
@@ -1238,11 +1287,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         }
       }
       if (certified) {
-      } else if (pre_rejected) {
-        set_state(comp, cur);
-        if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // an evaluated proposal, not accepted
-      } else
-      if (inb) {
+      } else if (inb) {
         if constexpr (kCert) {      // the cheap values could not decide: the expression, for the current state first if a cheap value has been standing in for it
           if (!lp_exact) { set_state(comp, cur); lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache); set_state(comp, prop); lp_exact = true; }
         }

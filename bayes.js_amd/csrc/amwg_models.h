@@ -496,10 +496,12 @@ struct HierNormalModel {
     // sum starts with (the lane's prior terms), the mean of its observations and the sd: together they determine the sum, bit for bit
     double a_start, a_mean, a_sd, a_T, b_start, b_mean, b_sd, b_T;
     bool a_recent;
+    // certified decisions (row layout; see log_post_approx below): this lane's sum of squares S2 = sum (y_i - mean)^2 over its row, with the mean it was formed for
+    double s2, s2_mean;
   };
   __device__ __forceinline__ static Cache cache_init() {
     const double nan = __builtin_nan("");
-    return Cache{norm_cache_init(), 0.0, 0.0, 0.0, 0.0, -1, false, false, nan, nan, 0.0, 0.0, 0.0, 0.0, 0.0, 0, nan, nan, nan, 0.0, nan, nan, nan, 0.0, false};
+    return Cache{norm_cache_init(), 0.0, 0.0, 0.0, 0.0, -1, false, false, nan, nan, 0.0, 0.0, 0.0, 0.0, 0.0, 0, nan, nan, nan, 0.0, nan, nan, nan, 0.0, false, 0.0, nan};
   }
   template <int GL>
   __device__ __forceinline__ static void load(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
@@ -789,55 +791,124 @@ struct HierNormalModel {
 #endif
     return out;
   }
-  // EARLY REJECTION of an update that moves nothing but the lanes' START values -- mu: the prior terms of theta and of mu itself (sweep kernel, amwg_kernel.h).
-  // Such a proposal leaves every lane's mean and sd alone: lane l's new sum is  start'_l + term_0 + term_1 + ...  over the SAME terms as its committed sum
-  // start_l + term_0 + ..., so as real numbers log_post(proposal) - log_post(current) = D = sum over the lanes of (start'_l - start_l), without a pass over the
-  // data.  What the stepper would compute differs from D by the roundings of the two sequential sums of every lane and of the two butterflies:
-  //     a sequential sum s_i = fl(s_(i-1) + t_i) of n terms is within  n 2^-53 max|s_i|  of the real one, and with t_i = c - q_i, q_i >= 0, every partial
-  //     sum lies between combinations of start, i c and the q's:  max|s_i| <= 2|start| + 2 n |c| + |T|   (T: the lane's final sum);
-  //     a butterfly of 64 values is within 6 x 2^-53 x (sum of their magnitudes) of the real sum.
-  // With eps the sum of those bounds and eta = 1.0625 eps + 2^-49 (V8's exp is within an ulp of exp), exp(D) (1 + eta) < u proves that the stepper's own
-  // test exp(prop_lp - lp_curr) > u fails: the update is REJECTED, and a rejected update leaves nothing behind but its counters -- the pass (a third of a
-  // step's arithmetic, more than half of mu's proposals) is not made.  Anything else -- acceptance, a uniform inside the sliver, sums not in the cache,
-  // non-finite values -- takes the ordinary evaluation.  (options.full_evaluation = 2 switches this off together with the all-at-once sweep decisions.)
-  static constexpr bool kEarlyReject = true;
-  // (out of line: two butterflies and an exponential that run once per step; inlined they cost the step loop a spilled register)
-  __device__ inline __attribute__((noinline)) static bool rejection_is_certain(double start_cur, double start_new, double T, double n_l, double c_abs, double u, double bound_scale) {
-    const double dl = start_new - start_cur;
-    const double D = butterfly<1, 64>(dl);
-    const double span = 2.0 * (__builtin_fabs(start_cur) + __builtin_fabs(start_new)) + 4.0 * n_l * c_abs + 2.0 * __builtin_fabs(T) + __builtin_fabs(dl);      // both sums' max|s_i|
-    const double leaf = __builtin_fabs(T) + __builtin_fabs(dl);                                                   // a bound on both butterflies' inputs (per lane)
-    const double e_l = ((n_l + 2.0) * span + 12.0 * (leaf + (n_l + 2.0) * span * 0x1p-50)) * 0x1p-53;
-    const double eps = butterfly<1, 64>(e_l) * 1.0625 + __builtin_fabs(D) * 0x1p-51;
-    const double eta = (eps * 1.0625 + 0x1p-49) * bound_scale;
-    const double ex = exp_v8(D);
-    return eta < 0x1p-7 && ex * (1.0 + eta) < u;      // (NaN anywhere: false)
+  // CERTIFIED DECISIONS in the row layout (the sweep kernel; amwg_kernel.h).  A lane's sum as a real number is
+  //     start + n_l c - S2 / den,      S2 = sum over its row of (y_i - mean)^2
+  // and S2 depends on the lane's MEAN only: neither sigma's nor mu's update needs a pass over the data (c, den and the start values are a handful of
+  // operations), and a sweep over theta needs the S2 of the proposed means -- two operations per observation (sub, fma) instead of the eight of the term.
+  // Bounds, u = 2^-53, per lane m_l = |start| + n_l |c| + Q_l (Q_l = S2 / den >= 0), M = their sum over the wavefront: the expression's lane sum (start, then n_l
+  // terms c - RN(tt / den) added in order) is within (n_l + 2) u m_l of the real number, the value here within (n_l / 4 + 9) u m_l (four partial sums of non-negative
+  // terms, exact squares inside the fma, 1 / den correctly rounded, n_l c and two additions), each butterfly within 6 u M:
+  //     a value of log_post:      eps = u M (2 n_l + 40) 1.25
+  //     a difference of two (the sweep's D_c, which also leaves out the lanes that do not change):   eps = u M (3 n_l + 48) 1.25,  M over max(m_l, m_l')
+  static constexpr bool kCertified = true;
+  static constexpr int kCertifiedLanes = 64;
+  static constexpr bool kCertifiedNeedsRows = true;      // (only the sweep kernel: the row tile is what the S2 pass reads)
+  struct Approx { double value, eps; };
+  // S2 of this lane's row for `mean`: four interleaved partial sums (the order is free: the value is used with its bound)
+  __device__ __forceinline__ static double rows_sq(const double *row, double mean, int n_obs, int sub) {
+    const int n_full = n_obs >> 6, rem = n_obs & 63;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int r = 0;
+    for (; r + 8 <= n_full; r += 8) {
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = row[r + u];
+      AMWG_STAGE_FENCE();
+      { const double t = x[0] - mean; a0 = __builtin_fma(t, t, a0); }
+      { const double t = x[1] - mean; a1 = __builtin_fma(t, t, a1); }
+      { const double t = x[2] - mean; a2 = __builtin_fma(t, t, a2); }
+      { const double t = x[3] - mean; a3 = __builtin_fma(t, t, a3); }
+      { const double t = x[4] - mean; a0 = __builtin_fma(t, t, a0); }
+      { const double t = x[5] - mean; a1 = __builtin_fma(t, t, a1); }
+      { const double t = x[6] - mean; a2 = __builtin_fma(t, t, a2); }
+      { const double t = x[7] - mean; a3 = __builtin_fma(t, t, a3); }
+    }
+    for (; r < n_full; ++r) { const double t = row[r] - mean; a0 = __builtin_fma(t, t, a0); }
+    if (sub < rem) { const double t = row[n_full] - mean; a1 = __builtin_fma(t, t, a1); }
+    return (a0 + a1) + (a2 + a3);
+  }
+  // ... the committed mean's S2, from the cache when the mean has not changed (every lane takes part: a wavefront-uniform call)
+  __device__ __forceinline__ static double lane_s2(Cache &k, const unsigned char *smem, double mean, const DataRef &d, int sub) {
+    const bool stale = f64_bits(mean) != f64_bits(k.s2_mean);
+    if (__ballot(stale) != 0ull) {
+      const double v = rows_sq(reinterpret_cast<const double *>(smem) + (size_t)sub * d.pad, mean, d.n_obs, sub);
+      if (stale) { k.s2 = v; k.s2_mean = mean; }
+    }
+    return k.s2;
+  }
+  struct ApproxLane { double value, mag; };      // this lane's start + n_l c - Q and |start| + n_l |c| + Q
+  __device__ __forceinline__ static ApproxLane approx_lane(const Cache &k, double start, double s2, const DataRef &d, int sub) {
+    const double n_l = (double)((d.n_obs >> 6) + (sub < (d.n_obs & 63) ? 1 : 0));
+    const double q = s2 * k.n.y.hi, nc = n_l * k.n.c;
+    return ApproxLane{(start + nc) - q, __builtin_fabs(start) + __builtin_fabs(nc) + q};
+  }
+  __device__ __forceinline__ static double value_bound(double M, const DataRef &d) { return M * (2.0 * (double)((d.n_obs >> 6) + 1) + 40.0) * 1.25 * 0x1p-53; }
+  __device__ __forceinline__ static double difference_bound(double M, const DataRef &d) { return M * (3.0 * (double)((d.n_obs >> 6) + 1) + 48.0) * 1.25 * 0x1p-53; }
+  // log_post of the state as it stands (the stepper has stored its proposal), cheaply: mu's and sigma's updates (no pass: every lane's mean is the cached one),
+  // any other update of the ordinary stepper (the lanes whose mean changed re-form their S2)
+  template <int G, int BT>
+  __device__ __forceinline__ static Approx log_post_approx(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    load<G>(k, S, mc, d, smem, sub);
+    if (!k.regs || d.pad <= 0) return Approx{0.0, __builtin_inf()};      // (wave-uniform: not the row layout with the register mirror -- the expression)
+    norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);
+    const double pr = prior(S, mc, d, k);
+    const double start = start_value(k, k.mu, pr, sub, d);
+    const double s2 = lane_s2(k, smem, k.th_pass, d, sub);
+    const ApproxLane a = approx_lane(k, start, s2, d, sub);
+    const double value = butterfly<1, 64>(a.value), M = butterfly<1, 64>(a.mag);
+    return Approx{value, value_bound(M, d)};
+#else
+    return Approx{0.0, __builtin_inf()};
+#endif
+  }
+  // the sweep: every lane's value now and under its entry's proposal (lane c < groups holds the proposal of theta_c, as for prefetch_rows)
+  struct SweepApprox { bool ok; int comp; double cur, neu, mag, mean_new, s2_new; };
+  __device__ __forceinline__ static SweepApprox sweep_approx(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub, double prop_own) {
+    SweepApprox out{false, -1, 0.0, 0.0, 0.0, 0.0, 0.0};
+#if defined(__HIP_DEVICE_COMPILE__)
+    load<64>(k, S, mc, d, smem, sub);
+    if (!k.regs || d.pad <= 0) return out;      // (wave-uniform)
+    norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);
+    const double own = sub < d.G ? prop_own : k.th_own;
+    double mean = 0.0;
+    {
+      const int src = (k.my_group >= 0 ? k.my_group : sub) << 2;
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(f64_bits(prop_own) >> 32)), lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)f64_bits(prop_own));
+      mean = k.my_group >= 0 ? bits_f64(((uint64_t)hi << 32) | (uint64_t)lo) : 0.0;
+    }
+    // (a lane that holds a term of theta's prior must have that same entry as its group: its value then depends on ONE entry)
+    const bool one_comp = !(sub < d.G && k.my_group >= 0 && k.my_group != sub);
+    if (__ballot(one_comp) != ~0ull) return out;
+    const double pr = prior(S, mc, d, k);
+    Cache k2 = k;
+    k2.th_own = own;
+    const double start_new = prior_split<64>(S, mc, d, sub, (sub == 0) ? pr : 0.0, k2);
+    const double start_cur = prior_split<64>(S, mc, d, sub, (sub == 0) ? pr : 0.0, k);
+    const double s2_cur = lane_s2(k, smem, k.th_pass, d, sub);
+    const double s2_new = rows_sq(reinterpret_cast<const double *>(smem) + (size_t)sub * d.pad, mean, d.n_obs, sub);
+    const ApproxLane c0 = approx_lane(k, start_cur, s2_cur, d, sub), c1 = approx_lane(k, start_new, s2_new, d, sub);
+    out.ok = true;
+    out.comp = k.my_group >= 0 ? k.my_group : (sub < d.G ? sub : -1);
+    out.cur = c0.value; out.neu = c1.value;
+    out.mag = c0.mag > c1.mag ? c0.mag : c1.mag;
+    out.mean_new = mean; out.s2_new = s2_new;
+#endif
+    return out;
+  }
+  // ... and what the accepted entries leave behind in this lane: the register mirror (as sweep_commit_all) and the S2 that goes with the new mean
+  __device__ __forceinline__ static void sweep_approx_commit(Cache &k, const SweepApprox &sa, uint64_t acc_mask, bool mine, double prop_own, int sub, const DataRef &d) {
+    const bool own = sub < d.G && ((acc_mask >> (sub & 63)) & 1ull) != 0ull;
+    k.th_own = own ? prop_own : k.th_own;
+    const bool grp = k.my_group >= 0 && mine;
+    k.th_pass = grp ? sa.mean_new : k.th_pass;
+    k.s2 = grp ? sa.s2_new : k.s2;
+    k.s2_mean = grp ? sa.mean_new : k.s2_mean;
   }
   __device__ __forceinline__ static double start_value(const Cache &k, double mu, double pr, int sub, const DataRef &d) {      // prior_split for the register mirror, mu given
     double acc = (sub == 0) ? pr : 0.0;
     if (sub < d.G) acc += norm_const_sd(k.th_own, mu, k.c1, k.den1, k.y1h, k.y1l, k.den1_ok);
     return acc;
-  }
-  __device__ __forceinline__ static bool surely_rejected(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, int sub, int comp, double old_value, double u, double bound_scale) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (comp != d.G || !k.loaded || !k.regs || d.pad <= 0) return false;      // (wave-uniform: mu, the register mirror in use, the row layout)
-    norm_cache_update<true>(k.n, k.sigma, mc.neg_half_log_2pi);               // (what the next evaluation needs in any case)
-    const double sd = k.n.sd;
-    const bool pr_cached = f64_bits(k.pr_mu) == f64_bits(old_value) && f64_bits(k.pr_sigma) == f64_bits(k.sigma);
-    const double pr_old = pr_cached ? k.pr_val : prior_mu_sigma_cold(old_value, k.sigma);
-    const double start_cur = start_value(k, old_value, pr_old, sub, d);
-    const double pr_new = prior(S, mc, d, k);      // (k.mu is the proposal: the stepper has stored it; this fills the cache for the evaluation that follows a "no")
-    const double start_new = start_value(k, k.mu, pr_new, sub, d);
-    const bool hitA = f64_bits(start_cur) == f64_bits(k.a_start) && f64_bits(k.th_pass) == f64_bits(k.a_mean) && f64_bits(sd) == f64_bits(k.a_sd);
-    const bool hitB = f64_bits(start_cur) == f64_bits(k.b_start) && f64_bits(k.th_pass) == f64_bits(k.b_mean) && f64_bits(sd) == f64_bits(k.b_sd);
-    if (__ballot(!(hitA || hitB)) != 0ull) return false;      // the committed sums are not all in the cache
-    const double n_l = (double)((d.n_obs >> 6) + (sub < (d.n_obs & 63) ? 1 : 0));
-    const bool sure = rejection_is_certain(start_cur, start_new, hitA ? k.a_T : k.b_T, n_l, __builtin_fabs(k.n.c), u, bound_scale);
-    if (sure) { k.pr_mu = old_value; k.pr_val = pr_old; }        // the stepper puts the old mu back: so is its prior
-    return sure;
-#else
-    return false;
-#endif
   }
   // the accepted entries of a sweep decided all at once (amwg_kernel.h): what on_set does for one store, for every accepted entry -- bit c of acc_mask: entry c
   __device__ __forceinline__ static void sweep_commit_all(Cache &k, const SweepRows &r, uint64_t acc_mask, double prop_own, int sub, const DataRef &d) {

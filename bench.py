@@ -66,18 +66,32 @@ def roofline_units(fam, lane_ops_per_s, ops_per_obs):
     return out
 
 
-HIER_SWEEP_PASSES = 3      # amwg_sweep_kernel: one pass for the whole sweep over theta, one for mu, one for sigma (csrc/amwg_models.h prefetch_rows)
+HIER_SWEEP_PASSES = 1      # amwg_sweep_kernel with certified decisions (round 5): ONE pass per step -- the sweep's sums of squares about the proposed means; neither
+HIER_SWEEP_OPS = 2         # mu's nor sigma's update reads the data (a lane's sum of squares depends on its mean only) -- of 2 operations per observation (sub, fma)
 
 
-def sweep_lane_ops(updates_per_s, P, n_obs, ops_per_obs):
-    """fp64 lane-operations/s of the hierarchical family's sweep kernel: a Sampler.step of P updates makes HIER_SWEEP_PASSES passes over the data (not P),
-    each n_obs x ops_per_obs; the stepper's own arithmetic (proposals, butterflies, accept tests) is not counted as algorithmic work."""
-    return updates_per_s / P * HIER_SWEEP_PASSES * n_obs * ops_per_obs
+def sweep_lane_ops(updates_per_s, P, n_obs):
+    """fp64 lane-operations/s of the hierarchical family's sweep kernel: a Sampler.step of P updates makes HIER_SWEEP_PASSES pass(es) over the data (not P), each
+    n_obs x HIER_SWEEP_OPS; the stepper's own arithmetic (proposals, butterflies, accept tests) is not counted as algorithmic work."""
+    return updates_per_s / P * HIER_SWEEP_PASSES * n_obs * HIER_SWEEP_OPS
 
 
-SWEEP_NOTE = ("roofline of the kernel that produces `value` (%s): a step of %d updates = 3 passes over the data (the sweep over theta, mu, sigma) x %d observations x 8 fp64 "
-              "operations; everything else the kernel issues (32 butterflies + accept tests, the window stream, proposals) is overhead against this roof.  The kernel that "
-              "passes over all the data in EVERY update (options.full_evaluation = 1) runs at %.3g param-updates/s, %.3f of the same roof in its own unit (one pass per update)")
+HIER_SWEEP_OPS_NOTE = ("2 = sub, fma: the sweep kernel's one pass per step forms every lane's sum of squares about the proposed mean of its group; the accept tests of the whole step "
+                       "(32 theta, mu, sigma) are decided from those sums with a rigorous bound on their distance from the reference's term-by-term expression (8 operations per "
+                       "observation), which is evaluated when a uniform falls inside the bound and once per launch and chain; every draw bit-identical to the reference's")
+
+
+def sweep_roofline_units(lane_ops_per_s):
+    return {"frac_issue": lane_ops_per_s / FP64_VALU_PEAK, "frac_survey_flops": lane_ops_per_s / HIER_SWEEP_OPS * 3 / FP64_FLOPS_PEAK,
+            "survey_flops_note": "the certified pass in flops (a sub and an fma per observation = 3, an FMA = 2) against 78.6 TFLOP/s"}
+
+
+SWEEP_NOTE = ("roofline of the kernel that produces `value` (%s): since it decides from certified sums (csrc/amwg_models.h HierNormalModel::sweep_approx / log_post_approx) a step of "
+              "%d updates reads the data ONCE -- the sweep's sums of squares about the proposed means, %d observations x 2 fp64 operations; mu's and sigma's updates need no pass "
+              "(a lane's sum of squares depends on its mean only).  Against that arithmetic the kernel is far from the fp64 roof BY CONSTRUCTION: what it issues is the stepper "
+              "(~2 500 vector + ~1 800 scalar instructions per step-wave, profiles/), two wavefronts per SIMD, latency bound (valu_pipe_busy 0.44).  The kernel that passes over "
+              "all the data in EVERY update (options.full_evaluation = 1, the reference's expression) runs at %.3g param-updates/s, %.3f of the roof in its own unit (8 operations "
+              "per observation, one pass per update)")
 
 
 def normal_spec():
@@ -452,6 +466,7 @@ def measure_other_config(A, name, device, group_local=0):
         kernel += " term-by-term pass (exact_division = 1)"
         note = ("roofline = the term-by-term pass (1 fp64 add per observation), %.3g param-updates/s; `value` is the exact fast-forward of the same two-valued "
                 "sum (bit-identical), which does not stream the data" % roof_updates_per_s)
+    sweep_kernel = False
     if name == "cfg4" and not group_local:
         # by default only the lanes whose sum an update can have changed are re-formed (csrc/amwg_models.h lane_sum_rows: bit-identical to evaluating
         # everything, like the cached log_post of the current state), so `value` no longer streams the data once per update: the roofline figure is
@@ -469,6 +484,7 @@ def measure_other_config(A, name, device, group_local=0):
             kernel = li["kernel"]
             note = SWEEP_NOTE % (kernel, P, n_obs, roof_updates_per_s, out["full_evaluation_frac"])
             roof_updates_per_s = None
+            sweep_kernel = True
         else:
             kernel += " with options.full_evaluation = 1"
             note = "roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s" % roof_updates_per_s
@@ -484,7 +500,7 @@ def measure_other_config(A, name, device, group_local=0):
         t.close()
         ops_per_obs, ops_note = CERTIFIED_GLM_OPS_PER_OBS, CERTIFIED_GLM_NOTE
         kernel = li.get("kernel", kernel) + " (certified decisions)"
-    lane_ops = sweep_lane_ops(value, P, n_obs, ops_per_obs) if roof_updates_per_s is None else roof_updates_per_s * n_obs * ops_per_obs
+    lane_ops = sweep_lane_ops(value, P, n_obs) if roof_updates_per_s is None else roof_updates_per_s * n_obs * ops_per_obs
     if group_local:
         # group-local evaluation: a step of the P = G + 2 updates makes TWO passes over the data (the sweep over theta and the sigma update)
         # instead of P; the fp64 work per update is what those two passes do, not one pass per update
@@ -497,7 +513,10 @@ def measure_other_config(A, name, device, group_local=0):
     out["roofline"] = {"bound": "fp64_valu", "achieved": lane_ops, "peak": FP64_VALU_PEAK, "frac": lane_ops / FP64_VALU_PEAK, "unit": "fp64 lane-operations/s",
                        "lane_ops_per_obs": ops_per_obs, "lane_ops_note": ops_note, "kernel": kernel, "note": note,
                        "effective_hbm_gbps": value * b_alg / 1e9}
-    out["roofline"].update(roofline_units(fam, lane_ops, ops_per_obs))
+    if sweep_kernel:
+        out["roofline"].update(lane_ops_per_obs=HIER_SWEEP_OPS, lane_ops_note=HIER_SWEEP_OPS_NOTE, **sweep_roofline_units(lane_ops))
+    else:
+        out["roofline"].update(roofline_units(fam, lane_ops, ops_per_obs))
     if lanes > 1 and not group_local:
         out["reference_order"] = reference_order_price(A, name, spec, device)
         if "value" in out["reference_order"]:
@@ -599,7 +618,7 @@ def main_inproc(args):
     collection["bytes"] = sum(s._pending * s.PR * s.C * 8 for s in shards)
     comm = A.group_comm_info(shards)
     sweep = str(li.get("kernel", "")).startswith("amwg_sweep_kernel")
-    lane_ops = sweep_lane_ops(value, P, n_obs, ops_per_obs) if sweep else value * n_obs * ops_per_obs * ((2.0 / P) if args.group_local else 1.0)
+    lane_ops = sweep_lane_ops(value, P, n_obs) if sweep else value * n_obs * ops_per_obs * ((2.0 / P) if args.group_local else 1.0)
     out = dict(base, value=value, ms_per_step=dt * 1e3 / K,
                config={"workload": label + (" -- GROUP-LOCAL evaluation" if args.group_local else ""), "n_obs": n_obs, "chains_total": total,
                        "chains_per_gpu": [s.C for s in shards], "components": P, "thin": thin, "lanes_per_chain": li["lanes_per_chain"],
@@ -609,8 +628,9 @@ def main_inproc(args):
                timing={"regions": len(regs), "reported": "median region (wall clock around sample_async x N + sync x N + group_gather_draws + group_moments)",
                        "region_ms": [r[0] * 1e3 for r in regs][:64], "slowest_device_kernel_ms_last_region": kernel_ms},
                roofline={"bound": "fp64_valu", "achieved": lane_ops, "peak": FP64_VALU_PEAK * N, "frac": lane_ops / (FP64_VALU_PEAK * N),
-                         "unit": "fp64 lane-operations/s", "lane_ops_per_obs": ops_per_obs, "lane_ops_note": OPS_NOTE[spec["model"]], "kernel": li.get("kernel"),
-                         "note": ("the sweep kernel: three passes over the data per step of %d updates" % P) if sweep else None},
+                         "unit": "fp64 lane-operations/s", "lane_ops_per_obs": HIER_SWEEP_OPS if sweep else ops_per_obs,
+                         "lane_ops_note": HIER_SWEEP_OPS_NOTE if sweep else OPS_NOTE[spec["model"]], "kernel": li.get("kernel"),
+                         "note": ("the sweep kernel: one certified 2-operation pass over the data per step of %d updates" % P) if sweep else None},
                posterior={"mean": mean.tolist()[:8], "sd": sd.tolist()[:8], "note": "amwg_group_moments over the recorded draws of all shards (last region)"})
     emit(out)
     for s in shards:
@@ -994,9 +1014,10 @@ def main():
         lane_ops = roof_updates * n_obs * ops_per_obs / roof_launch_s
         if str(kernel).startswith("amwg_sweep_kernel"):
             # `value` and `frac` describe the same kernel: the sweep kernel against the arithmetic of its three passes per step
-            lane_ops = sweep_lane_ops(roof_updates / roof_launch_s, P, n_obs, ops_per_obs)
+            lane_ops = sweep_lane_ops(roof_updates / roof_launch_s, P, n_obs)
             fe = full_eval or {"value": float("nan"), "frac": float("nan")}
             roof_note = SWEEP_NOTE % (kernel, P, n_obs, fe["value"], fe["frac"])
+            ops_per_obs, ops_note = HIER_SWEEP_OPS, HIER_SWEEP_OPS_NOTE
         if args.group_local:
             lane_ops *= 2.0 / P          # two passes per step of P updates (see measure_other_config)
             label += " -- GROUP-LOCAL evaluation (opt-in; not the reference's operation schedule)"
@@ -1036,7 +1057,8 @@ def main():
             "posterior": {"mean": mean.tolist()[:8], "sd": sd.tolist()[:8], "data_mean": float(np.mean(x)), "data_sd": float(np.std(x, ddof=1)),
                           "note": "moments over the recorded draws of the last region on ALL ranks (all-reduce of per-rank sums for N > 1; after %d warm-up + %d timed steps)" % (W, K * (len(regions) - 1))},
         }
-        out["roofline"].update(roofline_units(spec["model"], lane_ops, ops_per_obs) if not certified else
+        out["roofline"].update(sweep_roofline_units(lane_ops) if str(kernel).startswith("amwg_sweep_kernel") else
+                               roofline_units(spec["model"], lane_ops, ops_per_obs) if not certified else
                                {"frac_issue": lane_ops / FP64_VALU_PEAK, "frac_survey_flops": (roof_updates / roof_launch_s) * n_obs * (3 if ckind == "normal" else 50) / FP64_FLOPS_PEAK,
                                 "survey_flops_note": "the certified pass in flops (an FMA = 2) against 78.6 TFLOP/s: a sub and an fma per observation = 3 (Normal); 8 + 21 fmas = 50 (Poisson)"})
         import build_id

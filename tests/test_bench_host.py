@@ -125,8 +125,8 @@ def test_flip_rate_of_a_campaign_run_with_other_kernels_is_refused(tmp_path, mon
     assert "refused" in line["parity"]["flip_rate"]
 
 
-def test_sweep_kernel_roofline_counts_three_passes_per_step():
+def test_sweep_kernel_roofline_counts_one_certified_pass_per_step():
     import bench
-    # 1.6e9 updates/s of the 34-component model over 1e4 observations: 4.7e7 steps/s x 3 passes x 1e4 x 8 operations
-    ops = bench.sweep_lane_ops(1.6e9, 34, 10_000, 8)
-    assert abs(ops - 1.6e9 / 34 * 3 * 10_000 * 8) < 1 and 0.25 < ops / bench.FP64_VALU_PEAK < 0.35
+    # 3.4e9 updates/s of the 34-component model over 1e4 observations: 1e8 steps/s x 1 pass (the sweep's sums of squares; mu and sigma read no data) x 1e4 x 2 operations
+    ops = bench.sweep_lane_ops(3.4e9, 34, 10_000)
+    assert abs(ops - 3.4e9 / 34 * 1 * 10_000 * 2) < 1 and 0.04 < ops / bench.FP64_VALU_PEAK < 0.08

@@ -57,10 +57,10 @@ def test_default_line_has_the_contract_fields_and_an_honest_roofline():
         assert o["value"] > 0 and 0 < o["roofline"]["frac"] < 1 and o["parity"]["accept_counts_identical"] and o["parity"]["uniforms_consumed_identical"]
         assert q["value"] > 0 and 0 < q["frac"] < 1 and q["parity_ok"] is True
     assert full["other_configs"]["cfg3"]["parity"]["draws_bit_identical"] is True
-    # cfg4: `value` and `frac` describe the SAME kernel (the sweep kernel against its three passes per step); the price of strict reference order beside it
+    # cfg4: `value` and `frac` describe the SAME kernel (the sweep kernel against its one certified 2-operation pass per step); the price of strict reference order beside it
     c4 = full["other_configs"]["cfg4"]
     assert c4["roofline"]["kernel"].startswith("amwg_sweep_kernel") and c4["value_kernel"] == c4["roofline"]["kernel"]
-    assert abs(c4["roofline"]["achieved"] - c4["value"] / 34 * 3 * 10000 * 8) < 1e-6 * c4["roofline"]["achieved"] and 0 < c4["full_evaluation_frac"] < 1
+    assert abs(c4["roofline"]["achieved"] - c4["value"] / 34 * 1 * 10000 * 2) < 1e-6 * c4["roofline"]["achieved"] and 0 < c4["full_evaluation_frac"] < 1
     assert d["other_configs"]["cfg4"]["kernel"].startswith("amwg_sweep_kernel")
     for name in ("cfg4", "cfg5"):
         ro = full["other_configs"][name]["reference_order"]
@@ -68,9 +68,9 @@ def test_default_line_has_the_contract_fields_and_an_honest_roofline():
         assert ro["lanes_per_chain"] == 1 and 0 < ro["value"] and d["other_configs"][name]["reference_order_value"] > 0
     fr = full["parity"]["flip_rate"]
     assert ("refused" in fr) != ("flips_per_1e9" in fr)      # a campaign of other kernels is refused, not quoted
-    # (cfg4's default is the sweep kernel since round 4 -- the reference's schedule with three passes per step: the opt-in group-local evaluation is
-    # less than 2x ahead of it, and > 5x ahead of the kernel that evaluates everything)
-    assert full["other_configs"]["cfg4_group_local"]["speedup_over_cfg4"] > 1.05      # (round 5: the default's sweeps are decided all at once -- 1.23x left)
+    # (cfg4's default is the sweep kernel since round 4 -- the reference's schedule; since it decides from certified sums (round 5: one 2-operation pass per step) the
+    # opt-in group-local evaluation, two 8-operation passes per step, is BEHIND it: measured and reported, no longer a speed-up)
+    assert 0.5 < full["other_configs"]["cfg4_group_local"]["speedup_over_cfg4"] < 1.0
     assert full["other_configs"]["cfg4"]["value"] > 2.5 * full["other_configs"]["cfg4"]["full_evaluation_value"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "param-updates/s" and c["sample"]
