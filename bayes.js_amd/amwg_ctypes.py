@@ -46,7 +46,7 @@ class UserModel(C.Structure):
                 ("rows_n_obs", C.c_int32), ("rows_groups", C.c_int32), ("rows_sweep", C.c_int32)]
 
 
-EXPORTS = ["amwg_kernel_name", "amwg_group_gather_draws", "amwg_group_comm_info", "amwg_comm_unique_id", "amwg_comm_create", "amwg_comm_info", "amwg_comm_gather_draws", "amwg_comm_moments", "amwg_comm_destroy", "amwg_code_cache_stats", "amwg_tuning", "amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_fetch_draws_slices", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state", "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components", "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp", "amwg_log", "amwg_uniform"]      # include/amwg.h: the product library
+EXPORTS = ["amwg_kernel_name", "amwg_summation_order", "amwg_group_gather_draws", "amwg_group_comm_info", "amwg_comm_unique_id", "amwg_comm_create", "amwg_comm_info", "amwg_comm_gather_draws", "amwg_comm_moments", "amwg_comm_destroy", "amwg_code_cache_stats", "amwg_tuning", "amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_fetch_draws_slices", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state", "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components", "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp", "amwg_log", "amwg_uniform"]      # include/amwg.h: the product library
 SELFTEST_EXPORTS = ["amwg_math1", "amwg_math2", "amwg_hypot3", "amwg_log1p", "amwg_expm1", "amwg_two_valued_sum_check", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_device_eval"]      # include/amwg_selftest.h: libamwg_selftest.so only
 
 _lib = None
@@ -81,6 +81,7 @@ def lib():
         L.amwg_num_chains.restype = i64
         L.amwg_launch_info.argtypes = [vp, pi32, pi32, pi32, pi32, pi32, pd]
         L.amwg_kernel_name.argtypes = [vp]
+        L.amwg_summation_order.argtypes = [vp]
         L.amwg_kernel_name.restype = C.c_char_p
         L.amwg_destroy.argtypes = [vp]
         L.amwg_last_error.restype = C.c_char_p
@@ -356,7 +357,8 @@ class Sampler:
         ms = C.c_double()
         _check(lib().amwg_launch_info(self.h, *[C.byref(x) for x in v], C.byref(ms)))
         return {"lanes_per_chain": v[0].value, "block_threads": v[1].value, "grid_blocks": v[2].value,
-                "lds_bytes": v[3].value, "n_launches": v[4].value, "kernel_ms": ms.value, "kernel": (lib().amwg_kernel_name(self.h) or b"").decode()}
+                "lds_bytes": v[3].value, "n_launches": v[4].value, "kernel_ms": ms.value, "kernel": (lib().amwg_kernel_name(self.h) or b"").decode(),
+                "summation_order": lib().amwg_summation_order(self.h)}
 
 
 def _group(samplers):

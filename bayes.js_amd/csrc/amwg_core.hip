@@ -1636,6 +1636,13 @@ int amwg_launch_info(const amwg_sampler *s, int32_t *lanes, int32_t *block, int3
   return AMWG_OK;
 }
 
+int amwg_summation_order(const amwg_sampler *s) {
+  if (!s) return fail(AMWG_EINVAL, "amwg_summation_order: null sampler");
+  // (the certified kernels of the Poisson and the hierarchical family evaluate the expression in the reference's order: amwg_kernel.h kRefOrder)
+  if (s->lanes > 1 && certified_kernel(s) && (s->model == AMWG_MODEL_POIS_GLM || s->model == AMWG_MODEL_HIER_NORMAL)) return 1;
+  return s->lanes;
+}
+
 const char *amwg_kernel_name(const amwg_sampler *s) {
   if (!s) { (void)fail(AMWG_EINVAL, "amwg_kernel_name: null sampler"); return ""; }
   amwg_sampler *m = const_cast<amwg_sampler *>(s);

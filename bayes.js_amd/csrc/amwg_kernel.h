@@ -126,6 +126,11 @@ template <class M, int G> struct CertifiedAt<M, G, void_of<decltype(M::kCertifie
 template <class M, class = void> struct CertNeedsRows { static constexpr bool value = false; };
 template <class M> struct CertNeedsRows<M, void_of<decltype(M::kCertifiedNeedsRows)>> { static constexpr bool value = M::kCertifiedNeedsRows; };
 
+// ... and can the model evaluate the expression in the REFERENCE's order (one running sum) at this lane count (Model::kReferenceOrder, reference_order)?  Then the
+// certified kernels decide against THAT expression: accept counts identical to the reference's whatever the lane count
+template <class M, class = void> struct RefOrderOf { static constexpr bool value = false; };
+template <class M> struct RefOrderOf<M, void_of<decltype(M::kReferenceOrder)>> { static constexpr bool value = M::kReferenceOrder; };
+
 template <class M, class = void> struct OwnPassOf { static constexpr bool value = false; };
 template <class M> struct OwnPassOf<M, void_of<decltype(M::kOwnPass)>> { static constexpr bool value = M::kOwnPass; };
 
@@ -633,7 +638,17 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   else rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid);
   double lp_curr = a.ch.lp_curr[cl];
   __syncthreads();
-  if constexpr (!GL) { if (a.init_lp) lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache); }  // ctor warm-up call, mcmc.js:961-963 (the group-local kernel forms it from its pieces below, in every launch)
+  constexpr bool kCert = CertifiedAt<Model, G>::value && !GL && (SW == CertNeedsRows<Model>::value);      // (certified decisions, below.  One lane per chain: the Normal family; 16 lanes: the Poisson family; the sweep kernel: the hierarchical family)
+  // THE EXPRESSION: log_post of the state as it stands, term by term.  In the lane order of this geometry (log_post above: G per-lane sums and a butterfly) -- or, in
+  // the certified kernels of models that can (Model::reference_order), as ONE running sum in the reference's own order: slow (every term passes through a
+  // cross-lane broadcast), but it runs for ~1e-7 of the updates, and it makes what these kernels decide and store the REFERENCE's at every lane count.
+  constexpr bool kRefOrder = kCert && G > 1 && RefOrderOf<Model>::value;
+  auto expression = [&]() -> double {
+    if constexpr (kRefOrder) { if (a.certified) return Model::template reference_order<G>(cache, S, a.mc, a.d, data_lds, sub); }
+    if constexpr (!GL) return log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);
+    else return 0.0;      // (the group-local kernel forms log_post from its pieces)
+  };
+  if constexpr (!GL) { if (a.init_lp) lp_curr = expression(); }  // ctor warm-up call, mcmc.js:961-963 (the group-local kernel forms it from its pieces below, in every launch)
   // CERTIFIED DECISIONS (models with Model::log_post_approx; one lane per chain).  The accept test Math.exp(prop_lp - lp_curr) > u (mcmc.js:527-528) needs the
   // two values only as far as they decide the comparison.  The model hands back a cheaper value of log_post together with a bound on its distance from what
   // the reference's expression gives (the Normal family: prior + n c - sum (x - mu)^2 / den, two operations per observation instead of eight); the
@@ -644,7 +659,6 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // both states if need be; and whatever is stored, returned or compared -- lp_curr at the end of every launch, the ctor's value -- is the expression's.
   // Every decision, hence every draw, is the one the term-by-term evaluation makes (tests: the reference goldens, bit for bit, and the same sampler with
   // options.full_evaluation = 1, which evaluates the expression in every update).
-  constexpr bool kCert = CertifiedAt<Model, G>::value && !GL && (SW == CertNeedsRows<Model>::value);      // (one lane per chain: the Normal family; 16 lanes: the Poisson family; the sweep kernel: the hierarchical family)
   // (between launches the pair travels in ChainArrays::lp_curr / lp_eps: a launch does not close with an evaluation of the expression unless the host
   // asks for its value -- StepArgs::finalize_lp, amwg_chain_diag)
   double lpA = lp_curr, epsA = 0.0;      // the cheap value of log_post(current state) and its bound (0: lp_curr itself)
@@ -1149,12 +1163,17 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
                 }
               }
             }
-            // (the path below compares the expression's values: lp_curr must be one)
-            if (!sweep_certified && !lp_exact) { lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache); lp_exact = true; lpA = lp_curr; epsA = 0.0; }
+            // (the path below compares the expression's values in this geometry's lane order: lp_curr must be one)
+            if (!sweep_certified && !lp_exact && !(kRefOrder && a.certified)) { lp_curr = expression(); lp_exact = true; lpA = lp_curr; epsA = 0.0; }
           }
           if (sweep_certified) continue;
-          const auto rows = Model::template prefetch_rows<kPassU>(cache, S, a.mc, a.d, data_lds, sub, sw_eval, a.d.pad);
-          if (rows.ok && slot + d_len <= P_stepped) {
+          // (deciding against the reference's order: a sweep that is not certified as a whole is walked update by update -- each update certified on its own or
+          // decided by the expression in that order; the lanes' sums in THIS geometry's order, which the path below compares, are not what is compared then)
+          const bool by_sums = !(kRefOrder && a.certified);
+          using SweepRowsT = decltype(Model::template prefetch_rows<kPassU>(cache, S, a.mc, a.d, data_lds, sub, sw_eval, a.d.pad));
+          SweepRowsT rows{};      // (ok = false)
+          if (by_sums) rows = Model::template prefetch_rows<kPassU>(cache, S, a.mc, a.d, data_lds, sub, sw_eval, a.d.pad);
+          if (by_sums && rows.ok && slot + d_len <= P_stepped) {
             // every lane holds its committed sum and its sum under its component's proposal: an update is the butterfly of the 64 sums with the
             // proposed ones in the lanes of ITS component -- the value the whole evaluation returns for that state, bit for bit --, the accept test,
             // and on acceptance the new sums, value and state; counters and adaptation afterwards, every component in its own lane
@@ -1288,10 +1307,18 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       }
       if (certified) {
       } else if (inb) {
+        double prop_lp = 0.0;
         if constexpr (kCert) {      // the cheap values could not decide: the expression, for the current state first if a cheap value has been standing in for it
-          if (!lp_exact) { set_state(comp, cur); lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache); set_state(comp, prop); lp_exact = true; }
+          // (ONE call site for both: the reference-order evaluation is an out-of-line call, and every call site costs the loop saved registers)
+          for (int which = chain_true<G>(lp_exact) ? 1 : 0; which < 2; ++which) {
+            if (which == 0) set_state(comp, cur);
+            const double v = expression();
+            if (which == 0) { lp_curr = v; lp_exact = true; set_state(comp, prop); }
+            else prop_lp = v;
+          }
+        } else {
+          prop_lp = expression();
         }
-        const double prop_lp = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);
 #if defined(__HIP_DEVICE_COMPILE__)
         // the next slot's prefetched values are "used" HERE: the wait for them lands right behind the pass's own LDS reads (which returned
         // after them -- no stall), instead of at the top of the next slot behind this slot's closing stores and counter update
@@ -1326,7 +1353,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // the register mirror of the state (kTracksState models) is a second copy that every store must keep current (set_state -> on_set): once per
   // launch it is compared with the LDS copy, bit for bit -- a store that bypassed set_state would otherwise go unnoticed until a parity test
   if constexpr (kCert) {      // what leaves the launch: the expression's value of the final state if the host asked for it, else the pair the stepper holds
-    if (a.finalize_lp && !lp_exact) { lp_curr = log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache); lp_exact = true; }
+    if (a.finalize_lp && !lp_exact) { lp_curr = expression(); lp_exact = true; }
     if (!lp_exact) lp_curr = lpA;
     if (writer) cold_args()->ch.lp_eps[cl] = lp_exact ? 0.0 : epsA;
   }

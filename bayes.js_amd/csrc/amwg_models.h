@@ -798,8 +798,15 @@ struct HierNormalModel {
   // Bounds, u = 2^-53, per lane m_l = |start| + n_l |c| + Q_l (Q_l = S2 / den >= 0), M = their sum over the wavefront: the expression's lane sum (start, then n_l
   // terms c - RN(tt / den) added in order) is within (n_l + 2) u m_l of the real number, the value here within (n_l / 4 + 9) u m_l (four partial sums of non-negative
   // terms, exact squares inside the fma, 1 / den correctly rounded, n_l c and two additions), each butterfly within 6 u M:
-  //     a value of log_post:      eps = u M (2 n_l + 40) 1.25
-  //     a difference of two (the sweep's D_c, which also leaves out the lanes that do not change):   eps = u M (3 n_l + 48) 1.25,  M over max(m_l, m_l')
+  // -- that much is the distance to the expression summed in the chain's 64-lane order.  What the bounds below are FOR is the reference's own order (round 5,
+  // last part): one running sum, prior terms first, then the observations i = 0, 1, ... (reference_order below, the expression these kernels evaluate when a
+  // uniform falls inside a bound, and the value a launch leaves behind).  Its n + G + 2 additions each round a partial sum that stays below
+  // M' = M + 2 |prior(mu, sigma)| + 2 |lunif| (lane 0's start value is the rounded sum of three prior terms: their magnitudes add up to no more than that), its n
+  // terms carry 5 u (n |c| + Q) between them: within (n + G + 8) u M' of the real number.  With the (n_l / 4 + 15) u M of the value here:
+  //     a value of log_post:      eps = u M' (2 (n + G) + 64) 1.25
+  //     a difference of two (the sweep's D_c, which also leaves out the lanes that do not change):   eps = u M' (4 (n + G) + 128) 1.25,  M' over max(m_l, m_l')
+  // -- a decision certified with these is the one the REFERENCE makes (one lane per chain), not merely the one this geometry's own summation order would
+  // make: accept counts are the reference's at 64 lanes per chain (tests/test_gpu_decision_parity.py: zero first flips where rounds 3-4 counted ~0.1 per 1e9).
   static constexpr bool kCertified = true;
   static constexpr int kCertifiedLanes = 64;
   static constexpr bool kCertifiedNeedsRows = true;      // (only the sweep kernel: the row tile is what the S2 pass reads)
@@ -842,8 +849,41 @@ struct HierNormalModel {
     const double q = s2 * k.n.y.hi, nc = n_l * k.n.c;
     return ApproxLane{(start + nc) - q, __builtin_fabs(start) + __builtin_fabs(nc) + q};
   }
-  __device__ __forceinline__ static double value_bound(double M, const DataRef &d) { return M * (2.0 * (double)((d.n_obs >> 6) + 1) + 40.0) * 1.25 * 0x1p-53; }
-  __device__ __forceinline__ static double difference_bound(double M, const DataRef &d) { return M * (3.0 * (double)((d.n_obs >> 6) + 1) + 48.0) * 1.25 * 0x1p-53; }
+  __device__ __forceinline__ static double value_bound(double M, const DataRef &d) { return M * (2.0 * (double)(d.n_obs + d.G) + 64.0) * 1.25 * 0x1p-53; }
+  __device__ __forceinline__ static double difference_bound(double M, const DataRef &d) { return M * (4.0 * (double)(d.n_obs + d.G) + 128.0) * 1.25 * 0x1p-53; }
+  // (lane 0's share of M': see above)
+  __device__ __forceinline__ static double prior_magnitude(double pr, const ModelConsts &mc, int sub) { return sub == 0 ? 2.0 * (__builtin_fabs(pr) + __builtin_fabs(mc.lunif)) : 0.0; }
+  // THE REFERENCE'S ORDER in the row layout: log_post as the reference's closure forms it -- lp = prior(mu) + prior(sigma); for g: lp += prior(theta_g); for i: lp +=
+  // term_i (mcmc.js:524-526 calls it, the model is tests/model_spec.py's closure) -- with every lane computing the terms of ITS observations (the same operations
+  // on the same values as the one-lane kernel: a term depends on its observation, its group's mean and sigma only) and ONE running sum that visits them in the
+  // order i = 64 r + lane.  ~1e4 dependent additions through v_readlane: 200 us, which is why it is not the pass -- it runs when a uniform falls inside a
+  // certified bound (some 5e-8 of the updates at cfg4) and when the host asks for log_post.  Wave-uniform result; every lane of the wavefront takes part.
+  static constexpr bool kReferenceOrder = true;
+  __device__ inline __attribute__((noinline)) static double reference_order_sum(double acc, const double *state, int G, double mu, double c1, double den1, double y1h, double y1l, int den1_ok,
+                                                                                const double *row, int n_obs, int sub, double mean, double c, double den, double yh, double yl, bool fast) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int q = 0; q < G; ++q) acc += norm_const_sd(state[q], mu, c1, den1, y1h, y1l, den1_ok);
+    const int n_full = n_obs >> 6, rem = n_obs & 63;
+    for (int r = 0; r <= n_full; ++r) {
+      const int cnt = r < n_full ? 64 : rem;
+      const double t = row[sub < cnt ? r : 0] - mean;      // (a lane without an observation in the last round: any valid address, its term is not added)
+      const double tt = t * t;
+      const double term = c - (fast ? div_by_invariant(tt, den, Reciprocal{yh, yl}) : tt / den);
+      for (int l = 0; l < cnt; ++l) acc += lane_double(term, l);
+    }
+#endif
+    return acc;
+  }
+  template <int G>
+  __device__ __forceinline__ static double reference_order(Cache &k, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *smem, int sub) {
+    static_assert(G == 64, "the row layout: a chain on one wavefront");
+    load<G>(k, S, mc, d, smem, sub);
+    const Pass ps = begin<G>(S, mc, d, smem, k);
+    const double pr = prior(S, mc, d, k);
+    const double mean = sub < d.n_obs ? S((int)(smem + (size_t)64 * d.pad * 8)[sub]) : 0.0;      // this lane's ONE group (group_lane_const: what the row layout is chosen for)
+    return reference_order_sum(pr, S.base, d.G, k.mu, k.c1, k.den1, k.y1h, k.y1l, k.den1_ok, reinterpret_cast<const double *>(smem) + (size_t)sub * d.pad, d.n_obs, sub, mean,
+                               ps.c, ps.den, ps.y.hi, ps.y.lo, ps.fast);
+  }
   // log_post of the state as it stands (the stepper has stored its proposal), cheaply: mu's and sigma's updates (no pass: every lane's mean is the cached one),
   // any other update of the ordinary stepper (the lanes whose mean changed re-form their S2)
   template <int G, int BT>
@@ -856,7 +896,7 @@ struct HierNormalModel {
     const double start = start_value(k, k.mu, pr, sub, d);
     const double s2 = lane_s2(k, smem, k.th_pass, d, sub);
     const ApproxLane a = approx_lane(k, start, s2, d, sub);
-    const double value = butterfly<1, 64>(a.value), M = butterfly<1, 64>(a.mag);
+    const double value = butterfly<1, 64>(a.value), M = butterfly<1, 64>(a.mag + prior_magnitude(pr, mc, sub));
     return Approx{value, value_bound(M, d)};
 #else
     return Approx{0.0, __builtin_inf()};
@@ -891,7 +931,7 @@ struct HierNormalModel {
     out.ok = true;
     out.comp = k.my_group >= 0 ? k.my_group : (sub < d.G ? sub : -1);
     out.cur = c0.value; out.neu = c1.value;
-    out.mag = c0.mag > c1.mag ? c0.mag : c1.mag;
+    out.mag = (c0.mag > c1.mag ? c0.mag : c1.mag) + prior_magnitude(pr, mc, sub);
     out.mean_new = mean; out.s2_new = s2_new;
 #endif
     return out;
@@ -1140,7 +1180,12 @@ struct PoisGlmModel {
   //   log(exp_v8(eta)) vs eta: 2 u (1 + H) 1.01 per unit of y; exp_v8 vs e^eta: 2 u L; the term's three roundings: 4 u (H Y + L + F); eta's 13 roundings against
   //   the 7 here: 22 u H (Y + L) 1.05; exp_bounded: 2^-46 L = 128 u L; the per-lane sums of n_l terms and the butterflies, on both sides: 2 (n_l + 8) u W; the final
   //   combination 4 u W -- W = |prior| + (1 + H) Y + L + F bounds every sum of magnitudes above, n_l = n / 16 + 1 (the expression's lanes hold the longer sums).
-  //   eps = u W (2 n_l + 23 H + 200) 1.25.
+  //   eps = u W (2 n_l + 23 H + 200) 1.25  against the expression in the chain's 16-lane order.
+  // What the bound below is FOR is the reference's own order (round 5, last part; reference_order below: the expression this kernel evaluates when a uniform falls
+  // inside the bound, and the value a launch leaves behind): one running sum over the nine prior terms and the n observations in order -- n + 9 additions of partial
+  // sums below W' = W + 2 |lunif_cp| (lane 0's start value is the rounded sum of two prior terms) in place of the lanes' n_l + 8:
+  //   eps = u W' (2 (n + 16) + 23 H + 200) 1.25  (1.4e-6 at cfg5: ~3e-6 of the updates evaluate the expression).
+  // A decision certified with it is the REFERENCE's (one lane per chain), not merely this geometry's.
   // H > 690 (an eta could leave the range in which exp and log are ordinary), a negative count (F = +inf) or any non-finite value make eps non-finite: the
   // stepper then evaluates the expression.
   static constexpr bool kCertified = true;
@@ -1224,13 +1269,49 @@ struct PoisGlmModel {
       tot = mine == c ? t : tot;
       L = mine == c ? l : L;
     }
-    const double n_l = (double)(n_obs / G + 1);
-    const double W = Pabs + (1.0 + H) * mc.glm_sum_y + L + mc.glm_sum_lf;
-    const double eps = (H <= 690.0) ? W * (2.0 * n_l + 23.0 * H + 200.0) * 1.25 * 0x1p-53 : __builtin_inf();
+    const double W = Pabs + 2.0 * __builtin_fabs(mc.lunif_cp) + (1.0 + H) * mc.glm_sum_y + L + mc.glm_sum_lf;
+    const double eps = (H <= 690.0) ? W * (2.0 * (double)(n_obs + 16) + 23.0 * H + 200.0) * 1.25 * 0x1p-53 : __builtin_inf();
     return Approx{(P + tot) - mc.glm_sum_lf, eps};
 #else
     return Approx{0.0, __builtin_inf()};
 #endif
+  }
+  // THE REFERENCE'S ORDER at G lanes per chain: lp = 0; for k: lp += prior(b_k); lp += prior(cp); for i: lp += term_i (the closure of tests/model_spec.py, called by
+  // mcmc.js:524-526) -- the chain's lanes compute the terms of a round of G observations side by side (term_of: the operations of the one-lane kernel on the same
+  // values) and ONE running sum takes them in the order i = G k + lane (a ds_bpermute broadcast per term: ~1 ms for 5e4 observations, which is why it is not the
+  // pass).  Runs under the chain's own execution mask: the lanes it reads are its own.
+  static constexpr bool kReferenceOrder = true;
+  template <int G>
+  __device__ inline __attribute__((noinline)) static double reference_order_sum(const double *state, const double *x, const double *y, const double *lfact, int n_obs, int sub,
+                                                                                double m0, double c0, double den0, double y0h, double y0l, int den0_ok, double cp_upper, double lunif_cp) {
+    double acc = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    Pass ps;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ps.b[k] = state[k];
+    ps.cp = state[8];
+    ps.icp = !(ps.cp < 536870912.0) ? 536870912 : (ps.cp <= 0.0 ? 0 : (int)__builtin_ceil(ps.cp));      // (as begin())
+    ps.K = exp_log_regs();
+#pragma unroll
+    for (int k = 0; k < 7; ++k) ps.col[k] = reinterpret_cast<const char *>(x + (size_t)k * (size_t)n_obs);
+    ps.col[7] = reinterpret_cast<const char *>(y);
+    ps.col[8] = reinterpret_cast<const char *>(lfact);
+    for (int k = 0; k < 8; ++k) acc += norm_const_sd(ps.b[k], m0, c0, den0, y0h, y0l, den0_ok);
+    acc += (ps.cp < 0 || ps.cp > cp_upper) ? -kInf : lunif_cp;
+    const int base = (int)(threadIdx.x & 63u) & ~(G - 1);
+    for (int k0 = 0; k0 < n_obs; k0 += G) {
+      const int cnt = n_obs - k0 < G ? n_obs - k0 : G, i = k0 + sub;
+      Row r;
+      load_row(ps, sub < cnt ? i : k0, r);
+      const double term = term_of(ps, r, i, 1);
+      for (int l = 0; l < cnt; ++l) acc += __shfl(term, base + l, 64);
+    }
+#endif
+    return acc;
+  }
+  template <int G>
+  __device__ __forceinline__ static double reference_order(Cache &, const StateView &S, const ModelConsts &mc, const DataRef &d, const unsigned char *, int sub) {
+    return reference_order_sum<G>(S.base, d.x, d.y, d.lfact, d.n_obs, sub, mc.m0, mc.c0, mc.den0, mc.y0_hi, mc.y0_lo, mc.den0_ok, mc.cp_upper, mc.lunif_cp);
   }
   // two observations through exp / log side by side (one basic block: the two dependent chains interleave), added in order
   __device__ __forceinline__ static double pair_finish(const Pass &ps, double eta_a, double eta_b, double ya, double la, double yb, double lb, double acc) {

@@ -710,6 +710,8 @@ static napi_value LaunchInfo(napi_env env, napi_callback_info info) {
   napi_set_named_property(env, o, "kernel_ms", t);
   napi_create_string_utf8(env, amwg_kernel_name(s), NAPI_AUTO_LENGTH, &t);      /* the step kernel, as a profiler lists it */
   napi_set_named_property(env, o, "kernel", t);
+  napi_create_int32(env, amwg_summation_order(s), &t);      /* 1: decisions and log_post in the reference's own order */
+  napi_set_named_property(env, o, "summation_order", t);
   /* lanes_per_chain: -2 (AMWG_LANES_AUTOTUNE): what was timed at construction, [{lanes_per_chain, ms}, ...] */
   int32_t tl[16];
   double tm[16];

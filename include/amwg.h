@@ -306,6 +306,13 @@ int amwg_launch_info(const amwg_sampler *s, int32_t *lanes_per_chain, int32_t *b
  * "amwg_gl_kernel<HierGlModel,512>" (options.group_local), "amwg_user_step" (a translated closure).  The last number is the workgroup size
  * class the kernel was compiled for (256 / 512 / 1024).  Valid until the sampler is destroyed. */
 const char *amwg_kernel_name(const amwg_sampler *s);
+/* The summation order this sampler's decisions and its cached log_post follow: the number of per-lane partial sums log_post is formed from.
+ * 1 = the REFERENCE's own order (one running sum over the closure's terms, mcmc.js:524-526 calling the model's log_post): accept counts and draws are
+ * the reference's bit for bit -- every sampler at one lane per chain, and at any lane count the kernels that decide from certified values against the
+ * expression in that order (round 5: the hierarchical family's sweep kernel at 64 lanes, the Poisson family at 16 lanes; options.full_evaluation = 0).
+ * Otherwise lanes_per_chain: the expression is summed per lane and the lanes' sums by a butterfly (the oracle's lane order; a decision can differ from
+ * the reference's where a uniform falls between the two orders' values, ~1e-10 of the decisions).  Negative: an error code. */
+int amwg_summation_order(const amwg_sampler *s);
 int amwg_destroy(amwg_sampler *s);
 const char *amwg_last_error(void);
 const char *amwg_version(void);

@@ -46,7 +46,8 @@ def compare(A, spec, chains, steps, seed, alt, ref=None, steps_per_launch=0, ref
            "first_flips": differing, "flips_per_1e9": (differing / decisions * 1e9) if decisions else None,
            "upper_95_per_1e9": ((3.0 if differing == 0 else differing + 2.0 * np.sqrt(differing) + 2.0) / decisions * 1e9) if decisions else None,
            "reference_geometry": {"lanes_per_chain": la["lanes_per_chain"], "block_threads": la["block_threads"]},
-           "geometry": dict({"lanes_per_chain": lb["lanes_per_chain"], "block_threads": lb["block_threads"]}, **{k: v for k, v in alt.items() if k != "lanes_per_chain"}),
+           "geometry": dict({"lanes_per_chain": lb["lanes_per_chain"], "block_threads": lb["block_threads"], "summation_order": lb.get("summation_order"), "kernel": lb.get("kernel")},
+                            **{k: v for k, v in alt.items() if k != "lanes_per_chain"}),
            "lp_abs_diff_max": float(lpd.max()) if lpd.size else None, "lp_abs_diff_mean": float(lpd.mean()) if lpd.size else None,
            "lp_abs_typical": float(np.median(np.abs(da["log_post"][same]))) if same.any() else None,
            "expected_flips_bound": (2.0 * float(lpd.mean()) * decisions) if lpd.size else None,

@@ -1,10 +1,14 @@
 """-m gpu: north_star asks for "same seed => bit-identical integer accept counts".  With one lane per chain that holds by construction (the
-reference's summation order: every golden, the live reference).  At the DEFAULT geometry of cfg4 / cfg5 (64 lanes per chain) and in the
-opt-in group-local mode log_post differs from the reference's value in its last bits, and a decision `Math.exp(prop - curr) > u`
-(mcmc.js:527-528) can flip when u falls inside that sliver.  These tests put a number on it: the same seeded job in both geometries on the
-device, thousands of chains x thousands of steps, counting the chains that end up different (tests/decision_parity.py).  The stated bound:
-at most 50 first flips per 1e9 decisions (the analytic expectation, 2 x mean |log_post difference| per decision, is ~1e-11 x 1e9 = 0.01-0.1;
-tools/flip_rate.py runs the same comparison over 1e9 - 1e10 decisions and its result is quoted in DESIGN.md section 2)."""
+reference's summation order: every golden, the live reference).  Since round 5 it also holds at the DEFAULT geometries of cfg4 (the sweep kernel,
+64 lanes per chain) and cfg5 (16 lanes): those kernels decide from certified values against the expression in the REFERENCE's order and evaluate that
+expression when a uniform falls inside the bound (amwg_summation_order() == 1) -- the same seeded job at one lane per chain must then agree in EVERY
+chain, cached log_post included (zero flips, not a rate).
+Every other multi-lane kernel (the Normal family at > 1 lane, 64-lane Poisson, translated closures, options.full_evaluation != 0, the opt-in
+group-local mode) sums log_post in its own lane order: it differs from the reference's value in its last bits, and a decision
+`Math.exp(prop - curr) > u` (mcmc.js:527-528) can flip when u falls inside that sliver.  For those the tests put a number on it: the same seeded job in
+both geometries on the device, thousands of chains x thousands of steps, counting the chains that end up different (tests/decision_parity.py).  The
+stated bound: at most 50 first flips per 1e9 decisions (the analytic expectation, 2 x mean |log_post difference| per decision, is ~1e-11 x 1e9 =
+0.01-0.1; tools/flip_rate.py runs the same comparison over 1e9 - 1e10 decisions and its result is quoted in DESIGN.md section 2)."""
 import math
 
 import pytest
@@ -22,6 +26,7 @@ _REFERENCE_RUNS = {}
     ("hier_n640_g8", 4096, 10_000, {"lanes_per_chain": 64}),
     ("hier_n640_g8", 4096, 10_000, {"lanes_per_chain": 64, "group_local": 1}),
     ("glm_n500", 4096, 3_000, {"lanes_per_chain": 64}),
+    ("glm_n500", 4096, 3_000, {"lanes_per_chain": 16}),
     ("cfg4_size", 4096, 800, {"lanes_per_chain": 64}),
     ("cfg4_size", 4096, 800, {"lanes_per_chain": 64, "group_local": 1}),
     ("normal_n1000", 8192, 10_000, {"lanes_per_chain": 64}),
@@ -33,8 +38,13 @@ def test_decisions_at_many_lanes_equal_the_one_lane_run(workload, chains, steps,
         _REFERENCE_RUNS.clear()
         _REFERENCE_RUNS[key] = dp.run_one(A, spec, chains, steps, 20260925, {"lanes_per_chain": 1})
     r = dp.compare(A, spec, chains, steps, seed=20260925, alt=alt, ref_run=_REFERENCE_RUNS[key])
-    assert r["reference_geometry"]["lanes_per_chain"] == 1 and r["geometry"]["lanes_per_chain"] == 64
+    assert r["reference_geometry"]["lanes_per_chain"] == 1 and r["geometry"]["lanes_per_chain"] == alt["lanes_per_chain"]
     assert r["decisions"] > 0.5 * chains * steps * r["components"] * 0.9      # nearly every proposal is inside its bounds
+    reference_order = (workload.startswith(("hier", "cfg4")) and alt == {"lanes_per_chain": 64}) or (workload.startswith("glm") and alt == {"lanes_per_chain": 16})
+    assert (r["geometry"]["summation_order"] == 1) == reference_order, r
+    if reference_order:      # decided against the expression in the reference's order: the reference's chain, bit for bit
+        assert r["chains_differing"] == 0 and r["lp_abs_diff_max"] == 0.0, r
+        return
     allowed = math.ceil(BOUND_PER_1E9 * 1e-9 * r["decisions"])
     assert r["chains_differing"] <= allowed, r
     # the sliver itself: the two orders' log_post agree to ~1e-12 relative

@@ -80,9 +80,15 @@ def test_g_lanes_per_chain_matches_oracle_and_reference_decisions(name, lanes):
     rec = gold["chains"][0]
     spec = model_spec.spec_from_golden(gold, rec)
     s = A.Sampler(spec, chains=5, seed=case["seed"], chain_offset=rec["chain"], lanes_per_chain=lanes)
-    o = oracle_lib.OracleChain(spec, case["seed"], rec["chain"], lanes=lanes)
+    # (the oracle sums in the order the sampler does: `lanes` partial sums and a butterfly -- or, for the kernels that decide against the expression in the
+    # reference's own order (the hierarchical sweep kernel at 64 lanes, the Poisson family at 16), ONE running sum: the cached log_post is then the reference's too)
+    order = s.launch_info()["summation_order"]
+    assert order == (1 if (spec["model"], lanes) == ("pois_glm", 16) or s.launch_info()["kernel"].startswith("amwg_sweep_kernel") else lanes)
+    o = oracle_lib.OracleChain(spec, case["seed"], rec["chain"], lanes=order)
     gs, os_ = run_schedule(s, case["schedule"]), run_schedule(o, case["schedule"])
     assert_chain_equals_oracle(s, 0, o, gs, os_)
+    if order == 1:
+        assert float(s.diag()["log_post"][0]) == rec["log_post"]
     assert s.info()["accepts"][:, 0].tolist() == rec["accepts"]      # the reference's decisions
     assert s.info()["inbounds"][:, 0].tolist() == rec["inbounds"]
     assert int(s.diag()["uniforms"][0]) == rec["uniforms"]
@@ -122,7 +128,7 @@ def test_many_chains_auto_geometry_vs_oracle(model, n_obs, G):
     spec = model_spec.build_spec(model, data)
     chains, seed, off = 1000, 4242, 10_000_000_000      # > 2^32 global ids exercise the 64-bit counter words
     s = A.Sampler(spec, chains=chains, seed=seed, chain_offset=off)
-    lanes = s.launch_info()["lanes_per_chain"]
+    lanes = s.launch_info()["summation_order"]      # (lanes_per_chain, or 1 where the kernel decides against the expression in the reference's order)
     sched = [{"op": "burn", "n": 120}, {"op": "sample", "n": 60, "thin": 3}]
     gs = run_schedule(s, sched)
     for local in (0, 499, 999):
@@ -144,7 +150,7 @@ def test_poisson_pass_edges_vs_oracle(n_obs, lanes):
     sched = [{"op": "burn", "n": 60}, {"op": "sample", "n": 40, "thin": 2}]
     gs = run_schedule(s, sched)
     for local in (0, 5):
-        o = oracle_lib.OracleChain(spec, 31, 5 + local, lanes=lanes)
+        o = oracle_lib.OracleChain(spec, 31, 5 + local, lanes=s.launch_info()["summation_order"])      # (16 lanes: the reference's order)
         assert_chain_equals_oracle(s, local, o, gs, run_schedule(o, sched))
     cp = gs[0][:, 8, :]
     assert cp.min() >= 0 and cp.max() <= n_obs - 1
@@ -301,7 +307,7 @@ def test_hierarchical_pass_with_lane_constant_groups_equals_the_gathered_pass(gr
     assert all(a.tobytes() == b.tobytes() for a, b in zip(gs, ge))
     assert s.state().tobytes() == e.state().tobytes()
     for local in (0, 5):
-        o = oracle_lib.OracleChain(spec, 8, 3 + local, lanes=lanes)
+        o = oracle_lib.OracleChain(spec, 8, 3 + local, lanes=s.launch_info()["summation_order"])      # (the sweep kernel: the reference's order)
         assert_chain_equals_oracle(s, local, o, gs, run_schedule(o, sched))
     s.close()
     e.close()
@@ -450,10 +456,15 @@ def test_group_local_preconditions_are_enforced():
 @pytest.mark.parametrize("n_obs,G,chains,theta", [(10_000, 32, 300, None), (1_000, 8, 130, None), (640, 64, 70, None), (257, 2, 65, None),
                                                   (2_000, 32, 130, "bounded"), (1_000, 16, 70, "int"), (1_500, 8, 70, "shifted"), (900, 16, 66, "tiny")])
 def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains, theta):
-    """Hierarchical family on a wavefront per chain (labels that repeat with the lane stride): by default only the lanes whose sum an update
-    can have changed are re-formed (amwg_models.h lane_sum_rows); options.full_evaluation = 1 makes every evaluation pass over all the data.
-    The two must agree in EVERY bit of every chain -- draws, counters, proposal scales, log_post, uniforms -- over a schedule with short launches,
-    a stop / start of the adaptation, thinning, and states overwritten from the host in between (every cached sum is then stale)."""
+    """Hierarchical family on a wavefront per chain (labels that repeat with the lane stride), over a schedule with short launches, a stop / start of the
+    adaptation, thinning, and states overwritten from the host in between (every cached sum is then stale).
+    * options.full_evaluation = 1 (every evaluation passes over all the data) and = 2 (the row layout: only the lanes whose sum an update can have changed are
+      re-formed, amwg_models.h lane_sum_rows) evaluate the expression in the 64-lane order: they must agree with each other in EVERY bit of every chain.
+    * the default decides from certified sums against the expression in the REFERENCE's order (one running sum; amwg_models.h reference_order): it must agree in
+      every bit -- draws, counters, proposal scales, uniforms, the cached log_post -- with the same sampler at ONE lane per chain (the reference's order by
+      construction, pinned to the reference goldens elsewhere), with its bounds widened 2^12-fold (the expression often) and 2^40-fold (always: every decision of
+      the 64-lane kernel is then made by reference_order itself).
+    * the two groups agree in everything but the last bits of log_post (two summation orders of the same terms)."""
     data = model_spec.make_data("hier_normal", n_obs, 77, G=G)
     spec = model_spec.build_spec("hier_normal", data)
     # theta with bounds some proposals fall outside of, or of integer type: the sweep kernel then walks the parameter update by update (an update
@@ -479,13 +490,14 @@ def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains, th
     # differences with their rounding bound -- the path a sweep takes when a uniform falls inside that bound, some 1e-8 of the sweeps otherwise)
     # (test_bound_shift = 12: the rounding bounds of the all-at-once sweep decisions and of mu's early rejection made 4096 times wider -- a good share of the
     # sweeps then meets a uniform inside the bound and is walked update by update, mixed with sweeps that are not)
-    a, b, c2, c3 = mk(0), mk(1), mk(2), mk(0, 12)
+    a, b, c2, c3, c4 = mk(0), mk(1), mk(2), mk(0, 12), mk(0, 40)
+    one = A.Sampler(spec, chains=chains, seed=4, chain_offset=9, lanes_per_chain=1, steps_per_launch=7, full_evaluation=1, **kw)
     assert a.launch_info()["lds_bytes"] != b.launch_info()["lds_bytes"]      # the row layout (tile + term rows) is in use on one side only
     assert c2.launch_info()["kernel"] == a.launch_info()["kernel"] == c3.launch_info()["kernel"]
     assert a.launch_info()["kernel"].startswith("amwg_sweep_kernel<HierNormalModel") and b.launch_info()["kernel"].startswith("amwg_step_kernel<HierNormalModel,64")
-    rng = np.random.default_rng(3)
+    assert one.launch_info()["lanes_per_chain"] == 1
     outs = []
-    for s in (a, b, c2, c3):
+    for s in (a, c3, c4, one, b, c2):
         seq = [s.sample(40, 1)]
         s.burn(33)
         s.set_adapting(False)
@@ -502,33 +514,45 @@ def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains, th
         s.burn(50)
         seq.append(s.sample(30, 2))
         outs.append((seq, s.info(), s.diag(), s.state()))
-    (sa, ia, da, sta) = outs[0]
-    for (sb, ib, db, stb) in outs[1:]:
+    _same_chains(outs[0], outs[1:4], log_post_bits=True)       # default == bounds widened == the expression always == ONE lane per chain
+    _same_chains(outs[4], outs[5:], log_post_bits=True)        # the two 64-lane-order evaluations
+    _same_chains(outs[0], outs[4:5], log_post_bits=False)      # ... and across: everything but the last bits of log_post
+    for s in (a, b, c2, c3, c4, one):
+        s.close()
+
+
+def _same_chains(ref, others, log_post_bits):
+    (sa, ia, da, sta) = ref
+    for (sb, ib, db, stb) in others:
         for x, y in zip(sa, sb):
             assert x.tobytes() == y.tobytes()
         for k in ia:
             assert ia[k].tobytes() == ib[k].tobytes(), k
-        assert da["uniforms"].tobytes() == db["uniforms"].tobytes() and da["log_post"].tobytes() == db["log_post"].tobytes()
+        assert da["uniforms"].tobytes() == db["uniforms"].tobytes()
+        if log_post_bits:
+            assert da["log_post"].tobytes() == db["log_post"].tobytes()
+        else:
+            fin = np.isfinite(da["log_post"])
+            assert np.array_equal(fin, np.isfinite(db["log_post"])) and np.allclose(da["log_post"][fin], db["log_post"][fin], rtol=1e-11, atol=0)
         assert sta.tobytes() == stb.tobytes()
-    a.close()
-    b.close()
-    c2.close()
-    c3.close()
 
 
 @pytest.mark.parametrize("n_obs,chains,steps", [(500, 1024, 300), (3000, 512, 120), (449, 260, 200), (61, 256, 200)])
 def test_certified_decisions_of_the_poisson_family_equal_the_expression_in_every_update(n_obs, chains, steps):
     """Poisson GLM + integer change point, 16 lanes per chain (four chains to a wavefront): by default the accept test is decided from  prior + sum eta y - sum
     e^eta - sum lfactorial(y)  -- no logarithm of the exponential, the four chains of a wavefront sharing every row they read -- and a bound on its distance
-    from the reference's expression (csrc/amwg_models.h PoisGlmModel::log_post_approx); options.full_evaluation = 1 evaluates the expression in every update.
-    Every bit of every chain must agree: draws, counters, proposal scales, uniforms, the cached log_post; with the bound widened 2^14- and 2^40-fold as well
-    (updates fall back to the expression often / always).  Chain counts that leave a wavefront partly filled, fewer observations than lanes."""
+    from the reference's expression IN THE REFERENCE'S ORDER (csrc/amwg_models.h PoisGlmModel::log_post_approx, reference_order).  Every bit of every chain --
+    draws, counters, proposal scales, uniforms, the cached log_post -- must agree with the same sampler at ONE lane per chain (the reference's order by
+    construction), with the bound widened 2^14- and 2^40-fold as well (updates fall back to the expression often / always: at 2^40 every decision is made by
+    reference_order itself); options.full_evaluation = 1 (the expression in the 16-lane order in every update) agrees in everything but the last bits of
+    log_post.  Chain counts that leave a wavefront partly filled, fewer observations than lanes."""
     data = model_spec.make_data("pois_glm", n_obs, 123, exp=oracle_lib.lib().orc_exp)
     spec = model_spec.build_spec("pois_glm", data)
     mk = lambda full, shift=0: A.Sampler(spec, chains=chains, seed=21, chain_offset=2, lanes_per_chain=16, steps_per_launch=9, full_evaluation=full, test_bound_shift=shift)
     outs = []
-    for s in (mk(0), mk(1), mk(0, 14), mk(0, 40)):
-        assert s.launch_info()["lanes_per_chain"] == 16
+    one = A.Sampler(spec, chains=chains, seed=21, chain_offset=2, lanes_per_chain=1, steps_per_launch=9, full_evaluation=1)
+    for s in (mk(0), mk(0, 14), mk(0, 40), one, mk(1)):
+        assert s.launch_info()["lanes_per_chain"] == (1 if s is one else 16)
         seq = [s.sample(steps // 3, 2)]
         s.burn(steps // 3)
         s.set_adapting(False)
@@ -537,14 +561,8 @@ def test_certified_decisions_of_the_poisson_family_equal_the_expression_in_every
         s.burn(steps // 6)
         outs.append((seq, s.info(), s.diag(), s.state()))
         s.close()
-    (sa, ia, da, sta) = outs[0]
-    for (sb, ib, db, stb) in outs[1:]:
-        for x, y in zip(sa, sb):
-            assert x.tobytes() == y.tobytes()
-        for k in ia:
-            assert ia[k].tobytes() == ib[k].tobytes(), k
-        assert da["uniforms"].tobytes() == db["uniforms"].tobytes() and da["log_post"].tobytes() == db["log_post"].tobytes()
-        assert sta.tobytes() == stb.tobytes()
+    _same_chains(outs[0], outs[1:4], log_post_bits=True)
+    _same_chains(outs[0], outs[4:], log_post_bits=False)
 
 
 @pytest.mark.parametrize("n_obs,chains,steps,hyper", [(1000, 4096, 400, None), (777, 1024, 300, None), (17, 512, 300, None), (1000, 16384, 600, [0.0, 100.0, 0.0, 1.0])])
