@@ -48,6 +48,11 @@ step_kernel_t amwg_kernels_hier_normal(int lanes, int block);
 step_kernel_t amwg_kernels_pois_glm(int lanes, int block);
 step_kernel_t amwg_kernel_hier_gl(int block);      // the group-local kernel of the hierarchical family (amwg_gl.h)
 step_kernel_t amwg_kernel_hier_sweep(int block);   // the hierarchical family's kernel with the sweep prefetch (row layout, 64 lanes per chain)
+// ... and the kernels that decide from certified values (amwg_kernel.h kCert), where a family has one for this lane count (nullptr: none)
+step_kernel_t amwg_kernels_cert_normal(int lanes, int block);
+step_kernel_t amwg_kernels_cert_beta_bern(int lanes, int block);
+step_kernel_t amwg_kernels_cert_hier_normal(int lanes, int block);
+step_kernel_t amwg_kernels_cert_pois_glm(int lanes, int block);
 
 namespace {
 
@@ -76,6 +81,15 @@ step_kernel_t pick_kernel(int model, int G, int block) {
     case AMWG_MODEL_BETA_BERN: return amwg_kernels_beta_bern(G, block);
     case AMWG_MODEL_HIER_NORMAL: return amwg_kernels_hier_normal(G, block);
     case AMWG_MODEL_POIS_GLM: return amwg_kernels_pois_glm(G, block);
+  }
+  return nullptr;
+}
+step_kernel_t pick_certified_kernel(int model, int G, int block) {
+  switch (model) {
+    case AMWG_MODEL_NORMAL: return amwg_kernels_cert_normal(G, block);
+    case AMWG_MODEL_BETA_BERN: return amwg_kernels_cert_beta_bern(G, block);
+    case AMWG_MODEL_HIER_NORMAL: return amwg_kernels_cert_hier_normal(G, block);
+    case AMWG_MODEL_POIS_GLM: return amwg_kernels_cert_pois_glm(G, block);
   }
   return nullptr;
 }
@@ -201,6 +215,12 @@ int gl_layout(const double *y, const int32_t *g, int N, int Gn, GlLayoutHost *ou
 // G wins, ties go to the smaller G.  The choice depends only on the model, the data size and the chain count, so a
 // given sampler configuration always gets the same G (the lane count fixes the summation order, hence the draws).
 bool hier_rows_wanted(const amwg_sampler *s, int G);
+// would this geometry run a kernel that decides from certified values (amwg_kernel.h kCert)?  The Normal family at one lane per chain, the Poisson family at 16,
+// the hierarchical family's sweep kernel (64 lanes, the row layout in use); options.full_evaluation = 0, no exact_division, no group_local, not a closure
+static bool certified_wanted(const amwg_sampler *s, int lanes, bool rows) {
+  if (s->user || s->opt.full_evaluation != 0 || s->opt.exact_division || s->mc.group_local) return false;
+  return (s->model == AMWG_MODEL_NORMAL && lanes == 1) || (s->model == AMWG_MODEL_POIS_GLM && lanes == 16) || (s->model == AMWG_MODEL_HIER_NORMAL && lanes == 64 && rows);
+}
 bool hier_rows_fit(const amwg_sampler *s, int bt, size_t max_lds);
 bool user_rows_wanted(const amwg_sampler *s, int G);
 bool user_rows_fit(const amwg_sampler *s, int bt, size_t max_lds);
@@ -345,8 +365,10 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     s->user_sweep = rows && user_sweep_wanted(s, s->lanes, s->block, max_lds);
     return AMWG_OK;
   }
-  s->kernel = s->mc.group_local ? amwg_kernel_hier_gl(s->block)
-              : ((hier_rows_wanted(s, s->lanes) && hier_rows_fit(s, s->block, max_lds)) ? amwg_kernel_hier_sweep(s->block) : pick_kernel(s->model, s->lanes, s->block));
+  const bool rows = !s->mc.group_local && hier_rows_wanted(s, s->lanes) && hier_rows_fit(s, s->block, max_lds);
+  s->kernel = certified_wanted(s, s->lanes, rows) ? pick_certified_kernel(s->model, s->lanes, s->block) : nullptr;
+  s->certified = s->kernel != nullptr;
+  if (!s->kernel) s->kernel = s->mc.group_local ? amwg_kernel_hier_gl(s->block) : (rows ? amwg_kernel_hier_sweep(s->block) : pick_kernel(s->model, s->lanes, s->block));
   if (!s->kernel) return fail(AMWG_EINVAL, "no kernel for model %d with %d lanes per chain in workgroups of %d", s->model, s->lanes, s->block);
   return AMWG_OK;
 }
@@ -371,11 +393,7 @@ struct Roctx {
 Roctx &roctx() { static Roctx r; return r; }
 
 // does this sampler's kernel decide from a model's cheaper value of log_post (amwg_kernel.h kCert: NormalModel at one lane per chain, PoisGlmModel at 16)?
-static bool certified_kernel(const amwg_sampler *s) {
-  if (s->user || s->opt.full_evaluation != 0 || s->opt.exact_division || s->mc.group_local) return false;
-  return (s->model == AMWG_MODEL_NORMAL && s->lanes == 1) || (s->model == AMWG_MODEL_POIS_GLM && s->lanes == 16) ||
-         (s->model == AMWG_MODEL_HIER_NORMAL && s->lanes == 64 && s->d.pad > 0);      // (the sweep kernel: the row layout is in use)
-}
+static bool certified_kernel(const amwg_sampler *s) { return s->certified; }
 
 int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws, bool finalize = false) {
   Roctx &rx = roctx();
@@ -404,7 +422,7 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws, bool
   a.pl = s->pl;
   a.cpb = s->cpb;
   a.sweep_update_by_update = s->opt.full_evaluation == 2 ? 1 : 0;
-  a.certified = (s->opt.full_evaluation == 0 && !s->opt.exact_division) ? 1 : 0;
+  a.certified = s->certified ? 1 : 0;      // (informational: certified decisions are the kernel's, not a switch inside it)
   a.bound_scale = std::ldexp(1.0, s->opt.test_bound_shift);
   a.mc = s->mc;
   a.d = s->d;
@@ -987,6 +1005,7 @@ static int autotune_geometry(amwg_sampler *s, int n_cus, size_t max_lds, Prepare
   for (size_t i = 0; i < cand.size(); ++i) if (i != best && cand[i].module) (void)hipModuleUnload(cand[i].module);
   const TuneCandidate &c = cand[best];
   s->lanes = c.lanes; s->block = c.block; s->grid = c.grid; s->lds = c.lds; s->cpb = c.cpb; s->kernel = c.kernel; s->user_module = c.module; s->user_fn = c.fn;
+  s->certified = !s->user && c.kernel != nullptr && c.kernel == pick_certified_kernel(s->model, c.lanes, c.block);
   s->d.pad = c.pad; s->user_sweep = c.sweep;      // (the row layout and the sweep kernel go with the geometry)
   s->tuned.clear();
   for (auto &q : cand) s->tuned.push_back({q.lanes, q.ms});
@@ -1651,11 +1670,11 @@ const char *amwg_kernel_name(const amwg_sampler *s) {
     char buf[96];
     if (s->user) snprintf(buf, sizeof buf, "%s", s->user_sweep ? "amwg_user_sweep" : "amwg_user_step");
     else if (s->mc.group_local) snprintf(buf, sizeof buf, "amwg_gl_kernel<HierGlModel,%d>", cls);
-    else if (s->model == AMWG_MODEL_HIER_NORMAL && s->d.pad > 0) snprintf(buf, sizeof buf, "amwg_sweep_kernel<HierNormalModel,%d>", cls);
+    else if (s->model == AMWG_MODEL_HIER_NORMAL && s->d.pad > 0) snprintf(buf, sizeof buf, "amwg_sweep_kernel%s<HierNormalModel,%d>", s->certified ? "_cert" : "", cls);
     else {
       static const char *const fam[] = {"NormalModel", "BetaBernModel", "HierNormalModel", "PoisGlmModel"};
       const int f = s->model == AMWG_MODEL_NORMAL ? 0 : (s->model == AMWG_MODEL_BETA_BERN ? 1 : (s->model == AMWG_MODEL_HIER_NORMAL ? 2 : 3));
-      snprintf(buf, sizeof buf, "amwg_step_kernel<%s,%d,%d>", fam[f], s->lanes, s->lanes > 64 ? (s->lanes <= 256 ? 256 : (s->lanes <= 512 ? 512 : 1024)) : cls);
+      snprintf(buf, sizeof buf, "amwg_step_kernel%s<%s,%d,%d>", s->certified ? "_cert" : "", fam[f], s->lanes, s->lanes > 64 ? (s->lanes <= 256 ? 256 : (s->lanes <= 512 ? 512 : 1024)) : cls);
     }
     m->kernel_name = buf;
   }

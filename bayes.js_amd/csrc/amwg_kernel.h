@@ -117,7 +117,7 @@ template <class M, class = void> struct LaneReuseOf { static constexpr bool valu
 template <class M> struct LaneReuseOf<M, void_of<decltype(M::kLaneReuse)>> { static constexpr bool value = M::kLaneReuse; };
 
 // Does the model offer a cheaper value of log_post with a bound on its distance from the expression's (Model::kCertified, log_post_approx)?
-template <class M, class = void> struct CertifiedOf { static constexpr bool value = false; };
+template <class M, class = void> struct CertifiedOf { static constexpr bool value = false; static constexpr int lanes = 0; };
 template <class M> struct CertifiedOf<M, void_of<decltype(M::kCertified)>> { static constexpr bool value = M::kCertified; static constexpr int lanes = M::kCertifiedLanes; };
 template <class M, int G, class = void> struct CertifiedAt { static constexpr bool value = false; };
 template <class M, int G> struct CertifiedAt<M, G, void_of<decltype(M::kCertified)>> { static constexpr bool value = M::kCertified && M::kCertifiedLanes == G; };
@@ -562,7 +562,7 @@ template <class M> struct MirrorCheckOf<M, void_of<decltype(M::kMirrorCheck)>> {
 // BT: the workgroup size class the caller is compiled for (its register budget, see amwg_step_kernel); 1024-thread workgroups leave 128
 // VGPRs per lane, and with four waves per SIMD the staged pass does not need eight observations in flight per lane to keep the pipe busy:
 // it runs four-wide there (same operations in the same order, half the registers).
-template <class Model, int G, int BT = 256, bool GL = false, bool SW = false>
+template <class Model, int G, int BT = 256, bool GL = false, bool SW = false, bool CT = false>
 __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem) {
   // (round 5: in the sweep kernel the expression's passes are the rare path -- certified decisions, amwg_models.h HierNormalModel::sweep_approx --: two-wide, what
   // counts is the registers they leave to everything else)
@@ -638,14 +638,17 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   else rng.init(a.seed, a.chain_offset + (uint64_t)cl, a.ch.rng_n[cl], tid);
   double lp_curr = a.ch.lp_curr[cl];
   __syncthreads();
-  constexpr bool kCert = CertifiedAt<Model, G>::value && !GL && (SW == CertNeedsRows<Model>::value);      // (certified decisions, below.  One lane per chain: the Normal family; 16 lanes: the Poisson family; the sweep kernel: the hierarchical family)
+  // (CT: certified decisions are a kernel of their own -- amwg_step_kernel_cert / amwg_sweep_kernel_cert below --, not a run-time switch: the kernel that
+  // evaluates the expression in every update carries none of the certified paths, and the certified sweep kernel none of the lane-order sums)
+  constexpr bool kCert = CT && CertifiedAt<Model, G>::value && !GL && (SW == CertNeedsRows<Model>::value);      // (certified decisions, below.  One lane per chain: the Normal family; 16 lanes: the Poisson family; the sweep kernel: the hierarchical family)
+  static_assert(kCert == CT, "a certified kernel is instantiated for a model that has no certified value at this lane count");
   // THE EXPRESSION: log_post of the state as it stands, term by term.  In the lane order of this geometry (log_post above: G per-lane sums and a butterfly) -- or, in
   // the certified kernels of models that can (Model::reference_order), as ONE running sum in the reference's own order: slow (every term passes through a
   // cross-lane broadcast), but it runs for ~1e-7 of the updates, and it makes what these kernels decide and store the REFERENCE's at every lane count.
   constexpr bool kRefOrder = kCert && G > 1 && RefOrderOf<Model>::value;
   auto expression = [&]() -> double {
-    if constexpr (kRefOrder) { if (a.certified) return Model::template reference_order<G>(cache, S, a.mc, a.d, data_lds, sub); }
-    if constexpr (!GL) return log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);
+    if constexpr (kRefOrder) return Model::template reference_order<G>(cache, S, a.mc, a.d, data_lds, sub);
+    else if constexpr (!GL) return log_post<Model, G, kPassU>(S, a, data_lds, sub, xw, cache);
     else return 0.0;      // (the group-local kernel forms log_post from its pieces)
   };
   if constexpr (!GL) { if (a.init_lp) lp_curr = expression(); }  // ctor warm-up call, mcmc.js:961-963 (the group-local kernel forms it from its pieces below, in every launch)
@@ -1125,7 +1128,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           bool sweep_certified = false;
           if constexpr (kCert) {
             const int top = d_len;
-            if (a.certified && slot + d_len <= P_stepped && (top & (top - 1)) == 0) {
+            if (slot + d_len <= P_stepped && (top & (top - 1)) == 0) {
               const auto sa = Model::sweep_approx(cache, S, a.mc, a.d, data_lds, sub, sw_eval);      // {ok, comp, cur, neu (values), mag, mean_new, s2_new}
               const bool regular = sa.ok && __ballot(sa.comp != (lane64 & (top - 1))) == 0ull;
               if (regular) {
@@ -1164,15 +1167,15 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
               }
             }
             // (the path below compares the expression's values in this geometry's lane order: lp_curr must be one)
-            if (!sweep_certified && !lp_exact && !(kRefOrder && a.certified)) { lp_curr = expression(); lp_exact = true; lpA = lp_curr; epsA = 0.0; }
+            if constexpr (!kRefOrder) { if (!sweep_certified && !lp_exact) { lp_curr = expression(); lp_exact = true; lpA = lp_curr; epsA = 0.0; } }
           }
           if (sweep_certified) continue;
           // (deciding against the reference's order: a sweep that is not certified as a whole is walked update by update -- each update certified on its own or
           // decided by the expression in that order; the lanes' sums in THIS geometry's order, which the path below compares, are not what is compared then)
-          const bool by_sums = !(kRefOrder && a.certified);
+          constexpr bool by_sums = !kRefOrder;
           using SweepRowsT = decltype(Model::template prefetch_rows<kPassU>(cache, S, a.mc, a.d, data_lds, sub, sw_eval, a.d.pad));
           SweepRowsT rows{};      // (ok = false)
-          if (by_sums) rows = Model::template prefetch_rows<kPassU>(cache, S, a.mc, a.d, data_lds, sub, sw_eval, a.d.pad);
+          if constexpr (by_sums) rows = Model::template prefetch_rows<kPassU>(cache, S, a.mc, a.d, data_lds, sub, sw_eval, a.d.pad);
           if (by_sums && rows.ok && slot + d_len <= P_stepped) {
             // every lane holds its committed sum and its sum under its component's proposal: an update is the butterfly of the 64 sums with the
             // proposed ones in the lanes of ITS component -- the value the whole evaluation returns for that state, bit for bit --, the accept test,
@@ -1290,7 +1293,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       if constexpr (kCert) {
         // (the model's pass is the WAVEFRONT's: with a lane per chain the 64 chains of a wave are evaluated together, every lane taking part whether its own
         // proposal needs a value or not -- control flow is uniform here: the slot loop is, and the lanes have come back together from their rnorm loops)
-        if (a.certified && __ballot(inb) != 0ull) {
+        if (__ballot(inb) != 0ull) {
           wave_priority(0);
           const typename Model::Approx r = Model::template log_post_approx<G, BT>(cache, S, a.mc, a.d, data_lds, sub);
           wave_priority(kStepperPriority);
@@ -1399,6 +1402,18 @@ template <class Model, int BT>
 __global__ void __launch_bounds__(BT, MinWavesOf<Model>::value) amwg_sweep_kernel(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   step_body<Model, 64, BT, false, true>(a, smem);
+}
+// the kernels that DECIDE FROM CERTIFIED VALUES (step_body: kCert -- options.full_evaluation = 0 for a model and lane count that has them): the ordinary one
+// (the Normal family at one lane per chain, the Poisson family at 16) and the sweep kernel (the hierarchical family)
+template <class Model, int G, int BT>
+__global__ void __launch_bounds__(BT, MinWavesOf<Model>::value) amwg_step_kernel_cert(const StepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  step_body<Model, G, BT, false, false, true>(a, smem);
+}
+template <class Model, int BT>
+__global__ void __launch_bounds__(BT, MinWavesOf<Model>::value) amwg_sweep_kernel_cert(const StepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  step_body<Model, 64, BT, false, true, true>(a, smem);
 }
 // the group-local kernel of a family that has one (amwg_gl.h): a chain on one whole wavefront
 template <class Model, int BT>

@@ -15,15 +15,19 @@ using namespace amwg;
 #if AMWG_FAMILY == 0
 using Family = NormalModel;
 #define AMWG_FAMILY_LOOKUP amwg_kernels_normal
+#define AMWG_FAMILY_CERT_LOOKUP amwg_kernels_cert_normal
 #elif AMWG_FAMILY == 1
 using Family = BetaBernModel;
 #define AMWG_FAMILY_LOOKUP amwg_kernels_beta_bern
+#define AMWG_FAMILY_CERT_LOOKUP amwg_kernels_cert_beta_bern
 #elif AMWG_FAMILY == 2
 using Family = HierNormalModel;
 #define AMWG_FAMILY_LOOKUP amwg_kernels_hier_normal
+#define AMWG_FAMILY_CERT_LOOKUP amwg_kernels_cert_hier_normal
 #elif AMWG_FAMILY == 3
 using Family = PoisGlmModel;
 #define AMWG_FAMILY_LOOKUP amwg_kernels_pois_glm
+#define AMWG_FAMILY_CERT_LOOKUP amwg_kernels_cert_pois_glm
 #else
 #error "AMWG_FAMILY must be 0..3"
 #endif
@@ -74,6 +78,35 @@ step_kernel_t amwg_kernel_hier_sweep(int block) {
   }
 }
 #endif
+
+// the kernel that decides from certified values (amwg_kernel.h kCert; options.full_evaluation = 0), for the lane count the family has one at: the ordinary
+// stepper (Normal: one lane per chain; Poisson: 16), or -- families whose certified value needs the row layout -- the sweep kernel (hierarchical: 64 lanes,
+// workgroups of at most 512 threads).  nullptr: none.
+namespace {
+template <class Family>      // (a template: the branches a family has no kernel for must not be instantiated)
+step_kernel_t certified_lookup(int lanes, int block) {
+  if constexpr (CertifiedOf<Family>::value) {
+    constexpr int GC = CertifiedOf<Family>::lanes;
+    if (lanes != GC) return nullptr;
+    if constexpr (CertNeedsRows<Family>::value) {
+      switch (class_of(block)) {
+        case 256: return amwg_sweep_kernel_cert<Family, 256>;
+        case 512: return amwg_sweep_kernel_cert<Family, 512>;
+        default: return nullptr;
+      }
+    } else {
+      switch (class_of(block)) {
+        case 256: return amwg_step_kernel_cert<Family, GC, 256>;
+        case 512: if constexpr (Family::kMaxThreads >= 512) return amwg_step_kernel_cert<Family, GC, 512>; else return nullptr;
+        default: if constexpr (Family::kMaxThreads >= 1024) return amwg_step_kernel_cert<Family, GC, 1024>; else return nullptr;
+      }
+    }
+  }
+  (void)lanes; (void)block;
+  return nullptr;
+}
+}  // namespace
+step_kernel_t AMWG_FAMILY_CERT_LOOKUP(int lanes, int block) { return certified_lookup<Family>(lanes, block); }
 
 step_kernel_t AMWG_FAMILY_LOOKUP(int lanes, int block) {
   switch (lanes) {

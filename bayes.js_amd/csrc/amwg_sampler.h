@@ -32,6 +32,7 @@ struct amwg_sampler {
   // geometry
   int lanes = 0, block = 0, grid = 0, lds = 0, cpb = 0;   // cpb: chains per workgroup if fewer than block / lanes (StepArgs::cpb)
   step_kernel_t kernel = nullptr;
+  bool certified = false;      // `kernel` is one of the kernels that decide from certified values (amwg_kernel.h kCert: amwg_step_kernel_cert / amwg_sweep_kernel_cert)
   std::string kernel_name;          // amwg_kernel_name(): filled on first request
   uint32_t hier_periodic_mask = 0;   // HIER: bit j set = the group labels repeat with a lane stride of 2^j (g[i] == g[i mod 2^j])
   bool lp_ready = false;

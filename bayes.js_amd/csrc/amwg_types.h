@@ -112,8 +112,8 @@ struct StepArgs {
   int32_t init_lp;          // 1 = first launch: compute lp_curr = log_post(init) (the ctor's warm-up call, mcmc.js:961-963)
   int32_t finalize_lp;              // 1 = leave the expression's value of log_post(state) in lp_curr (amwg_chain_diag asks for it; a launch otherwise hands the stepper's
                                     // cheaper value and its bound on to the next launch: no closing evaluation per launch)
-  int32_t certified;                // 1 = accept tests may be decided from a model's cheaper value of log_post with its bound (amwg_kernel.h "certified decisions"):
-                                    // amwg_options::full_evaluation == 0 and not exact_division
+  int32_t certified;                // 1 = this launch is of a kernel that decides accept tests from a model's cheaper value of log_post with its bound (amwg_kernel.h
+                                    // "certified decisions": amwg_step_kernel_cert / amwg_sweep_kernel_cert).  Informational: the kernels do not branch on it
   double bound_scale;               // 2^amwg_options::test_bound_shift (1 in production): multiplies the bounds of the certified decisions
   int32_t sweep_update_by_update;   // amwg_options::full_evaluation == 2: the sweep kernel decides a sweep's accept tests one after the other (verification switch)
   int32_t cpb;              // chains per workgroup when the per-chain state of blockDim / lanes chains does not fit LDS (0 = all of them);

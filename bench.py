@@ -353,17 +353,20 @@ def flip_rate_record(kernel_id=None):
                 "library_version_of_campaign": r.get("version")}
     return {"source": os.path.relpath(fs[-1], ROOT), "decisions_total": r["decisions_total"], "first_flips_total": r["first_flips_total"],
             "flips_per_1e9": r["flips_per_1e9"], "upper_95_per_1e9": r["upper_95_per_1e9"], "library_version_of_campaign": r.get("version"),
+            "reference_order": r.get("reference_order"),
             "per_run": [{"workload": q["workload"], "geometry": q["geometry"], "chains": q["chains"], "steps": q["steps"], "decisions": q["decisions"],
                          "chains_differing": q["chains_differing"], "lp_abs_diff_max": q["lp_abs_diff_max"], "expected_flips_bound": q["expected_flips_bound"]} for q in r["runs"]],
-            "note": "one lane per chain IS the reference's order (bit-identical draws); at more lanes a decision can differ only when the accept uniform falls "
-                    "inside the ~1e-12-relative sliver between the two summation orders' exp(delta): counted here, chain by chain"}
+            "note": "one lane per chain IS the reference's order (bit-identical draws), and so are the multi-lane defaults of cfg4 / cfg5 (reference_order: decided against the "
+                    "expression in that order -- zero chains may differ); in the other multi-lane kernels (flips_per_1e9) a decision can differ only when the accept uniform "
+                    "falls inside the ~1e-12-relative sliver between the two summation orders' exp(delta): counted here, chain by chain"}
 
 
 def golden_schedule_check(s, gold, locals_and_records, lanes):
     """Runs the golden case's schedule ON THE GIVEN (full-size) SAMPLER -- device-resident draws -- and compares the listed local chains with
     the seeded run of the unmodified reference stored in tests/golden/<case>.json: accept counts, in-bounds counts, adaptation state and
-    uniforms consumed always (the reference's decisions); with one lane per chain (the reference's summation order) also every stored
-    draw, the running sums over all kept draws and the final state, bit for bit.  -> dict of booleans."""
+    uniforms consumed always (the reference's decisions); where the sampler decides in the reference's summation order (amwg_summation_order() == 1: one
+    lane per chain, and the certified multi-lane kernels of cfg4 / cfg5 since round 5) also every stored draw, the running sums over all kept draws, the
+    final state and the cached log_post, bit for bit.  -> dict of booleans."""
     import torch
     case = gold["case"]
     P, C = s.P, s.C
@@ -380,8 +383,9 @@ def golden_schedule_check(s, gold, locals_and_records, lanes):
             seg_draws.append(d)
     info, diag, state = s.info(), s.diag(), s.state()
     ok = {"accept_counts_identical": True, "uniforms_consumed_identical": True, "adaptation_state_identical": True}
+    lanes = s.launch_info().get("summation_order", lanes)      # (1: the reference's own order whatever the lane count)
     if lanes == 1:
-        ok.update({"draws_bit_identical": True, "running_sums_bit_identical": True, "final_state_bit_identical": True})
+        ok.update({"draws_bit_identical": True, "running_sums_bit_identical": True, "final_state_bit_identical": True, "log_post_bit_identical": True})
     for local, rec in locals_and_records:
         ok["accept_counts_identical"] &= info["accepts"][:, local].tolist() == rec["accepts"] and info["inbounds"][:, local].tolist() == rec["inbounds"]
         ok["uniforms_consumed_identical"] &= int(diag["uniforms"][local]) == rec["uniforms"]
@@ -390,6 +394,7 @@ def golden_schedule_check(s, gold, locals_and_records, lanes):
         if lanes == 1:
             ok["adaptation_state_identical"] &= info["prop_log_scale"][:, local].tolist() == rec["prop_log_scale"]
             ok["final_state_bit_identical"] &= state[:, local].tolist() == rec["final_state"]
+            ok["log_post_bit_identical"] &= float(diag["log_post"][local]) == rec["log_post"]
             for d, want in zip(seg_draws, rec["samples"]):
                 col = d[:, :, local].cpu().numpy()                      # (rows, P) of ONE chain
                 w = np.array(want["draws"], dtype=np.float64).reshape(-1, P)
@@ -409,12 +414,13 @@ def timed_geometry_parity(A, spec, workload, chains, make_sampler, lanes):
     shard of 2048).  Returns (report, the sampler of shard 0 -- advanced by the golden schedule, reused as the timed one)."""
     import golden_io
     gold = golden_io.load(GOLDEN_OF[workload])
-    first, report, checked = None, None, []
+    first, report, checked, order = None, None, [], lanes
     by_shard = {}
     for rec in gold["chains"]:
         by_shard.setdefault(rec["chain"] // chains, []).append(rec)
     for shard in sorted(by_shard):
         smp = make_sampler(shard * chains)
+        order = smp.launch_info().get("summation_order", lanes)
         r = golden_schedule_check(smp, gold, [(rec["chain"] - shard * chains, rec) for rec in by_shard[shard]], lanes)
         checked += [rec["chain"] for rec in by_shard[shard]]
         report = r if report is None else {k: report[k] and r[k] for k in r}
@@ -425,8 +431,10 @@ def timed_geometry_parity(A, spec, workload, chains, make_sampler, lanes):
     sched = gold["case"]["schedule"]
     report.update({"golden": "tests/golden/%s.json (seeded run of the unmodified reference)" % GOLDEN_OF[workload], "chains_checked": checked,
                    "schedule": sched, "from_timed_sampler": True, "chains_in_sampler": chains, "lanes_per_chain": lanes,
-                   "reference_order": lanes == 1,
+                   "summation_order": order, "reference_order": order == 1,
                    "note": ("one lane per chain: every draw of every chain is the reference's, bit for bit" if lanes == 1 else
+                            "%d lanes per chain, decisions certified against the expression in the REFERENCE's order (amwg_summation_order() == 1): every draw, the final "
+                            "state and the cached log_post of the checked chains are the reference's, bit for bit" % lanes if order == 1 else
                             "%d lanes per chain: the sum over observations is formed in lane order, so doubles are compared with the oracle in the same "
                             "order by the test suite; here: every accept decision, adaptation step and uniform count equals the reference's" % lanes)})
     return report, first
@@ -527,9 +535,11 @@ def measure_other_config(A, name, device, group_local=0):
 
 
 # What strict identity costs (round-4 review, item 7; mcmc.js:527-528): north_star asks for bit-identical accept counts.  With ONE lane per chain the
-# sum over observations is the reference's `lp += term`, so every draw and every decision is the reference's; the default geometry of cfg4 / cfg5
-# (a chain on a whole wavefront) decides 3 of 3.7e10 decisions differently (parity.flip_rate).  The same config forced to lanes_per_chain = 1, with the
-# chain count raised to the whole 8-GPU job so that the one-lane launch has lanes to fill the chip with (stated), is timed here.
+# sum over observations is the reference's `lp += term`, so every draw and every decision is the reference's.  Until round 5 the default geometry of cfg4 /
+# cfg5 summed in its own lane order (3 of 3.7e10 decisions differed); now those kernels decide against the expression in the reference's order
+# (amwg_summation_order() == 1: strict identity at no price), and the figure below -- the same config forced to lanes_per_chain = 1, with the chain count raised
+# to the whole 8-GPU job so that the one-lane launch has lanes to fill the chip with (stated) -- is what strict identity cost before, and still costs the
+# kernels that have no certified path (translated closures at > 1 lane, options.full_evaluation != 0).
 REFERENCE_ORDER_RUN = {"cfg4": (16_384, 20, 40), "cfg5": (65_536, 2, 3)}      # chains, warm-up steps, timed steps
 
 
@@ -697,6 +707,9 @@ def compact_line(out, detail_path=None):
         fr = p.get("flip_rate")
         if fr:
             line["parity"]["flip_rate"] = _pick(fr, "flips_per_1e9", "upper_95_per_1e9", "decisions_total", "first_flips_total", "refused")
+            ro = fr.get("reference_order")
+            if ro:      # the kernels that decide in the reference's order (cfg4 / cfg5 defaults): chains that differ from the one-lane run, of how many decisions
+                line["parity"]["flip_rate"]["reference_order"] = _pick(ro, "decisions_total", "chains_differing", "log_post_differs")
     oc = out.get("other_configs")
     if oc:
         line["other_configs"] = {}
@@ -711,6 +724,8 @@ def compact_line(out, detail_path=None):
                 q["kernel"] = kernel_base_name(rr["kernel"])
             pp = o.get("parity") or {}
             q["parity_ok"] = bool(pp) and all(v for k, v in pp.items() if k.endswith("_identical"))
+            if pp.get("summation_order") is not None:
+                q["summation_order"] = pp["summation_order"]      # (1: the reference's own order -- draws, final state and log_post are among the *_identical above)
             line["other_configs"][name] = q
     e = out.get("end_to_end_js")
     if isinstance(e, dict) and "updates_per_s" in e:

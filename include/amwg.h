@@ -123,16 +123,21 @@ typedef struct {
                               bit for bit; accept decisions, adaptation and uniforms consumed equal the reference's on every golden and over the
                               1e10-decision campaign of tools/flip_rate.py (a decision can differ only when the accept uniform falls inside the ~1e-12-relative
                               sliver between the two summation orders).  Opt-in, reported separately by bench.py */
-  int32_t full_evaluation; /* 0 = default: the hierarchical family on a wavefront per chain keeps the per-lane sums of log_post that an update cannot have changed
-                              (an update of theta_g changes the sums of the lanes that hold group g only; csrc/amwg_models.h lane_sum_rows), and draws the
-                              proposals of a whole sweep over theta ahead -- in stream order: nothing an update draws depends on an earlier decision -- so that
-                              ONE pass forms every lane's proposed sum (prefetch_rows; amwg_sweep_kernel) -- the same values, bit for bit, as evaluating
-                              everything, like the cached log_post of the current state; a translated closure with a row plan (amwg_user_model::rows_*)
-                              does the same.  The accept tests of such a sweep are decided all at once, each from the difference of its entry's lanes' sums
-                              with a rigorous bound on what the butterflies' roundings can add (csrc/amwg_kernel.h: a uniform inside that sliver, ~1e-8 of
-                              the sweeps, sends the sweep down the update-by-update path).  1 = every evaluation makes its full pass over the data.
-                              2 = as 0, but every sweep takes the update-by-update path (a butterfly of the 64 sums per update): a verification switch --
-                              0, 1 and 2 give the same bits */
+  int32_t full_evaluation; /* How accept tests get their log_post values (mcmc.js:524-528).  All three settings give the same draws; they differ in what is evaluated
+                              how often, and in the summation order the rare close call is decided in.
+                              0 = default: CERTIFIED DECISIONS where the library has them (csrc/amwg_kernel.h; the kernels amwg_step_kernel_cert / amwg_sweep_kernel_cert):
+                              the Normal family at one lane per chain, the Poisson family at 16 lanes, the hierarchical family on a wavefront per chain in its row
+                              layout (the proposals of a whole sweep over theta drawn ahead -- in stream order: nothing an update draws depends on an earlier decision --
+                              and all its accept tests decided at once).  The test is decided from a cheaper value of log_post with a rigorous bound on its distance from
+                              the reference's expression summed in the REFERENCE's order (one running sum); a uniform inside the bound (1e-7 .. 1e-6 of the updates)
+                              gets that expression itself.  Decisions, draws and the cached log_post are the reference's at every one of those lane counts
+                              (amwg_summation_order() == 1).  Every other geometry, and translated closures: the expression in every update, summed in lane order; a
+                              closure with a row plan (amwg_user_model::rows_*) keeps the per-lane sums an update cannot have changed and prepares a sweep's
+                              sums in one pass.
+                              1 = every evaluation is the expression, with its full pass over the data, summed in the geometry's lane order (amwg_step_kernel).
+                              2 = the hierarchical family's row layout without certified decisions (amwg_sweep_kernel): per-lane sums kept while an update cannot
+                              have changed them (csrc/amwg_models.h lane_sum_rows), a sweep's proposed sums formed in one pass (prefetch_rows), its accept tests
+                              one after the other from butterflies of those sums -- bit for bit what 1 computes.  A verification switch */
   int32_t test_bound_shift; /* TEST HOOK, 0 in production: the rounding bounds of the certified decisions (csrc/amwg_kernel.h: accept tests decided from a cheaper value
                                of log_post, from the local differences of a sweep, early rejections) are multiplied by 2^shift, 0..40.  A wider bound sends more
                                updates down the path that evaluates the reference's expression; the results must not change by a bit (tests run 0 against 14 and 40) */
@@ -302,7 +307,8 @@ int64_t amwg_num_chains(const amwg_sampler *s);
 int amwg_launch_info(const amwg_sampler *s, int32_t *lanes_per_chain, int32_t *block_threads, int32_t *grid_blocks,
                      int32_t *lds_bytes, int32_t *n_launches, double *kernel_ms);
 /* Name of the step kernel this sampler launches, as a profiler lists it (without the amwg:: qualifiers): "amwg_step_kernel<HierNormalModel,64,512>",
- * "amwg_sweep_kernel<HierNormalModel,512>" (the hierarchical family's row layout: lane-local re-evaluation + sweep prefetch),
+ * "amwg_sweep_kernel<HierNormalModel,512>" (the hierarchical family's row layout: lane-local re-evaluation + sweep prefetch), "amwg_step_kernel_cert<NormalModel,1,256>" /
+ * "amwg_sweep_kernel_cert<HierNormalModel,512>" (the kernels that decide from certified values: options.full_evaluation = 0 where a family has them),
  * "amwg_gl_kernel<HierGlModel,512>" (options.group_local), "amwg_user_step" (a translated closure).  The last number is the workgroup size
  * class the kernel was compiled for (256 / 512 / 1024).  Valid until the sampler is destroyed. */
 const char *amwg_kernel_name(const amwg_sampler *s);

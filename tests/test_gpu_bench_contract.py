@@ -39,7 +39,7 @@ def test_default_line_has_the_contract_fields_and_an_honest_roofline():
     assert abs(d["value"] - full["value"]) < 1e-6 * full["value"]
     r = d["roofline"]
     assert r["bound"] == "fp64_valu" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
-    assert "traffic" in r and r["kernel"].startswith("amwg_step_kernel<NormalModel,1") and "certified" in r["kernel"]
+    assert "traffic" in r and r["kernel"].startswith("amwg_step_kernel_cert<NormalModel,1") and "certified" in r["kernel"]
     # the default decides from the certified pass (2 operations per observation); the kernel that evaluates the reference's expression in every update is
     # measured beside it and is slower
     assert full["roofline"]["lane_ops_per_obs"] == 2 and 0 < d["full_evaluation"]["frac"] < 1 and d["full_evaluation"]["value"] < d["value"]
@@ -57,9 +57,13 @@ def test_default_line_has_the_contract_fields_and_an_honest_roofline():
         assert o["value"] > 0 and 0 < o["roofline"]["frac"] < 1 and o["parity"]["accept_counts_identical"] and o["parity"]["uniforms_consumed_identical"]
         assert q["value"] > 0 and 0 < q["frac"] < 1 and q["parity_ok"] is True
     assert full["other_configs"]["cfg3"]["parity"]["draws_bit_identical"] is True
+    for name in ("cfg4", "cfg5"):      # round 5: the multi-lane defaults decide in the reference's own summation order -- the reference golden's chains, every bit
+        pr = full["other_configs"][name]["parity"]
+        assert pr["lanes_per_chain"] > 1 and pr["summation_order"] == 1 and pr["reference_order"] is True, pr
+        assert pr["draws_bit_identical"] and pr["running_sums_bit_identical"] and pr["final_state_bit_identical"] and pr["log_post_bit_identical"], pr
     # cfg4: `value` and `frac` describe the SAME kernel (the sweep kernel against its one certified 2-operation pass per step); the price of strict reference order beside it
     c4 = full["other_configs"]["cfg4"]
-    assert c4["roofline"]["kernel"].startswith("amwg_sweep_kernel") and c4["value_kernel"] == c4["roofline"]["kernel"]
+    assert c4["roofline"]["kernel"].startswith("amwg_sweep_kernel_cert<") and c4["value_kernel"] == c4["roofline"]["kernel"]
     assert abs(c4["roofline"]["achieved"] - c4["value"] / 34 * 1 * 10000 * 2) < 1e-6 * c4["roofline"]["achieved"] and 0 < c4["full_evaluation_frac"] < 1
     assert d["other_configs"]["cfg4"]["kernel"].startswith("amwg_sweep_kernel")
     for name in ("cfg4", "cfg5"):

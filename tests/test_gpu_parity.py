@@ -493,8 +493,9 @@ def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains, th
     a, b, c2, c3, c4 = mk(0), mk(1), mk(2), mk(0, 12), mk(0, 40)
     one = A.Sampler(spec, chains=chains, seed=4, chain_offset=9, lanes_per_chain=1, steps_per_launch=7, full_evaluation=1, **kw)
     assert a.launch_info()["lds_bytes"] != b.launch_info()["lds_bytes"]      # the row layout (tile + term rows) is in use on one side only
-    assert c2.launch_info()["kernel"] == a.launch_info()["kernel"] == c3.launch_info()["kernel"]
-    assert a.launch_info()["kernel"].startswith("amwg_sweep_kernel<HierNormalModel") and b.launch_info()["kernel"].startswith("amwg_step_kernel<HierNormalModel,64")
+    assert a.launch_info()["kernel"] == c3.launch_info()["kernel"] == c4.launch_info()["kernel"] and a.launch_info()["kernel"].startswith("amwg_sweep_kernel_cert<HierNormalModel")
+    assert c2.launch_info()["kernel"].startswith("amwg_sweep_kernel<HierNormalModel") and b.launch_info()["kernel"].startswith("amwg_step_kernel<HierNormalModel,64")
+    assert [s.launch_info()["summation_order"] for s in (a, c3, c4, one, b, c2)] == [1, 1, 1, 1, 64, 64]
     assert one.launch_info()["lanes_per_chain"] == 1
     outs = []
     for s in (a, c3, c4, one, b, c2):

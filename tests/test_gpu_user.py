@@ -165,8 +165,8 @@ def test_row_plan_of_a_translated_closure_reproduces_the_reference_and_the_full_
 
 def test_translated_hierarchical_closure_at_full_size_runs_the_sweep_kernel_and_equals_the_hand_written_family():
     """BASELINE.json configs[3] written as a plain closure, 64 lanes per chain, 2 048 chains: the translated closure runs amwg_user_sweep (row plan + sweep
-    prefetch) and gives the same bits as the hand-written family's sweep kernel -- two implementations of the same 64-lane order -- and the decisions of the
-    seeded reference run (cfg4_full: chain ids 0 and 16383)."""
+    prefetch) and gives the same bits as the hand-written family's lane-order sweep kernel -- two implementations of the same 64-lane order --, the draws of its
+    certified sweep kernel, and the decisions of the seeded reference run (cfg4_full: chain ids 0 and 16383)."""
     import model_spec
     from gpu_util import run_schedule
     gold = golden_io.load("cfg4_full")
@@ -176,14 +176,17 @@ def test_translated_hierarchical_closure_at_full_size_runs_the_sweep_kernel_and_
         spec = _golden_spec(gold, rec, src, arrays, meta)
         bspec = model_spec.spec_from_golden(gold, rec)
         kw = dict(chains=4, seed=gold["case"]["seed"], chain_offset=rec["chain"], lanes_per_chain=64)
-        a, b = A.Sampler(spec, **kw), A.Sampler(bspec, **kw)
-        assert a.launch_info()["kernel"] == "amwg_user_sweep" and b.launch_info()["kernel"].startswith("amwg_sweep_kernel")
-        da, db = run_schedule(a, gold["case"]["schedule"]), run_schedule(b, gold["case"]["schedule"])
-        assert all(x.tobytes() == y.tobytes() for x, y in zip(da, db))
-        assert a.state().tobytes() == b.state().tobytes() and a.diag()["log_post"].tobytes() == b.diag()["log_post"].tobytes()
+        # (b: the hand-written family's sweep kernel in the same 64-lane order -- options.full_evaluation = 2; c: its default, the certified sweep kernel, which
+        # decides against the expression in the reference's order: same draws, log_post in the last bits apart)
+        a, b, c = A.Sampler(spec, **kw), A.Sampler(bspec, full_evaluation=2, **kw), A.Sampler(bspec, **kw)
+        assert a.launch_info()["kernel"] == "amwg_user_sweep" and b.launch_info()["kernel"].startswith("amwg_sweep_kernel<") and c.launch_info()["kernel"].startswith("amwg_sweep_kernel_cert<")
+        da, db, dc = (run_schedule(q, gold["case"]["schedule"]) for q in (a, b, c))
+        assert all(x.tobytes() == y.tobytes() == z.tobytes() for x, y, z in zip(da, db, dc))
+        assert a.state().tobytes() == b.state().tobytes() == c.state().tobytes() and a.diag()["log_post"].tobytes() == b.diag()["log_post"].tobytes()
+        assert float(c.diag()["log_post"][0]) == rec["log_post"]      # the reference's own value
         info = a.info()
         assert info["accepts"][:, 0].tolist() == rec["accepts"] and info["inbounds"][:, 0].tolist() == rec["inbounds"] and int(a.diag()["uniforms"][0]) == rec["uniforms"]
-        a.close(); b.close()
+        a.close(); b.close(); c.close()
 
 
 FULL_SIZE = [("bench_normal", "cfg2_full"), ("bench_bern", "cfg3_full"), ("bench_hier", "cfg4_full"), ("bench_glm", "cfg5_full")]

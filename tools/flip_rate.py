@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """tools/flip_rate.py -- the decision-parity campaign (GPU box): the same seeded job with one lane per chain (the reference's summation order)
-and at 64 lanes / group-local, counting the chains whose run ever differs (tests/decision_parity.py).  Prints one JSON object; the committed
-copy is profiles/r05_flip_rate.json, quoted in DESIGN.md section 2 and in the bench line's parity.flip_rate.
+and at 64 / 32 / 16 lanes / group-local, counting the chains whose run ever differs (tests/decision_parity.py).  Two groups: the kernels that decide
+against the expression in the reference's own order (amwg_summation_order() == 1: the defaults of cfg4 and cfg5 since round 5) must not differ in ANY chain,
+cached log_post included; the others (their own lane order) get a rate.  Prints one JSON object; the committed copy is profiles/r05_flip_rate.json, quoted in
+DESIGN.md section 2 and in the bench line's parity.flip_rate.
 
     python tools/flip_rate.py [--scale 1.0] > gpurun_out/flip_rate.json
 """
@@ -47,11 +49,19 @@ def main():
         runs.append(r)
         print("%-14s %-44s decisions %.3g  differing %d  lp diff max %.3g mean %.3g  (%.1f s)" %
               (wl, json.dumps(alt), r["decisions"], r["chains_differing"], r["lp_abs_diff_max"] or -1, r["lp_abs_diff_mean"] or -1, r["seconds"]), file=sys.stderr)
-    tot_d = sum(r["decisions"] for r in runs)
-    tot_f = sum(r["first_flips"] for r in runs)
+    ref = [r for r in runs if r["geometry"].get("summation_order") == 1]
+    lane = [r for r in runs if r["geometry"].get("summation_order") != 1]
+    tot_d = sum(r["decisions"] for r in lane)
+    tot_f = sum(r["first_flips"] for r in lane)
     out = {"what": "same seed, same chain ids: one lane per chain (reference order) vs the listed geometry; a chain 'differs' when its final state, accept / "
-                   "in-bounds counts, proposal scales or uniform count differ (mcmc.js:527-528: the accept test is the only place the summation order can matter)",
-           "version": A.lib().amwg_version().decode(), "runs": runs, "decisions_total": tot_d, "first_flips_total": tot_f,
+                   "in-bounds counts, proposal scales or uniform count differ (mcmc.js:527-528: the accept test is the only place the summation order can matter).  "
+                   "reference_order: the kernels that decide against the expression in the reference's order (summation_order 1) -- not one chain may differ, cached "
+                   "log_post included; decisions_total / flips_per_1e9: the kernels that sum in their own lane order",
+           "version": A.lib().amwg_version().decode(), "runs": runs,
+           "reference_order": {"decisions_total": sum(r["decisions"] for r in ref), "chains_differing": sum(r["chains_differing"] for r in ref),
+                               "log_post_differs": any((r["lp_abs_diff_max"] or 0.0) != 0.0 for r in ref),
+                               "geometries": [dict(r["geometry"], workload=r["workload"]) for r in ref]},
+           "decisions_total": tot_d, "first_flips_total": tot_f,
            "flips_per_1e9": tot_f / tot_d * 1e9, "upper_95_per_1e9": (3.0 if tot_f == 0 else tot_f + 2.0 * tot_f ** 0.5 + 2.0) / tot_d * 1e9}
     print(json.dumps(out))
 

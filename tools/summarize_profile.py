@@ -14,14 +14,17 @@ shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, tag +
 bench = json.load(open(os.path.join(src, "bench_under_trace.json")))
 # the kernel the bench line is about (the parity gate of bench.py also launches one-lane kernels: not those)
 import re
-m = re.match(r"amwg_step_kernel<(\w+),(\d+)(?:,(\d+))?>", bench["roofline"]["kernel"]) or re.match(r"amwg_(sweep|gl)_kernel<(\w+),(\d+)>", bench["roofline"]["kernel"])
+# ("amwg_step_kernel_cert<NormalModel,1,256> (certified decisions)" -> function name, template arguments; the kernels that decide from certified values are
+# functions of their own, amwg_step_kernel_cert / amwg_sweep_kernel_cert: a profile that also holds the plain kernel -- bench.py's full_evaluation side measurement --
+# must not mix the two)
+m = re.match(r"(amwg_step_kernel(?:_cert)?)<(\w+),(\d+)(?:,(\d+))?>", bench["roofline"]["kernel"]) or re.match(r"(amwg_(?:sweep|gl)_kernel(?:_cert)?)<(\w+),(\d+)>", bench["roofline"]["kernel"])
 workload = re.search(r"--workload (\w+)", open(os.path.join(src, "command.txt")).read() if os.path.exists(os.path.join(src, "command.txt")) else "")
 workload = workload.group(1) if workload else "cfg2"
-is_bench_kernel = lambda name: ("amwg_step_kernel" in name and re.search(r"%s,\s*%s(,\s*\d+)?>" % (m.group(1), m.group(2)), name) is not None)
+is_bench_kernel = lambda name: (m.group(1) + "<" in name and re.search(r"%s,\s*%s(,\s*\d+)?>" % (m.group(2), m.group(3)), name) is not None)
 if "--group-local" in (open(os.path.join(src, "command.txt")).read() if os.path.exists(os.path.join(src, "command.txt")) else ""):
     is_bench_kernel = lambda name: "amwg_gl_kernel" in name      # the group-local evaluation is its own kernel since round 4 (csrc/amwg_gl.h)
 elif bench["roofline"]["kernel"].startswith("amwg_sweep_kernel"):
-    is_bench_kernel = lambda name: "amwg_sweep_kernel" in name   # the hierarchical family's row layout (lane-local re-evaluation + sweep prefetch)
+    is_bench_kernel = lambda name: m.group(1) + "<" in name   # the hierarchical family's row layout (the certified sweep kernel, or the lane-order one)
 pmc = {}
 meta = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
