@@ -112,8 +112,16 @@ def test_translated_closure_equals_hand_written_family_at_any_lane_count(name, b
     da, db = run_schedule(a, sched), run_schedule(b, sched)
     assert da[0].tobytes() == db[0].tobytes()
     assert a.state().tobytes() == b.state().tobytes()
-    assert a.diag()["log_post"].tobytes() == b.diag()["log_post"].tobytes()
     assert a.info()["accepts"].tolist() == b.info()["accepts"].tolist()
+    if b.launch_info()["summation_order"] != lanes:
+        # the hand-written family's default at this lane count decides against the expression in the REFERENCE's order (certified kernels, round 5): same draws,
+        # log_post a last-bits neighbour; the kernel that sums in the closure's lane order is options.full_evaluation = 1
+        assert b.launch_info()["summation_order"] == 1 and lanes > 1
+        b.close()
+        b = A.Sampler(bspec, full_evaluation=1, **kw)
+        db = run_schedule(b, sched)
+        assert da[0].tobytes() == db[0].tobytes() and a.state().tobytes() == b.state().tobytes()
+    assert a.diag()["log_post"].tobytes() == b.diag()["log_post"].tobytes()
     a.close(); b.close()
 
 
