@@ -27,8 +27,8 @@ _REFERENCE_RUNS = {}
     ("hier_n640_g8", 4096, 10_000, {"lanes_per_chain": 64, "group_local": 1}),
     ("glm_n500", 4096, 3_000, {"lanes_per_chain": 64}),
     ("glm_n500", 4096, 3_000, {"lanes_per_chain": 16}),
-    ("cfg4_size", 4096, 800, {"lanes_per_chain": 64}),
-    ("cfg4_size", 4096, 800, {"lanes_per_chain": 64, "group_local": 1}),
+    ("cfg4_size", 4096, 500, {"lanes_per_chain": 64}),
+    ("cfg4_size", 4096, 500, {"lanes_per_chain": 64, "group_local": 1}),
     ("normal_n1000", 8192, 10_000, {"lanes_per_chain": 64}),
 ])
 def test_decisions_at_many_lanes_equal_the_one_lane_run(workload, chains, steps, alt):

@@ -245,7 +245,7 @@ def test_translated_closures_reproduce_the_reference_at_full_baseline_sizes(clos
         assert float(s.diag()["log_post"][0]) == rec["log_post"]
 
 
-@pytest.mark.parametrize("name,chains,steps,lanes", [("logit_n10k", 512, 800, 16), ("logit_bern_n10k", 256, 600, 64), ("logistic_softplus", 8192, 10_000, 4)])
+@pytest.mark.parametrize("name,chains,steps,lanes", [("logit_n10k", 512, 500, 16), ("logit_bern_n10k", 256, 400, 64), ("logistic_softplus", 8192, 10_000, 4)])
 def test_translated_logistic_decisions_at_many_lanes_equal_the_one_lane_run(name, chains, steps, lanes):
     """Translated closures, decision parity counted as for the built-in families (tests/decision_parity.py): the same seeded job with one lane per
     chain (the reference's summation order) and lane-split -- where the fused softplus runs in its branch-free form, four terms per flag test, several
