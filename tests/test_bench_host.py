@@ -113,12 +113,17 @@ def test_flip_rate_of_a_campaign_run_with_other_kernels_is_refused(tmp_path, mon
     prof = tmp_path / "profiles"
     prof.mkdir()
     rec = {"version": "amwg-mi355x 0.4 (gfx950) build aaaaaaaaaaaa kernels 111111111111", "runs": [], "decisions_total": 10 ** 10, "first_flips_total": 1,
-           "flips_per_1e9": 0.1, "upper_95_per_1e9": 0.5}
+           "flips_per_1e9": 0.1, "upper_95_per_1e9": 0.5,
+           "reference_order": {"decisions_total": 2 * 10 ** 10, "chains_differing": 0, "log_post_differs": False, "geometries": [{"lanes_per_chain": 64, "summation_order": 1}] * 3}}
     (prof / "r04_flip_rate.json").write_text(json.dumps(dict(rec, version=rec["version"].replace("111111111111", "000000000000"))))
     (prof / "r05_flip_rate.json").write_text(json.dumps(rec))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     ok = bench.flip_rate_record("111111111111")
     assert ok["source"].endswith("r05_flip_rate.json") and ok["flips_per_1e9"] == 0.1 and "refused" not in ok
+    # (round 5: the kernels that decide in the reference's order are reported apart -- chains differing of how many decisions -- and reach the stdout line without their geometry list)
+    assert ok["reference_order"]["chains_differing"] == 0 and len(ok["reference_order"]["geometries"]) == 3
+    line = json.loads(bench.compact_line({"metric": "m", "value": 1.0, "parity": {"accept_counts_identical": True, "flip_rate": ok}}))
+    assert line["parity"]["flip_rate"]["reference_order"] == {"decisions_total": 2 * 10 ** 10, "chains_differing": 0, "log_post_differs": False}
     no = bench.flip_rate_record("222222222222")
     assert "refused" in no and "111111111111" in no["refused"] and "222222222222" in no["refused"] and "flips_per_1e9" not in no
     line = json.loads(bench.compact_line({"metric": "m", "value": 1.0, "parity": {"accept_counts_identical": True, "flip_rate": no}}))
