@@ -366,6 +366,31 @@ __device__ __forceinline__ bool chain_true(bool c) {
   return c;
 }
 
+// THE CERTIFIED TEST (both sites of step_body's certified decisions).  The difference D of the expression's two values lies within eta of dA, the difference of
+// the cheap ones (eta: the two bounds + the subtraction's rounding, x 1.0625, + 2^-49).  Is exp_v8(D) > u (mcmc.js:527-528)?  +1: yes for every such D; -1: no
+// for every such D; 0: cannot tell -- the expression decides.
+//   eta < 2^-7 (all but pathological states): exp(D) lies within a factor 1 -+ eta of exp(dA) (exp(e) <= 1 + 1.0625 e there; the 2^-49 covers V8's exp being within
+//   an ulp of exp): one exponential, `ex`, which the caller has.  u = 0 (one uniform in 2^53) asks "is the exponential positive": answered only far from
+//   the underflow threshold.
+//   Wider bounds (out of line): the hopeless and the certain first -- dA + eta < -746: the exponential is exactly 0 (the stepper's own shortcut); dA - eta >= 0: it
+//   is >= 1 > u.  That is what a proposal far out in the tails needs: a sigma a thousand times too small has |log_post| ~ 1e10 and a bound to match, and is rejected
+//   all the same -- until this was added such proposals (1e-4 of sigma's while the proposal scales are not yet adapted) each cost an evaluation of the expression in
+//   the reference's order, and a launch waits for its slowest wavefront: 1.3 ms instead of 0.5 per 25 steps of cfg4.  In between: exp_v8(dA -+ eta) against u with
+//   2^-50 of slack for the two exponentials' own ulps.
+__device__ inline __attribute__((noinline)) int certified_test_wide(double dA, double eta, double u) {
+  const double lo = dA - eta, hi = dA + eta;
+  if (hi < -746.0) return -1;
+  if (lo >= 0.0) return 1;
+  if (!(eta < 0x1p+9) || !(u > 0x1p-60)) return 0;      // (a NaN; a bound wider than the exponential's whole range; u == 0)
+  if (exp_v8(lo) * (1.0 - 0x1p-50) > u) return 1;
+  if (exp_v8(hi) * (1.0 + 0x1p-50) < u) return -1;
+  return 0;
+}
+__device__ __forceinline__ int certified_test(double dA, double eta, double ex, double u) {
+  if (eta < 0x1p-7) return (ex * (1.0 - eta) > u && (u > 0.0 || dA > -700.0)) ? 1 : (ex * (1.0 + eta) < u ? -1 : 0);
+  return certified_test_wide(dA, eta, u);
+}
+
 template <class Rng>
 __device__ __forceinline__ double rnorm_js(Rng &rng, double mean, double sd) {  // mcmc.js:43-54
   constexpr int GU = Rng::kLanesPerChain;      // (a chain on a whole wave: the loop and its inner test are scalar branches, see chain_true)
@@ -1143,8 +1168,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
                 const double ex = exp_v8(dsum);
                 const uint64_t inb_s = uniform_u64(sw_inb);
                 const bool valid = lane64 < top && ((inb_s >> lane64) & 1ull) != 0ull;
-                const bool sure_acc = ex * (1.0 - eta) > sw_u, sure_rej = ex * (1.0 + eta) < sw_u;
-                const bool unsure = valid && !(eta < 0x1p-7 && (sure_acc || sure_rej));
+                const int verdict = certified_test(dsum, eta, ex, sw_u);
+                const bool sure_acc = verdict > 0;
+                const bool unsure = valid && verdict == 0;
                 if (__ballot(unsure) == 0ull) {
                   sweep_certified = true;
                   const uint64_t acc_mask = __ballot(valid && sure_acc);
@@ -1301,9 +1327,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
             const double dA = r.value - lpA;
             const double eta = ((r.eps + epsA + __builtin_fabs(dA) * 0x1p-51) * 1.0625 + 0x1p-49) * a.bound_scale;
             const double ex = exp_v8(dA);
-            const bool ok = eta < 0x1p-7;      // (false for a NaN; exp(eps) <= 1 + 1.0625 eps holds far beyond)
-            if (chain_true<G>(ok && ex * (1.0 - eta) > u_accept)) { certified = true; accepted = true; lpA = r.value; epsA = r.eps; lp_exact = false; }
-            else if (chain_true<G>(ok && ex * (1.0 + eta) < u_accept)) { certified = true; set_state(comp, cur); }
+            const int verdict = certified_test(dA, eta, ex, u_accept);      // (0 for a NaN anywhere)
+            if (chain_true<G>(verdict > 0)) { certified = true; accepted = true; lpA = r.value; epsA = r.eps; lp_exact = false; }
+            else if (chain_true<G>(verdict < 0)) { certified = true; set_state(comp, cur); }
             if (certified && counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }

@@ -490,15 +490,17 @@ def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains, th
     # differences with their rounding bound -- the path a sweep takes when a uniform falls inside that bound, some 1e-8 of the sweeps otherwise)
     # (test_bound_shift = 12: the rounding bounds of the all-at-once sweep decisions and of mu's early rejection made 4096 times wider -- a good share of the
     # sweeps then meets a uniform inside the bound and is walked update by update, mixed with sweeps that are not)
-    a, b, c2, c3, c4 = mk(0), mk(1), mk(2), mk(0, 12), mk(0, 40)
+    # (22: bounds of ~0.1 -- the WIDE regime of the certified test, csrc/amwg_kernel.h certified_test_wide: hopeless proposals rejected without an exponential, the
+    # rest from exp_v8(dA -+ eta), a good share by the expression)
+    a, b, c2, c3, c4, c5 = mk(0), mk(1), mk(2), mk(0, 12), mk(0, 40), mk(0, 22)
     one = A.Sampler(spec, chains=chains, seed=4, chain_offset=9, lanes_per_chain=1, steps_per_launch=7, full_evaluation=1, **kw)
     assert a.launch_info()["lds_bytes"] != b.launch_info()["lds_bytes"]      # the row layout (tile + term rows) is in use on one side only
     assert a.launch_info()["kernel"] == c3.launch_info()["kernel"] == c4.launch_info()["kernel"] and a.launch_info()["kernel"].startswith("amwg_sweep_kernel_cert<HierNormalModel")
     assert c2.launch_info()["kernel"].startswith("amwg_sweep_kernel<HierNormalModel") and b.launch_info()["kernel"].startswith("amwg_step_kernel<HierNormalModel,64")
-    assert [s.launch_info()["summation_order"] for s in (a, c3, c4, one, b, c2)] == [1, 1, 1, 1, 64, 64]
+    assert [s.launch_info()["summation_order"] for s in (a, c3, c4, c5, one, b, c2)] == [1, 1, 1, 1, 1, 64, 64]
     assert one.launch_info()["lanes_per_chain"] == 1
     outs = []
-    for s in (a, c3, c4, one, b, c2):
+    for s in (a, c3, c4, c5, one, b, c2):
         seq = [s.sample(40, 1)]
         s.burn(33)
         s.set_adapting(False)
@@ -515,10 +517,10 @@ def test_lane_local_reevaluation_equals_the_full_evaluation(n_obs, G, chains, th
         s.burn(50)
         seq.append(s.sample(30, 2))
         outs.append((seq, s.info(), s.diag(), s.state()))
-    _same_chains(outs[0], outs[1:4], log_post_bits=True)       # default == bounds widened == the expression always == ONE lane per chain
-    _same_chains(outs[4], outs[5:], log_post_bits=True)        # the two 64-lane-order evaluations
-    _same_chains(outs[0], outs[4:5], log_post_bits=False)      # ... and across: everything but the last bits of log_post
-    for s in (a, b, c2, c3, c4, one):
+    _same_chains(outs[0], outs[1:5], log_post_bits=True)       # default == bounds widened (three ways) == ONE lane per chain
+    _same_chains(outs[5], outs[6:], log_post_bits=True)        # the two 64-lane-order evaluations
+    _same_chains(outs[0], outs[5:6], log_post_bits=False)      # ... and across: everything but the last bits of log_post
+    for s in (a, b, c2, c3, c4, c5, one):
         s.close()
 
 
@@ -552,7 +554,7 @@ def test_certified_decisions_of_the_poisson_family_equal_the_expression_in_every
     mk = lambda full, shift=0: A.Sampler(spec, chains=chains, seed=21, chain_offset=2, lanes_per_chain=16, steps_per_launch=9, full_evaluation=full, test_bound_shift=shift)
     outs = []
     one = A.Sampler(spec, chains=chains, seed=21, chain_offset=2, lanes_per_chain=1, steps_per_launch=9, full_evaluation=1)
-    for s in (mk(0), mk(0, 14), mk(0, 40), one, mk(1)):
+    for s in (mk(0), mk(0, 14), mk(0, 40), mk(0, 18), one, mk(1)):      # (18: bounds of ~0.3, the wide regime of the certified test)
         assert s.launch_info()["lanes_per_chain"] == (1 if s is one else 16)
         seq = [s.sample(steps // 3, 2)]
         s.burn(steps // 3)
@@ -562,8 +564,8 @@ def test_certified_decisions_of_the_poisson_family_equal_the_expression_in_every
         s.burn(steps // 6)
         outs.append((seq, s.info(), s.diag(), s.state()))
         s.close()
-    _same_chains(outs[0], outs[1:4], log_post_bits=True)
-    _same_chains(outs[0], outs[4:], log_post_bits=False)
+    _same_chains(outs[0], outs[1:5], log_post_bits=True)
+    _same_chains(outs[0], outs[5:], log_post_bits=False)
 
 
 @pytest.mark.parametrize("n_obs,chains,steps,hyper", [(1000, 4096, 400, None), (777, 1024, 300, None), (17, 512, 300, None), (1000, 16384, 600, [0.0, 100.0, 0.0, 1.0])])
@@ -581,7 +583,7 @@ def test_certified_decisions_equal_the_expression_in_every_update(n_obs, chains,
     if hyper is not None:
         spec["params"][1] = dict(spec["params"][1], upper=1.0)
     mk = lambda full, shift=0: A.Sampler(spec, chains=chains, seed=8, chain_offset=3, lanes_per_chain=1, steps_per_launch=13, full_evaluation=full, test_bound_shift=shift)
-    variants = [mk(0), mk(1), mk(0, 14), mk(0, 40)] if hyper is None else [mk(0), mk(1)]
+    variants = [mk(0), mk(1), mk(0, 14), mk(0, 40), mk(0, 22)] if hyper is None else [mk(0), mk(1), mk(0, 9)]      # (22 / 9: bounds of ~0.1, the wide regime of the certified test)
     outs = []
     for s in variants:
         assert s.launch_info()["lanes_per_chain"] == 1

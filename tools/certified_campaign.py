@@ -30,7 +30,7 @@ CAMPAIGN = [
     (("normal", 1_000, 0), 65_536, 40_000, {"lanes_per_chain": 1}),
     (("pois_glm", 50_000, 0), 8_192, 300, {"lanes_per_chain": 16}),         # cfg5 itself
     (("pois_glm", 500, 0), 16_384, 10_000, {"lanes_per_chain": 16}),
-    (("hier_normal", 10_000, 32), 2_048, 20_000, {"lanes_per_chain": 64}),   # cfg4 itself: the sweeps decided at once, mu's early rejection
+    (("hier_normal", 10_000, 32), 2_048, 4_000, {"lanes_per_chain": 64}),    # cfg4 itself (the one-lane run of 2 048 chains is 32 wavefronts: 14 ms per step)
     (("hier_normal", 640, 8), 16_384, 20_000, {"lanes_per_chain": 64}),
 ]
 
