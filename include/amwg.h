@@ -139,7 +139,7 @@ typedef struct {
                               have changed them (csrc/amwg_models.h lane_sum_rows), a sweep's proposed sums formed in one pass (prefetch_rows), its accept tests
                               one after the other from butterflies of those sums -- bit for bit what 1 computes.  A verification switch */
   int32_t test_bound_shift; /* TEST HOOK, 0 in production: the rounding bounds of the certified decisions (csrc/amwg_kernel.h: accept tests decided from a cheaper value
-                               of log_post, from the local differences of a sweep, early rejections) are multiplied by 2^shift, 0..40.  A wider bound sends more
+                               of log_post, from the local differences of a sweep) are multiplied by 2^shift, 0..40.  A wider bound sends more
                                updates down the path that evaluates the reference's expression; the results must not change by a bit (tests run 0 against 14 and 40) */
 } amwg_options;
 
