@@ -1818,9 +1818,32 @@ Translator.prototype.rowPlan = function (body) {
   for (let l = 0; l < Math.min(K, 64, plan.n) && !why; l++) if (gl[l] !== l) why = 'no: observation ' + l + ' has label ' + gl[l];
   // (b) every read of the state in the head (and in helpers) is a scalar outside the vector, an entry of ANOTHER parameter vector, or `vec[k]` with k the
   // counter of lane-split loops over exactly 0 .. K-1 (lane k then reads entry k and no other)
-  const texts = head.concat(this.helperSources || []);
+  // (the loop's sd is read off the state with every proposal of the sweep written into it -- UserRows::prefetch_rows --: it is scanned like the head.  A use of
+  // the state that is not an `S(index)` read -- the state handed on as a whole: an EARLIER gathered loop `norm_data_loop_gather(y, labels, S, b, ng, ...)`, a
+  // helper taking the state -- is analysed if it is that call and its entries [b, b + ng) lie outside the vector, and refuses the sweep otherwise: whatever the
+  // scan does not recognise is a "no".  Round-5 advisor finding: such a loop over theta[g2[i]] and an sd of |theta[0]| + 1 both came back "proved".)
+  const texts = head.concat(this.helperSources || []).concat(['(row_sd) ' + plan.sd]);
   const bases = Object.keys(this.layout).map((nm) => this.layout[nm]);
-  for (const ln of texts) {
+  const isId = (ch) => ch !== undefined && /[\w$]/.test(ch);
+  for (const ln0 of texts) {
+    const cut = ln0.indexOf('//');
+    const ln = cut >= 0 ? ln0.slice(0, cut) : ln0;
+    // every occurrence of the identifier S that is not the read S( ... )
+    for (let q = 0; !why && (q = ln.indexOf('S', q)) >= 0; q++) {
+      if (isId(ln[q - 1]) || ln[q - 1] === '.' || isId(ln[q + 1])) continue;      // (part of a longer identifier, or a member)
+      let r = q + 1;
+      while (ln[r] === ' ') r++;
+      if (ln[r] === '(') continue;                                                  // a read: checked below
+      let call = null;
+      const re = /norm_data_loop_gather<[^;]*?>\(A\d+, A\d+, S, (\d+), (\d+), /g;
+      for (let m2; (m2 = re.exec(ln));) if (m2.index < q && q < m2.index + m2[0].length && ln.slice(q - 2, q + 3) === ', S, ') call = m2;
+      if (call) {
+        const b = Number(call[1]), ng = Number(call[2]);
+        if (b < base + K && b + ng > base) why = 'no: an earlier gathered loop of the head reads ' + vec + ' through other labels (entries ' + (b - base) + ' .. ' + (b + ng - 1 - base) + ')';
+        continue;
+      }
+      why = 'no: the state is handed on as a whole in `' + ln.trim().slice(0, 80) + '`';
+    }
     let at = 0;
     while (!why && (at = ln.indexOf('S(', at)) >= 0) {
       if (at > 0 && /[\w.]/.test(ln[at - 1])) { at += 2; continue; }      // (another identifier that ends in S)
@@ -1829,7 +1852,7 @@ Translator.prototype.rowPlan = function (body) {
       const arg = ln.slice(at + 2, j - 1).trim();
       at = j;
       let mm;
-      if (/^\d+$/.test(arg)) { const c = Number(arg); if (c >= base && c < base + K) why = 'no: the head reads entry ' + (c - base) + ' of ' + vec + ' by a constant index'; continue; }
+      if (/^\d+$/.test(arg)) { const c = Number(arg); if (c >= base && c < base + K) why = 'no: ' + (ln0.indexOf('(row_sd) ') === 0 ? 'the sd of the final loop' : 'the head') + ' reads entry ' + (c - base) + ' of ' + vec + ' by a constant index'; continue; }
       if ((mm = /^(?:(\d+) \+ )?v_(\w+)$/.exec(arg))) {
         const b = mm[1] ? Number(mm[1]) : 0;
         const other = bases.find((L) => L.base === b && !L.scalar);

@@ -303,6 +303,15 @@ run('partial_loop', 'function (s, d) { let lp = 0; for (let k = 0; k < 4; k++) l
 run('shifted_labels', 'function (s, d) { let lp = 0; for (let k = 0; k < 8; k++) lp += ld.norm(s.theta[k], s.mu, 10); ' + lik, Object.assign({}, d, { g: d.g.map((v) => (v + 1) % 8) }));
 run('not_last', 'function (s, d) { let lp = 0; for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], s.sigma); lp += ld.norm(s.mu, 0, 100); return lp; }');
 run('sd_local', 'function (s, d) { let lp = 0; const sd = Math.sqrt(s.sigma); for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], sd); return lp; }');
+// (round-5 advisor finding: both of these came back "proved" -- the scan only looked for `S(` reads in the head)
+const d2 = Object.assign({}, d, { z: d.y.map((v) => v + 1), g2: d.y.map((v, i) => (3 * i + 1) % 8), w: d.y.map((v) => v - 1), h: d.y.map((v, i) => i % 4) });
+const pri = 'function (s, d) { let lp = 0; for (let k = 0; k < 8; k++) lp += ld.norm(s.theta[k], s.mu, 10); ';
+run('earlier_gather', pri + 'for (let i = 0; i < d.z.length; i++) lp += ld.norm(d.z[i], s.theta[d.g2[i]], s.sigma); ' + lik, d2);
+run('sd_reads_theta', pri + 'for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], Math.abs(s.theta[0]) + 1); return lp; }');
+run('sd_reads_mu', pri + 'for (let i = 0; i < d.y.length; i++) lp += ld.norm(d.y[i], s.theta[d.g[i]], Math.abs(s.mu) + 1); return lp; }');
+const P2 = Object.assign({ phi: { type: 'real', dim: [4], lower: -Infinity, upper: Infinity, init: [0, 0, 0, 0] } }, P);
+const r2 = t.translate(pri + 'for (let i = 0; i < d.w.length; i++) lp += ld.norm(d.w[i], s.phi[d.h[i]], 3); ' + lik, P2, d2, {});      // an earlier gathered loop over ANOTHER vector
+out.earlier_gather_other_vector = [r2.rows_n_obs, r2.rows_groups, r2.rows_sweep, /kRowSweep = (true|false)/.exec(r2.source) ? RegExp.$1 : null, r2.source.slice(r2.source.indexOf('static double head('), r2.source.indexOf('template <int G, bool DERIVE>')).indexOf('(A0, A1, S, 0, 4, 640,') > 0];
 console.log(JSON.stringify(out));
 """
     f = tmp_path / "probe.js"
@@ -315,3 +324,7 @@ console.log(JSON.stringify(out));
     assert out["plain"] == [640, 8, 1, "true"]
     assert out["const_index"] == [640, 8, 0, "false"] and out["partial_loop"] == [640, 8, 0, "false"] and out["shifted_labels"] == [640, 8, 0, "false"]      # lane reuse yes, sweep no
     assert out["early_return"][:3] == [0, 0, 0] and out["not_last"][:3] == [0, 0, 0] and out["sd_local"][:3] == [0, 0, 0]
+    # the state handed on as a whole (an earlier gathered loop over the swept vector through other labels) and an sd that reads an entry of the vector: the
+    # lanes' three numbers then depend on entries other than their own -- lane reuse yes, sweep no; the same shapes off the vector keep the proof
+    assert out["earlier_gather"] == [640, 8, 0, "false"] and out["sd_reads_theta"] == [640, 8, 0, "false"]
+    assert out["sd_reads_mu"] == [640, 8, 1, "true"] and out["earlier_gather_other_vector"] == [640, 8, 1, "true", True]
