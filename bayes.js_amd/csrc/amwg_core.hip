@@ -22,7 +22,7 @@
 
 #include "../../include/amwg.h"
 #include "amwg_build_id.h"
-#if defined(AMWG_SELFTEST)
+#if defined(AMWG_SELFTEST) || defined(AMWG_AUDIT)
 #include "../../include/amwg_selftest.h"
 #endif
 #if defined(AMWG_SELFTEST)
@@ -424,6 +424,10 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws, bool
   a.sweep_update_by_update = s->opt.full_evaluation == 2 ? 1 : 0;
   a.certified = s->certified ? 1 : 0;      // (informational: certified decisions are the kernel's, not a switch inside it)
   a.bound_scale = std::ldexp(1.0, s->opt.test_bound_shift);
+  a.audit_adversarial = 0;
+#if defined(AMWG_AUDIT)
+  { const char *e = getenv("AMWG_AUDIT_ADVERSARIAL"); a.audit_adversarial = (e && e[0] == '1') ? 1 : 0; }
+#endif
   a.mc = s->mc;
   a.d = s->d;
   a.ch = s->ch;
@@ -647,7 +651,11 @@ static int check_options(const amwg_options *options, int max_threads) {
     return fail(AMWG_EINVAL, "block_threads must be a multiple of 64 in 64..1024");
   if (options->block_threads > max_threads)
     return fail(AMWG_EINVAL, "block_threads %d exceeds this model's workgroup limit %d", options->block_threads, max_threads);
+#if defined(AMWG_AUDIT)      // (the audit build also SHRINKS the bounds -- the converse experiment of tools/bound_audit.py: how far before a chain differs)
+  if (options->test_bound_shift < -60 || options->test_bound_shift > 40) return fail(AMWG_EINVAL, "test_bound_shift must be -60..40 in the audit build, got %d", options->test_bound_shift);
+#else
   if (options->test_bound_shift < 0 || options->test_bound_shift > 40) return fail(AMWG_EINVAL, "test_bound_shift must be 0..40, got %d", options->test_bound_shift);
+#endif
   if (options->full_evaluation < 0 || options->full_evaluation > 2)
     return fail(AMWG_EINVAL, "full_evaluation must be 0 (default), 1 (every evaluation passes over all the data) or 2 (sweeps decided update by update), got %d", options->full_evaluation);
   return AMWG_OK;
@@ -751,6 +759,14 @@ static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int
   TRYB(dev_alloc(s, &ch.lp_curr, C));
   TRYB(dev_alloc(s, &ch.lp_eps, C));
   TRYB(dev_alloc(s, &ch.error, (size_t)1));
+  ch.audit = nullptr;
+  ch.audit_hist = nullptr;
+#if defined(AMWG_AUDIT)      // (libamwg_audit.so: the bound audit's per-chain maxima and histograms, amwg_kernel.h "BOUND AUDIT")
+  TRYB(dev_alloc(s, &ch.audit, 4 * C));
+  TRYB(dev_alloc(s, &ch.audit_hist, (size_t)128));
+  HIPB(hipMemset(ch.audit, 0, 4 * C * 8));
+  HIPB(hipMemset(ch.audit_hist, 0, 128 * 8));
+#endif
   {
     std::vector<double> tmp(PC);
     for (int p = 0; p < P; ++p) for (size_t c = 0; c < C; ++c) tmp[(size_t)p * C + c] = init[p];
@@ -1708,6 +1724,19 @@ int amwg_fp64_peak(int32_t device, double *lane_ops_per_s) {
   *lane_ops_per_s = (double)blocks * threads * (double)iters * 64.0 / (best * 1e-3);
   return AMWG_OK;
 }
+
+#if defined(AMWG_AUDIT)
+// include/amwg_selftest.h: what the audited launches of this sampler have recorded so far (and optionally a reset)
+int amwg_audit_fetch(amwg_sampler *s, double *per_chain, uint64_t *hist, int32_t reset) {
+  if (!s) return fail(AMWG_EINVAL, "amwg_audit_fetch: null sampler");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (per_chain) HIP_TRY(hipMemcpy(per_chain, s->ch.audit, (size_t)4 * s->C * 8, hipMemcpyDeviceToHost));
+  if (hist) HIP_TRY(hipMemcpy(hist, s->ch.audit_hist, 128 * 8, hipMemcpyDeviceToHost));
+  if (reset) { HIP_TRY(hipMemset(s->ch.audit, 0, (size_t)4 * s->C * 8)); HIP_TRY(hipMemset(s->ch.audit_hist, 0, 128 * 8)); }
+  return AMWG_OK;
+}
+#endif
 
 #if defined(AMWG_SELFTEST)
 int amwg_two_valued_sum_check(int32_t device, const double *x, int32_t n, int64_t m, const double *acc0, const double *l1, const double *l0,

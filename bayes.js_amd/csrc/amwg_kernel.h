@@ -693,7 +693,54 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   bool lp_exact = true;                  // lp_curr is the expression's value of the current state
   if constexpr (kCert) { if (!a.init_lp) { epsA = a.ch.lp_eps[cl]; lp_exact = epsA == 0.0; } }
   (void)lpA; (void)epsA; (void)lp_exact;
-
+  // BOUND AUDIT (-DAMWG_AUDIT: libamwg_audit.so, tools/bound_audit.py -- never the product).  The certified kernels decide from a cheap value A of log_post and a
+  // hand-derived bound eps on |A - E|, E the expression's value; the campaigns of round 5 could not falsify a bound that is merely too small by a factor (the
+  // actual |A - E| is orders of magnitude below eps, so a wrong verdict needs a uniform in a ~1e-12-wide window).  The audit build therefore evaluates E next to
+  // A in EVERY audited update -- for the proposal, and carried along for the current state -- and keeps, per chain, max |A - E| / eps and max |dA - dE| / eta
+  // (dE = RN(E_prop - E_cur): the difference the reference's own test takes the exponential of), the number of audited decisions, and the number of certified
+  // verdicts that contradict exp_v8(dE) > u; plus histograms of the two ratios by binary exponent.  Ratios are of the bounds BEFORE test_bound_shift scales them.
+#if defined(AMWG_AUDIT)
+  constexpr bool kAudit = kCert;
+#else
+  constexpr bool kAudit = false;
+#endif
+  [[maybe_unused]] double audE = 0.0, aud_max_v = 0.0, aud_max_d = 0.0;      // E of the current state; the two maxima
+  [[maybe_unused]] uint32_t aud_n = 0u, aud_bad = 0u;
+  [[maybe_unused]] auto audit_bin = [&](int which, double ratio) {
+#if defined(AMWG_AUDIT)
+    if (writer) {
+      int b = 0;
+      if (ratio > 0.0) { b = (int)((f64_bits(ratio) >> 52) & 0x7ffu) - 1023 + 40; b = b < 1 ? 1 : (b > 63 ? 63 : b); }      // (bin 0: the two values agree exactly)
+      if (!(ratio == ratio)) b = 63;
+      (void)atomicAdd(cold_args()->ch.audit_hist + which * 64 + b, 1ull);
+    }
+#endif
+  };
+  // (--shrink's adversarial uniforms: u just outside the sliver of the certified test, where a bound that is too small by more than the placement's 1.5 gives a wrong verdict)
+  [[maybe_unused]] auto audit_adversarial_u = [&](double ex, double eta, double u, int parity) -> double {
+    if (!(eta < 0x1p-8) || !(ex > 0x1p-900) || !(ex < kInf)) return u;
+    const double below = ex * (1.0 - 1.5 * eta), above = ex * (1.0 + 1.5 * eta);
+    const double v = ((parity & 1) && above < 1.0) ? above : below;
+    return (v > 0.0 && v < 1.0) ? v : u;
+  };
+  [[maybe_unused]] auto audit_value = [&](double A, double eps, double E) {      // a cheap value against the expression's
+    if (eps == eps && eps < kInf && eps > 0.0 && E == E && __builtin_fabs(E) < kInf) {
+      const double r = __builtin_fabs(A - E) / eps;
+      aud_max_v = (r > aud_max_v || !(r == r)) ? r : aud_max_v;
+      audit_bin(0, r);
+    }
+  };
+  [[maybe_unused]] auto audit_difference = [&](double dA, double eta0, double dE, int verdict, double u) {      // ... a difference, and the verdict drawn from it
+    if (eta0 == eta0 && eta0 < kInf && eta0 > 0.0 && dE == dE && __builtin_fabs(dE) < kInf) {
+      const double r = __builtin_fabs(dA - dE) / eta0;
+      aud_max_d = (r > aud_max_d || !(r == r)) ? r : aud_max_d;
+      audit_bin(1, r);
+    }
+    const bool exact_acc = exp_v8(dE) > u;
+    ++aud_n;
+    if ((verdict > 0 && !exact_acc) || (verdict < 0 && exact_acc)) ++aud_bad;
+  };
+  // (set below, once `expression` and the state are usable: audE = E of the state the launch starts from)
   // every store to the state goes through here: the LDS copy (what translated closures, gathers and the final write-back read) and,
   // for models that mirror the state in registers, the mirror
   auto set_state = [&](int comp, double v) {
@@ -724,6 +771,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   // full-evaluation one, does not carry the extra registers: with the sweep compiled into it, it ran a third slower)
   constexpr bool kSweep = SW && !GL && LaneReuseOf<Model>::value && G == 64 && !BinaryOf<Model>::value;
   const bool sweep_rt = kSweep && ord_in_regs && a.d.pad > 0;
+  if constexpr (kAudit) { if (lp_exact) audE = lp_curr; else audE = expression(); }      // (BOUND AUDIT: the expression's value of the state the launch starts from)
   wave_priority(kStepperPriority);
   // ---- Sampler.sample: record the state BEFORE the step (mcmc.js:1020-1027)
   auto record_draws = [&](int step) {
@@ -1168,9 +1216,32 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
                 const double ex = exp_v8(dsum);
                 const uint64_t inb_s = uniform_u64(sw_inb);
                 const bool valid = lane64 < top && ((inb_s >> lane64) & 1ull) != 0ull;
+                if constexpr (kAudit) { if (a.audit_adversarial) sw_u = audit_adversarial_u(ex, eta, sw_u, step + lane64); }
                 const int verdict = certified_test(dsum, eta, ex, sw_u);
                 const bool sure_acc = verdict > 0;
                 const bool unsure = valid && verdict == 0;
+                [[maybe_unused]] double aud_E_walk = audE;
+                if constexpr (kAudit) {
+                  // BOUND AUDIT of the all-at-once decision: the sweep walked update by update in its order with the EXPRESSION -- entry c proposed on top of whatever the
+                  // expression's own tests accepted before it, exactly the reference's schedule -- and every entry's local difference dsum_c held against RN(E_prop - E_cur).
+                  // State and register mirror are put back afterwards; the walk's final E is the sweep's if the certified path then takes it.
+                  const auto cache_keep = cache;
+                  const double eta0 = (Model::difference_bound(M, a.d) + __builtin_fabs(dsum) * 0x1p-51) * 1.0625;
+                  for (int t = 0; t < top; ++t) {
+                    const int c = __builtin_amdgcn_readlane(ord, t);
+                    if (!((inb_s >> c) & 1ull)) continue;
+                    const double prop_c = lane_value(sw_prop, c), u_c = lane_value(sw_u, c), d_c = lane_value(dsum, c), e_c = lane_value(eta0, c);
+                    const int v_c = __builtin_amdgcn_readlane(verdict, c);
+                    const double old_c = Sme[sb + c];
+                    set_state(sb + c, prop_c);
+                    const double Ep = expression();
+                    const double dE = Ep - aud_E_walk;
+                    audit_difference(d_c, e_c, dE, v_c, u_c);
+                    if (exp_v8(dE) > u_c) aud_E_walk = Ep; else set_state(sb + c, old_c);
+                  }
+                  if (lane64 < top) Sme[sb + lane64] = cur_l;
+                  cache = cache_keep;
+                }
                 if (__ballot(unsure) == 0ull) {
                   sweep_certified = true;
                   const uint64_t acc_mask = __ballot(valid && sure_acc);
@@ -1181,6 +1252,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
                   lpA = butterfly<1, 64>(mine ? sa.neu : sa.cur);
                   epsA = Model::value_bound(M, a.d);
                   lp_exact = false;
+                  if constexpr (kAudit) { audE = aud_E_walk; audit_value(lpA, epsA, audE); }      // (the cheap value of the state the sweep leaves, against the walk's)
                   if (lane64 < top) {
                     const bool inb_l = ((inb_s >> lane64) & 1ull) != 0ull, acc_l = ((acc_mask >> lane64) & 1ull) != 0ull;
                     if (inb_l) TOTme[sb + lane64] += 1u + (acc_l ? 0x10000u : 0u);
@@ -1316,6 +1388,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       if (slot + 1 < P_stepped) nx = prefetch(next_comp());
       bool accepted = false;
       bool certified = false;
+      [[maybe_unused]] double aud_E_prop = 0.0;
       if constexpr (kCert) {
         // (the model's pass is the WAVEFRONT's: with a lane per chain the 64 chains of a wave are evaluated together, every lane taking part whether its own
         // proposal needs a value or not -- control flow is uniform here: the slot loop is, and the lanes have come back together from their rnorm loops)
@@ -1327,7 +1400,13 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
             const double dA = r.value - lpA;
             const double eta = ((r.eps + epsA + __builtin_fabs(dA) * 0x1p-51) * 1.0625 + 0x1p-49) * a.bound_scale;
             const double ex = exp_v8(dA);
+            if constexpr (kAudit) { if (a.audit_adversarial) u_accept = audit_adversarial_u(ex, eta, u_accept, step + slot); }
             const int verdict = certified_test(dA, eta, ex, u_accept);      // (0 for a NaN anywhere)
+            if constexpr (kAudit) {      // BOUND AUDIT: the expression's value of the proposal (the state holds it), beside the cheap one
+              aud_E_prop = expression();
+              audit_value(r.value, r.eps, aud_E_prop);
+              audit_difference(dA, (r.eps + epsA + __builtin_fabs(dA) * 0x1p-51) * 1.0625, aud_E_prop - audE, verdict, u_accept);
+            }
             if (chain_true<G>(verdict > 0)) { certified = true; accepted = true; lpA = r.value; epsA = r.eps; lp_exact = false; }
             else if (chain_true<G>(verdict < 0)) { certified = true; set_state(comp, cur); }
             if (certified && counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1375,6 +1454,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         if constexpr (kCert) { lpA = lp_curr; epsA = 0.0; }
         if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // run totals (not in the reference; parity tests compare them with the oracle's)
       }
+      if constexpr (kAudit) { if (inb && accepted) audE = aud_E_prop; }      // (BOUND AUDIT: E follows the state)
       if (chain_true<G>(me.adapting)) adapt_component(comp, accepted, me.cnt, me.batch_size, writer);
     }
   }
@@ -1388,6 +1468,16 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   }
   if constexpr (!GL && MirrorCheckOf<Model>::value) {
     if (!Model::template mirror_ok<G>(cache, S, a.d, sub)) (void)atomicOr(cold_args()->ch.error, kErrMirrorOutOfSync);
+  }
+  if constexpr (kAudit) {
+    if (writer) {
+      double *const au = cold_args()->ch.audit;
+      const double v0 = au[cl], d0 = au[C + cl];
+      au[cl] = (aud_max_v > v0 || !(aud_max_v == aud_max_v)) ? aud_max_v : v0;
+      au[C + cl] = (aud_max_d > d0 || !(aud_max_d == aud_max_d)) ? aud_max_d : d0;
+      au[2 * C + cl] += (double)aud_n;
+      au[3 * C + cl] += (double)aud_bad;
+    }
   }
   if (writer) {
     const cold_args_ptr ca = cold_args();

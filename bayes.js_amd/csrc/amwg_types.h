@@ -96,6 +96,9 @@ struct ChainArrays {
   double *lp_curr;          // [C] log_post(state): the expression's value -- or, between the launches of a kernel with certified decisions, the cheaper value the
                             // stepper last decided from, when lp_eps says so (made exact on demand: StepArgs::finalize_lp)
   double *lp_eps;           // [C] 0: lp_curr is the expression's value; else the bound that goes with the cheaper value in lp_curr
+  double *audit;            // BOUND AUDIT builds only (libamwg_audit.so, -DAMWG_AUDIT; null in the product): [4][C] per chain -- max |A - E| / eps over the audited values,
+                            // max |dA - dE| / eta over the audited differences, audited decisions, decisions a certified verdict got WRONG (amwg_kernel.h "BOUND AUDIT")
+  unsigned long long *audit_hist;   // ... and [2][64] counts of those ratios by binary exponent (bin 40 = [1, 2): a violated bound)
   int32_t *error;           // one word: bits set by a step kernel that refused its launch or found its own bookkeeping inconsistent (amwg_kernel.h
                             // device_error); the host reads it after every call and turns it into an error -- never a silent no-op
 };
@@ -115,6 +118,8 @@ struct StepArgs {
   int32_t certified;                // 1 = this launch is of a kernel that decides accept tests from a model's cheaper value of log_post with its bound (amwg_kernel.h
                                     // "certified decisions": amwg_step_kernel_cert / amwg_sweep_kernel_cert).  Informational: the kernels do not branch on it
   double bound_scale;               // 2^amwg_options::test_bound_shift (1 in production): multiplies the bounds of the certified decisions
+  int32_t audit_adversarial;        // BOUND AUDIT build only (0 in the product, which does not read it): the accept uniform of every certified decision is REPLACED by one placed
+                                    // 1.5 eta off exp(dA) -- just outside the sliver, alternately on either side --, the worst case for a bound that is too small (tools/bound_audit.py --shrink)
   int32_t sweep_update_by_update;   // amwg_options::full_evaluation == 2: the sweep kernel decides a sweep's accept tests one after the other (verification switch)
   int32_t cpb;              // chains per workgroup when the per-chain state of blockDim / lanes chains does not fit LDS (0 = all of them);
                             // the lane groups beyond cpb then replicate the workgroup's last chain (same stream, same stores)

@@ -30,6 +30,16 @@ int amwg_ld_device(int32_t device, int64_t n, const double *records, double *out
 int amwg_two_valued_sum_check(int32_t device, const double *x, int32_t n, int64_t m, const double *acc0, const double *l1, const double *l0,
                               double *out_fast_forward, double *out_term_by_term);
 
+/* BOUND AUDIT build only (libamwg_audit.so = the library's sources compiled with -DAMWG_AUDIT; tools/bound_audit.py, tests/test_gpu_bound_audit.py).  The kernels that
+ * decide accept tests from a cheaper value A of log_post and a bound eps (csrc/amwg_kernel.h "certified decisions") evaluate the reference's expression E in EVERY
+ * update there as well and record how far apart the two really are:
+ *   per_chain [4][chains]: max |A - E| / eps,  max |dA - dE| / eta,  audited decisions,  certified verdicts that contradict exp(dE) > u (must be 0)
+ *   hist      [2][64]:     counts of the two ratios by binary exponent, bin b >= 1 holding [2^(b-40), 2^(b-39)) -- bins >= 40 are violated bounds; bin 0: exactly equal
+ * reset != 0 clears both afterwards.  amwg_options::test_bound_shift may be negative (down to -60) in this build.  Not in the product library. */
+#if defined(AMWG_AUDIT)
+int amwg_audit_fetch(amwg_sampler *s, double *per_chain, uint64_t *hist, int32_t reset);
+#endif
+
 #ifdef __cplusplus
 }
 #endif

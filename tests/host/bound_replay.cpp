@@ -1,0 +1,260 @@
+// bound_replay.cpp -- TEST INFRASTRUCTURE (host only): the three derivations behind the certified decisions (csrc/amwg_models.h: NormalModel / HierNormalModel /
+// PoisGlmModel::log_post_approx and their eps), replayed in QUAD precision on the inputs the device audit uses.
+//
+// Each derivation says: the reference's expression E (fp64, term by term, one running sum -- mcmc.js:524-526 calling the closures of README.md:22-36 and
+// tests/model_spec.py) and the kernel's cheaper value A (fp64, other operations in another order) both approximate one REAL number R, within
+//     |E - R| <= bE,   |A - R| <= bA,   and the bound the stepper uses is   eps >= 2 (bE + bA).
+// Here E and A are computed in fp64 with the operations and summation orders of the oracle / the kernels (restated below), R in __float128 from the same fp64
+// inputs, and all three inequalities are checked with the constants AS WRITTEN in the comments of amwg_models.h.  The device audit (tools/bound_audit.py,
+// libamwg_audit.so) measures |A - E| / eps in the kernels themselves; this file checks the two HALVES of each bound against the real number, which the device
+// cannot do.  Prints the worst ratios; exit 1 if any exceeds 1 (halves) or 0.5 (eps).
+//   g++ -std=c++17 -O2 -ffp-contract=off -fno-fast-math -I bayes.js_amd/csrc -I oracle tests/host/bound_replay.cpp -lquadmath
+#include <quadmath.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "amwg_math.h"      // exp_bounded, exp_v8, log_v8: the kernel's own sources compiled for the host
+
+using namespace amwg;
+typedef __float128 quad;
+static const double U = 0x1p-53;
+static double worst_E = 0, worst_A = 0, worst_eps = 0;
+static long n_cases = 0, n_skipped = 0;
+static const char *worst_name = "";
+
+static double absq(quad v) { return (double)(v < 0 ? -v : v); }
+static void note(const char *name, double E, double A, quad R, double bE, double bA, double eps) {
+  if (!(eps < INFINITY) || !(std::fabs(E) < INFINITY)) { ++n_skipped; return; }      // (a non-finite bound: the stepper evaluates the expression)
+  ++n_cases;
+  const double rE = absq((quad)E - R) / bE, rA = absq((quad)A - R) / bA, re = std::fabs(A - E) / eps;
+  if (rE > worst_E) worst_E = rE;
+  if (rA > worst_A) worst_A = rA;
+  if (re > worst_eps) { worst_eps = re; worst_name = name; }
+  if (rE > 1 || rA > 1 || re > 0.5) printf("VIOLATION %s: |E-R|/bE %.3g  |A-R|/bA %.3g  |A-E|/eps %.3g\n", name, rE, rA, re);
+}
+
+// ld.norm(v, m, sd) with the loop invariants hoisted, as the kernel and the oracle form it (distributions.js:119-121): c - RN(RN(t t) / den)
+static double norm_term(double v, double m, double c, double den) { const double t = v - m; return c - (t * t) / den; }
+static const double NH = -0.5 * log_v8(2 * 3.141592653589793);
+
+// ---------------------------------------------------------------- (i) Normal family, one lane per chain
+static void normal_case(const char *name, const std::vector<double> &x, double mu, double sigma, double m0, double s0, double ua, double ub) {
+  const int n = (int)x.size();
+  const double c = NH - log_v8(sigma), den = 2 * sigma * sigma, c0 = NH - log_v8(s0), den0 = 2 * s0 * s0, lunif = log_v8(1 / (ub - ua));
+  double P = 0;
+  P += norm_term(mu, m0, c0, den0);
+  P += (sigma < ua || sigma > ub) ? -INFINITY : lunif;
+  // E: README.md:27-35 -- lp = priors; for i: lp += ld.norm(x[i], mu, sigma)
+  double E = P;
+  for (int i = 0; i < n; ++i) E += norm_term(x[i], mu, c, den);
+  // A: norm_sq_pass_wave -- lane l holds x_l, x_(l+64), ...: per-lane fma sums, then the transposing butterfly (pairwise over the lane index, 32 16 8 4 2 1)
+  double a[64];
+  for (int l = 0; l < 64; ++l) { a[l] = 0; for (int i = l; i < n; i += 64) { const double t = x[i] - mu; a[l] = std::fma(t, t, a[l]); } }
+  for (int off = 32; off >= 1; off >>= 1) for (int l = 0; l < off; ++l) a[l] = a[l] + a[l + off];
+  const double S2 = a[0], yhi = 1.0 / den, Q = S2 * yhi, nc = (double)n * c;
+  const double A = (P + nc) - Q;
+  const double eps = (2.0 * n + 64.0) * U * (std::fabs(P) + std::fabs(nc) + 2.0 * Q) * 1.25;
+  // R: P + n c - sum t_i^2 / den over the SAME rounded t_i = RN(x_i - mu) (both sides start from them), c, den, P
+  quad s2 = 0;
+  for (int i = 0; i < n; ++i) { const quad t = (quad)(x[i] - mu); s2 += t * t; }
+  const quad R = (quad)P + (quad)n * (quad)c - s2 / (quad)den;
+  const double mag = std::fabs(P) + n * std::fabs(c) + (double)(s2 / (quad)den);
+  // amwg_models.h:239-243: term by term (n + 2) u mag [+ the quotients' u Q and the subtractions' u (n|c| + Q): <= 2 u mag more]; here (n / 8 + 9) u mag
+  note(name, E, A, R, (n + 4.0) * U * mag, (n / 8.0 + 9.0) * U * mag, eps);
+}
+
+// ---------------------------------------------------------------- (iii) hierarchical family, row layout on 64 lanes, labels i mod G
+static void hier_case(const char *name, const std::vector<double> &y, int G, const std::vector<double> &theta, double mu, double sigma, double m0, double s0, double ua, double ub, double tau) {
+  const int n = (int)y.size();
+  const double c = NH - log_v8(sigma), den = 2 * sigma * sigma, c0 = NH - log_v8(s0), den0 = 2 * s0 * s0, c1 = NH - log_v8(tau), den1 = 2 * tau * tau;
+  const double lunif = log_v8(1 / (ub - ua));
+  double pr = 0;      // prior(mu, sigma) as both sides form it (amwg_models.h prior_mu_sigma_impl)
+  pr += norm_term(mu, m0, c0, den0);
+  pr += (sigma < ua || sigma > ub) ? -INFINITY : lunif;
+  // E: the reference's ONE running sum (reference_order): priors, the G terms of theta, the n observations in index order
+  double E = pr;
+  for (int g = 0; g < G; ++g) E += norm_term(theta[g], mu, c1, den1);
+  for (int i = 0; i < n; ++i) E += norm_term(y[i], theta[i % G], c, den);
+  // A: approx_lane per lane, rows_sq's four interleaved partial sums, butterfly over the 64 lanes
+  const int n_full = n >> 6, rem = n & 63;
+  double v[64], M = 0;
+  const double yhi = 1.0 / den;
+  quad Rq = (quad)pr;
+  for (int l = 0; l < 64; ++l) {
+    double start = l == 0 ? pr : 0.0;
+    if (l < G) { const double t = norm_term(theta[l], mu, c1, den1); start += t; Rq += (quad)t; }
+    const double mean = theta[l % G];
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    auto X = [&](int r) { return y[(size_t)r * 64 + l]; };
+    int r = 0;
+    for (; r + 8 <= n_full; r += 8) {
+      { const double t = X(r + 0) - mean; a0 = std::fma(t, t, a0); } { const double t = X(r + 1) - mean; a1 = std::fma(t, t, a1); }
+      { const double t = X(r + 2) - mean; a2 = std::fma(t, t, a2); } { const double t = X(r + 3) - mean; a3 = std::fma(t, t, a3); }
+      { const double t = X(r + 4) - mean; a0 = std::fma(t, t, a0); } { const double t = X(r + 5) - mean; a1 = std::fma(t, t, a1); }
+      { const double t = X(r + 6) - mean; a2 = std::fma(t, t, a2); } { const double t = X(r + 7) - mean; a3 = std::fma(t, t, a3); }
+    }
+    for (; r < n_full; ++r) { const double t = X(r) - mean; a0 = std::fma(t, t, a0); }
+    if (l < rem) { const double t = X(n_full) - mean; a1 = std::fma(t, t, a1); }
+    const double s2 = (a0 + a1) + (a2 + a3);
+    const double n_l = (double)(n_full + (l < rem ? 1 : 0));
+    const double q = s2 * yhi, nc = n_l * c;
+    v[l] = (start + nc) - q;
+    M += std::fabs(start) + std::fabs(nc) + q;
+    quad s2q = 0;
+    for (int rr = 0; rr < n_full + (l < rem ? 1 : 0); ++rr) { const quad t = (quad)(X(rr) - mean); s2q += t * t; }
+    Rq += (quad)n_l * (quad)c - s2q / (quad)den;
+  }
+  for (int off = 1; off < 64; off <<= 1) { double w[64]; for (int l = 0; l < 64; ++l) w[l] = v[l] + v[l ^ off]; std::copy(w, w + 64, v); }
+  const double A = v[0];
+  // the butterfly of the magnitudes is a sum of non-negative numbers: its rounding does not matter here
+  const double Mp = M + 2.0 * (std::fabs(pr) + std::fabs(lunif));
+  const double eps = Mp * (2.0 * (double)(n + G) + 64.0) * 1.25 * U;      // value_bound
+  // amwg_models.h:798-806: the reference-order sum within (n + G + 8) u M'; the value here within (n_l / 4 + 9) u m_l per lane + 6 u M for the butterfly
+  note(name, E, A, Rq, (n + G + 8.0) * U * Mp, ((n / 64.0 + 1) / 4.0 + 15.0) * U * M, eps);
+}
+
+// ---------------------------------------------------------------- (ii) Poisson family, 16 lanes per chain (the wavefront's 64 lanes share out the rows)
+static double lfactorial_js(double x) {      // distributions.js:63-76, 78-80 via lgamma(x + 1)
+  static const double cof[6] = {76.18009172947146, -86.50532032941677, 24.01409824083091, -1.231739572450155, 0.1208650973866179e-2, -0.5395239384953e-5};
+  double xx = x + 1, yv = xx, tmp = xx + 5.5, ser = 1.000000000190015;
+  tmp -= (xx + 0.5) * log_v8(tmp);
+  for (int j = 0; j < 6; ++j) ser += cof[j] / ++yv;
+  return log_v8(2.5066282746310005 * ser / xx) - tmp;
+}
+static void pois_case(const char *name, const std::vector<double> &Xm, const std::vector<double> &yc, const double *b, double cp) {
+  const int n = (int)yc.size();
+  const double s0 = 10.0, c0 = NH - log_v8(s0), den0 = 2 * s0 * s0, lunif_cp = log_v8(1 / ((double)(n - 1) - 0));
+  std::vector<double> lf(n);
+  double Y = 0, F = 0, xmax[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) { lf[i] = lfactorial_js(yc[i]); Y += yc[i]; F += lf[i]; for (int k = 0; k < 7; ++k) xmax[k] = std::max(xmax[k], std::fabs(Xm[(size_t)i * 7 + k])); }
+  // E: lp = 0; for k: lp += ld.norm(b_k, 0, 10); lp += ld.unif(cp, 0, n - 1); for i: lp += ld.pois(y_i, Math.exp(eta_i))   (oracle/amwg_oracle.c obs_term, prior_sum)
+  double E = 0;
+  quad Rq = 0;
+  for (int k = 0; k < 8; ++k) { const double t = norm_term(b[k], 0.0, c0, den0); E += t; Rq += (quad)t; }
+  E += (cp < 0 || cp > (double)(n - 1)) ? -INFINITY : lunif_cp;
+  Rq += (quad)lunif_cp;
+  for (int i = 0; i < n; ++i) {
+    double eta = 0;
+    for (int k = 0; k < 7; ++k) eta += Xm[(size_t)i * 7 + k] * b[k];
+    if ((double)i >= cp) eta += b[7];
+    const double lam = exp_v8(eta);
+    E += (log_v8(lam) * yc[i] - lam) - lf[i];
+    quad eq = 0;
+    for (int k = 0; k < 7; ++k) eq += (quad)Xm[(size_t)i * 7 + k] * (quad)b[k];
+    if ((double)i >= cp) eq += (quad)b[7];
+    Rq += eq * (quad)yc[i] - expq(eq) - (quad)lf[i];
+  }
+  // A: log_post_approx -- start values of the chain's 16 lanes (prior_split<16>) by a 16-lane butterfly; rows i = 64 k + lane: eta by one product and six fmas,
+  // exp_bounded, s1 = fma(eta, y, s1), ls += lam; 64-lane butterflies of (s1 - ls) and ls
+  double st[16], sa[16];
+  for (int l = 0; l < 16; ++l) { double acc = 0; for (int k = l; k < 8; k += 16) acc += norm_term(b[k], 0.0, c0, den0); if (l == 0) acc += lunif_cp; st[l] = acc; sa[l] = std::fabs(acc); }
+  for (int off = 1; off < 16; off <<= 1) { double w[16], z[16]; for (int l = 0; l < 16; ++l) { w[l] = st[l] + st[l ^ off]; z[l] = sa[l] + sa[l ^ off]; } std::copy(w, w + 16, st); std::copy(z, z + 16, sa); }
+  const double P = st[0], Pabs = sa[0];
+  const int icp = !(cp < 536870912.0) ? 536870912 : (cp <= 0.0 ? 0 : (int)std::ceil(cp));
+  const ExpTaylorRegs ER = exp_taylor_regs();
+  double s1[64], ls[64];
+  for (int l = 0; l < 64; ++l) {
+    s1[l] = ls[l] = 0;
+    for (int i = l; i < n; i += 64) {
+      const double *v = &Xm[(size_t)i * 7];
+      double eta = v[0] * b[0];
+      for (int k = 1; k < 7; ++k) eta = std::fma(v[k], b[k], eta);
+      eta = i >= icp ? eta + b[7] : eta;
+      const double lam = exp_bounded(eta, ER);
+      s1[l] = std::fma(eta, yc[i], s1[l]);
+      ls[l] += lam;
+    }
+  }
+  double d1[64], d2[64];
+  for (int l = 0; l < 64; ++l) { d1[l] = s1[l] - ls[l]; d2[l] = ls[l]; }
+  for (int off = 1; off < 64; off <<= 1) { double w[64], z[64]; for (int l = 0; l < 64; ++l) { w[l] = d1[l] + d1[l ^ off]; z[l] = d2[l] + d2[l ^ off]; } std::copy(w, w + 64, d1); std::copy(z, z + 64, d2); }
+  const double tot = d1[0], L = d2[0];
+  double H = std::fabs(b[7]);
+  for (int q = 0; q < 7; ++q) H += std::fabs(b[q]) * xmax[q];
+  const double W = Pabs + 2.0 * std::fabs(lunif_cp) + (1.0 + H) * Y + L + F;
+  const double eps = (H <= 690.0) ? W * (2.0 * (double)(n + 16) + 23.0 * H + 200.0) * 1.25 * U : INFINITY;
+  const double A = (P + tot) - F;
+  // amwg_models.h:1171-1187, the pieces: E -- log(exp_v8) vs eta 2 u (1 + H) 1.01 Y; exp_v8 2 u L; the term's roundings 4 u (H Y + L + F); eta's 13 roundings (its
+  // share of 22 u H (Y + L) 1.05: 13 / 20); the running sum (n + 9) u W'.   A -- eta's 7 roundings (7 / 20 of the same), exp_bounded 128 u L, sums and butterflies 2 (n_l + 8) u W
+  const double HYL = H * (Y + L) * 1.05;
+  const double bE = U * (2.02 * (1 + H) * Y + 2 * L + 4 * (H * Y + L + F) + 14.3 * HYL + (n + 9.0) * W);
+  const double bA = U * (7.7 * HYL + 128 * L + 2 * (n / 64.0 + 9.0) * W);
+  note(name, E, A, Rq, bE, bA, eps);
+}
+
+int main(int argc, char **argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 40;
+  std::mt19937_64 g(20260925);
+  std::normal_distribution<double> N01(0.0, 1.0);
+  std::uniform_real_distribution<double> U01(0.0, 1.0);
+  auto lognormal = [&](double lo, double hi) { return std::exp(std::log(lo) + (std::log(hi) - std::log(lo)) * U01(g)); };
+  for (int rep = 0; rep < reps; ++rep) {
+    // ---- Normal: ordinary states and the audit's adversarial ones
+    for (int n : {1, 2, 17, 63, 65, 1000, 10000}) {
+      std::vector<double> x(n);
+      for (double &v : x) v = 3.0 + 2.0 * N01(g);
+      normal_case("normal", x, 3.0 + 0.1 * N01(g), lognormal(0.5, 8.0), 0, 100, 0, 100);
+      normal_case("normal_far_state", x, 50.0 * N01(g), lognormal(1e-6, 1e6), 0, 100, 0, 1e7);
+      for (double &v : x) v = 1e8 + N01(g);
+      normal_case("normal_x1e8_near", x, 1e8 + 0.05 * N01(g), lognormal(0.5, 2.0), 0, 100, 0, 100);
+      normal_case("normal_x1e8_far", x, 0.5, 1.0, 0, 100, 0, 100);
+      for (double &v : x) v = 7.25;
+      normal_case("normal_constant", x, 7.25 + 0.01 * N01(g), lognormal(0.01, 1.0), 0, 100, 0, 100);
+      for (double &v : x) v = 1e-250 * (1.0 + U01(g));
+      normal_case("normal_tiny", x, 1e-250, lognormal(1e-3, 1.0), 0, 100, 0, 100);
+      normal_case("normal_tight_prior", x, 1e-4 * N01(g), 1.0, 0, 1e-3, 0, 100);
+    }
+    // ---- hierarchical
+    for (auto ng : {std::pair<int, int>{64, 32}, {65, 32}, {100, 4}, {640, 8}, {1024, 16}, {64, 64}, {10000, 32}}) {
+      const int n = ng.first, G = ng.second;
+      std::vector<double> th(G), y(n);
+      for (double &v : th) v = 5.0 + 3.0 * N01(g);
+      for (int i = 0; i < n; ++i) y[i] = th[i % G] + 2.0 * N01(g);
+      std::vector<double> st(G);
+      for (int k = 0; k < G; ++k) st[k] = th[k] + 0.3 * N01(g);
+      hier_case("hier", y, G, st, 5.0 + N01(g), lognormal(1.0, 4.0), 0, 100, 0, 100, 10);
+      hier_case("hier_small_sigma", y, G, st, 5.0, lognormal(1e-4, 1e-2), 0, 100, 0, 100, 10);
+      hier_case("hier_large_sigma", y, G, st, 5.0, lognormal(1e2, 1e4), 0, 100, 0, 1e5, 10);
+      std::vector<double> y8(n);
+      for (int i = 0; i < n; ++i) y8[i] = 1e8 + y[i];
+      for (int k = 0; k < G; ++k) st[k] += 1e8;
+      hier_case("hier_y1e8", y8, G, st, 1e8, 2.0, 0, 100, 0, 100, 10);
+    }
+    // ---- Poisson
+    for (int n : {2, 17, 63, 65, 500, 5000}) {
+      std::vector<double> X((size_t)n * 7), yc(n);
+      double b[8] = {0.5, 0.2, -0.1, 0.05, 0.1, -0.2, 0.15, 0.3};
+      for (int i = 0; i < n; ++i) {
+        X[(size_t)i * 7] = 1.0;
+        double eta = b[0];
+        for (int k = 1; k < 7; ++k) { X[(size_t)i * 7 + k] = 0.5 * N01(g); eta += X[(size_t)i * 7 + k] * b[k]; }
+        std::poisson_distribution<long> pd(std::exp(eta + (i >= 0.4 * n ? b[7] : 0.0)));
+        yc[i] = (double)pd(g);
+      }
+      double bs[8];
+      for (int k = 0; k < 8; ++k) bs[k] = b[k] + 0.05 * N01(g);
+      pois_case("pois", X, yc, bs, std::floor(0.4 * n));
+      for (int k = 0; k < 8; ++k) bs[k] = 3.0 * N01(g);
+      pois_case("pois_wild_state", X, yc, bs, std::floor(U01(g) * (n - 1)));
+      double bh[8] = {689.0 - 8.0 * U01(g), 0, 0, 0, 0, 0, 0, 0};
+      std::vector<double> X1 = X;
+      for (int i = 0; i < n; ++i) for (int k = 1; k < 7; ++k) X1[(size_t)i * 7 + k] *= 1e-3;
+      pois_case("pois_H_near_690", X1, yc, bh, 1.0);
+      std::vector<double> y0(n, 0.0);
+      pois_case("pois_zero_counts", X, y0, bs, 1.0);
+      std::vector<double> yb(n);
+      double bb[8] = {13.0, 0.02, -0.01, 0.005, 0.01, -0.02, 0.015, 0.3};
+      for (int i = 0; i < n; ++i) { std::poisson_distribution<long> pd(std::exp(13.0 + 0.1 * N01(g))); yb[i] = (double)pd(g); }
+      pois_case("pois_counts_1e6", X, yb, bb, 1.0);
+    }
+  }
+  printf("cases=%ld skipped_nonfinite=%ld worst |E-R|/bE=%.4g worst |A-R|/bA=%.4g worst |A-E|/eps=%.4g (%s)\n", n_cases, n_skipped, worst_E, worst_A, worst_eps, worst_name);
+  const bool ok = worst_E <= 1.0 && worst_A <= 1.0 && worst_eps <= 0.5;
+  printf(ok ? "bounds_hold=1\n" : "bounds_hold=0\n");
+  return ok ? 0 : 1;
+}

@@ -158,3 +158,18 @@ def test_fused_softplus_host_fuzz(tmp_path):
                            os.path.join(root, "tests", "host", "softplus_fuzz.cpp"), "-o", exe])
     p = subprocess.run([exe, "600000", os.path.join(root, "tests", "golden", "v8_softplus_pairs.bin")], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "mismatches=0" in p.stdout and "v8_mismatches=0" in p.stdout, p.stdout[-2000:]
+
+
+def test_certified_bounds_host_replay_in_quad_precision(tmp_path):
+    """The three derivations behind the certified decisions (csrc/amwg_models.h: Normal at one lane, the hierarchical family's row layout, the Poisson family at 16 lanes),
+    replayed on the host: E (the reference's term-by-term running sum, fp64) and A (the kernels' cheaper form in the kernels' summation order, fp64) against the REAL
+    number R in __float128 from the same inputs -- ordinary states and the device audit's adversarial ones (n in {1, 2, 17, 63, 65}, data at 1e8, sigma from 1e-6 to
+    1e6, constant and tiny data, H next to 690, counts of 1e6).  Each half of a bound must hold as written in the header's comments (|E - R| <= bE, |A - R| <= bA)
+    and |A - E| <= eps / 2.  The device side of the same audit: tools/bound_audit.py, tests/test_gpu_bound_audit.py (round-5 review, item 1)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "bound_replay")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(root, "bayes.js_amd", "csrc"),
+                           os.path.join(root, "tests", "host", "bound_replay.cpp"), "-o", exe, "-lquadmath"])
+    p = subprocess.run([exe, "25"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "bounds_hold=1" in p.stdout and "VIOLATION" not in p.stdout, p.stdout[-2000:]
