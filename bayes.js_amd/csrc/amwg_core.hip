@@ -5,11 +5,13 @@
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -18,6 +20,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/amwg.h"
@@ -222,6 +225,10 @@ static bool certified_wanted(const amwg_sampler *s, int lanes, bool rows) {
   return (s->model == AMWG_MODEL_NORMAL && lanes == 1) || (s->model == AMWG_MODEL_POIS_GLM && lanes == 16) || (s->model == AMWG_MODEL_HIER_NORMAL && lanes == 64 && rows);
 }
 bool hier_rows_fit(const amwg_sampler *s, int bt, size_t max_lds);
+// ... a translated closure with a certified tail (amwg_user.h norm_tail_approx; read off the generated source by amwg_create_user): one lane per chain
+static bool user_cert_wanted(const amwg_sampler *s, int lanes) {
+  return s->user && s->user_cert_tail_n > 0 && lanes == 1 && s->opt.full_evaluation == 0 && !s->opt.exact_division && !s->user_has_binary;
+}
 bool user_rows_wanted(const amwg_sampler *s, int G);
 bool user_rows_fit(const amwg_sampler *s, int bt, size_t max_lds);
 
@@ -245,6 +252,10 @@ double model_work(const amwg_sampler *s, int G) {
       return w;
     }
     case AMWG_MODEL_POIS_GLM: return (G == 16 && s->opt.full_evaluation == 0 && !s->opt.exact_division) ? 36.0 * N : 90.0 * N;      // (16 lanes per chain: the certified pass, four chains sharing every row they read)
+  }
+  if (user_cert_wanted(s, G)) {      // the tail loop's ~16 instructions per observation become the certified pass's 2.6
+    const double w1 = s->user_work_one_lane > 0 ? s->user_work_one_lane : s->user_work, n = (double)s->user_cert_tail_n;
+    return (w1 - 16.0 * n > 0 ? w1 - 16.0 * n : 0.0) + 2.6 * n;
   }
   if (G == 1 && s->user_work_one_lane > 0) return s->user_work_one_lane;   // translated closure with a two-valued sum: fast-forwarded
   double w = s->user_work > 0 ? s->user_work : 1e6;   // translated closure: the translator's estimate
@@ -292,8 +303,11 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const int max_bt = s->user ? s->user_max_threads : model_max_threads(s->model);
   // (the hierarchical family's sweep kernel -- row layout, 64 lanes per chain -- keeps the window stream and the sweep's per-lane values in registers:
   // compiled for at most 512 threads, where a lane has 256 of them; with the 128 of a 1024-thread workgroup it ran from scratch memory, five times slower)
+  // (one lane per chain with certified decisions -- the Normal family, a closure with a certified tail --: the wavefront's pass keeps 64 partial sums per lane, i.e. needs the
+  // 512 registers of a workgroup of at most 256 threads; measured 1.34e9 against 7.2e8 for the scalar-path pass of the larger classes, so those are not picked unless asked for)
+  const bool cert_one_lane = (!s->user && s->model == AMWG_MODEL_NORMAL && certified_wanted(s, 1, false)) || user_cert_wanted(s, 1);
   auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds && !(bt > 512 && hier_rows_wanted(s, G) && hier_rows_fit(s, 512, max_lds)) &&
-                                          !(bt > 512 && user_rows_wanted(s, G) && user_rows_fit(s, 512, max_lds)); };
+                                          !(bt > 512 && user_rows_wanted(s, G) && user_rows_fit(s, 512, max_lds)) && !(bt > 256 && G == 1 && cert_one_lane && !o.block_threads); };
   if (s->user && !s->user_parallel && o.lanes_per_chain > 1)
     return fail(AMWG_EINVAL, "this closure has no loop that can be split over lanes: lanes_per_chain must be 1 (or 0 = auto), got %d", o.lanes_per_chain);
   const int bts[5] = {1024, 512, 256, 128, 64};
@@ -307,7 +321,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     // translated closures: with one lane per chain every data index is wave-uniform and the compiler moves the
     // per-observation integer logic to the scalar unit, which issues 4x slower than the vector lanes (measured 2.5x on
     // the beta-Bernoulli closure); two lanes per chain keep it on the vector path at no measurable cost elsewhere
-    if (s->user && s->user_parallel && !fixed_lanes && G == 1 && !(s->user_work_one_lane > 0)) continue;
+    if (s->user && s->user_parallel && !fixed_lanes && G == 1 && !(s->user_work_one_lane > 0) && !user_cert_wanted(s, 1)) continue;
     int pick = 0;
     for (int bi = 0; bi < 5; ++bi) {   // largest workgroup with >= one workgroup per CU, else the smallest that fits
       const int bt = bts[bi];
@@ -363,6 +377,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     const bool rows = user_rows_wanted(s, s->lanes) && user_rows_fit(s, s->block, max_lds);
     s->d.pad = rows ? HierNormalModel::row_pitch(s->user_rows_n) : 0;
     s->user_sweep = rows && user_sweep_wanted(s, s->lanes, s->block, max_lds);
+    s->certified = !s->user_sweep && user_cert_wanted(s, s->lanes);      // (amwg_user_step_cert)
     return AMWG_OK;
   }
   const bool rows = !s->mc.group_local && hier_rows_wanted(s, s->lanes) && hier_rows_fit(s, s->block, max_lds);
@@ -392,6 +407,8 @@ struct Roctx {
 };
 Roctx &roctx() { static Roctx r; return r; }
 
+// which of the three kernels of a translated closure's code object this sampler launches (user_program)
+static const char *user_kernel_symbol(const amwg_sampler *s) { return s->user_sweep ? "amwg_user_sweep" : (s->certified ? "amwg_user_step_cert" : "amwg_user_step"); }
 // does this sampler's kernel decide from a model's cheaper value of log_post (amwg_kernel.h kCert: NormalModel at one lane per chain, PoisGlmModel at 16)?
 static bool certified_kernel(const amwg_sampler *s) { return s->certified; }
 
@@ -705,6 +722,20 @@ static int build_layout(amwg_sampler *s, const amwg_param_desc *params, int n_pa
   return AMWG_OK;
 }
 
+// AMWG_TIMING=1: the constructor's phases on stderr (development aid; the end-to-end bench reports the constructor as a whole)
+namespace {
+struct PhaseClock {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  PhaseClock() : on(getenv("AMWG_TIMING") && getenv("AMWG_TIMING")[0] == '1'), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char *what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[amwg timing] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+}  // namespace
 static int open_device(amwg_sampler *s, hipDeviceProp_t *prop) {
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -811,6 +842,14 @@ static std::string user_program(const char *source, int lanes, int block) {
            "  if constexpr (amwg::LaneReuseOf<amwg::UserModel>::value && %d == 64 && %d <= 512) amwg::step_body<amwg::UserModel, 64, 512, false, true>(a, smem);\n}\n",
            block, lanes, block, lanes, block);
   p += tail;
+  // amwg_user_step_cert: for a closure with a certified tail (amwg_user.h norm_tail_approx: UserModel::kCertified) at the lane count it has one for, the stepper
+  // that decides accept tests from it (amwg_step_kernel_cert's twin; BT: the wavefront's pass needs the 512 registers of a workgroup of at most 256 threads)
+  snprintf(tail, sizeof tail,
+           "extern \"C\" __global__ void __launch_bounds__(%d) amwg_user_step_cert(const amwg::StepArgs a) {\n"
+           "  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n"
+           "  if constexpr (amwg::CertifiedAt<amwg::UserModel, %d>::value && !amwg::CertNeedsRows<amwg::UserModel>::value) amwg::step_body<amwg::UserModel, %d, %d, false, false, true>(a, smem);\n}\n",
+           block, lanes, lanes, block <= 256 ? 256 : 1024);
+  p += tail;
   return p;
 }
 
@@ -906,7 +945,11 @@ static int compile_user(const char *source, int lanes, int block, const char *ar
                          amwg_hdr_kernel, amwg_hdr_user, amwg_hdr_twoval, amwg_hdr_kval, amwg_hdr_trig, amwg_hdr_pass, amwg_hdr_rows, amwg_hdr_window};
   constexpr int kHeaders = (int)(sizeof(texts) / sizeof(texts[0]));
   const std::string prog_src = user_program(source, lanes, block);
+#if defined(AMWG_AUDIT)      // (libamwg_audit.so: the certified kernels of translated closures record |A - E| / eps as the built-in families' do)
+  const char *const kOpts[] = {"-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-DAMWG_AUDIT=1"};
+#else
   const char *const kOpts[] = {"-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-falign-loops=64"};
+#endif
   // the on-disk cache (see above)
   std::string dir = cache_dir(), file;
   CacheKey key{};
@@ -1021,7 +1064,7 @@ static int autotune_geometry(amwg_sampler *s, int n_cus, size_t max_lds, Prepare
   for (size_t i = 0; i < cand.size(); ++i) if (i != best && cand[i].module) (void)hipModuleUnload(cand[i].module);
   const TuneCandidate &c = cand[best];
   s->lanes = c.lanes; s->block = c.block; s->grid = c.grid; s->lds = c.lds; s->cpb = c.cpb; s->kernel = c.kernel; s->user_module = c.module; s->user_fn = c.fn;
-  s->certified = !s->user && c.kernel != nullptr && c.kernel == pick_certified_kernel(s->model, c.lanes, c.block);
+  s->certified = s->user ? (!c.sweep && user_cert_wanted(s, c.lanes)) : (c.kernel != nullptr && c.kernel == pick_certified_kernel(s->model, c.lanes, c.block));
   s->d.pad = c.pad; s->user_sweep = c.sweep;      // (the row layout and the sweep kernel go with the geometry)
   s->tuned.clear();
   for (auto &q : cand) s->tuned.push_back({q.lanes, q.ms});
@@ -1066,6 +1109,7 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
 #undef HIPB
 #define TRYB(x) do { int rc_ = (x); if (rc_ != AMWG_OK) return bail(rc_); } while (0)
 #define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(AMWG_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
+  PhaseClock clk;
   TRYB(build_layout(s, params, n_params, false));
   const int P = s->P;
 
@@ -1095,7 +1139,9 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   }
 
   hipDeviceProp_t prop;
+  clk.mark("layout + checks");
   TRYB(open_device(s, &prop));
+  clk.mark("open device (HIP runtime)");
   // ---- model constants, with the kernel's own log (same roundings as the reference expression trees)
   ModelConsts &mc = s->mc;
   mc.neg_half_log_2pi = -0.5 * log_v8(2 * kPi);
@@ -1216,8 +1262,10 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
     for (int i = 0; i < N; ++i) { mc.glm_sum_y += std::fabs(m->y[i]); mc.glm_sum_lf += std::fabs(lf[i]); }
   }
   mc.data_mid_range = mid ? 1 : 0;
+  clk.mark("device + data upload");
 
   TRYB(alloc_chain_state(s, params, n_params, init, comp_opts));
+  clk.mark("chain state");
 
   // ---- geometry.  The constructor's warm-up log_post (mcmc.js:961-963) is folded into the first
   // launch (StepArgs.init_lp); amwg_chain_diag forces it with a 0-step launch if asked earlier.
@@ -1244,8 +1292,11 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   };
   if (options->lanes_per_chain == AMWG_LANES_AUTOTUNE) TRYB(autotune_geometry(s, n_cus, max_lds, prepare));
   else { TRYB(choose_geometry(s, n_cus, max_lds)); }
+  clk.mark("geometry");
   TRYB(prepare());
+  clk.mark("kernel attribute (module load)");
   HIPB(hipStreamSynchronize(s->stream));
+  clk.mark("sync");
   *out = s;
   return AMWG_OK;
 }
@@ -1274,10 +1325,25 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
   s->user_max_threads = max_threads;
   s->user_work = m->work_per_eval;
   s->user_work_one_lane = m->work_one_lane;
-  if (m->rows_n_obs < 0 || m->rows_groups < 0) return fail(AMWG_EINVAL, "amwg_create_user: negative row plan");
-  s->user_rows_n = m->rows_n_obs;
-  s->user_rows_groups = m->rows_groups;
-  s->user_rows_sweep = m->rows_sweep ? 1 : 0;
+  if (m->rows_n_obs < 0 || m->rows_groups < 0) { delete s; return fail(AMWG_EINVAL, "amwg_create_user: negative row plan"); }
+  {
+    // The row plan is honoured only as far as the GENERATED SOURCE states it (kRowN / kRowGroups / kRowSweep of translate.js): the source is what gets compiled, and
+    // a caller built against an older amwg_user_model -- a shorter struct: the rows_* fields are then whatever follows it in memory -- must not switch a layout on
+    // that the model has no code for (round-5 advisor finding).  The certified tail is read from the source alone (kCertifiedTail / kTailN): no struct field carries it.
+    auto int_after = [&](const char *key) -> long {
+      const char *q = strstr(m->source, key);
+      return q ? strtol(q + strlen(key), nullptr, 10) : -1;
+    };
+    const long src_n = int_after("kRowN = "), src_g = int_after("kRowGroups = ");
+    const bool src_sweep = strstr(m->source, "kRowSweep = true") != nullptr;
+    const bool rows_ok = m->rows_n_obs > 0 && src_n == (long)m->rows_n_obs && src_g == (long)m->rows_groups;
+    if (m->rows_n_obs > 0 && !rows_ok && src_n >= 0) { delete s; return fail(AMWG_EINVAL, "amwg_create_user: row plan (%d observations, %d groups) does not match the generated source (kRowN = %ld, kRowGroups = %ld)", m->rows_n_obs, m->rows_groups, src_n, src_g); }
+    s->user_rows_n = rows_ok ? m->rows_n_obs : 0;
+    s->user_rows_groups = rows_ok ? m->rows_groups : 0;
+    s->user_rows_sweep = (rows_ok && m->rows_sweep && src_sweep) ? 1 : 0;
+    const long tail_n = strstr(m->source, "kCertifiedTail = true") ? int_after("kTailN = ") : 0;
+    s->user_cert_tail_n = tail_n > 0 && tail_n < (1l << 28) ? (int)tail_n : 0;
+  }
   s->C = options->chains;
   s->device = options->device;
   auto bail = [&](int rc) { amwg_destroy(s); return rc; };
@@ -1351,7 +1417,7 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
     }
     if (s->user_module) return AMWG_OK;      // (autotune hands back the module it kept)
     hipError_t e = hipModuleLoadData(&s->user_module, it->second.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&s->user_fn, s->user_module, s->user_sweep ? "amwg_user_sweep" : "amwg_user_step");
+    if (e == hipSuccess) e = hipModuleGetFunction(&s->user_fn, s->user_module, user_kernel_symbol(s));
     if (e != hipSuccess) {
       // the cache is never a requirement: an object the loader refuses (a planted or half-written file that still passed the checks, another
       // driver) is dropped and the closure compiled afresh, once
@@ -1362,7 +1428,7 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
       if (rc != AMWG_OK) return rc;
       it->second = std::move(fresh);
       e = hipModuleLoadData(&s->user_module, it->second.data());
-      if (e == hipSuccess) e = hipModuleGetFunction(&s->user_fn, s->user_module, s->user_sweep ? "amwg_user_sweep" : "amwg_user_step");
+      if (e == hipSuccess) e = hipModuleGetFunction(&s->user_fn, s->user_module, user_kernel_symbol(s));
       if (e != hipSuccess) return fail(AMWG_EHIP, "loading the compiled log_post failed: %s", hipGetErrorString(e));
     }
     // workgroups of this kernel use up to the whole 160 KB LDS of a CU; not every runtime needs (or accepts) the opt-in for module functions
@@ -1441,44 +1507,119 @@ int amwg_sample_async(amwg_sampler *s, int64_t n, int64_t thin) {
   return amwg_sample_device(s, n, thin, s->d_draws, need);
 }
 
-// touches every page of [p, p + bytes) without changing a byte (a write fault maps a private page; the value written is the one read)
+// Makes the pages of [p, p + bytes) resident without changing a byte.  A freshly allocated typed array / numpy array is untouched virtual memory, and a copy from the
+// device into it runs at the speed the pages can be faulted in, not at the link's: measured on the GPU box (tools/ubench/pinned_copy.hip, 1 GiB) 9.8 GB/s into
+// untouched pageable memory against 56 GB/s into the same memory once resident (pinning it first buys nothing more: 57 GB/s, and hipHostRegister / hipHostMalloc
+// of a gigabyte cost 55-170 ms themselves).  Round 5 touched the pages with ONE thread -- ~6 GB/s, slower than the kernels produce rows at cfg2 (10 GB/s): sample()
+// took three times its kernels' time.  Now: transparent huge pages are asked for (512 times fewer faults where the host grants them), the kernel is asked to populate
+// the range in one call (MADV_POPULATE_WRITE, Linux 5.14), and where that is not available the pages are touched -- a write of the value just read.
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
 static void prefault(char *p, size_t bytes) {
   if (!p || !bytes) return;
   const size_t page = 4096;
+  const uintptr_t a0 = ((uintptr_t)p + page - 1) & ~(uintptr_t)(page - 1), a1 = ((uintptr_t)p + bytes) & ~(uintptr_t)(page - 1);
+  if (a1 > a0 && madvise(reinterpret_cast<void *>(a0), a1 - a0, MADV_POPULATE_WRITE) == 0) {
+    volatile char *q = p;
+    q[0] = q[0];
+    q[bytes - 1] = q[bytes - 1];      // (the partial pages at either end)
+    return;
+  }
   volatile char *q = p;
   for (size_t o = 0; o < bytes; o += page) q[o] = q[o];
   q[bytes - 1] = q[bytes - 1];
 }
+// ... by a few helper threads that run AHEAD of the copies: the rows of a sample call leave the device launch by launch (below), and the destination of launch j's rows must
+// be resident when its kernel ends.  The helpers walk the destination in the order the copies will (chunk by chunk, slice by slice) and publish how far they are.
+namespace {
+struct Prefaulter {
+  struct Piece { char *p; size_t bytes; size_t chunk; };
+  std::vector<Piece> pieces;              // in copy order
+  std::vector<std::thread> workers;
+  std::atomic<size_t> next{0};
+  std::vector<std::atomic<int>> done;     // pieces finished per chunk
+  std::vector<int> per_chunk;
+  explicit Prefaulter(size_t n_chunks) : done(n_chunks), per_chunk(n_chunks, 0) { for (auto &d : done) d.store(0); }
+  void add(char *p, size_t bytes, size_t chunk) {
+    const size_t step = (size_t)8 << 20;      // 8 MB pieces: several helpers share one chunk's range
+    for (size_t o = 0; o < bytes; o += step) { pieces.push_back({p + o, bytes - o < step ? bytes - o : step, chunk}); per_chunk[chunk]++; }
+  }
+  void start(int n_threads) {
+    for (int t = 0; t < n_threads; ++t)
+      workers.emplace_back([this] {
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= pieces.size()) return;
+          prefault(pieces[i].p, pieces[i].bytes);
+          done[pieces[i].chunk].fetch_add(1, std::memory_order_release);
+        }
+      });
+  }
+  void wait_chunk(size_t j) {      // (the caller helps instead of idling: it takes pieces too)
+    while (done[j].load(std::memory_order_acquire) < per_chunk[j]) {
+      const size_t i = next.fetch_add(1);
+      if (i < pieces.size()) { prefault(pieces[i].p, pieces[i].bytes); done[pieces[i].chunk].fetch_add(1, std::memory_order_release); }
+      else std::this_thread::yield();
+    }
+  }
+  ~Prefaulter() { for (auto &w : workers) w.join(); }
+};
+}  // namespace
 
 // The rows of a sample call are final launch by launch (launch_steps records an event after each): the rows of launch j leave the
 // device on copy_stream while launches j + 1, ... run on the sampler's stream -- a pageable destination (a JavaScript typed array, a numpy
-// array) makes each copy block THIS thread, not the GPU.  65 536 chains x 1000 draws x 2 components are 1.05 GB: 0.27 s of copying after
-// 0.33 s of kernels when done at the end, hidden behind them this way.
+// array) makes each copy block THIS thread, not the GPU.  65 536 chains x 1000 draws x 2 components are 1.05 GB: with the destination resident
+// in time (Prefaulter) they leave at the link's rate behind the kernels that produce them.
 int amwg_fetch_draws_slices(amwg_sampler *s, int32_t n_slices, const int32_t *base, const int32_t *len, double *const *out, const size_t *out_bytes) {
   if (!s) return fail(AMWG_EINVAL, "amwg_fetch_draws: null sampler");
   if (s->last_draws != s->d_draws) return fail(AMWG_EINVAL, "amwg_fetch_draws: no amwg_sample_async pending");
   if (n_slices < 0 || (n_slices > 0 && (!base || !len || !out || !out_bytes))) return fail(AMWG_EINVAL, "amwg_fetch_draws_slices: bad argument");
   const int PR = s->P + s->D;
   const size_t C = (size_t)s->C;
+  size_t total_bytes = 0;
   for (int k = 0; k < n_slices; ++k) {
     if (base[k] < 0 || len[k] < 0 || base[k] > PR || len[k] > PR - base[k]) return fail(AMWG_EINVAL, "amwg_fetch_draws_slices: slice %d = [%d, %d) outside the %d recorded values", k, base[k], base[k] + len[k], PR);
     const size_t need = (size_t)s->last_rows * (size_t)len[k] * C * 8;
     if (need && !out[k]) return fail(AMWG_EINVAL, "amwg_fetch_draws: null output");
     if (out_bytes[k] < need) return fail(AMWG_ESIZE, "amwg_sample: output needs %zu bytes, got %zu", need, out_bytes[k]);
+    total_bytes += need;
   }
   HIP_TRY(hipSetDevice(s->device));
   if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
   // (launches since the sample call -- a burn in between -- have reset the per-launch marks: then everything is final once the stream is idle)
   const bool marks = !s->chunk_rows.empty() && s->chunk_rows.back() == s->last_rows;
-  if (!marks) HIP_TRY(hipStreamSynchronize(s->stream));
   const size_t n_chunks = marks ? s->chunk_rows.size() : 1;
+  // the destination becomes resident ahead of the copies, in their order.  Helpers only where there is something to win (>= 16 MB): small results are touched inline
+  Prefaulter pf(n_chunks);
+  {
+    int64_t r0 = 0;
+    for (size_t j = 0; j < n_chunks; ++j) {
+      const int64_t r1 = marks ? s->chunk_rows[j] : s->last_rows;
+      if (r1 > r0)
+        for (int k = 0; k < n_slices; ++k) {
+          if (!len[k]) continue;
+          const size_t width = (size_t)len[k] * C * 8;
+          pf.add(reinterpret_cast<char *>(out[k]) + (size_t)r0 * width, (size_t)(r1 - r0) * width, j);
+        }
+      r0 = r1;
+    }
+    for (int k = 0; k < n_slices; ++k) {      // transparent huge pages for the whole destination, where the host grants them on request
+      const size_t need = (size_t)s->last_rows * (size_t)len[k] * C * 8;
+      const uintptr_t a0 = ((uintptr_t)out[k] + 4095) & ~(uintptr_t)4095, a1 = ((uintptr_t)out[k] + need) & ~(uintptr_t)4095;
+      if (need >= ((size_t)4 << 20) && a1 > a0) (void)madvise(reinterpret_cast<void *>(a0), a1 - a0, MADV_HUGEPAGE);
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    int helpers = total_bytes >= ((size_t)16 << 20) ? (hw >= 8 ? 4 : (hw >= 4 ? 2 : (hw >= 2 ? 1 : 0))) : 0;
+    if (const char *e = getenv("AMWG_PREFAULT_THREADS")) helpers = atoi(e) < 0 ? 0 : (atoi(e) > 16 ? 16 : atoi(e));
+    pf.start(helpers);
+  }
+  if (!marks) HIP_TRY(hipStreamSynchronize(s->stream));
   int64_t r0 = 0;
   for (size_t j = 0; j < n_chunks; ++j) {
     const int64_t r1 = marks ? s->chunk_rows[j] : s->last_rows;
     if (r1 > r0) {
-      // while launch j still runs: make the destination pages of its rows resident.  A freshly allocated typed array / numpy array is
-      // untouched virtual memory, and faulting it in page by page INSIDE the copy was most of the copy's time (1.05 GB: 0.27 s)
-      for (int k = 0; k < n_slices; ++k) prefault(reinterpret_cast<char *>(out[k]) + (size_t)r0 * (size_t)len[k] * C * 8, (size_t)(r1 - r0) * (size_t)len[k] * C * 8);
+      pf.wait_chunk(j);      // (while launch j still runs, usually: the helpers are ahead)
       if (marks) HIP_TRY(hipEventSynchronize(s->chunk_ev[j]));
       for (int k = 0; k < n_slices; ++k) {
         if (!len[k]) continue;
@@ -1684,7 +1825,7 @@ const char *amwg_kernel_name(const amwg_sampler *s) {
   if (m->kernel_name.empty()) {
     const int cls = s->block <= 256 ? 256 : (s->block <= 512 ? 512 : 1024);
     char buf[96];
-    if (s->user) snprintf(buf, sizeof buf, "%s", s->user_sweep ? "amwg_user_sweep" : "amwg_user_step");
+    if (s->user) snprintf(buf, sizeof buf, "%s", user_kernel_symbol(s));
     else if (s->mc.group_local) snprintf(buf, sizeof buf, "amwg_gl_kernel<HierGlModel,%d>", cls);
     else if (s->model == AMWG_MODEL_HIER_NORMAL && s->d.pad > 0) snprintf(buf, sizeof buf, "amwg_sweep_kernel%s<HierNormalModel,%d>", s->certified ? "_cert" : "", cls);
     else {

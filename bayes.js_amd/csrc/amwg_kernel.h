@@ -777,8 +777,17 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   auto record_draws = [&](int step) {
     if (recording && step == next_rec) {
       double *const draws = cold_args()->draws;
-      if (writer)
-        for (int p = 0; p < P; ++p) draws[(row * PR + p) * C + cl] = S(p);
+      // the row is written by ALL lanes of the chain that sit in its first wavefront -- lane j components j, j + L, ... (L = min(G, 64)): one store instruction per L
+      // components.  (Round 5 had the chain's first lane walk the P components: 34 dependent single-lane stores per step of cfg4, a quarter of a recording launch.)
+      {
+        constexpr int LW = G < 64 ? G : 64;
+        if (live && (!kMulti || sub < 64))
+          for (int p = sub & (LW - 1); p < P; p += LW) {
+#if !defined(AMWG_X_NOREC)      // (development experiment: a recording launch without its stores, tools/build_variant.sh)
+            draws[(row * PR + p) * C + cl] = S(p);
+#endif
+          }
+      }
       if constexpr (D > 0) {
         // derived quantities (`state.var = ...` inside log_post, mcmc.js:961-963, 990-995): the
         // reference re-evaluates log_post at the end of every step, so what sample() records is the

@@ -64,95 +64,8 @@ __device__ __forceinline__ void norm_cache_update(NormCache &k, double sd, doubl
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// The certified pass of the Normal family, one lane per chain, for the 64 chains of a wavefront AT ONCE:  S2_c = sum_i (x_i - mu_c)^2.
-// Lane l enters with its chain's mean and leaves with its chain's sum.  With a lane per chain every chain needs every observation: read one at a time
-// and broadcast (scalar loads, norm_sq_pass_uniform) the pass waits for its loads -- two operations per observation are not enough work to cover a scalar
-// cache round trip with one wavefront per SIMD (measured: 0.37 of the issue rate).  Here the ROLES are swapped for the length of the pass: a lane holds
-// OBSERVATIONS (lane l: x_l, x_(l+64), ...: coalesced reads of the LDS tile, each value used for all 64 chains), the means are broadcast (v_readlane, eight
-// chains' worth at a time), every lane keeps 64 partial sums -- one per chain -- and a transposing butterfly (v_permlane32_swap / v_permlane16_swap /
-// DPP: 63 exchange-and-add steps) leaves chain c's total in lane c.  Same count of fp64 operations, no load on the critical path.  The order of the
-// additions is whatever this schedule gives: the value is used with its rounding bound only (NormalModel::log_post_approx).
-template <int B>
-__device__ __forceinline__ double norm_sq_pass_wave(const double *x, double mu, int n_obs) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const int lane = (int)(threadIdx.x & 63u);
-  double a[64];
-#pragma unroll
-  for (int c = 0; c < 64; ++c) a[c] = 0.0;
-  const int mu_lo = (int)(uint32_t)f64_bits(mu), mu_hi = (int)(uint32_t)(f64_bits(mu) >> 32);
-  auto mean_of = [&](int c) { return bits_f64(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mu_hi, c) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mu_lo, c)); };
-  int base = 0;
-  for (; base + 64 * B <= n_obs; base += 64 * B) {
-    double xv[B];
-#pragma unroll
-    for (int b = 0; b < B; ++b) xv[b] = x[base + b * 64 + lane];
-#pragma unroll
-    for (int g = 0; g < 64; g += 8) {      // eight chains' means in scalar registers, then this lane's B observations against each: the eight running sums interleave
-      double m[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) m[j] = mean_of(g + j);
-#pragma unroll
-      for (int b = 0; b < B; ++b) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const double t = xv[b] - m[j]; a[g + j] = __builtin_fma(t, t, a[g + j]); }
-      }
-    }
-  }
-  for (; base < n_obs; base += 64) {       // the rest, 64 observations a round; the last round masked
-    const int i = base + lane;
-    const bool has = i < n_obs;
-    const double xv = x[has ? i : base];
-#pragma unroll
-    for (int g = 0; g < 64; g += 8) {
-      double m[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) m[j] = mean_of(g + j);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const double t = has ? xv - m[j] : 0.0; a[g + j] = __builtin_fma(t, t, a[g + j]); }
-    }
-  }
-  // transposing butterfly: after the step with offset o a lane holds the chains that agree with it in that bit, a[j] <- kept + received
-  auto swap_add = [&](double A, double Bv, int off) {      // A: what the lanes with the bit CLEAR keep, Bv: what the lanes with the bit SET keep
-    const uint32_t al = (uint32_t)f64_bits(A), ah = (uint32_t)(f64_bits(A) >> 32), bl = (uint32_t)f64_bits(Bv), bh = (uint32_t)(f64_bits(Bv) >> 32);
-    if (off == 32) {
-      const auto l = __builtin_amdgcn_permlane32_swap(al, bl, false, false), h = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
-      return bits_f64(((uint64_t)h[0] << 32) | (uint64_t)l[0]) + bits_f64(((uint64_t)h[1] << 32) | (uint64_t)l[1]);
-    } else {
-      const auto l = __builtin_amdgcn_permlane16_swap(al, bl, false, false), h = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
-      return bits_f64(((uint64_t)h[0] << 32) | (uint64_t)l[0]) + bits_f64(((uint64_t)h[1] << 32) | (uint64_t)l[1]);
-    }
-  };
-#pragma unroll
-  for (int j = 0; j < 32; ++j) a[j] = swap_add(a[j], a[j + 32], 32);      // the upper 32 lanes' a[j] <-> the lower 32 lanes' a[j + 32]: every lane then adds its two registers
-#pragma unroll
-  for (int j = 0; j < 16; ++j) a[j] = swap_add(a[j], a[j + 16], 16);      // likewise between the odd and the even rows of 16 lanes
-  {
-    const bool up = (lane & 8) != 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const double send = up ? a[j] : a[j + 8], keep = up ? a[j + 8] : a[j]; a[j] = keep + xor_partner<8, true>(send); }
-  }
-  {
-    const bool up = (lane & 4) != 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const double send = up ? a[j] : a[j + 4], keep = up ? a[j + 4] : a[j]; a[j] = keep + xor_partner<4, true>(send); }
-  }
-  {
-    const bool up = (lane & 2) != 0;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { const double send = up ? a[j] : a[j + 2], keep = up ? a[j + 2] : a[j]; a[j] = keep + xor_partner<2>(send); }
-  }
-  {
-    const bool up = (lane & 1) != 0;
-    const double send = up ? a[0] : a[1], keep = up ? a[1] : a[0];
-    a[0] = keep + xor_partner<1>(send);
-  }
-  return a[0];
-#else
-  (void)x; (void)mu; (void)n_obs;
-  return 0.0;
-#endif
-}
+// (norm_sq_pass_wave -- the certified pass of the Normal family for the 64 chains of a wavefront at once -- lives in amwg_pass.h: translated closures that end in the
+// same likelihood loop run it too, amwg_user.h norm_tail_approx)
 
 // ---------------------------------------------------------------------------------------------
 // x_i ~ norm(mu, sigma); mu ~ norm(m0,s0); sigma ~ unif(a,b)              README.md:22-36

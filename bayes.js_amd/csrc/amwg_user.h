@@ -81,6 +81,36 @@ AMWG_HD double norm_data_loop(const XT *x_staged, const XT *x_global, int n, dou
   return acc;
 }
 
+// CERTIFIED TAIL of a translated closure (translate.js tailPlan; amwg_kernel.h "certified decisions"; the hand-written twin is NormalModel::log_post_approx).  A
+// closure whose LAST statement is that loop -- lp = head; for (i) lp += ld.norm(x[i], mean, sd), mean and sd expressions of the state alone, x a whole f64 array --
+// evaluates, as a real number, to  head + n c - S2 / den  with S2 = sum (x_i - mean)^2: two operations per observation where the expression's term takes eight.  The
+// generated model hands the stepper that value with the bound the Normal family derives (amwg_models.h; `head` stands where its prior stands: the same fp64 number on
+// both sides) -- eps = (2 n + 64) u (|head| + n |c| + 2 Q) 1.25 -- and the step kernel decides from it exactly as it does for the family: the expression (the closure's
+// own body, one lane per chain = the reference's order) where a uniform falls inside the bound and wherever a value is stored.  One lane per chain only; the pass is
+// the wavefront's (norm_sq_pass_wave: workgroups of up to 256 threads), the scalar-path pass in larger workgroups.
+struct TailApprox { double value, eps; };
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)      // (device code only: the host build of a generated model -- tests/host -- evaluates the closure itself)
+template <class M, int G, int BT>
+__device__ __forceinline__ TailApprox norm_tail_approx(const StateView &S, const DataRef &d, const unsigned char *smem, int sub) {
+  static_assert(G == 1, "the certified tail of a translated closure is the one-lane one");
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double head = M::template tail_head<1>(S, d, smem, 0);
+  const NormInv k = norm_inv(M::tail_sd(S, d));
+  const double mean = M::tail_mean(S, d);
+  double S2;
+  if constexpr (BT <= 256) S2 = norm_sq_pass_wave<8>(M::tail_x(d, smem), mean, M::kTailN);      // (every lane of the wavefront takes part: the stepper's call site is wave-uniform)
+  else S2 = norm_sq_pass_uniform<8>(M::tail_x_global(d), mean, M::kTailN);
+  const double n = (double)M::kTailN;
+  const double Q = S2 * k.y.hi, nc = n * k.c;
+  const double mag = __builtin_fabs(head) + __builtin_fabs(nc) + 2.0 * Q;
+  return TailApprox{(head + nc) - Q, (2.0 * n + 64.0) * 0x1p-53 * mag * 1.25};
+#else
+  (void)S; (void)d; (void)smem; (void)sub;
+  return TailApprox{0.0, __builtin_inf()};
+#endif
+}
+#endif
+
 // The same for a GATHERED mean -- `for (i...) lp += ld.norm(y[i], state.theta[g[i]], sd)`, the likelihood loop of a model with group
 // means (random effects): g a data array of small integers (stored as bytes), theta a parameter vector at state offset `base` with
 // `n_groups` entries that g can reach.  PERIODIC (worked out by the translator for this lane count): g[i] == g[i % G] for every i, so a

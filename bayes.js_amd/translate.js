@@ -1349,10 +1349,18 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
         for (let i = 0; i < arr.flat.length && mid; i++) { const v = Math.abs(arr.flat[i]); mid = v === 0 || (v >= Math.pow(2, -200) && v <= Math.pow(2, 200)); }
         if (arr.ctype === 'double') this.uniformNormLoops = (this.uniformNormLoops || 0) + 1;      // scalar-load pass with one lane per chain
         else this.otherSplitLoops = (this.otherSplitLoops || 0) + 1;
+        // CERTIFIED TAIL candidate (csrc/amwg_user.h norm_tail_approx): this loop at the top level of the closure, adding to the closure's one accumulator, f64 observations,
+        // mean and sd expressions of the state alone.  run() decides (it must be the LAST statement: tailPlan).
+        const sdT = L.preamble.length === 1 && /^const NormInv (k\d+) = norm_inv\((.+)\);(?: KFASTCHECK\(\1\))?$/.exec(L.preamble[0].trim());
+        const stateOnly = (e) => !/\b(v_\w+|A\d+|t\d+|k\d+|tb_|it_|sub|dq_\w+)\b/.test(e);
+        const tailCand = !this.isHelper && !this.opts.no_cert_tail && !this.linear && this.acc && loopAcc === this.acc && indent === '    ' && !this.condDepth &&
+                         arr.ctype === 'double' && boundV.cst >= 1 && sdT && sdT[1] === mn[4] && stateOnly(sdT[2]) && stateOnly(mn[3]);
+        if (tailCand) out.push(indent + '//@TAIL x=A' + mn[1] + ' n=' + boundV.cst + ' acc=' + loopAcc + ' mean=' + mn[3] + ' @sd=' + sdT[2]);
         out.push(indent + '{');
         for (const ln of renderNorm(L.preamble.map((q) => '  ' + q), 'inv')) out.push(indent + ln);
         out.push(indent + '  ' + acc + ' = norm_data_loop<G>(A' + mn[1] + ', static_cast<const ' + arr.ctype + ' *>(user_arr<' + mn[1] + '>(d)), ' + boundV.cst + ', ' + mn[3] + ', ' + mn[4] + ', ' + (mid ? 'true' : 'false') + ', sub, ' + acc + ');');
         out.push(indent + '}');
+        if (tailCand) out.push(indent + '//@TAIL_END');
         return;
       }
       // ... and with a GATHERED mean, `lp += ld.norm(y[i], state.theta[g[i]], sd)`: g a byte-typed data array whose values index a
@@ -1705,6 +1713,7 @@ Translator.prototype.run = function () {
   // 1.52e7 -> 2.01e7 updates/s).  Plain arithmetic loops: up to 1024.
   const maxThreads = this.opts.max_threads || (this.heavyLoop ? (off > 73728 ? 512 : 256) : 1024);
   const rows = this.rowPlan(body);
+  const tail = rows ? null : this.tailPlan(body);
   const src = [];
   src.push('// generated by bayes.js_amd/translate.js from the user\'s log_post closure');
   src.push('namespace amwg {');
@@ -1752,6 +1761,35 @@ Translator.prototype.run = function () {
     src.push('    return v_' + rows.acc + ';');
     src.push('  }');
   }
+  if (tail) {
+    // CERTIFIED TAIL (csrc/amwg_user.h norm_tail_approx; amwg_kernel.h "certified decisions"): with one lane per chain the stepper decides accept tests from
+    // head + n c - S2 / den and its bound, and evaluates the closure itself (eval below: the reference's own order) where that does not decide
+    const tx = P1.plan[tail.x];
+    src.push('  // ---- certified tail: `' + tail.acc + '` ends in  for (i < ' + tail.n + ') ' + tail.acc + ' += ld.norm(A' + tail.x + '[i], ' + tail.mean + ', ' + tail.sd + ')');
+    src.push('  static constexpr bool kCertifiedTail = true, kCertified = true;');
+    src.push('  static constexpr int kCertifiedLanes = 1, kTailN = ' + tail.n + ';');
+    src.push('  typedef TailApprox Approx;');
+    src.push('  __device__ __forceinline__ static double tail_mean(const StateView &S, const DataRef &d) { (void)S; (void)d; return ' + tail.mean + '; }');
+    src.push('  __device__ __forceinline__ static double tail_sd(const StateView &S, const DataRef &d) { (void)S; (void)d; return ' + tail.sd + '; }');
+    src.push('  __device__ __forceinline__ static const double *tail_x_global(const DataRef &d) { return static_cast<const double *>(user_arr<' + tail.x + '>(d)); }');
+    src.push('  __device__ __forceinline__ static const double *tail_x(const DataRef &d, const unsigned char *smem) { (void)smem; return ' +
+             (tx.lds ? 'reinterpret_cast<const double *>(smem + ' + tx.off + ')' : 'tail_x_global(d)') + '; }      // (the one-lane plan of the arrays)');
+    src.push('  // the closure up to that loop: what its accumulator holds when the loop begins');
+    src.push('  template <int G>');
+    src.push('  __device__ static double tail_head(const StateView &S, const DataRef &d, const unsigned char *smem, int sub) {');
+    this.arrays.forEach((a, j) => {
+      const pl = P1.plan[j];
+      src.push('    const ' + a.ctype + ' *A' + j + ' = ' + (pl.lds ? 'reinterpret_cast<const ' + a.ctype + ' *>(smem + ' + pl.off + ')' : 'static_cast<const ' + a.ctype + ' *>(user_arr<' + j + '>(d))') + ';');
+    });
+    src.push('    (void)smem; (void)sub; (void)d;');
+    for (const ln of tail.head) src.push(ln);
+    src.push('    return v_' + tail.acc + ';');
+    src.push('  }');
+    src.push('  template <int G, int BT, class C>');
+    src.push('  __device__ __forceinline__ static Approx log_post_approx(C &, const StateView &S, const ModelConsts &, const DataRef &d, const unsigned char *smem, int sub) {');
+    src.push('    return norm_tail_approx<UserModel, G, BT>(S, d, smem, sub);');
+    src.push('  }');
+  }
   src.push('#endif');
   src.push('  template <int G, bool DERIVE>');
   src.push('  AMWG_HD static double eval(const StateView &S, const DataRef &d, const unsigned char *smem, int sub, double *dv) {');
@@ -1789,7 +1827,27 @@ Translator.prototype.run = function () {
     rows_n_obs: rows ? rows.n : 0,
     rows_groups: rows ? rows.K : 0,
     rows_sweep: rows && rows.sweep ? 1 : 0,
+    // certified tail (csrc/amwg_user.h norm_tail_approx): observations of the closure's final constant-mean normal loop; 0 = none.  (The host library reads the
+    // same fact off the generated source -- kCertifiedTail / kTailN -- so no field of amwg_user_model carries it.)
+    cert_tail_n: tail ? tail.n : 0,
   };
+};
+
+// The CERTIFIED TAIL of a closure (csrc/amwg_user.h norm_tail_approx): its LAST statement before `return acc` is the constant-mean normal loop forLoop() marked with
+// //@TAIL; everything before is the head -- it must not return early, and the closure must not write derived quantities (they are formed by the expression's pass).
+// -> {x (array index), n, acc, mean, sd, head: [lines]} or null
+Translator.prototype.tailPlan = function (body) {
+  if (this.derived.length || this.isHelper || this.opts.no_cert_tail || this.hasBinary) return null;
+  let iB = -1, iE = -1;
+  body.forEach((ln, i) => { const t = ln.trim(); if (t.indexOf('//@TAIL ') === 0) iB = i; else if (t === '//@TAIL_END') iE = i; });
+  if (iB < 0 || iE < iB) return null;
+  const m = /^\/\/@TAIL x=A(\d+) n=(\d+) acc=(\w+) mean=(.+) @sd=(.+)$/.exec(body[iB].trim());
+  if (!m) return null;
+  const tailLines = body.slice(iE + 1).map((ln) => ln.trim()).filter((t) => t && t.indexOf('//') !== 0);
+  if (!(tailLines.length === 2 && /^if constexpr \(DERIVE\) \{ \(void\)dv; \}$/.test(tailLines[0]) && tailLines[1] === 'return v_' + m[3] + ';')) return null;
+  const head = body.slice(0, iB);
+  if (head.some((ln) => /\breturn\b|\bdv\[|\bdq_/.test(ln))) return null;
+  return { x: Number(m[1]), n: Number(m[2]), acc: m[3], mean: m[4], sd: m[5], head };
 };
 
 // The ROW PLAN of a closure (csrc/amwg_rows.h): its LAST statement before `return acc` is the gathered normal loop forLoop() marked with //@ROWS, over all

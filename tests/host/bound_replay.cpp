@@ -253,6 +253,22 @@ int main(int argc, char **argv) {
       pois_case("pois_counts_1e6", X, yb, bb, 1.0);
     }
   }
+  // ---- the 2^-49 of certified_test (amwg_kernel.h): "V8's exp is within an ulp of exp".  exp_v8 is V8's own algorithm (fdlibm e_exp, pinned bit for bit against
+  // Node's Math.exp by tests/test_oracle_math.py / tests/golden/v8_math_pairs.bin); its distance from the real exponential over the range of arguments the certified
+  // test feeds it -- differences of log_post in (-746, 0] and a little beyond, where the result is a normal number -- measured against expq:
+  double worst_ulps = 0;
+  {
+    std::uniform_real_distribution<double> wide(-708.0, 2.0), nearz(-1.0, 0.0);
+    for (int i = 0; i < 400000 * std::max(1, reps / 10); ++i) {
+      const double x = (i & 1) ? wide(g) : nearz(g) * std::ldexp(1.0, -(i % 40));
+      const double e = exp_v8(x);
+      const quad r = expq((quad)x);
+      const double rel = absq((quad)e - r) / (double)r;
+      worst_ulps = std::max(worst_ulps, rel / 0x1p-52);      // (an ulp of e is at most 2^-52 e)
+    }
+  }
+  printf("exp_v8 vs the real exponential on [-708, 2]: worst relative error %.3f x 2^-52 (certified_test allows 2^-49 = 8 x 2^-52)\n", worst_ulps);
+  if (worst_ulps > 1.0) { printf("VIOLATION exp_v8 further than an ulp from exp\n"); return 1; }
   printf("cases=%ld skipped_nonfinite=%ld worst |E-R|/bE=%.4g worst |A-R|/bA=%.4g worst |A-E|/eps=%.4g (%s)\n", n_cases, n_skipped, worst_E, worst_A, worst_eps, worst_name);
   const bool ok = worst_E <= 1.0 && worst_A <= 1.0 && worst_eps <= 0.5;
   printf(ok ? "bounds_hold=1\n" : "bounds_hold=0\n");

@@ -197,6 +197,45 @@ def test_translated_hierarchical_closure_at_full_size_runs_the_sweep_kernel_and_
         a.close(); b.close(); c.close()
 
 
+def test_certified_tail_of_a_translated_closure_decides_like_the_expression_and_the_family():
+    """Round 6: a closure that ENDS in `for (i) lp += ld.norm(x[i], mean, sd)` over an f64 array gets certified decisions from the translator (translate.js tailPlan,
+    csrc/amwg_user.h norm_tail_approx): with one lane per chain amwg_user_step_cert decides from head + n c - S2 / den and its bound, and evaluates the closure
+    itself where that does not decide.  BASELINE.json configs[1] written as a plain closure (not recognised as the family: translated): the default equals the
+    expression in every update (full_evaluation = 1: amwg_user_step), the bounds widened 2^14- and 2^40-fold (fallbacks often / always), the hand-written family
+    on the same data, and the seeded reference run (cfg2_full) -- draws, state, counters, uniforms, cached log_post, bit for bit (mcmc.js:524-528)."""
+    import model_spec
+    gold = golden_io.load("cfg2_full")
+    src, arrays, meta = user_host.translated("bench_normal")
+    assert meta["cert_tail_n"] == 10000 and "kCertifiedTail = true" in src
+    for rec in gold["chains"]:
+        spec, bspec = _golden_spec(gold, rec, src, arrays, meta), model_spec.spec_from_golden(gold, rec)
+        kw = dict(chains=320, seed=gold["case"]["seed"], chain_offset=rec["chain"], lanes_per_chain=1)
+        runs = [A.Sampler(spec, **kw), A.Sampler(spec, full_evaluation=1, **kw), A.Sampler(spec, test_bound_shift=14, **kw), A.Sampler(spec, test_bound_shift=40, **kw), A.Sampler(bspec, **kw)]
+        names = [q.launch_info()["kernel"] for q in runs]
+        assert names[0] == names[2] == names[3] == "amwg_user_step_cert" and names[1] == "amwg_user_step" and names[4].startswith("amwg_step_kernel_cert<NormalModel,1,"), names
+        assert all(q.launch_info()["summation_order"] == 1 for q in runs)
+        outs = []
+        for q in runs:
+            q.burn(57)
+            d1 = q.sample(40, 1)
+            q.burn(130)
+            d2 = q.sample(21, 3)
+            outs.append((d1.tobytes(), d2.tobytes(), q.state().tobytes(), q.info()["accepts"].tobytes(), q.info()["prop_log_scale"].tobytes(), q.diag()["uniforms"].tobytes(), q.diag()["log_post"].tobytes()))
+        assert all(o == outs[0] for o in outs[1:]), [[x == y for x, y in zip(o, outs[0])] for o in outs[1:]]
+        for q in runs:
+            q.close()
+    # ... and out of the golden's own schedule: the reference's chain, bit for bit
+    from gpu_util import run_schedule
+    rec = gold["chains"][0]
+    s = A.Sampler(_golden_spec(gold, rec, src, arrays, meta), chains=64, seed=gold["case"]["seed"], chain_offset=rec["chain"], lanes_per_chain=1)
+    assert s.launch_info()["kernel"] == "amwg_user_step_cert"
+    for got, want in zip(run_schedule(s, gold["case"]["schedule"]), rec["samples"]):
+        w = np.array(want["draws"], dtype=np.float64)
+        assert np.ascontiguousarray(got[: w.shape[0], :, 0]).tobytes() == w.tobytes()
+    assert s.state()[:, 0].tolist() == rec["final_state"] and s.info()["accepts"][:, 0].tolist() == rec["accepts"] and float(s.diag()["log_post"][0]) == rec["log_post"]
+    s.close()
+
+
 FULL_SIZE = [("bench_normal", "cfg2_full"), ("bench_bern", "cfg3_full"), ("bench_hier", "cfg4_full"), ("bench_glm", "cfg5_full")]
 
 

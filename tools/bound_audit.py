@@ -24,6 +24,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import shutil
 import sys
 import time
 
@@ -108,7 +109,7 @@ def cases(quick):
     out.append(hier_case("hier_n640_g8", d["x"], d["g"], 8, hs, 120))
     # (one observation per lane; a ragged last round; lanes without any; 2 to 64 groups.  A group count that is not a power of two has no row layout -- its labels do not
     # repeat with the lane stride -- and runs the plain kernel: nothing certified, nothing to audit)
-    for n, G in ((64, 32), (65, 32), (100, 4), (40, 2), (1024, 16), (64, 64)):
+    for n, G in ((64, 32), (65, 32), (100, 4), (128, 2), (1024, 16), (64, 64)):
         dd = model_spec.make_data("hier_normal", n, 20260925 + n, G=G)
         out.append(hier_case("hier_n%d_g%d" % (n, G), dd["x"], dd["g"], G, hs, 80))
     g8 = np.arange(640) % 8
@@ -130,6 +131,16 @@ def cases(quick):
     out.append(pois_case("pois_H_689", Xo, rng.poisson(50.0, 300).astype(np.float64), ps, 100, state=[689.2] + [0.0] * 7 + [100.0]))      # H within 1 of the 690 cut-off: the bound is finite ...
     out.append(pois_case("pois_H_691", Xo, rng.poisson(50.0, 300).astype(np.float64), ps, 100, state=[690.6] + [0.0] * 7 + [100.0]))      # ... and beyond it the expression decides (nothing audited while H > 690)
     out.append(pois_case("pois_zero_counts", Xs, np.zeros(500), ps, 120))
+    # ---- a TRANSLATED closure with a certified tail (translate.js tailPlan, csrc/amwg_user.h norm_tail_approx): BASELINE configs[1] as a plain closure; hiprtc compiles
+    # its kernel with -DAMWG_AUDIT in the audit build
+    if shutil.which("node"):
+        import user_host
+        src, arrays, meta = user_host.translated("bench_normal")
+        inf = float("inf")
+        uparams = [{"type": "real", "len": 1, "top": 1, "multidim": 0, "lower": -inf, "upper": inf}, {"type": "real", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": inf}]
+        uspec = {"user": user_host.user_spec_part(src, arrays, meta), "params": uparams, "P": 2, "init": [0.5, 0.5], "comp_opts": [dict(model_spec.DEFAULT_OPT) for _ in range(2)], "n_obs": 10000}
+        out.append(dict(name="user_bench_normal", spec=uspec, chains=512 if quick else 65536, steps=150, lanes=1, state=None, seed=14))
+        out.append(dict(name="user_bench_normal_sigma_1e-5", spec=uspec, chains=512, steps=100, lanes=1, state=[3.0, 1e-5], seed=15))
     if not quick:
         # ---- BASELINE configs at full size
         out.append(normal_case("cfg2_full", model_spec.make_data("normal", 10000, 20260925)["x"], 65536, 150, seed=20260925))
