@@ -36,7 +36,7 @@ DEFAULT_HYPER = {"normal": [0, 100, 0, 100], "beta_bern": [2, 2], "hier_normal":
 class Options(C.Structure):
     _fields_ = [("chains", C.c_int64), ("seed", C.c_uint64), ("chain_offset", C.c_uint64), ("device", C.c_int32),
                 ("lanes_per_chain", C.c_int32), ("block_threads", C.c_int32), ("steps_per_launch", C.c_int32),
-                ("exact_division", C.c_int32), ("group_local", C.c_int32), ("full_evaluation", C.c_int32), ("test_bound_shift", C.c_int32)]
+                ("exact_division", C.c_int32), ("group_local", C.c_int32), ("full_evaluation", C.c_int32), ("test_bound_shift", C.c_int32), ("sufficient_statistics", C.c_int32)]
 
 
 class UserModel(C.Structure):
@@ -171,7 +171,7 @@ class Sampler:
     comp_opts[]) for a closure translated by bayes.js_amd/translate.js (amwg_create_user)."""
 
     def __init__(self, spec, chains, seed, chain_offset=0, device=0, lanes_per_chain=0, block_threads=0,
-                 steps_per_launch=0, exact_division=0, group_local=0, full_evaluation=0, test_bound_shift=0):
+                 steps_per_launch=0, exact_division=0, group_local=0, full_evaluation=0, test_bound_shift=0, sufficient_statistics=0):
         L = lib()
         keep = []
         user = spec.get("user")
@@ -238,6 +238,7 @@ class Sampler:
         op.group_local = group_local
         op.full_evaluation = full_evaluation
         op.test_bound_shift = test_bound_shift
+        op.sufficient_statistics = sufficient_statistics
         h = C.c_void_p()
         if user is None:
             _check(L.amwg_create(C.byref(md), pa, n, _dp(init), oa, C.byref(op), C.byref(h)))

@@ -225,6 +225,8 @@ static bool certified_wanted(const amwg_sampler *s, int lanes, bool rows) {
   return (s->model == AMWG_MODEL_NORMAL && lanes == 1) || (s->model == AMWG_MODEL_POIS_GLM && lanes == 16) || (s->model == AMWG_MODEL_HIER_NORMAL && lanes == 64 && rows);
 }
 bool hier_rows_fit(const amwg_sampler *s, int bt, size_t max_lds);
+// the Normal family at one lane per chain stages its observations in LDS only for the wavefront's certified pass (NormalModel::lds_bytes_of: DataRef::pad = 1)
+static bool normal_tile_wanted(const amwg_sampler *s, int bt) { return !s->user && s->model == AMWG_MODEL_NORMAL && certified_wanted(s, 1, false) && bt <= 256 && !s->opt.sufficient_statistics; }
 // ... a translated closure with a certified tail (amwg_user.h norm_tail_approx; read off the generated source by amwg_create_user): one lane per chain
 static bool user_cert_wanted(const amwg_sampler *s, int lanes) {
   return s->user && s->user_cert_tail_n > 0 && lanes == 1 && s->opt.full_evaluation == 0 && !s->opt.exact_division && !s->user_has_binary;
@@ -236,7 +238,7 @@ double model_work(const amwg_sampler *s, int G) {
   const double N = (double)s->d.n_obs;
   switch (s->model) {
     // (one lane per chain: accept tests are decided from the certified pass -- two operations per observation -- unless the caller asked for the expression in every update)
-    case AMWG_MODEL_NORMAL: return (G == 1 && s->opt.full_evaluation == 0 && !s->opt.exact_division) ? 2.6 * N : 9.0 * N;
+    case AMWG_MODEL_NORMAL: return (G == 1 && s->opt.full_evaluation == 0 && !s->opt.exact_division) ? (s->opt.sufficient_statistics ? 40.0 : 2.6 * N) : 9.0 * N;
     case AMWG_MODEL_BETA_BERN:   // one lane: exact fast-forward over ~log2(N) binades (or the scalar jump-table pass, one add per observation)
       return G == 1 ? (s->mc.exact_division ? 1.8 * N : 400.0 * (1.0 + std::log2(N + 2.0))) : 6.0 * N;
     case AMWG_MODEL_HIER_NORMAL: {
@@ -297,7 +299,8 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     const size_t data_bytes = s->user ? ((user_rows_wanted(s, G) && user_rows_fit(s, bt, max_lds)) ? user_rows_bytes(s, bt) : (size_t)(G == 1 ? s->user_lds_one_lane : s->user_lds))
                               : (s->mc.group_local ? HierGlModel::gl_lds_bytes(s->d.pad, bt / 64)
                                  : ((hier_rows_wanted(s, G) && hier_rows_fit(s, bt, max_lds)) ? HierNormalModel::rows_lds_bytes(HierNormalModel::row_pitch(s->d.n_obs), bt / 64, s->d.G)
-                                    : model_lds_bytes(s->model, s->d.n_obs, s->d.G, G)));
+                                    : ((!s->user && s->model == AMWG_MODEL_NORMAL && G == 1) ? (normal_tile_wanted(s, bt) ? NormalModel::one_lane_tile_bytes(s->d.n_obs) : 0)
+                                       : model_lds_bytes(s->model, s->d.n_obs, s->d.G, G))));
     return G > 64 ? lds_layout(data_bytes, s->P, G / 64, s->pl.max_top, s->n_params, true) : lds_layout(data_bytes, s->P, cpb ? cpb : bt / G, s->pl.max_top, s->n_params);
   };
   const int max_bt = s->user ? s->user_max_threads : model_max_threads(s->model);
@@ -381,6 +384,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     return AMWG_OK;
   }
   const bool rows = !s->mc.group_local && hier_rows_wanted(s, s->lanes) && hier_rows_fit(s, s->block, max_lds);
+  if (s->model == AMWG_MODEL_NORMAL) s->d.pad = (s->lanes == 1 && normal_tile_wanted(s, s->block)) ? 1 : 0;
   s->kernel = certified_wanted(s, s->lanes, rows) ? pick_certified_kernel(s->model, s->lanes, s->block) : nullptr;
   s->certified = s->kernel != nullptr;
   if (!s->kernel) s->kernel = s->mc.group_local ? amwg_kernel_hier_gl(s->block) : (rows ? amwg_kernel_hier_sweep(s->block) : pick_kernel(s->model, s->lanes, s->block));
@@ -448,9 +452,15 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws, bool
   a.mc = s->mc;
   a.d = s->d;
   a.ch = s->ch;
-  s->n_launches = 0;
-  s->chunk_rows.clear();
-  HIP_TRY(hipEventRecord(s->ev0, s->stream));
+  // (a 0-step finalize launch on chains that have stepped -- amwg_chain_diag asking for the expression's value after a certified kernel ran -- is not "the latest call":
+  // the sample call's launch count, its per-launch marks and its event pair stay, so that a diag() between sample_async and fetch_draws neither loses the copy overlap
+  // nor replaces the call's kernel time with its own; round-5 advisor finding)
+  const bool quiet = finalize && n == 0 && s->lp_ready;
+  if (!quiet) {
+    s->n_launches = 0;
+    s->chunk_rows.clear();
+    HIP_TRY(hipEventRecord(s->ev0, s->stream));
+  }
   int64_t done = 0, row = 0;
   do {
     const int64_t m = (n - done < chunk) ? n - done : chunk;
@@ -471,7 +481,7 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws, bool
     s->lp_ready = true;
     if (finalize || a.init_lp) s->lp_is_expression = true;                        // (the launch began / ends with the expression)
     if (m > 0 && !finalize && certified_kernel(s)) s->lp_is_expression = false;      // (it may have left the stepper's cheaper value and its bound behind)
-    s->n_launches++;
+    if (!quiet) s->n_launches++;
     if (d_draws) row += (m > a.step0) ? (m - a.step0 + thin - 1) / thin : 0;
     // a mark for amwg_fetch_draws*: only for the library's own buffer, and only once >= 8 MB of new rows (or the end of the call) stand
     // behind it -- a caller who asks for one-step launches gets a handful of events, not one per launch
@@ -489,7 +499,7 @@ int launch_steps(amwg_sampler *s, int64_t n, int64_t thin, double *d_draws, bool
     }
     done += m;
   } while (done < n);
-  HIP_TRY(hipEventRecord(s->ev1, s->stream));
+  if (!quiet) HIP_TRY(hipEventRecord(s->ev1, s->stream));
   return AMWG_OK;
 }
 
@@ -673,6 +683,8 @@ static int check_options(const amwg_options *options, int max_threads) {
 #else
   if (options->test_bound_shift < 0 || options->test_bound_shift > 40) return fail(AMWG_EINVAL, "test_bound_shift must be 0..40, got %d", options->test_bound_shift);
 #endif
+  if (options->sufficient_statistics != 0 && options->sufficient_statistics != 1) return fail(AMWG_EINVAL, "sufficient_statistics must be 0 or 1, got %d", options->sufficient_statistics);
+  if (options->sufficient_statistics && (options->full_evaluation != 0 || options->exact_division)) return fail(AMWG_EINVAL, "sufficient_statistics decides from certified values: not with full_evaluation or exact_division");
   if (options->full_evaluation < 0 || options->full_evaluation > 2)
     return fail(AMWG_EINVAL, "full_evaluation must be 0 (default), 1 (every evaluation passes over all the data) or 2 (sweeps decided update by update), got %d", options->full_evaluation);
   return AMWG_OK;
@@ -1172,6 +1184,24 @@ int amwg_create(const amwg_model_desc *m, const amwg_param_desc *params, int32_t
   mc.lunif_cp = log_v8(1 / (mc.cp_upper - 0.0));
   mc.exact_division = options->exact_division ? 1 : 0;
   mc.group_local = 0;
+  mc.sufficient = 0;
+  mc.suff_xbar_hi = mc.suff_xbar_lo = mc.suff_ss = 0.0;
+  if (options->sufficient_statistics) {
+    // amwg_options::sufficient_statistics: the two sufficient statistics of the Normal likelihood, in quad precision -- xbar as a double-double (its error must stay
+    // far below an ulp of xbar - mu when mu sits next to the data: 2^-106 |xbar|), SS = sum (x_i - xbar)^2 rounded once
+    if (m->model != AMWG_MODEL_NORMAL) return bail(fail(AMWG_EINVAL, "sufficient_statistics: only the Normal family has a pass-free certified value"));
+    if (options->lanes_per_chain > 1) return bail(fail(AMWG_EINVAL, "sufficient_statistics decides from the one-lane certified kernel: lanes_per_chain must be 0 or 1"));
+    __float128 sum = 0;
+    for (int i = 0; i < N; ++i) sum += (__float128)m->x[i];
+    const __float128 xbar = N > 0 ? sum / (__float128)N : (__float128)0;
+    __float128 ss = 0;
+    for (int i = 0; i < N; ++i) { const __float128 t = (__float128)m->x[i] - xbar; ss += t * t; }
+    mc.suff_xbar_hi = (double)xbar;
+    mc.suff_xbar_lo = (double)(xbar - (__float128)mc.suff_xbar_hi);
+    mc.suff_ss = (double)ss;
+    mc.sufficient = 1;
+    s->opt.lanes_per_chain = 1;
+  }
   GlLayoutHost gl;
   if (options->group_local) {
     // group-local evaluation (include/amwg.h, amwg_options::group_local; amwg_gl.h): the hierarchical family with a chain on one whole
@@ -1314,6 +1344,7 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
     int rc = check_options(options, max_threads);
     if (rc != AMWG_OK) return rc;
   }
+  if (options->sufficient_statistics) return fail(AMWG_EINVAL, "sufficient_statistics: only the built-in Normal family has a pass-free certified value (translated closures: the certified tail's pass)");
   amwg_sampler *s = new amwg_sampler();
   s->opt = *options;
   s->model = 0;

@@ -79,10 +79,15 @@ struct NormalModel {
   struct Pass { double mu, c, den; Reciprocal y; bool fast; const double *x; };
   // one lane per chain: the EXPRESSION's pass reads the observations through the scalar cache (norm_pass_uniform); the certified pass (norm_sq_pass_wave) reads
   // a tile in LDS when the data fits beside the stepper state of a full workgroup (else the array in global memory)
+  // (only that pass reads the one-lane tile: the host asks for it -- DataRef::pad = 1 -- when the launch is of the certified kernel in workgroups of at most 256 threads;
+  // the expression-in-every-update kernels, exact_division and the larger classes neither stage nor reserve it -- round-5 advisor finding)
   static constexpr size_t kOneLaneTileLimit = 96 * 1024;
-  __host__ __device__ static size_t lds_bytes(int n_obs, int, int lanes) { return lanes == 1 ? ((size_t)n_obs * 8 <= kOneLaneTileLimit ? (size_t)n_obs * 8 : 0) : (size_t)n_obs * 8; }
+  __host__ __device__ static size_t one_lane_tile_bytes(int n_obs) { return (size_t)n_obs * 8 <= kOneLaneTileLimit ? (size_t)n_obs * 8 : 0; }
+  __host__ __device__ static size_t lds_bytes(int n_obs, int, int lanes) { return lanes == 1 ? 0 : (size_t)n_obs * 8; }
+  static constexpr bool kDynamicLds = true;
+  __host__ __device__ static size_t lds_bytes_of(const DataRef &d, int lanes, int) { return lanes == 1 ? (d.pad > 0 ? one_lane_tile_bytes(d.n_obs) : 0) : (size_t)d.n_obs * 8; }
   __device__ static void stage(unsigned char *smem, const DataRef &d, int tid, int nt, int lanes) {
-    if (lanes == 1 && lds_bytes(d.n_obs, 0, 1) == 0) return;
+    if (lanes == 1 && lds_bytes_of(d, 1, nt) == 0) return;
     double *dst = reinterpret_cast<double *>(smem);
     for (int i = tid; i < d.n_obs; i += nt) dst[i] = d.x[i];
   }
@@ -167,7 +172,14 @@ struct NormalModel {
     // (every lane of the wavefront takes part: the caller has made sure of that.  The wavefront's pass keeps 64 partial sums per lane: workgroups of up to 256
     // threads, whose lanes have 512 registers; the larger classes read the observations one at a time through the scalar path)
     double S2;
-    if constexpr (BT <= 256) S2 = norm_sq_pass_wave<8>(lds_bytes(d.n_obs, 0, 1) ? reinterpret_cast<const double *>(smem) : d.x, kc.mu, d.n_obs);
+    if (mc.sufficient) {
+      // amwg_options::sufficient_statistics (opt-in, a third tier): S2 = SS + n (xbar - mu)^2 from the two sufficient statistics of the data, no pass.  As a real number
+      // this is sum (x_i - mu)^2; the expression squares the ROUNDED differences RN(x_i - mu), which moves its real-number target by at most 2 u S2; the three
+      // operations here add 3 u S2 and the host's quad-precision xbar and SS 2^-100: inside the (n / 8 + 9) u mag the derivation above grants this side
+      const double dm = (mc.suff_xbar_hi - kc.mu) + mc.suff_xbar_lo;
+      S2 = __builtin_fma((double)d.n_obs, dm * dm, mc.suff_ss);
+    } else
+    if constexpr (BT <= 256) S2 = norm_sq_pass_wave<kWaveBlock>(lds_bytes_of(d, 1, 0) ? reinterpret_cast<const double *>(smem) : d.x, kc.mu, d.n_obs);
     else S2 = norm_sq_pass_uniform<8>(d.x, kc.mu, d.n_obs);
     const double n = (double)d.n_obs;
     const double Q = S2 * kc.n.y.hi, nc = n * kc.n.c;

@@ -177,6 +177,7 @@ static int parse_common(napi_env env, napi_value *a /* [1]=params [2]=init [3]=c
   op->group_local = (int32_t)prop_i64(env, a[4], "group_local", 0);
   op->full_evaluation = (int32_t)prop_i64(env, a[4], "full_evaluation", 0);
   op->test_bound_shift = (int32_t)prop_i64(env, a[4], "test_bound_shift", 0);
+  op->sufficient_statistics = (int32_t)prop_i64(env, a[4], "sufficient_statistics", 0);
   *pd_out = pd; *co_out = co; *n_params_out = n_params; *init_out = init;
   return 1;
 }

@@ -358,6 +358,11 @@ AMWG_HD double norm_sq_pass_uniform(const double *x_global, double mean, int n_o
 // DPP: 63 exchange-and-add steps) leaves chain c's total in lane c.  Same count of fp64 operations, no load on the critical path.  The order of the
 // additions is whatever this schedule gives: the value is used with its rounding bound only (NormalModel::log_post_approx).
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)      // (device code only; the host builds of these headers -- tests/host -- never call it)
+#ifndef AMWG_WAVE_BLOCK
+#define AMWG_WAVE_BLOCK 16
+#endif
+constexpr int kWaveBlock = AMWG_WAVE_BLOCK;      // observations per lane and block of the wavefront's pass (tools/build_variant.sh -DAMWG_WAVE_BLOCK=8: round 5's)
+template <int N> struct PassBlock { static constexpr int value = N; };
 template <int B>
 __device__ __forceinline__ double norm_sq_pass_wave(const double *x, double mu, int n_obs) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -367,24 +372,35 @@ __device__ __forceinline__ double norm_sq_pass_wave(const double *x, double mu, 
   for (int c = 0; c < 64; ++c) a[c] = 0.0;
   const int mu_lo = (int)(uint32_t)f64_bits(mu), mu_hi = (int)(uint32_t)(f64_bits(mu) >> 32);
   auto mean_of = [&](int c) { return bits_f64(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mu_hi, c) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mu_lo, c)); };
-  int base = 0;
-  for (; base + 64 * B <= n_obs; base += 64 * B) {
-    double xv[B];
+  // a block of BB observations per lane against all 64 means: the means travel eight at a time into scalar registers (16 v_readlane per 8 BB subtract-fma pairs, so
+  // the longer the block the smaller their share: 2 + 2 / BB vector instructions per observation and chain -- 2.25 at eight, 2.06 at 32), the eight running sums interleave
+  auto block = [&](auto tag, int at) {
+    constexpr int BB = decltype(tag)::value;
+    double xv[BB];
 #pragma unroll
-    for (int b = 0; b < B; ++b) xv[b] = x[base + b * 64 + lane];
+    for (int b = 0; b < BB; ++b) xv[b] = x[at + b * 64 + lane];
 #pragma unroll
-    for (int g = 0; g < 64; g += 8) {      // eight chains' means in scalar registers, then this lane's B observations against each: the eight running sums interleave
+    for (int g = 0; g < 64; g += 8) {
       double m[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) m[j] = mean_of(g + j);
 #pragma unroll
-      for (int b = 0; b < B; ++b) {
+      for (int b = 0; b < BB; ++b) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const double t = xv[b] - m[j]; a[g + j] = __builtin_fma(t, t, a[g + j]); }
       }
     }
-  }
-  for (; base < n_obs; base += 64) {       // the rest, 64 observations a round; the last round masked
+  };
+  int base = 0;
+  for (; base + 64 * B <= n_obs; base += 64 * B) block(PassBlock<B>{}, base);
+  // the rest in blocks of half the length each (round 5 walked it 64 observations at a time: a quarter of a block's arithmetic for all of its broadcasts), the last round masked
+  if constexpr (B >= 32) { if (base + 64 * 16 <= n_obs) { block(PassBlock<16>{}, base); base += 64 * 16; } }
+  if constexpr (B >= 16) { if (base + 64 * 8 <= n_obs) { block(PassBlock<8>{}, base); base += 64 * 8; } }
+  if constexpr (B >= 8) { if (base + 64 * 4 <= n_obs) { block(PassBlock<4>{}, base); base += 64 * 4; } }
+  if constexpr (B >= 4) { if (base + 64 * 2 <= n_obs) { block(PassBlock<2>{}, base); base += 64 * 2; } }
+  if constexpr (B >= 2) { if (base + 64 <= n_obs) { block(PassBlock<1>{}, base); base += 64; } }
+  for (; base + 64 <= n_obs; base += 64) block(PassBlock<1>{}, base);
+  if (base < n_obs) {
     const int i = base + lane;
     const bool has = i < n_obs;
     const double xv = x[has ? i : base];

@@ -67,6 +67,9 @@ struct ModelConsts {
   // POIS_GLM, for the bounds of the certified pass (amwg_models.h PoisGlmModel::log_post_approx): max_i |X[i][k]| per column, sum of the counts, sum of
   // lfactorial(y_i) (+inf if some count is negative: such data always takes the expression)
   double glm_xmax[7], glm_sum_y, glm_sum_lf;
+  // NORMAL, amwg_options::sufficient_statistics: sum (x_i - mu)^2 = suff_ss + n (xbar - mu)^2, xbar = suff_xbar_hi + suff_xbar_lo (formed on the host in quad precision)
+  double suff_xbar_hi, suff_xbar_lo, suff_ss;
+  int32_t sufficient;
   int32_t group_lane_const;         // HIER: g[i] == g[i % lanes] for every i -- each lane of a chain only ever meets ONE group (balanced
                                     // round-robin designs such as g_i = i mod 32 with 64 lanes): its mean is read once per evaluation
 };

@@ -266,7 +266,8 @@ function AmwgSampler(params, log_post, data, options) {
     const handle = (user ? N.createUser : N.create)(user || desc, descs, Float64Array.from(init), compOpts, {
       chains: count, seed: this.seed, chain_offset: opt('chain_offset', 0) + offset, device: devices[r],
       lanes_per_chain: lanes, block_threads: opt('block_threads', 0),
-      steps_per_launch: opt('steps_per_launch', 0), exact_division: opt('exact_division', 0), group_local: opt('group_local', 0) ? 1 : 0, full_evaluation: Number(opt('full_evaluation', 0)) | 0, test_bound_shift: Number(opt('test_bound_shift', 0)) | 0 });
+      steps_per_launch: opt('steps_per_launch', 0), exact_division: opt('exact_division', 0), group_local: opt('group_local', 0) ? 1 : 0, full_evaluation: Number(opt('full_evaluation', 0)) | 0, test_bound_shift: Number(opt('test_bound_shift', 0)) | 0,
+      sufficient_statistics: opt('sufficient_statistics', 0) ? 1 : 0 });
     this._shards.push({ handle, offset, count, device: devices[r] });
     // one summation order for the whole job: what the first shard picked (cost model, or the measurement of lanes_per_chain: -2)
     // is what the other shards get -- a chain's draws must not depend on the shard it landed in

@@ -141,6 +141,13 @@ typedef struct {
   int32_t test_bound_shift; /* TEST HOOK, 0 in production: the rounding bounds of the certified decisions (csrc/amwg_kernel.h: accept tests decided from a cheaper value
                                of log_post, from the local differences of a sweep) are multiplied by 2^shift, 0..40.  A wider bound sends more
                                updates down the path that evaluates the reference's expression; the results must not change by a bit (tests run 0 against 14 and 40) */
+  int32_t sufficient_statistics; /* OPT-IN, 0 by default; the Normal family at one lane per chain only (AMWG_EINVAL elsewhere).  A THIRD TIER next to full_evaluation = 1
+                               (the expression in every update, 8 operations per observation) and the default (the certified pass, 2 per observation): the cheaper
+                               value of log_post the accept test is decided from (csrc/amwg_kernel.h "certified decisions") needs NO pass over the data for this
+                               likelihood -- sum (x_i - mu)^2 = SS + n (xbar - mu)^2, with xbar (a double-double) and SS formed once on the host in quad precision --, so
+                               an update costs the stepper alone, whatever n is.  Same bound, same fallback to the reference's expression, hence the same draws bit for
+                               bit (tests/test_gpu_parity.py; tools/bound_audit.py audits it); what changes is that mcmc.js:524-526's pass over the observations is
+                               made only where a uniform falls inside the bound.  Reported separately by bench.py, never as the headline */
 } amwg_options;
 
 typedef struct amwg_sampler amwg_sampler;

@@ -62,9 +62,9 @@ def hist_summary(h):
     return out
 
 
-def normal_case(name, x, chains, steps, state=None, hyper=None, seed=11):
+def normal_case(name, x, chains, steps, state=None, hyper=None, seed=11, suff=0):
     spec = model_spec.build_spec("normal", {"x": np.asarray(x, dtype=np.float64)}, hyper=hyper)
-    return dict(name=name, spec=spec, chains=chains, steps=steps, lanes=1, state=state, seed=seed)
+    return dict(name=name, spec=spec, chains=chains, steps=steps, lanes=1, state=state, seed=seed, suff=suff)
 
 
 def hier_case(name, y, g, G, chains, steps, state=None, hyper=None, seed=12):
@@ -103,6 +103,15 @@ def cases(quick):
     out.append(normal_case("normal_tiny_data", 1e-250 * (1.0 + rng.random(1000)), small, 200))
     out.append(normal_case("normal_tight_prior", x1k, small, 300, hyper=[0, 1e-3, 0, 100]))                    # |prior| dominates mag
     out.append(normal_case("normal_constant_data", np.full(513, 7.25), small, 300))                             # S2 = 0 at mu = 7.25
+    # ... and the opt-in third tier (amwg_options::sufficient_statistics: S2 = SS + n (xbar - mu)^2, no pass): the same bound on the same inputs
+    out.append(normal_case("suffstat_n1000", x1k, small, 300, suff=1))
+    out.append(normal_case("suffstat_n1", 3.0 + 2.0 * rng.standard_normal(1), small, 300, suff=1))
+    out.append(normal_case("suffstat_n65", 3.0 + 2.0 * rng.standard_normal(65), small, 300, suff=1))
+    out.append(normal_case("suffstat_x1e8_start_far", xfar, small, 300, suff=1))
+    out.append(normal_case("suffstat_x1e8_start_near", xfar, small, 300, state=[1e8, 1.0], suff=1))           # xbar - mu: the double-double matters here
+    out.append(normal_case("suffstat_sigma_1e-6", x1k, small, 200, state=[3.0, 1e-6], suff=1))
+    out.append(normal_case("suffstat_constant_data", np.full(513, 7.25), small, 300, suff=1))                   # SS = 0
+    out.append(normal_case("suffstat_tiny_data", 1e-250 * (1.0 + rng.random(1000)), small, 200, suff=1))
     # ---- hierarchical family, the sweep kernel (HierNormalModel::sweep_approx / log_post_approx / value_bound / difference_bound)
     hs = 64 if quick else 512
     d = model_spec.make_data("hier_normal", 640, 20260925, G=8)
@@ -144,6 +153,7 @@ def cases(quick):
     if not quick:
         # ---- BASELINE configs at full size
         out.append(normal_case("cfg2_full", model_spec.make_data("normal", 10000, 20260925)["x"], 65536, 150, seed=20260925))
+        out.append(normal_case("cfg2_full_suffstat", model_spec.make_data("normal", 10000, 20260925)["x"], 65536, 150, seed=20260925, suff=1))
         d4 = model_spec.make_data("hier_normal", 10000, 20260925, G=32)
         out.append(hier_case("cfg4_full", d4["x"], d4["g"], 32, 2048, 60, seed=20260925))
         d5 = model_spec.make_data("pois_glm", 50000, 20260925)
@@ -152,7 +162,8 @@ def cases(quick):
 
 
 def run_case(c, shift=0, full_evaluation=0):
-    s = A.Sampler(c["spec"], chains=c["chains"], seed=c["seed"], lanes_per_chain=c["lanes"], test_bound_shift=shift, full_evaluation=full_evaluation)
+    s = A.Sampler(c["spec"], chains=c["chains"], seed=c["seed"], lanes_per_chain=c["lanes"], test_bound_shift=shift, full_evaluation=full_evaluation,
+                  sufficient_statistics=(c.get("suff", 0) if full_evaluation == 0 else 0))
     try:
         kernel = s.launch_info()["kernel"]
         if c["state"] is not None:

@@ -42,13 +42,17 @@ DEFAULT_GATE = ["NormalModel,1,256,cert", "NormalModel,1,256", "HierNormalModel,
 # (the stepper, the window stream, the sweep's all-at-once decisions and the walk update by update) ~36 loop-invariant words.  No kernel may have a scratch
 # instruction inside a PASS -- an innermost loop with 40 or more fp64 instructions (checked for every gated kernel below).  (Until the certified paths became kernels
 # of their own -- amwg_*_kernel_cert -- both carried the lane-order expression as well: 25 and 49 spilled registers.)
-SPILL_ALLOW = {"PoisGlmModel,16,256,cert": {"vgpr_spill": 8, "loop_scratch": 8},
+# (round 6: the Normal family's certified kernel -- 64 partial sums + a block of 16 observations per lane -- parks 6 registers in accumulation registers: vgpr_spill_count
+# 6 with a private segment of 0 bytes, i.e. no scratch memory; allowed as long as no scratch instruction appears)
+SPILL_ALLOW = {"NormalModel,1,256,cert": {"vgpr_spill": 8, "loop_scratch": 0},
+               "PoisGlmModel,16,256,cert": {"vgpr_spill": 8, "loop_scratch": 8},
                "HierNormalModel,sweep,512,cert": {"vgpr_spill": 40, "loop_scratch": 56}}
 
 
 # v_readlane / v_writelane that are NOT spilled scalars: the certified pass of the Normal family broadcasts the 64 chains' means with 2 x 64 v_readlane per block of
-# observations and per tail round (csrc/amwg_models.h norm_sq_pass_wave), 256 + 128 static
-LANE_MOVE_LIMITS = {"NormalModel,1,256,cert": 1000}
+# observations (csrc/amwg_pass.h norm_sq_pass_wave); since round 6 the rest of a pass is walked in blocks of half the length each -- 16, 8, 4, 2, 1 rounds, a loop of
+# single rounds and the masked last one: seven static copies of the 128 broadcasts
+LANE_MOVE_LIMITS = {"NormalModel,1,256,cert": 1500}
 
 
 def compile_asm(family):
