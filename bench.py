@@ -211,6 +211,34 @@ def measured_traffic(chains, steps_per_launch, workload="cfg2", lanes=None, grou
     return None, None, None, stale or "no profile of this workload / geometry under profiles/"
 
 
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.0      # wave64 vector instructions per second: 1024 SIMDs, 16 lanes per clock each (MI355X_MICROARCH.md) -- the same rate as the fp64 peak, counted in instructions
+
+
+def profiled_valu_per_update(workload, kernel, kernel_id):
+    """Vector instructions one parameter update costs a wavefront's LANE in the kernel `kernel`, from the committed rocprofv3 PMC pass of the same kernel sources
+    (profiles/r*_<workload>_summary.json: SQ_INSTS_VALU per launch / the launch's updates).  What a PASS-FREE update is priced with (cfg3's exact fast-forward: the
+    stepper -- Philox, Leva's rnorm, two logarithms, the bisection over the binades -- is all there is): achieved = value x this, against the chip's vector issue rate.
+    -> (wave64 instructions per 64 updates, file, why-not)"""
+    import glob
+    stale = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), key=os.path.getmtime, reverse=True):
+        try:
+            p = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if p.get("workload") != workload or kernel_base_name(p.get("kernel", "")) != kernel_base_name(kernel):
+            continue
+        v = ((p.get("pmc_per_launch") or {}).get("SQ_INSTS_VALU") or {}).get("mean")
+        upd = (p.get("chains") or 0) * (p.get("steps_per_launch") or 0) * (p.get("components") or 1)
+        if not v or not upd:
+            continue
+        if kernel_id is not None and p.get("kernel_id") != kernel_id:
+            stale = stale or "%s is of kernels %s, this library is kernels %s: refused" % (os.path.relpath(f, ROOT), p.get("kernel_id"), kernel_id)
+            continue
+        return v / (upd / 64.0), os.path.relpath(f, ROOT), None
+    return None, None, stale or "no profile of this kernel under profiles/"
+
+
 def end_to_end_js(chains, n_obs):
     """SURVEY.md section 8(d) asks for kernel-only AND end-to-end: the same job through the JavaScript host (bench/js_e2e.js: require, constructor incl.
     translation + hiprtc or the on-disk code-object cache, burn(1000), sample(1000) INCLUDING the copy of every draw to the host and into the
@@ -233,6 +261,12 @@ def end_to_end_js(chains, n_obs):
            "updates_per_s": m["updates_per_s"], "updates_per_s_excl_constructor": m["updates_per_s_excl_ctor"], "unit": "param-updates/s",
            "ctor_ms": m["ctor_ms"], "burn_ms": m["burn_ms"], "sample_ms_incl_copy_out": m["sample_ms"], "total_ms": m["total_ms"], "gb_copied": m["gb_copied"],
            "lanes_per_chain": (m.get("launch") or [{}])[0].get("lanes_per_chain"), "node": r["node"], "require_ms": r["require_ms"], "code_cache": r.get("code_cache")}
+    t = r.get("many_chains_translated")
+    if t:      # the same job with a closure the family recogniser does not know: translated + hiprtc; certified decisions from the translator (round 6)
+        out["translated_many_chains"] = {"what": "the README model with its priors swapped (translate.js -> hiprtc), same data, chains and schedule",
+                                         "kernel": ((t.get("launch") or [{}])[0]).get("kernel"), "updates_per_s_excl_constructor": t["updates_per_s_excl_ctor"],
+                                         "ctor_ms": t["ctor_ms"], "burn_ms": t["burn_ms"], "sample_ms_incl_copy_out": t["sample_ms"],
+                                         "kernel_only_updates_per_s": (2.0 * t["chains"] * t["sample"] / (((t.get("launch") or [{}])[0]).get("kernel_ms", 0.0) * 1e-3)) if ((t.get("launch") or [{}])[0]).get("kernel_ms") else None}
     # a closure that has to be translated and compiled: a process with an empty code-object cache, then a second process that finds it on disk
     try:
         import tempfile
@@ -440,6 +474,28 @@ def timed_geometry_parity(A, spec, workload, chains, make_sampler, lanes):
     return report, first
 
 
+def measure_sufficient_statistics(A, spec, chains, device):
+    """cfg2 with options.sufficient_statistics = 1 (opt-in; include/amwg.h): the cheaper value of log_post the accept test is decided from comes from the data's two
+    sufficient statistics -- sum (x - mu)^2 = SS + n (xbar - mu)^2 -- instead of a pass, with the same bound and the same fallback to the reference's expression: the
+    same draws bit for bit (tests/test_gpu_parity.py), no O(n) work per update.  Reported here, NEVER as `value`: the headline's kernel passes over all observations in
+    every update.  HIP events around adapted burn launches, as for the other configs; the first chain's draws are compared with the default sampler's."""
+    mk = lambda suff: A.Sampler(spec, chains=chains, seed=SEED, device=device, steps_per_launch=100, sufficient_statistics=suff)
+    a, b = mk(1), mk(0)
+    same = True
+    for q in (a, b):
+        q.burn(150)
+    da, db = a.sample(40, 1), b.sample(40, 1)
+    same = da[:, :, :64].tobytes() == db[:, :, :64].tobytes() and a.state().tobytes() == b.state().tobytes()
+    b.close()
+    a.burn(800)
+    a.burn(500)
+    li = a.launch_info()
+    value = chains * 500 * spec["P"] / (li["kernel_ms"] * 1e-3)
+    a.close()
+    return {"value": value, "unit": "param-updates/s", "kernel": li["kernel"], "opt_in": "options.sufficient_statistics = 1", "draws_equal_the_default_samplers": bool(same),
+            "note": "the certified value from SS + n (xbar - mu)^2: no pass over the data; what is left is the stepper (Philox, rnorm, exp, accept, adaptation)"}
+
+
 def measure_other_config(A, name, device, group_local=0):
     """A short driver-visible measurement of one of the other BASELINE.json configs at its per-GPU size: golden check out of the full-size
     sampler, then HIP-event time of adapted launches.  -> dict for the bench line's `other_configs`."""
@@ -471,9 +527,22 @@ def measure_other_config(A, name, device, group_local=0):
         t.burn(20)
         roof_updates_per_s = chains * 20 * P / (t.launch_info()["kernel_ms"] * 1e-3)
         t.close()
-        kernel += " term-by-term pass (exact_division = 1)"
-        note = ("roofline = the term-by-term pass (1 fp64 add per observation), %.3g param-updates/s; `value` is the exact fast-forward of the same two-valued "
-                "sum (bit-identical), which does not stream the data" % roof_updates_per_s)
+        # `value` and `frac` describe the SAME kernel (round-5 review, item 5): the default's update is pass-free -- the exact fast-forward of the two-valued sum
+        # (csrc/amwg_twoval.h) -- so what bounds it is vector ISSUE: the stepper's instructions per update (from the committed PMC profile of these kernel sources)
+        # x the measured update rate, against the chip's issue rate.  The term-by-term pass (exact_division = 1) is reported beside it.
+        out["term_by_term_value"] = roof_updates_per_s
+        out["term_by_term_frac"] = roof_updates_per_s * n_obs * ops_per_obs / FP64_VALU_PEAK
+        kernel = li.get("kernel") or kernel
+        vpu, vfile, why = profiled_valu_per_update("cfg3", kernel, kernel_id_of(A.lib().amwg_version().decode()))
+        out["roofline"] = {"bound": "valu_issue", "achieved": (value / 64.0) * vpu if vpu else None, "peak": VALU_ISSUE_PEAK, "unit": "wave64 vector instructions/s",
+                           "frac": ((value / 64.0) * vpu / VALU_ISSUE_PEAK) if vpu else None, "kernel": kernel, "valu_per_64_updates": vpu, "profile": vfile, "profile_refused": why,
+                           "note": "pass-free update (exact fast-forward over ~log2 N binades): Philox + Leva's rnorm + two logarithms + the bisection; the roof is vector issue, "
+                                   "priced with the instructions per update of the committed rocprofv3 PMC pass of the same kernel sources.  Term by term (exact_division = 1, one fp64 "
+                                   "add per observation): %.3g param-updates/s, %.2f of the fp64 rate" % (roof_updates_per_s, out["term_by_term_frac"]),
+                           "effective_hbm_gbps": value * b_alg / 1e9}
+        out["seconds"] = time.perf_counter() - t0
+        s.close()
+        return out
     sweep_kernel = False
     if name == "cfg4" and not group_local:
         # by default only the lanes whose sum an update can have changed are re-formed (csrc/amwg_models.h lane_sum_rows: bit-identical to evaluating
@@ -689,10 +758,13 @@ def compact_line(out, detail_path=None):
             line[k] = _num(out[k])
     if isinstance(out.get("full_evaluation"), dict):      # the kernel that evaluates the reference's expression in every update, beside the default
         line["full_evaluation"] = _pick(out["full_evaluation"], "value", "frac")
+    if isinstance(out.get("term_by_term"), dict):         # cfg3: the term-by-term pass beside the fast-forward
+        line["term_by_term"] = _pick(out["term_by_term"], "value", "frac")
     r = out.get("roofline")
     if r:
         line["roofline"] = _pick(r, "bound", "achieved", "peak", "unit", "frac", "frac_of_measured_peak", "kernel", "launch_ms", "traffic", "traffic_ratio")
         line["roofline"].setdefault("traffic", None)
+        line["roofline"].setdefault("frac", None)
         if r.get("traffic") is None and r.get("traffic_refused"):
             line["roofline"]["traffic_refused"] = str(r["traffic_refused"])[:120]
         if r.get("effective_hbm"):
@@ -717,7 +789,7 @@ def compact_line(out, detail_path=None):
             if "error" in o:
                 line["other_configs"][name] = {"error": str(o["error"])[:100]}
                 continue
-            q = _pick(o, "value", "chains", "lanes_per_chain", "reference_order_value", "full_evaluation_value")
+            q = _pick(o, "value", "chains", "lanes_per_chain", "reference_order_value", "full_evaluation_value", "term_by_term_value", "term_by_term_frac")
             rr = o.get("roofline") or {}
             q.update(_pick(rr, "frac"))
             if rr.get("kernel"):
@@ -727,9 +799,15 @@ def compact_line(out, detail_path=None):
             if pp.get("summation_order") is not None:
                 q["summation_order"] = pp["summation_order"]      # (1: the reference's own order -- draws, final state and log_post are among the *_identical above)
             line["other_configs"][name] = q
+    ss = out.get("sufficient_statistics")
+    if isinstance(ss, dict):
+        line["sufficient_statistics"] = _pick(ss, "value", "opt_in", "draws_equal_the_default_samplers", "error")
     e = out.get("end_to_end_js")
     if isinstance(e, dict) and "updates_per_s" in e:
-        line["end_to_end_js"] = _pick(e, "updates_per_s", "total_ms")
+        line["end_to_end_js"] = _pick(e, "updates_per_s", "total_ms", "updates_per_s_excl_constructor", "ctor_ms", "sample_ms_incl_copy_out")
+        tm = e.get("translated_many_chains")
+        if tm:
+            line["end_to_end_js"]["translated"] = _pick(tm, "kernel", "updates_per_s_excl_constructor", "kernel_only_updates_per_s")
         sc = (e.get("single_chain") or {}).get("again")
         if sc:
             line["end_to_end_js"]["single_chain_warm_ms"] = _num(sc.get("total_ms"))
@@ -816,8 +894,9 @@ def main():
             sys.stderr.write("bench.py: --gpus %d without torch.distributed.run (WORLD_SIZE unset): the one-process multi-device path (--inproc)\n" % args.gpus)
             return main_inproc(args)
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
-    if not torch.cuda.is_available():
+    if not torch.cuda.is_available() and world == 1:
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # (N ranks started by the launcher on a box with fewer than N devices -- none included: the "not measured" line below, rc 0, like the launcher-less call)
     # Development switches (not used by the driver): AMWG_BENCH_BACKEND=gloo + AMWG_BENCH_ONE_DEVICE=1 run the
     # N-rank code path on a box with a single GPU (ranks share cuda:0, gather goes through host memory).
     backend = os.environ.get("AMWG_BENCH_BACKEND", "nccl")
@@ -987,17 +1066,16 @@ def main():
         bt_class = 256 if li["block_threads"] <= 256 else (512 if li["block_threads"] <= 512 else 1024)
         kernel = li.get("kernel") or "amwg_step_kernel<%s,%d,%d>" % (kname, li["lanes_per_chain"], bt_class)      # (amwg_kernel_name: what a profiler lists)
         roof_launch_s, roof_updates, roof_note, full_eval = launch_s, updates_per_launch, None, None
-        if args.workload == "cfg3":
-            # the headline value uses the exact fast-forward of the two-valued sum, which does not stream the data at all; the
-            # roofline figure is the TERM-BY-TERM pass (exact_division = 1: one fp64 add per observation), measured on the side
+        term_by_term = None
+        if args.workload == "cfg3" and not args.single_region:      # (profiling runs keep to ONE kind of launch)
+            # beside the default (the exact fast-forward of the two-valued sum: pass-free, priced against vector issue below): the TERM-BY-TERM pass
+            # (exact_division = 1: one fp64 add per observation)
             t = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=dev_index, lanes_per_chain=1, steps_per_launch=20, exact_division=1)
             t.burn(40)
             t.burn(20)
-            roof_launch_s, roof_updates = t.launch_info()["kernel_ms"] * 1e-3, chains * 20 * P
-            kernel = "amwg_step_kernel<BetaBernModel,1> term-by-term pass (exact_division = 1)"
-            roof_note = ("roofline = the term-by-term pass (scalar jump-table kernel, 1 fp64 add per observation), %.3g param-updates/s; `value` is the exact "
-                         "fast-forward of the same sum (bit-identical, ~log2(N) binade steps instead of N additions), which has no meaningful roofline"
-                         % (roof_updates / roof_launch_s))
+            tv = chains * 20 * P / (t.launch_info()["kernel_ms"] * 1e-3)
+            term_by_term = {"value": tv, "frac": tv * n_obs * ops_per_obs / FP64_VALU_PEAK, "kernel": t.launch_info()["kernel"],
+                            "note": "options.exact_division = 1: the scalar jump-table pass, one fp64 add per observation (bit-identical to the fast-forward)"}
             t.close()
         if args.workload == "cfg4" and not args.group_local and not args.full_evaluation and not args.single_region:      # (profiling runs -- --single-region -- keep to ONE kernel)
             t = A.Sampler(spec, chains=chains, seed=SEED, chain_offset=offset, device=dev_index, lanes_per_chain=args.lanes, block_threads=args.block, steps_per_launch=args.steps_per_launch, full_evaluation=1)
@@ -1072,6 +1150,17 @@ def main():
             "posterior": {"mean": mean.tolist()[:8], "sd": sd.tolist()[:8], "data_mean": float(np.mean(x)), "data_sd": float(np.std(x, ddof=1)),
                           "note": "moments over the recorded draws of the last region on ALL ranks (all-reduce of per-rank sums for N > 1; after %d warm-up + %d timed steps)" % (W, K * (len(regions) - 1))},
         }
+        if args.workload == "cfg3":
+            # `value` and `frac` describe the SAME kernel (round-5 review, item 5): a pass-free update is bound by vector ISSUE -- the stepper's instructions per update
+            # (committed rocprofv3 PMC pass of these kernel sources) x the measured update rate, against 1024 SIMDs x 2.4 GHz / 4 wave64 instructions per second
+            vpu, vfile, why = profiled_valu_per_update("cfg3", kernel, kernel_id_of(version))
+            rate = updates_per_launch / launch_s
+            out["roofline"].update({"bound": "valu_issue", "achieved": (rate / 64.0) * vpu if vpu else None, "peak": VALU_ISSUE_PEAK, "unit": "wave64 vector instructions/s",
+                                    "frac": ((rate / 64.0) * vpu / VALU_ISSUE_PEAK) if vpu else None, "frac_of_measured_peak": None, "valu_per_64_updates": vpu,
+                                    "valu_profile": vfile, "valu_profile_refused": why, "lane_ops_per_obs": None,
+                                    "lane_ops_note": "pass-free update: the exact fast-forward of the two-valued sum (csrc/amwg_twoval.h, ~log2 N binade steps) -- Philox, Leva's rnorm, two "
+                                                     "logarithms and the bisection are all there is; the roof is vector issue, priced with the PMC pass of the same kernel sources"})
+            out["term_by_term"] = term_by_term
         out["roofline"].update(sweep_roofline_units(lane_ops) if str(kernel).startswith("amwg_sweep_kernel") else
                                roofline_units(spec["model"], lane_ops, ops_per_obs) if not certified else
                                {"frac_issue": lane_ops / FP64_VALU_PEAK, "frac_survey_flops": (roof_updates / roof_launch_s) * n_obs * (3 if ckind == "normal" else 50) / FP64_FLOPS_PEAK,
@@ -1092,6 +1181,10 @@ def main():
                     out["other_configs"][name] = measure_other_config(A, name.split("_")[0], dev_index, group_local=int(name.endswith("group_local")))
                 except Exception as e:      # a failure here must not cost the headline line
                     out["other_configs"][name] = {"error": repr(e)}
+            try:      # the opt-in third tier of the Normal family (amwg_options::sufficient_statistics), beside the headline's pass kernel and full_evaluation
+                out["sufficient_statistics"] = measure_sufficient_statistics(A, spec, chains, dev_index)
+            except Exception as e:
+                out["sufficient_statistics"] = {"error": repr(e)}
             if not args.no_js:
                 out["end_to_end_js"] = end_to_end_js(chains, n_obs)
             o = out["other_configs"]

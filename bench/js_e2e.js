@@ -45,9 +45,21 @@ const log_post = function (state, data) {          // README.md:26-36
   return log_post;
 };
 
-function run(data, chainCount, burn, sample, thinBy) {
+// the same model with its priors written the other way round: NOT recognised as the family, hence translated (translate.js) and compiled (hiprtc) -- since round 6
+// such a closure gets certified decisions from the translator when it ends in the constant-mean normal loop (tailPlan: amwg_user_step_cert)
+const params_swapped = { sigma: { type: 'real', lower: 0 }, mu: { type: 'real' } };
+const log_post_swapped = function (state, data) {
+  var lp = 0;
+  lp += ld.unif(state.sigma, 0, 100);
+  lp += ld.norm(state.mu, 0, 100);
+  for (var i = 0; i < data.length; i++) lp += ld.norm(data[i], state.mu, state.sigma);
+  return lp;
+};
+
+function run(data, chainCount, burn, sample, thinBy, translated) {
   const t0 = now();
-  const s = new mcmc.AmwgSampler(params, log_post, data, { chains: chainCount, seed: 20260925 });
+  const s = translated ? new mcmc.AmwgSampler(params_swapped, log_post_swapped, data, { chains: chainCount, seed: 20260925 })
+                       : new mcmc.AmwgSampler(params, log_post, data, { chains: chainCount, seed: 20260925 });
   const t1 = now();
   s.burn(burn);
   const t2 = now();
@@ -93,6 +105,7 @@ if (opt('translated-only', 0)) {
   process.exit(0);
 }
 out.many_chains = run(makeData(N), chains, nBurn, nSample, thin);
+if (opt('translated-many', 1)) out.many_chains_translated = run(makeData(N), chains, nBurn, nSample, thin, true);
 if (opt('single', 1)) {
   // the reference's own use (README.md:18-43): ONE chain on the ten heights, 1000 + 5000 steps; twice -- the second construction of the
   // same closure + geometry finds the compiled code object (in this process: in memory; in a NEW process: in the on-disk cache)

@@ -106,6 +106,30 @@ def test_gpus_n_without_a_launcher_prints_the_not_measured_line_on_a_box_without
     assert p.stdout.count("\n") == 1 and line["value"] is None and line["n_gpus"] == 2 and line["steps"] == 20 and "not measured" in line["note"]
 
 
+def run_bench_under_the_launcher(tmp_path, n=2, port=29631):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 ... bench.py --gpus n` -- the command the driver runs for its scaling
+    curve -- on a box with fewer than n visible devices: every rank leaves with rc 0 and rank 0 prints ONE line, value null, "not measured".  -> the line"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["AMWG_BENCH_DETAIL"] = str(tmp_path / "d.json")
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-1500:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1500:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_under_torch_distributed_run_on_a_box_without_two_devices_say_not_measured(tmp_path):
+    """Round-5 review, item 7: the launcher-started two-process path must still hold where two devices are not visible (here: none)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    line = run_bench_under_the_launcher(tmp_path)
+    assert line["value"] is None and line["n_gpus"] == 2 and line["steps"] == 5 and "not measured" in line["note"]
+
+
 def test_flip_rate_of_a_campaign_run_with_other_kernels_is_refused(tmp_path, monkeypatch):
     """parity.flip_rate quotes the committed campaign only when it ran the kernels that are being timed (round-4 review: two kept bench lines quoted
     a campaign of earlier kernels); the newest campaign by ROUND NAME is the one looked at."""

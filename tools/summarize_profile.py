@@ -89,7 +89,7 @@ out = {"tag": tag, "workload": workload, "library_version": _ver, "kernel_id": _
        "rocprof_min_launch_ms": step["MinNs"] / 1e6, "rocprof_max_launch_ms": step["MaxNs"] / 1e6,
        "rocprof_note": "full-size launches only (grid %d); the kernel_stats.csv row also averages the one-chain launches of bench.py's parity block" % full_grid,
        "bench_launch_ms": bench["roofline"]["launch_ms"], "steps_per_launch": bench["config"]["steps_per_launch"],
-       "chains": bench["config"]["chains_per_gpu"], "kernel_resources": meta, "pmc_per_launch": pmc,
+       "chains": bench["config"]["chains_per_gpu"], "components": bench["config"].get("components"), "kernel_resources": meta, "pmc_per_launch": pmc,
        "hbm_traffic_bytes_per_launch": traffic,
        "hbm_traffic_formula": "(2*FETCH_SIZE + WRITE_SIZE) KB -> bytes; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE = RDREQ*64B for 128-B requests)",
        "algorithmic_bytes_per_launch": bench["config"]["chains_per_gpu"] * bench["config"]["steps_per_launch"] * bench["config"]["components"] * bench["roofline"]["algorithmic_bytes_per_update"]}
