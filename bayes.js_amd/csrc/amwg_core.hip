@@ -25,7 +25,7 @@
 
 #include "../../include/amwg.h"
 #include "amwg_build_id.h"
-#if defined(AMWG_SELFTEST) || defined(AMWG_AUDIT)
+#if defined(AMWG_SELFTEST) || defined(AMWG_AUDIT) || defined(AMWG_X_PHASES)
 #include "../../include/amwg_selftest.h"
 #endif
 #if defined(AMWG_SELFTEST)
@@ -804,7 +804,7 @@ static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int
   TRYB(dev_alloc(s, &ch.error, (size_t)1));
   ch.audit = nullptr;
   ch.audit_hist = nullptr;
-#if defined(AMWG_AUDIT)      // (libamwg_audit.so: the bound audit's per-chain maxima and histograms, amwg_kernel.h "BOUND AUDIT")
+#if defined(AMWG_AUDIT) || defined(AMWG_X_PHASES)      // (libamwg_audit.so: the bound audit's per-chain maxima and histograms, amwg_kernel.h "BOUND AUDIT"; the phase-clock development build)
   TRYB(dev_alloc(s, &ch.audit, 4 * C));
   TRYB(dev_alloc(s, &ch.audit_hist, (size_t)128));
   HIPB(hipMemset(ch.audit, 0, 4 * C * 8));
@@ -1897,7 +1897,7 @@ int amwg_fp64_peak(int32_t device, double *lane_ops_per_s) {
   return AMWG_OK;
 }
 
-#if defined(AMWG_AUDIT)
+#if defined(AMWG_AUDIT) || defined(AMWG_X_PHASES)
 // include/amwg_selftest.h: what the audited launches of this sampler have recorded so far (and optionally a reset)
 int amwg_audit_fetch(amwg_sampler *s, double *per_chain, uint64_t *hist, int32_t reset) {
   if (!s) return fail(AMWG_EINVAL, "amwg_audit_fetch: null sampler");

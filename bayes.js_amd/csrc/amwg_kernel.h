@@ -740,6 +740,17 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     ++aud_n;
     if ((verdict > 0 && !exact_acc) || (verdict < 0 && exact_acc)) ++aud_bad;
   };
+  // PHASE CLOCK (-DAMWG_X_PHASES, a development build: tools/phase_clock.py): shader-clock cycles per phase of the step loop, summed over the launch's wavefronts into
+  // ChainArrays::audit_hist[64 ..] -- where a latency-bound stepper spends its time, which counters of issued instructions cannot say
+#if defined(AMWG_X_PHASES)
+  uint64_t ph_acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) ph_acc[q] = 0;
+  uint64_t ph_last = __builtin_readcyclecounter();
+#define AMWG_PHASE(i) do { const uint64_t ph_now = __builtin_readcyclecounter(); ph_acc[i] += ph_now - ph_last; ph_last = ph_now; } while (0)
+#else
+#define AMWG_PHASE(i) do { } while (0)
+#endif
   // (set below, once `expression` and the state are usable: audE = E of the state the launch starts from)
   // every store to the state goes through here: the LDS copy (what translated closures, gathers and the final write-back read) and,
   // for models that mirror the state in registers, the mirror
@@ -1027,8 +1038,10 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     }
   } else
   for (int step = 0; step < n_steps; ++step) {
+    AMWG_PHASE(15);
     record_draws(step);
     shuffle_named();
+    AMWG_PHASE(0);
     // ---- every scalar component exactly once; `slot` is uniform across the block
     int np = 0, e = 0, e_top = 0, e_in = 0;   // position inside the current parameter: e = e_top * inner + e_in (no division per slot)
     // Sweep prefetch (models with the lane-local re-evaluation, Model::prefetch_rows): when the walk reaches the vector parameter whose entries are
@@ -1128,10 +1141,12 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
     };
     SlotPre nx{};
     if (P_stepped > 0) nx = prefetch(next_comp());
+    AMWG_PHASE(1);
     for (int slot = 0; slot < P_stepped; ++slot) {
       if constexpr (kSweep) {
         if (sw_pending) {      // (wave-uniform) the first slot of the sweep: draw everything its updates draw, in their order
           sw_pending = false;
+          AMWG_PHASE(14);
 #if defined(__HIP_DEVICE_COMPILE__)
           // Every lane draws the proposal of ITS component (sweep_comp: the one its sum depends on).  Which (u, v) pair of the stream survives rnorm's
           // rejection test (mcmc.js:44-53) is a property of the stream alone: the window stream holds those flags for 256 uniforms, a scalar loop walks
@@ -1154,6 +1169,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
             int ppv = 0, t_begin = 0;
             while (t_begin < top) {
               rng.ensure_b();
+              AMWG_PHASE(13);
               const uint64_t EA = uniform_u64(rng.EA), OA = uniform_u64(rng.OA), EB = uniform_u64(rng.EB) & ~(1ull << 63), OB = uniform_u64(rng.OB);
               uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)p_s);
               int t = __builtin_amdgcn_readfirstlane(t_begin);
@@ -1198,6 +1214,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
               if (t_begin < top) p_s = rng.position();
             }
           }
+          AMWG_PHASE(2);
           const uint64_t sw_inb = (d_len >= 64 ? ~0ull : ((1ull << d_len) - 1ull)) & inb_assume;      // (a proposal outside its bounds is not evaluated)
           // (the sums are prepared for proposals INSIDE their bounds; an entry whose proposal fell outside keeps its value: its lanes' sums are not used)
           const bool inb_mine = ((inb_assume >> cl) & 1ull) != 0ull;
@@ -1212,6 +1229,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
             const int top = d_len;
             if (slot + d_len <= P_stepped && (top & (top - 1)) == 0) {
               const auto sa = Model::sweep_approx(cache, S, a.mc, a.d, data_lds, sub, sw_eval);      // {ok, comp, cur, neu (values), mag, mean_new, s2_new}
+              AMWG_PHASE(3);
               const bool regular = sa.ok && __ballot(sa.comp != (lane64 & (top - 1))) == 0ull;
               if (regular) {
                 double dsum = sa.neu - sa.cur;
@@ -1222,7 +1240,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
                 if (top <= 2) dsum = xor_sum<2>(dsum);
                 const double M = butterfly<1, 64>(sa.mag);
                 const double eta = ((Model::difference_bound(M, a.d) + __builtin_fabs(dsum) * 0x1p-51) * 1.0625 + 0x1p-49) * a.bound_scale;
+                AMWG_PHASE(4);
                 const double ex = exp_v8(dsum);
+                AMWG_PHASE(5);
                 const uint64_t inb_s = uniform_u64(sw_inb);
                 const bool valid = lane64 < top && ((inb_s >> lane64) & 1ull) != 0ull;
                 if constexpr (kAudit) { if (a.audit_adversarial) sw_u = audit_adversarial_u(ex, eta, sw_u, step + lane64); }
@@ -1267,9 +1287,11 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
                     if (inb_l) TOTme[sb + lane64] += 1u + (acc_l ? 0x10000u : 0u);
                     if (adapt[sb + lane64] != 0) adapt_component(sb + lane64, acc_l, CNTme[sb + lane64], cc[sb + lane64].batch_size, live, true);
                   }
+                  AMWG_PHASE(6);
                   e = 0; e_top = 0; e_in = 0; ++np;
                   slot += d_len - 1;
                   if (slot + 1 < P_stepped) nx = prefetch(next_comp());
+                  AMWG_PHASE(7);
                 }
               }
             }
@@ -1378,6 +1400,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         if (slot + 1 < P_stepped) nx = prefetch(next_comp());
         continue;
       }
+      AMWG_PHASE(14);
       // ---- OnedimMetropolisStepper.step (mcmc.js:517-553)
       const double cur = me.cur;
       const bool in_sweep = kSweep && sw_left > 0;      // (this update's proposal and uniform were drawn when the sweep began)
@@ -1394,7 +1417,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
       if (in_sweep) --sw_left;
       // everything this slot draws is drawn: the next slot's component is known (and, if a multidimensional parameter begins there,
       // shuffled), and what the stepper needs of it is requested NOW, under the evaluation below
+      AMWG_PHASE(8);
       if (slot + 1 < P_stepped) nx = prefetch(next_comp());
+      AMWG_PHASE(9);
       bool accepted = false;
       bool certified = false;
       [[maybe_unused]] double aud_E_prop = 0.0;
@@ -1405,6 +1430,7 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
           wave_priority(0);
           const typename Model::Approx r = Model::template log_post_approx<G, BT>(cache, S, a.mc, a.d, data_lds, sub);
           wave_priority(kStepperPriority);
+          AMWG_PHASE(10);
           if (inb) {
             const double dA = r.value - lpA;
             const double eta = ((r.eps + epsA + __builtin_fabs(dA) * 0x1p-51) * 1.0625 + 0x1p-49) * a.bound_scale;
@@ -1464,7 +1490,9 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
         if (counter) (void)__hip_atomic_fetch_add(&TOTme[comp], 1u + (accepted ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // run totals (not in the reference; parity tests compare them with the oracle's)
       }
       if constexpr (kAudit) { if (inb && accepted) audE = aud_E_prop; }      // (BOUND AUDIT: E follows the state)
+      AMWG_PHASE(11);
       if (chain_true<G>(me.adapting)) adapt_component(comp, accepted, me.cnt, me.batch_size, writer);
+      AMWG_PHASE(12);
     }
   }
 
@@ -1478,6 +1506,13 @@ __device__ __forceinline__ void step_body(const StepArgs &a, unsigned char *smem
   if constexpr (!GL && MirrorCheckOf<Model>::value) {
     if (!Model::template mirror_ok<G>(cache, S, a.d, sub)) (void)atomicOr(cold_args()->ch.error, kErrMirrorOutOfSync);
   }
+#if defined(AMWG_X_PHASES)
+  if ((tid & 63) == 0 && live) {
+    unsigned long long *const hh = cold_args()->ch.audit_hist + 64;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) (void)atomicAdd(hh + q, (unsigned long long)ph_acc[q]);
+  }
+#endif
   if constexpr (kAudit) {
     if (writer) {
       double *const au = cold_args()->ch.audit;

@@ -36,7 +36,7 @@ int amwg_two_valued_sum_check(int32_t device, const double *x, int32_t n, int64_
  *   per_chain [4][chains]: max |A - E| / eps,  max |dA - dE| / eta,  audited decisions,  certified verdicts that contradict exp(dE) > u (must be 0)
  *   hist      [2][64]:     counts of the two ratios by binary exponent, bin b >= 1 holding [2^(b-40), 2^(b-39)) -- bins >= 40 are violated bounds; bin 0: exactly equal
  * reset != 0 clears both afterwards.  amwg_options::test_bound_shift may be negative (down to -60) in this build.  Not in the product library. */
-#if defined(AMWG_AUDIT)
+#if defined(AMWG_AUDIT) || defined(AMWG_X_PHASES)
 int amwg_audit_fetch(amwg_sampler *s, double *per_chain, uint64_t *hist, int32_t reset);
 #endif
 

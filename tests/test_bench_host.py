@@ -106,15 +106,16 @@ def test_gpus_n_without_a_launcher_prints_the_not_measured_line_on_a_box_without
     assert p.stdout.count("\n") == 1 and line["value"] is None and line["n_gpus"] == 2 and line["steps"] == 20 and "not measured" in line["note"]
 
 
-def run_bench_under_the_launcher(tmp_path, n=2, port=29631):
+def run_bench_under_the_launcher(tmp_path, n=2, port=29631, extra_env=None, extra_args=()):
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 ... bench.py --gpus n` -- the command the driver runs for its scaling
     curve -- on a box with fewer than n visible devices: every rank leaves with rc 0 and rank 0 prints ONE line, value null, "not measured".  -> the line"""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["AMWG_BENCH_DETAIL"] = str(tmp_path / "d.json")
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env.update(extra_env or {})
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2"], capture_output=True, text=True, env=env, timeout=600)
+                        os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2"] + list(extra_args), capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, (p.stdout[-500:], p.stderr[-1500:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-1500:]

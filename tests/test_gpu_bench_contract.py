@@ -145,3 +145,18 @@ def test_two_ranks_under_the_launcher_on_one_visible_device_say_not_measured(tmp
         assert line["value"] is None and "not measured" in line["note"]
     else:
         assert line["value"] > 0 and line["config"]["rccl_ranks_seen"] == 2
+
+
+def test_two_real_processes_with_their_own_library_handles_share_the_one_gpu(tmp_path):
+    """The N > 1 code path with REAL ranks (round-5 review: the gloo test on the CPU exercises shard offsets with the oracle standing in for the library): two processes
+    started by torch.distributed.run, each with its own libamwg sampler on the one visible device (bench.py's development switches AMWG_BENCH_ONE_DEVICE = 1 +
+    AMWG_BENCH_BACKEND = gloo: RCCL refuses two ranks on one device, so the gather of the recorded draws goes through torch.distributed), contiguous global chain ids,
+    barrier + max-over-ranks timing, rank 0's line.  What it cannot show is xGMI traffic."""
+    from test_bench_host import run_bench_under_the_launcher
+    line = run_bench_under_the_launcher(tmp_path, port=29651, extra_env={"AMWG_BENCH_ONE_DEVICE": "1", "AMWG_BENCH_BACKEND": "gloo"},
+                                        extra_args=["--chains-per-gpu", "2048", "--no-cpu-baseline", "--min-seconds", "0.05"])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["chains_total"] == 4096 and line["scaling"] == "weak"
+    full = json.load(open(str(tmp_path / "d.json")))
+    ranks = full["config"]["ranks"]
+    assert len(ranks) == 2 and [r["chains"] for r in ranks] == [2048, 2048]
+    assert abs(line["value"] - 4096 * 5 * 2 / (line["ms_per_step"] * 5e-3)) < 1e-5 * line["value"]
