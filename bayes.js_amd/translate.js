@@ -1351,11 +1351,20 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
         else this.otherSplitLoops = (this.otherSplitLoops || 0) + 1;
         // CERTIFIED TAIL candidate (csrc/amwg_user.h norm_tail_approx): this loop at the top level of the closure, adding to the closure's one accumulator, f64 observations,
         // mean and sd expressions of the state alone.  run() decides (it must be the LAST statement: tailPlan).
-        const sdT = L.preamble.length === 1 && /^const NormInv (k\d+) = norm_inv\((.+)\);(?: KFASTCHECK\(\1\))?$/.exec(L.preamble[0].trim());
-        const stateOnly = (e) => !/\b(v_\w+|A\d+|t\d+|k\d+|tb_|it_|sub|dq_\w+)\b/.test(e);
+        // (the loop's hoisted preamble: `const double kN = <expression of the state>;` lines -- sub-expressions of sd -- and the NormInv line last; they travel with sd)
+        const nPre = L.preamble.length;
+        const sdT = nPre >= 1 && /^const NormInv (k\d+) = norm_inv\((.+)\);(?: KFASTCHECK\(\1\))?$/.exec(L.preamble[nPre - 1].trim());
+        const stateOnly = (e, okNames) => !(e.match(/\b(v_\w+|A\d+|t\d+|k\d+|tb_\w*|it_\w*|sub|dq_\w+)\b/g) || []).some((w) => !(okNames || []).includes(w));
+        const sdLets = [];
+        let sdOk = !!sdT;
+        for (let q = 0; sdOk && q < nPre - 1; q++) {
+          const m2 = /^const double (k\d+) = (.+);$/.exec(L.preamble[q].trim());
+          if (m2 && stateOnly(m2[2], sdLets.map((z) => z[0]))) sdLets.push([m2[1], m2[2]]); else sdOk = false;
+        }
         const tailCand = !this.isHelper && !this.opts.no_cert_tail && !this.linear && this.acc && loopAcc === this.acc && indent === '    ' && !this.condDepth &&
-                         arr.ctype === 'double' && boundV.cst >= 1 && sdT && sdT[1] === mn[4] && stateOnly(sdT[2]) && stateOnly(mn[3]);
-        if (tailCand) out.push(indent + '//@TAIL x=A' + mn[1] + ' n=' + boundV.cst + ' acc=' + loopAcc + ' mean=' + mn[3] + ' @sd=' + sdT[2]);
+                         arr.ctype === 'double' && boundV.cst >= 1 && sdOk && sdT[1] === mn[4] && stateOnly(sdT[2], sdLets.map((z) => z[0])) && stateOnly(mn[3]);
+        const sdText = tailCand ? (sdLets.length ? '[&] { ' + sdLets.map((z) => 'const double ' + z[0] + ' = ' + z[1] + '; ').join('') + 'return ' + sdT[2] + '; }()' : sdT[2]) : '';
+        if (tailCand) out.push(indent + '//@TAIL x=A' + mn[1] + ' n=' + boundV.cst + ' acc=' + loopAcc + ' mean=' + mn[3] + ' @sd=' + sdText);
         out.push(indent + '{');
         for (const ln of renderNorm(L.preamble.map((q) => '  ' + q), 'inv')) out.push(indent + ln);
         out.push(indent + '  ' + acc + ' = norm_data_loop<G>(A' + mn[1] + ', static_cast<const ' + arr.ctype + ' *>(user_arr<' + mn[1] + '>(d)), ' + boundV.cst + ', ' + mn[3] + ', ' + mn[4] + ', ' + (mid ? 'true' : 'false') + ', sub, ' + acc + ');');

@@ -216,7 +216,7 @@ VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.0      # wave64 vector instructions per secon
 
 def profiled_valu_per_update(workload, kernel, kernel_id):
     """Vector instructions one parameter update costs a wavefront's LANE in the kernel `kernel`, from the committed rocprofv3 PMC pass of the same kernel sources
-    (profiles/r*_<workload>_summary.json: SQ_INSTS_VALU per launch / the launch's updates).  What a PASS-FREE update is priced with (cfg3's exact fast-forward: the
+    (profiles/r*_<workload>_summary.json: SQ_INSTS_VALU of the profile's adapted launches / a launch's updates).  What a PASS-FREE update is priced with (cfg3's exact fast-forward: the
     stepper -- Philox, Leva's rnorm, two logarithms, the bisection over the binades -- is all there is): achieved = value x this, against the chip's vector issue rate.
     -> (wave64 instructions per 64 updates, file, why-not)"""
     import glob
@@ -228,7 +228,9 @@ def profiled_valu_per_update(workload, kernel, kernel_id):
             continue
         if p.get("workload") != workload or kernel_base_name(p.get("kernel", "")) != kernel_base_name(kernel):
             continue
-        v = ((p.get("pmc_per_launch") or {}).get("SQ_INSTS_VALU") or {}).get("mean")
+        # (the MINIMUM over the profiled launches: the launches of a sampler whose proposal scales are still adapting reject more often inside rnorm and issue more;
+        # the rate this is multiplied with is measured on adapted launches)
+        v = ((p.get("pmc_per_launch") or {}).get("SQ_INSTS_VALU") or {}).get("min")
         upd = (p.get("chains") or 0) * (p.get("steps_per_launch") or 0) * (p.get("components") or 1)
         if not v or not upd:
             continue

@@ -334,6 +334,18 @@ const BENCH = {
       }
       return log_post;
     } },
+  // (round 6, the certified tail of translate.js tailPlan beyond the README shape: data too large for LDS, a ragged 65 observations, a head with
+  // other densities and a mean / sd that are EXPRESSIONS of the state)
+  bench_normal_50k: { params: CASES.readme_normal.params, data: () => synth.normal(50000, 20260926).x, log_post: CASES.readme_normal.log_post },
+  bench_normal_n65: { params: CASES.readme_normal.params, data: () => synth.normal(65, 20260927).x, log_post: CASES.readme_normal.log_post },
+  bench_normal_expr: { params: () => ({ a: { type: 'real' }, b: { type: 'real' }, tau: { type: 'real', lower: 0, init: 1 } }),
+    data: () => ({ x: synth.normal(3000, 20260928).x }),
+    log_post: function(state, data) {
+      var lp = ld.norm(state.a, 0, 10) + ld.norm(state.b, 1, 10);
+      lp += ld.gamma(state.tau, 2, 1);
+      for (var i = 0; i < data.x.length; i++) lp += ld.norm(data.x[i], state.a + 0.5 * state.b, 1 / Math.sqrt(state.tau));
+      return lp;
+    } },
   bench_hier: { params: CASES.hier_normal_closure.params, data: () => synth.hier(10000, 32, 20260925), log_post: CASES.hier_normal_closure.log_post },
   bench_glm: { params: CASES.pois_glm_closure.params, data: () => synth.glm(50000, 20260925), log_post: CASES.pois_glm_closure.log_post },
 };

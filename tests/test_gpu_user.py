@@ -236,6 +236,33 @@ def test_certified_tail_of_a_translated_closure_decides_like_the_expression_and_
     s.close()
 
 
+@pytest.mark.parametrize("name,params,init,n", [
+    ("bench_normal_50k", [("real", -INF, INF), ("real", 0.0, INF)], [0.5, 0.5], 50000),      # 400 KB of observations: the wavefront's pass reads global memory
+    ("bench_normal_n65", [("real", -INF, INF), ("real", 0.0, INF)], [0.5, 0.5], 65),         # one full round and one observation
+    ("bench_normal_expr", [("real", -INF, INF), ("real", -INF, INF), ("real", 0.0, INF)], [0.5, 0.5, 1.0], 3000)])      # mean = a + b / 2, sd = 1 / sqrt(tau), a gamma prior in the head
+def test_certified_tail_beyond_the_readme_shape(name, params, init, n):
+    """translate.js tailPlan on closures that are not the README's: the default (amwg_user_step_cert) against the expression in every update and widened bounds --
+    draws, state, counters, proposal scales, uniforms, cached log_post: every bit of every chain."""
+    src, arrays, meta = user_host.translated(name)
+    assert meta["cert_tail_n"] == n and "kCertifiedTail = true" in src
+    opt = {"prop_log_scale": 0.0, "batch_size": 50, "max_adaptation": 0.33, "initial_adaptation": 1.0, "target_accept_rate": 0.44, "is_adapting": True}
+    spec = {"user": user_host.user_spec_part(src, arrays, meta), "P": len(init), "init": init, "comp_opts": [dict(opt) for _ in init],
+            "params": [{"type": t, "len": 1, "top": 1, "multidim": 0, "lower": lo, "upper": hi} for t, lo, hi in params]}
+    chains = 192 if n > 10000 else 640
+    kw = dict(chains=chains, seed=5, chain_offset=11, lanes_per_chain=1, steps_per_launch=17)
+    runs = [A.Sampler(spec, **kw), A.Sampler(spec, full_evaluation=1, **kw), A.Sampler(spec, test_bound_shift=16, **kw), A.Sampler(spec, test_bound_shift=40, **kw)]
+    assert [q.launch_info()["kernel"] for q in runs] == ["amwg_user_step_cert", "amwg_user_step", "amwg_user_step_cert", "amwg_user_step_cert"]
+    outs = []
+    for q in runs:
+        d1 = q.sample(60, 2)
+        q.burn(90)
+        d2 = q.sample(30, 1)
+        outs.append((d1.tobytes(), d2.tobytes(), q.state().tobytes(), q.info()["accepts"].tobytes(), q.info()["prop_log_scale"].tobytes(), q.diag()["uniforms"].tobytes(), q.diag()["log_post"].tobytes()))
+        q.close()
+    assert all(o == outs[0] for o in outs[1:]), [[x == y for x, y in zip(o, outs[0])] for o in outs[1:]]
+    assert np.isfinite(np.frombuffer(outs[0][2], dtype=np.float64)).all()
+
+
 FULL_SIZE = [("bench_normal", "cfg2_full"), ("bench_bern", "cfg3_full"), ("bench_hier", "cfg4_full"), ("bench_glm", "cfg5_full")]
 
 

@@ -17,6 +17,9 @@ if os.environ.get("SWEEP_UNFUSE"):      # A/B: the softplus of a logistic likeli
 inf = float("inf")
 LAYOUT = {  # completed params of the bench closures
     "bench_normal": ([("real", 1, -inf, inf, 0.5), ("real", 1, 0.0, inf, 0.5)]),
+    "bench_normal_50k": ([("real", 1, -inf, inf, 0.5), ("real", 1, 0.0, inf, 0.5)]),
+    "bench_normal_n65": ([("real", 1, -inf, inf, 0.5), ("real", 1, 0.0, inf, 0.5)]),
+    "bench_normal_expr": ([("real", 1, -inf, inf, 0.5), ("real", 1, -inf, inf, 0.5), ("real", 1, 0.0, inf, 1.0)]),
     "bench_bern": ([("real", 1, 0.0, 1.0, 0.5)]),
     "bench_hier": ([("real", 32, -inf, inf, 0.5), ("real", 1, -inf, inf, 0.5), ("real", 1, 0.0, inf, 1.0)]),
     "bench_glm": ([("real", 8, -inf, inf, 0.0), ("int", 1, 0.0, 49999.0, 25000.0)]),
