@@ -581,6 +581,7 @@ def measure_other_config(A, name, device, group_local=0):
         kernel = li.get("kernel", kernel) + " (certified decisions)"
     lane_ops = sweep_lane_ops(value, P, n_obs) if roof_updates_per_s is None else roof_updates_per_s * n_obs * ops_per_obs
     if group_local:
+        kernel = li.get("kernel") or kernel      # (amwg_gl_kernel<HierGlModel,BT>: what a profiler lists -- round-5 review: the line named the plain step kernel here)
         # group-local evaluation: a step of the P = G + 2 updates makes TWO passes over the data (the sweep over theta and the sigma update)
         # instead of P; the fp64 work per update is what those two passes do, not one pass per update
         lane_ops = roof_updates_per_s * (2.0 / P) * n_obs * ops_per_obs

@@ -26,6 +26,8 @@ cfg = int(sys.argv[sys.argv.index("--cfg") + 1]) if "--cfg" in sys.argv else 4
 if cfg == 4:
     d = model_spec.make_data("hier_normal", 10000, 20260925, G=32)
     spec, chains, lanes, steps = model_spec.build_spec("hier_normal", d), 2048, 64, 200
+elif cfg == 1:      # README.md:18-43 as is: ONE chain on the ten heights (the latency of one wavefront's dependent chain)
+    spec, chains, lanes, steps = model_spec.build_spec("normal", {"x": np.array([183, 192, 182, 183, 177, 185, 188, 188, 182, 185], dtype=np.float64)}), 1, 64, 2000
 elif cfg == 2:
     spec, chains, lanes, steps = model_spec.build_spec("normal", model_spec.make_data("normal", 10000, 20260925)), 65536, 1, 100
 else:
