@@ -231,6 +231,8 @@ static bool normal_tile_wanted(const amwg_sampler *s, int bt) { return !s->user 
 static bool user_cert_wanted(const amwg_sampler *s, int lanes) {
   return s->user && s->user_cert_tail_n > 0 && lanes == 1 && s->opt.full_evaluation == 0 && !s->opt.exact_division && !s->user_has_binary;
 }
+// ... and a closure whose row plan the translator marked kRowCert: the sweep kernel decides from certified values, against the expression in the reference's order
+static bool user_rows_cert_wanted(const amwg_sampler *s) { return s->user && s->user_rows_cert && s->opt.full_evaluation == 0 && !s->opt.exact_division && !s->user_has_binary; }
 bool user_rows_wanted(const amwg_sampler *s, int G);
 bool user_rows_fit(const amwg_sampler *s, int bt, size_t max_lds);
 
@@ -380,7 +382,7 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
     const bool rows = user_rows_wanted(s, s->lanes) && user_rows_fit(s, s->block, max_lds);
     s->d.pad = rows ? HierNormalModel::row_pitch(s->user_rows_n) : 0;
     s->user_sweep = rows && user_sweep_wanted(s, s->lanes, s->block, max_lds);
-    s->certified = !s->user_sweep && user_cert_wanted(s, s->lanes);      // (amwg_user_step_cert)
+    s->certified = s->user_sweep ? user_rows_cert_wanted(s) : user_cert_wanted(s, s->lanes);      // (amwg_user_sweep_cert / amwg_user_step_cert)
     return AMWG_OK;
   }
   const bool rows = !s->mc.group_local && hier_rows_wanted(s, s->lanes) && hier_rows_fit(s, s->block, max_lds);
@@ -412,7 +414,9 @@ struct Roctx {
 Roctx &roctx() { static Roctx r; return r; }
 
 // which of the three kernels of a translated closure's code object this sampler launches (user_program)
-static const char *user_kernel_symbol(const amwg_sampler *s) { return s->user_sweep ? "amwg_user_sweep" : (s->certified ? "amwg_user_step_cert" : "amwg_user_step"); }
+static const char *user_kernel_symbol(const amwg_sampler *s) {
+  return s->user_sweep ? (s->certified ? "amwg_user_sweep_cert" : "amwg_user_sweep") : (s->certified ? "amwg_user_step_cert" : "amwg_user_step");
+}
 // does this sampler's kernel decide from a model's cheaper value of log_post (amwg_kernel.h kCert: NormalModel at one lane per chain, PoisGlmModel at 16)?
 static bool certified_kernel(const amwg_sampler *s) { return s->certified; }
 
@@ -856,6 +860,14 @@ static std::string user_program(const char *source, int lanes, int block) {
   p += tail;
   // amwg_user_step_cert: for a closure with a certified tail (amwg_user.h norm_tail_approx: UserModel::kCertified) at the lane count it has one for, the stepper
   // that decides accept tests from it (amwg_step_kernel_cert's twin; BT: the wavefront's pass needs the 512 registers of a workgroup of at most 256 threads)
+  // amwg_user_sweep_cert: a row plan the translator marked kRowCert (amwg_rows.h: certified values + the expression in the reference's order): amwg_sweep_kernel_cert's twin
+  snprintf(tail, sizeof tail,
+           "extern \"C\" __global__ void __launch_bounds__(%d) amwg_user_sweep_cert(const amwg::StepArgs a) {\n"
+           "  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n"
+           "  if constexpr (amwg::LaneReuseOf<amwg::UserModel>::value && amwg::CertifiedAt<amwg::UserModel, 64>::value && amwg::CertNeedsRows<amwg::UserModel>::value && %d == 64 && %d <= 512)\n"
+           "    amwg::step_body<amwg::UserModel, 64, 512, false, true, true>(a, smem);\n}\n",
+           block, lanes, block);
+  p += tail;
   snprintf(tail, sizeof tail,
            "extern \"C\" __global__ void __launch_bounds__(%d) amwg_user_step_cert(const amwg::StepArgs a) {\n"
            "  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n"
@@ -1076,7 +1088,7 @@ static int autotune_geometry(amwg_sampler *s, int n_cus, size_t max_lds, Prepare
   for (size_t i = 0; i < cand.size(); ++i) if (i != best && cand[i].module) (void)hipModuleUnload(cand[i].module);
   const TuneCandidate &c = cand[best];
   s->lanes = c.lanes; s->block = c.block; s->grid = c.grid; s->lds = c.lds; s->cpb = c.cpb; s->kernel = c.kernel; s->user_module = c.module; s->user_fn = c.fn;
-  s->certified = s->user ? (!c.sweep && user_cert_wanted(s, c.lanes)) : (c.kernel != nullptr && c.kernel == pick_certified_kernel(s->model, c.lanes, c.block));
+  s->certified = s->user ? (c.sweep ? user_rows_cert_wanted(s) : user_cert_wanted(s, c.lanes)) : (c.kernel != nullptr && c.kernel == pick_certified_kernel(s->model, c.lanes, c.block));
   s->d.pad = c.pad; s->user_sweep = c.sweep;      // (the row layout and the sweep kernel go with the geometry)
   s->tuned.clear();
   for (auto &q : cand) s->tuned.push_back({q.lanes, q.ms});
@@ -1372,6 +1384,7 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
     s->user_rows_n = rows_ok ? m->rows_n_obs : 0;
     s->user_rows_groups = rows_ok ? m->rows_groups : 0;
     s->user_rows_sweep = (rows_ok && m->rows_sweep && src_sweep) ? 1 : 0;
+    s->user_rows_cert = s->user_rows_sweep && strstr(m->source, "kRowCert = true") != nullptr;
     const long tail_n = strstr(m->source, "kCertifiedTail = true") ? int_after("kTailN = ") : 0;
     s->user_cert_tail_n = tail_n > 0 && tail_n < (1l << 28) ? (int)tail_n : 0;
   }
@@ -1846,7 +1859,7 @@ int amwg_launch_info(const amwg_sampler *s, int32_t *lanes, int32_t *block, int3
 int amwg_summation_order(const amwg_sampler *s) {
   if (!s) return fail(AMWG_EINVAL, "amwg_summation_order: null sampler");
   // (the certified kernels of the Poisson and the hierarchical family evaluate the expression in the reference's order: amwg_kernel.h kRefOrder)
-  if (s->lanes > 1 && certified_kernel(s) && (s->model == AMWG_MODEL_POIS_GLM || s->model == AMWG_MODEL_HIER_NORMAL)) return 1;
+  if (s->lanes > 1 && certified_kernel(s) && (s->user || s->model == AMWG_MODEL_POIS_GLM || s->model == AMWG_MODEL_HIER_NORMAL)) return 1;      // (a closure: amwg_user_sweep_cert)
   return s->lanes;
 }
 

@@ -32,6 +32,13 @@ AMWG_HD double ld_norm(double x, double mean, double sd) {
   return -0.5 * log_v8(2 * kPi) - log_v8(sd) - (t * t) / (2 * sd * sd);
 }
 AMWG_HD double ld_unif(double x, double lo, double hi) { return (x < lo || x > hi) ? -kInf : log_v8(1 / (hi - lo)); }
+// the same two with LITERAL parameters, their constants folded by the translator (translate.js foldConstantDensities: c = -0.5 log(2 pi) - log(sd) and den = (2 sd) sd;
+// log(1 / (hi - lo))) -- the same expression trees, the logarithms taken once at translation time by the V8 whose Math.log log_v8 restates
+AMWG_HD double ld_norm_c(double x, double mean, double c, double den) {
+  const double t = x - mean;
+  return c - (t * t) / den;
+}
+AMWG_HD double ld_unif_c(double x, double lo, double hi, double log_inv_width) { return (x < lo || x > hi) ? -kInf : log_inv_width; }
 AMWG_HD double ld_beta(double x, double a, double b) {
   if (x > 1 || x < 0) return -kInf;
   if (a == 1 && b == 1) return 0;

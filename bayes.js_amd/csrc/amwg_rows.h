@@ -21,6 +21,9 @@
 // global memory (they are read by lane 0 or by a short lane-split loop, once per evaluation).
 #pragma once
 #include "amwg_user.h"      // (which includes this file at its end: NormInv's formulas, user_arr)
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+#include "amwg_kernel.h"    // butterfly (the certified values below); every device build includes it anyway
+#endif
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)      // (device code throughout: the host build of a generated model -- tests/host -- sees nothing of it)
 #include "amwg_div.h"
 #include "amwg_ld.h"
@@ -39,9 +42,13 @@ struct RowsCache {
   double a_start, a_mean, a_sd, a_T, b_start, b_mean, b_sd, b_T;
   bool a_recent, loaded;
   int my_group;           // the label of this lane's observations (-1: the lane has none)
+  // certified decisions (round 6, below): this lane's sum of squares S2 = sum (y_i - mean)^2 over its row, with the mean it was formed for
+  double s2, s2_mean;
 };
 
 struct UserSweepRows { bool ok; double T_cur, T_new; int comp; bool new_in_b; };
+// what a lane's head contributes, with the magnitudes of its additions and their number (generated: UserModel::head_pair; the certified values below)
+struct HeadPair { double value, mag, cnt; };
 
 template <class M>
 struct UserRows {
@@ -76,7 +83,7 @@ struct UserRows {
   }
   __device__ __forceinline__ static Cache cache_init() {
     const double nan = __builtin_nan("");
-    return Cache{nan, 0.0, 0.0, Reciprocal{0.0, 0.0}, false, nan, nan, nan, 0.0, nan, nan, nan, 0.0, false, false, -1};
+    return Cache{nan, 0.0, 0.0, Reciprocal{0.0, 0.0}, false, nan, nan, nan, 0.0, nan, nan, nan, 0.0, false, false, -1, 0.0, nan};
   }
   __device__ __forceinline__ static void load(Cache &k, const unsigned char *smem, int pitch, int sub) {
     if (k.loaded) return;
@@ -254,6 +261,137 @@ struct UserRows {
     return out;
   }
   __device__ __forceinline__ static void sweep_done(Cache &k, const UserSweepRows &r, bool accepted_mine) { k.a_recent = r.new_in_b != accepted_mine; }
+
+  // ---------------------------------------------------------------------------------------------------------------------------------
+  // CERTIFIED DECISIONS in the row layout for a translated closure (round 6; the hand-written twin is HierNormalModel's, amwg_models.h; amwg_kernel.h
+  // "certified decisions").  Models the translator marks kRowCert (the head only ever ADDS to the accumulator; the sweep is proved).
+  // As a real number a lane's share of log_post is   head_l + n_l c - S2_l / den,   S2_l = sum over its row of (y_i - mean_l)^2 -- two operations per observation where
+  // the term takes eight, and S2 depends on the lane's MEAN only: an update of a parameter outside the swept vector needs no pass.  The reference's expression
+  // (reference_order below: the value these kernels decide against and leave behind) is ONE running sum: the head's K terms in the closure's order, then the n
+  // observations.  Bounds, u = 2^-53: with H_l = the magnitudes of the head's terms dealt to lane l (M::head_pair), m_l = H_l + n_l |c| + Q_l and M = sum_l m_l,
+  //     the running sum: K + n additions of partial sums below M, the terms' own roundings 5 u (n |c| + Q):      within (n + K + 8) u M of the real number
+  //     the value here: the lane's head (its <= K terms in the lane's order: K u H_l), n_l c - Q_l as in the hand-written family ((n_l / 4 + 9) u m_l),
+  //     the butterfly (6 u M):                                                                                    within (n_l / 4 + K + 15) u M
+  // => a value: eps = u M (2 (n + K) + 64) 1.25,  a difference of two: u M (4 (n + K) + 128) 1.25 (M over max(m_l, m_l')).  value_bound / difference_bound have the
+  // family's signature (M, d): the K-dependent factor is folded into the M that is handed to them -- M_eff = M (1 + 2 K / (2 n + 64)) gives exactly those numbers.
+  // (the head's terms themselves are the same fp64 numbers in both orders: a term is the same operations on the same values whichever lane forms it)
+  struct Approx { double value, eps; };
+  struct ApproxLane { double value, mag; };
+  __device__ __forceinline__ static double value_bound(double Mm, const DataRef &) { return Mm * (2.0 * (double)M::kRowN + 64.0) * 1.25 * 0x1p-53; }
+  __device__ __forceinline__ static double difference_bound(double Mm, const DataRef &) { return Mm * (4.0 * (double)M::kRowN + 128.0) * 1.25 * 0x1p-53; }
+  __device__ __forceinline__ static double head_factor(double K) { return 1.0 + 2.0 * K / (2.0 * (double)M::kRowN + 64.0); }
+  // S2 of this lane's row for `mean`: four interleaved partial sums (the order is free: the value is used with its bound)
+  __device__ __forceinline__ static double rows_sq(const double *row, double mean, int sub) {
+    constexpr int n_full = M::kRowN >> 6, rem = M::kRowN & 63;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int r = 0;
+    for (; r + 8 <= n_full; r += 8) {
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = row[r + u];
+      AMWG_STAGE_FENCE();
+      { const double t = x[0] - mean; a0 = __builtin_fma(t, t, a0); } { const double t = x[1] - mean; a1 = __builtin_fma(t, t, a1); }
+      { const double t = x[2] - mean; a2 = __builtin_fma(t, t, a2); } { const double t = x[3] - mean; a3 = __builtin_fma(t, t, a3); }
+      { const double t = x[4] - mean; a0 = __builtin_fma(t, t, a0); } { const double t = x[5] - mean; a1 = __builtin_fma(t, t, a1); }
+      { const double t = x[6] - mean; a2 = __builtin_fma(t, t, a2); } { const double t = x[7] - mean; a3 = __builtin_fma(t, t, a3); }
+    }
+    for (; r < n_full; ++r) { const double t = row[r] - mean; a0 = __builtin_fma(t, t, a0); }
+    if (sub < rem) { const double t = row[n_full] - mean; a1 = __builtin_fma(t, t, a1); }
+    return (a0 + a1) + (a2 + a3);
+  }
+  __device__ __forceinline__ static double lane_s2(Cache &k, const unsigned char *smem, double mean, int pitch, int sub) {      // (every lane takes part: a wavefront-uniform call)
+    const bool stale = f64_bits(mean) != f64_bits(k.s2_mean);
+    if (__ballot(stale) != 0ull) {
+      const double v = rows_sq(reinterpret_cast<const double *>(smem) + (size_t)sub * pitch, mean, sub);
+      if (stale) { k.s2 = v; k.s2_mean = mean; }
+    }
+    return k.s2;
+  }
+  __device__ __forceinline__ static ApproxLane approx_lane(const Cache &k, double start, double hmag, double s2, int sub) {
+    const double n_l = (double)((M::kRowN >> 6) + (sub < (M::kRowN & 63) ? 1 : 0));
+    const double q = s2 * k.y.hi, nc = n_l * k.c;
+    return ApproxLane{(start + nc) - q, hmag + __builtin_fabs(nc) + q};
+  }
+  // THE REFERENCE'S ORDER: the closure's own evaluation with one lane per chain -- head<1> is the head's statements in sequence --, continued by ONE running sum over the
+  // observations i = 64 r + lane whose terms the lanes compute side by side (the same operations on the same values as the one-lane kernel's loop).  Out of line, rare.
+  __device__ inline __attribute__((noinline)) static double reference_order_sum(double acc, const double *row, int sub, double mean, double c, double den, double yh, double yl, bool fast) {
+    constexpr int n_full = M::kRowN >> 6, rem = M::kRowN & 63;
+    for (int r = 0; r <= n_full; ++r) {
+      const int cnt = r < n_full ? 64 : rem;
+      const double t = row[sub < cnt ? r : 0] - mean;
+      const double tt = t * t;
+      const double term = c - (fast ? div_by_invariant(tt, den, Reciprocal{yh, yl}) : tt / den);
+      for (int l = 0; l < cnt; ++l) acc += lane_double(term, l);
+    }
+    return acc;
+  }
+  // (the head in sequence, out of line with the rest: its code -- the closure's loops over the parameter vectors, unrolled -- and its registers are not the hot path's)
+  __device__ __attribute__((noinline)) static double head_in_sequence(const StateView S, const DataRef &d, const unsigned char *smem) { return M::template head<1>(S, d, smem, 0); }
+  template <int G>
+  __device__ __forceinline__ static double reference_order(Cache &k, const StateView &S, const ModelConsts &, const DataRef &d, const unsigned char *smem, int sub) {
+    static_assert(G == 64, "the row layout: a chain on one wavefront");
+    load(k, smem, d.pad, sub);
+    update_inv(k, M::row_sd(S, d));
+    const double head1 = head_in_sequence(S, d, smem);      // (every lane forms the same number)
+    const double mean = k.my_group >= 0 ? S(M::kRowBase + k.my_group) : 0.0;
+    const bool fast = k.inv_fast && M::kRowDataMid && all_mid(mean, k.my_group >= 0);
+    return reference_order_sum(head1, reinterpret_cast<const double *>(smem) + (size_t)sub * d.pad, sub, mean, k.c, k.den, k.y.hi, k.y.lo, fast);
+  }
+  // log_post of the state as it stands, cheaply (the updates of parameters outside the swept vector, and the swept vector's when a sweep is walked update by update)
+  template <int G, int BT>
+  __device__ __forceinline__ static Approx log_post_approx(Cache &k, const StateView &S, const ModelConsts &, const DataRef &d, const unsigned char *smem, int sub) {
+    if (d.pad <= 0) return Approx{0.0, __builtin_inf()};      // (wave-uniform: not the row layout -- the expression)
+#if defined(AMWG_X_CUT_LPA)
+    return Approx{0.0, __builtin_inf()};
+#endif
+    load(k, smem, d.pad, sub);
+    update_inv(k, M::row_sd(S, d));
+    const HeadPair h = M::template head_pair<64>(S, d, smem, sub);
+    const double mean = k.my_group >= 0 ? S(M::kRowBase + k.my_group) : 0.0;
+    const double s2 = lane_s2(k, smem, mean, d.pad, sub);
+    const ApproxLane a = approx_lane(k, h.value, h.mag, s2, sub);
+    const double value = butterfly<1, 64>(a.value), Mv = butterfly<1, 64>(a.mag), K = butterfly<1, 64>(h.cnt);
+    return Approx{value, value_bound(Mv * head_factor(K), d)};
+  }
+  // the sweep: every lane's value now and under its entry's proposal (lane c < groups holds the proposal of entry c).  kRowSweep (the translator's proof): a lane's
+  // head and mean read the swept vector only as ITS entry, so all proposals are written into the state at once, read off it, and the state is put back.
+  struct SweepApprox { bool ok; int comp; double cur, neu, mag, mean_new, s2_new; };
+  __device__ __forceinline__ static SweepApprox sweep_approx(Cache &k, const StateView &S, const ModelConsts &, const DataRef &d, const unsigned char *smem, int sub, double prop_own) {
+    SweepApprox out{false, -1, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if constexpr (M::kRowSweep) {
+      if (d.pad <= 0) return out;      // (wave-uniform)
+#if defined(AMWG_X_CUT_SWA)
+      return out;
+#endif
+      load(k, smem, d.pad, sub);
+      update_inv(k, M::row_sd(S, d));
+      const bool has = k.my_group >= 0;
+      const HeadPair h0 = M::template head_pair<64>(S, d, smem, sub);
+      const double mean_cur = has ? S(M::kRowBase + k.my_group) : 0.0;
+      double *Sw = const_cast<double *>(S.base);
+      double keep = 0.0;
+      if (sub < M::kRowGroups) { keep = Sw[M::kRowBase + sub]; Sw[M::kRowBase + sub] = prop_own; }
+      const HeadPair h1 = M::template head_pair<64>(S, d, smem, sub);
+      const double mean_new = has ? S(M::kRowBase + k.my_group) : 0.0;
+      if (sub < M::kRowGroups) Sw[M::kRowBase + sub] = keep;
+      const double s2_cur = lane_s2(k, smem, mean_cur, d.pad, sub);
+      const double s2_new = rows_sq(reinterpret_cast<const double *>(smem) + (size_t)sub * d.pad, mean_new, sub);
+      const ApproxLane c0 = approx_lane(k, h0.value, h0.mag, s2_cur, sub), c1 = approx_lane(k, h1.value, h1.mag, s2_new, sub);
+      const double K = butterfly<1, 64>(h0.cnt > h1.cnt ? h0.cnt : h1.cnt);
+      out.ok = true;
+      out.comp = has ? k.my_group : (sub < M::kRowGroups ? sub : -1);
+      out.cur = c0.value; out.neu = c1.value;
+      out.mag = (c0.mag > c1.mag ? c0.mag : c1.mag) * head_factor(K);
+      out.mean_new = mean_new; out.s2_new = s2_new;
+    }
+    return out;
+  }
+  // what the accepted entries leave behind in this lane: the S2 that goes with the new mean (the state itself is written by the stepper)
+  __device__ __forceinline__ static void sweep_approx_commit(Cache &k, const SweepApprox &sa, uint64_t, bool mine, double, int, const DataRef &) {
+    const bool grp = k.my_group >= 0 && mine;
+    k.s2 = grp ? sa.s2_new : k.s2;
+    k.s2_mean = grp ? sa.mean_new : k.s2_mean;
+  }
 };
 
 }  // namespace amwg

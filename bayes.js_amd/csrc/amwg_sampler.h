@@ -43,6 +43,7 @@ struct amwg_sampler {
   int D = 0;                       // derived quantities recorded after the P components
   int user_lds = 0, user_lds_one_lane = 0, user_parallel = 0, user_max_threads = 1024;
   int user_rows_n = 0, user_rows_groups = 0, user_rows_sweep = 0;   // row plan of a translated closure (amwg_rows.h): observations and groups of its final likelihood loop; 0 = none
+  bool user_rows_cert = false;     // the row plan has certified values (kRowCert of the generated source: amwg_rows.h log_post_approx / sweep_approx / reference_order)
   int user_cert_tail_n = 0;        // certified tail of a translated closure (amwg_user.h norm_tail_approx): observations of its final constant-mean normal loop (kTailN of the generated source); 0 = none
   bool user_sweep = false, user_has_binary = false;                  // the chosen geometry runs amwg_user_sweep; the model has binary parameters
   double user_work = 0;            // translator's estimate of the instructions of one log_post evaluation

@@ -61,6 +61,87 @@ function hexFloat(v) {
   return sign + '0x1.' + mant + 'p' + (exp - 1023 >= 0 ? '+' : '') + (exp - 1023);
 }
 
+// norm_inv(<literal>) folded at translation time (round 6): the loop invariants of ld.norm with a CONSTANT sd -- c = -0.5 log(2 pi) - log(sd), den = 2 sd sd, the
+// double-double reciprocal of csrc/amwg_div.h -- as literals, instead of a logarithm and a division every time the generated code passes the statement (a prior
+// `lp += ld.norm(theta[k], mu, 10)` inside the head of a row plan is evaluated several times per step).  Math.log is V8's -- the function log_v8 restates bit for bit
+// (tests/test_oracle_math.py) --, the products and the quotient are IEEE, and the reciprocal's low word RN(fma(-den, hi, 1) * hi) is formed from the EXACT residual
+// (BigInt arithmetic on the significands; it is representable, Markstein) and one rounded product: the same bits as norm_inv() on the device, which the host build
+// of the generated text checks (tests/host/user_eval_host.cpp evaluates both forms).
+function parseLiteral(t) {
+  t = t.trim();
+  if (/^-?\d+(?:\.\d*)?(?:e[+-]?\d+)?$/i.test(t)) return Number(t);
+  const m = /^(-?)0x([01])\.([0-9a-f]{13})p([+-]?\d+)$/i.exec(t);
+  if (!m) return NaN;
+  const mant = (BigInt(m[2]) << 52n) | BigInt('0x' + m[3]);
+  return (m[1] ? -1 : 1) * Number(mant) * Math.pow(2, Number(m[4]) - 52);
+}
+function decompose(v) {      // v = m * 2^e exactly, m a BigInt (v finite, positive)
+  const buf = new DataView(new ArrayBuffer(8));
+  buf.setFloat64(0, v);
+  const hi = buf.getUint32(0), lo = buf.getUint32(4), ex = (hi >>> 20) & 0x7ff;
+  const frac = (BigInt(hi & 0xfffff) << 32n) | BigInt(lo);
+  return ex === 0 ? { m: frac, e: -1074 } : { m: frac | (1n << 52n), e: ex - 1075 };
+}
+function foldNormInv(sd) {
+  if (!(sd > 0) || !isFinite(sd)) return null;
+  const c = (-0.5 * Math.log(2 * Math.PI)) - Math.log(sd);
+  const den = (2 * sd) * sd;
+  if (!(den >= Math.pow(2, -200) && den <= Math.pow(2, 200))) return null;      // (mid_range: outside it the device takes IEEE division; leave the call)
+  const hi = 1 / den;
+  const a = decompose(den), b = decompose(hi);
+  const E = a.e + b.e;      // den * hi = a.m b.m 2^E, next to 1: E is about -104
+  if (E >= 0) return null;
+  const r = (1n << BigInt(-E)) - a.m * b.m;      // (1 - den * hi) * 2^-E, exact
+  let rn = r < 0n ? -r : r, sh = 0;
+  while (rn !== 0n && (rn & 1n) === 0n) { rn >>= 1n; sh++; }
+  if (rn >= (1n << 53n)) return null;            // (cannot happen for a correctly rounded reciprocal: the residual is representable)
+  const resid = (r < 0n ? -1 : 1) * Number(rn) * Math.pow(2, E + sh);
+  const lo = resid * hi;
+  return 'NormInv{' + hexFloat(c) + ', ' + hexFloat(den) + ', Reciprocal{' + hexFloat(hi) + ', ' + hexFloat(lo) + '}, true}';
+}
+// ... and the scalar densities with literal parameters, evaluated by the head of a closure on one lane several times per step: ld_norm(x, mean, <sd literal>) -> the
+// same expression tree with its two constants folded (c = -0.5 log(2 pi) - log(sd), den = (2 sd) sd: csrc/amwg_ld.h ld_norm_c); ld_unif(x, <lo>, <hi>) -> its constant
+// log(1 / (hi - lo)) folded (ld_unif_c).  Same operations on the same values: the logarithms are V8's either way.
+function splitCallArgs(text, open) {      // text[open] === '(' -> {args: [...], end: index after ')'} or null
+  let depth = 0, start = open + 1;
+  const args = [];
+  for (let i = open; i < text.length; i++) {
+    const ch = text[i];
+    if (ch === '(') depth++;
+    else if (ch === ')') { depth--; if (depth === 0) { args.push(text.slice(start, i).trim()); return { args, end: i + 1 }; } }
+    else if (ch === ',' && depth === 1) { args.push(text.slice(start, i).trim()); start = i + 1; }
+    else if (ch === '\n' || ch === ';') return null;
+  }
+  return null;
+}
+function foldConstantDensities(text) {
+  let out = '', at = 0;
+  const re = /\b(ld_norm|ld_unif)\(/g;
+  for (let m; (m = re.exec(text));) {
+    if (m.index < at) continue;
+    const call = splitCallArgs(text, m.index + m[1].length);
+    if (!call || call.args.length !== 3) continue;
+    let repl = null;
+    if (m[1] === 'ld_norm') {
+      const sd = parseLiteral(call.args[2]);
+      if (sd > 0 && isFinite(sd)) repl = 'ld_norm_c(' + call.args[0] + ', ' + call.args[1] + ', ' + hexFloat((-0.5 * Math.log(2 * Math.PI)) - Math.log(sd)) + ', ' + hexFloat((2 * sd) * sd) + ') /* ld_norm(., ., ' + call.args[2] + ') */';
+    } else {
+      const lo = parseLiteral(call.args[1]), hi = parseLiteral(call.args[2]);
+      if (!Number.isNaN(lo) && !Number.isNaN(hi)) repl = 'ld_unif_c(' + call.args[0] + ', ' + call.args[1] + ', ' + call.args[2] + ', ' + hexFloat(Math.log(1 / (hi - lo))) + ')';
+    }
+    if (repl) { out += text.slice(at, m.index) + repl; at = call.end; re.lastIndex = call.end; }
+  }
+  return out + text.slice(at);
+}
+function foldConstantNormInv(text) {
+  text = foldConstantDensities(text);
+  return text.replace(/norm_inv\((-?(?:0x[0-9a-fp.+-]+|[0-9][0-9.e+-]*))\)/gi, (whole, lit) => {
+    const v = parseLiteral(lit);
+    const f = Number.isNaN(v) ? null : foldNormInv(v);
+    return f ? f + ' /* norm_inv(' + lit + ') */' : whole;
+  });
+}
+
 const { tokenize, parseFunctionSource, desugarBlock, walk, assignedNames, definitelyAssigned, idsOf, containsKind, declaredIn } = require('./parse.js');
 
 
@@ -1769,6 +1850,23 @@ Translator.prototype.run = function () {
     for (const ln of rows.head) src.push(ln);
     src.push('    return v_' + rows.acc + ';');
     src.push('  }');
+    src.push('  // kRowCert: certified decisions in the row layout (csrc/amwg_rows.h; amwg_user_sweep_cert) -- the head only ever ADDS to `' + rows.acc + '`: ' + rows.certWhy);
+    src.push('  static constexpr bool kRowCert = ' + (rows.cert ? 'true' : 'false') + ';');
+    if (rows.cert) {
+      src.push('  static constexpr bool kCertified = true, kCertifiedNeedsRows = true, kReferenceOrder = true;');
+      src.push('  static constexpr int kCertifiedLanes = 64;');
+      src.push('  // the head\'s value together with the magnitudes of what it adds up (this lane\'s share) and how many additions that is -- the bound on the two orders the head\'s');
+      src.push('  // terms are summed in.  (Inlined at its three call sites: out of line every call spilled the ~170 registers the stepper keeps alive, and with the constants of');
+      src.push('  // ld.norm / ld.unif / norm_inv folded by the translator the body is a handful of instructions per lane)');
+      src.push('  template <int G>');
+      src.push('  __device__ __forceinline__ static HeadPair head_pair(const StateView S, const DataRef &d, const unsigned char *smem, int sub) {');
+      this.arrays.forEach((a, j) => { src.push('    const ' + a.ctype + ' *A' + j + ' = static_cast<const ' + a.ctype + ' *>(user_arr<' + j + '>(d));'); });
+      src.push('    (void)smem; (void)sub; (void)d;');
+      src.push('    double mag_ = 0.0, cnt_ = 0.0;');
+      for (const ln of rows.headMag) src.push(ln);
+      src.push('    return HeadPair{v_' + rows.acc + ', mag_, cnt_};');
+      src.push('  }');
+    }
   }
   if (tail) {
     // CERTIFIED TAIL (csrc/amwg_user.h norm_tail_approx; amwg_kernel.h "certified decisions"): with one lane per chain the stepper decides accept tests from
@@ -1817,7 +1915,7 @@ Translator.prototype.run = function () {
   src.push('};');
   src.push('}  // namespace amwg');
   return {
-    source: src.join('\n') + '\n',
+    source: (this.opts.no_fold_norm_inv ? src.join('\n') : foldConstantNormInv(src.join('\n'))) + '\n',
     arrays: this.arrays.map((a) => a.flat),
     array_types: this.arrays.map((a) => a.type),
     array_keys: this.arrays.map((a) => a.key),
@@ -1839,6 +1937,7 @@ Translator.prototype.run = function () {
     // certified tail (csrc/amwg_user.h norm_tail_approx): observations of the closure's final constant-mean normal loop; 0 = none.  (The host library reads the
     // same fact off the generated source -- kCertifiedTail / kTailN -- so no field of amwg_user_model carries it.)
     cert_tail_n: tail ? tail.n : 0,
+    rows_cert: rows && rows.cert ? 1 : 0,
   };
 };
 
@@ -1934,6 +2033,32 @@ Translator.prototype.rowPlan = function (body) {
   }
   plan.sweep = !why && !this.hasBinary;
   plan.sweepWhy = why || (this.hasBinary ? 'no: the model has binary parameters' : 'proved');
+  // ---- CERTIFIED VALUES for the row plan (round 6; csrc/amwg_rows.h UserRows::log_post_approx / sweep_approx / reference_order).  The cheap value of a lane is
+  // head_l + n_l c - S2_l / den; the reference's expression sums the head's terms and the observations' in ONE running sum.  The two orders of the head's terms are
+  // bounded through the MAGNITUDES of what the head adds up, which needs the head to be nothing but accumulations: every line that mentions the accumulator must be its
+  // declaration, `acc = (sub == 0) ? X : 0.0;`, `[if (sub == 0)] acc += X;` (also inside the lane-split loops), the save / restore around a loop's slow replay, or the
+  // return.  head_mag is the same text with every added value replaced by its magnitude and a count of the additions beside it.
+  const accV = 'v_' + plan.acc;
+  const esc = accV.replace(/[$]/g, '\\$');
+  const okLine = new RegExp('^(?:double ' + esc + ' = 0;|' + esc + ' = \\(sub == 0\\) \\? .+ : 0\\.0;|(?:if \\(sub == 0\\) )?' + esc + ' \\+= .+;|const double acc_save_ = ' + esc + ';|' + esc + ' = acc_save_;|for \\(.*\\) ' + esc + ' \\+= [^;]+;|for \\(.*\\) \\{ .*' + esc + ' \\+= [^;]+; \\})$');
+  let certWhy = plan.sweep ? '' : 'no: the sweep is not proved';
+  const mag = [];
+  for (const ln0 of head) {
+    const t = ln0.trim();
+    if (certWhy) break;
+    if (t.indexOf(accV) < 0 || t.indexOf('//') === 0) { mag.push(ln0); continue; }
+    if (!okLine.test(t)) { certWhy = 'no: the head does more with ' + plan.acc + ' than add to it: `' + t.slice(0, 70) + '`'; break; }
+    // (value, magnitude and count in ONE walk over the head's statements: head_pair)
+    let m2 = ln0;
+    m2 = m2.replace(new RegExp(esc + ' = \\(sub == 0\\) \\? (.+) : 0\\.0;'), (q, X) => '{ const double x_ = (sub == 0) ? (' + X + ') : 0.0; ' + accV + ' = x_; mag_ = __builtin_fabs(x_); if (sub == 0) cnt_ += 1.0; }');
+    m2 = m2.replace(new RegExp(esc + ' \\+= ([^;]+);', 'g'), (q, X) => '{ const double x_ = ' + X + '; ' + accV + ' += x_; mag_ += __builtin_fabs(x_); cnt_ += 1.0; }');
+    m2 = m2.replace(new RegExp('const double acc_save_ = ' + esc + ';'), 'const double acc_save_ = ' + accV + ', mag_save_ = mag_;');
+    m2 = m2.replace(new RegExp(esc + ' = acc_save_;'), accV + ' = acc_save_; mag_ = mag_save_;');
+    mag.push(m2);
+  }
+  plan.cert = !certWhy && !this.opts.no_row_cert;
+  plan.certWhy = certWhy || (this.opts.no_row_cert ? 'no: switched off (no_row_cert)' : 'yes');
+  plan.headMag = mag;
   return plan;
 };
 
@@ -1981,4 +2106,4 @@ function translate(fn, params, data, options) {
   return new Translator(fn, params, data, options).run();
 }
 
-module.exports = { translate, parseFunctionSource, hexFloat, tokenize };
+module.exports = { translate, parseFunctionSource, hexFloat, tokenize, foldConstantNormInv };

@@ -134,7 +134,7 @@ def _golden_spec(gold, rec, src, arrays, meta):
     return {"user": user_host.user_spec_part(src, arrays, meta), "params": params, "P": len(init), "init": init, "comp_opts": rec["comp_opts"]}
 
 
-@pytest.mark.parametrize("name,kernel", [("hier_normal_closure", "amwg_user_sweep"), ("hier_rows_bounded", "amwg_user_sweep"), ("hier_rows_int", "amwg_user_sweep")])
+@pytest.mark.parametrize("name,kernel", [("hier_normal_closure", "amwg_user_sweep_cert"), ("hier_rows_bounded", "amwg_user_sweep_cert"), ("hier_rows_int", "amwg_user_sweep_cert")])
 def test_row_plan_of_a_translated_closure_reproduces_the_reference_and_the_full_evaluation(name, kernel):
     """csrc/amwg_rows.h on the device, 64 lanes per chain: a closure that ends in the likelihood loop of a model with group means keeps the per-lane sums an
     update cannot have changed and evaluates the proposals of a whole sweep over theta in one pass -- for a swept vector that is not the first parameter, has
@@ -153,22 +153,33 @@ def test_row_plan_of_a_translated_closure_reproduces_the_reference_and_the_full_
         info = s.info()
         assert info["accepts"][:, 0].tolist() == rec["accepts"] and info["inbounds"][:, 0].tolist() == rec["inbounds"]
         assert info["batch_count"][:, 0].tolist() == rec["batch_count"] and int(s.diag()["uniforms"][0]) == rec["uniforms"]
-        assert np.allclose(s.state()[:, 0], rec["final_state"], rtol=1e-9, atol=1e-12)      # (64-lane order: the doubles are those of that order, the decisions the reference's)
+        # (round 6: the row plan's certified kernel decides against the expression in the REFERENCE's order and leaves that expression's value behind: the golden's
+        # own doubles, not merely its decisions)
+        assert s.launch_info()["summation_order"] == 1
+        assert s.state()[:, 0].tolist() == rec["final_state"] and float(s.diag()["log_post"][0]) == rec["log_post"]
         s.close()
     spec = _golden_spec(gold, gold["chains"][0], m.source, m.arrays, m.meta)
     sched = [{"op": "burn", "n": 130}, {"op": "sample", "n": 60, "thin": 2}, {"op": "burn", "n": 7}]
     kw = dict(chains=96, seed=77, chain_offset=5, lanes_per_chain=64)
     # (full_evaluation = 2: the row plan with every sweep's accept tests decided update by update -- the path a sweep takes when a uniform falls inside the
     # rounding bound of the all-at-once decision, csrc/amwg_kernel.h)
-    a, b, c2, c3 = A.Sampler(spec, **kw), A.Sampler(spec, full_evaluation=1, **kw), A.Sampler(spec, full_evaluation=2, **kw), A.Sampler(spec, test_bound_shift=12, **kw)
-    assert a.launch_info()["kernel"] == kernel and b.launch_info()["kernel"] == "amwg_user_step" and c2.launch_info()["kernel"] == kernel
+    # (c3 / c4: the certified bounds widened 2^12- and 2^40-fold -- fallbacks to the expression in the reference's order often / always; r1: ONE lane per chain with the
+    # expression in every update = the reference's own order: the certified kernel's log_post must be ITS value, bit for bit)
+    a, b, c2, c3, c4 = A.Sampler(spec, **kw), A.Sampler(spec, full_evaluation=1, **kw), A.Sampler(spec, full_evaluation=2, **kw), A.Sampler(spec, test_bound_shift=12, **kw), A.Sampler(spec, test_bound_shift=40, **kw)
+    r1 = A.Sampler(spec, full_evaluation=1, **dict(kw, lanes_per_chain=1))
+    assert a.launch_info()["kernel"] == kernel and b.launch_info()["kernel"] == "amwg_user_step" and c2.launch_info()["kernel"] == "amwg_user_sweep" and c3.launch_info()["kernel"] == kernel
     da = run_schedule(a, sched)
-    for o in (b, c2, c3):
+    for o in (b, c2, c3, c4, r1):
         do = run_schedule(o, sched)
         assert da[0].tobytes() == do[0].tobytes()
-        assert a.state().tobytes() == o.state().tobytes() and a.diag()["log_post"].tobytes() == o.diag()["log_post"].tobytes()
+        assert a.state().tobytes() == o.state().tobytes()
+        if o in (c3, c4, r1):
+            assert a.diag()["log_post"].tobytes() == o.diag()["log_post"].tobytes()
+        else:      # the lane-order kernels: the same chains, log_post in the last bits apart
+            assert np.allclose(a.diag()["log_post"], o.diag()["log_post"], rtol=1e-11, atol=0)
         assert a.info()["accepts"].tolist() == o.info()["accepts"].tolist() and a.diag()["uniforms"].tolist() == o.diag()["uniforms"].tolist()
-    a.close(); b.close(); c2.close(); c3.close()
+    for q in (a, b, c2, c3, c4, r1):
+        q.close()
 
 
 def test_translated_hierarchical_closure_at_full_size_runs_the_sweep_kernel_and_equals_the_hand_written_family():
@@ -179,22 +190,26 @@ def test_translated_hierarchical_closure_at_full_size_runs_the_sweep_kernel_and_
     from gpu_util import run_schedule
     gold = golden_io.load("cfg4_full")
     src, arrays, meta = user_host.translated("bench_hier")
-    assert (meta["rows_n_obs"], meta["rows_groups"], meta["rows_sweep"]) == (10000, 32, 1)
+    assert (meta["rows_n_obs"], meta["rows_groups"], meta["rows_sweep"], meta["rows_cert"]) == (10000, 32, 1, 1)
     for rec in gold["chains"]:
         spec = _golden_spec(gold, rec, src, arrays, meta)
         bspec = model_spec.spec_from_golden(gold, rec)
         kw = dict(chains=4, seed=gold["case"]["seed"], chain_offset=rec["chain"], lanes_per_chain=64)
         # (b: the hand-written family's sweep kernel in the same 64-lane order -- options.full_evaluation = 2; c: its default, the certified sweep kernel, which
         # decides against the expression in the reference's order: same draws, log_post in the last bits apart)
-        a, b, c = A.Sampler(spec, **kw), A.Sampler(bspec, full_evaluation=2, **kw), A.Sampler(bspec, **kw)
+        # (a: the closure's lane-order sweep kernel -- options.full_evaluation = 2; b: the hand-written family's, same 64-lane order; c: the family's default, the certified
+        # sweep kernel; e: round 6, the CLOSURE's default -- the translator's certified row plan, amwg_user_sweep_cert: decides against the expression in the reference's
+        # order like c: same draws as all of them, log_post the reference's own)
+        a, b, c, e = A.Sampler(spec, full_evaluation=2, **kw), A.Sampler(bspec, full_evaluation=2, **kw), A.Sampler(bspec, **kw), A.Sampler(spec, **kw)
         assert a.launch_info()["kernel"] == "amwg_user_sweep" and b.launch_info()["kernel"].startswith("amwg_sweep_kernel<") and c.launch_info()["kernel"].startswith("amwg_sweep_kernel_cert<")
-        da, db, dc = (run_schedule(q, gold["case"]["schedule"]) for q in (a, b, c))
-        assert all(x.tobytes() == y.tobytes() == z.tobytes() for x, y, z in zip(da, db, dc))
-        assert a.state().tobytes() == b.state().tobytes() == c.state().tobytes() and a.diag()["log_post"].tobytes() == b.diag()["log_post"].tobytes()
-        assert float(c.diag()["log_post"][0]) == rec["log_post"]      # the reference's own value
-        info = a.info()
-        assert info["accepts"][:, 0].tolist() == rec["accepts"] and info["inbounds"][:, 0].tolist() == rec["inbounds"] and int(a.diag()["uniforms"][0]) == rec["uniforms"]
-        a.close(); b.close(); c.close()
+        assert e.launch_info()["kernel"] == "amwg_user_sweep_cert" and e.launch_info()["summation_order"] == 1
+        da, db, dc, de = (run_schedule(q, gold["case"]["schedule"]) for q in (a, b, c, e))
+        assert all(x.tobytes() == y.tobytes() == z.tobytes() == w.tobytes() for x, y, z, w in zip(da, db, dc, de))
+        assert a.state().tobytes() == b.state().tobytes() == c.state().tobytes() == e.state().tobytes() and a.diag()["log_post"].tobytes() == b.diag()["log_post"].tobytes()
+        assert float(c.diag()["log_post"][0]) == rec["log_post"] and e.diag()["log_post"].tobytes() == c.diag()["log_post"].tobytes()      # the reference's own value
+        info = e.info()
+        assert info["accepts"][:, 0].tolist() == rec["accepts"] and info["inbounds"][:, 0].tolist() == rec["inbounds"] and int(e.diag()["uniforms"][0]) == rec["uniforms"]
+        a.close(); b.close(); c.close(); e.close()
 
 
 def test_certified_tail_of_a_translated_closure_decides_like_the_expression_and_the_family():

@@ -328,3 +328,20 @@ console.log(JSON.stringify(out));
     # lanes' three numbers then depend on entries other than their own -- lane reuse yes, sweep no; the same shapes off the vector keep the proof
     assert out["earlier_gather"] == [640, 8, 0, "false"] and out["sd_reads_theta"] == [640, 8, 0, "false"]
     assert out["sd_reads_mu"] == [640, 8, 1, "true"] and out["earlier_gather_other_vector"] == [640, 8, 1, "true", True]
+
+
+def test_constant_norm_inv_is_folded_to_the_device_functions_bits(tmp_path):
+    """translate.js foldConstantNormInv (round 6): `norm_inv(<literal>)` -- the loop invariants of ld.norm with a constant sd: V8's logarithm, two products, the
+    correctly rounded reciprocal and its low word from the exact residual (BigInt) -- becomes literals in the generated source; each must be the bits
+    csrc/amwg_user.h norm_inv() computes (tests/host/norm_inv_fold.cpp, 315 values of sd over 26 decades), and the README-style closures carry the folded form."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "norm_inv_fold")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(root, "bayes.js_amd", "csrc"),
+                           os.path.join(root, "tests", "host", "norm_inv_fold.cpp"), "-o", exe])
+    js = subprocess.run(["node", os.path.join(root, "tests", "js", "norm_inv_fold_cli.js")], capture_output=True, text=True, timeout=120)
+    assert js.returncode == 0, js.stderr[-1000:]
+    p = subprocess.run([exe], input=js.stdout, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "checked=315 unfolded=0 mismatches=0" in p.stdout, p.stdout[-1500:]
+    m = user_host.host_model("hier_normal_closure")
+    assert "/* norm_inv(10.0) */" in m.source and "norm_inv(10.0);" not in m.source

@@ -150,6 +150,14 @@ def cases(quick):
         uspec = {"user": user_host.user_spec_part(src, arrays, meta), "params": uparams, "P": 2, "init": [0.5, 0.5], "comp_opts": [dict(model_spec.DEFAULT_OPT) for _ in range(2)], "n_obs": 10000}
         out.append(dict(name="user_bench_normal", spec=uspec, chains=512 if quick else 65536, steps=150, lanes=1, state=None, seed=14))
         out.append(dict(name="user_bench_normal_sigma_1e-5", spec=uspec, chains=512, steps=100, lanes=1, state=[3.0, 1e-5], seed=15))
+        # ... and one with a ROW PLAN the translator marked kRowCert (csrc/amwg_rows.h: amwg_user_sweep_cert): BASELINE configs[3] as a plain closure, and a small one
+        for nm, nobs, G, ch, st in (("hier_normal_closure", 640, 8, 64 if quick else 512, 120), ("bench_hier", 10000, 32, 64 if quick else 2048, 40 if quick else 60)):
+            hsrc, harrays, hmeta = user_host.translated(nm) if nm == "bench_hier" else (user_host.host_model(nm).source, user_host.host_model(nm).arrays, user_host.host_model(nm).meta)
+            hparams = [{"type": "real", "len": G, "top": G, "multidim": 1, "lower": -inf, "upper": inf}, {"type": "real", "len": 1, "top": 1, "multidim": 0, "lower": -inf, "upper": inf},
+                       {"type": "real", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": inf}]
+            hspec = {"user": user_host.user_spec_part(hsrc, harrays, hmeta), "params": hparams, "P": G + 2, "init": [0.5] * G + [0.5, 1.0],
+                     "comp_opts": [dict(model_spec.DEFAULT_OPT) for _ in range(G + 2)], "n_obs": nobs}
+            out.append(dict(name="user_" + nm, spec=hspec, chains=ch, steps=st, lanes=64, state=None, seed=16))
     if not quick:
         # ---- BASELINE configs at full size
         out.append(normal_case("cfg2_full", model_spec.make_data("normal", 10000, 20260925)["x"], 65536, 150, seed=20260925))
