@@ -971,6 +971,8 @@ static int compile_user(const char *source, int lanes, int block, const char *ar
   const std::string prog_src = user_program(source, lanes, block);
 #if defined(AMWG_AUDIT)      // (libamwg_audit.so: the certified kernels of translated closures record |A - E| / eps as the built-in families' do)
   const char *const kOpts[] = {"-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-DAMWG_AUDIT=1"};
+#elif defined(AMWG_X_PHASES)      // (the phase-clock development build: translated closures are clocked too)
+  const char *const kOpts[] = {"-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-DAMWG_X_PHASES=1"};
 #else
   const char *const kOpts[] = {"-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-falign-loops=64"};
 #endif

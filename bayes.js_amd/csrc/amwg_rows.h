@@ -341,9 +341,6 @@ struct UserRows {
   template <int G, int BT>
   __device__ __forceinline__ static Approx log_post_approx(Cache &k, const StateView &S, const ModelConsts &, const DataRef &d, const unsigned char *smem, int sub) {
     if (d.pad <= 0) return Approx{0.0, __builtin_inf()};      // (wave-uniform: not the row layout -- the expression)
-#if defined(AMWG_X_CUT_LPA)
-    return Approx{0.0, __builtin_inf()};
-#endif
     load(k, smem, d.pad, sub);
     update_inv(k, M::row_sd(S, d));
     const HeadPair h = M::template head_pair<64>(S, d, smem, sub);
@@ -360,9 +357,6 @@ struct UserRows {
     SweepApprox out{false, -1, 0.0, 0.0, 0.0, 0.0, 0.0};
     if constexpr (M::kRowSweep) {
       if (d.pad <= 0) return out;      // (wave-uniform)
-#if defined(AMWG_X_CUT_SWA)
-      return out;
-#endif
       load(k, smem, d.pad, sub);
       update_inv(k, M::row_sd(S, d));
       const bool has = k.my_group >= 0;

@@ -2056,6 +2056,26 @@ Translator.prototype.rowPlan = function (body) {
     m2 = m2.replace(new RegExp(esc + ' = acc_save_;'), accV + ' = acc_save_; mag_ = mag_save_;');
     mag.push(m2);
   }
+  // (head_pair is instantiated for 64 lanes only.  A lane-split loop over at most 64 entries -- the proved sweep has one over the K <= 64 entries of the swept vector --
+  // gives a lane at most ONE iteration: its eight-wide block loop can never run and its remainder loop runs at most once.  Dropping the former from this copy of the
+  // text keeps the certified kernel's hot path small: three inlined heads per step.)
+  if (!certWhy) {
+    const slim = [];
+    let short = false, skipDepth = -1;
+    for (const ln of mag) {
+      const t = ln.trim();
+      const mN = /^const int i0_ = (\d+) \+ sub, n_ = \((\d+) - i0_ \+ G - 1\) \/ G;$/.exec(t);
+      if (mN) short = Number(mN[2]) - Number(mN[1]) <= 64;
+      if (skipDepth >= 0) {      // inside a dropped block loop: up to the line that closes it (same indentation as its `for`)
+        if (ln.length - ln.trimStart().length === skipDepth && t === '}') skipDepth = -1;
+        continue;
+      }
+      if (short && /^for \(; it_ \+ 8 <= n_; it_ \+= 8\) \{$/.test(t)) { skipDepth = ln.length - ln.trimStart().length; continue; }
+      slim.push(ln);
+    }
+    mag.length = 0;
+    for (const ln of slim) mag.push(ln);
+  }
   plan.cert = !certWhy && !this.opts.no_row_cert;
   plan.certWhy = certWhy || (this.opts.no_row_cert ? 'no: switched off (no_row_cert)' : 'yes');
   plan.headMag = mag;

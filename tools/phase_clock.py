@@ -26,6 +26,14 @@ cfg = int(sys.argv[sys.argv.index("--cfg") + 1]) if "--cfg" in sys.argv else 4
 if cfg == 4:
     d = model_spec.make_data("hier_normal", 10000, 20260925, G=32)
     spec, chains, lanes, steps = model_spec.build_spec("hier_normal", d), 2048, 64, 200
+elif cfg == 40:      # BASELINE configs[3] as a plain closure, translated: the certified row plan (amwg_user_sweep_cert)
+    import user_host
+    src, arrays, meta = user_host.translated("bench_hier")
+    inf = float("inf")
+    params = [{"type": "real", "len": 32, "top": 32, "multidim": 1, "lower": -inf, "upper": inf}, {"type": "real", "len": 1, "top": 1, "multidim": 0, "lower": -inf, "upper": inf},
+              {"type": "real", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": inf}]
+    spec = {"user": user_host.user_spec_part(src, arrays, meta), "params": params, "P": 34, "init": [0.5] * 32 + [0.5, 1.0], "comp_opts": [dict(model_spec.DEFAULT_OPT) for _ in range(34)]}
+    chains, lanes, steps = 2048, 64, 200
 elif cfg == 1:      # README.md:18-43 as is: ONE chain on the ten heights (the latency of one wavefront's dependent chain)
     spec, chains, lanes, steps = model_spec.build_spec("normal", {"x": np.array([183, 192, 182, 183, 177, 185, 188, 188, 182, 185], dtype=np.float64)}), 1, 64, 2000
 elif cfg == 2:
