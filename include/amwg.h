@@ -181,7 +181,11 @@ typedef struct {
    * with a stride of 64 and rows_groups <= 64 group means.  With 64 lanes per chain the library then lays the observations out in rows (one per lane)
    * and re-forms only the per-lane sums an update can have changed -- the same bits as evaluating everything (amwg_options::full_evaluation = 1
    * switches it off).  rows_sweep: the translator PROVED that a lane's sum depends on one entry of theta only, which allows the proposals of a whole
-   * sweep over theta to be evaluated in one pass (UserModel::kRowSweep in the source says the same).  0 / 0 / 0 = no row plan. */
+   * sweep over theta to be evaluated in one pass (UserModel::kRowSweep in the source says the same).  0 / 0 / 0 = no row plan.
+   * The struct carries no size or version field: amwg_create_user therefore honours these three only as far as the GENERATED SOURCE states the same
+   * (kRowN, kRowGroups, kRowSweep) and refuses a mismatch -- a caller built against an older, shorter struct cannot switch a layout on that the source has
+   * no code for.  Everything the translator added since is read from the source alone: kRowCert (certified decisions in the row layout: amwg_user_sweep_cert),
+   * kCertifiedTail / kTailN (certified decisions for a closure ending in a constant-mean normal loop: amwg_user_step_cert). */
   int32_t rows_n_obs, rows_groups, rows_sweep;
 } amwg_user_model;
 
