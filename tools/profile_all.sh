@@ -15,7 +15,8 @@ python tools/bound_audit.py --shrink --out gpurun_out/$T/${T}_bound_audit.json >
 python tools/flip_rate.py > gpurun_out/$T/${T}_flip_rate.json 2> gpurun_out/$T/${T}_flip_rate.log; tail -5 gpurun_out/$T/${T}_flip_rate.log
 python tools/certified_campaign.py --scale 0.5 > gpurun_out/$T/${T}_certified_campaign.json 2> gpurun_out/$T/${T}_certified_campaign.log; tail -3 gpurun_out/$T/${T}_certified_campaign.log
 cp gpurun_out/$T/${T}_flip_rate.json gpurun_out/$T/${T}_cfg*_summary.json profiles/ 2>/dev/null      # (so that the bench lines below find evidence of THESE kernels)
-python tools/phase_clock.py --cfg 4 > gpurun_out/$T/${T}_phase_clock.txt 2>&1; python tools/phase_clock.py --cfg 2 >> gpurun_out/$T/${T}_phase_clock.txt 2>&1; python tools/phase_clock.py --cfg 5 >> gpurun_out/$T/${T}_phase_clock.txt 2>&1
+[ -f build/phases/libamwg.so ] || bash tools/build_variant.sh phases -DAMWG_X_PHASES > /dev/null 2>&1      # (the phase-clock development build; the box has hipcc)
+python tools/phase_clock.py --cfg 4 > gpurun_out/$T/${T}_phase_clock.txt 2>&1; python tools/phase_clock.py --cfg 2 >> gpurun_out/$T/${T}_phase_clock.txt 2>&1; python tools/phase_clock.py --cfg 5 >> gpurun_out/$T/${T}_phase_clock.txt 2>&1; python tools/phase_clock.py --cfg 40 >> gpurun_out/$T/${T}_phase_clock.txt 2>&1; python tools/phase_clock.py --cfg 1 >> gpurun_out/$T/${T}_phase_clock.txt 2>&1
 python bench.py > gpurun_out/$T/${T}_bench_default.json 2> /dev/null; cp bench_detail.json gpurun_out/$T/${T}_bench_default_detail.json
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/$T/${T}_bench_driver_line.json 2> /dev/null; cp bench_detail.json gpurun_out/$T/${T}_bench_driver_line_detail.json
 python bench.py --workload cfg4 --weak --steps 300 --warmup 600 --no-cpu-baseline > gpurun_out/$T/${T}_bench_cfg4_line.json 2> /dev/null
