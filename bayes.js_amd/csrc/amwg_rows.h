@@ -91,13 +91,19 @@ struct UserRows {
     k.my_group = sub < M::kRowN ? (int)labels(smem, pitch)[sub] : -1;
   }
   // c, den and 1/den of the loop's sd: the same roundings in the same order as norm_inv (amwg_user.h), formed again only when sd changes
+  // (the logarithm and the division live out of line -- values by register, two calls as for the hand-written family's norm_cache_cold_a / _b --: sd changes in one
+  // update of a step's many, and inlined at every evaluation site the code was a tenth of the certified kernel's hot path)
+  struct InvA { double c, den; };
+  __device__ __attribute__((noinline)) static InvA inv_cold_a(double sd) { return InvA{norm_c(-0.5 * log_v8(2 * kPi), sd), norm_den(sd)}; }
+  __device__ __attribute__((noinline)) static Reciprocal inv_cold_b(double den) { return make_reciprocal(den); }
   __device__ __forceinline__ static void update_inv(Cache &k, double sd) {
     if (f64_bits(sd) == f64_bits(k.sd)) return;
+    const InvA a = inv_cold_a(sd);
     k.sd = sd;
-    k.c = norm_c(-0.5 * log_v8(2 * kPi), sd);
-    k.den = norm_den(sd);
-    k.y = make_reciprocal(k.den);
-    k.inv_fast = mid_range(k.den);
+    k.c = a.c;
+    k.den = a.den;
+    k.y = inv_cold_b(a.den);
+    k.inv_fast = mid_range(a.den);
   }
   __device__ __forceinline__ static double lane_double(double v, int src) {      // v of lane `src` (wave-uniform)
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(f64_bits(v) >> 32), src);
