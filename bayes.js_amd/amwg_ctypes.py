@@ -47,7 +47,7 @@ class UserModel(C.Structure):
 
 
 EXPORTS = ["amwg_kernel_name", "amwg_summation_order", "amwg_group_gather_draws", "amwg_group_comm_info", "amwg_comm_unique_id", "amwg_comm_create", "amwg_comm_info", "amwg_comm_gather_draws", "amwg_comm_moments", "amwg_comm_destroy", "amwg_code_cache_stats", "amwg_tuning", "amwg_group_moments", "amwg_group_diagnostics", "amwg_group_quantiles", "amwg_last_sample_quantiles", "amwg_fp64_peak", "amwg_set_state", "amwg_last_sample_diagnostics", "amwg_create_user", "amwg_compile_user", "amwg_num_recorded", "amwg_create", "amwg_burn", "amwg_burn_async", "amwg_sample", "amwg_sample_async", "amwg_fetch_draws", "amwg_fetch_draws_slices", "amwg_sample_device", "amwg_set_adapting", "amwg_get_state", "amwg_info", "amwg_chain_diag", "amwg_last_sample_moments", "amwg_sync", "amwg_num_components", "amwg_num_chains", "amwg_launch_info", "amwg_destroy", "amwg_last_error", "amwg_version", "amwg_exp", "amwg_log", "amwg_uniform"]      # include/amwg.h: the product library
-SELFTEST_EXPORTS = ["amwg_math1", "amwg_math2", "amwg_hypot3", "amwg_log1p", "amwg_expm1", "amwg_two_valued_sum_check", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_device_eval"]      # include/amwg_selftest.h: libamwg_selftest.so only
+SELFTEST_EXPORTS = ["amwg_prefault_selftest", "amwg_math1", "amwg_math2", "amwg_hypot3", "amwg_log1p", "amwg_expm1", "amwg_two_valued_sum_check", "amwg_pow", "amwg_ld_host", "amwg_ld_device", "amwg_device_eval"]      # include/amwg_selftest.h: libamwg_selftest.so only
 
 _lib = None
 
@@ -148,6 +148,7 @@ def selftest_lib():
         L.amwg_ld_host.restype = dbl
         L.amwg_ld_host.argtypes = [i32, dbl, dbl, dbl, dbl]
         L.amwg_ld_device.argtypes = [i32, i64, pd, pd]
+        L.amwg_prefault_selftest.argtypes = [C.c_void_p, C.c_size_t, i32, i32]
         _selftest = L
     return _selftest
 

@@ -1926,6 +1926,18 @@ int amwg_audit_fetch(amwg_sampler *s, double *per_chain, uint64_t *hist, int32_t
 #endif
 
 #if defined(AMWG_SELFTEST)
+// include/amwg_selftest.h: the host-side machinery that makes sample()'s destination resident ahead of the device-to-host copies (Prefaulter above), run on a
+// caller's buffer cut into `n_chunks` chunks with `threads` helpers: no byte may change, whatever the alignment and the sizes.  No GPU involved.
+int amwg_prefault_selftest(char *buf, size_t bytes, int32_t n_chunks, int32_t threads) {
+  if (!buf || n_chunks < 1 || threads < 0 || threads > 16) return fail(AMWG_EINVAL, "amwg_prefault_selftest: bad argument");
+  Prefaulter pf((size_t)n_chunks);
+  const size_t per = bytes / (size_t)n_chunks;
+  for (int32_t j = 0; j < n_chunks; ++j) pf.add(buf + (size_t)j * per, j == n_chunks - 1 ? bytes - (size_t)j * per : per, (size_t)j);
+  pf.start(threads);
+  for (int32_t j = 0; j < n_chunks; ++j) pf.wait_chunk((size_t)j);
+  return AMWG_OK;
+}
+
 int amwg_two_valued_sum_check(int32_t device, const double *x, int32_t n, int64_t m, const double *acc0, const double *l1, const double *l0,
                               double *out_fast_forward, double *out_term_by_term) {
   if (!x || !acc0 || !l1 || !l0 || !out_fast_forward || !out_term_by_term || n < 0 || m < 0) return fail(AMWG_EINVAL, "amwg_two_valued_sum_check: bad argument");

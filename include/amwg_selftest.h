@@ -30,6 +30,10 @@ int amwg_ld_device(int32_t device, int64_t n, const double *records, double *out
 int amwg_two_valued_sum_check(int32_t device, const double *x, int32_t n, int64_t m, const double *acc0, const double *l1, const double *l0,
                               double *out_fast_forward, double *out_term_by_term);
 
+/* The host machinery behind sample()'s copy-out (csrc/amwg_core.hip Prefaulter: huge pages, MADV_POPULATE_WRITE, helper threads that touch the destination ahead of
+ * the device-to-host copies) on a caller's buffer, cut into n_chunks chunks, with `threads` helpers (0 = the calling thread alone).  Changes no byte.  No GPU. */
+int amwg_prefault_selftest(char *buf, size_t bytes, int32_t n_chunks, int32_t threads);
+
 /* BOUND AUDIT build only (libamwg_audit.so = the library's sources compiled with -DAMWG_AUDIT; tools/bound_audit.py, tests/test_gpu_bound_audit.py).  The kernels that
  * decide accept tests from a cheaper value A of log_post and a bound eps (csrc/amwg_kernel.h "certified decisions") evaluate the reference's expression E in EVERY
  * update there as well and record how far apart the two really are:

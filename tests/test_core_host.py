@@ -176,3 +176,22 @@ def test_certified_bounds_host_replay_in_quad_precision(tmp_path):
                            os.path.join(root, "tests", "host", "bound_replay.cpp"), "-o", exe, "-lquadmath"])
     p = subprocess.run([exe, "25"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "bounds_hold=1" in p.stdout and "VIOLATION" not in p.stdout, p.stdout[-2000:]
+
+
+def test_copy_out_prefaulter_touches_without_changing_a_byte():
+    """csrc/amwg_core.hip Prefaulter (round 6: what makes sample()'s 1 GB copy-out run at the link's rate instead of the page-fault rate): on fresh, on
+    already-resident and on oddly aligned buffers, with 0 / 1 / 4 helper threads and more chunks than pieces, every byte stays what it was."""
+    import ctypes as C
+    import numpy as np
+    T = amwg_ctypes.selftest_lib()
+    rng = np.random.default_rng(5)
+    for nbytes, off, chunks, threads in ((1, 0, 1, 0), (4095, 1, 3, 1), (40 << 20, 0, 7, 4), (33 << 20, 13, 64, 4), (9 << 20, 4095, 2, 0)):
+        raw = np.zeros(nbytes + off + 16, dtype=np.uint8)      # (fresh pages: calloc-like)
+        view = raw[off:off + nbytes]
+        assert T.amwg_prefault_selftest(C.c_void_p(view.ctypes.data), nbytes, chunks, threads) == 0
+        assert not view.any()
+        view[:] = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        want = view.copy()
+        assert T.amwg_prefault_selftest(C.c_void_p(view.ctypes.data), nbytes, chunks, threads) == 0
+        assert np.array_equal(view, want)
+    assert T.amwg_prefault_selftest(None, 10, 1, 0) != 0
