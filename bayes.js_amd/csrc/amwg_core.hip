@@ -312,7 +312,10 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   // 512 registers of a workgroup of at most 256 threads; measured 1.34e9 against 7.2e8 for the scalar-path pass of the larger classes, so those are not picked unless asked for)
   const bool cert_one_lane = (!s->user && s->model == AMWG_MODEL_NORMAL && certified_wanted(s, 1, false)) || user_cert_wanted(s, 1);
   auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds && !(bt > 512 && hier_rows_wanted(s, G) && hier_rows_fit(s, 512, max_lds)) &&
-                                          !(bt > 512 && user_rows_wanted(s, G) && user_rows_fit(s, 512, max_lds)) && !(bt > 256 && G == 1 && cert_one_lane && !o.block_threads); };
+                                          !(bt > 512 && user_rows_wanted(s, G) && user_rows_fit(s, 512, max_lds)) && !(bt > 256 && G == 1 && cert_one_lane && !o.block_threads) &&
+                                          // (a closure's certified row plan -- amwg_user_sweep_cert -- keeps the generic head's values beside the stepper's: with the 256 registers of a
+                                          // 512-thread workgroup it spills ~520 of them (250 scratch accesses per step); 256-thread workgroups measured 2.35e9 against 1.87e9)
+                                          !(bt > 256 && G == 64 && user_rows_cert_wanted(s) && s->user_rows_sweep && user_rows_wanted(s, G) && user_rows_fit(s, 256, max_lds) && !o.block_threads); };
   if (s->user && !s->user_parallel && o.lanes_per_chain > 1)
     return fail(AMWG_EINVAL, "this closure has no loop that can be split over lanes: lanes_per_chain must be 1 (or 0 = auto), got %d", o.lanes_per_chain);
   const int bts[5] = {1024, 512, 256, 128, 64};

@@ -2059,7 +2059,7 @@ Translator.prototype.rowPlan = function (body) {
   // (head_pair is instantiated for 64 lanes only.  A lane-split loop over at most 64 entries -- the proved sweep has one over the K <= 64 entries of the swept vector --
   // gives a lane at most ONE iteration: its eight-wide block loop can never run and its remainder loop runs at most once.  Dropping the former from this copy of the
   // text keeps the certified kernel's hot path small: three inlined heads per step.)
-  if (!certWhy) {
+  if (!certWhy && !this.opts.no_slim_head) {
     const slim = [];
     let short = false, skipDepth = -1;
     for (const ln of mag) {
