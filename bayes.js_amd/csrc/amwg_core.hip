@@ -41,7 +41,7 @@ using namespace amwg;
 // together with the very same step kernel source the built-in models are compiled from.
 extern "C" {
 extern const char amwg_hdr_stdint[], amwg_hdr_types[], amwg_hdr_math[], amwg_hdr_div[], amwg_hdr_ld[], amwg_hdr_philox[],
-    amwg_hdr_kernel[], amwg_hdr_user[], amwg_hdr_twoval[], amwg_hdr_kval[], amwg_hdr_trig[], amwg_hdr_pass[], amwg_hdr_rows[], amwg_hdr_window[];
+    amwg_hdr_kernel[], amwg_hdr_user[], amwg_hdr_twoval[], amwg_hdr_kval[], amwg_hdr_trig[], amwg_hdr_pass[], amwg_hdr_rows[], amwg_hdr_window[], amwg_hdr_ptail[];
 }
 
 // the step kernels of the built-in families, one translation unit each (amwg_kernels.hip): kernel for (lanes per chain, workgroup size)
@@ -228,8 +228,10 @@ bool hier_rows_fit(const amwg_sampler *s, int bt, size_t max_lds);
 // the Normal family at one lane per chain stages its observations in LDS only for the wavefront's certified pass (NormalModel::lds_bytes_of: DataRef::pad = 1)
 static bool normal_tile_wanted(const amwg_sampler *s, int bt) { return !s->user && s->model == AMWG_MODEL_NORMAL && certified_wanted(s, 1, false) && bt <= 256 && !s->opt.sufficient_statistics; }
 // ... a translated closure with a certified tail (amwg_user.h norm_tail_approx; read off the generated source by amwg_create_user): one lane per chain
+// ... or a certified Poisson tail (amwg_ptail.h pois_tail_approx; kPoisTail of the generated source): 16 lanes per chain, four chains sharing every row they read
 static bool user_cert_wanted(const amwg_sampler *s, int lanes) {
-  return s->user && s->user_cert_tail_n > 0 && lanes == 1 && s->opt.full_evaluation == 0 && !s->opt.exact_division && !s->user_has_binary;
+  if (!s->user || s->opt.full_evaluation != 0 || s->opt.exact_division || s->user_has_binary) return false;
+  return (s->user_cert_tail_n > 0 && lanes == 1) || (s->user_pois_tail_n > 0 && lanes == 16);
 }
 // ... and a closure whose row plan the translator marked kRowCert: the sweep kernel decides from certified values, against the expression in the reference's order
 static bool user_rows_cert_wanted(const amwg_sampler *s) { return s->user && s->user_rows_cert && s->opt.full_evaluation == 0 && !s->opt.exact_division && !s->user_has_binary; }
@@ -256,6 +258,10 @@ double model_work(const amwg_sampler *s, int G) {
       return w;
     }
     case AMWG_MODEL_POIS_GLM: return (G == 16 && s->opt.full_evaluation == 0 && !s->opt.exact_division) ? 36.0 * N : 90.0 * N;      // (16 lanes per chain: the certified pass, four chains sharing every row they read)
+  }
+  if (user_cert_wanted(s, G) && s->user_pois_tail_n > 0) {      // exp + log per observation (~70 of the term's operations) become exp_bounded's 19, and a row is read once for four chains
+    const double n = (double)s->user_pois_tail_n, w = s->user_work > 0 ? s->user_work : 1e6;
+    return (w - 70.0 * n > 0.4 * w) ? w - 70.0 * n : 0.4 * w;
   }
   if (user_cert_wanted(s, G)) {      // the tail loop's ~16 instructions per observation become the certified pass's 2.6
     const double w1 = s->user_work_one_lane > 0 ? s->user_work_one_lane : s->user_work, n = (double)s->user_cert_tail_n;
@@ -967,9 +973,9 @@ static void dump_code_object(const std::vector<char> &code) {      // developmen
 // use_cache = false: compile even if the on-disk cache has the object (the caller found the cached one unloadable)
 static int compile_user(const char *source, int lanes, int block, const char *arch, std::vector<char> *code, bool use_cache = true) {
   static const char *names[] = {"amwg_stdint.h", "amwg_types.h", "amwg_math.h", "amwg_div.h", "amwg_ld.h", "amwg_philox.h",
-                                "amwg_kernel.h", "amwg_user.h", "amwg_twoval.h", "amwg_kval.h", "amwg_trig.h", "amwg_pass.h", "amwg_rows.h", "amwg_window.h"};
+                                "amwg_kernel.h", "amwg_user.h", "amwg_twoval.h", "amwg_kval.h", "amwg_trig.h", "amwg_pass.h", "amwg_rows.h", "amwg_window.h", "amwg_ptail.h"};
   const char *texts[] = {amwg_hdr_stdint, amwg_hdr_types, amwg_hdr_math, amwg_hdr_div, amwg_hdr_ld, amwg_hdr_philox,
-                         amwg_hdr_kernel, amwg_hdr_user, amwg_hdr_twoval, amwg_hdr_kval, amwg_hdr_trig, amwg_hdr_pass, amwg_hdr_rows, amwg_hdr_window};
+                         amwg_hdr_kernel, amwg_hdr_user, amwg_hdr_twoval, amwg_hdr_kval, amwg_hdr_trig, amwg_hdr_pass, amwg_hdr_rows, amwg_hdr_window, amwg_hdr_ptail};
   constexpr int kHeaders = (int)(sizeof(texts) / sizeof(texts[0]));
   const std::string prog_src = user_program(source, lanes, block);
 #if defined(AMWG_AUDIT)      // (libamwg_audit.so: the certified kernels of translated closures record |A - E| / eps as the built-in families' do)
@@ -1392,6 +1398,8 @@ int amwg_create_user(const amwg_user_model *m, const amwg_param_desc *params, in
     s->user_rows_cert = s->user_rows_sweep && strstr(m->source, "kRowCert = true") != nullptr;
     const long tail_n = strstr(m->source, "kCertifiedTail = true") ? int_after("kTailN = ") : 0;
     s->user_cert_tail_n = tail_n > 0 && tail_n < (1l << 28) ? (int)tail_n : 0;
+    const long ptail_n = strstr(m->source, "kPoisTail = true") ? int_after("kTailN = ") : 0;
+    s->user_pois_tail_n = ptail_n > 0 && ptail_n < (1l << 28) ? (int)ptail_n : 0;
   }
   s->C = options->chains;
   s->device = options->device;

@@ -18,3 +18,4 @@ AMWG_TEXT(amwg_hdr_trig, "amwg_trig.h");
 AMWG_TEXT(amwg_hdr_pass, "amwg_pass.h");
 AMWG_TEXT(amwg_hdr_rows, "amwg_rows.h");
 AMWG_TEXT(amwg_hdr_window, "amwg_window.h");
+AMWG_TEXT(amwg_hdr_ptail, "amwg_ptail.h");

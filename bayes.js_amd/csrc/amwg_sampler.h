@@ -45,6 +45,7 @@ struct amwg_sampler {
   int user_rows_n = 0, user_rows_groups = 0, user_rows_sweep = 0;   // row plan of a translated closure (amwg_rows.h): observations and groups of its final likelihood loop; 0 = none
   bool user_rows_cert = false;     // the row plan has certified values (kRowCert of the generated source: amwg_rows.h log_post_approx / sweep_approx / reference_order)
   int user_cert_tail_n = 0;        // certified tail of a translated closure (amwg_user.h norm_tail_approx): observations of its final constant-mean normal loop (kTailN of the generated source); 0 = none
+  int user_pois_tail_n = 0;        // certified Poisson tail of a translated closure (amwg_ptail.h pois_tail_approx): observations of its final log-link Poisson loop (kPoisTail / kTailN of the generated source); 0 = none
   bool user_sweep = false, user_has_binary = false;                  // the chosen geometry runs amwg_user_sweep; the model has binary parameters
   double user_work = 0;            // translator's estimate of the instructions of one log_post evaluation
   double user_work_one_lane = 0;   // the same with one lane per chain when that enables a fast-forwarded sum (0 = n/a)

@@ -269,3 +269,4 @@ AMWG_HD double js_fround(double a) { return (double)(float)a; }
 }  // namespace amwg
 
 #include "amwg_rows.h"      // lane-local re-evaluation + sweep prefetch for closures with a row plan (device only)
+#include "amwg_ptail.h"     // certified values for closures that end in a log-link Poisson loop (device only)

@@ -1480,8 +1480,77 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
         this.otherSplitLoops = (this.otherSplitLoops || 0) + 1;      // (one lane per chain gains nothing here: the data stays in LDS)
         return;
       }
+      // `for (i = 0; i < y.length; i++) { <eta from the state and row i>; lp += ld.pois(y[i], Math.exp(eta)); }` over whole arrays of counts: CERTIFIED POISSON TAIL
+      // candidate (csrc/amwg_ptail.h).  run() decides (it must be the LAST statement: poisTailPlan); the loop itself is emitted as any other lane-split loop.
+      const mp = /^ld_pois_pre_exp\(((?:\(double\))?)A(\d+)\[v_(\w+)\], (.+), A(\d+)\[v_\3\]\)$/.exec(term.code);
+      let ptailCand = false;
+      if (mp && mp[3] === canon.name && startV.cst === 0 && !canon.le && L.preamble.length === 0 && !this.isHelper && !this.opts.no_cert_tail && !this.linear && this.acc &&
+          loopAcc === this.acc && indent === '    ' && !this.condDepth) {
+        const ya = this.arrays[Number(mp[2])], la = this.arrays[Number(mp[5])], text = bodyText + ' ' + mp[4];
+        let ok = ya.type !== 0 && boundV.cst === ya.flat.length && boundV.cst === la.flat.length && boundV.cst >= 64 && !/\b(sub|G|dq_\w+|dv|return|goto|tb_\w*|it_\w*|u_|rr_)\b/.test(text);
+        for (let i = 0; ok && i < ya.flat.length; i++) ok = ya.flat[i] >= 0 && Number.isFinite(la.flat[i]);      // (a negative count: the reference's term is -inf)
+        // are the state's entries the statements read the same for every observation?  Every S(index): a constant, or constant + the counter of an inner loop with
+        // constant bounds (and nothing else writes that counter).  Then the pass keeps the four chains' entries in scalar registers (UniformState).
+        let uniform = ok;
+        if (ok) {
+          const counters = new Set();
+          let rest = text.replace(/for \((v_\w+) = (\d+); \1 < (\d+); \1 \+= 1\)/g, (q, nm) => { counters.add(nm); return 'for ()'; });
+          for (const nm of counters) if (new RegExp('\\b' + nm.replace(/[$]/g, '\\$') + '\\s*(?:[-+*/%]?=[^=]|\\+\\+|--)').test(rest) || nm === 'v_' + canon.name) uniform = false;
+          for (let at = text.indexOf('S('); uniform && at >= 0; at = text.indexOf('S(', at + 1)) {
+            if (at > 0 && /[\w.]/.test(text[at - 1])) continue;      // (an identifier that merely ends in S)
+            let depth = 0, end = at + 1;
+            for (; end < text.length; end++) { if (text[end] === '(') depth++; else if (text[end] === ')' && --depth === 0) break; }
+            const arg = text.slice(at + 2, end), ma = /^(?:\d+|(?:\d+ \+ )?(v_\w+))$/.exec(arg);
+            if (!ma || (ma[1] && !counters.has(ma[1]))) uniform = false;
+          }
+          if (/\bS\b(?!\()/.test(text)) ok = false;      // (the state handed on as a whole)
+        }
+        // ROW CACHE: does every read of a data array in the statements address observation i's own row -- `A[i]`, `A[i * K + c]`, `A[i * K + counter]` (c, the counter's
+        // range inside [0, K))?  Then the pass loads a row into registers a round AHEAD of its use (ptail_load / ptail_eta_row: the statements with the reads replaced by
+        // the row's entries) instead of waiting for every row where its first product needs it.
+        let rowInfo = null;
+        if (ok && uniform && !this.opts.no_tail_rows) {
+          const iv = 'v_' + canon.name, ivE = iv.replace(/[$]/g, '\\$'), cb = {};
+          text.replace(/for \((v_\w+) = (\d+); \1 < (\d+); \1 \+= 1\)/g, (q, nm, lo, hi) => { cb[nm] = cb[nm] ? [Math.min(cb[nm][0], +lo), Math.max(cb[nm][1], +hi)] : [+lo, +hi]; return q; });
+          const per = {};
+          per[Number(mp[2])] = { stride: 1, lo: 0, hi: 1 };      // (the count itself)
+          const scan = (t) => {      // -> [{at, end, j, rel}] or null
+            const reads = [], re = /\bA(\d+)\[/g;
+            let m;
+            while ((m = re.exec(t))) {
+              let depth = 0, end = m.index + m[0].length - 1;
+              for (; end < t.length; end++) { if (t[end] === '[') depth++; else if (t[end] === ']' && --depth === 0) break; }
+              const idx = t.slice(m.index + m[0].length, end), j = Number(m[1]);
+              let mm, stride, lo, hi, rel = '0';
+              if (idx === iv) { stride = 1; lo = 0; hi = 1; }
+              else if ((mm = new RegExp('^\\(' + ivE + ' \\* (\\d+)\\)$').exec(idx))) { stride = +mm[1]; lo = 0; hi = 1; }
+              else if ((mm = new RegExp('^\\(\\(' + ivE + ' \\* (\\d+)\\) \\+ (\\d+|v_\\w+)\\)$').exec(idx))) {
+                stride = +mm[1]; rel = mm[2];
+                if (/^\d+$/.test(rel)) { lo = +rel; hi = lo + 1; } else if (cb[rel]) { lo = cb[rel][0]; hi = cb[rel][1]; } else return null;
+              } else return null;
+              if (lo < 0 || hi > stride || (per[j] && per[j].stride !== stride) || stride * boundV.cst > this.arrays[j].flat.length) return null;
+              per[j] = per[j] ? { stride, lo: Math.min(per[j].lo, lo), hi: Math.max(per[j].hi, hi) } : { stride, lo, hi };
+              reads.push({ at: m.index, end, j, rel });
+            }
+            return reads;
+          };
+          const rb = scan(bodyText), re2 = scan(mp[4]);
+          let words = 0;
+          for (const j of Object.keys(per)) words += (per[j].hi - per[j].lo) * (this.arrays[j].ctype === 'double' ? 2 : 1);
+          if (rb && re2 && words <= 40) {
+            const rewrite = (t, reads) => { let o = t; for (let q = reads.length - 1; q >= 0; q--) { const r = reads[q]; o = o.slice(0, r.at) + 'R.a' + r.j + '[(' + r.rel + ') - ' + per[r.j].lo + ']' + o.slice(r.end + 1); } return o; };
+            rowInfo = { per, body: rewrite(bodyText, rb), eta: rewrite(mp[4], re2) };
+          }
+        }
+        if (ok) {
+          ptailCand = true;
+          this.ptailInfo = { y: Number(mp[2]), lf: Number(mp[5]), cast: mp[1], n: boundV.cst, acc: loopAcc, i: canon.name, uniform, eta: mp[4], body: bodyText, rows: rowInfo };
+          out.push(indent + '//@PTAIL');
+        }
+      }
       this.otherSplitLoops = (this.otherSplitLoops || 0) + 1;
       this.emitSplit(out, indent, L.preamble, head, loop, [loopAcc]);
+      if (ptailCand) out.push(indent + '//@PTAIL_END');
       return;
     }
     this.loopLabels.push({ native: true });
@@ -1804,6 +1873,7 @@ Translator.prototype.run = function () {
   const maxThreads = this.opts.max_threads || (this.heavyLoop ? (off > 73728 ? 512 : 256) : 1024);
   const rows = this.rowPlan(body);
   const tail = rows ? null : this.tailPlan(body);
+  const ptail = (rows || tail) ? null : this.poisTailPlan(body);
   const src = [];
   src.push('// generated by bayes.js_amd/translate.js from the user\'s log_post closure');
   src.push('namespace amwg {');
@@ -1897,6 +1967,81 @@ Translator.prototype.run = function () {
     src.push('    return norm_tail_approx<UserModel, G, BT>(S, d, smem, sub);');
     src.push('  }');
   }
+  if (ptail) {
+    // CERTIFIED POISSON TAIL (csrc/amwg_ptail.h; amwg_kernel.h "certified decisions"): with 16 lanes per chain the stepper decides accept tests from
+    // head + sum eta y - sum e^eta - sum lfactorial(y) and its bound, and evaluates the closure in the reference's order where that does not decide
+    const arrDecl = (j) => { const a = this.arrays[j], pl = plan[j];
+      return '    const ' + a.ctype + ' *A' + j + ' = ' + (pl.lds ? 'reinterpret_cast<const ' + a.ctype + ' *>(smem + ' + pl.off + ')' : 'static_cast<const ' + a.ctype + ' *>(user_arr<' + j + '>(d))') + ';'; };
+    src.push('  // ---- certified Poisson tail: `' + ptail.acc + '` ends in  for (i < ' + ptail.n + ') { ...; ' + ptail.acc + ' += ld.pois(A' + ptail.y + '[i], Math.exp(eta)) }');
+    src.push('  static constexpr bool kPoisTail = true, kCertified = true, kReferenceOrder = true;');
+    src.push('  static constexpr int kCertifiedLanes = 16, kTailN = ' + ptail.n + ', kStateN = ' + this.P + ';');
+    src.push('  static constexpr bool kTailUniformState = ' + (ptail.uniform && this.P <= 12 ? 'true' : 'false') + ';      // the entries of the state the loop reads do not depend on the observation (and are few): scalar registers');
+    src.push('  typedef TailApprox Approx;');
+    src.push('  __device__ __forceinline__ static double ptail_sum_y() { return ' + hexFloat(ptail.sumY) + '; }      // sum y[i] = ' + ptail.sumY);
+    src.push('  __device__ __forceinline__ static double ptail_sum_lf() { return ' + hexFloat(ptail.sumLF) + '; }      // sum lfactorial(y[i]) = ' + ptail.sumLF);
+    src.push('  __device__ __forceinline__ static double ptail_y(const DataRef &d, const unsigned char *smem, int i) { (void)d; (void)smem;');
+    src.push(arrDecl(ptail.y));
+    src.push('    return (double)A' + ptail.y + '[i]; }');
+    src.push('  __device__ __forceinline__ static double ptail_lf(const DataRef &d, const unsigned char *smem, int i) { (void)d; (void)smem;');
+    src.push(arrDecl(ptail.lf));
+    src.push('    return A' + ptail.lf + '[i]; }');
+    src.push('  // the loop\'s statements up to the term: eta of observation v_' + ptail.i + ' for the chain whose state is S');
+    src.push('  template <class SV>');
+    src.push('  __device__ __forceinline__ static double ptail_eta(const SV &S, const DataRef &d, const unsigned char *smem, const int v_' + ptail.i + ') {');
+    this.arrays.forEach((a, j) => src.push(arrDecl(j)));
+    src.push('    (void)smem; (void)d; (void)S;');
+    for (const dl of ptail.decls) src.push('    ' + dl);
+    src.push('    ' + ptail.body);
+    src.push('    return ' + ptail.eta + ';');
+    src.push('  }');
+    src.push('  static constexpr bool kTailRows = ' + (ptail.rows ? 'true' : 'false') + ';      // every data read of the statements addresses the observation\'s own row: loaded a round ahead (ptail_load)');
+    if (ptail.rows) {
+      const per = ptail.rows.per, js = Object.keys(per).map(Number).sort((a, b) => a - b);
+      src.push('  struct TailRow { ' + js.map((j) => this.arrays[j].ctype + ' a' + j + '[' + (per[j].hi - per[j].lo) + '];').join(' ') + ' };');
+      src.push('  __device__ __forceinline__ static void ptail_load(const DataRef &d, const unsigned char *smem, const int v_' + ptail.i + ', TailRow &R) {');
+      for (const j of js) src.push(arrDecl(j));
+      src.push('    (void)smem; (void)d;');
+      for (const j of js) {
+        src.push('#pragma unroll');
+        src.push('    for (int q_ = 0; q_ < ' + (per[j].hi - per[j].lo) + '; ++q_) R.a' + j + '[q_] = A' + j + '[v_' + ptail.i + ' * ' + per[j].stride + ' + ' + per[j].lo + ' + q_];');
+      }
+      src.push('  }');
+      src.push('  __device__ __forceinline__ static double ptail_y_row(const TailRow &R) { return (double)R.a' + ptail.y + '[0]; }');
+      src.push('  template <class SV>');
+      src.push('  __device__ __forceinline__ static double ptail_eta_row(const SV &S, const TailRow &R, const int v_' + ptail.i + ') {');
+      src.push('    (void)S; (void)R;');
+      for (const dl of ptail.decls) src.push('    ' + dl);
+      src.push('    ' + ptail.rows.body);
+      src.push('    return ' + ptail.rows.eta + ';');
+      src.push('  }');
+    }
+    src.push('  // the closure up to that loop: what its accumulator holds when the loop begins (this lane\'s share)');
+    src.push('  template <int G>');
+    src.push('  __device__ static double tail_head(const StateView &S, const DataRef &d, const unsigned char *smem, int sub) {');
+    this.arrays.forEach((a, j) => src.push(arrDecl(j)));
+    src.push('    (void)smem; (void)sub; (void)d;');
+    for (const ln of ptail.head) src.push(ln);
+    src.push('    return v_' + ptail.acc + ';');
+    src.push('  }');
+    src.push('  __device__ static double ptail_head_sequence(const StateView &S, const DataRef &d, const unsigned char *smem) { return tail_head<1>(S, d, smem, 0); }      // (one lane\'s walk: the reference\'s order)');
+    src.push('  // ... with the magnitudes of what it adds up and the number of additions');
+    src.push('  template <int G>');
+    src.push('  __device__ __forceinline__ static HeadPair ptail_head(const StateView &S, const DataRef &d, const unsigned char *smem, int sub) {');
+    this.arrays.forEach((a, j) => src.push(arrDecl(j)));
+    src.push('    (void)smem; (void)sub; (void)d;');
+    src.push('    double mag_ = 0.0, cnt_ = 0.0;');
+    for (const ln of ptail.headMag) src.push(ln);
+    src.push('    return HeadPair{v_' + ptail.acc + ', mag_, cnt_};');
+    src.push('  }');
+    src.push('  template <int G, int BT, class C>');
+    src.push('  __device__ __forceinline__ static Approx log_post_approx(C &, const StateView &S, const ModelConsts &, const DataRef &d, const unsigned char *smem, int sub) {');
+    src.push('    return pois_tail_approx<UserModel, G, BT>(S, d, smem, sub);');
+    src.push('  }');
+    src.push('  template <int G, class C>');
+    src.push('  __device__ __forceinline__ static double reference_order(C &, const StateView &S, const ModelConsts &, const DataRef &d, const unsigned char *smem, int sub) {');
+    src.push('    return pois_tail_reference<UserModel, G>(S.base, &d, smem, sub);');
+    src.push('  }');
+  }
   src.push('#endif');
   src.push('  template <int G, bool DERIVE>');
   src.push('  AMWG_HD static double eval(const StateView &S, const DataRef &d, const unsigned char *smem, int sub, double *dv) {');
@@ -1938,6 +2083,8 @@ Translator.prototype.run = function () {
     // same fact off the generated source -- kCertifiedTail / kTailN -- so no field of amwg_user_model carries it.)
     cert_tail_n: tail ? tail.n : 0,
     rows_cert: rows && rows.cert ? 1 : 0,
+    // certified Poisson tail (csrc/amwg_ptail.h): observations of the closure's final log-link Poisson loop; 0 = none (the host library reads kPoisTail / kTailN off the source)
+    pois_tail_n: ptail ? ptail.n : 0,
   };
 };
 
@@ -1956,6 +2103,62 @@ Translator.prototype.tailPlan = function (body) {
   const head = body.slice(0, iB);
   if (head.some((ln) => /\breturn\b|\bdv\[|\bdq_/.test(ln))) return null;
   return { x: Number(m[1]), n: Number(m[2]), acc: m[3], mean: m[4], sd: m[5], head };
+};
+
+// The CERTIFIED POISSON TAIL of a closure (csrc/amwg_ptail.h): its LAST statement before `return acc` is the log-link Poisson loop forLoop() marked with //@PTAIL;
+// everything before is the head -- it must not return early, must be nothing but accumulations (headMagnitude), and the closure must not write derived quantities.
+// -> {y, lf (array indices), n, acc, i, uniform, eta, body, decls, head, headMag, sumY, sumLF} or null
+Translator.prototype.poisTailPlan = function (body) {
+  if (!this.ptailInfo || this.derived.length || this.isHelper || this.opts.no_cert_tail || this.opts.no_pois_tail || this.hasBinary) return null;
+  let iB = -1, iE = -1, nB = 0;
+  body.forEach((ln, i) => { const t = ln.trim(); if (t === '//@PTAIL') { iB = i; nB++; } else if (t === '//@PTAIL_END') iE = i; });
+  if (nB !== 1 || iE < iB) return null;      // (ptailInfo describes the last candidate: it must be the only one)
+  const info = this.ptailInfo;
+  const tailLines = body.slice(iE + 1).map((ln) => ln.trim()).filter((t) => t && t.indexOf('//') !== 0);
+  if (!(tailLines.length === 2 && /^if constexpr \(DERIVE\) \{ \(void\)dv; \}$/.test(tailLines[0]) && tailLines[1] === 'return v_' + info.acc + ';')) return null;
+  const head = body.slice(0, iB);
+  if (head.some((ln) => /\breturn\b|\bdv\[|\bdq_/.test(ln))) return null;
+  const hm = this.headMagnitude(head, info.acc);
+  if (hm.why) return null;
+  // the closure's locals (declared at the top of the body): the loop's statements use them as scratch
+  const decls = [];
+  for (const ln of head) { const m = /^(double|int) (v_\w+) = 0;$/.exec(ln.trim()); if (m && m[2] !== 'v_' + info.i) decls.push(ln.trim()); }
+  // sum y (integers: exact) and sum lfactorial(y) (Neumaier's compensated sum: within an ulp or two of the real sum of the stored values)
+  let sumY = 0, sF = 0, cF = 0;
+  const yf = this.arrays[info.y].flat, lf = this.arrays[info.lf].flat;
+  for (let i = 0; i < info.n; i++) {
+    sumY += yf[i];
+    const t = sF + lf[i];
+    cF += Math.abs(sF) >= Math.abs(lf[i]) ? (sF - t) + lf[i] : (lf[i] - t) + sF;
+    sF = t;
+  }
+  return Object.assign({}, info, { decls, head, headMag: hm.mag, sumY, sumLF: sF + cF });
+};
+
+// The head of a plan (everything before the closure's final loop) as value + MAGNITUDES: the certified values bound the two orders the head's terms are summed in
+// through the magnitudes of what it adds up, which needs the head to be nothing but accumulations -- every line that mentions the accumulator must be its
+// declaration, `acc = (sub == 0) ? X : 0.0;`, `[if (sub == 0)] acc += X;` (also inside the lane-split loops), the save / restore around a loop's slow replay.
+// -> {why ('' = fine), mag: the same text with every added value's magnitude summed into mag_ and the additions counted in cnt_}
+Translator.prototype.headMagnitude = function (head, acc) {
+  const accV = 'v_' + acc;
+  const esc = accV.replace(/[$]/g, '\\$');
+  const okLine = new RegExp('^(?:double ' + esc + ' = 0;|' + esc + ' = \\(sub == 0\\) \\? .+ : 0\\.0;|(?:if \\(sub == 0\\) )?' + esc + ' \\+= .+;|const double acc_save_ = ' + esc + ';|' + esc + ' = acc_save_;|for \\(.*\\) ' + esc + ' \\+= [^;]+;|for \\(.*\\) \\{ .*' + esc + ' \\+= [^;]+; \\})$');
+  let why = '';
+  const mag = [];
+  for (const ln0 of head) {
+    const t = ln0.trim();
+    if (why) break;
+    if (t.indexOf(accV) < 0 || t.indexOf('//') === 0) { mag.push(ln0); continue; }
+    if (!okLine.test(t)) { why = 'no: the head does more with ' + acc + ' than add to it: `' + t.slice(0, 70) + '`'; break; }
+    // (value, magnitude and count in ONE walk over the head's statements)
+    let m2 = ln0;
+    m2 = m2.replace(new RegExp(esc + ' = \\(sub == 0\\) \\? (.+) : 0\\.0;'), (q, X) => '{ const double x_ = (sub == 0) ? (' + X + ') : 0.0; ' + accV + ' = x_; mag_ = __builtin_fabs(x_); if (sub == 0) cnt_ += 1.0; }');
+    m2 = m2.replace(new RegExp(esc + ' \\+= ([^;]+);', 'g'), (q, X) => '{ const double x_ = ' + X + '; ' + accV + ' += x_; mag_ += __builtin_fabs(x_); cnt_ += 1.0; }');
+    m2 = m2.replace(new RegExp('const double acc_save_ = ' + esc + ';'), 'const double acc_save_ = ' + accV + ', mag_save_ = mag_;');
+    m2 = m2.replace(new RegExp(esc + ' = acc_save_;'), accV + ' = acc_save_; mag_ = mag_save_;');
+    mag.push(m2);
+  }
+  return { why, mag };
 };
 
 // The ROW PLAN of a closure (csrc/amwg_rows.h): its LAST statement before `return acc` is the gathered normal loop forLoop() marked with //@ROWS, over all
@@ -2038,24 +2241,9 @@ Translator.prototype.rowPlan = function (body) {
   // bounded through the MAGNITUDES of what the head adds up, which needs the head to be nothing but accumulations: every line that mentions the accumulator must be its
   // declaration, `acc = (sub == 0) ? X : 0.0;`, `[if (sub == 0)] acc += X;` (also inside the lane-split loops), the save / restore around a loop's slow replay, or the
   // return.  head_mag is the same text with every added value replaced by its magnitude and a count of the additions beside it.
-  const accV = 'v_' + plan.acc;
-  const esc = accV.replace(/[$]/g, '\\$');
-  const okLine = new RegExp('^(?:double ' + esc + ' = 0;|' + esc + ' = \\(sub == 0\\) \\? .+ : 0\\.0;|(?:if \\(sub == 0\\) )?' + esc + ' \\+= .+;|const double acc_save_ = ' + esc + ';|' + esc + ' = acc_save_;|for \\(.*\\) ' + esc + ' \\+= [^;]+;|for \\(.*\\) \\{ .*' + esc + ' \\+= [^;]+; \\})$');
-  let certWhy = plan.sweep ? '' : 'no: the sweep is not proved';
-  const mag = [];
-  for (const ln0 of head) {
-    const t = ln0.trim();
-    if (certWhy) break;
-    if (t.indexOf(accV) < 0 || t.indexOf('//') === 0) { mag.push(ln0); continue; }
-    if (!okLine.test(t)) { certWhy = 'no: the head does more with ' + plan.acc + ' than add to it: `' + t.slice(0, 70) + '`'; break; }
-    // (value, magnitude and count in ONE walk over the head's statements: head_pair)
-    let m2 = ln0;
-    m2 = m2.replace(new RegExp(esc + ' = \\(sub == 0\\) \\? (.+) : 0\\.0;'), (q, X) => '{ const double x_ = (sub == 0) ? (' + X + ') : 0.0; ' + accV + ' = x_; mag_ = __builtin_fabs(x_); if (sub == 0) cnt_ += 1.0; }');
-    m2 = m2.replace(new RegExp(esc + ' \\+= ([^;]+);', 'g'), (q, X) => '{ const double x_ = ' + X + '; ' + accV + ' += x_; mag_ += __builtin_fabs(x_); cnt_ += 1.0; }');
-    m2 = m2.replace(new RegExp('const double acc_save_ = ' + esc + ';'), 'const double acc_save_ = ' + accV + ', mag_save_ = mag_;');
-    m2 = m2.replace(new RegExp(esc + ' = acc_save_;'), accV + ' = acc_save_; mag_ = mag_save_;');
-    mag.push(m2);
-  }
+  const hm = this.headMagnitude(head, plan.acc);
+  let certWhy = plan.sweep ? hm.why : 'no: the sweep is not proved';
+  const mag = hm.mag;
   // (head_pair is instantiated for 64 lanes only.  A lane-split loop over at most 64 entries -- the proved sweep has one over the K <= 64 entries of the swept vector --
   // gives a lane at most ONE iteration: its eight-wide block loop can never run and its remainder loop runs at most once.  Dropping the former from this copy of the
   // text keeps the certified kernel's hot path small: three inlined heads per step.)

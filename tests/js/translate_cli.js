@@ -26,5 +26,5 @@ for (const name of (want.length ? want : um.names)) {
   }
   fs.writeFileSync(path.join(out, name + '.arrays.bin'), buf);
   fs.writeFileSync(path.join(out, name + '.meta.json'), JSON.stringify({ name, P: tr.P, derived: tr.derived, lds_bytes: tr.lds_bytes, lds_bytes_one_lane: tr.lds_bytes_one_lane,
-    parallel: tr.parallel, max_threads: tr.max_threads, work_per_eval: tr.work_per_eval, work_one_lane: tr.work_one_lane, rows_n_obs: tr.rows_n_obs, rows_groups: tr.rows_groups, rows_sweep: tr.rows_sweep, cert_tail_n: tr.cert_tail_n, rows_cert: tr.rows_cert, array_keys: tr.array_keys, array_types: tr.array_types, array_len: tr.arrays.map((a) => a.length) }));
+    parallel: tr.parallel, max_threads: tr.max_threads, work_per_eval: tr.work_per_eval, work_one_lane: tr.work_one_lane, rows_n_obs: tr.rows_n_obs, rows_groups: tr.rows_groups, rows_sweep: tr.rows_sweep, cert_tail_n: tr.cert_tail_n, rows_cert: tr.rows_cert, pois_tail_n: tr.pois_tail_n, array_keys: tr.array_keys, array_types: tr.array_types, array_len: tr.arrays.map((a) => a.length) }));
 }

@@ -284,6 +284,36 @@ def test_certified_tail_beyond_the_readme_shape(name, params, init, n):
     assert np.isfinite(np.frombuffer(outs[0][2], dtype=np.float64)).all()
 
 
+def test_certified_poisson_tail_of_a_translated_closure_reproduces_the_reference_and_the_full_evaluation():
+    """translate.js poisTailPlan + csrc/amwg_ptail.h: a closure that ends in `lp += ld.pois(y[i], Math.exp(eta))` runs amwg_user_step_cert at 16 lanes per chain (four
+    chains of a wavefront share every row).  Its decisions are the expression's in the REFERENCE's order: chain by chain the reference's golden trajectory, and every bit
+    of the run that evaluates the expression in every update at one lane per chain; widened and narrowed bounds change nothing."""
+    from gpu_util import run_schedule
+    spec, m, gold = spec_for("pois_glm_closure")
+    assert m.meta["pois_tail_n"] == 500 and "kPoisTail = true" in m.source and "kTailUniformState = true" in m.source
+    sched = gold["case"]["schedule"]
+    seed = gold["case"]["seed"]
+    auto = A.Sampler(spec, chains=8192, seed=seed)      # (enough chains for the work model to look at lane counts at all)
+    assert (auto.launch_info()["lanes_per_chain"], auto.launch_info()["kernel"], auto.launch_info()["summation_order"]) == (16, "amwg_user_step_cert", 1)
+    auto.close()
+    kw = dict(chains=64, seed=seed, steps_per_launch=23)
+    runs = [A.Sampler(spec, lanes_per_chain=16, **kw), A.Sampler(spec, lanes_per_chain=1, full_evaluation=1, **kw),
+            A.Sampler(spec, lanes_per_chain=16, test_bound_shift=12, **kw), A.Sampler(spec, lanes_per_chain=16, test_bound_shift=30, **kw)]
+    assert [q.launch_info()["kernel"] for q in runs] == ["amwg_user_step_cert", "amwg_user_step", "amwg_user_step_cert", "amwg_user_step_cert"]
+    outs = []
+    for q in runs:
+        segs = run_schedule(q, sched)
+        outs.append((b"".join(g.tobytes() for g in segs), q.state().tobytes(), q.info()["accepts"].tobytes(), q.info()["prop_log_scale"].tobytes(), q.diag()["uniforms"].tobytes(), q.diag()["log_post"].tobytes()))
+    assert all(o == outs[0] for o in outs[1:]), [[x == y for x, y in zip(o, outs[0])] for o in outs[1:]]
+    for rec in gold["chains"]:      # the reference's own chains
+        c = rec["chain"]
+        assert runs[0].info()["accepts"][:, c].tolist() == rec["accepts"]
+        assert runs[0].state()[:, c].tolist() == rec["final_state"]
+        assert float(runs[0].diag()["log_post"][c]) == rec["log_post"]      # (the expression in the reference's order: the reference's own double)
+    for q in runs:
+        q.close()
+
+
 FULL_SIZE = [("bench_normal", "cfg2_full"), ("bench_bern", "cfg3_full"), ("bench_hier", "cfg4_full"), ("bench_glm", "cfg5_full")]
 
 

@@ -330,6 +330,60 @@ console.log(JSON.stringify(out));
     assert out["sd_reads_mu"] == [640, 8, 1, "true"] and out["earlier_gather_other_vector"] == [640, 8, 1, "true", True]
 
 
+def test_poisson_tail_plan_is_found_and_refused_where_it_must_be(tmp_path):
+    """translate.js poisTailPlan (csrc/amwg_ptail.h): a closure that ENDS in `lp += ld.pois(y[i], Math.exp(eta))` over all observations gets certified values at 16 lanes
+    per chain.  Scalar-register state only if every state index is the same for all observations, the row cache only if every data read is of the observation's own row;
+    no plan at all for a negative count (the reference's term is -inf), a loop that is not the last statement, a head that does more than add, an early return."""
+    import ctypes as C
+    import json
+    import subprocess
+    m = user_host.host_model("pois_glm_closure")
+    assert m.meta["pois_tail_n"] == 500 and m.meta["cert_tail_n"] == 0 and m.meta["rows_cert"] == 0
+    for token in ("kPoisTail = true, kCertified = true, kReferenceOrder = true", "kCertifiedLanes = 16, kTailN = 500, kStateN = 9", "kTailUniformState = true", "kTailRows = true",
+                  "struct TailRow { uint8_t a0[1]; double a1[7]; };", "R.a1[(v___b1_k) - 0] * S(v___b1_k)", "pois_tail_approx<UserModel, G, BT>", "pois_tail_reference<UserModel, G>"):
+        assert token in m.source, token
+    L = A.lib()
+    n = C.c_size_t(0)
+    assert L.amwg_compile_user(m.source.encode(), 16, 256, b"gfx950", C.byref(n)) == 0, L.amwg_last_error().decode()[-3000:]
+    js = r"""
+const t = require(process.argv[2]); const synth = require(process.argv[3]);
+global.ld = require(process.argv[4]);
+const d = synth.glm(500, 20260925);
+const P = { beta: { type: 'real', dim: [8], lower: -Infinity, upper: Infinity, init: [0,0,0,0,0,0,0,0] }, cp: { type: 'int', dim: [1], lower: 0, upper: 499, init: 250 } };
+const pri = 'function (s, d) { let lp = 0; const N = d.y.length, K = d.K; for (let k = 0; k < 8; k++) lp += ld.norm(s.beta[k], 0, 10); lp += ld.unif(s.cp, 0, N - 1); ';
+const loop = (eta) => 'for (let i = 0; i < N; i++) { let eta = 0; ' + eta + ' lp += ld.pois(d.y[i], Math.exp(eta)); } ';
+const lin = 'for (let k = 0; k < K; k++) eta += d.X[i * K + k] * s.beta[k]; if (i >= s.cp) eta += s.beta[7];';
+const out = {}, src = {};
+const flag = (r, k) => { const m = new RegExp(k + ' = (true|false)').exec(r.source); return m ? m[1] : null; };
+const run = (k, text, data) => { const r = t.translate(text, P, data || d, {}); out[k] = [r.pois_tail_n, flag(r, 'kTailUniformState'), flag(r, 'kTailRows')]; src[k] = r.source; };
+run('plain', pri + loop(lin) + 'return lp; }');
+run('negative_count', pri + loop(lin) + 'return lp; }', Object.assign({}, d, { y: d.y.map((v, i) => (i === 7 ? -1 : v)) }));
+run('not_last', pri + loop(lin) + 'lp += ld.norm(s.beta[0], 0, 1); return lp; }');
+run('early_return', 'function (s, d) { let lp = 0; const N = d.y.length, K = d.K; if (s.beta[0] > 50) return -Infinity; ' + loop(lin) + 'return lp; }');
+run('head_scales', pri + 'lp = lp * 0.5; ' + loop(lin) + 'return lp; }');
+run('gathered_state', pri + loop('eta = s.beta[d.y[i] % 8] + d.X[i * K] * s.beta[1];') + 'return lp; }');
+run('next_row', pri + loop('eta = d.X[((i + 1) % N) * K] * s.beta[0];') + 'return lp; }');
+run('switched_off', pri + loop(lin) + 'return lp; }');
+out.switched_off = ((r) => [r.pois_tail_n, /kPoisTail/.test(r.source)])(t.translate(pri + loop(lin) + 'return lp; }', P, d, { no_pois_tail: true }));
+require('fs').writeFileSync(process.argv[5], JSON.stringify(src));
+console.log(JSON.stringify(out));
+"""
+    f = tmp_path / "probe.js"
+    f.write_text(js)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(["node", str(f), os.path.join(root, "bayes.js_amd", "translate.js"), os.path.join(root, "oracle", "synth.js"), os.path.join(root, "bayes.js_amd", "ld.js"), str(tmp_path / "src.json")],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["plain"] == [500, "true", "true"]
+    assert out["negative_count"][0] == 0 and out["not_last"][0] == 0 and out["early_return"][0] == 0 and out["head_scales"][0] == 0 and out["switched_off"] == [0, False]
+    assert out["gathered_state"] == [500, "false", "false"]      # per-lane LDS reads of the state, the plain loop
+    assert out["next_row"] == [500, "true", "false"]            # scalar-register state, but a read that is not of the observation's own row: no row cache
+    srcs = json.load(open(tmp_path / "src.json"))
+    for k in ("gathered_state", "next_row"):      # the fallback paths compile too
+        assert L.amwg_compile_user(srcs[k].encode(), 16, 256, b"gfx950", C.byref(n)) == 0, (k, L.amwg_last_error().decode()[-3000:])
+
+
 def test_constant_norm_inv_is_folded_to_the_device_functions_bits(tmp_path):
     """translate.js foldConstantNormInv (round 6): `norm_inv(<literal>)` -- the loop invariants of ld.norm with a constant sd: V8's logarithm, two products, the
     correctly rounded reciprocal and its low word from the exact residual (BigInt) -- becomes literals in the generated source; each must be the bits

@@ -158,6 +158,15 @@ def cases(quick):
             hspec = {"user": user_host.user_spec_part(hsrc, harrays, hmeta), "params": hparams, "P": G + 2, "init": [0.5] * G + [0.5, 1.0],
                      "comp_opts": [dict(model_spec.DEFAULT_OPT) for _ in range(G + 2)], "n_obs": nobs}
             out.append(dict(name="user_" + nm, spec=hspec, chains=ch, steps=st, lanes=64, state=None, seed=16))
+        # ... and one with a certified POISSON TAIL (translate.js poisTailPlan, csrc/amwg_ptail.h pois_tail_approx: amwg_user_step_cert at 16 lanes per chain): the small
+        # closure of the goldens, the same pressed against the 690 cut-off's neighbourhood by a large intercept, and BASELINE configs[4] as a plain closure
+        for nm, nobs, ch, st, state in (("pois_glm_closure", 500, 64 if quick else 256, 150, None), ("pois_glm_closure", 500, 64, 100, [3.0, 0.2, -0.1, 0.05, 0.1, -0.2, 0.15, 0.3, 160.0]),
+                                        ("bench_glm", 50000, 64 if quick else 2048, 20 if quick else 40, None)):
+            psrc, parrays, pmeta = user_host.translated(nm)
+            pparams = [{"type": "real", "len": 8, "top": 8, "multidim": 1, "lower": -inf, "upper": inf}, {"type": "int", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": float(nobs - 1)}]
+            pspec = {"user": user_host.user_spec_part(psrc, parrays, pmeta), "params": pparams, "P": 9, "init": [0.0] * 8 + [float(nobs // 2)],
+                     "comp_opts": [dict(model_spec.DEFAULT_OPT) for _ in range(9)], "n_obs": nobs}
+            out.append(dict(name="user_" + nm + ("_large_rates" if state else ""), spec=pspec, chains=ch, steps=st, lanes=16, state=state, seed=17))
     if not quick:
         # ---- BASELINE configs at full size
         out.append(normal_case("cfg2_full", model_spec.make_data("normal", 10000, 20260925)["x"], 65536, 150, seed=20260925))
@@ -221,7 +230,7 @@ def main():
         # decision's uniform replaced by one 1.5 eta off exp(dA), alternately on either side -- the sliver's edge, where a bound too small by more than 1.5 MUST produce a
         # wrong verdict): the first k with wrong verdicts measures how much room the bound really has, and shows that the audit's detector fires at all.
         by = {c["name"]: c for c in cases(True)}
-        for name in ("normal_n1000", "normal_constant_data", "hier_n640_g8", "pois_n500", "pois_zero_counts"):
+        for name in ("normal_n1000", "normal_constant_data", "hier_n640_g8", "pois_n500", "pois_zero_counts") + (("user_pois_glm_closure",) if "user_pois_glm_closure" in by else ()):
             c = dict(by[name])
             c["chains"], c["steps"] = (4096, 400) if name.startswith("normal") else (512, 150)
             ref = run_case(c, full_evaluation=1)      # the expression in every update (the multi-lane families: compared through accept counts and uniforms consumed)
