@@ -1115,7 +1115,9 @@ struct PoisGlmModel {
   // What the bound below is FOR is the reference's own order (round 5, last part; reference_order below: the expression this kernel evaluates when a uniform falls
   // inside the bound, and the value a launch leaves behind): one running sum over the nine prior terms and the n observations in order -- n + 9 additions of partial
   // sums below W' = W + 2 |lunif_cp| (lane 0's start value is the rounded sum of two prior terms) in place of the lanes' n_l + 8:
-  //   eps = u W' (2 (n + 16) + 23 H + 200) 1.25  (1.4e-6 at cfg5: ~3e-6 of the updates evaluate the expression).
+  //   eps = u W' (n + n / 32 + 48 + 23 H + 200) 1.25  (7e-7 at cfg5; rounds 5 and 6 up to the last day carried 2 (n + 16) here -- the reference's n + 9 additions counted
+  //   for BOTH sides, where this pass's own share is the lanes' 2 (n / 64 + 9): twice the bound, twice as many updates that evaluate the expression, each of which holds a
+  //   wavefront for a millisecond at n = 5e4).
   // A decision certified with it is the REFERENCE's (one lane per chain), not merely this geometry's.
   // H > 690 (an eta could leave the range in which exp and log are ordinary), a negative count (F = +inf) or any non-finite value make eps non-finite: the
   // stepper then evaluates the expression.
@@ -1174,18 +1176,24 @@ struct PoisGlmModel {
       for (int c = 0; c < CW; ++c) { s1[c] = __builtin_fma(eta[c], v[7], s1[c]); ls[c] += lam[c]; }
     };
     const int n_obs = d.n_obs, n_full = n_obs >> 6, rem = n_obs & 63;
-    double a[8], nx[8];
+    // (two row buffers, alternating: the round-5 loop copied the next row over the current one after every round -- 16 moves of the ~145 instructions a row costs;
+    // the rows reach every lane's sums in the same order, so the value is the same double)
+    double a[8], b[8];
     int k = 0;
-    if (n_full >= 2) {
+    if (n_full >= 3) {
       load8(lane, a);
-      for (; k + 1 < n_full; ++k) {                              // round k + 1 < n_full: every lane has that row
-        load8((k + 1) * 64 + lane, nx);
+      for (; k + 2 < n_full; k += 2) {                           // rounds k + 1, k + 2 < n_full: every lane has those rows
+        load8((k + 1) * 64 + lane, b);
         AMWG_STAGE_FENCE();
         row(a, k * 64 + lane);
         AMWG_STAGE_FENCE();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) a[q] = nx[q];
+        load8((k + 2) * 64 + lane, a);
+        AMWG_STAGE_FENCE();
+        row(b, (k + 1) * 64 + lane);
+        AMWG_STAGE_FENCE();
       }
+      row(a, k * 64 + lane);                                     // (round k < n_full, loaded above)
+      ++k;
     }
     for (; k < n_full + (lane < rem ? 1 : 0); ++k) {
       load8(k * 64 + lane, a);
@@ -1201,7 +1209,7 @@ struct PoisGlmModel {
       L = mine == c ? l : L;
     }
     const double W = Pabs + 2.0 * __builtin_fabs(mc.lunif_cp) + (1.0 + H) * mc.glm_sum_y + L + mc.glm_sum_lf;
-    const double eps = (H <= 690.0) ? W * (2.0 * (double)(n_obs + 16) + 23.0 * H + 200.0) * 1.25 * 0x1p-53 : __builtin_inf();
+    const double eps = (H <= 690.0) ? W * ((double)n_obs + (double)(n_obs >> 5) + 48.0 + 23.0 * H + 200.0) * 1.25 * 0x1p-53 : __builtin_inf();
     return Approx{(P + tot) - mc.glm_sum_lf, eps};
 #else
     return Approx{0.0, __builtin_inf()};

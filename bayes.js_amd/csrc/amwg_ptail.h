@@ -20,9 +20,12 @@
 //   the head in the lanes' order Hc u Hm, per-lane sums of n / 64 + 1 fused steps and six butterfly additions on two sums (n / 64 + 7) u (H Y + L), their difference
 //   and the closing (P + tot) - F: 3 u W;  F itself: 2 u F.   In all  < u W (n + n / 64 + 2 Hc + 150);  the bound handed on is
 //       eps = u W (n + n / 32 + 2 Hc + 23 H + 200) 1.25
-//   (the hand-written family's formula has 2 (n + 16) where this one counts the reference's n additions once and the pass's n / 64 separately, and its 23 H term
-//   covers a DIFFERENT eta on the two sides: here it is slack.  Half the bound is half as many updates that fall back to the expression, each of which holds a
-//   wavefront for a millisecond at n = 5e4.)
+//   (the hand-written family's formula is the same count with its nine prior terms; its 23 H term covers a DIFFERENT eta on the two sides: here it is slack.)
+// LINEAR PREDICTORS (M::kTailLinear: eta is a sum of (row entry) x (state entry) products, state entries and literals -- the translator's proof on the loop's
+// statements): the pass forms eta by fused steps, K + 1 roundings where the closure's statements have 2 K + 1, and H = sum |state entry| x max_i |row entry| (column
+// maxima from the translator) bounds every summand's magnitude, hence |eta| and each rounding of either eta: |eta_fused - eta_reference| <= R u H 1.05, R the
+// roundings of both; that distance enters sum eta y and sum e^eta as R u H (Y + L) 1.05 -- the coefficient of H in eps is then 1.1 R + 1 (the family: 13 + 7 -> 23).
+// 36 operations per observation and chain against the generic 44, and no running maximum.
 // H > 690 (exp and log leave their ordinary range), any non-finite value: eps is not finite and the stepper evaluates the expression.  A negative count makes the
 // reference's term -inf: the translator does not emit this plan for such data.
 // Checked like the other bounds: tools/bound_audit.py case user_pois_glm_closure (libamwg_audit.so evaluates the expression beside every certified value).
@@ -71,11 +74,16 @@ __device__ __forceinline__ TailApprox pois_tail_approx(const StateView &S, const
 #pragma unroll
   for (int c = 0; c < CW; ++c) { s1[c] = 0.0; ls[c] = 0.0; }
   constexpr int n = M::kTailN;
+  // a LINEAR predictor (M::kTailLinear; needs the row cache): eta by fused steps -- one rounding per product where the closure's statements have two --, and
+  // H = M::ptail_hlin(S) = sum |state entry| x column maximum >= sum of the magnitudes of eta's summands, once per pass, instead of max |eta_i| over the rows
+  constexpr bool kLinear = M::kTailLinear && M::kTailRows;
   auto pass = [&](const auto &Sc) {
     auto consume = [&](const double (&eta)[CW], double y) {
       double lam[CW];
+      if constexpr (!kLinear) {
 #pragma unroll
-      for (int c = 0; c < CW; ++c) hm = __builtin_fmax(hm, __builtin_fabs(eta[c]));
+        for (int c = 0; c < CW; ++c) hm = __builtin_fmax(hm, __builtin_fabs(eta[c]));
+      }
 #pragma unroll
       for (int c = 0; c < CW; ++c) lam[c] = exp_bounded(eta[c], E);
 #pragma unroll
@@ -90,7 +98,10 @@ __device__ __forceinline__ TailApprox pois_tail_approx(const StateView &S, const
       auto compute = [&](const typename M::TailRow &R, int i) {
         double eta[CW];
 #pragma unroll
-        for (int c = 0; c < CW; ++c) eta[c] = M::ptail_eta_row(Sc[c], R, i);
+        for (int c = 0; c < CW; ++c) {
+          if constexpr (kLinear) eta[c] = M::ptail_eta_fused(Sc[c], R, i);
+          else eta[c] = M::ptail_eta_row(Sc[c], R, i);
+        }
         consume(eta, M::ptail_y_row(R));
       };
       typename M::TailRow A, B;
@@ -149,8 +160,14 @@ __device__ __forceinline__ TailApprox pois_tail_approx(const StateView &S, const
     pass(Sc);
   }
   // every chain's totals over the wavefront; a lane keeps its own chain's.  H: the largest |eta| any of the four chains met (fmax skips a NaN: the sums carry it)
+  double cH = 23.0;      // (slack for the closure's own eta on both sides; the hand-written family's coefficient)
+  if constexpr (kLinear) {
+    hm = M::ptail_hlin(S);      // this lane's own chain
+    cH = 1.1 * (double)M::kTailLinearRoundings + 1.0;      // eta's roundings on the two sides, each below u H: |eta_fused - eta_reference| <= kTailLinearRoundings u H 1.05
+  } else {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) hm = __builtin_fmax(hm, __shfl_xor(hm, o));
+    for (int o = 32; o > 0; o >>= 1) hm = __builtin_fmax(hm, __shfl_xor(hm, o));
+  }
   const int mine = lane / G;
   double tot = 0.0, L = 0.0;
 #pragma unroll
@@ -161,7 +178,7 @@ __device__ __forceinline__ TailApprox pois_tail_approx(const StateView &S, const
   }
   const double Y = M::ptail_sum_y(), F = M::ptail_sum_lf(), H = hm;
   const double W = Hm + (1.0 + H) * Y + L + __builtin_fabs(F);
-  const double eps = (H <= 690.0) ? W * ((double)n + (double)(n / 32) + 2.0 * Hc + 23.0 * H + 200.0) * 1.25 * 0x1p-53 : __builtin_inf();
+  const double eps = (H <= 690.0) ? W * ((double)n + (double)(n / 32) + 2.0 * Hc + cH * H + 200.0) * 1.25 * 0x1p-53 : __builtin_inf();
   return TailApprox{(P + tot) - F, eps};
 #else
   (void)S; (void)d; (void)smem; (void)sub;

@@ -1542,9 +1542,83 @@ Translator.prototype.forLoop = function (s, out, indent, ctx) {
             rowInfo = { per, body: rewrite(bodyText, rb), eta: rewrite(mp[4], re2) };
           }
         }
+        // LINEAR PREDICTOR: is eta nothing but a sum of products (row entry) x (state entry), state entries and literals -- `eta = 0; for (k) eta += X[i K + k] * b[k];
+        // if (...) eta += b[7]`?  Then the pass forms it by fused steps (one rounding per product instead of two) and bounds |eta| AND the distance between the two
+        // etas by H = sum |b_k| max_i |x_ik| + ..., once per pass, instead of taking max |eta_i| over the rows (csrc/amwg_ptail.h, kTailLinear).
+        let linInfo = null;
+        if (rowInfo && /^v_\w+$/.test(rowInfo.eta) && !this.opts.no_tail_linear) {
+          const E = rowInfo.eta, Ee = E.replace(/[$]/g, '\\$'), T = rowInfo.body;
+          const loops = [];      // {name, lo, hi, from, to}: the constant-bound loops of the statements and the extent of their bodies in T
+          const reFor = /for \((v_\w+) = (\d+); \1 < (\d+); \1 \+= 1\) \{/g;
+          let mf, good = true;
+          while ((mf = reFor.exec(T))) {
+            let depth = 0, end = mf.index + mf[0].length - 1;
+            for (; end < T.length; end++) { if (T[end] === '{') depth++; else if (T[end] === '}' && --depth === 0) break; }
+            loops.push({ name: mf[1], lo: +mf[2], hi: +mf[3], from: mf.index, to: end });
+          }
+          const colmax = (j, stride, o) => { let m = 0; const f = this.arrays[j].flat; for (let i = 0; i < boundV.cst; i++) m = Math.max(m, Math.abs(f[i * stride + o])); return m; };
+          const terms = [];      // [text of one summand of H]
+          let refRound = 0, fusedRound = 0;
+          const reAsg = new RegExp(Ee + ' = ([^;]+);', 'g');
+          let fused = '', last = 0, ma;
+          while (good && (ma = reAsg.exec(T))) {
+            const rhs = ma[1], at = ma.index;
+            const inLoops = loops.filter((q) => at > q.from && at < q.to);
+            const tripOthers = (used) => inLoops.filter((q) => q.name !== used).reduce((t, q) => t * (q.hi - q.lo), 1);
+            const trips = inLoops.reduce((t, q) => t * (q.hi - q.lo), 1);      // how often the statement runs per observation (at most)
+            let mm, out = null;
+            if (/^-?(?:\d+\.?\d*(?:e[-+]?\d+)?|0x[\da-f.]+p[-+]?\d+)$/i.test(rhs)) {      // eta = literal
+              if (inLoops.length) good = false;
+              const v = Math.abs(parseLiteral(rhs));
+              if (!(v >= 0)) good = false; else if (v > 0) terms.push(hexFloat(v));
+              out = ma[0];
+            } else if ((mm = new RegExp('^\\(' + Ee + ' ([-+]) \\((R\\.a(\\d+)\\[\\((\\d+|v_\\w+)\\) - (\\d+)\\]) \\* (S\\(((?:\\d+ \\+ )?)(\\d+|v_\\w+)\\))\\)\\)$').exec(rhs)) ||
+                       (mm = new RegExp('^\\(' + Ee + ' ([-+]) \\((S\\(((?:\\d+ \\+ )?)(\\d+|v_\\w+)\\)) \\* (R\\.a(\\d+)\\[\\((\\d+|v_\\w+)\\) - (\\d+)\\])\\)\\)$').exec(rhs))) {
+              // (two orders of the factors: normalise to data x state)
+              const dataFirst = mm[2].indexOf('R.') === 0;
+              const sign = mm[1], rd = dataFirst ? mm[2] : mm[5], j = +(dataFirst ? mm[3] : mm[6]), rel = dataFirst ? mm[4] : mm[7], sv = dataFirst ? mm[6] : mm[2], sbase = (dataFirst ? mm[7] : mm[3]), sidx = dataFirst ? mm[8] : mm[4];
+              const per = rowInfo.per[j], ctr = /^v_/.test(rel) ? rel : (/^v_/.test(sidx) ? sidx : null);
+              if ((/^v_/.test(rel) && /^v_/.test(sidx) && rel !== sidx) || (ctr && !inLoops.some((q) => q.name === ctr))) good = false;
+              else {
+                const q = ctr ? inLoops.find((z) => z.name === ctr) : null, mult = tripOthers(ctr);
+                const b0 = sbase ? parseInt(sbase, 10) : 0;
+                for (let c = q ? q.lo : 0; c < (q ? q.hi : 1); c++) {
+                  const o = /^v_/.test(rel) ? c : +rel, si = b0 + (/^v_/.test(sidx) ? c : +sidx);
+                  if (o < per.lo || o >= per.hi || si < 0 || si >= this.P) { good = false; break; }
+                  const cm = colmax(j, per.stride, o) * mult;
+                  if (!Number.isFinite(cm)) { good = false; break; }
+                  if (cm > 0) terms.push(hexFloat(cm) + ' * __builtin_fabs(S(' + si + '))');
+                }
+                refRound += 2 * trips; fusedRound += trips;
+                out = E + ' = __builtin_fma(' + (sign === '-' ? '-' : '') + rd + ', ' + sv + ', ' + E + ');';
+              }
+            } else if ((mm = new RegExp('^\\(' + Ee + ' [-+] S\\(((?:\\d+ \\+ )?)(\\d+|v_\\w+)\\)\\)$').exec(rhs))) {      // eta +- a state entry
+              const ctr = /^v_/.test(mm[2]) ? mm[2] : null;
+              if (ctr && !inLoops.some((q) => q.name === ctr)) good = false;
+              else {
+                const q = ctr ? inLoops.find((z) => z.name === ctr) : null, mult = tripOthers(ctr), b0 = mm[1] ? parseInt(mm[1], 10) : 0;
+                for (let c = q ? q.lo : 0; c < (q ? q.hi : 1); c++) {
+                  const si = b0 + (ctr ? c : +mm[2]);
+                  if (si < 0 || si >= this.P) { good = false; break; }
+                  terms.push((mult > 1 ? mult + '.0 * ' : '') + '__builtin_fabs(S(' + si + '))');
+                }
+                refRound += trips; fusedRound += trips;
+                out = ma[0];
+              }
+            } else good = false;
+            if (good) { fused += T.slice(last, at) + out; last = at + ma[0].length; }
+          }
+          if (good) {
+            fused += T.slice(last);
+            // eta appears nowhere but in those assignments (a condition on eta, eta handed to a function: not a linear predictor)
+            const rest = T.replace(reAsg, ';');
+            if (new RegExp('\\b' + Ee + '\\b').test(rest) || !terms.length || terms.length > 64 || refRound + fusedRound > 200) good = false;
+          }
+          if (good) linInfo = { body: fused, hlin: terms.join(' + '), roundings: refRound + fusedRound };
+        }
         if (ok) {
           ptailCand = true;
-          this.ptailInfo = { y: Number(mp[2]), lf: Number(mp[5]), cast: mp[1], n: boundV.cst, acc: loopAcc, i: canon.name, uniform, eta: mp[4], body: bodyText, rows: rowInfo };
+          this.ptailInfo = { y: Number(mp[2]), lf: Number(mp[5]), cast: mp[1], n: boundV.cst, acc: loopAcc, i: canon.name, uniform, eta: mp[4], body: bodyText, rows: rowInfo, linear: linInfo };
           out.push(indent + '//@PTAIL');
         }
       }
@@ -2014,6 +2088,19 @@ Translator.prototype.run = function () {
       src.push('    ' + ptail.rows.body);
       src.push('    return ' + ptail.rows.eta + ';');
       src.push('  }');
+    }
+    src.push('  static constexpr bool kTailLinear = ' + (ptail.linear ? 'true' : 'false') + ';      // eta is a sum of (row entry) x (state entry) products, state entries and literals: formed by fused steps');
+    if (ptail.linear) {
+      src.push('  static constexpr int kTailLinearRoundings = ' + ptail.linear.roundings + ';      // roundings of eta in the closure\'s statements + in the fused form');
+      src.push('  template <class SV>');
+      src.push('  __device__ __forceinline__ static double ptail_eta_fused(const SV &S, const TailRow &R, const int v_' + ptail.i + ') {');
+      src.push('    (void)S; (void)R;');
+      for (const dl of ptail.decls) src.push('    ' + dl);
+      src.push('    ' + ptail.linear.body);
+      src.push('    return ' + ptail.rows.eta + ';');
+      src.push('  }');
+      src.push('  // H >= sum of the magnitudes of eta\'s summands for every observation (column maxima of the data x |state entry|): bounds |eta| and both etas\' roundings');
+      src.push('  __device__ __forceinline__ static double ptail_hlin(const StateView &S) { return ' + ptail.linear.hlin + '; }');
     }
     src.push('  // the closure up to that loop: what its accumulator holds when the loop begins (this lane\'s share)');
     src.push('  template <int G>');

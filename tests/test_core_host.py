@@ -175,7 +175,7 @@ def test_certified_bounds_host_replay_in_quad_precision(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(root, "bayes.js_amd", "csrc"),
                            os.path.join(root, "tests", "host", "bound_replay.cpp"), "-o", exe, "-lquadmath"])
     p = subprocess.run([exe, "25"], capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0 and "bounds_hold=1" in p.stdout and "VIOLATION" not in p.stdout, p.stdout[-2000:]
+    assert p.returncode == 0 and "bounds_hold=1" in p.stdout and "VIOLATION" not in p.stdout and "pieces_over_bound=0" in p.stdout, p.stdout[-2000:]      # (the pieces of every derivation add up to no more than the bound handed on)
 
 
 def test_copy_out_prefaulter_touches_without_changing_a_byte():

@@ -339,7 +339,7 @@ def test_poisson_tail_plan_is_found_and_refused_where_it_must_be(tmp_path):
     import subprocess
     m = user_host.host_model("pois_glm_closure")
     assert m.meta["pois_tail_n"] == 500 and m.meta["cert_tail_n"] == 0 and m.meta["rows_cert"] == 0
-    for token in ("kPoisTail = true, kCertified = true, kReferenceOrder = true", "kCertifiedLanes = 16, kTailN = 500, kStateN = 9", "kTailUniformState = true", "kTailRows = true",
+    for token in ("kPoisTail = true, kCertified = true, kReferenceOrder = true", "kCertifiedLanes = 16, kTailN = 500, kStateN = 9", "kTailUniformState = true", "kTailRows = true", "kTailLinear = true", "kTailLinearRoundings = 23", "__builtin_fma(R.a1[(v___b1_k) - 0], S(v___b1_k), v_eta)",
                   "struct TailRow { uint8_t a0[1]; double a1[7]; };", "R.a1[(v___b1_k) - 0] * S(v___b1_k)", "pois_tail_approx<UserModel, G, BT>", "pois_tail_reference<UserModel, G>"):
         assert token in m.source, token
     L = A.lib()
@@ -355,7 +355,7 @@ const loop = (eta) => 'for (let i = 0; i < N; i++) { let eta = 0; ' + eta + ' lp
 const lin = 'for (let k = 0; k < K; k++) eta += d.X[i * K + k] * s.beta[k]; if (i >= s.cp) eta += s.beta[7];';
 const out = {}, src = {};
 const flag = (r, k) => { const m = new RegExp(k + ' = (true|false)').exec(r.source); return m ? m[1] : null; };
-const run = (k, text, data) => { const r = t.translate(text, P, data || d, {}); out[k] = [r.pois_tail_n, flag(r, 'kTailUniformState'), flag(r, 'kTailRows')]; src[k] = r.source; };
+const run = (k, text, data) => { const r = t.translate(text, P, data || d, {}); out[k] = [r.pois_tail_n, flag(r, 'kTailUniformState'), flag(r, 'kTailRows'), flag(r, 'kTailLinear')]; src[k] = r.source; };
 run('plain', pri + loop(lin) + 'return lp; }');
 run('negative_count', pri + loop(lin) + 'return lp; }', Object.assign({}, d, { y: d.y.map((v, i) => (i === 7 ? -1 : v)) }));
 run('not_last', pri + loop(lin) + 'lp += ld.norm(s.beta[0], 0, 1); return lp; }');
@@ -363,7 +363,9 @@ run('early_return', 'function (s, d) { let lp = 0; const N = d.y.length, K = d.K
 run('head_scales', pri + 'lp = lp * 0.5; ' + loop(lin) + 'return lp; }');
 run('gathered_state', pri + loop('eta = s.beta[d.y[i] % 8] + d.X[i * K] * s.beta[1];') + 'return lp; }');
 run('next_row', pri + loop('eta = d.X[((i + 1) % N) * K] * s.beta[0];') + 'return lp; }');
-run('switched_off', pri + loop(lin) + 'return lp; }');
+run('minus_and_literal', pri + loop('eta = 0.25; eta -= d.X[i * K + 1] * s.beta[1]; eta += s.beta[2] * d.X[i * K + 3]; eta -= s.beta[7];') + 'return lp; }');
+run('product_of_states', pri + loop('eta = d.X[i * K] * s.beta[0] * s.beta[1];') + 'return lp; }');
+run('eta_in_a_condition', pri + loop(lin + ' if (eta > 3) eta += s.beta[6];') + 'return lp; }');
 out.switched_off = ((r) => [r.pois_tail_n, /kPoisTail/.test(r.source)])(t.translate(pri + loop(lin) + 'return lp; }', P, d, { no_pois_tail: true }));
 require('fs').writeFileSync(process.argv[5], JSON.stringify(src));
 console.log(JSON.stringify(out));
@@ -375,12 +377,13 @@ console.log(JSON.stringify(out));
                        capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads(p.stdout.strip().splitlines()[-1])
-    assert out["plain"] == [500, "true", "true"]
+    assert out["plain"] == [500, "true", "true", "true"]      # scalar-register state, row cache, linear predictor (fused steps, H from column maxima)
+    assert out["minus_and_literal"] == [500, "true", "true", "true"] and out["product_of_states"] == [500, "true", "true", "false"] and out["eta_in_a_condition"] == [500, "true", "true", "false"]
     assert out["negative_count"][0] == 0 and out["not_last"][0] == 0 and out["early_return"][0] == 0 and out["head_scales"][0] == 0 and out["switched_off"] == [0, False]
-    assert out["gathered_state"] == [500, "false", "false"]      # per-lane LDS reads of the state, the plain loop
-    assert out["next_row"] == [500, "true", "false"]            # scalar-register state, but a read that is not of the observation's own row: no row cache
+    assert out["gathered_state"] == [500, "false", "false", "false"]      # per-lane LDS reads of the state, the plain loop
+    assert out["next_row"] == [500, "true", "false", "false"]            # scalar-register state, but a read that is not of the observation's own row: no row cache
     srcs = json.load(open(tmp_path / "src.json"))
-    for k in ("gathered_state", "next_row"):      # the fallback paths compile too
+    for k in ("gathered_state", "next_row", "minus_and_literal", "product_of_states"):      # the fallback paths (and a linear predictor with signs and a literal) compile too
         assert L.amwg_compile_user(srcs[k].encode(), 16, 256, b"gfx950", C.byref(n)) == 0, (k, L.amwg_last_error().decode()[-3000:])
 
 
