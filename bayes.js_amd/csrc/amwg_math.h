@@ -419,21 +419,24 @@ AMWG_HD void exp_log_v8_open(const double (&x)[U], double (&lam)[U], double (&lg
 // ld.t, ld.weibull and user closures; Math.pow(t, 2) never gets here (it is exactly t*t).
 // exp(x), |x| <= 700, to a relative error below 2^-46 -- NOT V8's exp (exp_v8 above is), for the certified pass of the Poisson family, which uses the value with
 // its bound only (amwg_models.h PoisGlmModel::log_post_approx).  k = round(x / ln2); r = x - k ln2 by two fused steps (|r| <= 0.3466: the products are exact
-// inside the fma, each step rounds a value of that size: 2 x 2^-53 x 0.35); the Taylor polynomial of degree 13 by Horner's rule in fmas: truncation
-// 0.3466^14 / 14! = 4.1e-18, roundings <= 26 x 2^-53 x e^|r| = 4.1e-15 (the classical bound; measured: < 2^-51, tests/host/explog_fuzz.cpp); times 2^k, exact.
-// 19 operations, none of them a reciprocal.  C: the coefficients as a type (literals, or per-lane registers: ExpTaylorRegs).
+// inside the fma, each step rounds a value of that size: 2 x 2^-53 x 0.35); a polynomial of degree 11 by Horner's rule in fmas -- the one that interpolates exp at
+// the twelve Chebyshev nodes of [-ln2 / 2, ln2 / 2] (tools/exp_poly.py: 60-digit arithmetic; with its coefficients rounded to doubles it is 1.7e-17 from exp in exact
+// arithmetic, c0 and c1 round to 1) --: roundings <= 22 x 2^-53 x e^|r| / e^-|r| = 4.9e-15 (the classical bound; measured 1.5e-16, tests/host/explog_fuzz.cpp); times
+// 2^k, exact.  (Rounds 5 and 6 carried the Taylor polynomial of degree 13 -- the degree 11 one is 8.8e-15 off at r = -ln2 / 2: two fused steps per exponential that
+// better coefficients make unnecessary.)
+// 17 operations, none of them a reciprocal.  C: the coefficients as a type (literals, or per-lane registers: ExpTaylorRegs).
 struct ExpTaylorLiterals {
   static constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10, inv_ln2 = 1.44269504088896338700e+00;
-  static constexpr double c2 = 1.0 / 2, c3 = 1.0 / 6, c4 = 1.0 / 24, c5 = 1.0 / 120, c6 = 1.0 / 720, c7 = 1.0 / 5040, c8 = 1.0 / 40320, c9 = 1.0 / 362880,
-                          c10 = 1.0 / 3628800, c11 = 1.0 / 39916800, c12 = 1.0 / 479001600, c13 = 1.0 / 6227020800.0;
+  static constexpr double c2 = 0x1.0000000000011p-1, c3 = 0x1.555555555555ap-3, c4 = 0x1.555555554f0cep-5, c5 = 0x1.111111110f225p-7, c6 = 0x1.6c16c187fbe13p-10,
+                          c7 = 0x1.a01a01b14379ap-13, c8 = 0x1.a01991ac8440bp-16, c9 = 0x1.71ddf5749b43dp-19, c10 = 0x1.28b40581fba5cp-22, c11 = 0x1.af631d03b18bfp-26;
 };
-struct ExpTaylorRegs { double ln2_hi, ln2_lo, inv_ln2, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13; };
+struct ExpTaylorRegs { double ln2_hi, ln2_lo, inv_ln2, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11; };
 AMWG_HD ExpTaylorRegs exp_taylor_regs() {
   typedef ExpTaylorLiterals L;
-  ExpTaylorRegs k{L::ln2_hi, L::ln2_lo, L::inv_ln2, L::c2, L::c3, L::c4, L::c5, L::c6, L::c7, L::c8, L::c9, L::c10, L::c11, L::c12, L::c13};
+  ExpTaylorRegs k{L::ln2_hi, L::ln2_lo, L::inv_ln2, L::c2, L::c3, L::c4, L::c5, L::c6, L::c7, L::c8, L::c9, L::c10, L::c11};
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" : "+v"(k.ln2_hi), "+v"(k.ln2_lo), "+v"(k.inv_ln2), "+v"(k.c2), "+v"(k.c3), "+v"(k.c4), "+v"(k.c5), "+v"(k.c6), "+v"(k.c7), "+v"(k.c8), "+v"(k.c9),
-               "+v"(k.c10), "+v"(k.c11), "+v"(k.c12), "+v"(k.c13));      // (vector registers: a 64-bit literal cannot be an operand of v_fma_f64, and the scalar ones are few)
+               "+v"(k.c10), "+v"(k.c11));      // (vector registers: a 64-bit literal cannot be an operand of v_fma_f64, and the scalar ones are few)
 #endif
   return k;
 }
@@ -442,9 +445,7 @@ AMWG_HD double exp_bounded(double x, const C &c) {
   const double t = __builtin_rint(x * c.inv_ln2);
   double r = __builtin_fma(-t, c.ln2_hi, x);
   r = __builtin_fma(-t, c.ln2_lo, r);
-  double p = __builtin_fma(c.c13, r, c.c12);
-  p = __builtin_fma(p, r, c.c11);
-  p = __builtin_fma(p, r, c.c10);
+  double p = __builtin_fma(c.c11, r, c.c10);
   p = __builtin_fma(p, r, c.c9);
   p = __builtin_fma(p, r, c.c8);
   p = __builtin_fma(p, r, c.c7);

@@ -1099,7 +1099,7 @@ struct PoisGlmModel {
   // CERTIFIED DECISIONS (16 lanes per chain: four chains to a wavefront; amwg_kernel.h).  The reference's term is  log(lambda) y - lambda - lfactorial(y)  with
   // lambda = exp(eta) -- it takes the LOGARITHM of the exponential it has just formed (ld.pois(y, Math.exp(eta)), distributions.js:282-284), which V8 returns to
   // within an ulp of eta but not as eta: 36 of the term's 86 operations.  As real numbers log_post = prior + sum eta_i y_i - sum e^eta_i - sum lfactorial(y_i); the
-  // pass below forms exactly that -- eta by one product and six fmas, e^eta by exp_bounded (19 operations, no reciprocal), two running sums; the third sum is a
+  // pass below forms exactly that -- eta by one product and six fmas, e^eta by exp_bounded (17 operations, no reciprocal), two running sums; the third sum is a
   // constant of the data -- ~32 operations per observation, and hands it to the stepper with a bound eps on how far it and the expression's value (log_post
   // above, in the chain's lane order) can be apart.
   //   And it is the WAVEFRONT's pass: the expression's pass re-reads the 72 bytes of every observation for every chain (3.6 MB per evaluation through L1 / L2:

@@ -6,7 +6,7 @@
 // log(lambda) y - lambda - lfactorial(y), lambda = exp(eta) (distributions.js:282-284): it takes the LOGARITHM of the exponential it has just formed, ~70 of the
 // term's operations.  As real numbers   log_post = head + sum eta_i y_i - sum e^eta_i - sum lfactorial(y_i),   and that is what the pass below forms:
 //   * eta_i by the closure's OWN statements (M::ptail_eta: the same operations in the same order as the expression's pass -- bit for bit the reference's eta_i);
-//   * e^eta by exp_bounded (amwg_math.h: 19 operations, relative error < 2^-46), two running sums per chain; the third sum is a constant of the data;
+//   * e^eta by exp_bounded (amwg_math.h: 17 operations, relative error < 2^-46), two running sums per chain; the third sum is a constant of the data;
 //   * and it is the WAVEFRONT's pass (16 lanes per chain, four chains to a wavefront): the 64 lanes share out the OBSERVATIONS whichever chain they belong to, a row
 //     -- once in registers -- is evaluated for all four chains, whose parameters are read from their LDS state at wave-uniform addresses and kept in SCALAR
 //     registers (ScalarState: the translator has proved that every state index in the statements is the same for all observations).  A quarter of the memory
