@@ -127,9 +127,9 @@ CERTIFIED_NOTE = ("2 = sub, fma: by default the accept test of the Normal family
                   "distance from the reference's term-by-term expression (csrc/amwg_kernel.h 'certified decisions'); every update still passes over all the observations; the "
                   "expression itself (8 operations per observation) is evaluated when a uniform falls inside the bound (~1e-7 of the updates) and once per launch and chain. "
                   "Every draw is bit-identical to the reference's (parity block).  `full_evaluation` beside this: the kernel that evaluates the expression in every update")
-CERTIFIED_GLM_OPS_PER_OBS = 29
-CERTIFIED_GLM_NOTE = ("29 = the certified pass of the Poisson family (16 lanes per chain, the four chains of a wavefront sharing every row they read): linear predictor as one "
-                      "product + six fmas (7), change point (1), exp_bounded (19: k = round(x / ln2), two fused reduction steps, a degree-13 Taylor polynomial by Horner's rule "
+CERTIFIED_GLM_OPS_PER_OBS = 27
+CERTIFIED_GLM_NOTE = ("27 = the certified pass of the Poisson family (16 lanes per chain, the four chains of a wavefront sharing every row they read): linear predictor as one "
+                      "product + six fmas (7), change point (1), exp_bounded (17: k = round(x / ln2), two fused reduction steps, a degree-11 interpolating polynomial by Horner's rule "
                       "in fmas, conversion of k, ldexp), sum eta y (1 fma), sum lambda (1).  The logarithm of the exponential the reference takes is NOT formed: the value is used "
                       "with a rigorous bound on its distance from the expression's (csrc/amwg_models.h PoisGlmModel::log_post_approx); the expression itself (86 operations per "
                       "observation) is evaluated when a uniform falls inside the bound and once per launch and chain.  `full_evaluation` beside this: the expression in every update")
@@ -569,7 +569,7 @@ def measure_other_config(A, name, device, group_local=0):
             note = "roofline = every evaluation passes over all the data (full_evaluation = 1), %.3g param-updates/s" % roof_updates_per_s
     ops_note = OPS_NOTE[fam]
     if name == "cfg5" and certified_kind(fam, li["lanes_per_chain"]):
-        # the default runs the certified pass (29 operations per observation, four chains sharing a row): `value` and `frac` describe that kernel; the
+        # the default runs the certified pass (27 operations per observation, four chains sharing a row): `value` and `frac` describe that kernel; the
         # kernel that evaluates the reference's expression in every update is measured beside it
         t = A.Sampler(spec, chains=chains, seed=SEED, device=device, lanes_per_chain=li["lanes_per_chain"], steps_per_launch=10, full_evaluation=1)
         t.burn(10)
