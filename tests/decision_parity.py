@@ -64,7 +64,30 @@ WORKLOADS = {
 }
 
 
+def user_spec_of(name):
+    """a TRANSLATED closure of tests/js/user_models.js as a sampler spec (needs node): 'user:<closure>'"""
+    import model_spec
+    import user_host
+    src, arrays, meta = user_host.translated(name)
+    inf = float("inf")
+    vec = lambda n: {"type": "real", "len": n, "top": n, "multidim": 1, "lower": -inf, "upper": inf}
+    sca = lambda lo=-inf, hi=inf, ty="real": {"type": ty, "len": 1, "top": 1, "multidim": 0, "lower": lo, "upper": hi}
+    if name in ("hier_normal_closure", "bench_hier"):
+        G = 8 if name == "hier_normal_closure" else 32
+        params, init = [vec(G), sca(), sca(0.0)], [0.5] * G + [0.5, 1.0]
+    elif name in ("pois_glm_closure", "bench_glm"):
+        n = 500 if name == "pois_glm_closure" else 50000
+        params, init = [vec(8), sca(0.0, float(n - 1), "int")], [0.0] * 8 + [float(n // 2)]
+    elif name == "bench_normal":
+        params, init = [sca(), sca(0.0)], [0.5, 0.5]
+    else:
+        raise KeyError(name)
+    return {"user": user_host.user_spec_part(src, arrays, meta), "params": params, "P": len(init), "init": init, "comp_opts": [dict(model_spec.DEFAULT_OPT) for _ in init]}
+
+
 def spec_of(A, name, data_seed=20260925):
     import model_spec
+    if name.startswith("user:"):
+        return user_spec_of(name[5:])
     fam, n_obs, G = WORKLOADS[name]
     return model_spec.build_spec(fam, model_spec.make_data(fam, n_obs, data_seed, G=G or 32, exp=A.lib().amwg_exp))

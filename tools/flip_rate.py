@@ -28,6 +28,11 @@ CAMPAIGN = [
     ("cfg4_size", 16_384, 4_000, {"lanes_per_chain": 64, "group_local": 1}),
     ("cfg4_size", 16_384, 4_000, {"lanes_per_chain": 32}),
     ("normal_n1000", 65_536, 20_000, {"lanes_per_chain": 64}),
+    # (round 6) TRANSLATED closures whose certified kernels decide in the reference's order (translate.js rowPlan / poisTailPlan; docs/CERTIFIED.md): against the same closure
+    # at one lane per chain -- not one chain may differ, cached log_post included
+    ("user:hier_normal_closure", 65_536, 10_000, {"lanes_per_chain": 64}),
+    ("user:pois_glm_closure", 16_384, 10_000, {"lanes_per_chain": 16}),
+    ("user:bench_hier", 4_096, 2_000, {"lanes_per_chain": 64}),
 ]
 
 
@@ -37,7 +42,10 @@ def main():
     args = ap.parse_args()
     runs = []
     ref_runs = {}      # the one-lane reference run of a (workload, chains, steps) is made once
+    import shutil
     for wl, chains, steps, alt in CAMPAIGN:
+        if wl.startswith("user:") and shutil.which("node") is None:
+            continue
         t0 = time.perf_counter()
         n = max(10, int(steps * args.scale))
         spec = dp.spec_of(A, wl)
