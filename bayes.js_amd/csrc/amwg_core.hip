@@ -318,10 +318,9 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   // 512 registers of a workgroup of at most 256 threads; measured 1.34e9 against 7.2e8 for the scalar-path pass of the larger classes, so those are not picked unless asked for)
   const bool cert_one_lane = (!s->user && s->model == AMWG_MODEL_NORMAL && certified_wanted(s, 1, false)) || user_cert_wanted(s, 1);
   auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds && !(bt > 512 && hier_rows_wanted(s, G) && hier_rows_fit(s, 512, max_lds)) &&
-                                          !(bt > 512 && user_rows_wanted(s, G) && user_rows_fit(s, 512, max_lds)) && !(bt > 256 && G == 1 && cert_one_lane && !o.block_threads) &&
-                                          // (a closure's certified row plan -- amwg_user_sweep_cert -- keeps the generic head's values beside the stepper's: with the 256 registers of a
-                                          // 512-thread workgroup it spills ~520 of them (250 scratch accesses per step); 256-thread workgroups measured 2.35e9 against 1.87e9)
-                                          !(bt > 256 && G == 64 && user_rows_cert_wanted(s) && s->user_rows_sweep && user_rows_wanted(s, G) && user_rows_fit(s, 256, max_lds) && !o.block_threads); };
+                                          !(bt > 512 && user_rows_wanted(s, G) && user_rows_fit(s, 512, max_lds)) && !(bt > 256 && G == 1 && cert_one_lane && !o.block_threads); };
+  // (a closure's certified row plan -- amwg_user_sweep_cert -- ran in 256-thread workgroups for a day of round 6: in 512-thread ones it spilled 520 registers.  With the
+  // S2 pass out of line -- amwg_rows.h rows_sq -- it spills 40 and the 512-thread class, two wavefronts per SIMD, is the faster one again: 2.82e9 against 1.90e9)
   if (s->user && !s->user_parallel && o.lanes_per_chain > 1)
     return fail(AMWG_EINVAL, "this closure has no loop that can be split over lanes: lanes_per_chain must be 1 (or 0 = auto), got %d", o.lanes_per_chain);
   const int bts[5] = {1024, 512, 256, 128, 64};
@@ -1007,8 +1006,9 @@ static int compile_user(const char *source, int lanes, int block, const char *ar
   if (r != HIPRTC_SUCCESS) return fail(AMWG_EHIP, "hiprtcCreateProgram failed: %s", hiprtcGetErrorString(r));
   const std::string arch_opt = std::string("--offload-arch=") + arch;
   // same floating-point contract as the Makefile: one rounding per operation, no fused contraction
-  const char *opts[] = {arch_opt.c_str(), kOpts[0], kOpts[1], kOpts[2], kOpts[3], kOpts[4], kOpts[5]};
-  r = hiprtcCompileProgram(prog, 7, opts);
+  std::vector<const char *> opts = {arch_opt.c_str()};
+  for (const char *o : kOpts) opts.push_back(o);
+  r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (r != HIPRTC_SUCCESS) {
     size_t n = 0;
     hiprtcGetProgramLogSize(prog, &n);

@@ -286,8 +286,17 @@ struct UserRows {
   __device__ __forceinline__ static double value_bound(double Mm, const DataRef &) { return Mm * (2.0 * (double)M::kRowN + 64.0) * 1.25 * 0x1p-53; }
   __device__ __forceinline__ static double difference_bound(double Mm, const DataRef &) { return Mm * (4.0 * (double)M::kRowN + 128.0) * 1.25 * 0x1p-53; }
   __device__ __forceinline__ static double head_factor(double K) { return 1.0 + 2.0 * K / (2.0 * (double)M::kRowN + 64.0); }
-  // S2 of this lane's row for `mean`: four interleaved partial sums (the order is free: the value is used with its bound)
-  __device__ __forceinline__ static double rows_sq(const double *row, double mean, int sub) {
+  // S2 of this lane's row for `mean`: four interleaved partial sums (the order is free: the value is used with its bound).
+  // OUT OF LINE (round 6, last day): inlined at its three call sites -- each with its eight staged loads behind a scheduling fence -- the certified sweep kernel of a
+  // translated closure needed ~780 vector registers and, in 512-thread workgroups (256 per lane), spilled 520 of them: 1 200 bytes of scratch per lane, ~250 scratch
+  // accesses per step.  As a call it spills 40 (112 bytes); the call costs ~30 instructions beside the pass's ~320.  Translated cfg4: 1.87e9 -> 2.82e9 with the call,
+  // 3.94e9 once the call's row argument became an LDS offset (below).
+  // (the row travels as its LDS byte offset: across a call boundary a `const double *` is a generic pointer, and the pass read the tile with flat loads -- 9 000 cycles
+  // per pass where ds_read takes 2 500)
+  typedef __attribute__((address_space(3))) const double *LdsRow;
+  __device__ __forceinline__ static uint32_t lds_offset(const double *p) { return (uint32_t)(uintptr_t)(LdsRow)p; }
+  __device__ __attribute__((noinline)) static double rows_sq(uint32_t row_off, double mean, int sub) {
+    const LdsRow row = (LdsRow)(uintptr_t)row_off;
     constexpr int n_full = M::kRowN >> 6, rem = M::kRowN & 63;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int r = 0;
@@ -308,7 +317,7 @@ struct UserRows {
   __device__ __forceinline__ static double lane_s2(Cache &k, const unsigned char *smem, double mean, int pitch, int sub) {      // (every lane takes part: a wavefront-uniform call)
     const bool stale = f64_bits(mean) != f64_bits(k.s2_mean);
     if (__ballot(stale) != 0ull) {
-      const double v = rows_sq(reinterpret_cast<const double *>(smem) + (size_t)sub * pitch, mean, sub);
+      const double v = rows_sq(lds_offset(reinterpret_cast<const double *>(smem) + (size_t)sub * pitch), mean, sub);
       if (stale) { k.s2 = v; k.s2_mean = mean; }
     }
     return k.s2;
@@ -375,7 +384,7 @@ struct UserRows {
       const double mean_new = has ? S(M::kRowBase + k.my_group) : 0.0;
       if (sub < M::kRowGroups) Sw[M::kRowBase + sub] = keep;
       const double s2_cur = lane_s2(k, smem, mean_cur, d.pad, sub);
-      const double s2_new = rows_sq(reinterpret_cast<const double *>(smem) + (size_t)sub * d.pad, mean_new, sub);
+      const double s2_new = rows_sq(lds_offset(reinterpret_cast<const double *>(smem) + (size_t)sub * d.pad), mean_new, sub);
       const ApproxLane c0 = approx_lane(k, h0.value, h0.mag, s2_cur, sub), c1 = approx_lane(k, h1.value, h1.mag, s2_new, sub);
       const double K = butterfly<1, 64>(h0.cnt > h1.cnt ? h0.cnt : h1.cnt);
       out.ok = true;
