@@ -601,9 +601,37 @@ def measure_other_config(A, name, device, group_local=0):
         out["reference_order"] = reference_order_price(A, name, spec, device)
         if "value" in out["reference_order"]:
             out["reference_order_value"] = out["reference_order"]["value"]
+    if name in TRANSLATED_TWIN and not group_local:
+        out["translated_closure"] = measure_translated_twin(A, name, chains, device, warm, timed)
     out["seconds"] = time.perf_counter() - t0
     s.close()
     return out
+
+
+# The same config written as a PLAIN JavaScript closure that the family recogniser does not know (tests/js/user_models.js bench_hier / bench_glm): translated by
+# bayes.js_amd/translate.js, compiled with hiprtc, certified decisions from the translator's own plans (docs/CERTIFIED.md: row plan / Poisson tail).  Reported beside
+# the hand-written family's `value`, never as it.  Needs node (the translator is JavaScript); absent -> {"skipped": ...}.
+TRANSLATED_TWIN = {"cfg4": "bench_hier", "cfg5": "bench_glm"}
+
+
+def measure_translated_twin(A, name, chains, device, warm, timed):
+    import shutil
+    if shutil.which("node") is None:
+        return {"skipped": "node is not installed: the closure translator is JavaScript"}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import decision_parity
+        spec = decision_parity.user_spec_of(TRANSLATED_TWIN[name])
+        t = A.Sampler(spec, chains=chains, seed=SEED, device=device, steps_per_launch=100)
+        t.burn(warm + (150 if name == "cfg4" else 40))      # (the family's sampler above has also run its golden schedule before its timed launches)
+        t.burn(timed)
+        li = t.launch_info()
+        t.close()
+        return {"closure": "tests/js/user_models.js " + TRANSLATED_TWIN[name], "value": chains * spec["P"] * timed / (li["kernel_ms"] * 1e-3), "unit": "param-updates/s",
+                "kernel": li.get("kernel"), "lanes_per_chain": li["lanes_per_chain"], "block_threads": li["block_threads"], "summation_order": li.get("summation_order"),
+                "timing": "HIP events around the launches of one burn(%d) call" % timed}
+    except Exception as e:      # (a reported side measurement: never the reason a bench line is missing)
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 # What strict identity costs (round-4 review, item 7; mcmc.js:527-528): north_star asks for bit-identical accept counts.  With ONE lane per chain the
@@ -801,6 +829,9 @@ def compact_line(out, detail_path=None):
             q["parity_ok"] = bool(pp) and all(v for k, v in pp.items() if k.endswith("_identical"))
             if pp.get("summation_order") is not None:
                 q["summation_order"] = pp["summation_order"]      # (1: the reference's own order -- draws, final state and log_post are among the *_identical above)
+            tc = o.get("translated_closure")
+            if isinstance(tc, dict) and "value" in tc:      # the same config as a plain closure through translate.js + hiprtc (reported beside the family's value)
+                q["translated_closure_value"] = _num(tc["value"])
             line["other_configs"][name] = q
     ss = out.get("sufficient_statistics")
     if isinstance(ss, dict):

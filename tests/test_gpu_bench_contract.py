@@ -45,6 +45,15 @@ def test_default_line_has_the_contract_fields_and_an_honest_roofline():
     assert full["roofline"]["lane_ops_per_obs"] == 2 and 0 < d["full_evaluation"]["frac"] < 1 and d["full_evaluation"]["value"] < d["value"]
     c5 = full["other_configs"]["cfg5"]
     assert c5["lanes_per_chain"] == 16 and c5["roofline"]["lane_ops_per_obs"] == 27 and c5["full_evaluation_value"] < c5["value"]
+    # the same configs as PLAIN closures through translate.js + hiprtc, reported beside the families' values (round 6: certified row plan / Poisson tail): the reference's
+    # order, and within a factor of the hand-written kernels
+    import shutil
+    if shutil.which("node"):
+        for name, kernel in (("cfg4", "amwg_user_sweep_cert"), ("cfg5", "amwg_user_step_cert")):
+            tc = full["other_configs"][name]["translated_closure"]
+            assert tc.get("kernel") == kernel and tc["summation_order"] == 1, tc
+            assert 0.5 * full["other_configs"][name]["value"] < tc["value"] < 1.5 * full["other_configs"][name]["value"], tc
+            assert d["other_configs"][name]["translated_closure_value"] == pytest.approx(tc["value"], rel=1e-3)
     assert r["effective_hbm"]["lds_resident"] is True and r["effective_hbm"]["unit"] == "GB/s"
     assert d["parity"]["draws_bit_identical"] and d["parity"]["accept_counts_identical"] and d["parity"]["final_state_bit_identical"]
     assert d["detail"].endswith("bench_detail.json")
