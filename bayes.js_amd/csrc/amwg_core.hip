@@ -813,6 +813,13 @@ static int alloc_chain_state(amwg_sampler *s, const amwg_param_desc *params, int
   TRYB(dev_alloc(s, &ch.rng_n, C));
   TRYB(dev_alloc(s, &ch.lp_curr, C));
   TRYB(dev_alloc(s, &ch.lp_eps, C));
+  // (64 doubles per wavefront of a one-lane-per-chain launch: where the certified pass of the Normal family / a closure's certified tail leaves the wavefront's means for the
+  // scalar memory path, amwg_pass.h norm_sq_pass_wave.  C / 64 wavefronts + the last workgroup's spare ones; AMWG_WAVE_SCRATCH=0: none, the pass broadcasts with v_readlane)
+  s->d.wave_scratch = nullptr;
+  {
+    const char *env = getenv("AMWG_WAVE_SCRATCH");
+    if (!(env && env[0] == '0')) TRYB(dev_alloc(s, &s->d.wave_scratch, ((size_t)C / 64 + 64) * 64));
+  }
   TRYB(dev_alloc(s, &ch.error, (size_t)1));
   ch.audit = nullptr;
   ch.audit_hist = nullptr;

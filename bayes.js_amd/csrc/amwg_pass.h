@@ -363,8 +363,26 @@ AMWG_HD double norm_sq_pass_uniform(const double *x_global, double mean, int n_o
 #endif
 constexpr int kWaveBlock = AMWG_WAVE_BLOCK;      // observations per lane and block of the wavefront's pass (tools/build_variant.sh -DAMWG_WAVE_BLOCK=8: round 5's)
 template <int N> struct PassBlock { static constexpr int value = N; };
+// MEANS THROUGH THE SCALAR MEMORY PATH (round 6, last day).  The 64 means of a wavefront's chains reach the blocks' arithmetic as scalar operands; v_readlane -- two
+// per mean and block, 1 536 of a cfg2 pass's 23 800 vector-issue slots -- is itself a vector instruction.  With a scratch line per wavefront in device memory
+// (`scr`, 64 doubles: DataRef::wave_scratch) every lane STORES its mean once per pass; when the stores have reached L2 (vmcnt 0) the wavefront drops what the scalar
+// cache may hold of the line from the pass before (s_dcache_inv: the scalar cache is read-only and not kept coherent with vector stores) and the blocks fetch eight means
+// at a time with s_load_dwordx16 -- the scalar unit's own issue slots --, one group ahead of its use: the first block's loads come from L2, the later ones from the
+// scalar cache.  cfg2: 1.435e9 -> 1.505e9 updates/s (2.38 -> 2.27 vector instructions per observation-lane).  Loads that bypass the scalar cache (glc) measured 1.24e9:
+// ~1 300 cycles each, more than a group's arithmetic covers.  scr == nullptr (AMWG_WAVE_SCRATCH=0, or a host that allocated none): v_readlane.
+typedef int amwg_v16i __attribute__((ext_vector_type(16)));
+// this wavefront's line of DataRef::wave_scratch (nullptr when the host gave none)
+__device__ __forceinline__ double *wave_scratch_of(const DataRef &d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!d.wave_scratch) return nullptr;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));      // (the same for all its lanes: a scalar register)
+  return d.wave_scratch + (size_t)wave * 64;
+#else
+  (void)d; return nullptr;
+#endif
+}
 template <int B>
-__device__ __forceinline__ double norm_sq_pass_wave(const double *x, double mu, int n_obs) {
+__device__ __forceinline__ double norm_sq_pass_wave(const double *x, double mu, int n_obs, double *scr = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const int lane = (int)(threadIdx.x & 63u);
   double a[64];
@@ -372,6 +390,59 @@ __device__ __forceinline__ double norm_sq_pass_wave(const double *x, double mu, 
   for (int c = 0; c < 64; ++c) a[c] = 0.0;
   const int mu_lo = (int)(uint32_t)f64_bits(mu), mu_hi = (int)(uint32_t)(f64_bits(mu) >> 32);
   auto mean_of = [&](int c) { return bits_f64(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mu_hi, c) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mu_lo, c)); };
+  bool smem_done = false;
+#if !defined(AMWG_X_NO_SMEM_MEANS)
+  if (scr != nullptr) {      // (wave-uniform)
+    scr[lane] = mu;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");      // (the stores have reached L2; this wavefront's line of the scalar cache, if an earlier pass left one, is dropped)
+    auto fetch = [&](int g) { amwg_v16i r; asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(r) : "s"(scr), "s"(g * 8)); return r; };
+    auto landed = [&](amwg_v16i &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); };
+    auto mean_in = [&](const amwg_v16i &r, int j) { return bits_f64(((uint64_t)(uint32_t)r[2 * j + 1] << 32) | (uint64_t)(uint32_t)r[2 * j]); };
+    auto block_s = [&](auto tag, int at) {
+      constexpr int BB = decltype(tag)::value;
+      double xv[BB];
+      amwg_v16i cur = fetch(0);
+#pragma unroll
+      for (int b = 0; b < BB; ++b) xv[b] = x[at + b * 64 + lane];
+#pragma unroll
+      for (int g = 0; g < 64; g += 8) {
+        landed(cur);
+        amwg_v16i nxt = cur;
+        if (g + 8 < 64) nxt = fetch(g + 8);
+#pragma unroll
+        for (int b = 0; b < BB; ++b) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const double t = xv[b] - mean_in(cur, j); a[g + j] = __builtin_fma(t, t, a[g + j]); }
+        }
+        cur = nxt;
+      }
+    };
+    int base = 0;
+    for (; base + 64 * B <= n_obs; base += 64 * B) block_s(PassBlock<B>{}, base);
+    if constexpr (B >= 32) { if (base + 64 * 16 <= n_obs) { block_s(PassBlock<16>{}, base); base += 64 * 16; } }
+    if constexpr (B >= 16) { if (base + 64 * 8 <= n_obs) { block_s(PassBlock<8>{}, base); base += 64 * 8; } }
+    if constexpr (B >= 8) { if (base + 64 * 4 <= n_obs) { block_s(PassBlock<4>{}, base); base += 64 * 4; } }
+    if constexpr (B >= 4) { if (base + 64 * 2 <= n_obs) { block_s(PassBlock<2>{}, base); base += 64 * 2; } }
+    for (; base + 64 <= n_obs; base += 64) block_s(PassBlock<1>{}, base);
+    if (base < n_obs) {
+      const int i = base + lane;
+      const bool has = i < n_obs;
+      const double xv = x[has ? i : base];
+      amwg_v16i cur = fetch(0);
+#pragma unroll
+      for (int g = 0; g < 64; g += 8) {
+        landed(cur);
+        amwg_v16i nxt = cur;
+        if (g + 8 < 64) nxt = fetch(g + 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const double t = has ? xv - mean_in(cur, j) : 0.0; a[g + j] = __builtin_fma(t, t, a[g + j]); }
+        cur = nxt;
+      }
+    }
+    smem_done = true;
+  }
+#endif
+  if (!smem_done) {
   // a block of BB observations per lane against all 64 means: the means travel eight at a time into scalar registers (16 v_readlane per 8 BB subtract-fma pairs, so
   // the longer the block the smaller their share: 2 + 2 / BB vector instructions per observation and chain -- 2.25 at eight, 2.06 at 32), the eight running sums interleave
   auto block = [&](auto tag, int at) {
@@ -413,6 +484,7 @@ __device__ __forceinline__ double norm_sq_pass_wave(const double *x, double mu, 
       for (int j = 0; j < 8; ++j) { const double t = has ? xv - m[j] : 0.0; a[g + j] = __builtin_fma(t, t, a[g + j]); }
     }
   }
+  }      // (!smem_done)
   // transposing butterfly: after the step with offset o a lane holds the chains that agree with it in that bit, a[j] <- kept + received
   auto swap_add = [&](double A, double Bv, int off) {      // A: what the lanes with the bit CLEAR keep, Bv: what the lanes with the bit SET keep
     const uint32_t al = (uint32_t)f64_bits(A), ah = (uint32_t)(f64_bits(A) >> 32), bl = (uint32_t)f64_bits(Bv), bh = (uint32_t)(f64_bits(Bv) >> 32);

@@ -85,6 +85,8 @@ struct DataRef {
   const void *arr[kInlineUserArrays];  // translated models: the data arrays the closure reads (row-major; f64, or u8 / i32
                                        // when every value of the array is a small integer -- the translator picks the type)
   const void *const *arr_ext;          // arrays kInlineUserArrays, kInlineUserArrays + 1, ... (device table), see user_arr()
+  double *wave_scratch;                // 64 doubles per wavefront of the launch (device memory): where the certified pass of the Normal family at one lane per chain
+                                       // leaves the wavefront's 64 means for the scalar memory path (amwg_pass.h norm_sq_pass_wave); nullptr = v_readlane
 };
 
 // Per-chain state, structure-of-arrays with the chain index fastest: element (p, c) at p*C + c.

@@ -98,7 +98,7 @@ __device__ __forceinline__ TailApprox norm_tail_approx(const StateView &S, const
   const NormInv k = norm_inv(M::tail_sd(S, d));
   const double mean = M::tail_mean(S, d);
   double S2;
-  if constexpr (BT <= 256) S2 = norm_sq_pass_wave<kWaveBlock>(M::tail_x(d, smem), mean, M::kTailN);      // (every lane of the wavefront takes part: the stepper's call site is wave-uniform)
+  if constexpr (BT <= 256) S2 = norm_sq_pass_wave<kWaveBlock>(M::tail_x(d, smem), mean, M::kTailN, wave_scratch_of(d));      // (every lane of the wavefront takes part: the stepper's call site is wave-uniform)
   else S2 = norm_sq_pass_uniform<8>(M::tail_x_global(d), mean, M::kTailN);
   const double n = (double)M::kTailN;
   const double Q = S2 * k.y.hi, nc = n * k.c;
