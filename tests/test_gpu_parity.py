@@ -5,6 +5,8 @@ reference's summation order) every double bit-identical to the REFERENCE; with G
 chain every double bit-identical to the oracle run in the same G-lane order, and every accept
 decision still identical to the reference's.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -584,6 +586,13 @@ def test_certified_decisions_equal_the_expression_in_every_update(n_obs, chains,
         spec["params"][1] = dict(spec["params"][1], upper=1.0)
     mk = lambda full, shift=0, suff=0: A.Sampler(spec, chains=chains, seed=8, chain_offset=3, lanes_per_chain=1, steps_per_launch=13, full_evaluation=full, test_bound_shift=shift, sufficient_statistics=suff)
     variants = [mk(0), mk(1), mk(0, 14), mk(0, 40), mk(0, 22)] if hyper is None else [mk(0), mk(1), mk(0, 9)]      # (22 / 9: bounds of ~0.1, the wide regime of the certified test)
+    # (round 6, last day: the pass takes the wavefront's 64 means through a scratch line and the scalar cache -- csrc/amwg_pass.h --; AMWG_WAVE_SCRATCH=0 at construction
+    # keeps the v_readlane broadcast: the same sums in the same order)
+    os.environ["AMWG_WAVE_SCRATCH"] = "0"
+    try:
+        variants.append(mk(0))
+    finally:
+        del os.environ["AMWG_WAVE_SCRATCH"]
     # (round 6, opt-in third tier -- options.sufficient_statistics: the cheap value from SS + n (xbar - mu)^2, no pass over the data; same bound, same fallback, same bits)
     variants += [mk(0, 0, 1), mk(0, 14, 1)]
     outs = []
