@@ -226,7 +226,7 @@ static bool certified_wanted(const amwg_sampler *s, int lanes, bool rows) {
 }
 bool hier_rows_fit(const amwg_sampler *s, int bt, size_t max_lds);
 // the Normal family at one lane per chain stages its observations in LDS only for the wavefront's certified pass (NormalModel::lds_bytes_of: DataRef::pad = 1)
-static bool normal_tile_wanted(const amwg_sampler *s, int bt) { return !s->user && s->model == AMWG_MODEL_NORMAL && certified_wanted(s, 1, false) && bt <= 256 && !s->opt.sufficient_statistics; }
+static bool normal_tile_wanted(const amwg_sampler *s, int bt) { return !s->user && s->model == AMWG_MODEL_NORMAL && certified_wanted(s, 1, false) && bt <= 512 && !s->opt.sufficient_statistics; }
 // ... a translated closure with a certified tail (amwg_user.h norm_tail_approx; read off the generated source by amwg_create_user): one lane per chain
 // ... or a certified Poisson tail (amwg_ptail.h pois_tail_approx; kPoisTail of the generated source): 16 lanes per chain, four chains sharing every row they read
 static bool user_cert_wanted(const amwg_sampler *s, int lanes) {
@@ -314,11 +314,13 @@ int choose_geometry(amwg_sampler *s, int n_cus, size_t max_lds) {
   const int max_bt = s->user ? s->user_max_threads : model_max_threads(s->model);
   // (the hierarchical family's sweep kernel -- row layout, 64 lanes per chain -- keeps the window stream and the sweep's per-lane values in registers:
   // compiled for at most 512 threads, where a lane has 256 of them; with the 128 of a 1024-thread workgroup it ran from scratch memory, five times slower)
-  // (one lane per chain with certified decisions -- the Normal family, a closure with a certified tail --: the wavefront's pass keeps 64 partial sums per lane, i.e. needs the
-  // 512 registers of a workgroup of at most 256 threads; measured 1.34e9 against 7.2e8 for the scalar-path pass of the larger classes, so those are not picked unless asked for)
+  // (one lane per chain with certified decisions -- the Normal family, a closure with a certified tail --: the wavefront's pass keeps 64 partial sums per lane: the 512
+  // registers of a 256-thread workgroup with blocks of 16 observations, the 256 of a 512-thread one with blocks of 8 (round 6, last day: 9 spilled registers; 1.58e9 against
+  // the 256-thread class's 1.55e9 at >= 131 072 chains, where 512-thread workgroups still fill every CU).  The 1024-thread class keeps the scalar-path pass (7.2e8) and is not
+  // picked unless asked for; a closure's certified tail is compiled for the 256-thread class only)
   const bool cert_one_lane = (!s->user && s->model == AMWG_MODEL_NORMAL && certified_wanted(s, 1, false)) || user_cert_wanted(s, 1);
   auto fits = [&](int bt, int G) { return bt <= max_bt && bt % G == 0 && layout(bt, G).total <= max_lds && !(bt > 512 && hier_rows_wanted(s, G) && hier_rows_fit(s, 512, max_lds)) &&
-                                          !(bt > 512 && user_rows_wanted(s, G) && user_rows_fit(s, 512, max_lds)) && !(bt > 256 && G == 1 && cert_one_lane && !o.block_threads); };
+                                          !(bt > 512 && user_rows_wanted(s, G) && user_rows_fit(s, 512, max_lds)) && !(bt > (user_cert_wanted(s, 1) ? 256 : 512) && G == 1 && cert_one_lane && !o.block_threads); };
   // (a closure's certified row plan -- amwg_user_sweep_cert -- ran in 256-thread workgroups for a day of round 6: in 512-thread ones it spilled 520 registers.  With the
   // S2 pass out of line -- amwg_rows.h rows_sq -- it spills 40 and the 512-thread class, two wavefronts per SIMD, is the faster one again: 2.82e9 against 1.90e9)
   if (s->user && !s->user_parallel && o.lanes_per_chain > 1)

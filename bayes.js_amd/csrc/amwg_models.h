@@ -179,7 +179,8 @@ struct NormalModel {
       const double dm = (mc.suff_xbar_hi - kc.mu) + mc.suff_xbar_lo;
       S2 = __builtin_fma((double)d.n_obs, dm * dm, mc.suff_ss);
     } else
-    if constexpr (BT <= 256) S2 = norm_sq_pass_wave<kWaveBlock>(lds_bytes_of(d, 1, 0) ? reinterpret_cast<const double *>(smem) : d.x, kc.mu, d.n_obs, wave_scratch_of(d));
+    // (the wavefront's pass in the 256- and 512-thread classes: blocks of 16 observations per lane where a lane has 512 registers, of 8 where it has 256)
+    if constexpr (BT <= 512) S2 = norm_sq_pass_wave<(BT <= 256 ? kWaveBlock : 8)>(lds_bytes_of(d, 1, 0) ? reinterpret_cast<const double *>(smem) : d.x, kc.mu, d.n_obs, wave_scratch_of(d));
     else S2 = norm_sq_pass_uniform<8>(d.x, kc.mu, d.n_obs);
     const double n = (double)d.n_obs;
     const double Q = S2 * kc.n.y.hi, nc = n * kc.n.c;
