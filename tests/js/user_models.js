@@ -348,6 +348,46 @@ const BENCH = {
     } },
   bench_hier: { params: CASES.hier_normal_closure.params, data: () => synth.hier(10000, 32, 20260925), log_post: CASES.hier_normal_closure.log_post },
   bench_glm: { params: CASES.pois_glm_closure.params, data: () => synth.glm(50000, 20260925), log_post: CASES.pois_glm_closure.log_post },
+  // (round 6, the certified Poisson tail of translate.js poisTailPlan on its FALLBACK paths -- csrc/amwg_ptail.h: a predictor that is not linear (a product of two
+  // coefficients: the closure's own statements for eta, H = max |eta| over the rows), a coefficient gathered by the data (per-lane LDS reads of the state, the plain
+  // loop), a read of the NEXT observation's row (scalar-register state, no row cache), and a ragged 517 observations)
+  pois_tail_nonlinear: { params: CASES.pois_glm_closure.params, data: () => synth.glm(517, 20260929),
+    log_post: function (s, d) {
+      let lp = 0;
+      const N = d.y.length, K = d.K;
+      for (let k = 0; k < 8; k++) lp += ld.norm(s.beta[k], 0, 3);
+      lp += ld.unif(s.cp, 0, N - 1);
+      for (let i = 0; i < N; i++) {
+        let eta = 0.25 * d.X[i * K] * s.beta[0] * s.beta[1] + d.X[i * K + 2] * s.beta[2];
+        if (i >= s.cp) eta -= s.beta[7];
+        lp += ld.pois(d.y[i], Math.exp(eta));
+      }
+      return lp;
+    } },
+  pois_tail_gather: { params: CASES.pois_glm_closure.params, data: () => synth.glm(517, 20260929),
+    log_post: function (s, d) {
+      let lp = 0;
+      const N = d.y.length, K = d.K;
+      for (let k = 0; k < 8; k++) lp += ld.norm(s.beta[k], 0, 3);
+      lp += ld.unif(s.cp, 0, N - 1);
+      for (let i = 0; i < N; i++) {
+        let eta = s.beta[d.y[i] % 4] * 0.5 + d.X[i * K + 1] * s.beta[5];
+        lp += ld.pois(d.y[i], Math.exp(eta));
+      }
+      return lp;
+    } },
+  pois_tail_next_row: { params: CASES.pois_glm_closure.params, data: () => synth.glm(517, 20260929),
+    log_post: function (s, d) {
+      let lp = 0;
+      const N = d.y.length, K = d.K;
+      for (let k = 0; k < 8; k++) lp += ld.norm(s.beta[k], 0, 3);
+      lp += ld.unif(s.cp, 0, N - 1);
+      for (let i = 0; i < N; i++) {
+        let eta = d.X[((i + 1) % N) * K + 3] * s.beta[3] + d.X[i * K] * s.beta[0];
+        lp += ld.pois(d.y[i], Math.exp(eta));
+      }
+      return lp;
+    } },
 };
 
 // ---- array-valued densities (distributions.js:125-134, 203-214, 232-238), the ** operator, local arrays

@@ -314,6 +314,36 @@ def test_certified_poisson_tail_of_a_translated_closure_reproduces_the_reference
         q.close()
 
 
+@pytest.mark.parametrize("name,flags", [("pois_tail_nonlinear", ("true", "true", "false")), ("pois_tail_gather", ("false", "false", "false")), ("pois_tail_next_row", ("true", "false", "false"))])
+def test_certified_poisson_tail_fallback_paths_equal_the_expression(name, flags):
+    """csrc/amwg_ptail.h off its fast path -- a predictor that is not linear (eta by the closure's own statements, H = max |eta| over the rows), a coefficient gathered
+    by the data (per-lane LDS reads of the state, the plain loop), a read of the next observation's row (no row cache) --, 517 observations (a ragged last round): the
+    16-lane certified kernel against the same closure at ONE lane per chain with the expression in every update, and against narrowed / widened bounds: every bit of
+    every chain, cached log_post included (the certified kernel evaluates the expression in the reference's order)."""
+    import re
+    src, arrays, meta = user_host.translated(name)
+    assert meta["pois_tail_n"] == 517
+    got = tuple(re.search(k + r" = (true|false)", src).group(1) for k in ("kTailUniformState", "kTailRows", "kTailLinear"))
+    assert got == flags, got
+    opt = {"prop_log_scale": 0.0, "batch_size": 50, "max_adaptation": 0.33, "initial_adaptation": 1.0, "target_accept_rate": 0.44, "is_adapting": True}
+    params = [{"type": "real", "len": 8, "top": 8, "multidim": 1, "lower": -INF, "upper": INF}, {"type": "int", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": 516.0}]
+    spec = {"user": user_host.user_spec_part(src, arrays, meta), "params": params, "P": 9, "init": [0.1] * 8 + [250.0], "comp_opts": [dict(opt) for _ in range(9)]}
+    kw = dict(chains=96, seed=11, chain_offset=5, steps_per_launch=19)
+    runs = [A.Sampler(spec, lanes_per_chain=16, **kw), A.Sampler(spec, lanes_per_chain=1, full_evaluation=1, **kw),
+            A.Sampler(spec, lanes_per_chain=16, test_bound_shift=10, **kw), A.Sampler(spec, lanes_per_chain=16, test_bound_shift=34, **kw)]
+    assert [q.launch_info()["kernel"] for q in runs] == ["amwg_user_step_cert", "amwg_user_step", "amwg_user_step_cert", "amwg_user_step_cert"]
+    assert runs[0].launch_info()["summation_order"] == 1
+    outs = []
+    for q in runs:
+        d1 = q.sample(70, 2)
+        q.burn(110)
+        d2 = q.sample(25, 1)
+        outs.append((d1.tobytes(), d2.tobytes(), q.state().tobytes(), q.info()["accepts"].tobytes(), q.info()["prop_log_scale"].tobytes(), q.diag()["uniforms"].tobytes(), q.diag()["log_post"].tobytes()))
+        q.close()
+    assert all(o == outs[0] for o in outs[1:]), [[x == y for x, y in zip(o, outs[0])] for o in outs[1:]]
+    assert np.isfinite(np.frombuffer(outs[0][2], dtype=np.float64)).all()
+
+
 FULL_SIZE = [("bench_normal", "cfg2_full"), ("bench_bern", "cfg3_full"), ("bench_hier", "cfg4_full"), ("bench_glm", "cfg5_full")]
 
 

@@ -167,6 +167,12 @@ def cases(quick):
             pspec = {"user": user_host.user_spec_part(psrc, parrays, pmeta), "params": pparams, "P": 9, "init": [0.0] * 8 + [float(nobs // 2)],
                      "comp_opts": [dict(model_spec.DEFAULT_OPT) for _ in range(9)], "n_obs": nobs}
             out.append(dict(name="user_" + nm + ("_large_rates" if state else ""), spec=pspec, chains=ch, steps=st, lanes=16, state=state, seed=17))
+        # ... and the tail's fallback paths (amwg_ptail.h: eta by the closure's own statements with H taken over the rows; per-lane state reads; no row cache)
+        for nm in ("pois_tail_nonlinear", "pois_tail_gather", "pois_tail_next_row"):
+            psrc, parrays, pmeta = user_host.translated(nm)
+            pparams = [{"type": "real", "len": 8, "top": 8, "multidim": 1, "lower": -inf, "upper": inf}, {"type": "int", "len": 1, "top": 1, "multidim": 0, "lower": 0.0, "upper": 516.0}]
+            pspec = {"user": user_host.user_spec_part(psrc, parrays, pmeta), "params": pparams, "P": 9, "init": [0.1] * 8 + [250.0], "comp_opts": [dict(model_spec.DEFAULT_OPT) for _ in range(9)], "n_obs": 517}
+            out.append(dict(name="user_" + nm, spec=pspec, chains=64 if quick else 256, steps=120, lanes=16, state=None, seed=18))
     if not quick:
         # ---- BASELINE configs at full size
         out.append(normal_case("cfg2_full", model_spec.make_data("normal", 10000, 20260925)["x"], 65536, 150, seed=20260925))
